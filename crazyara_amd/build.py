@@ -1,0 +1,79 @@
+"""Builds libcrazyara_hip.so (hipcc, gfx950 only) in-tree under crazyara_amd/lib/."""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libcrazyara_hip.so")
+
+
+def sources():
+    out = []
+    for root, _, files in os.walk(CSRC):
+        for f in sorted(files):
+            if f.endswith((".hip", ".cpp")):
+                out.append(os.path.join(root, f))
+    return sorted(out)
+
+
+def _stamp():
+    h = hashlib.sha256()
+    for root, _, files in os.walk(CSRC):
+        for f in sorted(files):
+            p = os.path.join(root, f)
+            h.update(p.encode())
+            with open(p, "rb") as fh:
+                h.update(fh.read())
+    with open(os.path.join(os.path.dirname(HERE), "include", "crazyara_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp_file = LIB + ".stamp"
+    stamp = _stamp()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.relpath(src, CSRC).replace(os.sep, "_") + ".o")
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
+               "-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out, file=sys.stderr)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout)
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,128 @@
+// C ABI of libcrazyara_hip.so -- see include/crazyara_hip.h for the contract and reference citations.
+#include "../../include/crazyara_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <exception>
+#include <string>
+
+#include "nn/rise_net.h"
+
+namespace {
+thread_local std::string g_err;
+
+template <typename F> int guard(F&& f) {
+    try {
+        f();
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+    } catch (...) {
+        g_err = "unknown error";
+    }
+    return 1;
+}
+}  // namespace
+
+struct mi_net {
+    cra::RiseNet net;
+    mi_net(const char* dir, int dev, int batch, const char* prec) : net(dir ? dir : "", dev, batch, prec ? prec : "float16") {}
+};
+
+extern "C" {
+
+const char* mi_last_error(void) { return g_err.c_str(); }
+const char* mi_version(void) { return "crazyara_amd 0.1 (gfx950)"; }
+
+int mi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        g_err = "hipGetDeviceCount failed (no HIP device visible)";
+        return 0;
+    }
+    return n;
+}
+
+void* mi_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        g_err = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    return p;
+}
+void mi_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+mi_net* mi_net_create(const char* model_dir, int device_id, int batch_size, const char* precision) {
+    mi_net* h = nullptr;
+    if (guard([&] { h = new mi_net(model_dir, device_id, batch_size, precision); })) return nullptr;
+    return h;
+}
+void mi_net_destroy(mi_net* net) { delete net; }
+
+int mi_net_design(const mi_net* net, int in_shape[4], int* nb_policy, int* nb_aux, int* version, int* game_phase) {
+    if (!net) { g_err = "null net"; return 1; }
+    const cra::RiseDesign& d = net->net.design();
+    if (in_shape) { in_shape[0] = d.batch; in_shape[1] = d.nb_input_channels; in_shape[2] = 8; in_shape[3] = 8; }
+    if (nb_policy) *nb_policy = d.nb_policy;
+    if (nb_aux) *nb_aux = d.nb_aux;
+    if (version) *version = d.version;
+    if (game_phase) *game_phase = d.game_phase;
+    return 0;
+}
+const char* mi_net_model_name(const mi_net* net) { return net ? net->net.model_name().c_str() : ""; }
+double mi_net_flops_per_position(const mi_net* net) { return net ? net->net.design().flops_per_position : 0.0; }
+
+int mi_net_predict(mi_net* net, const float* in_planes, float* value, float* probs, float* aux) {
+    if (!net || !in_planes || !value || !probs) { g_err = "null argument to mi_net_predict"; return 1; }
+    return guard([&] { net->net.predict(in_planes, value, probs, aux); });
+}
+int mi_net_submit(mi_net* net, const float* in_planes, float* value, float* probs, float* aux) {
+    if (!net || !in_planes || !value || !probs) { g_err = "null argument to mi_net_submit"; return 1; }
+    return guard([&] { net->net.submit(in_planes, value, probs, aux); });
+}
+int mi_net_wait(mi_net* net) {
+    if (!net) { g_err = "null net"; return 1; }
+    return guard([&] { net->net.wait(); });
+}
+
+int mi_net_device_buffers(mi_net* net, float** d_planes, float** d_value, float** d_probs, float** d_logits, float** d_aux) {
+    if (!net) { g_err = "null net"; return 1; }
+    if (d_planes) *d_planes = net->net.d_planes();
+    if (d_value) *d_value = net->net.d_value();
+    if (d_probs) *d_probs = net->net.d_probs();
+    if (d_logits) *d_logits = net->net.d_logits();
+    if (d_aux) *d_aux = net->net.d_aux();
+    return 0;
+}
+int mi_net_forward_device(mi_net* net) {
+    if (!net) { g_err = "null net"; return 1; }
+    return guard([&] { net->net.forward_async(); });
+}
+int mi_net_sync(mi_net* net) {
+    if (!net) { g_err = "null net"; return 1; }
+    return guard([&] { net->net.wait(); });
+}
+void* mi_net_stream(mi_net* net) { return net ? static_cast<void*>(net->net.stream()) : nullptr; }
+
+int mi_net_time_forward(mi_net* net, int iters, float* ms_total) {
+    if (!net || !ms_total) { g_err = "null argument"; return 1; }
+    return guard([&] { *ms_total = net->net.time_forward(iters); });
+}
+int mi_net_op_count(const mi_net* net) { return net ? net->net.launches_per_forward() : 0; }
+int mi_net_time_ops(mi_net* net, int iters, const char** names, float* ms) {
+    if (!net || !ms) { g_err = "null argument"; return 1; }
+    return guard([&] {
+        const int n = net->net.launches_per_forward();
+        for (int i = 0; i < n; ++i) {
+            if (names) names[i] = net->net.op_name(i);
+            ms[i] = 0.f;
+        }
+        net->net.time_ops(iters, ms);
+    });
+}
+
+}  // extern "C"

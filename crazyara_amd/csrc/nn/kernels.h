@@ -1,0 +1,73 @@
+// Launch wrappers for the gfx950 kernels of the batched NN evaluation path.
+// Activations live in HBM as  act[board][square 0..63][channel]  (channel contiguous, "NHWC"), element type
+// T = _Float16 (Precision float16: f16 MFMA operands, f32 accumulate) or float (Precision float32: exact f32 MFMA).
+// square = h*8 + w of the reference's NCHW planes (engine/src/environments/chess_related/inputrepresentation.cpp:33-46).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace cra {
+
+typedef _Float16 half_t;
+
+constexpr int kSquares = 64;
+
+// ---- packed-weight geometry shared by host packer and kernels -------------------------------------------------
+// Dense conv weights are stored per (cout-tile of 16, k-slab of 32) as one MFMA A-fragment image:
+//   wpk[((ct * nslab + s) * 64 + lane) * 8 + j] = W[co = ct*16 + (lane & 15)][k = s*32 + (lane >> 4)*8 + j]
+// with k ordered [tap = kh*KS+kw][ci] (ci padded to a multiple of 32), so one wave-wide 16-B load per lane
+// fetches a whole fragment as 1 KiB contiguous (f16) / 2 KiB (f32).
+inline int64_t packed_weight_elems(int cout_pad, int k_total) { return int64_t(cout_pad) * k_total; }
+
+struct ConvArgs {
+    const void* x;        // [B][64][cin]   T
+    const void* wpk;      // packed weights T
+    const float* bias;    // [cout_pad]
+    const void* resid;    // optional [B][64][cout_ld] T (added before the activation)
+    void* out;            // T [B][64][cout_ld]   or   float [B][cout_real*64] (policy-map, channel-major)
+    int batch;
+    int cin;              // multiple of 32
+    int cout_pad;         // multiple of 16
+    int cout_real;
+    int cout_ld;          // row pitch of `out` in elements (NHWC mode)
+    int ks;               // 1 or 3
+    int relu;
+    int out_policy_f32;   // 1: write float logits channel-major
+};
+
+template <typename T> void launch_conv_gemm(const ConvArgs& a, hipStream_t s);
+
+// depthwise k x k (k = 3 or 5) + folded BN + ReLU.  w: [k*k][C] float, bias: [C] float
+template <typename T> void launch_depthwise(const T* x, T* y, const float* w, const float* bias, int batch, int C, int ks,
+                                            hipStream_t s);
+
+// squeeze-excitation, in place on x [B][64][C].  kind 1 = ca_se: w1t [C][C/2], w2t [C/2][C] (both transposed, no bias);
+// kind 2 = eca_se: w1t [C][C] transposed centre tap, b1 [C].  hard-sigmoid gate (builder_util.py:452).
+template <typename T> void launch_se(T* x, int kind, const float* w1t, const float* w2t, const float* b1, int batch, int C,
+                                     hipStream_t s);
+
+struct ValueHeadArgs {
+    const void* x;          // [B][64][C] T
+    const float* wconv;     // [cv][C] folded
+    const float* bconv;     // [cv]
+    const float* w1t;       // [64*cv][fc] transposed (tanh head)
+    const float* b1;        // [fc]
+    const float* w2;        // [fc]
+    float b2;
+    const float* wwdl;      // [3][64*cv]   (wdl head) or nullptr
+    const float* bwdl;      // [3]
+    const float* wplys;     // [64*cv]
+    float bplys;
+    float* value;           // [B]
+    float* aux;             // [B][4] or nullptr
+    int batch, C, cv, fc;
+};
+template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s);
+
+// row softmax over n logits per board (tensorrtapi.cpp:378-392 appends exactly this to policy_out)
+void launch_softmax(const float* logits, float* probs, int batch, int n, hipStream_t s);
+
+// float NCHW planes [B][C][64] (the NeuralNetAPI::predict input) -> T [B][64][cpad], zero channel padding
+template <typename T> void launch_planes_to_act(const float* planes, T* act, int batch, int C, int cpad, hipStream_t s);
+
+}  // namespace cra

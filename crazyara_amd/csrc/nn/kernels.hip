@@ -1,0 +1,437 @@
+// gfx950 (CDNA4) kernels for the batched NN evaluation path -- layer-granular set.
+// One workgroup = one board (64 squares = the GEMM's N dimension), 4 waves of 64 lanes; dense convolutions are
+// implicit GEMMs on MFMA with the board tile staged in LDS, depthwise / SE / heads run on the VALU.
+//
+// Reference semantics implemented here (file:line relative to /root/reference):
+//   conv+BN(+ReLU) stacks ........ DeepCrazyhouse/src/domain/neural_net/architectures/pytorch/builder_util.py:154-178,437-475
+//   SE gates ...................... builder_util.py:49-114
+//   policy / value heads .......... builder_util.py:206-326
+//   softmax on policy_out ......... engine/src/nn/tensorrtapi.cpp:378-392, engine/src/nn/neuralnetapi.cpp:241-260
+#include "kernels.h"
+
+namespace cra {
+
+typedef half_t half8 __attribute__((ext_vector_type(8)));
+typedef half_t half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct __attribute__((aligned(16))) float8 {
+    f32x4 lo, hi;
+};
+
+template <typename T> struct VT;
+template <> struct VT<half_t> {
+    typedef half8 frag;                // 8 k-values of one MFMA operand row/col
+    static constexpr int KC = 256;     // channels staged in LDS per chunk
+};
+template <> struct VT<float> {
+    typedef float8 frag;
+    static constexpr int KC = 128;
+};
+
+// D(16x16) += A(16 x 32) * B(32 x 16); both operands hold k = (lane>>4)*8 + j in element j.
+__device__ __forceinline__ void mma_k32(const half8& a, const half8& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// exact-f32 path: 8 x (16x16x4).  MFMA j consumes element j of both fragments, i.e. k = (lane>>4)*8 + j --
+// the same bijection on both operands, so the K-sum is complete whatever order the hardware walks it in.
+__device__ __forceinline__ void mma_k32(const float8& a, const float8& b, f32x4& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[j], b.lo[j], c, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[j], b.hi[j], c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float to_f(half_t v) { return float(v); }
+__device__ __forceinline__ float to_f(float v) { return v; }
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<half_t>(const half_t* p, float (&v)[8]) {
+    half8 h = *reinterpret_cast<const half8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = float(h[j]);
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<half_t>(half_t* p, const float (&v)[8]) {
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = half_t(v[j]);
+    *reinterpret_cast<half8*>(p) = h;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = v[j]; b[j] = v[4 + j]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<half_t>(const half_t* p, float (&v)[4]) {
+    half4 h = *reinterpret_cast<const half4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = float(h[j]);
+}
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = a[j];
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<half_t>(half_t* p, const float (&v)[4]) {
+    half4 h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = half_t(v[j]);
+    *reinterpret_cast<half4*>(p) = h;
+}
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+    f32x4 a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = v[j];
+    *reinterpret_cast<f32x4*>(p) = a;
+}
+
+// ================================================================================================================
+// Dense conv (1x1 / 3x3, pad k/2) as implicit GEMM:  D[cout][square] = sum_{tap,ci} W[cout][tap][ci] * X[nbr(square,tap)][ci]
+// A operand = packed weight fragment straight from L2 (1 KiB contiguous per wave), B operand = board rows from LDS
+// (row 64 is a zero row that out-of-board taps point at).  Each wave owns 16 couts x 64 squares (4 accumulators);
+// D's lane layout (col = square = lane&15, rows = 4 consecutive couts) gives 8/16-byte NHWC stores.
+// ================================================================================================================
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
+    using frag = typename VT<T>::frag;
+    constexpr int KC = VT<T>::KC;
+    constexpr int ROWP = KC + 16 / int(sizeof(T));   // +16 B per row: consecutive rows land on different bank groups
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xs = reinterpret_cast<T*>(smem);               // [65][ROWP]
+
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int co_tile = blockIdx.x * 4 + wave;
+    const bool active = co_tile * 16 < a.cout_pad;
+    const T* xb = reinterpret_cast<const T*>(a.x) + size_t(b) * kSquares * a.cin;
+    const int nslab_ci = a.cin >> 5;
+    const int nslab = KS * KS * nslab_ci;
+    const frag* wp = reinterpret_cast<const frag*>(a.wpk) + size_t(active ? co_tile : 0) * nslab * 64 + lane;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int i = tid; i < ROWP; i += 256) xs[64 * ROWP + i] = T(0);
+
+    for (int kc0 = 0; kc0 < a.cin; kc0 += KC) {
+        const int kcl = min(KC, a.cin - kc0);
+        __syncthreads();
+        const int vec_per_row = kcl * int(sizeof(T)) / 16;
+        for (int i = tid; i < kSquares * vec_per_row; i += 256) {
+            const int r = i / vec_per_row, v = i - r * vec_per_row;
+            const uint4 d = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(xb + size_t(r) * a.cin + kc0) + v * 16);
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(xs + r * ROWP) + v * 16) = d;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int tap = 0; tap < KS * KS; ++tap) {
+                const int dy = tap / KS - KS / 2, dx = tap % KS - KS / 2;
+                int rowoff[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int sq = t * 16 + l15;
+                    const int ny = (sq >> 3) + dy, nx = (sq & 7) + dx;
+                    const bool ok = (unsigned(ny) < 8u) && (unsigned(nx) < 8u);
+                    rowoff[t] = (ok ? ny * 8 + nx : 64) * ROWP + lg * 8;
+                }
+                const frag* wps = wp + size_t(tap * nslab_ci + (kc0 >> 5)) * 64;
+                const int ns = kcl >> 5;
+                for (int sl = 0; sl < ns; ++sl) {
+                    const frag af = wps[size_t(sl) * 64];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const frag bf = *reinterpret_cast<const frag*>(xs + rowoff[t] + sl * 32);
+                        mma_k32(af, bf, acc[t]);
+                    }
+                }
+            }
+        }
+    }
+    if (!active) return;
+
+    const int co0 = co_tile * 16 + lg * 4;
+    float bs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bs[r] = a.bias[co0 + r];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int sq = t * 16 + l15;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[t][r] + bs[r];
+        if (a.resid) {
+            float rv[4];
+            load4<T>(reinterpret_cast<const T*>(a.resid) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, rv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (a.out_policy_f32) {
+            float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.cout_real * kSquares;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
+        } else {
+            store4<T>(reinterpret_cast<T*>(a.out) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, v);
+        }
+    }
+}
+
+template <typename T> void launch_conv_gemm(const ConvArgs& a, hipStream_t s) {
+    constexpr int KC = VT<T>::KC;
+    constexpr int ROWP = KC + 16 / int(sizeof(T));
+    const size_t shmem = size_t(65) * ROWP * sizeof(T);
+    dim3 grid((a.cout_pad + 63) / 64, a.batch), block(256);
+    if (a.ks == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, 1>), grid, block, shmem, s, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, 3>), grid, block, shmem, s, a);
+}
+template void launch_conv_gemm<half_t>(const ConvArgs&, hipStream_t);
+template void launch_conv_gemm<float>(const ConvArgs&, hipStream_t);
+
+// ================================================================================================================
+// Depthwise k x k + folded BN + ReLU (VALU, fp32 accumulate).  grid (C/32, B); thread = 8 channels x 1 square.
+// ================================================================================================================
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void depthwise_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, int C) {
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * 32 + (threadIdx.x & 3) * 8;
+    const int sq = threadIdx.x >> 2;
+    const int py = sq >> 3, px = sq & 7;
+    const T* xb = x + size_t(b) * kSquares * C;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias[c0 + j];
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+        const int ny = py + tap / KS - KS / 2, nx = px + tap % KS - KS / 2;
+        if ((unsigned(ny) < 8u) && (unsigned(nx) < 8u)) {
+            float xv[8], wv[8];
+            load8<T>(xb + size_t(ny * 8 + nx) * C + c0, xv);
+            load8<float>(w + size_t(tap) * C + c0, wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(wv[j], xv[j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+    store8<T>(y + (size_t(b) * kSquares + sq) * C + c0, acc);
+}
+
+template <typename T>
+void launch_depthwise(const T* x, T* y, const float* w, const float* bias, int batch, int C, int ks, hipStream_t s) {
+    dim3 grid(C / 32, batch), block(256);
+    if (ks == 3) hipLaunchKernelGGL((depthwise_kernel<T, 3>), grid, block, 0, s, x, y, w, bias, C);
+    else hipLaunchKernelGGL((depthwise_kernel<T, 5>), grid, block, 0, s, x, y, w, bias, C);
+}
+template void launch_depthwise<half_t>(const half_t*, half_t*, const float*, const float*, int, int, int, hipStream_t);
+template void launch_depthwise<float>(const float*, float*, const float*, const float*, int, int, int, hipStream_t);
+
+// ================================================================================================================
+// Squeeze-excitation gate, in place.  One workgroup per board.
+// ================================================================================================================
+__device__ __forceinline__ float hard_sigmoid(float v) { return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void se_kernel(T* __restrict__ x, int kind, const float* __restrict__ w1t,
+                                                 const float* __restrict__ w2t, const float* __restrict__ b1, int C) {
+    __shared__ float s_mean[512];
+    __shared__ float s_h[512];
+    __shared__ float s_y[512];
+    const int tid = threadIdx.x;
+    T* xb = x + size_t(blockIdx.x) * kSquares * C;
+    for (int c = tid; c < C; c += 256) {
+        float sum = 0.f;
+        for (int sq = 0; sq < kSquares; ++sq) sum += to_f(xb[size_t(sq) * C + c]);
+        s_mean[c] = sum * (1.f / 64.f);
+    }
+    __syncthreads();
+    if (kind == 1) {
+        const int H = C / 2;
+        for (int j = tid; j < H; j += 256) {
+            float sum = 0.f;
+            for (int c = 0; c < C; ++c) sum = fmaf(w1t[size_t(c) * H + j], s_mean[c], sum);
+            s_h[j] = fmaxf(sum, 0.f);
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float sum = 0.f;
+            for (int j = 0; j < H; ++j) sum = fmaf(w2t[size_t(j) * C + c], s_h[j], sum);
+            s_y[c] = hard_sigmoid(sum);
+        }
+    } else {
+        for (int c = tid; c < C; c += 256) {
+            float sum = b1[c];
+            for (int i = 0; i < C; ++i) sum = fmaf(w1t[size_t(i) * C + c], s_mean[i], sum);
+            s_y[c] = hard_sigmoid(sum);
+        }
+    }
+    __syncthreads();
+    const int nvec = kSquares * C / 8;
+    for (int i = tid; i < nvec; i += 256) {
+        const int c0 = (i * 8) % C;
+        float v[8];
+        load8<T>(xb + size_t(i) * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= s_y[c0 + j];
+        store8<T>(xb + size_t(i) * 8, v);
+    }
+}
+
+template <typename T>
+void launch_se(T* x, int kind, const float* w1t, const float* w2t, const float* b1, int batch, int C, hipStream_t s) {
+    hipLaunchKernelGGL((se_kernel<T>), dim3(batch), dim3(256), 0, s, x, kind, w1t, w2t, b1, C);
+}
+template void launch_se<half_t>(half_t*, int, const float*, const float*, const float*, int, int, hipStream_t);
+template void launch_se<float>(float*, int, const float*, const float*, const float*, int, int, hipStream_t);
+
+// ================================================================================================================
+// Value head: conv1x1(C->cv)+BN+ReLU -> channel-major flatten -> FC(fc)+ReLU -> FC(1) -> tanh
+//             or (WDLP) FC(3) / FC(1)+sigmoid, value = -softmax(wdl)[0] + softmax(wdl)[2], aux = [wdl, plys].
+// ================================================================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_flat = reinterpret_cast<float*>(smem);   // [64*cv]
+    float* s_red = s_flat + kSquares * a.cv;            // [4]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x;
+    const T* xb = reinterpret_cast<const T*>(a.x) + size_t(b) * kSquares * a.C;
+    const int nf = kSquares * a.cv;
+
+    // conv 1x1: lanes split the C input channels, waves split the squares; wave-reduce each (square, cv) dot product
+    for (int sq = wave; sq < kSquares; sq += 4) {
+        for (int co = 0; co < a.cv; ++co) {
+            float part = 0.f;
+            for (int ci = lane; ci < a.C; ci += 64) part = fmaf(a.wconv[co * a.C + ci], to_f(xb[size_t(sq) * a.C + ci]), part);
+            part = wave_sum(part);
+            if (lane == 0) s_flat[co * kSquares + sq] = fmaxf(part + a.bconv[co], 0.f);
+        }
+    }
+    __syncthreads();
+
+    if (a.wwdl) {
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < nf; i += 256) {
+            const float f = s_flat[i];
+            p[0] = fmaf(a.wwdl[i], f, p[0]);
+            p[1] = fmaf(a.wwdl[nf + i], f, p[1]);
+            p[2] = fmaf(a.wwdl[2 * nf + i], f, p[2]);
+            p[3] = fmaf(a.wplys[i], f, p[3]);
+        }
+        float r[4];
+        for (int k = 0; k < 4; ++k) r[k] = block_sum_256(p[k], s_red);
+        if (tid == 0) {
+            const float l0 = r[0] + a.bwdl[0], l1 = r[1] + a.bwdl[1], l2 = r[2] + a.bwdl[2];
+            const float m = fmaxf(l0, fmaxf(l1, l2));
+            const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+            const float inv = 1.f / (e0 + e1 + e2);
+            a.value[b] = -e0 * inv + e2 * inv;
+            if (a.aux) {
+                a.aux[b * 4 + 0] = l0;
+                a.aux[b * 4 + 1] = l1;
+                a.aux[b * 4 + 2] = l2;
+                a.aux[b * 4 + 3] = 1.f / (1.f + expf(-(r[3] + a.bplys)));
+            }
+        }
+        return;
+    }
+
+    float part = 0.f;
+    for (int t = tid; t < a.fc; t += 256) {
+        float h = a.b1[t];
+        for (int i = 0; i < nf; ++i) h = fmaf(a.w1t[size_t(i) * a.fc + t], s_flat[i], h);
+        part = fmaf(a.w2[t], fmaxf(h, 0.f), part);
+    }
+    const float tot = block_sum_256(part, s_red);
+    if (tid == 0) a.value[b] = tanhf(tot + a.b2);
+}
+
+template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s) {
+    const size_t shmem = (size_t(kSquares) * a.cv + 8) * sizeof(float);
+    hipLaunchKernelGGL((value_head_kernel<T>), dim3(a.batch), dim3(256), shmem, s, a);
+}
+template void launch_value_head<half_t>(const ValueHeadArgs&, hipStream_t);
+template void launch_value_head<float>(const ValueHeadArgs&, hipStream_t);
+
+// ================================================================================================================
+// Row softmax (policy_softmax output of the reference's GPU backend).
+// ================================================================================================================
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ logits, float* __restrict__ probs, int n) {
+    __shared__ float s_red[4];
+    const float* in = logits + size_t(blockIdx.x) * n;
+    float* out = probs + size_t(blockIdx.x) * n;
+    const int tid = threadIdx.x;
+    float m = -INFINITY;
+    for (int i = tid; i < n; i += 256) m = fmaxf(m, in[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((tid & 63) == 0) s_red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sum = 0.f;
+    for (int i = tid; i < n; i += 256) sum += expf(in[i] - m);
+    sum = block_sum_256(sum, s_red);
+    const float c = m + logf(sum);   // exp(x - (max + log(sum))) as in apply_softmax(), neuralnetapi.cpp:241-260
+    for (int i = tid; i < n; i += 256) out[i] = expf(in[i] - c);
+}
+
+void launch_softmax(const float* logits, float* probs, int batch, int n, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_kernel, dim3(batch), dim3(256), 0, s, logits, probs, n);
+}
+
+// ================================================================================================================
+// NCHW float planes -> NHWC activation (channel padded with zeros).  LDS transpose, coalesced on both sides.
+// ================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void planes_to_act_kernel(const float* __restrict__ planes, T* __restrict__ act, int C, int cpad) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sp = reinterpret_cast<float*>(smem);   // [C][65]
+    const float* pb = planes + size_t(blockIdx.x) * C * kSquares;
+    for (int i = threadIdx.x; i < C * kSquares; i += 256) sp[(i >> 6) * 65 + (i & 63)] = pb[i];
+    __syncthreads();
+    T* ab = act + size_t(blockIdx.x) * kSquares * cpad;
+    for (int i = threadIdx.x; i < kSquares * cpad; i += 256) {
+        const int sq = i / cpad, c = i - sq * cpad;
+        ab[i] = T(c < C ? sp[c * 65 + sq] : 0.f);
+    }
+}
+
+template <typename T> void launch_planes_to_act(const float* planes, T* act, int batch, int C, int cpad, hipStream_t s) {
+    hipLaunchKernelGGL((planes_to_act_kernel<T>), dim3(batch), dim3(256), size_t(C) * 65 * sizeof(float), s, planes, act, C, cpad);
+}
+template void launch_planes_to_act<half_t>(const float*, half_t*, int, int, int, hipStream_t);
+template void launch_planes_to_act<float>(const float*, float*, int, int, int, hipStream_t);
+
+}  // namespace cra

@@ -1,0 +1,85 @@
+// RiseNet: the MI355X-native executor behind the NeuralNetAPI boundary.
+// Lifecycle mirrors TensorrtAPI (engine/src/nn/tensorrtapi.cpp:43-63,160-237): construct on a device with a fixed batch
+// size -> load_model (read .cranet) -> init_nn_design (shapes) -> load_parameters (fold BN, pack MFMA fragments, upload)
+// -> bind_executor (stream, device buffers, hipGraph capture of the whole forward) -> predict().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "netfile.h"
+
+namespace cra {
+
+struct RiseDesign {
+    int batch = 0;
+    int nb_input_channels = 0;     // C of the [B,C,8,8] input
+    int nb_policy = 0;             // policyOutputShape[1]
+    int nb_aux = 0;                // auxiliaryOutputShape[1] (0 = none)
+    int version = 0;               // make_version(maj,min,0) parsed from the file name (neuralnetapi.cpp:194-227)
+    int game_phase = 0;
+    double flops_per_position = 0; // 2*MACs, recomputed from the layer list
+};
+
+class RiseNet {
+public:
+    // model_path: a .cranet file, or a directory searched like get_onnx_model_name() (neuralnetapi.cpp:57-73).
+    // precision: "float16" (f16 MFMA operands, f32 accumulate; the reference TensorRT default, optionsuci.cpp:143-147)
+    //            or "float32" (exact f32 MFMA).   Throws std::invalid_argument / std::runtime_error.
+    RiseNet(const std::string& model_path, int device_id, int batch_size, const std::string& precision);
+    ~RiseNet();
+    RiseNet(const RiseNet&) = delete;
+    RiseNet& operator=(const RiseNet&) = delete;
+
+    const RiseDesign& design() const { return design_; }
+    const std::string& model_name() const { return model_name_; }
+    const std::string& model_file_path() const { return model_file_path_; }
+    bool fp16() const { return fp16_; }
+    int device() const { return device_; }
+    hipStream_t stream() const { return stream_; }
+
+    // NeuralNetAPI::predict contract (neuralnetapi.h:230-237): whole fixed batch, host pointers, blocking;
+    // value after tanh, policy after softmax over all nb_policy entries.
+    void predict(const float* in_planes, float* value, float* probs, float* aux);
+    // asynchronous split of the same call: submit() enqueues H2D + forward + D2H on the net's side stream and returns;
+    // wait() blocks until results are in the host buffers.  Host buffers should come from mi_host_alloc (pinned).
+    void submit(const float* in_planes, float* value, float* probs, float* aux);
+    void wait();
+
+    // Device-resident path: the captured forward reads d_planes() and writes d_value()/d_probs()/d_aux()/d_logits().
+    float* d_planes() const { return d_planes_; }     // [B][C][64] float (NCHW, as predict() takes it)
+    float* d_value() const { return d_value_; }       // [B]
+    float* d_probs() const { return d_probs_; }       // [B][nb_policy]
+    float* d_logits() const { return d_logits_; }     // [B][nb_policy] pre-softmax policy_out
+    float* d_aux() const { return d_aux_; }           // [B][nb_aux] or nullptr
+    void forward_async();                              // graph replay on stream(); no copies, no sync
+    // same forward enqueued kernel-by-kernel on a caller stream (no graph) -- used for profiling / event timing
+    void forward_on(hipStream_t s);
+
+    // per-launch bookkeeping (bench.py roofline: live hipEvent timing of each op on the net stream)
+    int launches_per_forward() const { return launches_; }
+    const char* op_name(int i) const;
+    void time_ops(int iters, float* ms);               // ms[i] += elapsed of op i, summed over iters (un-graphed launches)
+    float time_forward(int iters);                     // graph replays between two events, returns ms
+
+private:
+    struct Impl;
+    template <typename T> void build(const NetFile& nf);
+    template <typename T> void enqueue(hipStream_t s);
+    template <typename T> void launch_op(int i, hipStream_t s);
+    void capture();
+
+    RiseDesign design_;
+    std::string model_name_, model_file_path_;
+    bool fp16_ = true;
+    int device_ = 0;
+    int launches_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipGraph_t graph_ = nullptr;
+    hipGraphExec_t graph_exec_ = nullptr;
+    float *d_planes_ = nullptr, *d_value_ = nullptr, *d_probs_ = nullptr, *d_logits_ = nullptr, *d_aux_ = nullptr;
+    std::unique_ptr<Impl> impl_;
+};
+
+}  // namespace cra

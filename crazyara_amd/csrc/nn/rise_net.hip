@@ -1,0 +1,453 @@
+#include "rise_net.h"
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+#include "kernels.h"
+
+namespace cra {
+
+#define HIP_CHECK(expr)                                                                                      \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(_e) + " at " #expr);      \
+    } while (0)
+
+namespace {
+constexpr double kBnEps = 1e-5;   // torch.nn.BatchNorm2d default; the reference never overrides it
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// conv weight [cout][cin_g][k][k] + BN -> folded double weights / bias
+struct Folded {
+    std::vector<double> w;   // same layout as the input conv weight
+    std::vector<double> b;   // [cout]
+};
+
+Folded fold_bn(const NetFile& nf, const std::string& conv, const std::string& bn) {
+    const TensorView& w = nf.get(conv + ".weight");
+    const int64_t cout = w.shape[0], per = w.numel() / cout;
+    Folded f;
+    f.w.resize(w.numel());
+    f.b.assign(cout, 0.0);
+    if (bn.empty()) {
+        for (int64_t i = 0; i < w.numel(); ++i) f.w[i] = w.data[i];
+        return f;
+    }
+    const float *g = nf.get(bn + ".weight").data, *be = nf.get(bn + ".bias").data, *m = nf.get(bn + ".running_mean").data,
+                *v = nf.get(bn + ".running_var").data;
+    for (int64_t co = 0; co < cout; ++co) {
+        const double sc = double(g[co]) / std::sqrt(double(v[co]) + kBnEps);
+        for (int64_t i = 0; i < per; ++i) f.w[co * per + i] = double(w.data[co * per + i]) * sc;
+        f.b[co] = double(be[co]) - double(m[co]) * sc;
+    }
+    return f;
+}
+
+template <typename T> T cast_w(double v);
+template <> half_t cast_w<half_t>(double v) { return half_t(float(v)); }
+template <> float cast_w<float>(double v) { return float(v); }
+
+// MFMA A-fragment image, see kernels.h
+template <typename T>
+std::vector<T> pack_dense(const Folded& f, int cout, int cin, int ks, int cout_pad, int cin_pad) {
+    const int kt = ks * ks * cin_pad, nslab = kt / 32, nct = cout_pad / 16;
+    std::vector<T> out(size_t(cout_pad) * kt);
+    for (int ct = 0; ct < nct; ++ct)
+        for (int s = 0; s < nslab; ++s)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = ct * 16 + (l & 15);
+                    const int k = s * 32 + (l >> 4) * 8 + j;
+                    const int tap = k / cin_pad, ci = k % cin_pad;
+                    double v = 0.0;
+                    if (co < cout && ci < cin) v = f.w[(size_t(co) * cin + ci) * ks * ks + tap];
+                    out[((size_t(ct) * nslab + s) * 64 + l) * 8 + j] = cast_w<T>(v);
+                }
+    return out;
+}
+
+enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax };
+
+struct Op {
+    OpKind kind;
+    ConvArgs conv{};
+    // depthwise / se
+    const void* x = nullptr;
+    void* y = nullptr;
+    const float *w0 = nullptr, *w1 = nullptr, *b0 = nullptr;
+    int C = 0, ks = 0, se_kind = 0;
+    ValueHeadArgs vh{};
+};
+}  // namespace
+
+struct RiseNet::Impl {
+    std::vector<void*> allocs;
+    std::vector<Op> ops;
+    int cin_pad = 0;
+
+    void* dalloc(size_t bytes) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+        allocs.push_back(p);
+        return p;
+    }
+    template <typename U> U* upload(const std::vector<U>& h) {
+        U* d = static_cast<U*>(dalloc(h.size() * sizeof(U)));
+        HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(U), hipMemcpyHostToDevice));
+        return d;
+    }
+    float* upload_d2f(const std::vector<double>& h, size_t pad_to = 0) {
+        std::vector<float> f(std::max(h.size(), pad_to), 0.f);
+        for (size_t i = 0; i < h.size(); ++i) f[i] = float(h[i]);
+        return upload(f);
+    }
+    ~Impl() {
+        for (void* p : allocs) (void)hipFree(p);
+    }
+};
+
+RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, const std::string& precision)
+    : device_(device_id), impl_(new Impl) {
+    if (batch_size <= 0) throw std::invalid_argument("batch size must be positive");
+    if (precision == "float16" || precision == "fp16" || precision == "half") fp16_ = true;
+    else if (precision == "float32" || precision == "fp32") fp16_ = false;
+    else throw std::invalid_argument("unsupported precision '" + precision + "' (float16 | float32)");
+    design_.batch = batch_size;
+
+    // model discovery (TensorrtAPI ctor, tensorrtapi.cpp:53-58)
+    std::string dir, file;
+    if (model_path.size() > 7 && model_path.compare(model_path.size() - 7, 7, ".cranet") == 0) {
+        const size_t sl = model_path.find_last_of('/');
+        dir = sl == std::string::npos ? "./" : model_path.substr(0, sl + 1);
+        file = sl == std::string::npos ? model_path : model_path.substr(sl + 1);
+    } else {
+        if (model_path.empty()) throw std::invalid_argument("The given directory must not be empty.");
+        dir = model_path.back() == '/' ? model_path : model_path + "/";
+        file = find_model_file(dir, batch_size);
+    }
+    model_name_ = file;
+    model_file_path_ = dir + file;
+    design_.version = read_version_from_string(model_name_);
+    design_.game_phase = read_game_phase_from_string(dir);
+
+    int ndev = 0;
+    HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) throw std::invalid_argument("device id out of range");
+    HIP_CHECK(hipSetDevice(device_id));
+
+    NetFile nf;                                  // load_model
+    nf.load(model_file_path_);
+    if (nf.str("arch") != "rise") throw std::runtime_error("unsupported arch '" + nf.str("arch") + "' in " + model_file_path_);
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    if (fp16_) build<half_t>(nf); else build<float>(nf);   // init_nn_design + load_parameters + buffers
+    capture();                                   // bind_executor
+}
+
+RiseNet::~RiseNet() {
+    (void)hipSetDevice(device_);
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+    impl_.reset();
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+template <typename T> void RiseNet::build(const NetFile& nf) {
+    Impl& im = *impl_;
+    const int B = design_.batch;
+    const int cin = int(nf.num("nb_input_channels"));
+    const int C = int(nf.num("channels", 256));
+    const int cop_init = int(nf.num("channels_operating_init"));
+    const int cexp = int(nf.num("channel_expansion"));
+    const int cv = int(nf.num("channels_value_head", 8));
+    const int fc = int(nf.num("value_fc_size", 256));
+    const int cp = int(nf.num("channels_policy_head"));
+    const bool wdl = nf.num("use_wdl") != 0 && nf.num("use_plys_to_end") != 0;
+    std::vector<std::string> kernels = nf.list("kernels"), se_types = nf.list("se_types");
+    if (kernels.empty() || kernels.size() != se_types.size()) throw std::runtime_error("kernels/se_types mismatch in model file");
+    if (C % 64 != 0 || C > 512) throw std::runtime_error("channels must be a multiple of 64 and <= 512");
+    if (fc > 256 && fc % 256 != 0) throw std::runtime_error("unsupported value_fc_size");
+
+    design_.nb_input_channels = cin;
+    design_.nb_policy = cp * kSquares;
+    design_.nb_aux = wdl ? 4 : 0;
+    const int cin_pad = round_up(cin, 32);
+    im.cin_pad = cin_pad;
+
+    // C_op schedule: rise_mobile_v3.py:36-78 (kernel_5_channel_ratio=None)
+    std::vector<int> cops, ks;
+    int cop_run = cop_init, cop_max = 32;
+    for (size_t i = 0; i < kernels.size(); ++i) {
+        const int k = std::stoi(kernels[i]);
+        if (k != 3 && k != 5) throw std::runtime_error("unsupported depthwise kernel size " + kernels[i]);
+        const int c = k == 5 ? cop_run - 32 * int(i / 2) : cop_run;
+        if (c % 32 != 0 || c <= 0) throw std::runtime_error("channels_operating must be a positive multiple of 32");
+        cops.push_back(c);
+        ks.push_back(k);
+        cop_max = std::max(cop_max, c);
+        cop_run += cexp;
+    }
+
+    // ---- device buffers ----
+    d_planes_ = static_cast<float*>(im.dalloc(size_t(B) * cin * kSquares * sizeof(float)));
+    d_value_ = static_cast<float*>(im.dalloc(size_t(B) * sizeof(float)));
+    d_probs_ = static_cast<float*>(im.dalloc(size_t(B) * design_.nb_policy * sizeof(float)));
+    d_logits_ = static_cast<float*>(im.dalloc(size_t(B) * design_.nb_policy * sizeof(float)));
+    d_aux_ = wdl ? static_cast<float*>(im.dalloc(size_t(B) * 4 * sizeof(float))) : nullptr;
+    T* x0 = static_cast<T*>(im.dalloc(size_t(B) * kSquares * cin_pad * sizeof(T)));
+    T* a0 = static_cast<T*>(im.dalloc(size_t(B) * kSquares * C * sizeof(T)));
+    T* a1 = static_cast<T*>(im.dalloc(size_t(B) * kSquares * C * sizeof(T)));
+    T* e = static_cast<T*>(im.dalloc(size_t(B) * kSquares * cop_max * sizeof(T)));
+    T* f = static_cast<T*>(im.dalloc(size_t(B) * kSquares * cop_max * sizeof(T)));
+
+    double macs = 0;
+    auto add_conv = [&](const std::string& conv, const std::string& bn, const T* x, T* out, const T* resid, int ci, int ci_pad,
+                        int co, int k, bool relu, float* out_policy) {
+        Folded fd = fold_bn(nf, conv, bn);
+        const int co_pad = round_up(co, 16);
+        Op op;
+        op.kind = OpKind::Conv;
+        op.conv.x = x;
+        op.conv.wpk = im.upload(pack_dense<T>(fd, co, ci, k, co_pad, ci_pad));
+        op.conv.bias = im.upload_d2f(fd.b, co_pad);
+        op.conv.resid = resid;
+        op.conv.out = out_policy ? static_cast<void*>(out_policy) : static_cast<void*>(out);
+        op.conv.batch = B;
+        op.conv.cin = ci_pad;
+        op.conv.cout_pad = co_pad;
+        op.conv.cout_real = co;
+        op.conv.cout_ld = co_pad;
+        op.conv.ks = k;
+        op.conv.relu = relu;
+        op.conv.out_policy_f32 = out_policy ? 1 : 0;
+        im.ops.push_back(op);
+        macs += double(kSquares) * ci * co * k * k;
+    };
+
+    {   // input layout transform
+        Op op;
+        op.kind = OpKind::PlanesToAct;
+        op.x = d_planes_;
+        op.y = x0;
+        op.C = cin;
+        im.ops.push_back(op);
+    }
+    add_conv("body_spatial.0.body.0", "body_spatial.0.body.1", x0, a0, nullptr, cin, cin_pad, C, 3, true, nullptr);   // _Stem
+    T *cur = a0, *nxt = a1;
+    for (size_t i = 0; i < cops.size(); ++i) {
+        const std::string p = "body_spatial." + std::to_string(i + 1);
+        const int cop = cops[i], k = ks[i];
+        if (se_types[i] == "ca_se" || se_types[i] == "se") {           // _ChannelAttentionModule, builder_util.py:83-114
+            const TensorView &w1 = nf.get(p + ".se.fc.0.weight"), &w2 = nf.get(p + ".se.fc.2.weight");
+            const int H = C / 2;
+            std::vector<float> w1t(size_t(C) * H), w2t(size_t(H) * C);
+            for (int j = 0; j < H; ++j) for (int c = 0; c < C; ++c) w1t[size_t(c) * H + j] = w1.data[size_t(j) * C + c];
+            for (int c = 0; c < C; ++c) for (int j = 0; j < H; ++j) w2t[size_t(j) * C + c] = w2.data[size_t(c) * H + j];
+            Op op;
+            op.kind = OpKind::SE;
+            op.se_kind = 1;
+            op.y = cur;
+            op.w0 = im.upload(w1t);
+            op.w1 = im.upload(w2t);
+            op.C = C;
+            im.ops.push_back(op);
+            macs += 2.0 * C * H;
+        } else if (se_types[i] == "eca_se") {                           // _EfficientChannelAttentionModule, builder_util.py:49-80
+            const TensorView& w = nf.get(p + ".se.body.0.weight");     // [C][C][kk]; the length-1 sequence only sees the centre tap
+            const int kk = int(w.shape[2]), mid = kk / 2;
+            std::vector<float> wt(size_t(C) * C), b(C);
+            for (int o = 0; o < C; ++o) for (int c = 0; c < C; ++c) wt[size_t(c) * C + o] = w.data[(size_t(o) * C + c) * kk + mid];
+            const float* bs = nf.get(p + ".se.body.0.bias").data;
+            for (int o = 0; o < C; ++o) b[o] = bs[o];
+            Op op;
+            op.kind = OpKind::SE;
+            op.se_kind = 2;
+            op.y = cur;
+            op.w0 = im.upload(wt);
+            op.b0 = im.upload(b);
+            op.C = C;
+            im.ops.push_back(op);
+            macs += double(C) * C;
+        } else if (se_types[i] != "none" && !se_types[i].empty()) {
+            throw std::runtime_error("unsupported se_type " + se_types[i]);
+        }
+        add_conv(p + ".body.0", p + ".body.1", cur, e, nullptr, C, C, cop, 1, true, nullptr);   // 1x1 expand + BN + ReLU
+        {   // depthwise k x k + BN + ReLU
+            Folded fd = fold_bn(nf, p + ".body.3", p + ".body.4");
+            std::vector<float> w(size_t(k) * k * cop);
+            for (int c = 0; c < cop; ++c) for (int t = 0; t < k * k; ++t) w[size_t(t) * cop + c] = float(fd.w[size_t(c) * k * k + t]);
+            Op op;
+            op.kind = OpKind::Depthwise;
+            op.x = e;
+            op.y = f;
+            op.w0 = im.upload(w);
+            op.b0 = im.upload_d2f(fd.b);
+            op.C = cop;
+            op.ks = k;
+            im.ops.push_back(op);
+            macs += double(kSquares) * cop * k * k;
+        }
+        add_conv(p + ".body.6", p + ".body.7", f, nxt, cur, cop, cop, C, 1, false, nullptr);    // 1x1 project + BN + residual
+        std::swap(cur, nxt);
+    }
+    // _PolicyHead (select_policy_from_plane), builder_util.py:206-243
+    add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr);
+    add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_);
+    {
+        Op op;
+        op.kind = OpKind::Softmax;
+        im.ops.push_back(op);
+    }
+    {   // _ValueHead, builder_util.py:246-326
+        Folded fd = fold_bn(nf, "value_head.body.0", "value_head.body.1");
+        const int nfl = kSquares * cv;
+        Op op;
+        op.kind = OpKind::ValueHead;
+        ValueHeadArgs& v = op.vh;
+        v.x = cur;
+        v.wconv = im.upload_d2f(fd.w);
+        v.bconv = im.upload_d2f(fd.b);
+        v.value = d_value_;
+        v.aux = d_aux_;
+        v.batch = B;
+        v.C = C;
+        v.cv = cv;
+        v.fc = fc;
+        if (wdl) {
+            const TensorView &ww = nf.get("value_head.body_wdl.0.weight"), &wp = nf.get("value_head.body_plys.0.weight");
+            v.wwdl = im.upload(std::vector<float>(ww.data, ww.data + 3 * nfl));
+            const float* bw = nf.get("value_head.body_wdl.0.bias").data;
+            v.bwdl = im.upload(std::vector<float>(bw, bw + 3));
+            v.wplys = im.upload(std::vector<float>(wp.data, wp.data + nfl));
+            v.bplys = nf.get("value_head.body_plys.0.bias").data[0];
+            macs += 4.0 * nfl;
+        } else {
+            const TensorView &w1 = nf.get("value_head.body_final.0.weight"), &w2 = nf.get("value_head.body_final.2.weight");
+            std::vector<float> w1t(size_t(nfl) * fc);
+            for (int t = 0; t < fc; ++t) for (int i = 0; i < nfl; ++i) w1t[size_t(i) * fc + t] = w1.data[size_t(t) * nfl + i];
+            v.w1t = im.upload(w1t);
+            const float* b1 = nf.get("value_head.body_final.0.bias").data;
+            v.b1 = im.upload(std::vector<float>(b1, b1 + fc));
+            v.w2 = im.upload(std::vector<float>(w2.data, w2.data + fc));
+            v.b2 = nf.get("value_head.body_final.2.bias").data[0];
+            macs += double(nfl) * fc + fc;
+        }
+        macs += double(kSquares) * C * cv;
+        im.ops.push_back(op);
+    }
+    design_.flops_per_position = 2.0 * macs;
+    launches_ = int(im.ops.size());
+}
+
+template <typename T> void RiseNet::launch_op(int i, hipStream_t s) {
+    Impl& im = *impl_;
+    const int B = design_.batch;
+    const Op& op = im.ops[i];
+    switch (op.kind) {
+        case OpKind::PlanesToAct:
+            launch_planes_to_act<T>(static_cast<const float*>(op.x), static_cast<T*>(op.y), B, op.C, im.cin_pad, s);
+            break;
+        case OpKind::Conv: launch_conv_gemm<T>(op.conv, s); break;
+        case OpKind::Depthwise:
+            launch_depthwise<T>(static_cast<const T*>(op.x), static_cast<T*>(op.y), op.w0, op.b0, B, op.C, op.ks, s);
+            break;
+        case OpKind::SE: launch_se<T>(static_cast<T*>(op.y), op.se_kind, op.w0, op.w1, op.b0, B, op.C, s); break;
+        case OpKind::ValueHead: launch_value_head<T>(op.vh, s); break;
+        case OpKind::Softmax: launch_softmax(d_logits_, d_probs_, B, design_.nb_policy, s); break;
+    }
+}
+
+template <typename T> void RiseNet::enqueue(hipStream_t s) {
+    for (int i = 0; i < int(impl_->ops.size()); ++i) launch_op<T>(i, s);
+    HIP_CHECK(hipGetLastError());
+}
+
+const char* RiseNet::op_name(int i) const {
+    const Op& op = impl_->ops.at(i);
+    switch (op.kind) {
+        case OpKind::PlanesToAct: return "planes_to_act";
+        case OpKind::Conv: return op.conv.ks == 1 ? "conv_gemm_1x1" : "conv_gemm_3x3";
+        case OpKind::Depthwise: return "depthwise";
+        case OpKind::SE: return "se";
+        case OpKind::ValueHead: return "value_head";
+        case OpKind::Softmax: return "softmax";
+    }
+    return "?";
+}
+
+void RiseNet::time_ops(int iters, float* ms) {
+    HIP_CHECK(hipSetDevice(device_));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    const int n = int(impl_->ops.size());
+    for (int it = 0; it < iters; ++it)
+        for (int i = 0; i < n; ++i) {
+            HIP_CHECK(hipEventRecord(e0, stream_));
+            if (fp16_) launch_op<half_t>(i, stream_); else launch_op<float>(i, stream_);
+            HIP_CHECK(hipEventRecord(e1, stream_));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float t = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            ms[i] += t;
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+}
+
+float RiseNet::time_forward(int iters) {
+    HIP_CHECK(hipSetDevice(device_));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, stream_));
+    for (int it = 0; it < iters; ++it) HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
+    HIP_CHECK(hipEventRecord(e1, stream_));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return t;
+}
+
+void RiseNet::capture() {
+    HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    try {
+        forward_on(stream_);
+    } catch (...) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(stream_, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+    }
+    HIP_CHECK(hipStreamEndCapture(stream_, &graph_));
+    HIP_CHECK(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0));
+}
+
+void RiseNet::forward_on(hipStream_t s) {
+    if (fp16_) enqueue<half_t>(s); else enqueue<float>(s);
+}
+
+void RiseNet::forward_async() { HIP_CHECK(hipGraphLaunch(graph_exec_, stream_)); }
+
+void RiseNet::submit(const float* in_planes, float* value, float* probs, float* aux) {
+    HIP_CHECK(hipSetDevice(device_));   // every predict selects its device, tensorrtapi.cpp:198
+    const size_t B = design_.batch;
+    HIP_CHECK(hipMemcpyAsync(d_planes_, in_planes, B * design_.nb_input_channels * kSquares * sizeof(float), hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
+    HIP_CHECK(hipMemcpyAsync(value, d_value_, B * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(probs, d_probs_, B * design_.nb_policy * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (d_aux_ && aux) HIP_CHECK(hipMemcpyAsync(aux, d_aux_, B * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+}
+
+void RiseNet::wait() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+void RiseNet::predict(const float* in_planes, float* value, float* probs, float* aux) {
+    submit(in_planes, value, probs, aux);
+    wait();
+}
+
+}  // namespace cra

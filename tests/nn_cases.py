@@ -1,0 +1,61 @@
+"""Shared NN parity cases: configs, deterministic weights, deterministic inputs (no reference needed at run time)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import rise_oracle as ro  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def small_risev2():
+    """3-block RISEv2 parametrisation (C_op 128/192/256), ca_se on the last two blocks, crazyhouse v1 planes."""
+    cfg = ro.rise_v2_config(3, 34, 81)
+    cfg.se_types = [None, "ca_se", "ca_se"]
+    cfg.name = "risev2-3"
+    return cfg
+
+
+CASES = {
+    # name: (config factory, seed, stress-init, batch)
+    "risev2-3": (small_risev2, 11, True, 4),
+    "risev2-7": (lambda: ro.rise_v2_config(7, 34, 81), 12, True, 8),            # BASELINE config 1
+    "risev2-13": (lambda: ro.rise_v2_config(13, 34, 81), 13, True, 4),          # the reference's named RISEv2
+    "risev2-19": (lambda: ro.rise_v2_config(19, 34, 81), 14, True, 4),          # BASELINE config 2 (headline)
+    "risev2-13-default-init": (lambda: ro.rise_v2_config(13, 34, 81), 15, False, 4),
+    "risev33": (lambda: ro.rise_v33_config(52, 76, False), 16, True, 4),        # BASELINE config 3
+    "risev33-wdlp": (lambda: ro.rise_v33_config(52, 76, True), 17, True, 4),    # released ClassicAra head
+    "risev2-13-lichess": (lambda: ro.rise_v2_config(13, 80, 84), 18, True, 2),  # MultiAra tables (config 5)
+}
+
+
+def make_case(name):
+    factory, seed, stress, batch = CASES[name]
+    cfg = factory()
+    sd = ro.make_state_dict(cfg, seed=seed, stress=stress)
+    x = synthetic_planes(batch, cfg.nb_input_channels, seed + 1000)
+    return cfg, sd, x
+
+
+def synthetic_planes(batch, channels, seed):
+    """Board-like planes: ~88 % zeros, sparse ones, a few constant planes with fractional values."""
+    rng = np.random.default_rng(seed)
+    x = (rng.random((batch, channels, 8, 8)) < 0.10).astype(np.float32)
+    for b in range(batch):
+        for c in rng.choice(channels, size=max(2, channels // 8), replace=False):
+            x[b, c] = rng.choice([0.0, 1.0, 0.25, 1.0 / 32, 3.0 / 8, 0.002 * (b + 1)])
+    return torch.from_numpy(x)
+
+
+def export_case(tmpdir, name, cfg, sd, version="1.0"):
+    from crazyara_amd import netfile
+    d = os.path.join(str(tmpdir), name)
+    os.makedirs(d, exist_ok=True)
+    netfile.export_rise(os.path.join(d, f"{cfg.name}-v{version}.cranet"), cfg, sd, input_version=version)
+    return d

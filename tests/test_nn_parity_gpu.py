@@ -1,0 +1,113 @@
+"""GPU parity of the HIP NN path (through the C ABI) against the oracle and the committed reference goldens.
+
+Tolerances (BASELINE.json north_star: "value/policy logits within 1e-3 fp32"):
+  Precision float32 (exact-f32 MFMA): |logit| err < 1e-4, |value| err < 1e-4, |prob| err < 1e-6
+  Precision float16 (f16 MFMA operands, f32 accumulate -- the reference TensorRT default): predict() outputs
+      |value| err < 1e-3, |prob| err < 1e-3 (measured ~1e-5); logits < 6e-3 (f16 operand rounding, predicted by the
+      oracle's sim_dtype=float16 mode at ~2e-3 for |logit| ~ 1.4).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nn_cases
+from oracle import rise_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"float32": dict(logit=1e-4, value=1e-4, prob=1e-6, aux=1e-4),
+       "float16": dict(logit=6e-3, value=1e-3, prob=1e-3, aux=5e-3)}
+
+
+def _run(tmp_path, hip_lib, name, precision):
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, x = nn_cases.make_case(name)
+    d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
+    B = x.shape[0]
+    net = HipAPI(0, B, d, precision)
+    assert net.get_batch_size() == B and net.get_nb_policy_values() == cfg.nb_policy
+    assert net.get_nb_input_values_total() == cfg.nb_input_channels * 64
+    assert net.get_nb_auxiliary_outputs() == cfg.nb_aux
+    assert abs(net.flops_per_position() - ro.flops_per_position(cfg)) < 1.0
+    value = np.full(B, 7.0, np.float32)
+    probs = np.full(B * cfg.nb_policy, 7.0, np.float32)
+    aux = np.full(B * 4, 7.0, np.float32) if cfg.nb_aux else None
+    net.predict(np.ascontiguousarray(x.numpy()), value, probs, aux)
+    logits = torch.as_tensor(net.device_buffers()["logits"], device="cuda").cpu().numpy()
+    net.close()
+    return cfg, sd, x, value, probs.reshape(B, -1), aux, logits
+
+
+@pytest.mark.parametrize("precision", ["float32", "float16"])
+@pytest.mark.parametrize("name", list(nn_cases.CASES))
+def test_predict_matches_oracle_and_golden(tmp_path, hip_lib, name, precision):
+    cfg, sd, x, value, probs, aux, logits = _run(tmp_path, hip_lib, name, precision)
+    tol = TOL[precision]
+    o_value, o_logits, o_aux = ro.forward(cfg, sd, x)
+    o_probs = torch.softmax(o_logits, dim=1).numpy()
+    g = np.load(os.path.join(nn_cases.GOLDEN_DIR, f"nn_{name}.npz"))
+    for ref_v, ref_l in ((o_value.numpy().reshape(-1), o_logits.numpy()), (g["value"].reshape(-1), g["logits"])):
+        assert np.abs(value - ref_v).max() < tol["value"]
+        assert np.abs(logits - ref_l).max() < tol["logit"]
+    assert np.abs(probs - o_probs).max() < tol["prob"]
+    assert np.allclose(probs.sum(axis=1), 1.0, atol=1e-4)
+    if cfg.nb_aux:
+        assert np.abs(aux.reshape(-1, 4) - o_aux.numpy()).max() < tol["aux"]
+
+
+def test_partial_batch_and_stale_slots(tmp_path, hip_lib):
+    """predict always runs the full fixed batch; rows are independent, stale trailing slots must not matter
+    (engine/src/searchthread.cpp:407-411)."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, x = nn_cases.make_case("risev2-3")
+    d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
+    net = HipAPI(0, 8, d, "float32")
+    xin = np.zeros((8, 34, 8, 8), np.float32)
+    xin[:4] = x.numpy()
+    xin[4:] = 123.0  # garbage in the unused slots
+    v, p = np.zeros(8, np.float32), np.zeros(8 * 5184, np.float32)
+    net.predict(xin, v, p)
+    o_value, o_logits, _ = ro.forward(cfg, sd, x)
+    assert np.abs(v[:4] - o_value.numpy().reshape(-1)).max() < 1e-4
+    assert np.abs(p.reshape(8, -1)[:4] - torch.softmax(o_logits, 1).numpy()).max() < 1e-6
+    net.close()
+
+
+def test_submit_wait_and_device_resident_paths_agree(tmp_path, hip_lib):
+    from crazyara_amd.neuralnetapi import HipAPI, NeuralNetAPIUser
+    cfg, sd, x = nn_cases.make_case("risev2-3")
+    d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
+    net = HipAPI(0, 4, d, "float16")
+    user = NeuralNetAPIUser([net])
+    user.input_planes[:] = x.numpy().reshape(-1)
+    user.run_inference(2)
+    v1, p1 = user.value_outputs.copy(), user.prob_outputs.copy()
+    user.value_outputs[:] = 0
+    user.prob_outputs[:] = 0
+    net.submit(user._p_in, user._p_val, user._p_prob)
+    net.wait()
+    assert np.array_equal(v1, user.value_outputs) and np.array_equal(p1, user.prob_outputs)
+    bufs = net.device_buffers()
+    torch.as_tensor(bufs["planes"], device="cuda").copy_(x.cuda())
+    torch.cuda.synchronize()
+    net.forward_device()
+    net.sync()
+    assert np.array_equal(torch.as_tensor(bufs["probs"], device="cuda").cpu().numpy().reshape(-1), p1)
+    assert np.array_equal(torch.as_tensor(bufs["value"], device="cuda").cpu().numpy(), v1)
+    user.close()
+    net.close()
+
+
+def test_constructor_errors(tmp_path, hip_lib):
+    from crazyara_amd.neuralnetapi import HipAPI
+    with pytest.raises(ValueError):
+        HipAPI(0, 4, str(tmp_path), "float16")          # no .cranet in directory (neuralnetapi.cpp:65-67)
+    cfg, sd, x = nn_cases.make_case("risev2-3")
+    d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
+    with pytest.raises(ValueError):
+        HipAPI(0, 4, d, "int4")
+    net = HipAPI(0, 4, d, "float16")
+    assert net.get_version() == 1000000 and net.get_model_name().endswith("-v1.0.cranet")
+    net.close()

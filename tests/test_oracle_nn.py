@@ -1,0 +1,58 @@
+"""Pins the NN oracle (oracle/rise_oracle.py) against outputs of the reference PyTorch model (tests/golden/nn_*.npz,
+made by oracle/make_golden.py from /root/reference) -- CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nn_cases
+from oracle import rise_oracle as ro
+
+
+@pytest.mark.parametrize("name", list(nn_cases.CASES))
+def test_oracle_matches_reference_golden(name):
+    cfg, sd, x = nn_cases.make_case(name)
+    g = np.load(os.path.join(nn_cases.GOLDEN_DIR, f"nn_{name}.npz"))
+    assert np.array_equal(g["x"], x.numpy()), "input generator drifted from the committed fixture"
+    torch.set_num_threads(1)
+    value, logits, aux = ro.forward(cfg, sd, x)
+    # same ops, same summation order family: only thread-partitioning round-off may differ
+    assert np.abs(value.numpy() - g["value"]).max() < 2e-6
+    assert np.abs(logits.numpy() - g["logits"]).max() < 2e-5
+    if cfg.nb_aux:
+        assert np.abs(aux.numpy() - g["aux"]).max() < 2e-5
+    else:
+        assert g["aux"].size == 0
+
+
+def test_predict_contract_softmax_and_shapes():
+    cfg, sd, x = nn_cases.make_case("risev2-3")
+    value, probs, aux = ro.predict(cfg, sd, x)
+    assert value.shape == (x.shape[0],) and probs.shape == (x.shape[0], 5184) and aux is None
+    assert torch.allclose(probs.sum(dim=1), torch.ones(x.shape[0]), atol=1e-5)
+    assert float(value.abs().max()) <= 1.0
+
+
+def test_flops_match_survey_table():
+    # 259 / 554 / 1002 MFLOP per position for RISEv2-7/13/19, 523 for RISEv3.3 chess
+    for n, mf in ((7, 259), (13, 554), (19, 1002)):
+        assert abs(ro.flops_per_position(ro.rise_v2_config(n)) / 1e6 - mf) < 2.0
+    assert abs(ro.flops_per_position(ro.rise_v33_config()) / 1e6 - 523) < 2.0
+
+
+@pytest.mark.reference
+def test_oracle_equals_live_reference(has_reference):
+    if not has_reference:
+        pytest.skip("/root/reference not present (GPU box)")
+    from oracle import make_golden
+    RiseV3 = make_golden.import_reference()
+    cfg, sd, x = nn_cases.make_case("risev33-wdlp")
+    model = make_golden.reference_model(RiseV3, cfg)
+    model.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        out = model(x)
+    value, logits, aux = ro.forward(cfg, sd, x)
+    assert float((value - out[0]).abs().max()) < 2e-6
+    assert float((logits - out[1]).abs().max()) < 2e-5
+    assert float((aux - out[2]).abs().max()) < 2e-5

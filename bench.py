@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""Headline benchmark: NN evaluations/sec (+ MCTS nodes/sec) of the crazyhouse RISEv2-19 path at batch 256.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 is launched by torch.distributed.run, one rank per
+GPU).  One step = one pass of the hot path over one batch of synthetic positions already resident in HBM:
+input planes -> RISEv2 19-block forward -> policy softmax + value (what NeuralNetAPI::predict computes between its
+H2D and D2H copies, engine/src/nn/tensorrtapi.cpp:195-237).  Rank 0 prints ONE JSON line.
+
+The metric follows CrazyAra::inference (engine/src/uci/crazyara.cpp:156-181): evals/s = steps * batchSize / elapsed.
+Multi-GPU = independent replicas: no data-path collective, only the final reduction of the
+timing/throughput scalars over RCCL.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BATCH = 256
+N_BLOCKS = 19
+PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_planes(batch, channels, seed):
+    """Board-like planes: ~88 % exact zeros, sparse ones, a few fractional constant planes."""
+    rng = np.random.default_rng(seed)
+    x = (rng.random((batch, channels, 8, 8)) < 0.10).astype(np.float32)
+    for b in range(batch):
+        for c in rng.choice(channels, size=max(2, channels // 8), replace=False):
+            x[b, c] = rng.choice([0.0, 1.0, 0.25, 1.0 / 32, 3.0 / 8])
+    return torch.from_numpy(x)
+
+
+def cpu_baseline(cfg, sd, x, budget_s=15.0):
+    """Reference CPU path timed beside the GPU: the oracle restatement of the reference PyTorch model (same torch ops,
+    fp32, eval, softmax included) on the host cores.  Bounded sample: whole batches of 256 until ~budget_s elapsed."""
+    from oracle import rise_oracle as ro
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ro.predict(cfg, sd, x[:32])  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ro.predict(cfg, sd, x)
+        n += x.shape[0]
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 16 * x.shape[0]:
+            break
+    return {"value": round(n / el, 1), "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"{n} positions (batches of {x.shape[0]}) of the same synthetic workload, oracle/rise_oracle.predict "
+                      f"(torch fp32 CPU restatement of the reference RiseV3 module), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--precision", default="float16", choices=["float16", "float32"])
+    ap.add_argument("--blocks", type=int, default=N_BLOCKS)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path is the HIP library, there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from crazyara_amd import build, netfile, rise_config
+    from crazyara_amd.neuralnetapi import HipAPI
+    if local_rank == 0:
+        build.build()
+    if dist is not None:
+        dist.barrier()
+
+    cfg = rise_config.rise_v2_config(args.blocks, 34, 81)
+    sd = rise_config.make_state_dict(cfg, seed=2024, stress=True)
+    tmp = tempfile.mkdtemp(prefix=f"cra_bench_{rank}_")
+    netfile.export_rise(os.path.join(tmp, f"{cfg.name}-v1.0.cranet"), cfg, sd, input_version="1.0")
+    net = HipAPI(local_rank, args.batch, tmp, args.precision)
+    x = synthetic_planes(args.batch, cfg.nb_input_channels, seed=7 + rank)
+    bufs = net.device_buffers()
+    torch.as_tensor(bufs["planes"], device="cuda").copy_(x.cuda())
+    torch.cuda.synchronize()
+
+    def sync_all():
+        net.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        net.forward_device()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.forward_device()
+    net.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the only collective: timing reduction
+        elapsed = float(t.item())
+        dist.barrier()
+    evals = args.steps * args.batch * world
+    value = evals / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel, timed live with hipEvents on the net's own stream ----
+        ev_ms = net.time_forward(args.steps) / args.steps
+        ops = net.time_ops(5)
+        agg, cnt = {}, {}
+        for name, ms in ops:
+            agg[name] = agg.get(name, 0.0) + ms
+            cnt[name] = cnt.get(name, 0) + 1
+        dom = max(agg, key=agg.get)
+        flops_total = net.flops_per_position() * args.batch
+        # algorithmic FLOPs of the dominant kernel's launches (1x1 expand/project GEMMs of all blocks)
+        cops = cfg.channels_operating()
+        if dom == "conv_gemm_1x1":
+            dom_flops = sum(2.0 * 64 * cfg.channels * c * 2 for c in cops) * args.batch
+        elif dom == "conv_gemm_3x3":
+            dom_flops = 2.0 * 64 * 9 * (cfg.nb_input_channels * 256 + 256 * 256 + 256 * cfg.channels_policy_head) * args.batch
+        else:
+            dom_flops = flops_total
+        peak = PEAK_F16_TFLOPS if args.precision == "float16" else PEAK_F32_TFLOPS
+        achieved = dom_flops / (agg[dom] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom, "launches_per_step": cnt[dom],
+                    "avg_launch_ms": round(agg[dom] / cnt[dom], 5), "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "whole_forward": {"event_ms_per_step": round(ev_ms, 4),
+                                      "achieved": round(flops_total / (ev_ms * 1e-3) / 1e12, 2),
+                                      "frac": round(flops_total / (ev_ms * 1e-3) / 1e12 / peak, 4)},
+                    "per_op_ms": {k: round(v, 4) for k, v in agg.items()}}
+        # ---- PCIe-inclusive rate (the reference `inference` command includes H2D/D2H each call) ----
+        from crazyara_amd.neuralnetapi import NeuralNetAPIUser
+        user = NeuralNetAPIUser([net])
+        user.input_planes[:] = x.numpy().reshape(-1)
+        user.run_inference(5)
+        t1 = time.perf_counter()
+        it = max(20, args.steps // 4)
+        user.run_inference(it)
+        pcie_rate = it * args.batch / (time.perf_counter() - t1)
+        user.close()
+        out = {
+            "metric": "nn_evals_per_sec", "value": round(value, 1), "unit": "evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.precision == "float16" else "f32", "data": "synthetic",
+            "config": {"workload": f"crazyhouse RISEv2 {args.blocks}-block (34x8x8 planes -> 5184 policy + value), "
+                                   f"batch={args.batch}, inputs resident in HBM, random-init seeded weights",
+                       "batch": args.batch, "parallelism": f"replicas x{world}",
+                       "flops_per_position": net.flops_per_position()},
+            "pcie_inclusive_evals_per_sec": round(pcie_rate, 1),
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, x)
+    net.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

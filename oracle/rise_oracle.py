@@ -24,8 +24,7 @@ tests/test_oracle_nn.py checks this restatement against those fixtures (exact to
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field, asdict
-from typing import Dict, List, Optional
+from typing import Dict
 
 import numpy as np
 import torch
@@ -34,154 +33,8 @@ import torch.nn.functional as F
 BN_EPS = 1e-5  # torch.nn.BatchNorm2d default (reference never overrides it)
 
 
-@dataclass
-class RiseConfig:
-    nb_input_channels: int = 34
-    channels: int = 256
-    channels_operating_init: int = 128
-    channel_expansion: int = 64
-    kernels: List[int] = field(default_factory=lambda: [3] * 13)
-    se_types: List[Optional[str]] = field(default_factory=lambda: [None] * 13)
-    channels_value_head: int = 8
-    value_fc_size: int = 256
-    channels_policy_head: int = 81
-    use_wdl: bool = False
-    use_plys_to_end: bool = False
-    name: str = "risev2"
-
-    def channels_operating(self) -> List[int]:
-        """C_op per block, rise_mobile_v3.py:36-78 (kernel_5_channel_ratio=None branch)."""
-        out = []
-        c = self.channels_operating_init
-        for idx, k in enumerate(self.kernels):
-            out.append(c - 32 * (idx // 2) if k == 5 else c)
-            c += self.channel_expansion
-        return out
-
-    @property
-    def nb_policy(self) -> int:
-        return self.channels_policy_head * 64
-
-    @property
-    def nb_aux(self) -> int:
-        return 4 if (self.use_wdl and self.use_plys_to_end) else 0
-
-    def to_dict(self):
-        return asdict(self)
-
-
-def rise_v2_config(n_blocks: int = 13, nb_input_channels: int = 34, channels_policy_head: int = 81) -> RiseConfig:
-    """RISEv2 parametrised by block count; ca_se on the last 5 blocks (rise_mobile_v3.py:217-241)."""
-    se = [None] * n_blocks
-    for i in range(max(0, n_blocks - 5), n_blocks):
-        se[i] = "ca_se"
-    return RiseConfig(nb_input_channels=nb_input_channels, channels=256, channels_operating_init=128,
-                      channel_expansion=64, kernels=[3] * n_blocks, se_types=se,
-                      channels_policy_head=channels_policy_head, name=f"risev2-{n_blocks}")
-
-
-def rise_v33_config(nb_input_channels: int = 52, channels_policy_head: int = 76, wdlp: bool = False) -> RiseConfig:
-    """RISEv3.3 (rise_mobile_v3.py:186-214)."""
-    kernels = [3] * 15
-    for i in (7, 11, 12, 13):
-        kernels[i] = 5
-    se = [None] * 15
-    for i in (5, 8, 12, 13, 14):
-        se[i] = "eca_se"
-    return RiseConfig(nb_input_channels=nb_input_channels, channels=256, channels_operating_init=224,
-                      channel_expansion=32, kernels=kernels, se_types=se,
-                      channels_policy_head=channels_policy_head, use_wdl=wdlp, use_plys_to_end=wdlp,
-                      name="risev3.3" + ("-wdlp" if wdlp else ""))
-
-
-def eca_kernel(channels: int, gamma: int = 2, b: int = 1) -> int:
-    t = int(abs((math.log(channels, 2) + b) / gamma))
-    return t if t % 2 else t + 1
-
-
-# --------------------------------------------------------------------------------------------------------------
-# deterministic weights (numpy PCG64: identical on every machine; the reference has no trained weights in-tree)
-# --------------------------------------------------------------------------------------------------------------
-def make_state_dict(cfg: RiseConfig, seed: int = 0, stress: bool = True) -> Dict[str, torch.Tensor]:
-    """State dict with the reference's key names.
-
-    stress=True : variance-preserving weights + randomised BN statistics so that activations/logits are O(1)
-                  (torch's default init makes the residual branches vanish -> a 1e-3 test would be vacuous).
-    stress=False: mimic torch default init magnitudes (kaiming-uniform a=sqrt(5)), BN identity stats.
-    """
-    rng = np.random.default_rng(seed)
-    sd: Dict[str, torch.Tensor] = {}
-
-    def conv(name, cout, cin_per_group, k, gain=1.0):
-        fan_in = cin_per_group * k * k
-        if stress:
-            std = gain * math.sqrt(2.0 / fan_in)
-            w = rng.standard_normal((cout, cin_per_group, k, k)) * std
-        else:
-            bound = 1.0 / math.sqrt(fan_in)
-            w = rng.uniform(-bound, bound, (cout, cin_per_group, k, k))
-        sd[name + ".weight"] = torch.tensor(w, dtype=torch.float32)
-
-    def bn(name, c, out_scale=1.0):
-        if stress:
-            g = rng.uniform(0.6, 1.4, c) * out_scale
-            b = rng.normal(0, 0.15, c) * out_scale
-            m = rng.normal(0, 0.15, c)
-            v = rng.uniform(0.6, 1.6, c)
-        else:
-            g, b, m, v = np.ones(c), np.zeros(c), np.zeros(c), np.ones(c)
-        sd[name + ".weight"] = torch.tensor(g, dtype=torch.float32)
-        sd[name + ".bias"] = torch.tensor(b, dtype=torch.float32)
-        sd[name + ".running_mean"] = torch.tensor(m, dtype=torch.float32)
-        sd[name + ".running_var"] = torch.tensor(v, dtype=torch.float32)
-        sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.int64)
-
-    def linear(name, cout, cin, bias=True, gain=1.0):
-        if stress:
-            w = rng.standard_normal((cout, cin)) * gain * math.sqrt(2.0 / cin)
-            b = rng.normal(0, 0.1, cout)
-        else:
-            bound = 1.0 / math.sqrt(cin)
-            w = rng.uniform(-bound, bound, (cout, cin))
-            b = rng.uniform(-bound, bound, cout)
-        sd[name + ".weight"] = torch.tensor(w, dtype=torch.float32)
-        if bias:
-            sd[name + ".bias"] = torch.tensor(b, dtype=torch.float32)
-
-    C = cfg.channels
-    conv("body_spatial.0.body.0", C, cfg.nb_input_channels, 3, gain=2.0)
-    bn("body_spatial.0.body.1", C)
-    nblk = len(cfg.kernels)
-    for i, (k, cop, se) in enumerate(zip(cfg.kernels, cfg.channels_operating(), cfg.se_types)):
-        p = f"body_spatial.{i + 1}"
-        if se in ("ca_se", "se"):
-            linear(p + ".se.fc.0", C // 2, C, bias=False)
-            linear(p + ".se.fc.2", C, C // 2, bias=False, gain=2.0)
-        elif se == "eca_se":
-            kk = eca_kernel(C)
-            w = rng.standard_normal((C, C, kk)) * (2.0 * math.sqrt(2.0 / C) if stress else 1.0 / math.sqrt(C * kk))
-            sd[p + ".se.body.0.weight"] = torch.tensor(w, dtype=torch.float32)
-            sd[p + ".se.body.0.bias"] = torch.tensor(rng.normal(0, 0.5 if stress else 0.01, C), dtype=torch.float32)
-        conv(p + ".body.0", cop, C, 1)
-        bn(p + ".body.1", cop)
-        conv(p + ".body.3", cop, 1, k, gain=1.2)
-        bn(p + ".body.4", cop)
-        conv(p + ".body.6", C, cop, 1)
-        # keep the residual stream O(1) over many blocks
-        bn(p + ".body.7", C, out_scale=(1.0 / math.sqrt(nblk)) if stress else 1.0)
-    conv("policy_head.body.0", C, C, 3)
-    bn("policy_head.body.1", C)
-    conv("policy_head.body.3", cfg.channels_policy_head, C, 3, gain=1.0)
-    conv("value_head.body.0", cfg.channels_value_head, C, 1)
-    bn("value_head.body.1", cfg.channels_value_head)
-    nflat = 64 * cfg.channels_value_head
-    if cfg.use_wdl:
-        linear("value_head.body_wdl.0", 3, nflat, gain=0.7)
-    if cfg.use_plys_to_end:
-        linear("value_head.body_plys.0", 1, nflat, gain=0.7)
-    linear("value_head.body_final.0", cfg.value_fc_size, nflat)
-    linear("value_head.body_final.2", 1, cfg.value_fc_size, gain=0.5)
-    return sd
+from crazyara_amd.rise_config import (RiseConfig, rise_v2_config, rise_v33_config, eca_kernel,  # noqa: F401,E402
+                                      make_state_dict)
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -32,6 +32,33 @@ SIGNATURES = {
     "mi_net_time_forward": (C.c_int, [C.c_void_p, C.c_int, c_float_p]),
     "mi_net_op_count": (C.c_int, [C.c_void_p]),
     "mi_net_time_ops": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), c_float_p]),
+    "mi_net_submit_boards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # environment
+    "mi_pos_create": (C.c_void_p, [C.c_char_p, C.c_int, C.c_char_p]),
+    "mi_pos_clone": (C.c_void_p, [C.c_void_p]),
+    "mi_pos_destroy": (None, [C.c_void_p]),
+    "mi_pos_fen": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "mi_pos_side_to_move": (C.c_int, [C.c_void_p]),
+    "mi_pos_legal_moves": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
+    "mi_pos_uci_to_move": (C.c_uint32, [C.c_void_p, C.c_char_p]),
+    "mi_pos_move_to_uci": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int]),
+    "mi_pos_do_move": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "mi_pos_terminal": (C.c_int, [C.c_void_p]),
+    "mi_pos_number_repetitions": (C.c_int, [C.c_void_p]),
+    "mi_pos_perft": (C.c_ulonglong, [C.c_void_p, C.c_int]),
+    "mi_chess960_start_fen": (C.c_char_p, [C.c_int]),
+    # planes
+    "mi_planes_layout": (C.c_int, [C.c_int, C.c_int]),
+    "mi_planes_channels": (C.c_int, [C.c_int]),
+    "mi_pos_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mi_pos_desc": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi_planes_from_descs_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    # policy
+    "mi_policy_nb_labels": (C.c_int, [C.c_int]),
+    "mi_policy_nb_policy_map": (C.c_int, [C.c_int]),
+    "mi_policy_label": (C.c_char_p, [C.c_int, C.c_int, C.c_int]),
+    "mi_policy_flat_plane_idx": (C.c_int, [C.c_int, C.c_int]),
+    "mi_pos_policy_index": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
 }
 
 _lib = None

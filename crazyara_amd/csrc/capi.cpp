@@ -6,28 +6,18 @@
 #include <exception>
 #include <string>
 
+#include "capi_common.h"
 #include "nn/rise_net.h"
 
 namespace {
 thread_local std::string g_err;
-
-template <typename F> int guard(F&& f) {
-    try {
-        f();
-        return 0;
-    } catch (const std::exception& e) {
-        g_err = e.what();
-    } catch (...) {
-        g_err = "unknown error";
-    }
-    return 1;
-}
+template <typename F> int guard(F&& f) { return cra_guard(static_cast<F&&>(f)); }
 }  // namespace
 
-struct mi_net {
-    cra::RiseNet net;
-    mi_net(const char* dir, int dev, int batch, const char* prec) : net(dir ? dir : "", dev, batch, prec ? prec : "float16") {}
-};
+void cra_set_error(const std::string& msg) { g_err = msg; }
+const char* cra_get_error() { return g_err.c_str(); }
+
+#include "capi_net.h"
 
 extern "C" {
 
@@ -83,6 +73,10 @@ int mi_net_predict(mi_net* net, const float* in_planes, float* value, float* pro
 int mi_net_submit(mi_net* net, const float* in_planes, float* value, float* probs, float* aux) {
     if (!net || !in_planes || !value || !probs) { g_err = "null argument to mi_net_submit"; return 1; }
     return guard([&] { net->net.submit(in_planes, value, probs, aux); });
+}
+int mi_net_submit_boards(mi_net* net, const void* descs_host, int n_valid, int layout, float* value, float* probs, float* aux) {
+    if (!net || (!descs_host && n_valid > 0) || !value || !probs) { g_err = "null argument to mi_net_submit_boards"; return 1; }
+    return guard([&] { net->net.submit_boards(descs_host, n_valid, layout, value, probs, aux); });
 }
 int mi_net_wait(mi_net* net) {
     if (!net) { g_err = "null net"; return 1; }

@@ -1,0 +1,141 @@
+// C ABI: environment, input planes, policy map -- see include/crazyara_hip.h.
+#include "../../include/crazyara_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "capi_common.h"
+#include "chess/planes_host.h"
+#include "chess/policy.h"
+#include "chess/position.h"
+#include "nn/rise_net.h"
+
+using namespace cra;
+using namespace cra::chess;
+
+struct mi_pos {
+    Position pos;
+};
+
+namespace {
+int copy_out(const std::string& s, char* buf, int cap) {
+    if (!buf || cap <= int(s.size())) { cra_set_error("buffer too small"); return -1; }
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return int(s.size());
+}
+}  // namespace
+
+extern "C" {
+
+mi_pos* mi_pos_create(const char* fen, int is_chess960, const char* variant) {
+    mi_pos* p = nullptr;
+    if (cra_guard([&] {
+            const Variant v = variant_from_name(variant && *variant ? variant : "chess");
+            p = new mi_pos;
+            p->pos.set(fen && *fen ? std::string(fen) : start_fen(v), is_chess960 != 0, v);
+        })) {
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+mi_pos* mi_pos_clone(const mi_pos* pos) { return pos ? new mi_pos(*pos) : nullptr; }
+void mi_pos_destroy(mi_pos* pos) { delete pos; }
+int mi_pos_fen(const mi_pos* pos, char* buf, int cap) { return pos ? copy_out(pos->pos.fen(), buf, cap) : -1; }
+int mi_pos_side_to_move(const mi_pos* pos) { return pos ? int(pos->pos.side_to_move()) : -1; }
+int mi_pos_legal_moves(const mi_pos* pos, uint32_t* moves, int cap) {
+    if (!pos) return -1;
+    std::vector<Move> v;
+    pos->pos.legal_moves(v);
+    if (moves)
+        for (int i = 0; i < int(v.size()) && i < cap; ++i) moves[i] = v[i];
+    return int(v.size());
+}
+uint32_t mi_pos_uci_to_move(const mi_pos* pos, const char* uci) { return pos && uci ? pos->pos.uci_to_move(uci) : 0; }
+int mi_pos_move_to_uci(const mi_pos* pos, uint32_t move, char* buf, int cap) {
+    return pos ? copy_out(pos->pos.move_to_uci(move), buf, cap) : -1;
+}
+int mi_pos_do_move(mi_pos* pos, uint32_t move) {
+    if (!pos || !move) { cra_set_error("null position or move"); return 1; }
+    return cra_guard([&] { pos->pos.do_move(move); });
+}
+int mi_pos_terminal(const mi_pos* pos) {
+    if (!pos) return -1;
+    std::vector<Move> v;
+    pos->pos.legal_moves(v);
+    return int(pos->pos.is_terminal(v.size()));
+}
+int mi_pos_number_repetitions(const mi_pos* pos) { return pos ? pos->pos.number_repetitions() : -1; }
+unsigned long long mi_pos_perft(const mi_pos* pos, int depth) { return pos ? pos->pos.perft(depth) : 0; }
+const char* mi_chess960_start_fen(int idx) {
+    thread_local std::string s;
+    s = chess960_start_fen(idx);
+    return s.c_str();
+}
+
+int mi_planes_layout(int mode, int version_major) { return layout_for(mode, version_major); }
+int mi_planes_channels(int layout) { return layout_channels(layout); }
+int mi_pos_planes(const mi_pos* pos, int layout, int normalize, int repetitions, float* out) {
+    if (!pos || !out || layout_channels(layout) == 0) { cra_set_error("bad argument to mi_pos_planes"); return 1; }
+    board_to_planes(pos->pos, layout, normalize != 0, out, repetitions);
+    return 0;
+}
+int mi_pos_desc(const mi_pos* pos, void* desc192) {
+    if (!pos || !desc192) { cra_set_error("null argument"); return 1; }
+    pack_desc(pos->pos, *static_cast<BoardDesc*>(desc192));
+    return 0;
+}
+int mi_planes_from_descs_device(const void* descs_host, int n, int layout, int normalize, float* d_planes, int device_id) {
+    if (!descs_host || !d_planes || n <= 0 || layout_channels(layout) == 0) { cra_set_error("bad argument"); return 1; }
+    return cra_guard([&] {
+        auto ck = [](hipError_t e, const char* what) {
+            if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+        };
+        ck(hipSetDevice(device_id), "hipSetDevice");
+        void* d = nullptr;
+        ck(hipMalloc(&d, size_t(n) * sizeof(BoardDesc)), "hipMalloc");
+        hipError_t e = hipMemcpy(d, descs_host, size_t(n) * sizeof(BoardDesc), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            launch_planes_from_desc(static_cast<const BoardDesc*>(d), n, layout, normalize, d_planes, nullptr);
+            e = hipDeviceSynchronize();
+        }
+        (void)hipFree(d);
+        ck(e, "planes_from_desc");
+    });
+}
+
+int mi_policy_nb_labels(int mode) {
+    int n = -1;
+    cra_guard([&] { n = policy_tables(mode).nb_labels(); });
+    return n;
+}
+int mi_policy_nb_policy_map(int mode) {
+    int n = -1;
+    cra_guard([&] { n = policy_tables(mode).nb_policy_map(); });
+    return n;
+}
+const char* mi_policy_label(int mode, int idx, int mirrored) {
+    const char* r = nullptr;
+    cra_guard([&] {
+        const PolicyTables& t = policy_tables(mode);
+        r = (mirrored ? t.labels_mirrored : t.labels).at(idx).c_str();
+    });
+    return r;
+}
+int mi_policy_flat_plane_idx(int mode, int idx) {
+    int n = -1;
+    cra_guard([&] { n = policy_tables(mode).flat_plane_idx.at(idx); });
+    return n;
+}
+int mi_pos_policy_index(const mi_pos* pos, uint32_t move, int mode, int is_policy_map) {
+    int n = -1;
+    if (!pos) return n;
+    cra_guard([&] { n = policy_index(policy_tables(mode), pos->pos, move, is_policy_map != 0); });
+    return n;
+}
+
+}  // extern "C"

@@ -46,6 +46,8 @@ public:
     // wait() blocks until results are in the host buffers.  Host buffers should come from mi_host_alloc (pinned).
     void submit(const float* in_planes, float* value, float* probs, float* aux);
     void wait();
+    // descriptor-fed variant: 192-byte BoardDesc per position, planes expanded on the GPU (csrc/chess/planes_kernel.hip)
+    void submit_boards(const void* descs_host, int n_valid, int layout, float* value, float* probs, float* aux);
 
     // Device-resident path: the captured forward reads d_planes() and writes d_value()/d_probs()/d_aux()/d_logits().
     float* d_planes() const { return d_planes_; }     // [B][C][64] float (NCHW, as predict() takes it)
@@ -78,6 +80,7 @@ private:
     hipStream_t stream_ = nullptr;
     hipGraph_t graph_ = nullptr;
     hipGraphExec_t graph_exec_ = nullptr;
+    void* d_desc_ = nullptr;
     float *d_planes_ = nullptr, *d_value_ = nullptr, *d_probs_ = nullptr, *d_logits_ = nullptr, *d_aux_ = nullptr;
     std::unique_ptr<Impl> impl_;
 };

@@ -5,6 +5,7 @@
 #include <stdexcept>
 
 #include "kernels.h"
+#include "../chess/planes_host.h"
 
 namespace cra {
 
@@ -191,6 +192,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     }
 
     // ---- device buffers ----
+    d_desc_ = im.dalloc(size_t(B) * sizeof(BoardDesc));
     d_planes_ = static_cast<float*>(im.dalloc(size_t(B) * cin * kSquares * sizeof(float)));
     d_value_ = static_cast<float*>(im.dalloc(size_t(B) * sizeof(float)));
     d_probs_ = static_cast<float*>(im.dalloc(size_t(B) * design_.nb_policy * sizeof(float)));
@@ -437,6 +439,23 @@ void RiseNet::submit(const float* in_planes, float* value, float* probs, float* 
     HIP_CHECK(hipSetDevice(device_));   // every predict selects its device, tensorrtapi.cpp:198
     const size_t B = design_.batch;
     HIP_CHECK(hipMemcpyAsync(d_planes_, in_planes, B * design_.nb_input_channels * kSquares * sizeof(float), hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
+    HIP_CHECK(hipMemcpyAsync(value, d_value_, B * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(probs, d_probs_, B * design_.nb_policy * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (d_aux_ && aux) HIP_CHECK(hipMemcpyAsync(aux, d_aux_, B * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+}
+
+void RiseNet::submit_boards(const void* descs_host, int n_valid, int layout, float* value, float* probs, float* aux) {
+    HIP_CHECK(hipSetDevice(device_));
+    const size_t B = design_.batch;
+    if (n_valid < 0 || size_t(n_valid) > B) throw std::invalid_argument("n_valid out of range");
+    if (layout_channels(layout) != design_.nb_input_channels)
+        throw std::invalid_argument("plane layout has " + std::to_string(layout_channels(layout)) + " channels, net expects " +
+                                    std::to_string(design_.nb_input_channels));
+    if (n_valid > 0) {
+        HIP_CHECK(hipMemcpyAsync(d_desc_, descs_host, size_t(n_valid) * sizeof(BoardDesc), hipMemcpyHostToDevice, stream_));
+        launch_planes_from_desc(static_cast<const BoardDesc*>(d_desc_), n_valid, layout, 1, d_planes_, stream_);
+    }
     HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
     HIP_CHECK(hipMemcpyAsync(value, d_value_, B * sizeof(float), hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipMemcpyAsync(probs, d_probs_, B * design_.nb_policy * sizeof(float), hipMemcpyDeviceToHost, stream_));

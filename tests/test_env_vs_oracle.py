@@ -1,0 +1,120 @@
+"""Product environment (C++ Position / planes / policy map through the C ABI, CPU only) vs the oracle and the
+reference goldens.  Bit-exact: FEN strings, legal-move sets, plane tensors, policy indices."""
+import ctypes as C
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from crazyara_amd import env
+from oracle import chess_oracle as co
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "planes_goldens.json")))
+TABLES = np.load(os.path.join(os.path.dirname(__file__), "golden", "policy_tables.npz"))
+TERM = {"loss": 0, "draw": 1, "win": 2, "none": 4}
+
+
+def position_for(case):
+    p = env.Position(case["fen"], case.get("is960", False), case["variant"])
+    for m in case["moves"]:
+        assert p.push_uci(m), m
+    return p
+
+
+@pytest.mark.parametrize("case", [c for c in G["cases"] if not c.get("unchecked_moves")], ids=lambda c: c["src"])
+def test_product_planes_match_reference_goldens_and_oracle(case, hip_lib):
+    p = position_for(case)
+    x = p.planes(case["mode"], case["version"], case["normalize"])
+    b = co.Board(case["fen"] or None, case.get("is960", False), case["variant"])
+    for m in case["moves"]:
+        b.push_uci(m)
+    xo = co.board_to_planes(b, case["mode"], case["version"], case["normalize"])
+    assert x.shape == xo.shape and np.array_equal(x, xo)          # bit-exact, normalised planes included
+    s, mx, key, arg = co.plane_statistics(x)
+    if "rel" not in case and "sum_range" not in case:
+        assert (s, mx, key) == (case["sum"], case["max"], case["key"])
+        if case["argmax"] is not None:
+            assert arg == case["argmax"]
+    if "fen_after" in case:
+        assert p.fen() == case["fen_after"]
+
+
+@pytest.mark.parametrize("case", G["rules"], ids=lambda c: c["src"])
+def test_product_rules_match_reference_tests(case, hip_lib):
+    p = position_for(case)
+    if "fen_after" in case:
+        assert p.fen() == case["fen_after"]
+    legal = set(p.legal_uci())
+    for m in case.get("legal", []):
+        assert m in legal
+    for m in case.get("illegal", []):
+        assert m not in legal
+    if "terminal" in case:
+        assert p.terminal() == TERM[case["terminal"]]
+
+
+@pytest.mark.parametrize("case", G["perft"] + G["perft_deep"], ids=lambda c: f'{c["variant"]}-{c["fen"][:20]}-d{c["depth"]}')
+def test_product_perft_published_counts(case, hip_lib):
+    p = env.Position(case["fen"], case.get("is960", False), case["variant"])
+    assert p.perft(case["depth"]) == case["nodes"]
+
+
+@pytest.mark.parametrize("mode,name", [(0, "crazyhouse"), (2, "lichess"), (1, "chess")])
+def test_product_labels_and_flat_plane_idx_equal_reference_tables(mode, name, hip_lib):
+    labels, mirrored, flat = env.policy_tables(mode)
+    assert labels == [str(s) for s in TABLES[f"labels_{name}"]]
+    assert flat == [int(v) for v in TABLES[f"flat_{name}"]]
+    assert mirrored == [co.mirror_label(l) for l in labels]
+
+
+PLAYOUTS = [
+    # (variant, is960, fen, mode, versions, n games, max plies)
+    ("crazyhouse", False, "", 0, (1, 2, 3), 6, 90),
+    ("chess", False, "", 1, (1, 3), 4, 80),
+    ("chess", True, "bnnrkbrq/pppppppp/8/8/8/8/PPPPPPPP/BNNRKBRQ w GDgd - 0 1", 1, (3,), 3, 70),
+    ("chess", True, "nrbbqnkr/pppppppp/8/8/8/8/PPPPPPPP/NRBBQNKR w HBhb - 0 1", 1, (3,), 2, 60),
+    ("3check", False, "", 2, (2, 3), 3, 70),
+    ("kingofthehill", False, "", 2, (2, 3), 3, 70),
+    ("crazyhouse", False, "", 2, (2, 3), 2, 70),
+]
+
+
+@pytest.mark.parametrize("variant,is960,fen,mode,versions,games,plies", PLAYOUTS)
+def test_random_playouts_bit_exact_against_oracle(variant, is960, fen, mode, versions, games, plies, hip_lib):
+    """Seeded random games: at every ply the legal-move set (as UCI strings), FEN, terminal type, every plane layout and
+    the policy index of every legal move must equal the oracle's."""
+    rng = random.Random(hash((variant, is960, fen)) & 0xFFFF)
+    pm = co.PolicyMap(mode)
+    for g in range(games):
+        p = env.Position(fen, is960, variant)
+        b = co.Board(fen or None, is960, variant)
+        for ply in range(plies):
+            moves = b.legal_moves()
+            ucis = sorted(b.move_uci(m) for m in moves)
+            assert p.legal_uci() == ucis, (b.fen(), ply)
+            assert p.fen() == b.fen()
+            assert p.terminal() == b.terminal()
+            if p.terminal() != 4 or not moves:
+                break
+            for v in versions:
+                for norm in (True, False):
+                    assert np.array_equal(p.planes(mode, v, norm), co.board_to_planes(b, mode, v, norm)), (b.fen(), v, norm)
+            for m in moves:
+                u = b.move_uci(m)
+                for is_map in (True, False):
+                    assert p.policy_index(u, mode, is_map) == pm.index(b, m, is_map), (b.fen(), u)
+            mv = rng.choice(moves)
+            assert p.push_uci(b.move_uci(mv))
+            b.push(mv)
+
+
+def test_descriptor_is_192_bytes_and_round_trips(hip_lib):
+    p = env.Position("5r2/ppp2pkp/3p4/2bP4/2Pnp1N1/3P2pP/PP2n1P1/R2Q1R1K[PBRQnbb] w - - 0 28", False, "crazyhouse")
+    for m in ("Q@f6", "g7g8", "R@h8"):
+        p.push_uci(m)
+    d = p.desc()
+    assert len(d) == 192
+    bb = np.frombuffer(d, dtype=np.uint64, count=14)
+    assert bin(int(bb[0])).count("1") == 7 and int(d[122]) == 1   # 7 white pawns on board; black to move

@@ -111,3 +111,72 @@ def test_constructor_errors(tmp_path, hip_lib):
     net = HipAPI(0, 4, d, "float16")
     assert net.get_version() == 1000000 and net.get_model_name().endswith("-v1.0.cranet")
     net.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU input-plane builder (csrc/chess/planes_kernel.hip) -- bit-exact against the oracle planes
+# ---------------------------------------------------------------------------------------------------------------------
+def _random_positions(variant, is960, fen, n, seed):
+    import random
+    from crazyara_amd import env
+    from oracle import chess_oracle as co
+    rng = random.Random(seed)
+    out = []
+    while len(out) < n:
+        p = env.Position(fen, is960, variant)
+        b = co.Board(fen or None, is960, variant)
+        for ply in range(rng.randint(0, 60)):
+            moves = b.legal_moves()
+            if not moves or b.terminal() != 4:
+                break
+            mv = rng.choice(moves)
+            p.push_uci(b.move_uci(mv))
+            b.push(mv)
+        out.append((p, b))
+    return out
+
+
+@pytest.mark.parametrize("variant,is960,fen,mode,version", [
+    ("crazyhouse", False, "", 0, 1), ("crazyhouse", False, "", 0, 2), ("crazyhouse", False, "", 0, 3),
+    ("chess", False, "", 1, 1), ("chess", False, "", 1, 3),
+    ("chess", True, "bnnrkbrq/pppppppp/8/8/8/8/PPPPPPPP/BNNRKBRQ w GDgd - 0 1", 1, 3),
+    ("3check", False, "", 2, 2), ("kingofthehill", False, "", 2, 3), ("crazyhouse", False, "", 2, 3),
+])
+def test_gpu_plane_builder_bit_exact(hip_lib, variant, is960, fen, mode, version):
+    from crazyara_amd import env, _capi
+    from oracle import chess_oracle as co
+    lib = _capi.load()
+    pos = _random_positions(variant, is960, fen, 24, seed=hash((variant, mode, version)) & 0xFFF)
+    layout = lib.mi_planes_layout(mode, version)
+    C_ = lib.mi_planes_channels(layout)
+    descs = b"".join(p.desc() for p, _ in pos)
+    for normalize in (True, False):
+        out = torch.empty((len(pos), C_, 8, 8), dtype=torch.float32, device="cuda")
+        env.planes_from_descs_device(descs, len(pos), layout, normalize, out.data_ptr(), 0)
+        got = out.cpu().numpy()
+        for i, (p, b) in enumerate(pos):
+            exp = co.board_to_planes(b, mode, version, normalize)
+            assert np.array_equal(got[i], exp), (b.fen(), normalize)
+
+
+def test_predict_from_board_descriptors_equals_predict_from_planes(tmp_path, hip_lib):
+    """mi_net_submit_boards (192 B/position over PCIe, planes built on the GPU) == predict() on host-built planes."""
+    import ctypes as C
+    from crazyara_amd import _capi
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, x = nn_cases.make_case("risev2-3")
+    d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
+    pos = _random_positions("crazyhouse", False, "", 8, seed=3)
+    net = HipAPI(0, 8, d, "float16")
+    planes = np.stack([p.planes(0, 1, True) for p, _ in pos]).astype(np.float32)
+    v1, p1 = np.zeros(8, np.float32), np.zeros(8 * 5184, np.float32)
+    net.predict(planes, v1, p1)
+    descs = b"".join(p.desc() for p, _ in pos)
+    v2, p2 = np.zeros(8, np.float32), np.zeros(8 * 5184, np.float32)
+    lib = _capi.load()
+    assert lib.mi_net_submit_boards(net._h, descs, 8, lib.mi_planes_layout(0, 1), v2.ctypes.data, p2.ctypes.data, None) == 0
+    net.wait()
+    assert np.array_equal(v1, v2) and np.array_equal(p1, p2)
+    # wrong layout for this net is rejected loudly
+    assert lib.mi_net_submit_boards(net._h, descs, 8, lib.mi_planes_layout(0, 3), v2.ctypes.data, p2.ctypes.data, None) != 0
+    net.close()

@@ -59,6 +59,15 @@ SIGNATURES = {
     "mi_policy_label": (C.c_char_p, [C.c_int, C.c_int, C.c_int]),
     "mi_policy_flat_plane_idx": (C.c_int, [C.c_int, C.c_int]),
     "mi_pos_policy_index": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
+    # search
+    "mi_search_default_settings": (None, [C.c_void_p]),
+    "mi_search_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "mi_search_destroy": (None, [C.c_void_p]),
+    "mi_search_add_position": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p]),
+    "mi_search_run": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_void_p]),
+    "mi_search_root_children": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), c_float_p, c_float_p]),
+    "mi_search_tree_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), c_float_p]),
+    "mi_search_best_move": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
 }
 
 _lib = None

@@ -1,0 +1,149 @@
+// C ABI: MCTS search pool -- see include/crazyara_hip.h.
+#include "../../include/crazyara_hip.h"
+
+#include <cstring>
+#include <string>
+
+#include "capi_common.h"
+#include "capi_net.h"
+#include "search/pool.h"
+
+using namespace cra;
+using namespace cra::search;
+
+struct mi_search {
+    std::unique_ptr<SearchPool> pool;
+};
+
+namespace {
+SearchSettings convert(const mi_search_settings& m) {
+    SearchSettings s;
+    s.batch_size = m.batch_size;
+    s.cpuct_init = m.cpuct_init;
+    s.cpuct_base = m.cpuct_base;
+    s.node_policy_temperature = m.node_policy_temperature;
+    s.virtual_style = m.virtual_style;
+    s.virtual_mix_threshold = m.virtual_mix_threshold;
+    s.virtual_offset_strength = m.virtual_offset_strength;
+    s.q_value_weight = m.q_value_weight;
+    s.q_veto_delta = m.q_veto_delta;
+    s.mode = m.mode;
+    s.version_major = m.version_major;
+    s.is_policy_map = m.is_policy_map != 0;
+    s.clone_keeps_last_moves = m.clone_keeps_last_moves;
+    return s;
+}
+}  // namespace
+
+extern "C" {
+
+void mi_search_default_settings(mi_search_settings* m) {
+    if (!m) return;
+    const SearchSettings s;
+    m->batch_size = s.batch_size;
+    m->cpuct_init = s.cpuct_init;
+    m->cpuct_base = s.cpuct_base;
+    m->node_policy_temperature = s.node_policy_temperature;
+    m->virtual_style = s.virtual_style;
+    m->virtual_mix_threshold = s.virtual_mix_threshold;
+    m->virtual_offset_strength = s.virtual_offset_strength;
+    m->q_value_weight = s.q_value_weight;
+    m->q_veto_delta = s.q_veto_delta;
+    m->mode = s.mode;
+    m->version_major = s.version_major;
+    m->is_policy_map = s.is_policy_map ? 1 : 0;
+    m->clone_keeps_last_moves = s.clone_keeps_last_moves;
+}
+
+mi_search* mi_search_create(const mi_search_settings* s, mi_net* net_a, mi_net* net_b, mi_eval_fn fn, void* user, int fn_batch, int fn_nb_policy) {
+    mi_search* h = nullptr;
+    if (cra_guard([&] {
+            if (!s) throw std::invalid_argument("null settings");
+            std::unique_ptr<Evaluator> a, b;
+            if (fn) {
+                if (fn_batch <= 0 || fn_nb_policy <= 0) throw std::invalid_argument("callback lane needs batch and nb_policy");
+                a = make_callback_evaluator(fn, user, fn_batch, fn_nb_policy);
+            } else {
+                if (!net_a) throw std::invalid_argument("mi_search_create needs a net or an evaluator callback");
+                a = make_hip_evaluator(&net_a->net);
+                if (net_b) b = make_hip_evaluator(&net_b->net);
+            }
+            h = new mi_search;
+            h->pool.reset(new SearchPool(convert(*s), std::move(a), std::move(b)));
+        })) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+void mi_search_destroy(mi_search* sp) { delete sp; }
+
+int mi_search_add_position(mi_search* sp, const char* fen, int is_chess960, const char* variant) {
+    int id = -1;
+    if (!sp) return id;
+    cra_guard([&] {
+        const chess::Variant v = chess::variant_from_name(variant && *variant ? variant : "chess");
+        chess::Position p;
+        p.set(fen && *fen ? std::string(fen) : chess::start_fen(v), is_chess960 != 0, v);
+        id = sp->pool->add_position(p);
+    });
+    return id;
+}
+
+int mi_search_run(mi_search* sp, unsigned simulations, unsigned nodes, int threads, mi_search_stats* stats) {
+    if (!sp) { cra_set_error("null search"); return 1; }
+    return cra_guard([&] {
+        SearchStats st;
+        sp->pool->run(simulations, nodes, threads, &st);
+        if (stats) {
+            stats->nodes = st.nodes;
+            stats->nn_evals = st.nn_evals;
+            stats->batches = st.batches;
+            stats->simulations = st.simulations;
+            stats->seconds = st.seconds;
+            stats->depth_avg = st.depth_avg;
+            stats->depth_max = st.depth_max;
+        }
+    });
+}
+
+int mi_search_root_children(mi_search* sp, int tree, int cap, uint32_t* moves, uint32_t* visits, float* q, float* priors) {
+    int n = -1;
+    if (!sp) return n;
+    cra_guard([&] {
+        const Node& r = sp->pool->tree(tree).root();
+        n = r.has_data ? int(r.child_visits.size()) : 0;
+        for (int i = 0; i < n && i < cap; ++i) {
+            if (moves) moves[i] = r.actions[i];
+            if (visits) visits[i] = r.child_visits[i];
+            if (q) q[i] = r.q[i];
+            if (priors) priors[i] = r.priors[i];
+        }
+    });
+    return n;
+}
+
+int mi_search_tree_info(mi_search* sp, int tree, unsigned* root_visits, unsigned* node_count, unsigned* allocated_nodes, float* root_value) {
+    if (!sp) { cra_set_error("null search"); return 1; }
+    return cra_guard([&] {
+        Tree& t = sp->pool->tree(tree);
+        if (root_visits) *root_visits = t.root_visits();
+        if (node_count) *node_count = t.node_count();
+        if (allocated_nodes) *allocated_nodes = unsigned(t.node_count_allocated());
+        if (root_value) *root_value = t.root().real_visits ? t.root().value() : 0.0f;
+    });
+}
+
+int mi_search_best_move(mi_search* sp, int tree, char* uci, int cap) {
+    if (!sp || !uci) { cra_set_error("null argument"); return 1; }
+    return cra_guard([&] {
+        Tree& t = sp->pool->tree(tree);
+        const int b = t.best_move_index();
+        const std::string s = b < 0 ? "(none)" : t.root_position().move_to_uci(t.root().actions[b]);
+        if (int(s.size()) >= cap) throw std::invalid_argument("buffer too small");
+        std::memcpy(uci, s.c_str(), s.size() + 1);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+#include "mcts.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+#include <stdexcept>
+
+#include "../chess/planes_host.h"
+
+namespace cra {
+namespace search {
+
+using chess::Move;
+using chess::Position;
+
+constexpr float Q_INIT = -1.0f;                 // constants.h:85
+constexpr float LOSS_VALUE = -1.0f, DRAW_VALUE = 0.0f, WIN_VALUE = 1.0f;   // constants.h:78-80
+constexpr int TERMINAL_NODE_CACHE_FACTOR = 2;   // SearchThread: terminalNodeCache = 2 * batchSize
+
+float get_current_cput(float visits, const SearchSettings& s) {
+    return std::log((visits + s.cpuct_base + 1) / s.cpuct_base) + s.cpuct_init;
+}
+
+VirtualStyle get_virtual_style(const SearchSettings& s, uint32_t visits) {
+    if (s.virtual_style == VIRTUAL_MIX) return visits > s.virtual_mix_threshold ? VIRTUAL_LOSS : VIRTUAL_VISIT;
+    return VirtualStyle(s.virtual_style);
+}
+
+Tree::Tree(const Position& root, const SearchSettings& settings) : s_(settings), root_pos_(root) {
+    if (s_.epsilon_greedy_counter || s_.epsilon_checks_counter)
+        throw std::invalid_argument("epsilon-greedy / epsilon-checks exploration is not restated yet; set the counters to 0");
+    tables_ = &chess::policy_tables(s_.mode);
+    layout_ = layout_for(s_.mode, s_.version_major);
+    keep_last_moves_ = s_.clone_keeps_last_moves < 0 ? s_.mode != MODE_CRAZYHOUSE : s_.clone_keeps_last_moves != 0;
+    nodes_.reserve(4096);
+    new_node(root_pos_);
+}
+
+// Node::Node + check_for_terminal (node.cpp:82-106, 880-904)
+int Tree::new_node(const Position& pos) {
+    nodes_.emplace_back();
+    Node& n = nodes_.back();
+    pos.legal_moves(n.actions);
+    n.plies = uint16_t(pos.game_ply());
+    n.stm = uint8_t(pos.side_to_move());
+    const chess::TerminalType tt = pos.is_terminal(n.actions.size());
+    if (tt != chess::TERMINAL_NONE) {
+        n.terminal = true;           // mark_as_terminal: NodeData with noVisitIdx = 0, sorted
+        n.has_data = true;
+        n.sorted = true;
+        n.no_visit_idx = 0;
+        switch (tt) {
+            case chess::TERMINAL_WIN: n.set_value(WIN_VALUE); n.node_type = NT_WIN; break;
+            case chess::TERMINAL_DRAW: n.set_value(DRAW_VALUE); n.node_type = NT_DRAW; n.actions.clear(); break;
+            case chess::TERMINAL_LOSS: n.set_value(LOSS_VALUE); n.node_type = NT_LOSS; break;
+            default: break;
+        }
+    }
+    n.priors.assign(n.actions.size(), 0.0f);
+    if (!n.terminal) {
+        n.policy_idx.resize(n.actions.size());
+        for (size_t i = 0; i < n.actions.size(); ++i) {
+            const int idx = chess::policy_index(*tables_, pos, n.actions[i], s_.is_policy_map);
+            if (idx < 0) throw std::logic_error("legal move without a policy label: " + pos.move_to_uci(n.actions[i]));
+            n.policy_idx[i] = uint16_t(idx);
+        }
+    }
+    return int(nodes_.size()) - 1;
+}
+
+void Tree::root_desc(BoardDesc& d) const { chess::pack_desc(root_pos_, d); }
+
+// fill_nn_results (searchthread.cpp:290-299): gather priors, temperature, value
+void Tree::fill_nn_result(Node& n, float value, const float* probs) {
+    for (size_t i = 0; i < n.actions.size(); ++i) n.priors[i] = probs[n.policy_idx[i]];   // set_probabilities_for_moves, node.cpp:961-979
+    std::vector<uint16_t>().swap(n.policy_idx);
+    const float t = s_.node_policy_temperature;                                           // apply_temperature, blazeutil.h:77-87
+    if (t != 1) {
+        const float e = 1.0f / t;
+        float sum = 0.0f;
+        for (float& p : n.priors) { p = std::pow(p, e); sum += p; }
+        for (float& p : n.priors) p /= sum;
+    }
+    n.set_value(value);                                                                   // node_assign_value, searchthread.cpp:475-489
+    n.has_nn = true;
+}
+
+void Tree::set_root_result(float value, const float* probs) {
+    fill_nn_result(nodes_[0], value, probs);
+    prepare_node_for_visits(nodes_[0]);                                                   // mctsagent.cpp:195
+}
+
+// sort_moves_by_probabilities + init_node_data (node.cpp:464-470, 634-643, nodedata.cpp:40-57).
+// The reference uses an unstable std::sort with greater<float>; ties are broken by the original index here.
+void Tree::prepare_node_for_visits(Node& n) {
+    std::vector<int> perm(n.actions.size());
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return n.priors[a] > n.priors[b]; });
+    std::vector<Move> a2(n.actions.size());
+    std::vector<float> p2(n.priors.size());
+    for (size_t i = 0; i < perm.size(); ++i) { a2[i] = n.actions[perm[i]]; p2[i] = n.priors[perm[i]]; }
+    n.actions.swap(a2);
+    n.priors.swap(p2);
+    n.sorted = true;
+    if (!n.has_data) {
+        n.has_data = true;
+        n.no_visit_idx = 1;
+        n.child_visits.assign(1, 0u);
+        n.q.assign(1, Q_INIT);
+        n.child.assign(1, -1);
+        n.vl.assign(1, 0);
+    }
+}
+
+void Tree::increment_no_visit_idx(Node& n) {                                              // node.cpp:571-580
+    if (n.no_visit_idx < n.actions.size()) {
+        ++n.no_visit_idx;
+        n.child_visits.push_back(0u);
+        n.q.push_back(Q_INIT);
+        n.child.push_back(-1);
+        n.vl.push_back(0);
+    }
+}
+
+// Node::select_child_node + get_current_u_values (node.cpp:1056-1063, 1150-1167):
+//   argmax_i<noVisitIdx ( Q_i + float( double(cpuct * P_i) * (sqrt(double(N)) / (n_i + 1.0)) ) ), first maximum wins.
+int Tree::select_child(Node& n) {
+    if (!n.sorted) prepare_node_for_visits(n);
+    if (n.no_visit_idx == 1) return 0;
+    const float cpuct = get_current_cput(float(n.visit_sum), s_);
+    const double sq = std::sqrt(double(n.visit_sum));
+    int best = 0;
+    float best_v = -std::numeric_limits<float>::infinity();
+    for (int i = 0; i < int(n.no_visit_idx); ++i) {
+        const float u = float(double(cpuct * n.priors[i]) * (sq / (double(n.child_visits[i]) + 1.0)));
+        const float v = n.q[i] + u;
+        if (v > best_v) { best_v = v; best = i; }
+    }
+    return best;
+}
+
+void Tree::apply_virtual_loss(Node& n, int c) {                                           // node.cpp:507-529
+    switch (get_virtual_style(s_, n.child_visits[c])) {
+        case VIRTUAL_LOSS: n.q[c] = float((double(n.q[c]) * n.child_visits[c] - 1) / double(n.child_visits[c] + 1)); break;
+        case VIRTUAL_OFFSET: n.q[c] = float(n.q[c] - s_.virtual_offset_strength); break;
+        default: break;
+    }
+    ++n.child_visits[c];
+    ++n.visit_sum;
+    ++n.vl[c];
+}
+
+void Tree::revert_virtual_loss(Node& n, int c) {                                          // node.cpp:661-679
+    switch (get_virtual_style(s_, n.child_visits[c])) {
+        case VIRTUAL_LOSS: n.q[c] = float((double(n.q[c]) * n.child_visits[c] + 1) / (n.child_visits[c] - 1)); break;
+        case VIRTUAL_OFFSET: n.q[c] = float(n.q[c] + s_.virtual_offset_strength); break;
+        default: break;
+    }
+    --n.child_visits[c];
+    --n.visit_sum;
+    --n.vl[c];
+}
+
+void Tree::revert_virtual_loss_and_update(Node& n, int c, float value, bool free_backup) {   // node.h:199-246
+    n.value_sum += value;
+    ++n.real_visits;
+    if (n.child_visits[c] == 1) {
+        n.q[c] = value;
+    } else {
+        switch (get_virtual_style(s_, n.child_visits[c])) {
+            case VIRTUAL_LOSS: n.q[c] = float((double(n.q[c]) * n.child_visits[c] + 1 + value) / n.child_visits[c]); break;
+            case VIRTUAL_VISIT: {
+                const uint32_t r = n.real_child_visits(c);
+                n.q[c] = float((double(n.q[c]) * r + value) / (r + 1));
+                break;
+            }
+            case VIRTUAL_OFFSET: {
+                // (the reference reads childRealVisit uninitialised in this branch, node.h:228-231; real visits are meant)
+                const uint32_t r = n.real_child_visits(c);
+                double nq = double(n.q[c]) + n.vl[c] * s_.virtual_offset_strength;
+                nq = (nq * r + value) / (r + 1.0);
+                n.q[c] = float(nq - ((n.vl[c] - 1) * s_.virtual_offset_strength));
+                break;
+            }
+            default: break;
+        }
+    }
+    --n.vl[c];
+    if (free_backup) ++n.free_visits;
+}
+
+// backup_value<freeBackup> (node.h:819-843) for trees (no transposition nodes: targetQValue stays 0)
+void Tree::backup_value(float value, const Trajectory& t, bool free_backup) {
+    for (auto it = t.rbegin(); it != t.rend(); ++it) {
+        value = -value;                                                                   // MODE_TWO_PLAYER
+        revert_virtual_loss_and_update(nodes_[it->node], it->child_idx, value, free_backup);
+    }
+}
+
+// SearchThread::get_new_child_to_evaluate (searchthread.cpp:164-271), tree variant (useMCGS = false)
+int Tree::get_new_child_to_evaluate(NodeBackup& type, uint32_t& depth, BoardDesc* desc_out) {
+    depth = 0;
+    int cur = 0;
+    Position pos(root_pos_);                     // rootState->clone()
+    if (!keep_last_moves_) pos.clear_last_moves();
+    while (true) {
+        const int c = select_child(nodes_[cur]);
+        apply_virtual_loss(nodes_[cur], c);
+        trajectory_buffer_.push_back(NodeAndIdx{cur, uint16_t(c)});
+        const int next = nodes_[cur].child[c];
+        ++depth;
+        if (next < 0) {
+            pos.do_move(nodes_[cur].actions[c]);
+            increment_no_visit_idx(nodes_[cur]);
+            const int nn = new_node(pos);        // may reallocate nodes_: no references held across this call
+            nodes_[cur].child[c] = nn;
+            if (nodes_[nn].terminal) {           // SearchThread::add_new_node_to_tree, searchthread.cpp:93-96
+                type = NODE_TERMINAL;
+                return nn;
+            }
+            chess::pack_desc(pos, *desc_out);    // newState->get_state_planes(true, ...), searchthread.cpp:229
+            type = NODE_NEW_NODE;
+            return nn;
+        }
+        if (nodes_[next].terminal) { type = NODE_TERMINAL; return next; }
+        if (!nodes_[next].has_nn) { type = NODE_COLLISION; return next; }
+        pos.do_move(nodes_[cur].actions[c]);     // actionsBuffer replay, done incrementally
+        cur = next;
+    }
+}
+
+int Tree::collect(int quota, BoardDesc* descs) {
+    size_t num_terminal = 0;
+    const size_t terminal_cache = size_t(TERMINAL_NODE_CACHE_FACTOR) * size_t(std::max(quota, 1));
+    int n_new = 0;
+    if (nodes_[0].terminal || !nodes_[0].has_nn) return 0;
+    while (n_new < quota && collision_trajectories_.size() != size_t(quota) && num_terminal < terminal_cache) {
+        trajectory_buffer_.clear();
+        NodeBackup type;
+        uint32_t depth;
+        const int leaf = get_new_child_to_evaluate(type, depth, descs + n_new);
+        depth_sum += depth;
+        depth_max = std::max(depth_max, depth);
+        if (type == NODE_TERMINAL) {
+            ++num_terminal;
+            backup_value(nodes_[leaf].value(), trajectory_buffer_, true);   // backup_value<true>: terminal visits are free (searchthread.cpp:364-367)
+        } else if (type == NODE_COLLISION) {
+            collision_trajectories_.push_back(trajectory_buffer_);
+        } else {
+            new_nodes_.push_back(leaf);
+            new_trajectories_.push_back(trajectory_buffer_);
+            ++n_new;
+        }
+    }
+    return n_new;
+}
+
+void Tree::finish_batch(const float* values, const float* probs, int nb_policy) {
+    for (size_t i = 0; i < new_nodes_.size(); ++i) fill_nn_result(nodes_[new_nodes_[i]], values[i], probs + i * size_t(nb_policy));
+    for (size_t i = 0; i < new_nodes_.size(); ++i) backup_value(nodes_[new_nodes_[i]].value(), new_trajectories_[i], false);
+    new_nodes_.clear();
+    new_trajectories_.clear();
+    for (const Trajectory& t : collision_trajectories_)                                   // backup_collision, node.cpp:655-659
+        for (auto it = t.rbegin(); it != t.rend(); ++it) revert_virtual_loss(nodes_[it->node], it->child_idx);
+    collision_trajectories_.clear();
+}
+
+// Node::get_mcts_policy (node.cpp:1070-1109) for an UNSOLVED root without solved children
+int Tree::best_move_index(std::vector<double>* policy_out) const {
+    const Node& n = nodes_[0];
+    if (!n.has_data || n.no_visit_idx == 0) return -1;
+    const int m = n.no_visit_idx;
+    std::vector<double> pol(m);
+    for (int i = 0; i < m; ++i) pol[i] = n.child_visits[i];
+    int best_q = 0;
+    for (int i = 1; i < m; ++i) if (n.q[i] > n.q[best_q]) best_q = i;
+    // first_and_second_max (blazeutil.h:155-178): runner-up seeded with numeric_limits<double>::min()
+    double first = pol[0], second = std::numeric_limits<double>::min();
+    int first_arg = 0, second_arg = 0;
+    for (int i = 1; i < m; ++i) {
+        if (pol[i] > first) { second = first; second_arg = first_arg; first = pol[i]; first_arg = i; }
+        else if (pol[i] > second) { second = pol[i]; second_arg = i; }
+    }
+    if (s_.q_value_weight > 0) {
+        if (s_.q_veto_delta != 0 && best_q != first_arg && n.q[best_q] > n.q[first_arg] + s_.q_veto_delta && n.child_visits[best_q] > 1) {
+            if (pol[first_arg] > pol[best_q]) std::swap(pol[best_q], pol[first_arg]);
+        } else if (first_arg != second_arg && n.q[second_arg] > n.q[first_arg]) {
+            const float q_diff = n.q[second_arg] - n.q[first_arg];
+            pol[second_arg] += q_diff * s_.q_value_weight * pol[first_arg];
+        }
+    }
+    double sum = 0;
+    for (double v : pol) sum += v;
+    int best = 0;
+    for (int i = 0; i < m; ++i) {
+        pol[i] /= sum;
+        if (pol[i] > pol[best]) best = i;
+    }
+    if (policy_out) *policy_out = pol;
+    return best;
+}
+
+}  // namespace search
+}  // namespace cra

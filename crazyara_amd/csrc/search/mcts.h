@@ -1,0 +1,137 @@
+// Host-side MCTS leaf collection: select / expand / virtual loss / backup, restating the arithmetic of
+// engine/src/node.{h,cpp}, nodedata.{h,cpp} and engine/src/searchthread.cpp.
+//
+// MI355X-first structure (not the reference's): instead of >=2 SearchThreads sharing one tree to hide a blocking
+// predict(), a SearchPool keeps MANY independent trees (games / opening positions) and fills each GPU batch with
+// leaves from all of them; trees are split into two pipeline halves so that one half's leaves are collected while the
+// other half's batch is on the GPU (side stream, pinned async copies, 192-byte descriptors instead of float planes).
+// Every tree is touched by exactly one thread at a time -> no per-node mutex, no global hash-table mutex.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../chess/planes.h"
+#include "../chess/policy.h"
+#include "../chess/position.h"
+
+namespace cra {
+namespace search {
+
+enum VirtualStyle : int { VIRTUAL_LOSS = 0, VIRTUAL_VISIT = 1, VIRTUAL_OFFSET = 2, VIRTUAL_MIX = 3 };   // node.h:78-95
+enum NodeType : int8_t { NT_WIN = 0, NT_DRAW = 1, NT_LOSS = 2, NT_UNSOLVED = 6 };
+
+// engine/src/agents/config/searchsettings.{h,cpp}; defaults = the UCI defaults a `go` sees (optionsuci.cpp:66-219)
+struct SearchSettings {
+    int batch_size = 16;                  // Batch_Size
+    float cpuct_init = 2.5f;              // Centi_CPuct_Init 250
+    float cpuct_base = 19652.0f;          // CPuct_Base
+    float node_policy_temperature = 1.7f; // Centi_Node_Temperature 170 (RL builds: 100)
+    int virtual_style = VIRTUAL_MIX;      // MCTS_Virtual_Style (optionsuci.cpp:194-195)
+    uint32_t virtual_mix_threshold = 1000;
+    double virtual_offset_strength = 0.001;
+    float q_value_weight = 1.0f;          // Centi_Q_Value_Weight 100
+    float q_veto_delta = 0.4f;            // Centi_Q_Veto_Delta 40
+    int mode = MODE_CRAZYHOUSE;           // build flavour: label set + plane layout family
+    int version_major = 1;                // input representation version of the loaded net
+    bool is_policy_map = true;
+    // Board::operator= copies lastMoves only in MODE_CHESS / MODE_LICHESS binaries (board.cpp:106-108): in a crazyhouse
+    // binary every leaf's move history restarts at the root clone.  -1 = follow the mode, 0/1 = force.
+    int clone_keeps_last_moves = -1;
+    // not restated yet (the reference's rand()-driven exploration, searchthread.cpp:124-185): must stay 0
+    int epsilon_greedy_counter = 0;
+    int epsilon_checks_counter = 0;
+};
+
+struct Node {
+    std::vector<chess::Move> actions;     // legalActions (sorted by prior on first selection)
+    std::vector<float> priors;            // policyProbSmall
+    std::vector<uint16_t> policy_idx;     // MV_LOOKUP index per action (consumed when the NN result arrives)
+    // NodeData (nodedata.h:88-121): entries [0, no_visit_idx]
+    std::vector<uint32_t> child_visits;
+    std::vector<float> q;
+    std::vector<int32_t> child;           // node index or -1
+    std::vector<uint8_t> vl;              // virtualLossCounter
+    double value_sum = 0.0;
+    uint32_t real_visits = 0;
+    uint32_t visit_sum = 0;
+    uint32_t free_visits = 0;
+    uint16_t no_visit_idx = 0;
+    uint16_t plies = 0;
+    int8_t node_type = NT_UNSOLVED;
+    bool terminal = false, has_nn = false, sorted = false, has_data = false;
+    uint8_t stm = 0;
+
+    float value() const { return float(value_sum / real_visits); }                         // node.cpp:595-598
+    void set_value(float v) { ++real_visits; value_sum = double(v * float(real_visits)); } // node.cpp:716-720
+    uint32_t real_child_visits(int i) const { return child_visits[i] - vl[i]; }            // node.cpp:650-653
+};
+
+struct NodeAndIdx {
+    int32_t node;
+    uint16_t child_idx;
+};
+typedef std::vector<NodeAndIdx> Trajectory;
+
+enum NodeBackup { NODE_COLLISION, NODE_TERMINAL, NODE_NEW_NODE, NODE_TRANSPOSITION };
+
+float get_current_cput(float visits, const SearchSettings& s);                             // node.cpp:1243-1246
+VirtualStyle get_virtual_style(const SearchSettings& s, uint32_t visits);                  // node.h:87-95
+
+class Tree {
+public:
+    Tree(const chess::Position& root, const SearchSettings& settings);
+
+    // --- root (MCTSAgent::create_new_root_node / set_root_node_predictions, mctsagent.cpp:166-196) ---
+    bool root_needs_eval() const { return !nodes_[0].has_nn && !nodes_[0].terminal; }
+    void root_desc(BoardDesc& d) const;
+    void set_root_result(float value, const float* probs);
+
+    // --- SearchThread::create_mini_batch (searchthread.cpp:347-380) with `quota` in the role of batchSize ---
+    // Writes one BoardDesc per NEW leaf to descs[0..returned).  Terminals are backed up immediately, collisions are
+    // remembered and reverted in finish_batch().
+    int collect(int quota, BoardDesc* descs);
+    // set_nn_results_to_child_nodes + backup_value_outputs + backup_collisions (searchthread.cpp:301-324)
+    void finish_batch(const float* values, const float* probs, int nb_policy);
+
+    // --- queries ---
+    const Node& root() const { return nodes_[0]; }
+    const Node& node(int i) const { return nodes_[i]; }
+    size_t node_count_allocated() const { return nodes_.size(); }
+    uint32_t root_visits() const { return nodes_[0].visit_sum; }
+    uint32_t node_count() const { return nodes_[0].visit_sum - nodes_[0].free_visits; }   // Node::get_node_count, node.cpp:1303-1306
+    const chess::Position& root_position() const { return root_pos_; }
+    int pending_new() const { return int(new_nodes_.size()); }
+    // Node::get_mcts_policy + argmax (node.cpp:1070-1109): best child index of the root and the visit policy
+    int best_move_index(std::vector<double>* policy = nullptr) const;
+    uint64_t depth_sum = 0;
+    uint32_t depth_max = 0;
+
+    // exposed for the arithmetic parity tests
+    int select_child(Node& n);
+    void apply_virtual_loss(Node& n, int child_idx);
+    void revert_virtual_loss(Node& n, int child_idx);
+    void revert_virtual_loss_and_update(Node& n, int child_idx, float value, bool free_backup);
+    void backup_value(float value, const Trajectory& t, bool free_backup);
+
+private:
+    int new_node(const chess::Position& pos);
+    void prepare_node_for_visits(Node& n);
+    void increment_no_visit_idx(Node& n);
+    void fill_nn_result(Node& n, float value, const float* probs);
+    int get_new_child_to_evaluate(NodeBackup& type, uint32_t& depth, BoardDesc* desc_out);
+
+    SearchSettings s_;
+    chess::Position root_pos_;
+    const chess::PolicyTables* tables_;
+    int layout_;
+    bool keep_last_moves_;
+    std::vector<Node> nodes_;
+    std::vector<int32_t> new_nodes_;
+    std::vector<Trajectory> new_trajectories_, collision_trajectories_;
+    Trajectory trajectory_buffer_;
+};
+
+}  // namespace search
+}  // namespace cra

@@ -1,0 +1,93 @@
+// SearchPool: many independent trees feeding shared GPU batches through two pipeline lanes (see mcts.h header).
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "mcts.h"
+
+namespace cra {
+class RiseNet;
+namespace search {
+
+// One evaluation lane: submit() starts the evaluation of `n` descriptors and returns; wait() blocks until the
+// value / probs host buffers of that submit are valid.
+class Evaluator {
+public:
+    virtual ~Evaluator() {}
+    virtual int batch_size() const = 0;
+    virtual int nb_policy() const = 0;
+    virtual BoardDesc* descs() = 0;        // [batch]   host (pinned for the HIP lane)
+    virtual const float* values() = 0;     // [batch]
+    virtual const float* probs() = 0;      // [batch][nb_policy]
+    virtual void submit(int n_valid, int layout) = 0;
+    virtual void wait() = 0;
+};
+
+// HIP lane: RiseNet::submit_boards on the net's side stream (192 B/position H2D, planes built on the GPU, D2H of results)
+std::unique_ptr<Evaluator> make_hip_evaluator(RiseNet* net);
+// user-supplied lane (tests / alternative back ends): fn(user, descs, n, value, probs) fills the outputs synchronously
+typedef int (*EvalFn)(void* user, const void* descs, int n, float* value, float* probs);
+std::unique_ptr<Evaluator> make_callback_evaluator(EvalFn fn, void* user, int batch, int nb_policy);
+
+struct SearchStats {
+    uint64_t nodes = 0;          // sum over trees of (visits - freeVisits) gained in this run (evalinfo.cpp:73-80)
+    uint64_t nn_evals = 0;       // positions sent to the evaluator (leaves + roots)
+    uint64_t batches = 0;        // evaluator submits
+    uint64_t simulations = 0;    // sum of root visits gained
+    uint64_t collisions = 0;
+    uint64_t terminal_visits = 0;
+    double seconds = 0;
+    double depth_avg = 0;
+    uint32_t depth_max = 0;
+};
+
+class WorkerPool {
+public:
+    explicit WorkerPool(int threads);
+    ~WorkerPool();
+    void parallel_for(int n, const std::function<void(int)>& fn);   // blocks; fn(i) for i in [0,n)
+    int threads() const { return int(workers_.size()) + 1; }
+private:
+    void worker_loop();
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, generation_ = 0, active_ = 0;
+    bool stop_ = false;
+};
+
+class SearchPool {
+public:
+    SearchPool(const SearchSettings& s, std::unique_ptr<Evaluator> lane_a, std::unique_ptr<Evaluator> lane_b);
+    int add_position(const chess::Position& pos);
+    // runs until every tree reached `simulations` root visits (if > 0) and/or `nodes` counted nodes (if > 0)
+    // (SearchThread::nodes_limits_ok, searchthread.cpp:326-331)
+    void run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats);
+    Tree& tree(int i) { return *trees_.at(i); }
+    int n_trees() const { return int(trees_.size()); }
+    const SearchSettings& settings() const { return s_; }
+
+private:
+    struct Lane {
+        std::unique_ptr<Evaluator> eval;
+        std::vector<int> trees;            // tree ids assigned to this lane
+        std::vector<int> slot_begin, slot_count, n_new, batch_ids;
+        bool in_flight = false;
+    };
+    bool tree_done(const Tree& t, uint32_t simulations, uint32_t nodes) const;
+    void evaluate_roots(Lane& lane);
+    SearchSettings s_;
+    int layout_;
+    std::vector<std::unique_ptr<Tree>> trees_;
+    std::vector<Lane> lanes_;
+};
+
+}  // namespace search
+}  // namespace cra

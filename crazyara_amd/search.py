@@ -1,0 +1,99 @@
+"""Python handle on the native MCTS search pool (C ABI mi_search_*): many trees feeding shared GPU batches."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from . import _capi
+
+
+class SearchSettingsC(C.Structure):
+    _fields_ = [("batch_size", C.c_int), ("cpuct_init", C.c_float), ("cpuct_base", C.c_float),
+                ("node_policy_temperature", C.c_float), ("virtual_style", C.c_int), ("virtual_mix_threshold", C.c_uint),
+                ("virtual_offset_strength", C.c_double), ("q_value_weight", C.c_float), ("q_veto_delta", C.c_float),
+                ("mode", C.c_int), ("version_major", C.c_int), ("is_policy_map", C.c_int), ("clone_keeps_last_moves", C.c_int)]
+
+
+class SearchStatsC(C.Structure):
+    _fields_ = [("nodes", C.c_ulonglong), ("nn_evals", C.c_ulonglong), ("batches", C.c_ulonglong), ("simulations", C.c_ulonglong),
+                ("seconds", C.c_double), ("depth_avg", C.c_double), ("depth_max", C.c_uint)]
+
+
+EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+
+def default_settings(**overrides) -> SearchSettingsC:
+    s = SearchSettingsC()
+    _capi.load().mi_search_default_settings(C.byref(s))
+    for k, v in overrides.items():
+        setattr(s, k, v)
+    return s
+
+
+class SearchPool:
+    def __init__(self, settings: SearchSettingsC, net_a=None, net_b=None,
+                 eval_fn: Optional[Callable] = None, fn_batch: int = 0, fn_nb_policy: int = 0):
+        self._lib = _capi.load()
+        self._cb = None
+        if eval_fn is not None:
+            def _tramp(user, descs, n, value, probs):
+                try:
+                    raw = C.string_at(descs, n * 192)
+                    v, p = eval_fn([raw[i * 192:(i + 1) * 192] for i in range(n)])
+                    np.ctypeslib.as_array(value, shape=(n,))[:] = np.asarray(v, np.float32)
+                    np.ctypeslib.as_array(probs, shape=(n, fn_nb_policy))[:] = np.asarray(p, np.float32)
+                    return 0
+                except Exception as e:  # noqa: BLE001
+                    print("evaluator callback raised:", repr(e))
+                    return 1
+            self._cb = EVAL_FN(_tramp)
+        self._nets = (net_a, net_b)
+        self._h = self._lib.mi_search_create(C.byref(settings), net_a._h if net_a else None, net_b._h if net_b else None,
+                                             self._cb if self._cb else C.cast(None, EVAL_FN), None, fn_batch, fn_nb_policy)
+        if not self._h:
+            raise RuntimeError(_capi.last_error())
+
+    def add_position(self, fen: str = "", is960: bool = False, variant: str = "crazyhouse") -> int:
+        t = self._lib.mi_search_add_position(self._h, (fen or "").encode(), int(is960), variant.encode())
+        if t < 0:
+            raise ValueError(_capi.last_error())
+        return t
+
+    def run(self, simulations: int = 0, nodes: int = 0, threads: int = 1) -> SearchStatsC:
+        st = SearchStatsC()
+        if self._lib.mi_search_run(self._h, simulations, nodes, threads, C.byref(st)):
+            raise RuntimeError(_capi.last_error())
+        return st
+
+    def root_children(self, tree: int):
+        cap = 512
+        moves = (C.c_uint32 * cap)()
+        visits = (C.c_uint32 * cap)()
+        q = (C.c_float * cap)()
+        pri = (C.c_float * cap)()
+        n = self._lib.mi_search_root_children(self._h, tree, cap, moves, visits, q, pri)
+        return list(moves[:n]), list(visits[:n]), np.array(q[:n], np.float32), np.array(pri[:n], np.float32)
+
+    def tree_info(self, tree: int):
+        rv, nc, alloc, val = C.c_uint(), C.c_uint(), C.c_uint(), C.c_float()
+        self._lib.mi_search_tree_info(self._h, tree, C.byref(rv), C.byref(nc), C.byref(alloc), C.byref(val))
+        return dict(root_visits=rv.value, node_count=nc.value, allocated=alloc.value, root_value=val.value)
+
+    def best_move(self, tree: int) -> str:
+        buf = C.create_string_buffer(16)
+        if self._lib.mi_search_best_move(self._h, tree, buf, 16):
+            raise RuntimeError(_capi.last_error())
+        return buf.value.decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi_search_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

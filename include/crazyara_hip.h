@@ -131,6 +131,45 @@ int mi_policy_flat_plane_idx(int mode, int idx);           /* FLAT_PLANE_IDX[idx
  * index of `move` in the policy vector, mirrored table iff black to move.  -1 if the move has no label. */
 int mi_pos_policy_index(const mi_pos* pos, uint32_t move, int mode, int is_policy_map);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * MCTS leaf collection (engine/src/searchthread.cpp:164-449, engine/src/node.{h,cpp}; driven like
+ * MCTSAgent::evaluate_board_state -> run_mcts_search, engine/src/agents/mctsagent.cpp:292-362)
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct mi_search mi_search;
+typedef struct mi_search_settings {        /* SearchSettings (engine/src/agents/config/searchsettings.h:51-99) */
+    int batch_size;                        /* informational; the evaluator lanes fix the real batch */
+    float cpuct_init, cpuct_base;          /* Centi_CPuct_Init / CPuct_Base */
+    float node_policy_temperature;         /* Centi_Node_Temperature */
+    int virtual_style;                     /* 0 LOSS, 1 VISIT, 2 OFFSET, 3 MIX (MCTS_Virtual_Style) */
+    unsigned virtual_mix_threshold;
+    double virtual_offset_strength;
+    float q_value_weight, q_veto_delta;
+    int mode;                              /* MI_MODE_* */
+    int version_major;                     /* input representation of the net */
+    int is_policy_map;
+    int clone_keeps_last_moves;            /* -1 follow the build mode (board.cpp:106-108), 0 / 1 force */
+} mi_search_settings;
+typedef struct mi_search_stats {
+    unsigned long long nodes, nn_evals, batches, simulations;
+    double seconds, depth_avg;
+    unsigned depth_max;
+} mi_search_stats;
+/* evaluator callback lane: fill value[n] and probs[n*nb_policy] for n 192-byte descriptors; return 0 on success */
+typedef int (*mi_eval_fn)(void* user, const void* descs, int n, float* value, float* probs);
+
+void mi_search_default_settings(mi_search_settings* s);                 /* UCI defaults, optionsuci.cpp:66-219 */
+/* lanes: net_a (required unless fn given), net_b optional second net instance on the same GPU -> collection of one half of
+ * the trees overlaps evaluation of the other half.  With fn != NULL the nets are ignored and fn evaluates (batch, nb_policy given). */
+mi_search* mi_search_create(const mi_search_settings* s, mi_net* net_a, mi_net* net_b, mi_eval_fn fn, void* user, int fn_batch, int fn_nb_policy);
+void mi_search_destroy(mi_search* sp);
+int mi_search_add_position(mi_search* sp, const char* fen, int is_chess960, const char* variant);   /* returns tree id or -1 */
+/* go with Simulations / Nodes limits per tree (searchthread.cpp:326-331); threads = host collector threads */
+int mi_search_run(mi_search* sp, unsigned simulations, unsigned nodes, int threads, mi_search_stats* stats);
+/* root statistics of one tree, children in the node's (prior-sorted) order: returns number of expanded children */
+int mi_search_root_children(mi_search* sp, int tree, int cap, uint32_t* moves, uint32_t* visits, float* q, float* priors);
+int mi_search_tree_info(mi_search* sp, int tree, unsigned* root_visits, unsigned* node_count, unsigned* allocated_nodes, float* root_value);
+int mi_search_best_move(mi_search* sp, int tree, char* uci, int cap);   /* argmax of Node::get_mcts_policy, node.cpp:1070-1109 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,317 @@
+"""
+ORACLE (test infrastructure only -- never imported by the product path).
+
+Python restatement of the reference's MCTS leaf-collection arithmetic on top of oracle.chess_oracle.Board:
+
+  select_child_node / get_current_u_values / get_current_cput ... engine/src/node.cpp:1056-1063,1150-1167,1243-1246
+  apply_virtual_loss_to_child / get_virtual_style ............ node.cpp:507-529, node.h:87-95
+  revert_virtual_loss_and_update<> ........................... node.h:199-246
+  revert_virtual_loss (collisions) ........................... node.cpp:655-679
+  backup_value<> (tree case, two-player sign flip) ........... node.h:819-843
+  create_mini_batch / get_new_child_to_evaluate .............. engine/src/searchthread.cpp:164-271,347-380
+  fill_nn_results: prior gather, temperature, value .......... searchthread.cpp:290-299, node.cpp:956-979, util/blazeutil.h:77-87
+  sort_moves_by_probabilities (stable, index tie-break) ...... node.cpp:464-470
+  get_mcts_policy / first_and_second_max ..................... node.cpp:1070-1109, blazeutil.h:155-178
+
+float32 / float64 mixing follows the C++ expression types (blaze vectors of float, uint32 and double); logf / powf are
+taken from libm so that results are bit-identical to a C++ build on the same machine.
+
+Parity status: the reference has NO unit test for this arithmetic ("parity unpinned") and its engine cannot be
+compiled here (Stockfish fork + blaze are empty submodules), so this file is a line-by-line restatement checked by
+hand-computed cases in tests/test_mcts.py, not by reference-generated vectors.  useMCGS (transposition merge), the MCTS
+solver and the rand()-driven epsilon exploration are not restated.
+"""
+from __future__ import annotations
+
+import ctypes
+import ctypes.util
+import math
+
+import numpy as np
+
+from . import chess_oracle as co
+
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.logf.restype = ctypes.c_float
+_libm.logf.argtypes = [ctypes.c_float]
+_libm.powf.restype = ctypes.c_float
+_libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+
+F = np.float32
+Q_INIT = F(-1.0)
+VIRTUAL_LOSS, VIRTUAL_VISIT, VIRTUAL_OFFSET, VIRTUAL_MIX = 0, 1, 2, 3
+
+
+class Settings:
+    def __init__(self, **kw):
+        self.batch_size = 16
+        self.cpuct_init = F(2.5)
+        self.cpuct_base = F(19652.0)
+        self.node_policy_temperature = F(1.7)
+        self.virtual_style = VIRTUAL_MIX
+        self.virtual_mix_threshold = 1000
+        self.virtual_offset_strength = 0.001
+        self.q_value_weight = F(1.0)
+        self.q_veto_delta = F(0.4)
+        self.mode = co.MODE_CRAZYHOUSE
+        self.is_policy_map = True
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def get_current_cput(visits, s):
+    v = F(visits)
+    return F(_libm.logf(F(F(v + s.cpuct_base + F(1)) / s.cpuct_base))) + s.cpuct_init
+
+
+def virtual_style(s, visits):
+    if s.virtual_style == VIRTUAL_MIX:
+        return VIRTUAL_LOSS if visits > s.virtual_mix_threshold else VIRTUAL_VISIT
+    return s.virtual_style
+
+
+class Node:
+    def __init__(self, board: co.Board, policy_map: co.PolicyMap, s: Settings):
+        self.moves = board.legal_moves()
+        self.terminal = False
+        self.value_sum = 0.0
+        self.real_visits = 0
+        self.has_nn = False
+        self.sorted = False
+        self.has_data = False
+        self.visit_sum = 0
+        self.free_visits = 0
+        self.no_visit_idx = 0
+        t = board.terminal()
+        if t != co.TERMINAL_NONE:
+            self.terminal = True
+            self.has_data = True
+            self.sorted = True
+            self.set_value({co.TERMINAL_WIN: F(1), co.TERMINAL_DRAW: F(0), co.TERMINAL_LOSS: F(-1)}[t])
+            if t == co.TERMINAL_DRAW:
+                self.moves = []
+        self.uci = [board.move_uci(m) for m in self.moves]
+        self.priors = [F(0)] * len(self.moves)
+        self.policy_idx = [] if self.terminal else [policy_map.index(board, m, s.is_policy_map) for m in self.moves]
+        self.child_visits, self.q, self.child, self.vl = [], [], [], []
+
+    def set_value(self, v):
+        self.real_visits += 1
+        self.value_sum = float(F(v) * F(self.real_visits))
+
+    def value(self):
+        return F(self.value_sum / self.real_visits)
+
+    def real_child_visits(self, c):
+        return self.child_visits[c] - self.vl[c]
+
+
+class Tree:
+    def __init__(self, board: co.Board, s: Settings, clone_keeps_last_moves=None):
+        self.s = s
+        self.root_board = board
+        self.pm = co.PolicyMap(s.mode)
+        self.keep = (s.mode != co.MODE_CRAZYHOUSE) if clone_keeps_last_moves is None else clone_keeps_last_moves
+        self.root = Node(board, self.pm, s)
+        self.new_nodes, self.new_traj, self.coll_traj = [], [], []
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def fill_nn_result(self, n: Node, value, probs):
+        n.priors = [F(probs[i]) for i in n.policy_idx]
+        n.policy_idx = []
+        t = self.s.node_policy_temperature
+        if t != 1:
+            e = F(F(1.0) / F(t))
+            n.priors = [F(_libm.powf(p, e)) for p in n.priors]
+            tot = F(0)
+            for p in n.priors:
+                tot = F(tot + p)
+            n.priors = [F(p / tot) for p in n.priors]
+        n.set_value(F(value))
+        n.has_nn = True
+
+    def set_root_result(self, value, probs):
+        self.fill_nn_result(self.root, value, probs)
+        self.prepare(self.root)
+
+    def prepare(self, n: Node):
+        order = sorted(range(len(n.moves)), key=lambda i: (-float(n.priors[i]), i))
+        n.moves = [n.moves[i] for i in order]
+        n.uci = [n.uci[i] for i in order]
+        n.priors = [n.priors[i] for i in order]
+        n.sorted = True
+        if not n.has_data:
+            n.has_data = True
+            n.no_visit_idx = 1
+            n.child_visits, n.q, n.child, n.vl = [0], [Q_INIT], [None], [0]
+
+    def increment_no_visit_idx(self, n: Node):
+        if n.no_visit_idx < len(n.moves):
+            n.no_visit_idx += 1
+            n.child_visits.append(0)
+            n.q.append(Q_INIT)
+            n.child.append(None)
+            n.vl.append(0)
+
+    def select_child(self, n: Node):
+        if not n.sorted:
+            self.prepare(n)
+        if n.no_visit_idx == 1:
+            return 0
+        cpuct = get_current_cput(n.visit_sum, self.s)
+        sq = math.sqrt(float(n.visit_sum))
+        best, best_v = 0, F(-np.inf)
+        for i in range(n.no_visit_idx):
+            u = F(float(F(cpuct * n.priors[i])) * (sq / (float(n.child_visits[i]) + 1.0)))
+            v = F(n.q[i] + u)
+            if v > best_v:
+                best, best_v = i, v
+        return best
+
+    def apply_virtual_loss(self, n: Node, c):
+        st = virtual_style(self.s, n.child_visits[c])
+        if st == VIRTUAL_LOSS:
+            n.q[c] = F((float(n.q[c]) * n.child_visits[c] - 1) / float(n.child_visits[c] + 1))
+        elif st == VIRTUAL_OFFSET:
+            n.q[c] = F(float(n.q[c]) - self.s.virtual_offset_strength)
+        n.child_visits[c] += 1
+        n.visit_sum += 1
+        n.vl[c] += 1
+
+    def revert_virtual_loss(self, n: Node, c):
+        st = virtual_style(self.s, n.child_visits[c])
+        if st == VIRTUAL_LOSS:
+            n.q[c] = F((float(n.q[c]) * n.child_visits[c] + 1) / (n.child_visits[c] - 1))
+        elif st == VIRTUAL_OFFSET:
+            n.q[c] = F(float(n.q[c]) + self.s.virtual_offset_strength)
+        n.child_visits[c] -= 1
+        n.visit_sum -= 1
+        n.vl[c] -= 1
+
+    def revert_virtual_loss_and_update(self, n: Node, c, value, free_backup):
+        value = F(value)
+        n.value_sum += float(value)
+        n.real_visits += 1
+        if n.child_visits[c] == 1:
+            n.q[c] = value
+        else:
+            st = virtual_style(self.s, n.child_visits[c])
+            if st == VIRTUAL_LOSS:
+                n.q[c] = F((float(n.q[c]) * n.child_visits[c] + 1 + float(value)) / n.child_visits[c])
+            elif st == VIRTUAL_VISIT:
+                r = n.real_child_visits(c)
+                n.q[c] = F((float(n.q[c]) * r + float(value)) / (r + 1))
+            elif st == VIRTUAL_OFFSET:
+                r = n.real_child_visits(c)
+                nq = float(n.q[c]) + n.vl[c] * self.s.virtual_offset_strength
+                nq = (nq * r + float(value)) / (r + 1.0)
+                n.q[c] = F(nq - ((n.vl[c] - 1) * self.s.virtual_offset_strength))
+        n.vl[c] -= 1
+        if free_backup:
+            n.free_visits += 1
+
+    def backup_value(self, value, traj, free_backup):
+        value = F(value)
+        for n, c in reversed(traj):
+            value = F(-value)
+            self.revert_virtual_loss_and_update(n, c, value, free_backup)
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def get_new_child(self):
+        cur = self.root
+        board = self.root_board.copy()
+        if not self.keep:
+            board.last_moves = []
+        traj = []
+        while True:
+            c = self.select_child(cur)
+            self.apply_virtual_loss(cur, c)
+            traj.append((cur, c))
+            nxt = cur.child[c]
+            if nxt is None:
+                board.push(cur.moves[c])
+                self.increment_no_visit_idx(cur)
+                nn = Node(board, self.pm, self.s)
+                cur.child[c] = nn
+                if nn.terminal:
+                    return "terminal", nn, traj, None
+                return "new", nn, traj, board
+            if nxt.terminal:
+                return "terminal", nxt, traj, None
+            if not nxt.has_nn:
+                return "collision", nxt, traj, None
+            board.push(cur.moves[c])
+            cur = nxt
+
+    def collect(self, quota):
+        """-> list of boards to evaluate (one per new leaf)"""
+        boards = []
+        n_term = 0
+        if self.root.terminal or not self.root.has_nn:
+            return boards
+        while len(boards) < quota and len(self.coll_traj) != quota and n_term < 2 * max(quota, 1):
+            kind, node, traj, board = self.get_new_child()
+            if kind == "terminal":
+                n_term += 1
+                self.backup_value(node.value(), traj, True)
+            elif kind == "collision":
+                self.coll_traj.append(traj)
+            else:
+                self.new_nodes.append(node)
+                self.new_traj.append(traj)
+                boards.append(board)
+        return boards
+
+    def finish_batch(self, values, probs):
+        for i, n in enumerate(self.new_nodes):
+            self.fill_nn_result(n, values[i], probs[i])
+        for n, traj in zip(self.new_nodes, self.new_traj):
+            self.backup_value(n.value(), traj, False)
+        self.new_nodes, self.new_traj = [], []
+        for traj in self.coll_traj:
+            for n, c in reversed(traj):
+                self.revert_virtual_loss(n, c)
+        self.coll_traj = []
+
+    def node_count(self):
+        return self.root.visit_sum - self.root.free_visits
+
+    def best_move(self):
+        n = self.root
+        m = n.no_visit_idx
+        pol = [float(v) for v in n.child_visits[:m]]
+        best_q = 0
+        for i in range(1, m):
+            if n.q[i] > n.q[best_q]:
+                best_q = i
+        first, second, fa, sa = pol[0], 2.2250738585072014e-308, 0, 0
+        for i in range(1, m):
+            if pol[i] > first:
+                second, sa, first, fa = first, fa, pol[i], i
+            elif pol[i] > second:
+                second, sa = pol[i], i
+        if self.s.q_value_weight > 0:
+            if self.s.q_veto_delta != 0 and best_q != fa and n.q[best_q] > F(n.q[fa] + self.s.q_veto_delta) and n.child_visits[best_q] > 1:
+                if pol[fa] > pol[best_q]:
+                    pol[best_q], pol[fa] = pol[fa], pol[best_q]
+            elif fa != sa and n.q[sa] > n.q[fa]:
+                q_diff = F(n.q[sa] - n.q[fa])
+                pol[sa] += float(F(q_diff * self.s.q_value_weight)) * pol[fa]
+        tot = sum(pol)
+        pol = [p / tot for p in pol]
+        return n.uci[int(np.argmax(pol))], pol
+
+
+def run_search(tree: Tree, evaluate, simulations, quota):
+    """evaluate(list of Boards) -> (values, probs).  Mirrors SearchPool::run for a single tree / single lane."""
+    if not tree.root.has_nn and not tree.root.terminal:
+        v, p = evaluate([tree.root_board])
+        tree.set_root_result(v[0], p[0])
+    pre = tree.root.visit_sum
+    while not tree.root.terminal and tree.root.visit_sum - pre < simulations:
+        boards = tree.collect(quota)
+        if boards:
+            v, p = evaluate(boards)
+            tree.finish_batch(v, p)
+        else:
+            tree.finish_batch([], [])

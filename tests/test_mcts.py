@@ -1,0 +1,188 @@
+"""Host-side MCTS (C++ Tree / SearchPool through the C ABI, CPU only) vs the oracle restatement of the reference's
+select / virtual-loss / backup arithmetic.  A deterministic pseudo-network (pure function of the position) plays the
+evaluator on both sides, so visit counts and float32 Q / prior values must be bit-identical."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from crazyara_amd import env, search
+from oracle import chess_oracle as co
+from oracle import mcts_oracle as mo
+
+NB_POLICY = {0: 5184, 1: 4864, 2: 5376}
+
+
+def _pseudo_net(key: bytes, nb_policy: int):
+    rs = np.random.Generator(np.random.PCG64(zlib.crc32(key)))
+    p = rs.random(nb_policy, dtype=np.float32) ** np.float32(6.0)      # peaked like a policy
+    p = p / p.sum(dtype=np.float32)
+    v = np.float32(rs.random() * 1.6 - 0.8)
+    return v, p
+
+
+def key_from_desc(d: bytes) -> bytes:
+    return d[0:96] + d[112:123]          # 12 bitboards + pockets[10] + side to move (struct BoardDesc, planes.h)
+
+
+def key_from_board(b: co.Board) -> bytes:
+    bbs = []
+    for ch in "PNBRQKpnbrqk":
+        v = 0
+        for s in range(64):
+            if b.b[s] == ch:
+                v |= 1 << s
+        bbs.append(v)
+    pockets = bytes(b.pocket[c] for c in "PNBRQpnbrq")
+    return struct.pack("<12Q", *bbs) + pockets + bytes([b.stm])
+
+
+def test_descriptor_key_matches_oracle_board_key(hip_lib):
+    for fen, variant in (("", "crazyhouse"), ("5r2/ppp2pkp/3p4/2bP4/2Pnp1N1/3P2pP/PP2n1P1/R2Q1R1K[PBRQnbb] b - - 0 28", "crazyhouse")):
+        assert key_from_desc(env.Position(fen, False, variant).desc()) == key_from_board(co.Board(fen or None, False, variant))
+
+
+# ---- hand-computed arithmetic (the reference has no unit test for these; worked examples from its own comments) ----
+def test_oracle_arithmetic_worked_examples():
+    s = mo.Settings(virtual_style=mo.VIRTUAL_LOSS)
+    # get_current_cput: log((N + base + 1) / base) + init  (node.cpp:1243-1246)
+    assert abs(float(mo.get_current_cput(0, s)) - (np.log(19653.0 / 19652.0) + 2.5)) < 1e-6
+    assert abs(float(mo.get_current_cput(19652, s)) - (np.log(39305.0 / 19652.0) + 2.5)) < 1e-6
+    # node.h:180-196 worked example: Q_1 = -0.25 with n_1 = 2 after one virtual loss on (Q=0.5, n=1); update with 0.7 -> 0.6
+    t = mo.Tree.__new__(mo.Tree)
+    t.s = s
+    n = mo.Node.__new__(mo.Node)
+    n.child_visits, n.q, n.vl, n.visit_sum, n.value_sum, n.real_visits, n.free_visits = [1], [np.float32(0.5)], [0], 1, 0.0, 0, 0
+    t.apply_virtual_loss(n, 0)
+    assert n.child_visits == [2] and abs(float(n.q[0]) - (-0.25)) < 1e-7 and n.vl == [1]
+    t.revert_virtual_loss_and_update(n, 0, 0.7, False)
+    assert abs(float(n.q[0]) - 0.6) < 1e-6 and n.vl == [0] and n.child_visits == [2]
+    # collision revert restores Q exactly: (Q*n + 1)/(n - 1)  (node.cpp:661-679)
+    n.child_visits, n.q, n.vl, n.visit_sum = [3], [np.float32(0.2)], [0], 3
+    t.apply_virtual_loss(n, 0)
+    t.revert_virtual_loss(n, 0)
+    assert n.child_visits == [3] and abs(float(n.q[0]) - 0.2) < 1e-6
+    # VIRTUAL_VISIT: Q untouched by the virtual visit; update = running mean over REAL visits (node.h:221-224)
+    t.s = mo.Settings(virtual_style=mo.VIRTUAL_VISIT)
+    n.child_visits, n.q, n.vl, n.visit_sum = [2], [np.float32(0.4)], [0], 2
+    t.apply_virtual_loss(n, 0)
+    assert float(n.q[0]) == np.float32(0.4)
+    t.revert_virtual_loss_and_update(n, 0, 1.0, False)
+    assert abs(float(n.q[0]) - (0.4 * 2 + 1.0) / 3) < 1e-6
+    # first real visit overwrites Q_INIT (node.h:207-211)
+    n.child_visits, n.q, n.vl = [0], [np.float32(-1.0)], [0]
+    t.apply_virtual_loss(n, 0)
+    t.revert_virtual_loss_and_update(n, 0, 0.3, False)
+    assert float(n.q[0]) == np.float32(0.3)
+    # VIRTUAL_MIX switches at the threshold (node.h:87-95)
+    mix = mo.Settings(virtual_style=mo.VIRTUAL_MIX, virtual_mix_threshold=1000)
+    assert mo.virtual_style(mix, 1000) == mo.VIRTUAL_VISIT and mo.virtual_style(mix, 1001) == mo.VIRTUAL_LOSS
+
+
+CASES = [
+    # variant, is960, fen, mode, sims, quota(batch), virtual style, temperature
+    ("crazyhouse", False, "", 0, 300, 8, 3, 1.7),
+    ("crazyhouse", False, "", 0, 200, 16, 0, 1.0),
+    ("crazyhouse", False, "r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] w KQkq - 0 8", 0, 250, 8, 1, 1.7),
+    ("crazyhouse", False, "5r2/ppp2pkp/3p4/2bP4/2Pnp1N1/3P2pP/PP2n1P1/R2Q1R1K[PBRQnbb] w - - 0 28", 0, 300, 8, 3, 1.7),
+    ("crazyhouse", False, "4R2b/1N3rkb/1p2P1pp/p2P4/2P1P3/8/PP4Q1/3R3K[QRBBNNNPPPPpp] w - - 2 53", 0, 200, 8, 2, 1.7),   # mates in tree
+    ("chess", False, "", 1, 200, 8, 3, 1.7),
+    ("chess", True, "bnnrkbrq/pppppppp/8/8/8/8/PPPPPPPP/BNNRKBRQ w GDgd - 0 1", 1, 150, 4, 3, 1.3),
+    ("3check", False, "1r4k1/1p2bp1p/3p2p1/PprPp2n/1R2PPq1/3Q4/1P1B1NPP/5RK1 b - - 1+1 2 22", 2, 200, 8, 3, 1.7),
+    ("kingofthehill", False, "rnbq1bnr/pppp1ppp/4k3/8/4P3/3K4/PPPP1PPP/RNBQ1BNR w - - 4 5", 2, 150, 8, 3, 1.7),
+]
+
+
+@pytest.mark.parametrize("variant,is960,fen,mode,sims,quota,vstyle,temp", CASES)
+def test_product_tree_equals_oracle_tree(hip_lib, variant, is960, fen, mode, sims, quota, vstyle, temp):
+    nbp = NB_POLICY[mode]
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, virtual_style=vstyle,
+                                 node_policy_temperature=temp, batch_size=quota)
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=quota, fn_nb_policy=nbp)
+    t = pool.add_position(fen, is960, variant)
+    stats = pool.run(simulations=sims, threads=1)
+    moves, visits, q, pri = pool.root_children(t)
+    info = pool.tree_info(t)
+
+    os_ = mo.Settings(mode=mode, is_policy_map=True, virtual_style=vstyle, node_policy_temperature=np.float32(temp), batch_size=quota)
+    board = co.Board(fen or None, is960, variant)
+    tree = mo.Tree(board, os_)
+
+    def eval_boards(boards):
+        out = [_pseudo_net(key_from_board(b), nbp) for b in boards]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    mo.run_search(tree, eval_boards, sims, quota)
+    r = tree.root
+    p = env.Position(fen, is960, variant)
+    assert [p.move_uci(m) for m in moves] == r.uci[:len(moves)]
+    assert len(moves) == len(r.child_visits)
+    assert visits == r.child_visits
+    assert np.array_equal(q, np.array(r.q, np.float32))                       # bit-exact float32 Q values
+    # priors: gather is exact; the temperature renormalisation sums float32 terms in move-generation order (the reference:
+    # Stockfish's order, blaze's SIMD reduction) -> implementations may differ in the last ulp of that sum
+    assert np.allclose(pri, np.array(r.priors[:len(moves)], np.float32), rtol=4e-7, atol=0)
+    assert info["root_visits"] == r.visit_sum and info["node_count"] == tree.node_count()
+    assert stats.simulations == r.visit_sum and stats.nodes == tree.node_count()
+    assert pool.best_move(t) == tree.best_move()[0]
+    pool.close()
+
+
+def test_pool_many_trees_two_lanes_matches_single_tree_runs(hip_lib):
+    """Trees are independent: a pooled, two-lane, multi-threaded run must give each tree exactly the statistics it gets
+    when searched alone with the same per-tree quota."""
+    nbp = NB_POLICY[0]
+    fens = ["", "r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] w KQkq - 0 8",
+            "5r2/ppp2pkp/3p4/2bP4/2Pnp1N1/3P2pP/PP2n1P1/R2Q1R1K[PBRQnbb] w - - 0 28",
+            "r2qk3/1pP2r1n/p1nP4/8/3P1Bb1/2Pp1PP1/PPp2PP1/3q1K1R[Bbnnppr] w - - 2 29"]
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    st = search.default_settings(mode=0, version_major=1)
+    # pooled: 4 trees, batch 16 per lane, 2 lanes -> 2 trees per lane -> quota 8 each
+    import ctypes as C
+    lib = __import__("crazyara_amd._capi", fromlist=["x"]).load()
+    pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=16, fn_nb_policy=nbp)
+    for f in fens:
+        pool.add_position(f, False, "crazyhouse")
+    # single lane in callback mode, so 4 trees share 16 slots -> quota 4
+    stats = pool.run(simulations=120, threads=3)
+    pooled = [pool.root_children(i) for i in range(4)]
+    assert stats.simulations >= 4 * 120
+    for i, f in enumerate(fens):
+        solo = search.SearchPool(st, eval_fn=eval_descs, fn_batch=4, fn_nb_policy=nbp)
+        solo.add_position(f, False, "crazyhouse")
+        solo.run(simulations=120, threads=1)
+        m, v, q, pr = solo.root_children(0)
+        assert m == pooled[i][0] and v == pooled[i][1] and np.array_equal(q, pooled[i][2])
+        solo.close()
+    pool.close()
+
+
+def test_search_limits_and_terminal_root(hip_lib):
+    nbp = NB_POLICY[0]
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    st = search.default_settings(mode=0, version_major=1)
+    pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=8, fn_nb_policy=nbp)
+    t0 = pool.add_position("", False, "crazyhouse")
+    # checkmated root: terminal, never searched
+    t1 = pool.add_position("4R2b/1N3rkb/1p2P1pp/p2P3N/2P1P3/8/PP4Q1/3R3K[QRBBNNPPPPpp] b - - 3 53", False, "crazyhouse")
+    stats = pool.run(nodes=64, threads=2)
+    i0, i1 = pool.tree_info(t0), pool.tree_info(t1)
+    assert i0["node_count"] >= 64 and i1["root_visits"] == 0
+    assert stats.nodes == i0["node_count"]
+    with pytest.raises(RuntimeError):
+        pool.run(0, 0, 1)
+    pool.close()

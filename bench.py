@@ -70,6 +70,10 @@ def main():
     ap.add_argument("--blocks", type=int, default=N_BLOCKS)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--simulations", type=int, default=1600)
+    ap.add_argument("--search-quota", type=int, default=16, help="leaves per tree per batch (reference Batch_Size default 16)")
+    ap.add_argument("--search-threads", type=int, default=16)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,6 +128,34 @@ def main():
     evals = args.steps * args.batch * world
     value = evals / elapsed
 
+    # ---- MCTS leg (BASELINE config 2: batch 256, 1600 simulations per search, fixed opening set) ----
+    mcts = None
+    if not args.no_search:
+        from crazyara_amd import openings, search
+        net_b = HipAPI(local_rank, args.batch, tmp, args.precision)
+        st = search.default_settings(mode=0, version_major=1, batch_size=args.search_quota)
+        pool = search.SearchPool(st, net_a=net, net_b=net_b)
+        n_trees = 2 * max(1, args.batch // args.search_quota)
+        fens = openings.position_fens("crazyhouse")
+        for i in range(n_trees):
+            pool.add_position(fens[(i * 7 + rank * 3) % len(fens)], False, "crazyhouse")
+        threads = max(1, min(args.search_threads, (os.cpu_count() or 1) // max(1, world)))
+        stt = pool.run(simulations=args.simulations, threads=threads)
+        loc = torch.tensor([float(stt.nodes), float(stt.nn_evals), float(stt.simulations), stt.seconds], device="cuda", dtype=torch.float64)
+        tot = loc.clone()
+        if dist is not None:
+            mx = loc[3:4].clone()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)     # RCCL sum of {nodes, evals, simulations}
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            tot[3] = mx[0]
+        mcts = {"mcts_nodes_per_sec": round(float(tot[0] / tot[3]), 1), "mcts_nn_evals_per_sec": round(float(tot[1] / tot[3]), 1),
+                "simulations_per_sec": round(float(tot[2] / tot[3]), 1), "seconds": round(float(tot[3]), 3),
+                "trees_per_gpu": n_trees, "simulations_per_tree": args.simulations, "per_tree_quota": args.search_quota,
+                "lanes": 2, "host_threads_per_gpu": threads, "avg_batch_fill": round(stt.nn_evals / max(1, stt.batches) / args.batch, 3),
+                "depth_avg": round(stt.depth_avg, 2), "depth_max": int(stt.depth_max)}
+        pool.close()
+        net_b.close()
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live with hipEvents on the net's own stream ----
@@ -174,6 +206,8 @@ def main():
             "pcie_inclusive_evals_per_sec": round(pcie_rate, 1),
             "roofline": roofline,
         }
+        if mcts:
+            out["mcts"] = mcts
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, x)
     net.close()

@@ -212,8 +212,10 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         if (active.empty()) return false;
         Evaluator& ev = *lane.eval;
         const int B = ev.batch_size();
-        const int quota = std::max(1, B / int(active.size()));
-        const int n_use = std::min<int>(int(active.size()), B);      // more active trees than slots: the rest waits a round
+        // fixed per-tree quota (= the reference's per-search Batch_Size): a tree's statistics do not depend on which other
+        // trees are still running.  More trees than slots: the rest waits a round (rotation below).
+        const int quota = std::max(1, B / int(lane.trees.size()));
+        const int n_use = std::min<int>(int(active.size()), B / quota);
         lane.slot_begin.assign(n_use, 0);
         lane.slot_count.assign(n_use, 0);
         lane.n_new.assign(n_use, 0);

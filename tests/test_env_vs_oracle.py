@@ -118,3 +118,22 @@ def test_descriptor_is_192_bytes_and_round_trips(hip_lib):
     assert len(d) == 192
     bb = np.frombuffer(d, dtype=np.uint64, count=14)
     assert bin(int(bb[0])).count("1") == 7 and int(d[122]) == 1   # 7 white pawns on board; black to move
+
+
+@pytest.mark.parametrize("variant", ["crazyhouse", "chess"])
+def test_reference_calibration_games_replay_identically(variant, hip_lib):
+    """Every move of the reference's hard-coded games (chessbatchstream.cpp:44-94) is legal in product and oracle and both
+    reach identical FENs / planes along the way."""
+    from crazyara_amd import openings
+    for game in openings.games(variant):
+        p = env.Position("", False, variant)
+        b = co.Board(None, False, variant)
+        for i, mv in enumerate(game):
+            assert mv in b.legal_uci(), (mv, b.fen())
+            assert p.push_uci(mv), (mv, p.fen())
+            b.push_uci(mv)
+            assert p.fen() == b.fen()
+            if i % 7 == 0:
+                mode = 0 if variant == "crazyhouse" else 1
+                assert np.array_equal(p.planes(mode, 3, True), co.board_to_planes(b, mode, 3, True))
+    assert len(openings.position_fens("crazyhouse")) > 200

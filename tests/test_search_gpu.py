@@ -1,0 +1,68 @@
+"""GPU: the whole hot path end to end -- position -> 192-byte descriptor -> GPU plane builder -> RISE forward -> policy
+gather in the leaf collector -- against the oracle chain (oracle planes -> oracle NN -> oracle policy index)."""
+import numpy as np
+import pytest
+import torch
+
+import nn_cases
+from crazyara_amd import env, openings, search
+from crazyara_amd.neuralnetapi import HipAPI
+from oracle import chess_oracle as co
+from oracle import rise_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+
+def test_root_priors_and_value_match_oracle_chain(tmp_path, hip_lib):
+    cfg, sd, _ = nn_cases.make_case("risev2-3")
+    d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
+    fens = openings.position_fens("crazyhouse")[::23][:8]
+    net = HipAPI(0, 8, d, "float32")
+    st = search.default_settings(mode=0, version_major=1, node_policy_temperature=1.0)
+    pool = search.SearchPool(st, net_a=net)
+    for f in fens:
+        pool.add_position(f, False, "crazyhouse")
+    stats = pool.run(simulations=1, threads=2)          # evaluates the roots (+1 simulation each)
+    assert stats.nn_evals >= len(fens)
+    pm = co.PolicyMap(co.MODE_CRAZYHOUSE)
+    for i, f in enumerate(fens):
+        b = co.Board(f, False, "crazyhouse")
+        x = torch.from_numpy(co.board_to_planes(b, co.MODE_CRAZYHOUSE, 1, True)[None])
+        v, p, _ = ro.predict(cfg, sd, x)
+        exp = {b.move_uci(m): float(p[0, pm.index(b, m, True)]) for m in b.legal_moves()}
+        # root node keeps every legal move with its gathered prior (T = 1: no renormalisation)
+        lib = __import__("crazyara_amd._capi", fromlist=["x"]).load()
+        info = pool.tree_info(i)
+        assert abs(info["root_value"] - float(v[0])) < 1e-4 or info["root_visits"] > 0
+        moves, visits, q, pri = pool.root_children(i)
+        pos = env.Position(f, False, "crazyhouse")
+        for m, pr in zip(moves, pri):
+            assert abs(exp[pos.move_uci(m)] - float(pr)) < 1e-6
+        # children are sorted by descending prior, so the first expanded child is the oracle's argmax move
+        best = max(exp, key=exp.get)
+        assert abs(exp[pos.move_uci(moves[0])] - exp[best]) < 1e-7
+    pool.close()
+    net.close()
+
+
+def test_two_lane_pool_on_opening_set(tmp_path, hip_lib):
+    cfg, sd, _ = nn_cases.make_case("risev2-3")
+    d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
+    a, b = HipAPI(0, 64, d, "float16"), HipAPI(0, 64, d, "float16")
+    st = search.default_settings(mode=0, version_major=1)
+    pool = search.SearchPool(st, net_a=a, net_b=b)
+    fens = openings.position_fens("crazyhouse")[:16]
+    for f in fens:
+        pool.add_position(f, False, "crazyhouse")
+    stats = pool.run(simulations=200, threads=4)
+    assert stats.simulations >= 16 * 200 and stats.nodes > 0 and stats.nn_evals > 16 and stats.seconds > 0
+    for i, f in enumerate(fens):
+        info = pool.tree_info(i)
+        assert info["root_visits"] >= 200 and info["node_count"] <= info["root_visits"]
+        assert pool.best_move(i) in env.Position(f, False, "crazyhouse").legal_uci()
+    # second `go` on the same pool reuses the trees (tree reuse, mctsagent.cpp:136-164): limits count from the new start
+    stats2 = pool.run(simulations=50, threads=4)
+    assert stats2.simulations >= 16 * 50
+    pool.close()
+    a.close()
+    b.close()

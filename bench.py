@@ -46,7 +46,9 @@ def cpu_baseline(cfg, sd, x, budget_s=15.0):
     """Reference CPU path timed beside the GPU: the oracle restatement of the reference PyTorch model (same torch ops,
     fp32, eval, softmax included) on the host cores.  Bounded sample: whole batches of 256 until ~budget_s elapsed."""
     from oracle import rise_oracle as ro
-    cores = os.cpu_count() or 1
+    # measured on the MI355X host (256 logical CPUs): torch CPU inference peaks at 16 threads (8: 183, 16: 474, 32: 374,
+    # 64: 198, 128: 80 evals/s on this model) -- more threads oversubscribe the 8x8 convolutions
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     ro.predict(cfg, sd, x[:32])  # warm-up
     n, t0 = 0, time.perf_counter()
@@ -169,7 +171,9 @@ def main():
         flops_total = net.flops_per_position() * args.batch
         # algorithmic FLOPs of the dominant kernel's launches (1x1 expand/project GEMMs of all blocks)
         cops = cfg.channels_operating()
-        if dom == "conv_gemm_1x1":
+        if dom == "fused_block":
+            dom_flops = sum(2.0 * 64 * c * (2 * cfg.channels + 9) for c in cops) * args.batch
+        elif dom == "conv_gemm_1x1":
             dom_flops = sum(2.0 * 64 * cfg.channels * c * 2 for c in cops) * args.batch
         elif dom == "conv_gemm_3x3":
             dom_flops = 2.0 * 64 * 9 * (cfg.nb_input_channels * 256 + 256 * 256 + 256 * cfg.channels_policy_head) * args.batch

@@ -37,6 +37,25 @@ struct ConvArgs {
 
 template <typename T> void launch_conv_gemm(const ConvArgs& a, hipStream_t s);
 
+// Fused mobile-bottleneck block (_BottlekneckResidualBlock, builder_util.py:437-475):
+//   y = x + BN3(conv1x1_project(ReLU(BN2(dw_kxk(ReLU(BN1(conv1x1_expand(x))))))))     (x already SE-scaled if the block has SE)
+// One workgroup per board; the C_op-wide intermediate never leaves the CU (LDS tiles of 64 channels), the 256 x 64
+// project accumulator lives in registers.  Algorithmic HBM bytes per board: 2 * 64*C*sizeof(T) (x in, y out); weights
+// (2*C*C_op*sizeof(T) + small) stream from L2.
+struct BlockArgs {
+    const void* x;        // [B][64][C] T
+    void* y;              // [B][64][C] T
+    const void* w1pk;     // expand  weights packed (cout = cop_pad, k = C)
+    const float* b1;      // [cop_pad]
+    const float* wdw;     // [ks*ks][cop_pad] float (folded), zero padded
+    const float* b2;      // [cop_pad]
+    const void* w3pk;     // project weights packed (cout = C, k = cop_pad)
+    const float* b3;      // [C]
+    int batch, C, cop_pad, ks;
+};
+template <typename T> void launch_block(const BlockArgs& a, hipStream_t s);
+template <typename T> void init_block_kernel_attributes();
+
 // depthwise k x k (k = 3 or 5) + folded BN + ReLU.  w: [k*k][C] float, bias: [C] float
 template <typename T> void launch_depthwise(const T* x, T* y, const float* w, const float* bias, int batch, int C, int ks,
                                             hipStream_t s);

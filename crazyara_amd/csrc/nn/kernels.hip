@@ -435,3 +435,233 @@ template void launch_planes_to_act<half_t>(const float*, half_t*, int, int, int,
 template void launch_planes_to_act<float>(const float*, float*, int, int, int, hipStream_t);
 
 }  // namespace cra
+
+// ================================================================================================================
+// Fused bottleneck block: expand (MFMA) -> depthwise (VALU, via LDS) -> project (MFMA, register accumulator) -> +x
+// ================================================================================================================
+namespace cra {
+
+template <typename T, int KS> struct BlockGeomK {
+    static constexpr int C = 256;                       // residual-stream width the kernel is specialised for
+    static constexpr int CK = 64;                       // C_op channels per chunk
+    static constexpr int PAD = 16 / int(sizeof(T));
+    static constexpr int XROW = C + PAD;
+    static constexpr int TROW = CK + PAD;
+    static constexpr int WDW = KS * KS * CK + 2 * CK;   // floats: depthwise taps [KS*KS][CK], then b1[CK], b2[CK] of the chunk
+    static constexpr size_t lds_bytes = (size_t(64) * XROW + 2 * size_t(64) * TROW) * sizeof(T) + size_t(WDW) * sizeof(float);
+};
+
+// Software pipeline per chunk (4 waves, one board):
+//   E  expand MFMAs (w1 fragments prefetched into registers during the previous P phase; x tile from LDS)
+//      -> epilogue writes the chunk's 64 x 64 tile t1 (+BN1 bias, ReLU) and parks the prefetched depthwise taps/biases in LDS
+//   -- barrier --   (w3 fragments of this chunk are requested here, they land while D runs)
+//   D  depthwise k x k on the VALU from t1 (taps in registers for 3x3), +BN2 bias, ReLU -> t2
+//   -- barrier --   (w1 fragments + depthwise taps + biases of the NEXT chunk are requested here, they land while P runs)
+//   P  project MFMAs into the 64(cout) x 64(square) register accumulator of each wave
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void block_kernel(const BlockArgs a) {
+    using frag = typename VT<T>::frag;
+    using G = BlockGeomK<T, KS>;
+    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NT = KS * KS;
+    constexpr int NW4 = (NT * CK + 2 * CK) / 4;          // float4s of per-chunk depthwise parameters
+    constexpr int W4_PER_THREAD = (NW4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xs = reinterpret_cast<T*>(smem);          // [64][XROW]  block input (also the residual)
+    T* t1 = xs + 64 * XROW;                      // [64][TROW]  expand output of the current chunk
+    T* t2 = t1 + 64 * TROW;                      // [64][TROW]  depthwise output of the current chunk
+    float* wl = reinterpret_cast<float*>(t2 + 64 * TROW);   // [NT][CK] taps, b1[CK], b2[CK]
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const int nchunk = a.cop_pad / CK;
+    const int nslab3 = a.cop_pad >> 5;
+    const frag* w1base = reinterpret_cast<const frag*>(a.w1pk) + lane;
+    const frag* w3base = reinterpret_cast<const frag*>(a.w3pk) + lane;
+
+    // per-chunk depthwise parameter prefetch: element i of [taps | b1 | b2] (float4 granularity)
+    auto dw_param_ptr = [&](int ch, int i4) -> const float* {
+        const int e = i4 * 4;
+        if (e < NT * CK) return a.wdw + size_t(e / CK) * a.cop_pad + ch * CK + (e % CK);
+        if (e < NT * CK + CK) return a.b1 + ch * CK + (e - NT * CK);
+        return a.b2 + ch * CK + (e - NT * CK - CK);
+    };
+    frag w1f[C / 32];
+    f32x4 dwp[W4_PER_THREAD];
+    auto prefetch_chunk = [&](int ch) {
+        const frag* w1 = w1base + size_t(ch * 4 + wave) * (C / 32) * 64;
+#pragma unroll
+        for (int s = 0; s < C / 32; ++s) w1f[s] = w1[s * 64];
+#pragma unroll
+        for (int k = 0; k < W4_PER_THREAD; ++k) {
+            const int i4 = tid + k * 256;
+            if (i4 < NW4) dwp[k] = *reinterpret_cast<const f32x4*>(dw_param_ptr(ch, i4));
+        }
+    };
+    prefetch_chunk(0);
+
+    const T* xb = reinterpret_cast<const T*>(a.x) + size_t(b) * 64 * C;
+    {
+        constexpr int vec_per_row = C * int(sizeof(T)) / 16;
+        for (int i = tid; i < 64 * vec_per_row; i += 256) {
+            const int r = i / vec_per_row, v = i - r * vec_per_row;
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(xs + r * XROW) + v * 16) =
+                *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(xb + size_t(r) * C) + v * 16);
+        }
+    }
+    __syncthreads();
+
+    f32x4 accP[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accP[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // depthwise thread mapping: 8 channels x 2 squares
+    const int cg = tid & 7, sqb = tid >> 3;
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        // ---------------- E: expand, 16 channels x 64 squares per wave, K = C ----------------
+        f32x4 accE[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accE[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < C / 32; ++s) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const frag bf = *reinterpret_cast<const frag*>(xs + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                mma_k32(w1f[s], bf, accE[t]);
+            }
+        }
+        // park this chunk's depthwise parameters in LDS (wl was last read in the previous chunk's D phase, two barriers ago)
+#pragma unroll
+        for (int k = 0; k < W4_PER_THREAD; ++k) {
+            const int i4 = tid + k * 256;
+            if (i4 < NW4) *reinterpret_cast<f32x4*>(wl + i4 * 4) = dwp[k];
+        }
+        __syncthreads();   // wl visible (b1 is read from it right below); also orders t1 writes after the previous D reads
+        {
+            const int cl = wave * 16 + lg * 4;           // channel inside the chunk
+            float bs[4];
+            load4<float>(wl + NT * CK + cl, bs);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(accE[t][r] + bs[r], 0.f);
+                store4<T>(t1 + (t * 16 + l15) * TROW + cl, v);
+            }
+        }
+        // request this chunk's project fragments now; they land while the depthwise phase runs
+        frag w3f[2][4];
+#pragma unroll
+        for (int s2 = 0; s2 < CK / 32; ++s2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w3f[s2][j] = w3base[(size_t(wave * 4 + j) * nslab3 + ch * (CK / 32) + s2) * 64];
+        __syncthreads();
+        // ---------------- D: depthwise k x k + BN + ReLU (fp32 accumulate) ----------------
+        {
+            float bias2[8];
+            load8<float>(wl + NT * CK + CK + cg * 8, bias2);
+            if constexpr (KS == 3) {
+                float wr[9][8];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) load8<float>(wl + tap * CK + cg * 8, wr[tap]);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int sq = sqb + 32 * jj;
+                    const int py = sq >> 3, px = sq & 7;
+                    float acc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = bias2[j];
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int ny = py + tap / 3 - 1, nx = px + tap % 3 - 1;
+                        if ((unsigned(ny) < 8u) && (unsigned(nx) < 8u)) {
+                            float xv[8];
+                            load8<T>(t1 + (ny * 8 + nx) * TROW + cg * 8, xv);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[j] = fmaf(wr[tap][j], xv[j], acc[j]);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+                    store8<T>(t2 + sq * TROW + cg * 8, acc);
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int sq = sqb + 32 * jj;
+                    const int py = sq >> 3, px = sq & 7;
+                    float acc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = bias2[j];
+#pragma unroll
+                    for (int tap = 0; tap < NT; ++tap) {
+                        const int ny = py + tap / KS - KS / 2, nx = px + tap % KS - KS / 2;
+                        if ((unsigned(ny) < 8u) && (unsigned(nx) < 8u)) {
+                            float xv[8], wv[8];
+                            load8<T>(t1 + (ny * 8 + nx) * TROW + cg * 8, xv);
+                            load8<float>(wl + tap * CK + cg * 8, wv);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[j] = fmaf(wv[j], xv[j], acc[j]);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+                    store8<T>(t2 + sq * TROW + cg * 8, acc);
+                }
+            }
+        }
+        __syncthreads();
+        // request the next chunk's expand fragments / depthwise parameters; they land while the project MFMAs run
+        if (ch + 1 < nchunk) prefetch_chunk(ch + 1);
+        // ---------------- P: project, 64 couts x 64 squares per wave, K = CK (accumulates over chunks) ----------------
+#pragma unroll
+        for (int s2 = 0; s2 < CK / 32; ++s2) {
+            frag bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const frag*>(t2 + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mma_k32(w3f[s2][j], bf[t], accP[j][t]);
+        }
+    }
+
+    // ---------------- epilogue: + BN3 bias + residual (the SE-scaled input tile) ----------------
+    T* yb = reinterpret_cast<T*>(a.y) + size_t(b) * 64 * C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co0 = (wave * 4 + j) * 16 + lg * 4;
+        float bs[4];
+        load4<float>(a.b3 + co0, bs);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int sq = t * 16 + l15;
+            float rv[4], v[4];
+            load4<T>(xs + sq * XROW + co0, rv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = accP[j][t][r] + bs[r] + rv[r];
+            store4<T>(yb + size_t(sq) * C + co0, v);
+        }
+    }
+}
+
+template <typename T> void init_block_kernel_attributes() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_kernel<T, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              int(BlockGeomK<T, 3>::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_kernel<T, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              int(BlockGeomK<T, 5>::lds_bytes));
+}
+template void init_block_kernel_attributes<half_t>();
+template void init_block_kernel_attributes<float>();
+
+template <typename T> void launch_block(const BlockArgs& a, hipStream_t s) {
+    constexpr size_t lds3 = BlockGeomK<T, 3>::lds_bytes, lds5 = BlockGeomK<T, 5>::lds_bytes;
+    if (a.ks == 3) hipLaunchKernelGGL((block_kernel<T, 3>), dim3(a.batch), dim3(256), lds3, s, a);
+    else hipLaunchKernelGGL((block_kernel<T, 5>), dim3(a.batch), dim3(256), lds5, s, a);
+}
+template void launch_block<half_t>(const BlockArgs&, hipStream_t);
+template void launch_block<float>(const BlockArgs&, hipStream_t);
+
+}  // namespace cra

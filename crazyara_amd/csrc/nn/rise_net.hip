@@ -70,7 +70,7 @@ std::vector<T> pack_dense(const Folded& f, int cout, int cin, int ks, int cout_p
     return out;
 }
 
-enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax };
+enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block };
 
 struct Op {
     OpKind kind;
@@ -81,6 +81,7 @@ struct Op {
     const float *w0 = nullptr, *w1 = nullptr, *b0 = nullptr;
     int C = 0, ks = 0, se_kind = 0;
     ValueHeadArgs vh{};
+    BlockArgs blk{};
 };
 }  // namespace
 
@@ -113,8 +114,14 @@ struct RiseNet::Impl {
 RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, const std::string& precision)
     : device_(device_id), impl_(new Impl) {
     if (batch_size <= 0) throw std::invalid_argument("batch size must be positive");
-    if (precision == "float16" || precision == "fp16" || precision == "half") fp16_ = true;
-    else if (precision == "float32" || precision == "fp32") fp16_ = false;
+    std::string prec = precision;
+    const std::string unfused_tag = "-unfused";   // layer-granular kernels (A/B reference for the fused block kernel)
+    if (prec.size() > unfused_tag.size() && prec.compare(prec.size() - unfused_tag.size(), unfused_tag.size(), unfused_tag) == 0) {
+        fused_ = false;
+        prec.resize(prec.size() - unfused_tag.size());
+    }
+    if (prec == "float16" || prec == "fp16" || prec == "half") fp16_ = true;
+    else if (prec == "float32" || prec == "fp32") fp16_ = false;
     else throw std::invalid_argument("unsupported precision '" + precision + "' (float16 | float32)");
     design_.batch = batch_size;
 
@@ -275,23 +282,50 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         } else if (se_types[i] != "none" && !se_types[i].empty()) {
             throw std::runtime_error("unsupported se_type " + se_types[i]);
         }
-        add_conv(p + ".body.0", p + ".body.1", cur, e, nullptr, C, C, cop, 1, true, nullptr);   // 1x1 expand + BN + ReLU
-        {   // depthwise k x k + BN + ReLU
-            Folded fd = fold_bn(nf, p + ".body.3", p + ".body.4");
-            std::vector<float> w(size_t(k) * k * cop);
-            for (int c = 0; c < cop; ++c) for (int t = 0; t < k * k; ++t) w[size_t(t) * cop + c] = float(fd.w[size_t(c) * k * k + t]);
+        if (fused_ && C == 256) {
+            // fused bottleneck block: expand -> depthwise -> project -> +x in one launch (kernels.hip: block_kernel)
+            const int cop_pad = round_up(cop, 64);
+            Folded f1 = fold_bn(nf, p + ".body.0", p + ".body.1");
+            Folded f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
+            Folded f3 = fold_bn(nf, p + ".body.6", p + ".body.7");
+            std::vector<float> w(size_t(k) * k * cop_pad, 0.f);
+            for (int c = 0; c < cop; ++c) for (int t = 0; t < k * k; ++t) w[size_t(t) * cop_pad + c] = float(f2.w[size_t(c) * k * k + t]);
             Op op;
-            op.kind = OpKind::Depthwise;
-            op.x = e;
-            op.y = f;
-            op.w0 = im.upload(w);
-            op.b0 = im.upload_d2f(fd.b);
-            op.C = cop;
-            op.ks = k;
+            op.kind = OpKind::Block;
+            BlockArgs& ba = op.blk;
+            ba.x = cur;
+            ba.y = nxt;
+            ba.w1pk = im.upload(pack_dense<T>(f1, cop, C, 1, cop_pad, C));
+            ba.b1 = im.upload_d2f(f1.b, cop_pad);
+            ba.wdw = im.upload(w);
+            ba.b2 = im.upload_d2f(f2.b, cop_pad);
+            ba.w3pk = im.upload(pack_dense<T>(f3, C, cop, 1, C, cop_pad));
+            ba.b3 = im.upload_d2f(f3.b, C);
+            ba.batch = B;
+            ba.C = C;
+            ba.cop_pad = cop_pad;
+            ba.ks = k;
             im.ops.push_back(op);
-            macs += double(kSquares) * cop * k * k;
+            macs += double(kSquares) * cop * (2.0 * C + k * k);
+        } else {
+            add_conv(p + ".body.0", p + ".body.1", cur, e, nullptr, C, C, cop, 1, true, nullptr);   // 1x1 expand + BN + ReLU
+            {   // depthwise k x k + BN + ReLU
+                Folded fd = fold_bn(nf, p + ".body.3", p + ".body.4");
+                std::vector<float> w(size_t(k) * k * cop);
+                for (int c = 0; c < cop; ++c) for (int t = 0; t < k * k; ++t) w[size_t(t) * cop + c] = float(fd.w[size_t(c) * k * k + t]);
+                Op op;
+                op.kind = OpKind::Depthwise;
+                op.x = e;
+                op.y = f;
+                op.w0 = im.upload(w);
+                op.b0 = im.upload_d2f(fd.b);
+                op.C = cop;
+                op.ks = k;
+                im.ops.push_back(op);
+                macs += double(kSquares) * cop * k * k;
+            }
+            add_conv(p + ".body.6", p + ".body.7", f, nxt, cur, cop, cop, C, 1, false, nullptr);    // 1x1 project + BN + residual
         }
-        add_conv(p + ".body.6", p + ".body.7", f, nxt, cur, cop, cop, C, 1, false, nullptr);    // 1x1 project + BN + residual
         std::swap(cur, nxt);
     }
     // _PolicyHead (select_policy_from_plane), builder_util.py:206-243
@@ -339,6 +373,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         macs += double(kSquares) * C * cv;
         im.ops.push_back(op);
     }
+    init_block_kernel_attributes<T>();
     design_.flops_per_position = 2.0 * macs;
     launches_ = int(im.ops.size());
 }
@@ -358,6 +393,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s) {
         case OpKind::SE: launch_se<T>(static_cast<T*>(op.y), op.se_kind, op.w0, op.w1, op.b0, B, op.C, s); break;
         case OpKind::ValueHead: launch_value_head<T>(op.vh, s); break;
         case OpKind::Softmax: launch_softmax(d_logits_, d_probs_, B, design_.nb_policy, s); break;
+        case OpKind::Block: launch_block<T>(op.blk, s); break;
     }
 }
 
@@ -375,6 +411,7 @@ const char* RiseNet::op_name(int i) const {
         case OpKind::SE: return "se";
         case OpKind::ValueHead: return "value_head";
         case OpKind::Softmax: return "softmax";
+        case OpKind::Block: return "fused_block";
     }
     return "?";
 }

@@ -55,6 +55,7 @@ struct BlockArgs {
 };
 template <typename T> void launch_block(const BlockArgs& a, hipStream_t s);
 template <typename T> void init_block_kernel_attributes();
+template <typename T> int block_chunk_channels();   // C_op must be padded to a multiple of this
 
 // depthwise k x k (k = 3 or 5) + folded BN + ReLU.  w: [k*k][C] float, bias: [C] float
 template <typename T> void launch_depthwise(const T* x, T* y, const float* w, const float* bias, int batch, int C, int ks,

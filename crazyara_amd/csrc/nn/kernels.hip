@@ -441,9 +441,10 @@ template void launch_planes_to_act<float>(const float*, float*, int, int, int, h
 // ================================================================================================================
 namespace cra {
 
-template <typename T, int KS> struct BlockGeomK {
+template <typename T, int KS, int NW> struct BlockGeomK {
     static constexpr int C = 256;                       // residual-stream width the kernel is specialised for
-    static constexpr int CK = 64;                       // C_op channels per chunk
+    static constexpr int CK = 16 * NW;                  // C_op channels per chunk: one 16-channel MFMA tile per wave
+    static constexpr int NTHR = 64 * NW;
     static constexpr int PAD = 16 / int(sizeof(T));
     static constexpr int XROW = C + PAD;
     static constexpr int TROW = CK + PAD;
@@ -458,13 +459,15 @@ template <typename T, int KS> struct BlockGeomK {
 //   D  depthwise k x k on the VALU from t1 (taps in registers for 3x3), +BN2 bias, ReLU -> t2
 //   -- barrier --   (w1 fragments + depthwise taps + biases of the NEXT chunk are requested here, they land while P runs)
 //   P  project MFMAs into the 64(cout) x 64(square) register accumulator of each wave
-template <typename T, int KS>
-__global__ __launch_bounds__(256) void block_kernel(const BlockArgs a) {
+template <typename T, int KS, int NW>
+__global__ __launch_bounds__(64 * NW) void block_kernel(const BlockArgs a) {
     using frag = typename VT<T>::frag;
-    using G = BlockGeomK<T, KS>;
-    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NT = KS * KS;
+    using G = BlockGeomK<T, KS, NW>;
+    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NT = KS * KS, NTHR = G::NTHR;
     constexpr int NW4 = (NT * CK + 2 * CK) / 4;          // float4s of per-chunk depthwise parameters
-    constexpr int W4_PER_THREAD = (NW4 + 255) / 256;
+    constexpr int W4_PER_THREAD = (NW4 + NTHR - 1) / NTHR;
+    constexpr int NJ = C / 16 / NW;                      // cout tiles per wave in the project phase
+    constexpr int NCG = CK / 8;                          // 8-channel groups per chunk (depthwise thread mapping)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* xs = reinterpret_cast<T*>(smem);          // [64][XROW]  block input (also the residual)
     T* t1 = xs + 64 * XROW;                      // [64][TROW]  expand output of the current chunk
@@ -488,12 +491,12 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockArgs a) {
     frag w1f[C / 32];
     f32x4 dwp[W4_PER_THREAD];
     auto prefetch_chunk = [&](int ch) {
-        const frag* w1 = w1base + size_t(ch * 4 + wave) * (C / 32) * 64;
+        const frag* w1 = w1base + size_t(ch * NW + wave) * (C / 32) * 64;
 #pragma unroll
         for (int s = 0; s < C / 32; ++s) w1f[s] = w1[s * 64];
 #pragma unroll
         for (int k = 0; k < W4_PER_THREAD; ++k) {
-            const int i4 = tid + k * 256;
+            const int i4 = tid + k * NTHR;
             if (i4 < NW4) dwp[k] = *reinterpret_cast<const f32x4*>(dw_param_ptr(ch, i4));
         }
     };
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockArgs a) {
     const T* xb = reinterpret_cast<const T*>(a.x) + size_t(b) * 64 * C;
     {
         constexpr int vec_per_row = C * int(sizeof(T)) / 16;
-        for (int i = tid; i < 64 * vec_per_row; i += 256) {
+        for (int i = tid; i < 64 * vec_per_row; i += NTHR) {
             const int r = i / vec_per_row, v = i - r * vec_per_row;
             *reinterpret_cast<uint4*>(reinterpret_cast<char*>(xs + r * XROW) + v * 16) =
                 *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(xb + size_t(r) * C) + v * 16);
@@ -510,14 +513,14 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockArgs a) {
     }
     __syncthreads();
 
-    f32x4 accP[4][4];
+    f32x4 accP[NJ][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int t = 0; t < 4; ++t) accP[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // depthwise thread mapping: 8 channels x 2 squares
-    const int cg = tid & 7, sqb = tid >> 3;
+    const int cg = tid % NCG, sqb = tid / NCG;
 
     for (int ch = 0; ch < nchunk; ++ch) {
         // ---------------- E: expand, 16 channels x 64 squares per wave, K = C ----------------
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockArgs a) {
         // park this chunk's depthwise parameters in LDS (wl was last read in the previous chunk's D phase, two barriers ago)
 #pragma unroll
         for (int k = 0; k < W4_PER_THREAD; ++k) {
-            const int i4 = tid + k * 256;
+            const int i4 = tid + k * NTHR;
             if (i4 < NW4) *reinterpret_cast<f32x4*>(wl + i4 * 4) = dwp[k];
         }
         __syncthreads();   // wl visible (b1 is read from it right below); also orders t1 writes after the previous D reads
@@ -552,11 +555,11 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockArgs a) {
             }
         }
         // request this chunk's project fragments now; they land while the depthwise phase runs
-        frag w3f[2][4];
+        frag w3f[CK / 32][NJ];
 #pragma unroll
         for (int s2 = 0; s2 < CK / 32; ++s2)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w3f[s2][j] = w3base[(size_t(wave * 4 + j) * nslab3 + ch * (CK / 32) + s2) * 64];
+            for (int j = 0; j < NJ; ++j) w3f[s2][j] = w3base[(size_t(wave * NJ + j) * nslab3 + ch * (CK / 32) + s2) * 64];
         __syncthreads();
         // ---------------- D: depthwise k x k + BN + ReLU (fp32 accumulate) ----------------
         {
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const frag*>(t2 + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) mma_k32(w3f[s2][j], bf[t], accP[j][t]);
         }
@@ -631,8 +634,8 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockArgs a) {
     // ---------------- epilogue: + BN3 bias + residual (the SE-scaled input tile) ----------------
     T* yb = reinterpret_cast<T*>(a.y) + size_t(b) * 64 * C;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int co0 = (wave * 4 + j) * 16 + lg * 4;
+    for (int j = 0; j < NJ; ++j) {
+        const int co0 = (wave * NJ + j) * 16 + lg * 4;
         float bs[4];
         load4<float>(a.b3 + co0, bs);
 #pragma unroll
@@ -647,19 +650,32 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockArgs a) {
     }
 }
 
+template <typename T> struct BlockWaves;
+template <> struct BlockWaves<half_t> { static constexpr int NW = 8; };   // 512 threads: two waves per SIMD hide LDS / MFMA latencies
+template <> struct BlockWaves<float> { static constexpr int NW = 4; };    // f32 fragments are twice as wide: stay at one wave per SIMD
+
 template <typename T> void init_block_kernel_attributes() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_kernel<T, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              int(BlockGeomK<T, 3>::lds_bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_kernel<T, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              int(BlockGeomK<T, 5>::lds_bytes));
+    constexpr int NW = BlockWaves<T>::NW;
+    constexpr int lds3 = int(BlockGeomK<T, 3, NW>::lds_bytes), lds5 = int(BlockGeomK<T, 5, NW>::lds_bytes);
+    auto k3 = &block_kernel<T, 3, NW>;
+    auto k5 = &block_kernel<T, 5, NW>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k5), hipFuncAttributeMaxDynamicSharedMemorySize, lds5);
 }
 template void init_block_kernel_attributes<half_t>();
 template void init_block_kernel_attributes<float>();
 
+template <typename T> int block_chunk_channels() { return BlockGeomK<T, 3, BlockWaves<T>::NW>::CK; }
+template int block_chunk_channels<half_t>();
+template int block_chunk_channels<float>();
+
 template <typename T> void launch_block(const BlockArgs& a, hipStream_t s) {
-    constexpr size_t lds3 = BlockGeomK<T, 3>::lds_bytes, lds5 = BlockGeomK<T, 5>::lds_bytes;
-    if (a.ks == 3) hipLaunchKernelGGL((block_kernel<T, 3>), dim3(a.batch), dim3(256), lds3, s, a);
-    else hipLaunchKernelGGL((block_kernel<T, 5>), dim3(a.batch), dim3(256), lds5, s, a);
+    constexpr int NW = BlockWaves<T>::NW;
+    constexpr size_t lds3 = BlockGeomK<T, 3, NW>::lds_bytes, lds5 = BlockGeomK<T, 5, NW>::lds_bytes;
+    auto k3 = &block_kernel<T, 3, NW>;
+    auto k5 = &block_kernel<T, 5, NW>;
+    if (a.ks == 3) hipLaunchKernelGGL(k3, dim3(a.batch), dim3(64 * NW), lds3, s, a);
+    else hipLaunchKernelGGL(k5, dim3(a.batch), dim3(64 * NW), lds5, s, a);
 }
 template void launch_block<half_t>(const BlockArgs&, hipStream_t);
 template void launch_block<float>(const BlockArgs&, hipStream_t);

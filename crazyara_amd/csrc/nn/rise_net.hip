@@ -284,7 +284,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
         if (fused_ && C == 256) {
             // fused bottleneck block: expand -> depthwise -> project -> +x in one launch (kernels.hip: block_kernel)
-            const int cop_pad = round_up(cop, 64);
+            const int cop_pad = round_up(cop, block_chunk_channels<T>());
             Folded f1 = fold_bn(nf, p + ".body.0", p + ".body.1");
             Folded f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
             Folded f3 = fold_bn(nf, p + ".body.6", p + ".body.7");

@@ -33,6 +33,8 @@ struct ConvArgs {
     int ks;               // 1 or 3
     int relu;
     int out_policy_f32;   // 1: write float logits channel-major
+    int out_flat;         // 1: write T channel-major flat, out[b*flat_pitch + co*64 + sq] (the value head's .view(-1, nb_flatten))
+    int flat_pitch;
 };
 
 template <typename T> void launch_conv_gemm(const ConvArgs& a, hipStream_t s);
@@ -52,6 +54,8 @@ struct BlockArgs {
     const void* w3pk;     // project weights packed (cout = C, k = cop_pad)
     const float* b3;      // [C]
     int batch, C, cop_pad, ks;
+    const float* gate;    // optional [B][C]: SE gate multiplied into x while the tile is loaded (residual uses the gated x)
+    float* pool_out;      // optional [B][C]: sum over the 64 squares of y (feeds the NEXT block's SE gate)
 };
 template <typename T> void launch_block(const BlockArgs& a, hipStream_t s);
 template <typename T> void init_block_kernel_attributes();
@@ -65,6 +69,13 @@ template <typename T> void launch_depthwise(const T* x, T* y, const float* w, co
 // kind 2 = eca_se: w1t [C][C] transposed centre tap, b1 [C].  hard-sigmoid gate (builder_util.py:452).
 template <typename T> void launch_se(T* x, int kind, const float* w1t, const float* w2t, const float* b1, int batch, int C,
                                      hipStream_t s);
+
+// SE gate MLP on pooled sums (the squeeze already happened in the producer's epilogue): gate[b][c] = hard_sigmoid(...)
+//  kind 1 (ca_se):  relu(W1 mean) -> W2 -> hard-sigmoid   w1t [C][C/2], w2t [C/2][C]
+//  kind 2 (eca_se): Wc mean + b -> hard-sigmoid            w1t [C][C],   b1 [C]
+// 8 boards per 1024-thread workgroup; every weight is loaded once per workgroup with all loads of a thread in flight.
+void launch_se_gate(const float* pool, float* gate, int kind, const float* w1t, const float* w2t, const float* b1, int batch, int C,
+                    hipStream_t s);
 
 struct ValueHeadArgs {
     const void* x;          // [B][64][C] T
@@ -83,6 +94,21 @@ struct ValueHeadArgs {
     int batch, C, cv, fc;
 };
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s);
+
+// last stage of the value head, one wave per board.
+//  tanh head : value = tanh(b2 + dot(w2, h[b]))            h: [B][fc] T (FC1 + ReLU output of the conv_gemm "FC" launch)
+//  WDLP head : wdl = W_wdl flat + b, plys = sigmoid(w_plys flat + b); value = -softmax(wdl)[0] + softmax(wdl)[2]; aux = [wdl, plys]
+struct ValueFinalArgs {
+    const void* in;         // T [B][n]  (n = fc for the tanh head, 64*cv for WDLP)
+    int n;
+    const float* w;         // [n] (tanh head)  or  [4][n] = wdl rows 0..2, plys row (WDLP)
+    float b[4];
+    int wdlp;
+    float* value;           // [B]
+    float* aux;             // [B][4] or nullptr
+    int batch;
+};
+template <typename T> void launch_value_final(const ValueFinalArgs& a, hipStream_t s);
 
 // row softmax over n logits per board (tensorrtapi.cpp:378-392 appends exactly this to policy_out)
 void launch_softmax(const float* logits, float* probs, int batch, int n, hipStream_t s);

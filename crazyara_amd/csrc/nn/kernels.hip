@@ -188,6 +188,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
+        } else if (a.out_flat) {
+            T* o = reinterpret_cast<T*>(a.out) + size_t(b) * a.flat_pitch;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = T(v[r]);
         } else {
             store4<T>(reinterpret_cast<T*>(a.out) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, v);
         }
@@ -295,6 +300,102 @@ __global__ __launch_bounds__(256) void se_kernel(T* __restrict__ x, int kind, co
     }
 }
 
+// ---- SE gate on pooled sums: 8 boards per 1024-thread workgroup -------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__ pool, float* __restrict__ gate,
+                                                       const float* __restrict__ w1t, const float* __restrict__ w2t,
+                                                       const float* __restrict__ b1, int batch) {
+    constexpr int C = 256, H = 128, NB = 8;
+    __shared__ float s_mean[NB][C];            //  8 KB
+    __shared__ float s_part[8 * NB * H];       // 32 KB (also reused as [4][NB][C])
+    __shared__ float s_h[NB][H];               //  4 KB
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * NB;
+    const int nb = min(NB, batch - b0);
+    for (int i = tid; i < NB * C; i += 1024) {
+        const int bb = i / C, c = i - bb * C;
+        s_mean[bb][c] = bb < nb ? pool[size_t(b0 + bb) * C + c] * (1.f / 64.f) : 0.f;
+    }
+    __syncthreads();
+    if (KIND == 1) {
+        {   // FC1: 128 outputs, K = 256 split in 8 slices of 32
+            const int j = tid & (H - 1), kq = tid >> 7;
+            float w[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) w[k] = w1t[size_t(kq * 32 + k) * H + j];
+            float acc[NB];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) acc[bb] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) acc[bb] = fmaf(w[k], s_mean[bb][kq * 32 + k], acc[bb]);
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) s_part[(kq * NB + bb) * H + j] = acc[bb];
+        }
+        __syncthreads();
+        {
+            const int bb = tid >> 7, j = tid & (H - 1);
+            float sum = 0.f;
+#pragma unroll
+            for (int kq = 0; kq < 8; ++kq) sum += s_part[(kq * NB + bb) * H + j];
+            s_h[bb][j] = fmaxf(sum, 0.f);
+        }
+        __syncthreads();
+        {   // FC2: 256 outputs, K = 128 split in 4 slices of 32
+            const int c = tid & (C - 1), kq = tid >> 8;
+            float w[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) w[k] = w2t[size_t(kq * 32 + k) * C + c];
+            float acc[NB];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) acc[bb] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) acc[bb] = fmaf(w[k], s_h[bb][kq * 32 + k], acc[bb]);
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) s_part[(kq * NB + bb) * C + c] = acc[bb];
+        }
+    } else {
+        // eca: 256 outputs, K = 256 split in 4 slices of 64
+        const int c = tid & (C - 1), kq = tid >> 8;
+        float acc[NB];
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) acc[bb] = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float w[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) w[k] = w1t[size_t(kq * 64 + h * 32 + k) * C + c];
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) acc[bb] = fmaf(w[k], s_mean[bb][kq * 64 + h * 32 + k], acc[bb]);
+        }
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) s_part[(kq * NB + bb) * C + c] = acc[bb];
+    }
+    __syncthreads();
+    for (int i = tid; i < NB * C; i += 1024) {
+        const int bb = i / C, c = i - bb * C;
+        if (bb < nb) {
+            float sum = KIND == 2 ? b1[c] : 0.f;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) sum += s_part[(kq * NB + bb) * C + c];
+            gate[size_t(b0 + bb) * C + c] = hard_sigmoid(sum);
+        }
+    }
+}
+
+void launch_se_gate(const float* pool, float* gate, int kind, const float* w1t, const float* w2t, const float* b1, int batch, int C,
+                    hipStream_t s) {
+    (void)C;   // specialised for C = 256 (checked by the caller)
+    dim3 grid((batch + 7) / 8), block(1024);
+    if (kind == 1) hipLaunchKernelGGL(se_gate_kernel<1>, grid, block, 0, s, pool, gate, w1t, w2t, b1, batch);
+    else hipLaunchKernelGGL(se_gate_kernel<2>, grid, block, 0, s, pool, gate, w1t, w2t, b1, batch);
+}
+
 template <typename T>
 void launch_se(T* x, int kind, const float* w1t, const float* w2t, const float* b1, int batch, int C, hipStream_t s) {
     hipLaunchKernelGGL((se_kernel<T>), dim3(batch), dim3(256), 0, s, x, kind, w1t, w2t, b1, C);
@@ -377,6 +478,48 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
     const float tot = block_sum_256(part, s_red);
     if (tid == 0) a.value[b] = tanhf(tot + a.b2);
 }
+
+template <typename T>
+__global__ __launch_bounds__(256) void value_final_kernel(const ValueFinalArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= a.batch) return;
+    const T* in = reinterpret_cast<const T*>(a.in) + size_t(b) * a.n;
+    if (!a.wdlp) {
+        float part = 0.f;
+        for (int i = lane; i < a.n; i += 64) part = fmaf(a.w[i], to_f(in[i]), part);
+        part = wave_sum(part);
+        if (lane == 0) a.value[b] = tanhf(part + a.b[0]);
+        return;
+    }
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < a.n; i += 64) {
+        const float f = to_f(in[i]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = fmaf(a.w[k * a.n + i], f, p[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = wave_sum(p[k]);
+    if (lane == 0) {
+        const float l0 = p[0] + a.b[0], l1 = p[1] + a.b[1], l2 = p[2] + a.b[2];
+        const float m = fmaxf(l0, fmaxf(l1, l2));
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+        const float inv = 1.f / (e0 + e1 + e2);
+        a.value[b] = -e0 * inv + e2 * inv;
+        if (a.aux) {
+            a.aux[b * 4 + 0] = l0;
+            a.aux[b * 4 + 1] = l1;
+            a.aux[b * 4 + 2] = l2;
+            a.aux[b * 4 + 3] = 1.f / (1.f + expf(-(p[3] + a.b[3])));
+        }
+    }
+}
+
+template <typename T> void launch_value_final(const ValueFinalArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((value_final_kernel<T>), dim3((a.batch + 3) / 4), dim3(256), 0, s, a);
+}
+template void launch_value_final<half_t>(const ValueFinalArgs&, hipStream_t);
+template void launch_value_final<float>(const ValueFinalArgs&, hipStream_t);
 
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s) {
     const size_t shmem = (size_t(kSquares) * a.cv + 8) * sizeof(float);
@@ -505,10 +648,25 @@ __global__ __launch_bounds__(64 * NW) void block_kernel(const BlockArgs a) {
     const T* xb = reinterpret_cast<const T*>(a.x) + size_t(b) * 64 * C;
     {
         constexpr int vec_per_row = C * int(sizeof(T)) / 16;
-        for (int i = tid; i < 64 * vec_per_row; i += NTHR) {
-            const int r = i / vec_per_row, v = i - r * vec_per_row;
-            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(xs + r * XROW) + v * 16) =
-                *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(xb + size_t(r) * C) + v * 16);
+        if (a.gate == nullptr) {
+            for (int i = tid; i < 64 * vec_per_row; i += NTHR) {
+                const int r = i / vec_per_row, v = i - r * vec_per_row;
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(xs + r * XROW) + v * 16) =
+                    *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(xb + size_t(r) * C) + v * 16);
+            }
+        } else {   // x := x * gate[b][c]  (_ChannelAttentionModule.forward: x * y.expand_as(x), builder_util.py:114)
+            constexpr int EPV = 16 / int(sizeof(T));     // elements per 16-byte vector
+            const float* g = a.gate + size_t(b) * C;
+            for (int i = tid; i < 64 * vec_per_row; i += NTHR) {
+                const int r = i / vec_per_row, v = i - r * vec_per_row;
+                float xv[EPV], gv[EPV];
+                if constexpr (EPV == 8) { load8<T>(xb + size_t(r) * C + v * 8, xv); load8<float>(g + v * 8, gv); }
+                else { load4<T>(xb + size_t(r) * C + v * 4, xv); load4<float>(g + v * 4, gv); }
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) xv[j] *= gv[j];
+                if constexpr (EPV == 8) store8<T>(xs + r * XROW + v * 8, xv);
+                else store4<T>(xs + r * XROW + v * 4, xv);
+            }
         }
     }
     __syncthreads();
@@ -638,14 +796,25 @@ __global__ __launch_bounds__(64 * NW) void block_kernel(const BlockArgs a) {
         const int co0 = (wave * NJ + j) * 16 + lg * 4;
         float bs[4];
         load4<float>(a.b3 + co0, bs);
+        float pool[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int sq = t * 16 + l15;
             float rv[4], v[4];
             load4<T>(xs + sq * XROW + co0, rv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = accP[j][t][r] + bs[r] + rv[r];
+            for (int r = 0; r < 4; ++r) {
+                v[r] = accP[j][t][r] + bs[r] + rv[r];
+                pool[r] += to_f(T(v[r]));               // pool what the next block will read
+            }
             store4<T>(yb + size_t(sq) * C + co0, v);
+        }
+        if (a.pool_out) {                               // squeeze (AdaptiveAvgPool2d) of the block output, fused here
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) pool[r] += __shfl_xor(pool[r], off, 64);
+            if (l15 == 0) store4<float>(a.pool_out + size_t(b) * C + co0, pool);
         }
     }
 }

@@ -70,7 +70,7 @@ std::vector<T> pack_dense(const Folded& f, int cout, int cin, int ks, int cout_p
     return out;
 }
 
-enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block };
+enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate };
 
 struct Op {
     OpKind kind;
@@ -82,6 +82,7 @@ struct Op {
     int C = 0, ks = 0, se_kind = 0;
     ValueHeadArgs vh{};
     BlockArgs blk{};
+    ValueFinalArgs vf{};
 };
 }  // namespace
 
@@ -245,6 +246,28 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     }
     add_conv("body_spatial.0.body.0", "body_spatial.0.body.1", x0, a0, nullptr, cin, cin_pad, C, 3, true, nullptr);   // _Stem
     T *cur = a0, *nxt = a1;
+    // SE plumbing for the fused path: the squeeze (per-channel sums) is produced by the previous block kernel's epilogue,
+    // a small gate kernel turns it into gate[b][c], and this block's prologue multiplies it into x while loading the tile.
+    float *se_pool = nullptr, *se_gate = nullptr;
+    const float* pending_gate = nullptr;
+    int last_block_op = -1;
+    auto add_se = [&](Op op) {
+        if (fused_ && C == 256 && last_block_op >= 0) {
+            if (!se_pool) {
+                se_pool = static_cast<float*>(im.dalloc(size_t(B) * C * sizeof(float)));
+                se_gate = static_cast<float*>(im.dalloc(size_t(B) * C * sizeof(float)));
+            }
+            im.ops[last_block_op].blk.pool_out = se_pool;
+            op.kind = OpKind::SEGate;
+            op.x = se_pool;
+            op.y = se_gate;
+            pending_gate = se_gate;
+        } else {
+            op.kind = OpKind::SE;      // in-place scaling kernel (input produced by the stem conv, or layer-granular path)
+            op.y = cur;
+        }
+        im.ops.push_back(op);
+    };
     for (size_t i = 0; i < cops.size(); ++i) {
         const std::string p = "body_spatial." + std::to_string(i + 1);
         const int cop = cops[i], k = ks[i];
@@ -255,13 +278,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             for (int j = 0; j < H; ++j) for (int c = 0; c < C; ++c) w1t[size_t(c) * H + j] = w1.data[size_t(j) * C + c];
             for (int c = 0; c < C; ++c) for (int j = 0; j < H; ++j) w2t[size_t(j) * C + c] = w2.data[size_t(c) * H + j];
             Op op;
-            op.kind = OpKind::SE;
             op.se_kind = 1;
-            op.y = cur;
             op.w0 = im.upload(w1t);
             op.w1 = im.upload(w2t);
             op.C = C;
-            im.ops.push_back(op);
+            add_se(op);
             macs += 2.0 * C * H;
         } else if (se_types[i] == "eca_se") {                           // _EfficientChannelAttentionModule, builder_util.py:49-80
             const TensorView& w = nf.get(p + ".se.body.0.weight");     // [C][C][kk]; the length-1 sequence only sees the centre tap
@@ -271,13 +292,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             const float* bs = nf.get(p + ".se.body.0.bias").data;
             for (int o = 0; o < C; ++o) b[o] = bs[o];
             Op op;
-            op.kind = OpKind::SE;
             op.se_kind = 2;
-            op.y = cur;
             op.w0 = im.upload(wt);
             op.b0 = im.upload(b);
             op.C = C;
-            im.ops.push_back(op);
+            add_se(op);
             macs += double(C) * C;
         } else if (se_types[i] != "none" && !se_types[i].empty()) {
             throw std::runtime_error("unsupported se_type " + se_types[i]);
@@ -305,6 +324,9 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             ba.C = C;
             ba.cop_pad = cop_pad;
             ba.ks = k;
+            ba.gate = pending_gate;
+            pending_gate = nullptr;
+            last_block_op = int(im.ops.size());
             im.ops.push_back(op);
             macs += double(kSquares) * cop * (2.0 * C + k * k);
         } else {
@@ -336,6 +358,89 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         op.kind = OpKind::Softmax;
         im.ops.push_back(op);
     }
+    if (fused_) {
+        // _ValueHead (builder_util.py:246-326) as three MFMA/wave-level launches instead of one latency-bound VALU kernel:
+        //   (1) conv1x1(C->cv)+BN+ReLU on the conv-GEMM kernel, written channel-major flat  (x.view(-1, nb_flatten))
+        //   (2) FC(nfl->fc)+ReLU as a GEMM over the BATCH: 64 boards play the role of the 64 "squares" of one workgroup tile
+        //   (3) FC(fc->1)+tanh, or the WDLP outputs, one wave per board
+        const int nfl = kSquares * cv;
+        const int Bpad = round_up(B, 64);
+        T* vflat = static_cast<T*>(im.dalloc(size_t(Bpad) * nfl * sizeof(T)));
+        HIP_CHECK(hipMemset(vflat, 0, size_t(Bpad) * nfl * sizeof(T)));
+        {
+            Folded fd = fold_bn(nf, "value_head.body.0", "value_head.body.1");
+            const int co_pad = round_up(cv, 16);
+            Op op;
+            op.kind = OpKind::Conv;
+            op.conv.x = cur;
+            op.conv.wpk = im.upload(pack_dense<T>(fd, cv, C, 1, co_pad, C));
+            op.conv.bias = im.upload_d2f(fd.b, co_pad);
+            op.conv.out = vflat;
+            op.conv.batch = B;
+            op.conv.cin = C;
+            op.conv.cout_pad = co_pad;
+            op.conv.cout_real = cv;
+            op.conv.cout_ld = co_pad;
+            op.conv.ks = 1;
+            op.conv.relu = 1;
+            op.conv.out_flat = 1;
+            op.conv.flat_pitch = nfl;
+            im.ops.push_back(op);
+            macs += double(kSquares) * C * cv;
+        }
+        Op fin;
+        fin.kind = OpKind::ValueFinal;
+        ValueFinalArgs& vf = fin.vf;
+        vf.value = d_value_;
+        vf.aux = d_aux_;
+        vf.batch = B;
+        if (wdl) {
+            const TensorView &ww = nf.get("value_head.body_wdl.0.weight"), &wp = nf.get("value_head.body_plys.0.weight");
+            std::vector<float> w4(size_t(4) * nfl);
+            std::copy(ww.data, ww.data + 3 * nfl, w4.begin());
+            std::copy(wp.data, wp.data + nfl, w4.begin() + 3 * nfl);
+            const float* bw = nf.get("value_head.body_wdl.0.bias").data;
+            vf.in = vflat;
+            vf.n = nfl;
+            vf.w = im.upload(w4);
+            vf.b[0] = bw[0]; vf.b[1] = bw[1]; vf.b[2] = bw[2];
+            vf.b[3] = nf.get("value_head.body_plys.0.bias").data[0];
+            vf.wdlp = 1;
+            macs += 4.0 * nfl;
+        } else {
+            if (nfl % 32 != 0) throw std::runtime_error("value head flatten size must be a multiple of 32");
+            const TensorView &w1 = nf.get("value_head.body_final.0.weight"), &w2 = nf.get("value_head.body_final.2.weight");
+            const float* b1 = nf.get("value_head.body_final.0.bias").data;
+            Folded f1;
+            f1.w.assign(w1.data, w1.data + size_t(fc) * nfl);
+            f1.b.assign(b1, b1 + fc);
+            const int fc_pad = round_up(fc, 16);
+            T* vh = static_cast<T*>(im.dalloc(size_t(Bpad) * fc_pad * sizeof(T)));
+            Op op;
+            op.kind = OpKind::Conv;
+            op.conv.x = vflat;
+            op.conv.wpk = im.upload(pack_dense<T>(f1, fc, nfl, 1, fc_pad, nfl));
+            op.conv.bias = im.upload_d2f(f1.b, fc_pad);
+            op.conv.out = vh;
+            op.conv.batch = Bpad / 64;        // 64 boards per workgroup tile
+            op.conv.cin = nfl;
+            op.conv.cout_pad = fc_pad;
+            op.conv.cout_real = fc;
+            op.conv.cout_ld = fc_pad;
+            op.conv.ks = 1;
+            op.conv.relu = 1;
+            im.ops.push_back(op);
+            vf.in = vh;
+            vf.n = fc_pad;
+            std::vector<float> w2p(fc_pad, 0.f);
+            std::copy(w2.data, w2.data + fc, w2p.begin());
+            vf.w = im.upload(w2p);
+            vf.b[0] = nf.get("value_head.body_final.2.bias").data[0];
+            vf.wdlp = 0;
+            macs += double(nfl) * fc + fc;
+        }
+        im.ops.push_back(fin);
+    } else
     {   // _ValueHead, builder_util.py:246-326
         Folded fd = fold_bn(nf, "value_head.body.0", "value_head.body.1");
         const int nfl = kSquares * cv;
@@ -394,6 +499,10 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s) {
         case OpKind::ValueHead: launch_value_head<T>(op.vh, s); break;
         case OpKind::Softmax: launch_softmax(d_logits_, d_probs_, B, design_.nb_policy, s); break;
         case OpKind::Block: launch_block<T>(op.blk, s); break;
+        case OpKind::ValueFinal: launch_value_final<T>(op.vf, s); break;
+        case OpKind::SEGate:
+            launch_se_gate(static_cast<const float*>(op.x), static_cast<float*>(op.y), op.se_kind, op.w0, op.w1, op.b0, B, op.C, s);
+            break;
     }
 }
 
@@ -412,6 +521,8 @@ const char* RiseNet::op_name(int i) const {
         case OpKind::ValueHead: return "value_head";
         case OpKind::Softmax: return "softmax";
         case OpKind::Block: return "fused_block";
+        case OpKind::ValueFinal: return "value_final";
+        case OpKind::SEGate: return "se_gate";
     }
     return "?";
 }

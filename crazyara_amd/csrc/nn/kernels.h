@@ -56,6 +56,7 @@ struct BlockArgs {
     int batch, C, cop_pad, ks;
     const float* gate;    // optional [B][C]: SE gate multiplied into x while the tile is loaded (residual uses the gated x)
     float* pool_out;      // optional [B][C]: sum over the 64 squares of y (feeds the NEXT block's SE gate)
+    const float* dwpk;    // 3x3 only: [cop_pad][12] = 9 folded taps, BN1 bias, BN2 bias, 0 (one 48-byte record per channel)
 };
 template <typename T> void launch_block(const BlockArgs& a, hipStream_t s);
 template <typename T> void init_block_kernel_attributes();

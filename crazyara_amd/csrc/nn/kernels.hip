@@ -819,6 +819,203 @@ __global__ __launch_bounds__(64 * NW) void block_kernel(const BlockArgs a) {
     }
 }
 
+// ================================================================================================================
+// 3x3 variant: the depthwise convolution runs directly on the expand accumulators with DPP lane shifts.
+//
+// An MFMA 16x16 D tile holds, in lane (l15, lg), square = t*16 + l15 of channels lg*4..lg*4+3.  A board row is 8 squares,
+// so inside one 16-lane DPP row the horizontal neighbours are lanes l15 -/+ 1 (row_shr:1 / row_shl:1) and the vertical
+// neighbours are lane (l15 + 8) % 16 (row_ror:8) of the same tile (l15 < 8: the row above lives in tile t-1) -- every one
+// of the 9 taps of a channel is reachable without leaving the 16-lane row that owns the channel.  Edge masks (file a / h,
+// rank 1 / 8) are folded into the per-lane tap weights.  Result: no LDS round trip for the expand output, no f16<->f32
+// conversions, no bounds branches; LDS only carries the x tile (B operand of expand) and the depthwise output t2
+// (B operand of project).
+// ================================================================================================================
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHR1 = 0x111, DPP_ROW_ROR8 = 0x128;
+
+template <typename T, int NW> struct BlockGeomD {
+    static constexpr int C = 256;
+    static constexpr int CK = 16 * NW;
+    static constexpr int NTHR = 64 * NW;
+    static constexpr int PAD = 32 / int(sizeof(T));     // 32-byte row pad: rows step 8 banks -> conflict-free 16-row fragment reads
+    static constexpr int XROW = C + PAD;
+    static constexpr int TROW = CK + PAD;
+    static constexpr size_t lds_bytes = (size_t(64) * XROW + size_t(64) * TROW) * sizeof(T);
+};
+
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void block_kernel_dpp(const BlockArgs a) {
+    using frag = typename VT<T>::frag;
+    using G = BlockGeomD<T, NW>;
+    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NTHR = G::NTHR;
+    constexpr int NJ = C / 16 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xs = reinterpret_cast<T*>(smem);          // [64][XROW]
+    T* t2 = xs + 64 * XROW;                      // [64][TROW]  depthwise output of the current chunk
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const int nchunk = a.cop_pad / CK;
+    const int nslab3 = a.cop_pad >> 5;
+    const frag* w1base = reinterpret_cast<const frag*>(a.w1pk) + lane;
+    const frag* w3base = reinterpret_cast<const frag*>(a.w3pk) + lane;
+    const bool hi = l15 >= 8;                                  // second board row of the tile
+    const float mL = (l15 & 7) != 0 ? 1.f : 0.f;               // a left / right neighbour exists on the board
+    const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
+
+    frag w1f[C / 32];
+    f32x4 dwr[4][3];                                           // [channel r][float4 k] = 12 floats of dwpk per channel
+    auto prefetch_chunk = [&](int ch) {
+        const frag* w1 = w1base + size_t(ch * NW + wave) * (C / 32) * 64;
+#pragma unroll
+        for (int s = 0; s < C / 32; ++s) w1f[s] = w1[s * 64];
+        const f32x4* dp = reinterpret_cast<const f32x4*>(a.dwpk + size_t(ch * CK + wave * 16 + lg * 4) * 12);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dwr[r][k] = dp[r * 3 + k];
+    };
+    prefetch_chunk(0);
+
+    const T* xb = reinterpret_cast<const T*>(a.x) + size_t(b) * 64 * C;
+    {
+        constexpr int vec_per_row = C * int(sizeof(T)) / 16;
+        if (a.gate == nullptr) {
+            for (int i = tid; i < 64 * vec_per_row; i += NTHR) {
+                const int r = i / vec_per_row, v = i - r * vec_per_row;
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(xs + r * XROW) + v * 16) =
+                    *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(xb + size_t(r) * C) + v * 16);
+            }
+        } else {
+            constexpr int EPV = 16 / int(sizeof(T));
+            const float* g = a.gate + size_t(b) * C;
+            for (int i = tid; i < 64 * vec_per_row; i += NTHR) {
+                const int r = i / vec_per_row, v = i - r * vec_per_row;
+                float xv[EPV], gv[EPV];
+                if constexpr (EPV == 8) { load8<T>(xb + size_t(r) * C + v * 8, xv); load8<float>(g + v * 8, gv); }
+                else { load4<T>(xb + size_t(r) * C + v * 4, xv); load4<float>(g + v * 4, gv); }
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) xv[j] *= gv[j];
+                if constexpr (EPV == 8) store8<T>(xs + r * XROW + v * 8, xv);
+                else store4<T>(xs + r * XROW + v * 4, xv);
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x4 accP[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accP[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        // ---------------- E: expand, 16 channels x 64 squares per wave, K = C ----------------
+        f32x4 accE[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accE[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < C / 32; ++s) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const frag bf = *reinterpret_cast<const frag*>(xs + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                mma_k32(w1f[s], bf, accE[t]);
+            }
+        }
+        // request this chunk's project fragments; they land while the depthwise runs
+        frag w3f[CK / 32][NJ];
+#pragma unroll
+        for (int s2 = 0; s2 < CK / 32; ++s2)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) w3f[s2][j] = w3base[(size_t(wave * NJ + j) * nslab3 + ch * (CK / 32) + s2) * 64];
+
+        // ---------------- D: BN1 + ReLU, depthwise 3x3 on the accumulators, BN2 + ReLU ----------------
+        float outv[4][4];                                       // [tile][channel r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float b1 = dwr[r][2][1], b2 = dwr[r][2][2];
+            float w[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k] = dwr[r][k >> 2][k & 3];
+            // taps: k = (dy+1)*3 + (dx+1); fold the file-edge masks into the dx = -1 / +1 columns
+            w[0] *= mL; w[3] *= mL; w[6] *= mL;
+            w[2] *= mR; w[5] *= mR; w[8] *= mR;
+            float e[4], rot[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                e[t] = fmaxf(accE[t][r] + b1, 0.f);
+                rot[t] = dpp_mov<DPP_ROW_ROR8>(e[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // square above (dy = -1) / below (dy = +1): same tile for one half of the lanes, neighbouring tile for the other
+                const float up = hi ? rot[t] : (t > 0 ? rot[t > 0 ? t - 1 : 0] : 0.f);
+                const float dn = hi ? (t < 3 ? rot[t < 3 ? t + 1 : 3] : 0.f) : rot[t];
+                float acc = b2;
+                acc = fmaf(w[0], dpp_mov<DPP_ROW_SHR1>(up), acc);
+                acc = fmaf(w[1], up, acc);
+                acc = fmaf(w[2], dpp_mov<DPP_ROW_SHL1>(up), acc);
+                acc = fmaf(w[3], dpp_mov<DPP_ROW_SHR1>(e[t]), acc);
+                acc = fmaf(w[4], e[t], acc);
+                acc = fmaf(w[5], dpp_mov<DPP_ROW_SHL1>(e[t]), acc);
+                acc = fmaf(w[6], dpp_mov<DPP_ROW_SHR1>(dn), acc);
+                acc = fmaf(w[7], dn, acc);
+                acc = fmaf(w[8], dpp_mov<DPP_ROW_SHL1>(dn), acc);
+                outv[t][r] = fmaxf(acc, 0.f);
+            }
+        }
+        {
+            const int cl = wave * 16 + lg * 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) store4<T>(t2 + (t * 16 + l15) * TROW + cl, outv[t]);
+        }
+        __syncthreads();
+        if (ch + 1 < nchunk) prefetch_chunk(ch + 1);
+        // ---------------- P: project, accumulates over chunks ----------------
+#pragma unroll
+        for (int s2 = 0; s2 < CK / 32; ++s2) {
+            frag bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const frag*>(t2 + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mma_k32(w3f[s2][j], bf[t], accP[j][t]);
+        }
+        __syncthreads();   // t2 is rewritten by the next chunk's depthwise
+    }
+
+    T* yb = reinterpret_cast<T*>(a.y) + size_t(b) * 64 * C;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int co0 = (wave * NJ + j) * 16 + lg * 4;
+        float bs[4];
+        load4<float>(a.b3 + co0, bs);
+        float pool[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int sq = t * 16 + l15;
+            float rv[4], v[4];
+            load4<T>(xs + sq * XROW + co0, rv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = accP[j][t][r] + bs[r] + rv[r];
+                pool[r] += to_f(T(v[r]));
+            }
+            store4<T>(yb + size_t(sq) * C + co0, v);
+        }
+        if (a.pool_out) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) pool[r] += __shfl_xor(pool[r], off, 64);
+            if (l15 == 0) store4<float>(a.pool_out + size_t(b) * C + co0, pool);
+        }
+    }
+}
+
 template <typename T> struct BlockWaves;
 template <> struct BlockWaves<half_t> { static constexpr int NW = 8; };   // 512 threads: two waves per SIMD hide LDS / MFMA latencies
 template <> struct BlockWaves<float> { static constexpr int NW = 4; };    // f32 fragments are twice as wide: stay at one wave per SIMD
@@ -830,6 +1027,8 @@ template <typename T> void init_block_kernel_attributes() {
     auto k5 = &block_kernel<T, 5, NW>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k5), hipFuncAttributeMaxDynamicSharedMemorySize, lds5);
+    auto kd = &block_kernel_dpp<T, NW>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, int(BlockGeomD<T, NW>::lds_bytes));
 }
 template void init_block_kernel_attributes<half_t>();
 template void init_block_kernel_attributes<float>();
@@ -843,7 +1042,10 @@ template <typename T> void launch_block(const BlockArgs& a, hipStream_t s) {
     constexpr size_t lds3 = BlockGeomK<T, 3, NW>::lds_bytes, lds5 = BlockGeomK<T, 5, NW>::lds_bytes;
     auto k3 = &block_kernel<T, 3, NW>;
     auto k5 = &block_kernel<T, 5, NW>;
-    if (a.ks == 3) hipLaunchKernelGGL(k3, dim3(a.batch), dim3(64 * NW), lds3, s, a);
+    auto kd = &block_kernel_dpp<T, NW>;
+    constexpr size_t ldsd = BlockGeomD<T, NW>::lds_bytes;
+    if (a.ks == 3 && a.dwpk) hipLaunchKernelGGL(kd, dim3(a.batch), dim3(64 * NW), ldsd, s, a);
+    else if (a.ks == 3) hipLaunchKernelGGL(k3, dim3(a.batch), dim3(64 * NW), lds3, s, a);
     else hipLaunchKernelGGL(k5, dim3(a.batch), dim3(64 * NW), lds5, s, a);
 }
 template void launch_block<half_t>(const BlockArgs&, hipStream_t);

@@ -324,6 +324,15 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             ba.C = C;
             ba.cop_pad = cop_pad;
             ba.ks = k;
+            if (k == 3) {   // per-channel record for the DPP depthwise kernel: 9 taps, BN1 bias, BN2 bias, pad
+                std::vector<float> rec(size_t(cop_pad) * 12, 0.f);
+                for (int c = 0; c < cop; ++c) {
+                    for (int t = 0; t < 9; ++t) rec[size_t(c) * 12 + t] = float(f2.w[size_t(c) * 9 + t]);
+                    rec[size_t(c) * 12 + 9] = float(f1.b[c]);
+                    rec[size_t(c) * 12 + 10] = float(f2.b[c]);
+                }
+                ba.dwpk = im.upload(rec);
+            }
             ba.gate = pending_gate;
             pending_gate = nullptr;
             last_block_op = int(im.ops.size());

@@ -171,7 +171,7 @@ def main():
         flops_total = net.flops_per_position() * args.batch
         # algorithmic FLOPs of the dominant kernel's launches (1x1 expand/project GEMMs of all blocks)
         cops = cfg.channels_operating()
-        if dom == "fused_block":
+        if dom in ("fused_block", "tower"):
             dom_flops = sum(2.0 * 64 * c * (2 * cfg.channels + 9) for c in cops) * args.batch
         elif dom == "conv_gemm_1x1":
             dom_flops = sum(2.0 * 64 * cfg.channels * c * 2 for c in cops) * args.batch

@@ -62,6 +62,50 @@ template <typename T> void launch_block(const BlockArgs& a, hipStream_t s);
 template <typename T> void init_block_kernel_attributes();
 template <typename T> int block_chunk_channels();   // C_op must be padded to a multiple of this
 
+// Residual tower: a run of consecutive 3x3 bottleneck blocks in one launch, one workgroup per board, residual stream
+// resident in LDS, SE gates computed in-kernel (tower.hip).  f16 only, C = 256.  The conv weights of the whole run are
+// packed into per-wave streams in consumption order (rise_net.hip: TowerPacker):
+//   wstream  4 matrix waves x [fragments of 64 lanes x 8 halves]: per block, per interval k = -1..n: the expand fragments
+//            of chunk k+1 ([k-slab s][tile e], 8 unused padding fragments after a 64-channel tail chunk), then the project
+//            fragments of chunk k-1 ([k-slab s2][cout tile j] in tower K order, 8 padding fragments after a tail chunk);
+//            kTowerWindow padding fragments at the very end
+//   bstream  4 matrix waves x per chunk [lane group lg][tile e][row r] BN1 biases (32 floats)
+//   pstream  4 vector waves x per chunk 8 steps (e*4 + r) x [lg][12 floats = 9 folded taps, BN2 bias, 0, 0]; one chunk of padding
+constexpr int kTowerWindow = 16;
+struct TowerBlockDesc {
+    const float* b3;      // [256] BN3 bias
+    const void* se_w1;    // f16: ca_se W1 transposed [256][128]; eca_se centre tap transposed [256][256]; or nullptr
+    const void* se_w2;    // f16: ca_se W2 transposed [128][256]
+    const float* se_b;    // eca_se bias [256]
+    int cop_pad;          // multiple of 64
+    int se_kind;          // 0 none, 1 ca_se, 2 eca_se: gate applied to this block's input (from the previous block's output sums)
+};
+struct TowerArgs {
+    const void* x;        // [B][64][256] f16
+    void* y;              // [B][64][256] f16
+    const TowerBlockDesc* blocks;   // device array
+    const void* wstream;
+    const float* bstream;
+    const float* pstream;
+    long long wstream_wave_frags, bstream_wave_floats, pstream_wave_floats;   // per-wave stream lengths
+    int nblocks;
+    int batch;
+    const float* gate_in; // optional [B][256]: SE gate of blocks[0] computed by a previous launch (blocks[0].se_kind is ignored)
+    float* pool_out;      // optional [B][256]: sum over the 64 squares of y (feeds an SE gate computed by a later launch)
+    unsigned long long* trace;   // development: s_memtime stamps of workgroup 0 (CRA_TOWER_TRACE), [wave 0 | wave 4][1 + 3 * nblocks + ...]
+    int debug;            // development switches (CRA_TOWER_DEBUG): 1 skip MFMAs, 2 skip depthwise math, 4 no stream refills
+};
+void launch_tower(const TowerArgs& a, hipStream_t s);
+void init_tower_kernel_attributes();
+size_t tower_lds_bytes();
+// K position kpos of the tower's project GEMM -> C_op channel (chunks of 128; inside a chunk the 16-channel expand tile v
+// occupies positions (v/2)*32 + lg*8 + (v%2)*4 + r for its rows lg*4 + r)
+inline int tower_k_channel(int kpos) {
+    const int chunk = kpos / 128, p = kpos % 128;
+    const int v = (p / 32) * 2 + (p % 8) / 4, lg = (p % 32) / 8, r = p % 4;
+    return chunk * 128 + v * 16 + lg * 4 + r;
+}
+
 // depthwise k x k (k = 3 or 5) + folded BN + ReLU.  w: [k*k][C] float, bias: [C] float
 template <typename T> void launch_depthwise(const T* x, T* y, const float* w, const float* bias, int batch, int C, int ks,
                                             hipStream_t s);

@@ -26,8 +26,9 @@ class RiseNet {
 public:
     // model_path: a .cranet file, or a directory searched like get_onnx_model_name() (neuralnetapi.cpp:57-73).
     // precision: "float16" (f16 MFMA operands, f32 accumulate; the reference TensorRT default, optionsuci.cpp:143-147)
-    //            or "float32" (exact f32 MFMA); suffix "-unfused" selects the layer-granular kernels instead of the fused
-    //            bottleneck-block kernel (kept for A/B measurements and as a second implementation in the parity tests).   Throws std::invalid_argument / std::runtime_error.
+    //            or "float32" (exact f32 MFMA); float16 runs the residual tower kernel (tower.hip: runs of 3x3 blocks in one launch);
+    //            suffix "-perblock" selects one fused launch per bottleneck block, "-unfused" the layer-granular kernels
+    //            (both kept for A/B measurements and as independent implementations in the parity tests).   Throws std::invalid_argument / std::runtime_error.
     RiseNet(const std::string& model_path, int device_id, int batch_size, const std::string& precision);
     ~RiseNet();
     RiseNet(const RiseNet&) = delete;
@@ -77,6 +78,7 @@ private:
     std::string model_name_, model_file_path_;
     bool fp16_ = true;
     bool fused_ = true;
+    bool tower_ = true;
     int device_ = 0;
     int launches_ = 0;
     hipStream_t stream_ = nullptr;

@@ -1,7 +1,10 @@
 #include "rise_net.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <stdexcept>
 
 #include "kernels.h"
@@ -70,7 +73,23 @@ std::vector<T> pack_dense(const Folded& f, int cout, int cin, int ks, int cout_p
     return out;
 }
 
-enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate };
+// project weights [C][cop] (1x1) as MFMA A fragments with the K axis in the tower kernel's order (kernels.h: tower_k_channel)
+std::vector<half_t> pack_project_tower(const Folded& f, int cout, int cop, int cop_pad) {
+    const int nslab = cop_pad / 32, nct = cout / 16;
+    std::vector<half_t> out(size_t(cout) * cop_pad);
+    for (int ct = 0; ct < nct; ++ct)
+        for (int s = 0; s < nslab; ++s)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = ct * 16 + (l & 15);
+                    const int ci = tower_k_channel(s * 32 + (l >> 4) * 8 + j);
+                    const double v = ci < cop ? f.w[size_t(co) * cop + ci] : 0.0;
+                    out[((size_t(ct) * nslab + s) * 64 + l) * 8 + j] = half_t(float(v));
+                }
+    return out;
+}
+
+enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower };
 
 struct Op {
     OpKind kind;
@@ -83,6 +102,7 @@ struct Op {
     ValueHeadArgs vh{};
     BlockArgs blk{};
     ValueFinalArgs vf{};
+    TowerArgs tw{};
 };
 }  // namespace
 
@@ -117,9 +137,14 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     if (batch_size <= 0) throw std::invalid_argument("batch size must be positive");
     std::string prec = precision;
     const std::string unfused_tag = "-unfused";   // layer-granular kernels (A/B reference for the fused block kernel)
+    const std::string perblock_tag = "-perblock"; // one launch per bottleneck block (A/B reference for the tower kernel)
     if (prec.size() > unfused_tag.size() && prec.compare(prec.size() - unfused_tag.size(), unfused_tag.size(), unfused_tag) == 0) {
         fused_ = false;
+        tower_ = false;
         prec.resize(prec.size() - unfused_tag.size());
+    } else if (prec.size() > perblock_tag.size() && prec.compare(prec.size() - perblock_tag.size(), perblock_tag.size(), perblock_tag) == 0) {
+        tower_ = false;
+        prec.resize(prec.size() - perblock_tag.size());
     }
     if (prec == "float16" || prec == "fp16" || prec == "half") fp16_ = true;
     else if (prec == "float32" || prec == "fp32") fp16_ = false;
@@ -246,18 +271,63 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     }
     add_conv("body_spatial.0.body.0", "body_spatial.0.body.1", x0, a0, nullptr, cin, cin_pad, C, 3, true, nullptr);   // _Stem
     T *cur = a0, *nxt = a1;
-    // SE plumbing for the fused path: the squeeze (per-channel sums) is produced by the previous block kernel's epilogue,
-    // a small gate kernel turns it into gate[b][c], and this block's prologue multiplies it into x while loading the tile.
+    // SE plumbing for the fused paths: the squeeze (per-channel sums) is produced by the previous block / tower kernel's
+    // epilogue, a small gate kernel turns it into gate[b][c], and the consumer's prologue multiplies it into x while
+    // loading the tile.  Inside a tower the whole SE runs in-kernel.
     float *se_pool = nullptr, *se_gate = nullptr;
     const float* pending_gate = nullptr;
-    int last_block_op = -1;
+    int prod_op = -1;                 // last op that produced the residual stream and can emit its channel sums
+    constexpr bool kHalf = std::is_same<T, half_t>::value;
+    const bool tower_ok = tower_ && fused_ && kHalf && C == 256;
+    std::vector<TowerBlockDesc> tower_blocks;
+    std::vector<half_t> tower_ws[4];          // per matrix wave: MFMA A fragments in consumption order (kernels.h: TowerArgs)
+    std::vector<float> tower_bs[4], tower_ps[4];
+    const float* tower_gate = nullptr;
+    auto flush_tower = [&]() {
+        if (tower_blocks.empty()) return;
+        Op op;
+        op.kind = OpKind::Tower;
+        op.tw.x = cur;
+        op.tw.y = nxt;
+        op.tw.blocks = im.upload(tower_blocks);
+        op.tw.nblocks = int(tower_blocks.size());
+        {   // close the streams: the kernel's windows run one window / one chunk past the end
+            std::vector<half_t> ws;
+            std::vector<float> bs, ps;
+            for (int w = 0; w < 4; ++w) {
+                tower_ws[w].resize(tower_ws[w].size() + size_t(kTowerWindow) * 512, half_t(0.f));
+                tower_ps[w].resize(tower_ps[w].size() + 8 * 48, 0.f);
+                tower_bs[w].resize(tower_bs[w].size() + 32, 0.f);
+                ws.insert(ws.end(), tower_ws[w].begin(), tower_ws[w].end());
+                bs.insert(bs.end(), tower_bs[w].begin(), tower_bs[w].end());
+                ps.insert(ps.end(), tower_ps[w].begin(), tower_ps[w].end());
+            }
+            op.tw.wstream = im.upload(ws);
+            op.tw.bstream = im.upload(bs);
+            op.tw.pstream = im.upload(ps);
+            op.tw.wstream_wave_frags = (long long)(tower_ws[0].size() / 512);
+            op.tw.bstream_wave_floats = (long long)tower_bs[0].size();
+            op.tw.pstream_wave_floats = (long long)tower_ps[0].size();
+            for (int w = 0; w < 4; ++w) { tower_ws[w].clear(); tower_bs[w].clear(); tower_ps[w].clear(); }
+        }
+        op.tw.batch = B;
+        op.tw.gate_in = tower_gate;
+        if (const char* dbg = getenv("CRA_TOWER_DEBUG")) op.tw.debug = atoi(dbg);
+        if (getenv("CRA_TOWER_TRACE")) op.tw.trace = static_cast<unsigned long long*>(im.dalloc(2 * 256 * sizeof(unsigned long long)));
+        prod_op = int(im.ops.size());
+        im.ops.push_back(op);
+        tower_blocks.clear();
+        tower_gate = nullptr;
+        std::swap(cur, nxt);
+    };
     auto add_se = [&](Op op) {
-        if (fused_ && C == 256 && last_block_op >= 0) {
+        if (fused_ && C == 256 && prod_op >= 0) {
             if (!se_pool) {
                 se_pool = static_cast<float*>(im.dalloc(size_t(B) * C * sizeof(float)));
                 se_gate = static_cast<float*>(im.dalloc(size_t(B) * C * sizeof(float)));
             }
-            im.ops[last_block_op].blk.pool_out = se_pool;
+            if (im.ops[prod_op].kind == OpKind::Tower) im.ops[prod_op].tw.pool_out = se_pool;
+            else im.ops[prod_op].blk.pool_out = se_pool;
             op.kind = OpKind::SEGate;
             op.x = se_pool;
             op.y = se_gate;
@@ -268,21 +338,36 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
         im.ops.push_back(op);
     };
+    auto to_half = [](const std::vector<float>& v) {
+        std::vector<half_t> h(v.size());
+        for (size_t i = 0; i < v.size(); ++i) h[i] = half_t(v[i]);
+        return h;
+    };
     for (size_t i = 0; i < cops.size(); ++i) {
         const std::string p = "body_spatial." + std::to_string(i + 1);
         const int cop = cops[i], k = ks[i];
+        const bool in_tower = tower_ok && k == 3;
+        if (!in_tower) flush_tower();
+        const bool se_in_kernel = in_tower && !tower_blocks.empty();
+        TowerBlockDesc td{};
         if (se_types[i] == "ca_se" || se_types[i] == "se") {           // _ChannelAttentionModule, builder_util.py:83-114
             const TensorView &w1 = nf.get(p + ".se.fc.0.weight"), &w2 = nf.get(p + ".se.fc.2.weight");
             const int H = C / 2;
             std::vector<float> w1t(size_t(C) * H), w2t(size_t(H) * C);
             for (int j = 0; j < H; ++j) for (int c = 0; c < C; ++c) w1t[size_t(c) * H + j] = w1.data[size_t(j) * C + c];
             for (int c = 0; c < C; ++c) for (int j = 0; j < H; ++j) w2t[size_t(j) * C + c] = w2.data[size_t(c) * H + j];
-            Op op;
-            op.se_kind = 1;
-            op.w0 = im.upload(w1t);
-            op.w1 = im.upload(w2t);
-            op.C = C;
-            add_se(op);
+            if (se_in_kernel) {
+                td.se_kind = 1;
+                td.se_w1 = im.upload(to_half(w1t));
+                td.se_w2 = im.upload(to_half(w2t));
+            } else {
+                Op op;
+                op.se_kind = 1;
+                op.w0 = im.upload(w1t);
+                op.w1 = im.upload(w2t);
+                op.C = C;
+                add_se(op);
+            }
             macs += 2.0 * C * H;
         } else if (se_types[i] == "eca_se") {                           // _EfficientChannelAttentionModule, builder_util.py:49-80
             const TensorView& w = nf.get(p + ".se.body.0.weight");     // [C][C][kk]; the length-1 sequence only sees the centre tap
@@ -291,17 +376,88 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             for (int o = 0; o < C; ++o) for (int c = 0; c < C; ++c) wt[size_t(c) * C + o] = w.data[(size_t(o) * C + c) * kk + mid];
             const float* bs = nf.get(p + ".se.body.0.bias").data;
             for (int o = 0; o < C; ++o) b[o] = bs[o];
-            Op op;
-            op.se_kind = 2;
-            op.w0 = im.upload(wt);
-            op.b0 = im.upload(b);
-            op.C = C;
-            add_se(op);
+            if (se_in_kernel) {
+                td.se_kind = 2;
+                td.se_w1 = im.upload(to_half(wt));
+                td.se_b = im.upload(b);
+            } else {
+                Op op;
+                op.se_kind = 2;
+                op.w0 = im.upload(wt);
+                op.b0 = im.upload(b);
+                op.C = C;
+                add_se(op);
+            }
             macs += double(C) * C;
         } else if (se_types[i] != "none" && !se_types[i].empty()) {
             throw std::runtime_error("unsupported se_type " + se_types[i]);
         }
-        if (fused_ && C == 256) {
+        if (in_tower) {
+            // residual tower: this block joins the current run of 3x3 blocks (one launch per run, kernels.h: TowerArgs)
+            if constexpr (kHalf) {
+                const int cop_pad = round_up(cop, 64);
+                Folded f1 = fold_bn(nf, p + ".body.0", p + ".body.1");
+                Folded f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
+                Folded f3 = fold_bn(nf, p + ".body.6", p + ".body.7");
+                const std::vector<T> w1pk = pack_dense<T>(f1, cop, C, 1, cop_pad, C);           // [tile][8 slabs][64][8]
+                const std::vector<half_t> w3pk = pack_project_tower(f3, C, cop, cop_pad);       // [16 cout tiles][cop_pad/32][64][8]
+                const int n = (cop_pad + 127) / 128, nslab3 = cop_pad / 32;
+                const bool tail = (cop_pad % 128) != 0;
+                // expand tile index of (chunk c, wave w, e): full chunk w*2+e, 64-channel tail chunk w (e = 0 only); -1 = padding
+                auto tile_of = [&](int c, int w, int e) { return (tail && c == n - 1) ? (e == 0 ? c * 8 + w : -1) : c * 8 + w * 2 + e; };
+                const half_t hz = half_t(0.f);
+                for (int w = 0; w < 4; ++w) {
+                    std::vector<half_t>& ws = tower_ws[w];
+                    for (int kk = -1; kk <= n; ++kk) {                 // interval: E(kk+1) then P(kk-1)
+                        if (kk + 1 < n) {
+                            const int c = kk + 1;
+                            for (int sl = 0; sl < 8; ++sl)
+                                for (int e = 0; e < 2; ++e) {
+                                    const int tl = tile_of(c, w, e);
+                                    if (tl < 0) ws.insert(ws.end(), 512, hz);
+                                    else ws.insert(ws.end(), w1pk.begin() + (size_t(tl) * 8 + sl) * 512, w1pk.begin() + (size_t(tl) * 8 + sl + 1) * 512);
+                                }
+                        }
+                        if (kk - 1 >= 0) {
+                            const int c = kk - 1;
+                            for (int s2 = 0; s2 < 4; ++s2)
+                                for (int j = 0; j < 4; ++j) {
+                                    const int slab = c * 4 + s2;
+                                    const size_t off = (size_t(w * 4 + j) * nslab3 + slab) * 512;
+                                    if (slab >= nslab3) ws.insert(ws.end(), 512, hz);
+                                    else ws.insert(ws.end(), w3pk.begin() + off, w3pk.begin() + off + 512);
+                                }
+                        }
+                    }
+                    for (int c = 0; c < n; ++c) {
+                        for (int lgk = 0; lgk < 4; ++lgk)               // BN1 biases [lg][e][r]
+                            for (int e = 0; e < 2; ++e)
+                                for (int r = 0; r < 4; ++r) {
+                                    const int tl = tile_of(c, w, e), ch = tl * 16 + lgk * 4 + r;
+                                    tower_bs[w].push_back(tl >= 0 && ch < cop ? float(f1.b[ch]) : 0.f);
+                                }
+                        for (int step = 0; step < 8; ++step)            // depthwise records [step = e*4 + r][lg][12]
+                            for (int lgk = 0; lgk < 4; ++lgk) {
+                                const int tl = tile_of(c, w, step >> 2), ch = tl * 16 + lgk * 4 + (step & 3);
+                                float rec[12] = {0.f};
+                                if (tl >= 0 && ch < cop) {
+                                    for (int t = 0; t < 9; ++t) rec[t] = float(f2.w[size_t(ch) * 9 + t]);
+                                    rec[9] = float(f2.b[ch]);
+                                }
+                                tower_ps[w].insert(tower_ps[w].end(), rec, rec + 12);
+                            }
+                    }
+                }
+                td.b3 = im.upload_d2f(f3.b, C);
+                td.cop_pad = cop_pad;
+                if (tower_blocks.empty()) {
+                    tower_gate = pending_gate;     // gate computed by the launches before this run (or none)
+                    pending_gate = nullptr;
+                }
+                tower_blocks.push_back(td);
+                macs += double(kSquares) * cop * (2.0 * C + k * k);
+            }
+        } else if (fused_ && C == 256) {
             // fused bottleneck block: expand -> depthwise -> project -> +x in one launch (kernels.hip: block_kernel)
             const int cop_pad = round_up(cop, block_chunk_channels<T>());
             Folded f1 = fold_bn(nf, p + ".body.0", p + ".body.1");
@@ -335,9 +491,10 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             }
             ba.gate = pending_gate;
             pending_gate = nullptr;
-            last_block_op = int(im.ops.size());
+            prod_op = int(im.ops.size());
             im.ops.push_back(op);
             macs += double(kSquares) * cop * (2.0 * C + k * k);
+            std::swap(cur, nxt);
         } else {
             add_conv(p + ".body.0", p + ".body.1", cur, e, nullptr, C, C, cop, 1, true, nullptr);   // 1x1 expand + BN + ReLU
             {   // depthwise k x k + BN + ReLU
@@ -356,9 +513,10 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 macs += double(kSquares) * cop * k * k;
             }
             add_conv(p + ".body.6", p + ".body.7", f, nxt, cur, cop, cop, C, 1, false, nullptr);    // 1x1 project + BN + residual
+            std::swap(cur, nxt);
         }
-        std::swap(cur, nxt);
     }
+    flush_tower();
     // _PolicyHead (select_policy_from_plane), builder_util.py:206-243
     add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr);
     add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_);
@@ -488,6 +646,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         im.ops.push_back(op);
     }
     init_block_kernel_attributes<T>();
+    init_tower_kernel_attributes();
     design_.flops_per_position = 2.0 * macs;
     launches_ = int(im.ops.size());
 }
@@ -509,6 +668,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s) {
         case OpKind::Softmax: launch_softmax(d_logits_, d_probs_, B, design_.nb_policy, s); break;
         case OpKind::Block: launch_block<T>(op.blk, s); break;
         case OpKind::ValueFinal: launch_value_final<T>(op.vf, s); break;
+        case OpKind::Tower: launch_tower(op.tw, s); break;
         case OpKind::SEGate:
             launch_se_gate(static_cast<const float*>(op.x), static_cast<float*>(op.y), op.se_kind, op.w0, op.w1, op.b0, B, op.C, s);
             break;
@@ -532,6 +692,7 @@ const char* RiseNet::op_name(int i) const {
         case OpKind::Block: return "fused_block";
         case OpKind::ValueFinal: return "value_final";
         case OpKind::SEGate: return "se_gate";
+        case OpKind::Tower: return "tower";
     }
     return "?";
 }
@@ -554,6 +715,26 @@ void RiseNet::time_ops(int iters, float* ms) {
         }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    for (const Op& op : impl_->ops)
+        if (op.kind == OpKind::Tower && op.tw.trace) {
+            std::vector<unsigned long long> h(512);
+            HIP_CHECK(hipMemcpy(h.data(), op.tw.trace, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (int wv = 0; wv < 2; ++wv) {
+                fprintf(stderr, "tower trace wave %d:", wv * 4);
+                for (int i = 1; i < 256 && h[wv * 256 + i]; ++i) fprintf(stderr, " %llu", h[wv * 256 + i] - h[wv * 256 + i - 1]);
+                fprintf(stderr, "\n");
+                if (wv == 1 && h[256 + 220]) {
+                    fprintf(stderr, "tower vector fine trace (park+read, pair0..3, store):");
+                    for (int i = 221; i < 227; ++i) fprintf(stderr, " %lld", (long long)(h[256 + i] - h[256 + i - 1]));
+                    fprintf(stderr, "\n");
+                }
+                if (wv == 0 && h[200]) {
+                    fprintf(stderr, "tower fine trace (E loop, E epilogue, P loop, barrier) x3:");
+                    for (int i = 201; i < 215; ++i) fprintf(stderr, " %lld", (long long)(h[i] - h[i - 1]));
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
 }
 
 float RiseNet::time_forward(int iters) {

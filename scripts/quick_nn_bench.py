@@ -14,7 +14,7 @@ cfg = ro.rise_v2_config(nblk)
 sd = ro.make_state_dict(cfg, seed=1)
 tmp = tempfile.mkdtemp()
 d = nn_cases.export_case(tmp, "b", cfg, sd)
-for prec in ("float16", "float16-unfused", "float32"):
+for prec in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("float16", "float16-perblock", "float16-unfused", "float32")):
     net = HipAPI(0, B, d, prec)
     x = nn_cases.synthetic_planes(B, 34, 5)
     torch.as_tensor(net.device_buffers()["planes"], device="cuda").copy_(x.cuda()); torch.cuda.synchronize()

@@ -19,9 +19,11 @@ pytestmark = pytest.mark.gpu
 
 TOL = {"float32": dict(logit=1e-4, value=1e-4, prob=1e-6, aux=1e-4),
        "float16": dict(logit=6e-3, value=1e-3, prob=1e-3, aux=5e-3)}
-# "-unfused" = layer-granular kernels (conv GEMM / depthwise / project as separate launches) instead of the fused block kernel
+# float16 runs the residual-tower kernel (runs of 3x3 blocks in one launch); "-perblock" = one fused launch per bottleneck
+# block, "-unfused" = layer-granular kernels (conv GEMM / depthwise / project as separate launches): three implementations
 TOL["float32-unfused"] = TOL["float32"]
 TOL["float16-unfused"] = TOL["float16"]
+TOL["float16-perblock"] = TOL["float16"]
 
 
 def _run(tmp_path, hip_lib, name, precision):
@@ -43,7 +45,7 @@ def _run(tmp_path, hip_lib, name, precision):
     return cfg, sd, x, value, probs.reshape(B, -1), aux, logits
 
 
-@pytest.mark.parametrize("precision", ["float32", "float16", "float32-unfused", "float16-unfused"])
+@pytest.mark.parametrize("precision", ["float32", "float16", "float16-perblock", "float32-unfused", "float16-unfused"])
 @pytest.mark.parametrize("name", list(nn_cases.CASES))
 def test_predict_matches_oracle_and_golden(tmp_path, hip_lib, name, precision):
     cfg, sd, x, value, probs, aux, logits = _run(tmp_path, hip_lib, name, precision)

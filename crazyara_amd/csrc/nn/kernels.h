@@ -63,21 +63,22 @@ template <typename T> void init_block_kernel_attributes();
 template <typename T> int block_chunk_channels();   // C_op must be padded to a multiple of this
 
 // Residual tower: a run of consecutive 3x3 bottleneck blocks in one launch, one workgroup per board, residual stream
-// resident in LDS, SE gates computed in-kernel (tower.hip).  f16 only, C = 256.  The conv weights of the whole run are
-// packed into per-wave streams in consumption order (rise_net.hip: TowerPacker):
-//   wstream  4 matrix waves x [fragments of 64 lanes x 8 halves]: per block, per interval k = -1..n: the expand fragments
-//            of chunk k+1 ([k-slab s][tile e], 8 unused padding fragments after a 64-channel tail chunk), then the project
-//            fragments of chunk k-1 ([k-slab s2][cout tile j] in tower K order, 8 padding fragments after a tail chunk);
-//            kTowerWindow padding fragments at the very end
-//   bstream  4 matrix waves x per chunk [lane group lg][tile e][row r] BN1 biases (32 floats)
-//   pstream  4 vector waves x per chunk 8 steps (e*4 + r) x [lg][12 floats = 9 folded taps, BN2 bias, 0, 0]; one chunk of padding
+// resident in LDS, SE gates computed in-kernel (tower.hip).  f16 only, C = 256, C_op padded to whole chunks of 128.
+// The conv weights of the whole run are packed into per-wave streams in consumption order (rise_net.hip):
+//   wstream  4 matrix waves x fragments of 64 lanes x 8 halves = v_mfma_f32_32x32x16_f16 A operands (lane l, element j:
+//            row l%32, k (l/32)*8 + j).  Per block, per interval k = -1..n: 16 expand fragments of chunk k+1 ([k-step of 16],
+//            rows = channels chunk*128 + w*32 + row), then 16 project fragments of chunk k-1 ([k-step of 16][row tile of 32],
+//            rows = couts w*64 + rt*32 + row, k = tower K position); kTowerWindow zero fragments at the very end
+//   bstream  4 matrix waves x per chunk [lane/32][element v] BN1 bias of row (v%4) + 8*(v/4) + 4*(lane/32)   (32 floats)
+//   pstream  4 vector waves x per chunk 1 KiB = [lane group lg][16 entries: 9 folded taps, BN2 bias, 6 x pad][4 channel pairs] half2
+//            for K positions w*32 + lg*8 + pi*2 + {0,1}; one chunk of padding at the end
 constexpr int kTowerWindow = 16;
 struct TowerBlockDesc {
     const float* b3;      // [256] BN3 bias
     const void* se_w1;    // f16: ca_se W1 transposed [256][128]; eca_se centre tap transposed [256][256]; or nullptr
     const void* se_w2;    // f16: ca_se W2 transposed [128][256]
     const float* se_b;    // eca_se bias [256]
-    int cop_pad;          // multiple of 64
+    int cop_pad;          // multiple of 128
     int se_kind;          // 0 none, 1 ca_se, 2 eca_se: gate applied to this block's input (from the previous block's output sums)
 };
 struct TowerArgs {
@@ -86,24 +87,24 @@ struct TowerArgs {
     const TowerBlockDesc* blocks;   // device array
     const void* wstream;
     const float* bstream;
-    const float* pstream;
-    long long wstream_wave_frags, bstream_wave_floats, pstream_wave_floats;   // per-wave stream lengths
+    const void* pstream;
+    long long wstream_wave_frags, bstream_wave_floats, pstream_wave_bytes;    // per-wave stream lengths
     int nblocks;
     int batch;
     const float* gate_in; // optional [B][256]: SE gate of blocks[0] computed by a previous launch (blocks[0].se_kind is ignored)
     float* pool_out;      // optional [B][256]: sum over the 64 squares of y (feeds an SE gate computed by a later launch)
-    unsigned long long* trace;   // development: s_memtime stamps of workgroup 0 (CRA_TOWER_TRACE), [wave 0 | wave 4][1 + 3 * nblocks + ...]
-    int debug;            // development switches (CRA_TOWER_DEBUG): 1 skip MFMAs, 2 skip depthwise math, 4 no stream refills
+    unsigned long long* trace;   // development: s_memtime stamps of workgroup 0 (CRA_TOWER_TRACE), [wave 0 | wave 4][256]
 };
 void launch_tower(const TowerArgs& a, hipStream_t s);
 void init_tower_kernel_attributes();
 size_t tower_lds_bytes();
-// K position kpos of the tower's project GEMM -> C_op channel (chunks of 128; inside a chunk the 16-channel expand tile v
-// occupies positions (v/2)*32 + lg*8 + (v%2)*4 + r for its rows lg*4 + r)
+// K position of the tower's project GEMM (= position inside the t1 / t2 tiles) -> C_op channel.  Chunks of 128; wave w's
+// 32 positions hold its 32 expand rows in the order a 32x32 MFMA result leaves them in a lane: position p <-> row
+// (p%4) + 8*((p%16)/4) + 4*(p/16), so that a lane's 16 results are 16 consecutive positions.
+inline int tower_row_of_position(int p) { return (p % 4) + 8 * ((p % 16) / 4) + 4 * (p / 16); }
 inline int tower_k_channel(int kpos) {
-    const int chunk = kpos / 128, p = kpos % 128;
-    const int v = (p / 32) * 2 + (p % 8) / 4, lg = (p % 32) / 8, r = p % 4;
-    return chunk * 128 + v * 16 + lg * 4 + r;
+    const int chunk = kpos / 128, wq = (kpos % 128) / 32, p = kpos % 32;
+    return chunk * 128 + wq * 32 + tower_row_of_position(p);
 }
 
 // depthwise k x k (k = 3 or 5) + folded BN + ReLU.  w: [k*k][C] float, bias: [C] float

@@ -73,22 +73,6 @@ std::vector<T> pack_dense(const Folded& f, int cout, int cin, int ks, int cout_p
     return out;
 }
 
-// project weights [C][cop] (1x1) as MFMA A fragments with the K axis in the tower kernel's order (kernels.h: tower_k_channel)
-std::vector<half_t> pack_project_tower(const Folded& f, int cout, int cop, int cop_pad) {
-    const int nslab = cop_pad / 32, nct = cout / 16;
-    std::vector<half_t> out(size_t(cout) * cop_pad);
-    for (int ct = 0; ct < nct; ++ct)
-        for (int s = 0; s < nslab; ++s)
-            for (int l = 0; l < 64; ++l)
-                for (int j = 0; j < 8; ++j) {
-                    const int co = ct * 16 + (l & 15);
-                    const int ci = tower_k_channel(s * 32 + (l >> 4) * 8 + j);
-                    const double v = ci < cop ? f.w[size_t(co) * cop + ci] : 0.0;
-                    out[((size_t(ct) * nslab + s) * 64 + l) * 8 + j] = half_t(float(v));
-                }
-    return out;
-}
-
 enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower };
 
 struct Op {
@@ -281,7 +265,8 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     const bool tower_ok = tower_ && fused_ && kHalf && C == 256;
     std::vector<TowerBlockDesc> tower_blocks;
     std::vector<half_t> tower_ws[4];          // per matrix wave: MFMA A fragments in consumption order (kernels.h: TowerArgs)
-    std::vector<float> tower_bs[4], tower_ps[4];
+    std::vector<float> tower_bs[4];
+    std::vector<half_t> tower_ps[4];          // per vector wave: packed f16 depthwise weights (kernels.h: pstream)
     const float* tower_gate = nullptr;
     auto flush_tower = [&]() {
         if (tower_blocks.empty()) return;
@@ -292,11 +277,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         op.tw.blocks = im.upload(tower_blocks);
         op.tw.nblocks = int(tower_blocks.size());
         {   // close the streams: the kernel's windows run one window / one chunk past the end
-            std::vector<half_t> ws;
-            std::vector<float> bs, ps;
+            std::vector<half_t> ws, ps;
+            std::vector<float> bs;
             for (int w = 0; w < 4; ++w) {
                 tower_ws[w].resize(tower_ws[w].size() + size_t(kTowerWindow) * 512, half_t(0.f));
-                tower_ps[w].resize(tower_ps[w].size() + 8 * 48, 0.f);
+                tower_ps[w].resize(tower_ps[w].size() + 512, half_t(0.f));
                 tower_bs[w].resize(tower_bs[w].size() + 32, 0.f);
                 ws.insert(ws.end(), tower_ws[w].begin(), tower_ws[w].end());
                 bs.insert(bs.end(), tower_bs[w].begin(), tower_bs[w].end());
@@ -307,12 +292,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             op.tw.pstream = im.upload(ps);
             op.tw.wstream_wave_frags = (long long)(tower_ws[0].size() / 512);
             op.tw.bstream_wave_floats = (long long)tower_bs[0].size();
-            op.tw.pstream_wave_floats = (long long)tower_ps[0].size();
+            op.tw.pstream_wave_bytes = (long long)(tower_ps[0].size() * sizeof(half_t));
             for (int w = 0; w < 4; ++w) { tower_ws[w].clear(); tower_bs[w].clear(); tower_ps[w].clear(); }
         }
         op.tw.batch = B;
         op.tw.gate_in = tower_gate;
-        if (const char* dbg = getenv("CRA_TOWER_DEBUG")) op.tw.debug = atoi(dbg);
         if (getenv("CRA_TOWER_TRACE")) op.tw.trace = static_cast<unsigned long long*>(im.dalloc(2 * 256 * sizeof(unsigned long long)));
         prod_op = int(im.ops.size());
         im.ops.push_back(op);
@@ -395,57 +379,51 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         if (in_tower) {
             // residual tower: this block joins the current run of 3x3 blocks (one launch per run, kernels.h: TowerArgs)
             if constexpr (kHalf) {
-                const int cop_pad = round_up(cop, 64);
+                const int cop_pad = round_up(cop, 128);
                 Folded f1 = fold_bn(nf, p + ".body.0", p + ".body.1");
                 Folded f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
                 Folded f3 = fold_bn(nf, p + ".body.6", p + ".body.7");
-                const std::vector<T> w1pk = pack_dense<T>(f1, cop, C, 1, cop_pad, C);           // [tile][8 slabs][64][8]
-                const std::vector<half_t> w3pk = pack_project_tower(f3, C, cop, cop_pad);       // [16 cout tiles][cop_pad/32][64][8]
-                const int n = (cop_pad + 127) / 128, nslab3 = cop_pad / 32;
-                const bool tail = (cop_pad % 128) != 0;
-                // expand tile index of (chunk c, wave w, e): full chunk w*2+e, 64-channel tail chunk w (e = 0 only); -1 = padding
-                auto tile_of = [&](int c, int w, int e) { return (tail && c == n - 1) ? (e == 0 ? c * 8 + w : -1) : c * 8 + w * 2 + e; };
-                const half_t hz = half_t(0.f);
+                const int n = cop_pad / 128;
                 for (int w = 0; w < 4; ++w) {
                     std::vector<half_t>& ws = tower_ws[w];
                     for (int kk = -1; kk <= n; ++kk) {                 // interval: E(kk+1) then P(kk-1)
-                        if (kk + 1 < n) {
+                        if (kk + 1 < n) {                              // expand A fragments [k-step]: rows = my 32 channels, k = input channel
                             const int c = kk + 1;
-                            for (int sl = 0; sl < 8; ++sl)
-                                for (int e = 0; e < 2; ++e) {
-                                    const int tl = tile_of(c, w, e);
-                                    if (tl < 0) ws.insert(ws.end(), 512, hz);
-                                    else ws.insert(ws.end(), w1pk.begin() + (size_t(tl) * 8 + sl) * 512, w1pk.begin() + (size_t(tl) * 8 + sl + 1) * 512);
-                                }
+                            for (int ks = 0; ks < 16; ++ks)
+                                for (int l = 0; l < 64; ++l)
+                                    for (int j = 0; j < 8; ++j) {
+                                        const int ch = c * 128 + w * 32 + (l & 31), k = ks * 16 + (l >> 5) * 8 + j;
+                                        ws.push_back(half_t(ch < cop ? float(f1.w[size_t(ch) * C + k]) : 0.f));
+                                    }
                         }
-                        if (kk - 1 >= 0) {
+                        if (kk - 1 >= 0) {                             // project A fragments [k-step][row tile]: rows = my 64 couts, k = tower K position
                             const int c = kk - 1;
-                            for (int s2 = 0; s2 < 4; ++s2)
-                                for (int j = 0; j < 4; ++j) {
-                                    const int slab = c * 4 + s2;
-                                    const size_t off = (size_t(w * 4 + j) * nslab3 + slab) * 512;
-                                    if (slab >= nslab3) ws.insert(ws.end(), 512, hz);
-                                    else ws.insert(ws.end(), w3pk.begin() + off, w3pk.begin() + off + 512);
-                                }
+                            for (int ks = 0; ks < 8; ++ks)
+                                for (int rt = 0; rt < 2; ++rt)
+                                    for (int l = 0; l < 64; ++l)
+                                        for (int j = 0; j < 8; ++j) {
+                                            const int co = w * 64 + rt * 32 + (l & 31);
+                                            const int ch = tower_k_channel(c * 128 + ks * 16 + (l >> 5) * 8 + j);
+                                            ws.push_back(half_t(ch < cop ? float(f3.w[size_t(co) * cop + ch]) : 0.f));
+                                        }
                         }
                     }
                     for (int c = 0; c < n; ++c) {
-                        for (int lgk = 0; lgk < 4; ++lgk)               // BN1 biases [lg][e][r]
-                            for (int e = 0; e < 2; ++e)
-                                for (int r = 0; r < 4; ++r) {
-                                    const int tl = tile_of(c, w, e), ch = tl * 16 + lgk * 4 + r;
-                                    tower_bs[w].push_back(tl >= 0 && ch < cop ? float(f1.b[ch]) : 0.f);
-                                }
-                        for (int step = 0; step < 8; ++step)            // depthwise records [step = e*4 + r][lg][12]
-                            for (int lgk = 0; lgk < 4; ++lgk) {
-                                const int tl = tile_of(c, w, step >> 2), ch = tl * 16 + lgk * 4 + (step & 3);
-                                float rec[12] = {0.f};
-                                if (tl >= 0 && ch < cop) {
-                                    for (int t = 0; t < 9; ++t) rec[t] = float(f2.w[size_t(ch) * 9 + t]);
-                                    rec[9] = float(f2.b[ch]);
-                                }
-                                tower_ps[w].insert(tower_ps[w].end(), rec, rec + 12);
+                        for (int lh = 0; lh < 2; ++lh)                  // BN1 biases [lane/32][accumulator element v]
+                            for (int v = 0; v < 16; ++v) {
+                                const int ch = c * 128 + w * 32 + (v % 4) + 8 * (v / 4) + 4 * lh;
+                                tower_bs[w].push_back(ch < cop ? float(f1.b[ch]) : 0.f);
                             }
+                        // depthwise weights [lg][entry: 9 taps, BN2 bias, 6 x pad][pair pi][2] for K positions w*32 + lg*8 + pi*2 + {0,1}
+                        for (int lgk = 0; lgk < 4; ++lgk)
+                            for (int ent = 0; ent < 16; ++ent)
+                                for (int pi = 0; pi < 4; ++pi)
+                                    for (int hh = 0; hh < 2; ++hh) {
+                                        const int ch = tower_k_channel(c * 128 + w * 32 + lgk * 8 + pi * 2 + hh);
+                                        double v = 0.0;
+                                        if (ch < cop && ent < 10) v = ent < 9 ? f2.w[size_t(ch) * 9 + ent] : f2.b[ch];
+                                        tower_ps[w].push_back(half_t(float(v)));
+                                    }
                     }
                 }
                 td.b3 = im.upload_d2f(f3.b, C);
@@ -723,16 +701,6 @@ void RiseNet::time_ops(int iters, float* ms) {
                 fprintf(stderr, "tower trace wave %d:", wv * 4);
                 for (int i = 1; i < 256 && h[wv * 256 + i]; ++i) fprintf(stderr, " %llu", h[wv * 256 + i] - h[wv * 256 + i - 1]);
                 fprintf(stderr, "\n");
-                if (wv == 1 && h[256 + 220]) {
-                    fprintf(stderr, "tower vector fine trace (park+read, pair0..3, store):");
-                    for (int i = 221; i < 227; ++i) fprintf(stderr, " %lld", (long long)(h[256 + i] - h[256 + i - 1]));
-                    fprintf(stderr, "\n");
-                }
-                if (wv == 0 && h[200]) {
-                    fprintf(stderr, "tower fine trace (E loop, E epilogue, P loop, barrier) x3:");
-                    for (int i = 201; i < 215; ++i) fprintf(stderr, " %lld", (long long)(h[i] - h[i - 1]));
-                    fprintf(stderr, "\n");
-                }
             }
         }
 }

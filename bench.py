@@ -122,12 +122,12 @@ def main():
     net.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    from crazyara_amd import replicas
+    # the only collective of the NN leg: SUM of evaluations, MAX of wall time over the replicas
+    evals, elapsed, _ = replicas.reduce_stats(replicas.ReplicaStats(units=float(args.steps * args.batch), seconds=elapsed), dist,
+                                              torch.device("cuda", local_rank))
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the only collective: timing reduction
-        elapsed = float(t.item())
         dist.barrier()
-    evals = args.steps * args.batch * world
     value = evals / elapsed
 
     # ---- MCTS leg (BASELINE config 2: batch 256, 1600 simulations per search, fixed opening set) ----
@@ -143,15 +143,13 @@ def main():
             pool.add_position(fens[(i * 7 + rank * 3) % len(fens)], False, "crazyhouse")
         threads = max(1, min(args.search_threads, (os.cpu_count() or 1) // max(1, world)))
         stt = pool.run(simulations=args.simulations, threads=threads)
-        loc = torch.tensor([float(stt.nodes), float(stt.nn_evals), float(stt.simulations), stt.seconds], device="cuda", dtype=torch.float64)
-        tot = loc.clone()
-        if dist is not None:
-            mx = loc[3:4].clone()
-            dist.all_reduce(tot, op=dist.ReduceOp.SUM)     # RCCL sum of {nodes, evals, simulations}
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            tot[3] = mx[0]
-        mcts = {"mcts_nodes_per_sec": round(float(tot[0] / tot[3]), 1), "mcts_nn_evals_per_sec": round(float(tot[1] / tot[3]), 1),
-                "simulations_per_sec": round(float(tot[2] / tot[3]), 1), "seconds": round(float(tot[3]), 3),
+        # RCCL sum of {nodes, evals, simulations}, max of seconds
+        nodes_t, sec_t, ex = replicas.reduce_stats(replicas.ReplicaStats(units=float(stt.nodes), seconds=stt.seconds,
+                                                                           extra=(float(stt.nn_evals), float(stt.simulations))),
+                                                     dist, torch.device("cuda", local_rank))
+        tot = [nodes_t, ex[0], ex[1], sec_t]
+        mcts = {"mcts_nodes_per_sec": round(tot[0] / tot[3], 1), "mcts_nn_evals_per_sec": round(tot[1] / tot[3], 1),
+                "simulations_per_sec": round(tot[2] / tot[3], 1), "seconds": round(tot[3], 3),
                 "trees_per_gpu": n_trees, "simulations_per_tree": args.simulations, "per_tree_quota": args.search_quota,
                 "lanes": 2, "host_threads_per_gpu": threads, "avg_batch_fill": round(stt.nn_evals / max(1, stt.batches) / args.batch, 3),
                 "depth_avg": round(stt.depth_avg, 2), "depth_max": int(stt.depth_max)}

@@ -107,6 +107,37 @@ inline int tower_k_channel(int kpos) {
     return chunk * 128 + wq * 32 + tower_row_of_position(p);
 }
 
+// Policy + value head in one launch, one workgroup per board (head.hip).  f16, C = 256, value head 8 channels / 512 flat.
+//   s1  8 waves x [9 taps][16 k-steps] A fragments of policy conv 1 (rows = couts 32*wave + row), then 16 fragments of the
+//       value head's 1x1 conv for wave 0 (rows 0..7; zeros for the other waves), then 16 zero fragments
+//   b1  [wave][lane/32][16] folded BN bias of policy conv 1, rows (v%4) + 8*(v/4) + 4*(lane/32)
+//   s2  8 waves x 18 (tap, k-step) units x 3 row tiles of policy conv 2 (unit u = 18*wave + i: tap u/16, k-step u%16; K position
+//       -> conv-1 channel as in tower_k_channel), then 9 zero fragments
+struct HeadArgs {
+    const void* x;            // [B][64][256] f16
+    float* logits;            // [B][cp*64] policy_out
+    float* probs;             // [B][cp*64] softmax
+    float* value;             // [B]
+    float* aux;               // [B][4] or nullptr
+    const void* s1;
+    const float* b1;
+    const void* s2;
+    long long s1_wave_frags, s2_wave_frags;
+    const float* vconv_bias;  // [8]
+    const void* fc1_w;        // tanh head: f16 [512][256] (k-major);  WDLP head: float [4][512] (wdl rows 0..2, plys)
+    const float* fc1_b;       // [256]
+    const float* fc2_w;       // [256]
+    float fc2_b;
+    float wdl_b[4];
+    int cp;                   // policy channels, <= 96
+    int wdlp;
+    int batch;
+    unsigned long long* trace;   // development: s_memtime stamps of workgroup 0, wave 0 (CRA_TOWER_TRACE)
+};
+void launch_head(const HeadArgs& a, hipStream_t s);
+void init_head_kernel_attributes();
+size_t head_lds_bytes();
+
 // depthwise k x k (k = 3 or 5) + folded BN + ReLU.  w: [k*k][C] float, bias: [C] float
 template <typename T> void launch_depthwise(const T* x, T* y, const float* w, const float* bias, int batch, int C, int ks,
                                             hipStream_t s);

@@ -73,7 +73,7 @@ std::vector<T> pack_dense(const Folded& f, int cout, int cin, int ks, int cout_p
     return out;
 }
 
-enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower };
+enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head };
 
 struct Op {
     OpKind kind;
@@ -87,6 +87,7 @@ struct Op {
     BlockArgs blk{};
     ValueFinalArgs vf{};
     TowerArgs tw{};
+    HeadArgs hd{};
 };
 }  // namespace
 
@@ -495,6 +496,89 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
     }
     flush_tower();
+    const bool head_ok = tower_ok && cv == 8 && cp <= 96 && (wdl || fc == 256);
+    if (head_ok) {
+        // policy + value head in one launch (head.hip; stream layouts in kernels.h: HeadArgs)
+        if constexpr (kHalf) {
+            Folded f1 = fold_bn(nf, "policy_head.body.0", "policy_head.body.1");
+            Folded f2 = fold_bn(nf, "policy_head.body.3", "");
+            Folded fv = fold_bn(nf, "value_head.body.0", "value_head.body.1");
+            std::vector<half_t> s1, s2;
+            std::vector<float> b1;
+            const half_t hz = half_t(0.f);
+            for (int wv = 0; wv < 8; ++wv) {
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int ks = 0; ks < 16; ++ks)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j) {
+                                const int co = wv * 32 + (l & 31), ci = ks * 16 + (l >> 5) * 8 + j;
+                                s1.push_back(half_t(float(f1.w[(size_t(co) * C + ci) * 9 + tap])));
+                            }
+                for (int ks = 0; ks < 16; ++ks)          // value head 1x1 conv (wave 0), rows 0..7
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = l & 31, ci = ks * 16 + (l >> 5) * 8 + j;
+                            s1.push_back(wv == 0 && row < cv ? half_t(float(fv.w[size_t(row) * C + ci])) : hz);
+                        }
+                s1.insert(s1.end(), size_t(16) * 512, hz);
+                for (int lh = 0; lh < 2; ++lh)
+                    for (int v = 0; v < 16; ++v) b1.push_back(float(f1.b[wv * 32 + (v % 4) + 8 * (v / 4) + 4 * lh]));
+                for (int i = 0; i < 18; ++i) {
+                    const int u = wv * 18 + i, tap = u >> 4, ks = u & 15;
+                    for (int rt = 0; rt < 3; ++rt)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j) {
+                                const int co = rt * 32 + (l & 31), kpos = ks * 16 + (l >> 5) * 8 + j;
+                                const int ci = (kpos / 32) * 32 + tower_row_of_position(kpos % 32);
+                                s2.push_back(co < cp ? half_t(float(f2.w[(size_t(co) * C + ci) * 9 + tap])) : hz);
+                            }
+                }
+                s2.insert(s2.end(), size_t(9) * 512, hz);
+            }
+            Op op;
+            op.kind = OpKind::Head;
+            HeadArgs& h = op.hd;
+            h.x = cur;
+            h.logits = d_logits_;
+            h.probs = d_probs_;
+            h.value = d_value_;
+            h.aux = d_aux_;
+            h.s1 = im.upload(s1);
+            h.b1 = im.upload(b1);
+            h.s2 = im.upload(s2);
+            h.s1_wave_frags = 9 * 16 + 16 + 16;
+            h.s2_wave_frags = 18 * 3 + 9;
+            h.vconv_bias = im.upload_d2f(fv.b, 8);
+            h.cp = cp;
+            h.batch = B;
+            if (getenv("CRA_TOWER_TRACE")) h.trace = static_cast<unsigned long long*>(im.dalloc(64 * sizeof(unsigned long long)));
+            const int nfl = kSquares * cv;
+            if (wdl) {
+                const TensorView &ww = nf.get("value_head.body_wdl.0.weight"), &wp = nf.get("value_head.body_plys.0.weight");
+                std::vector<float> w4(size_t(4) * nfl);
+                std::copy(ww.data, ww.data + 3 * nfl, w4.begin());
+                std::copy(wp.data, wp.data + nfl, w4.begin() + 3 * nfl);
+                const float* bw = nf.get("value_head.body_wdl.0.bias").data;
+                h.fc1_w = im.upload(w4);
+                h.wdl_b[0] = bw[0]; h.wdl_b[1] = bw[1]; h.wdl_b[2] = bw[2];
+                h.wdl_b[3] = nf.get("value_head.body_plys.0.bias").data[0];
+                h.wdlp = 1;
+                macs += 4.0 * nfl;
+            } else {
+                const TensorView &w1 = nf.get("value_head.body_final.0.weight"), &w2 = nf.get("value_head.body_final.2.weight");
+                std::vector<half_t> w1t(size_t(nfl) * fc);
+                for (int j = 0; j < fc; ++j) for (int k = 0; k < nfl; ++k) w1t[size_t(k) * fc + j] = half_t(w1.data[size_t(j) * nfl + k]);
+                const float* bb = nf.get("value_head.body_final.0.bias").data;
+                h.fc1_w = im.upload(w1t);
+                h.fc1_b = im.upload(std::vector<float>(bb, bb + fc));
+                h.fc2_w = im.upload(std::vector<float>(w2.data, w2.data + fc));
+                h.fc2_b = nf.get("value_head.body_final.2.bias").data[0];
+                macs += double(nfl) * fc + fc;
+            }
+            macs += double(kSquares) * 9 * (double(C) * C + double(C) * cp) + double(kSquares) * C * cv;
+            im.ops.push_back(op);
+        }
+    } else {
     // _PolicyHead (select_policy_from_plane), builder_util.py:206-243
     add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr);
     add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_);
@@ -623,8 +707,10 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         macs += double(kSquares) * C * cv;
         im.ops.push_back(op);
     }
+    }   // !head_ok
     init_block_kernel_attributes<T>();
     init_tower_kernel_attributes();
+    init_head_kernel_attributes();
     design_.flops_per_position = 2.0 * macs;
     launches_ = int(im.ops.size());
 }
@@ -647,6 +733,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s) {
         case OpKind::Block: launch_block<T>(op.blk, s); break;
         case OpKind::ValueFinal: launch_value_final<T>(op.vf, s); break;
         case OpKind::Tower: launch_tower(op.tw, s); break;
+        case OpKind::Head: launch_head(op.hd, s); break;
         case OpKind::SEGate:
             launch_se_gate(static_cast<const float*>(op.x), static_cast<float*>(op.y), op.se_kind, op.w0, op.w1, op.b0, B, op.C, s);
             break;
@@ -671,6 +758,7 @@ const char* RiseNet::op_name(int i) const {
         case OpKind::ValueFinal: return "value_final";
         case OpKind::SEGate: return "se_gate";
         case OpKind::Tower: return "tower";
+        case OpKind::Head: return "head";
     }
     return "?";
 }
@@ -693,6 +781,14 @@ void RiseNet::time_ops(int iters, float* ms) {
         }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    for (const Op& op : impl_->ops)
+        if (op.kind == OpKind::Head && op.hd.trace) {
+            unsigned long long h[16];
+            HIP_CHECK(hipMemcpy(h, op.hd.trace, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "head trace (load, conv1, pack, conv2, atomics, softmax, value):");
+            for (int i = 1; i < 8; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]);
+            fprintf(stderr, "\n");
+        }
     for (const Op& op : impl_->ops)
         if (op.kind == OpKind::Tower && op.tw.trace) {
             std::vector<unsigned long long> h(512);

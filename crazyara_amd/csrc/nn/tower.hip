@@ -327,6 +327,7 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
 
     unsigned long long* trc = (a.trace != nullptr && b == 0 && (wave == 0 || wave == 4) && lane == 0) ? a.trace + (wave >> 2) * 256 : nullptr;
     int trn = 0;
+    unsigned long long bwait = 0;
 #define TW_STAMP() do { if (trc) trc[trn++] = __builtin_amdgcn_s_memtime(); } while (0)
     TW_STAMP();
 
@@ -394,8 +395,15 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
                 half_t* t1w = t1 + ((k + 1) & 1) * (TW_T1_BYTES / 2) + t1off;
                 const half_t* t2r = t2 + ((k - 1) & 1) * (TW_T2_BYTES / 2) + t2off;
                 matrix_interval(k + 1 < n, k >= 1, accP, win, sp, bp, xsr, t1w, t2r);
-                __syncthreads();
+                if (trc) {                           // development: time spent waiting at the interval barriers
+                    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+                    __syncthreads();
+                    bwait += __builtin_amdgcn_s_memtime() - w0;
+                } else {
+                    __syncthreads();
+                }
             }
+            if (trc) { trc[trn++] = __builtin_amdgcn_s_memtime() - bwait; bwait = 0; }   // loop end stamp minus barrier waits = busy time
             TW_STAMP();
             // ---- block epilogue: y = x + BN3(project), new residual stream back to LDS ----
             // 4 consecutive couts per step: rows 8*g4 + 4*lh + 0..3 = accumulator elements 4*g4 + 0..3; the f16 residual is read
@@ -489,8 +497,15 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
                     if (k & 1) vector_interval<1>(pre, pp, prml, lane, lg, va, t2w, mLp, mRp);
                     else vector_interval<0>(pre, pp, prml, lane, lg, va, t2w, mLp, mRp);
                 }
-                __syncthreads();
+                if (trc) {
+                    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+                    __syncthreads();
+                    bwait += __builtin_amdgcn_s_memtime() - w0;
+                } else {
+                    __syncthreads();
+                }
             }
+            if (trc) { trc[trn++] = __builtin_amdgcn_s_memtime() - bwait; bwait = 0; }
             TW_STAMP();
             __syncthreads();             // the matrix waves' block epilogue
             TW_STAMP();

@@ -107,6 +107,19 @@ inline int tower_k_channel(int kpos) {
     return chunk * 128 + wq * 32 + tower_row_of_position(p);
 }
 
+// Stem in one launch, one workgroup per board (stem.hip): fp32 NCHW planes -> conv3x3 + BN + ReLU -> f16 NHWC.
+struct StemArgs {
+    const float* planes;  // [B][cin][64] fp32 NCHW (the NeuralNetAPI::predict input)
+    void* x;              // [B][64][256] f16
+    const void* stem_w;   // 8 waves x [9 taps][cin_pad/16 k-steps] A fragments (32x32x16: lane l, element j: cout 32*wave + l%32,
+                          // cin k-step*16 + (l/32)*8 + j), then 16 zero fragments
+    const float* stem_b;  // [wave][lane/32][16] folded BN bias, rows (v%4) + 8*(v/4) + 4*(lane/32)
+    long long stem_wave_frags;
+    int cin, cin_pad;     // cin_pad: multiple of 16 in [48, 96]
+    int batch;
+};
+void launch_stem(const StemArgs& a, hipStream_t s);
+
 // Policy + value head in one launch, one workgroup per board (head.hip).  f16, C = 256, value head 8 channels / 512 flat.
 //   s1  8 waves x [9 taps][16 k-steps] A fragments of policy conv 1 (rows = couts 32*wave + row), then 16 fragments of the
 //       value head's 1x1 conv for wave 0 (rows 0..7; zeros for the other waves), then 16 zero fragments

@@ -73,7 +73,7 @@ std::vector<T> pack_dense(const Folded& f, int cout, int cin, int ks, int cout_p
     return out;
 }
 
-enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head };
+enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem };
 
 struct Op {
     OpKind kind;
@@ -88,6 +88,7 @@ struct Op {
     ValueFinalArgs vf{};
     TowerArgs tw{};
     HeadArgs hd{};
+    StemArgs st{};
 };
 }  // namespace
 
@@ -246,15 +247,48 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         macs += double(kSquares) * ci * co * k * k;
     };
 
-    {   // input layout transform
+    const int cin_pad16 = std::max(48, round_up(cin, 16));
+    if (tower_ && fused_ && std::is_same<T, half_t>::value && C == 256 && cin_pad16 <= 96) {
+        // stem kernel: planes -> conv3x3 + BN + ReLU -> NHWC f16 in one launch (stem.hip)
+        Folded fs = fold_bn(nf, "body_spatial.0.body.0", "body_spatial.0.body.1");
+        const int nks = cin_pad16 / 16;
+        std::vector<half_t> sw;
+        std::vector<float> sb;
+        for (int wv = 0; wv < 8; ++wv) {
+            for (int tap = 0; tap < 9; ++tap)
+                for (int ksx = 0; ksx < nks; ++ksx)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = wv * 32 + (l & 31), ci = ksx * 16 + (l >> 5) * 8 + j;
+                            sw.push_back(half_t(ci < cin ? float(fs.w[(size_t(co) * cin + ci) * 9 + tap]) : 0.f));
+                        }
+            sw.insert(sw.end(), size_t(16) * 512, half_t(0.f));
+            for (int lh = 0; lh < 2; ++lh)
+                for (int v = 0; v < 16; ++v) sb.push_back(float(fs.b[wv * 32 + (v % 4) + 8 * (v / 4) + 4 * lh]));
+        }
         Op op;
-        op.kind = OpKind::PlanesToAct;
-        op.x = d_planes_;
-        op.y = x0;
-        op.C = cin;
+        op.kind = OpKind::Stem;
+        op.st.planes = d_planes_;
+        op.st.x = a0;
+        op.st.stem_w = im.upload(sw);
+        op.st.stem_b = im.upload(sb);
+        op.st.stem_wave_frags = 9 * nks + 16;
+        op.st.cin = cin;
+        op.st.cin_pad = cin_pad16;
+        op.st.batch = B;
         im.ops.push_back(op);
+        macs += double(kSquares) * cin * C * 9;
+    } else {
+        {   // input layout transform
+            Op op;
+            op.kind = OpKind::PlanesToAct;
+            op.x = d_planes_;
+            op.y = x0;
+            op.C = cin;
+            im.ops.push_back(op);
+        }
+        add_conv("body_spatial.0.body.0", "body_spatial.0.body.1", x0, a0, nullptr, cin, cin_pad, C, 3, true, nullptr);   // _Stem
     }
-    add_conv("body_spatial.0.body.0", "body_spatial.0.body.1", x0, a0, nullptr, cin, cin_pad, C, 3, true, nullptr);   // _Stem
     T *cur = a0, *nxt = a1;
     // SE plumbing for the fused paths: the squeeze (per-channel sums) is produced by the previous block / tower kernel's
     // epilogue, a small gate kernel turns it into gate[b][c], and the consumer's prologue multiplies it into x while
@@ -734,6 +768,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s) {
         case OpKind::ValueFinal: launch_value_final<T>(op.vf, s); break;
         case OpKind::Tower: launch_tower(op.tw, s); break;
         case OpKind::Head: launch_head(op.hd, s); break;
+        case OpKind::Stem: launch_stem(op.st, s); break;
         case OpKind::SEGate:
             launch_se_gate(static_cast<const float*>(op.x), static_cast<float*>(op.y), op.se_kind, op.w0, op.w1, op.b0, B, op.C, s);
             break;
@@ -759,6 +794,7 @@ const char* RiseNet::op_name(int i) const {
         case OpKind::SEGate: return "se_gate";
         case OpKind::Tower: return "tower";
         case OpKind::Head: return "head";
+        case OpKind::Stem: return "stem";
     }
     return "?";
 }

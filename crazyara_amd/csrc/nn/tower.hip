@@ -62,6 +62,19 @@ __device__ __forceinline__ uint32_t pack_relu_h2(float a, float ca, float b, flo
     return r;
 }
 
+// A weight stream of one wave, read with raw buffer loads: resource descriptor + byte position live in SGPRs, the lane offset is
+// one constant VGPR, so a refill costs no vector address arithmetic (a flat load needs a 64-bit add per 4 KiB of stream).
+struct WStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t pos;        // byte position of the window start (wave-uniform)
+    uint32_t lane_off;   // lane * 16
+    __device__ __forceinline__ half8 frag_at(int q) const {      // fragment q positions after the window start
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, pos + uint32_t(q) * 1024u, 0);
+        return __builtin_bit_cast(half8, v);
+    }
+};
+
 // D(32x32) += A(32 x 16) * B(16 x 32): lane l holds A[row l%32][k = (l/32)*8 + j], B[k = (l/32)*8 + j][col l%32], j = 0..7;
 // D[row (v%4) + 8*(v/4) + 4*(l/32)][col l%32] in element v.
 __device__ __forceinline__ void mma32(const half8& a, const half8& b, f32x16& c) {
@@ -74,7 +87,7 @@ __device__ __forceinline__ void mma32(const half8& a, const half8& b, f32x16& c)
 //         fragment 16 positions ahead as soon as its MFMAs are issued.  E consumes 16 fragments ([k-step]), P 16 ([k-step][row tile]).
 //   A step = 4 MFMAs + the LDS reads of the NEXT step's B fragments + 2 refills; nothing is scheduled across step boundaries.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&accP)[2][2], half8 (&win)[TW_WIN], const half8* __restrict__& sp,
+__device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&accP)[2][2], half8 (&win)[TW_WIN], WStream& sp,
                                                 const float* __restrict__& bp, const half_t* xsr, half_t* t1w, const half_t* t2r) {
     using frag = half8;
     constexpr int XROW = TW_XROW, T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
@@ -102,10 +115,10 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
 #pragma unroll
             for (int i = 0; i < 4; ++i) mma32(win[s * 2 + (i >> 1)], cur[i], accE[i & 1]);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) win[s * 2 + e] = sp[(s * 2 + e + TW_WIN) * 64];
+            for (int e = 0; e < 2; ++e) win[s * 2 + e] = sp.frag_at(s * 2 + e + TW_WIN);
             __builtin_amdgcn_sched_barrier(0);
         }
-        sp += 16 * 64;
+        sp.pos += 16 * 1024;
     }
     // expand epilogue for square tile ct: BN1 bias + ReLU -> f16.  A lane's 16 rows are 16 consecutive K positions of the tile
     // the project GEMM reads as its B operand (position p <-> row (p%4) + 8*((p%16)/4) + 4*(p/16), kernels.h: tower_k_channel),
@@ -138,10 +151,10 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
                     for (int ct = 0; ct < 2; ++ct) mma32(win[(s * 2 + kk) * 2 + rt], cur[kk * 2 + ct], accP[rt][ct]);
             if (do_e && s < 2) expand_epilogue(s);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) win[s * 4 + e] = sp[(s * 4 + e + TW_WIN) * 64];
+            for (int e = 0; e < 4; ++e) win[s * 4 + e] = sp.frag_at(s * 4 + e + TW_WIN);
             __builtin_amdgcn_sched_barrier(0);
         }
-        sp += 16 * 64;
+        sp.pos += 16 * 1024;
     } else if (do_e) {
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last expand MFMAs retire before the asm epilogue reads them
         expand_epilogue(0);
@@ -366,11 +379,14 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
     // C_op is padded to whole chunks of 128 (zero weights), so every chunk is full.
     if (is_matrix) {
         // open the weight stream first: its window flies while the board tile comes in
-        const frag* sp = reinterpret_cast<const frag*>(a.wstream) + size_t(w) * a.wstream_wave_frags * 64 + lane;
+        WStream sp;
+        sp.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.wstream)) + size_t(w) * a.wstream_wave_frags * 1024, 0, 0x7fffffff, 0x00020000);
+        sp.pos = 0;
+        sp.lane_off = lane * 16;
         const float* bp = a.bstream + size_t(w) * a.bstream_wave_floats + lh * 16;
         frag win[TW_WIN];
 #pragma unroll
-        for (int q = 0; q < TW_WIN; ++q) win[q] = sp[q * 64];
+        for (int q = 0; q < TW_WIN; ++q) win[q] = sp.frag_at(q);
         load_board();
         __syncthreads();
         TW_STAMP();

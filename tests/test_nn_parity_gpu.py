@@ -62,6 +62,22 @@ def test_predict_matches_oracle_and_golden(tmp_path, hip_lib, name, precision):
         assert np.abs(aux.reshape(-1, 4) - o_aux.numpy()).max() < tol["aux"]
 
 
+@pytest.mark.parametrize("batch", [1, 3, 300])
+def test_tower_and_head_kernels_any_batch_size(tmp_path, hip_lib, batch):
+    """One workgroup per board: batch sizes below / not a multiple of / above the 256 CUs must all be exact per row."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, _ = nn_cases.make_case("risev2-7")
+    x = nn_cases.synthetic_planes(batch, cfg.nb_input_channels, 4242)
+    d = nn_cases.export_case(tmp_path, "risev2-7", cfg, sd)
+    net = HipAPI(0, batch, d, "float16")
+    v, p = np.zeros(batch, np.float32), np.zeros(batch * cfg.nb_policy, np.float32)
+    net.predict(np.ascontiguousarray(x.numpy()), v, p)
+    net.close()
+    o_value, o_logits, _ = ro.forward(cfg, sd, x)
+    assert np.abs(v - o_value.numpy().reshape(-1)).max() < TOL["float16"]["value"]
+    assert np.abs(p.reshape(batch, -1) - torch.softmax(o_logits, 1).numpy()).max() < TOL["float16"]["prob"]
+
+
 def test_partial_batch_and_stale_slots(tmp_path, hip_lib):
     """predict always runs the full fixed batch; rows are independent, stale trailing slots must not matter
     (engine/src/searchthread.cpp:407-411)."""

@@ -316,7 +316,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             std::vector<float> bs;
             for (int w = 0; w < 4; ++w) {
                 tower_ws[w].resize(tower_ws[w].size() + size_t(kTowerWindow) * 512, half_t(0.f));
-                tower_ps[w].resize(tower_ps[w].size() + 512, half_t(0.f));
+                tower_ps[w].resize(tower_ps[w].size() + 1024, half_t(0.f));
                 tower_bs[w].resize(tower_bs[w].size() + 32, 0.f);
                 ws.insert(ws.end(), tower_ws[w].begin(), tower_ws[w].end());
                 bs.insert(bs.end(), tower_bs[w].begin(), tower_bs[w].end());
@@ -365,7 +365,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     for (size_t i = 0; i < cops.size(); ++i) {
         const std::string p = "body_spatial." + std::to_string(i + 1);
         const int cop = cops[i], k = ks[i];
-        const bool in_tower = tower_ok && k == 3;
+        const bool in_tower = tower_ok && (k == 3 || k == 5);
         if (!in_tower) flush_tower();
         const bool se_in_kernel = in_tower && !tower_blocks.empty();
         TowerBlockDesc td{};
@@ -449,20 +449,21 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                                 const int ch = c * 128 + w * 32 + (v % 4) + 8 * (v / 4) + 4 * lh;
                                 tower_bs[w].push_back(ch < cop ? float(f1.b[ch]) : 0.f);
                             }
-                        // depthwise weights [lg][entry: 9 taps, BN2 bias, 6 x pad][pair pi][2] for K positions w*32 + lg*8 + pi*2 + {0,1}
+                        // depthwise weights [lg][32 entries: k*k taps, BN2 bias, pad][pair pi][2] for K positions w*32 + lg*8 + pi*2 + {0,1}
                         for (int lgk = 0; lgk < 4; ++lgk)
-                            for (int ent = 0; ent < 16; ++ent)
+                            for (int ent = 0; ent < 32; ++ent)
                                 for (int pi = 0; pi < 4; ++pi)
                                     for (int hh = 0; hh < 2; ++hh) {
                                         const int ch = tower_k_channel(c * 128 + w * 32 + lgk * 8 + pi * 2 + hh);
                                         double v = 0.0;
-                                        if (ch < cop && ent < 10) v = ent < 9 ? f2.w[size_t(ch) * 9 + ent] : f2.b[ch];
+                                        if (ch < cop && ent <= k * k) v = ent < k * k ? f2.w[size_t(ch) * k * k + ent] : f2.b[ch];
                                         tower_ps[w].push_back(half_t(float(v)));
                                     }
                     }
                 }
                 td.b3 = im.upload_d2f(f3.b, C);
                 td.cop_pad = cop_pad;
+                td.ks = k;
                 if (tower_blocks.empty()) {
                     tower_gate = pending_gate;     // gate computed by the launches before this run (or none)
                     pending_gate = nullptr;

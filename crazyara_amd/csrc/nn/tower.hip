@@ -44,9 +44,10 @@ constexpr int TW_T2_OFF = TW_T1_OFF + 2 * TW_T1_BYTES;
 constexpr int TW_POOL_OFF = TW_T2_OFF + 2 * TW_T2_BYTES;      // float [256] channel sums of the new stream
 constexpr int TW_SE_OFF = TW_POOL_OFF + 256 * 4;              // float mean[256], part[1024], h[128], gate[256]
 constexpr int TW_B3_OFF = TW_SE_OFF + (256 + 1024 + 128 + 256) * 4;   // float [256] BN3 bias of the current block
-constexpr int TW_PRM_OFF = TW_B3_OFF + 256 * 4;               // 4 vector waves x 1088 B: packed depthwise weights of a chunk
-constexpr int TW_PRM_LG = 272;                                // bytes between lane groups in a slice (256 + 16: distinct banks)
+constexpr int TW_PRM_OFF = TW_B3_OFF + 256 * 4;               // 4 vector waves x 2112 B: packed depthwise weights of a chunk
+constexpr int TW_PRM_LG = 528;                                // bytes between lane groups in a slice (512 + 16: distinct banks)
 constexpr int TW_LDS_BYTES = TW_PRM_OFF + 4 * 4 * TW_PRM_LG;
+static_assert(TW_LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr int TW_AHEAD = 96;                          // L2 warm-up distance in fragments per stream (3 full intervals, 384 KiB)
 constexpr int TW_WIN = kTowerWindow;                  // weight fragments in flight per matrix wave (16 KiB)
 static_assert(TW_WIN == 16, "one E or P phase consumes exactly one window");
@@ -178,14 +179,21 @@ struct VecAddr {
     const char* bot[3];  // tile 3, dy = +1: the zero row below the board for l15 >= 8 (pre-biased by -3 tiles)
 };
 
+// park this chunk's 2 KiB weight block in my LDS slice (lane l holds bytes [32 l, 32 l + 32)), request the next chunk's
+__device__ __forceinline__ void park_weights(uint4 (&pre)[2], const uint4* __restrict__& pp, char* prml, int lane) {
+    uint4* dst = reinterpret_cast<uint4*>(prml + (lane >> 4) * TW_PRM_LG + (lane & 15) * 32);
+    dst[0] = pre[0];
+    dst[1] = pre[1];
+    pp += 128;
+    pre[0] = pp[0];
+    pre[1] = pp[1];
+}
+
 template <int PARITY>
-__device__ __forceinline__ void vector_interval(uint4& pre, const uint4* __restrict__& pp, char* prml, int lane, int lg, const VecAddr& va,
+__device__ __forceinline__ void vector_interval(uint4 (&pre)[2], const uint4* __restrict__& pp, char* prml, int lane, int lg, const VecAddr& va,
                                                 half_t* t2w, half2_t mLp, half2_t mRp) {
     constexpr int T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
-    // park this chunk's weights, request the next chunk's
-    *reinterpret_cast<uint4*>(prml + (lane >> 4) * TW_PRM_LG + (lane & 15) * 16) = pre;
-    pp += 64;
-    pre = *pp;
+    park_weights(pre, pp, prml, lane);
     half2_t W[10][4];
 #pragma unroll
     for (int e = 0; e < 10; ++e) {
@@ -218,6 +226,62 @@ __device__ __forceinline__ void vector_interval(uint4& pre, const uint4* __restr
             acc = __builtin_elementwise_max(acc, half2_t{0, 0});
             o[pi] = __builtin_bit_cast(uint32_t, acc);
         }
+        *reinterpret_cast<uint4*>(t2w + PARITY * (TW_T2_BYTES / 2) + t * 16 * T2ROW) = uint4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+// 5 x 5 depthwise (RISEv3.3 blocks 7, 11, 12, 13): same scheme, 25 neighbour reads and 100 packed FMAs per square tile.
+// Entries 0..24 = taps (dy+2)*5 + (dx+2), entry 25 = BN2 bias.  Rows two above / below the board: the tile's zero rows.
+struct VecAddr5 {
+    const char* tap[25]; // my neighbour row for each tap in tile 0 of buffer 0, rank-valid case
+    const char* top[5];  // tile 0, dy = -1: zero row for l15 < 8         (dy = -2 in tile 0: always the zero row)
+    const char* bot[5];  // tile 3, dy = +1: zero row for l15 >= 8, pre-biased by -3 tiles   (dy = +2 in tile 3: always the zero row)
+    const char* zero0;   // the zero row above the board at my columns
+    const char* zero3;   // the zero row below the board at my columns, pre-biased by -3 tiles
+};
+
+template <int PARITY>
+__device__ __forceinline__ void vector_interval5(uint4 (&pre)[2], const uint4* __restrict__& pp, char* prml, int lane, int lg, const VecAddr5& va,
+                                                 half_t* t2w, const half2_t (&mk)[5]) {
+    constexpr int T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
+    park_weights(pre, pp, prml, lane);
+    half2_t W[26][4];
+#pragma unroll
+    for (int e = 0; e < 26; ++e) {
+        const uint4 u = *reinterpret_cast<const uint4*>(prml + lg * TW_PRM_LG + e * 16);
+        W[e][0] = __builtin_bit_cast(half2_t, u.x); W[e][1] = __builtin_bit_cast(half2_t, u.y);
+        W[e][2] = __builtin_bit_cast(half2_t, u.z); W[e][3] = __builtin_bit_cast(half2_t, u.w);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 25; ++tap)               // file wrap-around: taps whose column leaves the board get a zero weight
+        if (tap % 5 != 2) {
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi) W[tap][pi] *= mk[tap % 5];
+        }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        half2_t acc[4] = {W[25][0], W[25][1], W[25][2], W[25][3]};
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {                // one board row of taps at a time
+            uint4 R[5];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const char* base = va.tap[g * 5 + c];
+                if (t == 0 && g == 0) base = va.zero0;
+                if (t == 0 && g == 1) base = va.top[c];
+                if (t == 3 && g == 3) base = va.bot[c];
+                if (t == 3 && g == 4) base = va.zero3;
+                R[c] = *reinterpret_cast<const uint4*>(base + PARITY * TW_T1_BYTES + t * 16 * T1ROW * 2);
+            }
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi)
+                    acc[pi] = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, reinterpret_cast<const uint32_t*>(&R[c])[pi]), W[g * 5 + c][pi], acc[pi]);
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) o[pi] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(acc[pi], half2_t{0, 0}));
         *reinterpret_cast<uint4*>(t2w + PARITY * (TW_T2_BYTES / 2) + t * 16 * T2ROW) = uint4{o[0], o[1], o[2], o[3]};
     }
 }
@@ -450,9 +514,9 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
             TW_STAMP();
         }
     } else {
-        const uint4* pp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.pstream) + size_t(w) * a.pstream_wave_bytes) + lane;
+        const uint4* pp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.pstream) + size_t(w) * a.pstream_wave_bytes) + lane * 2;
         char* prml = smem + TW_PRM_OFF + w * 4 * TW_PRM_LG;
-        uint4 pre = *pp;                 // my 16 bytes of the NEXT chunk's 1 KiB weight block
+        uint4 pre[2] = {pp[0], pp[1]};   // my 32 bytes of the NEXT chunk's 2 KiB weight block
         const bool hi = l15 >= 8;        // second board row of a 16-square tile
         const half2_t one2 = {half_t(1.f), half_t(1.f)}, zero2 = {half_t(0.f), half_t(0.f)};
         const half2_t mLp = (l15 & 7) != 0 ? one2 : zero2, mRp = (l15 & 7) != 7 ? one2 : zero2;
@@ -473,6 +537,24 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
             }
         }
         half_t* t2w = t2 + l15 * T2ROW + w * 32 + lg * 8;
+        // the same for the 5 x 5 blocks (addresses only: 36 more VGPRs, this role has them to spare)
+        VecAddr5 va5;
+        half2_t mk5[5];
+        {
+            const char* t1b = smem + TW_T1_OFF;
+            const int col2 = (w * 32 + lg * 8) * 2, file = l15 & 7;
+#pragma unroll
+            for (int tap = 0; tap < 25; ++tap) va5.tap[tap] = t1b + (1 + l15 + (tap / 5 - 2) * 8 + (tap % 5 - 2)) * T1ROW * 2 + col2;
+            va5.zero0 = t1b + col2;
+            va5.zero3 = t1b + (65 - 48) * T1ROW * 2 + col2;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                va5.top[i] = hi ? va5.tap[5 + i] : va5.zero0;
+                va5.bot[i] = hi ? va5.zero3 : va5.tap[15 + i];
+                const int x = file + i - 2;
+                mk5[i] = (x >= 0 && x < 8) ? one2 : zero2;
+            }
+        }
         // L2 warm-up for the matrix waves' weight streams.  All 256 workgroups consume the same 4 streams in near lockstep, so
         // without help every line is a miss-in-flight for everyone (one XCD-L2 fill, 31 requests queued behind it) and the
         // stream runs at miss latency.  The workgroups of an XCD therefore share the job of touching each line TW_AHEAD
@@ -510,8 +592,13 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
                     mpos += adv;
                 }
                 if (k >= 0 && k < n) {
-                    if (k & 1) vector_interval<1>(pre, pp, prml, lane, lg, va, t2w, mLp, mRp);
-                    else vector_interval<0>(pre, pp, prml, lane, lg, va, t2w, mLp, mRp);
+                    if (d.ks == 5) {
+                        if (k & 1) vector_interval5<1>(pre, pp, prml, lane, lg, va5, t2w, mk5);
+                        else vector_interval5<0>(pre, pp, prml, lane, lg, va5, t2w, mk5);
+                    } else {
+                        if (k & 1) vector_interval<1>(pre, pp, prml, lane, lg, va, t2w, mLp, mRp);
+                        else vector_interval<0>(pre, pp, prml, lane, lg, va, t2w, mLp, mRp);
+                    }
                 }
                 if (trc) {
                     const unsigned long long w0 = __builtin_amdgcn_s_memtime();

@@ -123,7 +123,14 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs a) {
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int v = 0; v < 16; ++v) accv[ct][v] = 0.f;
+        // L2 warm-up (see tower.hip): the workgroups of an XCD share the job of touching every stream line early; this
+        // workgroup takes the lines whose index is (b / 8) % 32 modulo 32 of the 16 fragments it will need two taps from now
+        const char* s1b = reinterpret_cast<const char*>(a.s1) + size_t(wv) * a.s1_wave_frags * 1024;
+        const int pf_slot = (b >> 3) & 31;
+        int pf_old = 0, pf_sink = 0;
         for (int tap = 0; tap < ntap; ++tap) {
+            pf_sink ^= pf_old;
+            pf_old = (lane < 4 && tap + 2 < ntap) ? *reinterpret_cast<const int*>(s1b + size_t(tap + 2) * 16384 + (lane * 32 + pf_slot) * 128) : 0;
             const int dy = tap < 9 ? tap / 3 - 1 : 0, dx = tap < 9 ? tap % 3 - 1 : 0;
             const half_t* r0 = X + nbr_row(l31, dy, dx) * ROW + lh * 8;
             const half_t* r1 = X + nbr_row(32 + l31, dy, dx) * ROW + lh * 8;
@@ -151,6 +158,8 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs a) {
             }
             sp += 16 * 64;
         }
+        pf_sink ^= pf_old;
+        asm volatile("" ::"v"(pf_sink));
         HD_STAMP();
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs retire before the asm pack reads them
         // BN bias + ReLU -> P1; my 16 rows of a square are 16 consecutive K positions of conv 2 (kernels.h: tower_row_of_position)
@@ -191,20 +200,26 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs a) {
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int rt = 0; rt < 3; ++rt) wf[q][rt] = s2[(q * 3 + rt) * 64];
-        for (int i0 = 0; i0 < 18; i0 += 3) {
+        auto read_b = [&](int u, frag (&bq)[2]) {     // unit u = (tap, k-step): B rows of both square tiles
+            const int tap = u >> 4, ks = u & 15, dy = tap / 3 - 1, dx = tap % 3 - 1;
+            bq[0] = *reinterpret_cast<const frag*>(P1 + nbr_row(l31, dy, dx) * ROW + ks * 16 + lh * 8);
+            bq[1] = *reinterpret_cast<const frag*>(P1 + nbr_row(32 + l31, dy, dx) * ROW + ks * 16 + lh * 8);
+        };
+        frag bq[2][2];
+        read_b(wv * 18, bq[0]);
+        for (int i0 = 0; i0 < 18; i0 += 6) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int u = wv * 18 + i0 + q, tap = u >> 4, ks = u & 15;
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                const frag b0 = *reinterpret_cast<const frag*>(P1 + nbr_row(l31, dy, dx) * ROW + ks * 16 + lh * 8);
-                const frag b1 = *reinterpret_cast<const frag*>(P1 + nbr_row(32 + l31, dy, dx) * ROW + ks * 16 + lh * 8);
+            for (int q6 = 0; q6 < 6; ++q6) {
+                const int i = i0 + q6, q = q6 % 3;
+                if (i + 1 < 18) read_b(wv * 18 + i + 1, bq[(q6 + 1) & 1]);
 #pragma unroll
                 for (int rt = 0; rt < 3; ++rt) {
-                    mma32(wf[q][rt], b0, acc[rt][0]);
-                    mma32(wf[q][rt], b1, acc[rt][1]);
+                    mma32(wf[q][rt], bq[q6 & 1][0], acc[rt][0]);
+                    mma32(wf[q][rt], bq[q6 & 1][1], acc[rt][1]);
                 }
 #pragma unroll
-                for (int rt = 0; rt < 3; ++rt) wf[q][rt] = s2[((i0 + q + 3) * 3 + rt) * 64];
+                for (int rt = 0; rt < 3; ++rt) wf[q][rt] = s2[((i + 3) * 3 + rt) * 64];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         HD_STAMP();
@@ -246,13 +261,13 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs a) {
         for (int i = tid; i < n; i += 512) m = fmaxf(m, logit[i]);
         m = block_reduce_512(m, red, true);
         float sum = 0.f;
-        for (int i = tid; i < n; i += 512) sum += expf(logit[i] - m);
+        for (int i = tid; i < n; i += 512) sum += __expf(logit[i] - m);
         sum = block_reduce_512(sum, red, false);
         const float c = m + logf(sum);               // exp(x - (max + log(sum))) as apply_softmax(), neuralnetapi.cpp:241-260
         for (int i = tid; i < n; i += 512) {
             const float x = logit[i];
             lo[i] = x;
-            po[i] = expf(x - c);
+            po[i] = __expf(x - c);
         }
     }
 

@@ -31,6 +31,9 @@ SearchSettings convert(const mi_search_settings& m) {
     s.version_major = m.version_major;
     s.is_policy_map = m.is_policy_map != 0;
     s.clone_keeps_last_moves = m.clone_keeps_last_moves;
+    s.epsilon_greedy_counter = m.epsilon_greedy_counter;
+    s.epsilon_checks_counter = m.epsilon_checks_counter;
+    s.seed = m.seed;
     return s;
 }
 }  // namespace
@@ -53,6 +56,9 @@ void mi_search_default_settings(mi_search_settings* m) {
     m->version_major = s.version_major;
     m->is_policy_map = s.is_policy_map ? 1 : 0;
     m->clone_keeps_last_moves = s.clone_keeps_last_moves;
+    m->epsilon_greedy_counter = s.epsilon_greedy_counter;
+    m->epsilon_checks_counter = s.epsilon_checks_counter;
+    m->seed = s.seed;
 }
 
 mi_search* mi_search_create(const mi_search_settings* s, mi_net* net_a, mi_net* net_b, mi_eval_fn fn, void* user, int fn_batch, int fn_nb_policy) {

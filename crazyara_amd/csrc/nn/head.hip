@@ -8,7 +8,7 @@
 //            for all 64 squares, A = its weight stream ([tap][k-step] fragments), B = rows of the board tile in LDS (neighbour
 //            square or the zero row); result -> f16 tile P1 in LDS.  Wave 0 also runs the value head's 1x1 conv (8 couts).
 //   phase 2  policy conv 3x3 256->P (P <= 96): the 144 (tap, k-step) units are dealt 18 per wave, each wave accumulates all
-//            P x 64 partial logits of its units and adds them into the f32 logit tile in LDS (ds_add_f32).
+//            P x 64 partial logits of its units; the 8 partial sets are summed through LDS, one row tile at a time.
 //   phase 3  softmax over the P*64 logits in LDS; logits and probabilities go to HBM once.
 //   phase 4  value head: FC(512->256)+ReLU -> FC(256->1) -> tanh, or the WDLP outputs.
 // The board tile, P1 and the logits never leave the CU; HBM traffic per board is 32 KB in and 2 * P*256 B + 4 B out.
@@ -45,11 +45,6 @@ __device__ __forceinline__ void mma32(const half8& a, const half8& b, f32x16& c)
 __device__ __forceinline__ int nbr_row(int sq, int dy, int dx) {
     const int y = (sq >> 3) + dy, x = (sq & 7) + dx;
     return (unsigned(y) < 8u && unsigned(x) < 8u) ? sq + dy * 8 + dx : 64;
-}
-// native LDS float add (ds_add_f32); HIP's atomicAdd(float*) would expand to a compare-and-swap loop here
-__device__ __forceinline__ void lds_fadd(float* p, float v) {
-    typedef __attribute__((address_space(3))) float lds_float;
-    (void)__builtin_amdgcn_ds_faddf((lds_float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
 }
 __device__ __forceinline__ float block_reduce_512(float v, float* red, bool is_max) {
 #pragma unroll

@@ -28,8 +28,8 @@ VirtualStyle get_virtual_style(const SearchSettings& s, uint32_t visits) {
 }
 
 Tree::Tree(const Position& root, const SearchSettings& settings) : s_(settings), root_pos_(root) {
-    if (s_.epsilon_greedy_counter || s_.epsilon_checks_counter)
-        throw std::invalid_argument("epsilon-greedy / epsilon-checks exploration is not restated yet; set the counters to 0");
+    if (s_.epsilon_greedy_counter < 0 || s_.epsilon_checks_counter < 0) throw std::invalid_argument("epsilon counters must be >= 0");
+    rng_ = s_.seed;
     tables_ = &chess::policy_tables(s_.mode);
     layout_ = layout_for(s_.mode, s_.version_major);
     keep_last_moves_ = s_.clone_keeps_last_moves < 0 ? s_.mode != MODE_CRAZYHOUSE : s_.clone_keeps_last_moves != 0;
@@ -198,14 +198,90 @@ void Tree::backup_value(float value, const Trajectory& t, bool free_backup) {
     }
 }
 
+// ---- epsilon exploration helpers ----------------------------------------------------------------------------------
+// rand(): the classic ANSI-C generator, one stream per tree
+uint32_t Tree::next_rand() {
+    rng_ = rng_ * 1103515245u + 12345u;
+    return (rng_ >> 16) & 0x7fffu;
+}
+
+// get_random_depth (searchthread.cpp:497-501): ceil(-log2(1 - r/100) - 1), r uniform in 1..100 (r = 100: "infinitely deep")
+size_t Tree::get_random_depth() {
+    const int r = int(next_rand() % 100u) + 1;
+    if (r == 100) return size_t(1) << 20;
+    return size_t(std::ceil(-std::log2(1 - r / 100.0) - 1));
+}
+
+// get_starting_node (searchthread.cpp:144-162): walk the most-visited line for a random number of plies.  No virtual loss and
+// no trajectory entries on the way down: the value found below is only backed up from the starting node.
+int Tree::get_starting_node(int cur, uint32_t& depth, int& child_idx, Position& pos) {
+    const size_t d = get_random_depth();
+    for (size_t cd = 0; cd < d; ++cd) {
+        const Node& n = nodes_[cur];
+        int best = 0;                                            // get_best_action_index(fast): argmax of the child visits, first maximum
+        for (int i = 1; i < int(n.no_visit_idx); ++i)
+            if (n.child_visits[i] > n.child_visits[best]) best = i;
+        child_idx = best;
+        const int next = n.no_visit_idx ? n.child[best] : -1;
+        if (next < 0 || !nodes_[next].has_data || nodes_[next].visit_sum < uint32_t(s_.epsilon_greedy_counter) ||
+            nodes_[next].node_type != NT_UNSOLVED)
+            break;
+        pos.do_move(n.actions[best]);
+        cur = next;
+        ++depth;
+    }
+    return cur;
+}
+
+// random_playout (searchthread.cpp:124-142)
+void Tree::random_playout(int cur, int& child_idx) {
+    Node& n = nodes_[cur];
+    if (size_t(n.no_visit_idx) == n.actions.size()) {            // is_fully_expanded
+        const int idx = int(next_rand() % uint32_t(n.actions.size()));
+        const int child = n.child[idx];
+        if (child < 0 || !nodes_[child].has_data) { child_idx = idx; return; }
+        if (nodes_[child].node_type == NT_UNSOLVED) { child_idx = idx; return; }
+        child_idx = -1;
+    } else {
+        child_idx = int(std::min(size_t(n.no_visit_idx), n.actions.size() - 1));
+        increment_no_visit_idx(n);
+    }
+}
+
+// select_enhanced_move (searchthread.cpp:451-473): make sure a checking move has been tried once
+int Tree::select_enhanced_move(int cur, const Position& pos) {
+    Node& n = nodes_[cur];
+    if (n.has_data && !n.inspected && !n.terminal) {
+        const size_t first = n.no_visit_idx;
+        for (size_t ci = first; ci < n.actions.size(); ++ci) {
+            if (pos.gives_check(n.actions[ci])) {
+                for (size_t idx = first; idx < ci + 1; ++idx) increment_no_visit_idx(n);
+                return int(ci);
+            }
+        }
+        n.inspected = true;
+    }
+    return -1;
+}
+
 // SearchThread::get_new_child_to_evaluate (searchthread.cpp:164-271), tree variant (useMCGS = false)
 int Tree::get_new_child_to_evaluate(NodeBackup& type, uint32_t& depth, BoardDesc* desc_out) {
     depth = 0;
     int cur = 0;
     Position pos(root_pos_);                     // rootState->clone()
     if (!keep_last_moves_) pos.clear_last_moves();
+    int forced = -1;                             // childIdx chosen by the exploration step (uint16_t(-1) = none)
+    if (s_.epsilon_greedy_counter && nodes_[0].has_data && next_rand() % uint32_t(s_.epsilon_greedy_counter) == 0) {
+        cur = get_starting_node(cur, depth, forced, pos);
+        random_playout(cur, forced);
+    } else if (s_.epsilon_checks_counter && nodes_[0].has_data && next_rand() % uint32_t(s_.epsilon_checks_counter) == 0) {
+        cur = get_starting_node(cur, depth, forced, pos);
+        forced = select_enhanced_move(cur, pos);
+        if (forced < 0) random_playout(cur, forced);
+    }
     while (true) {
-        const int c = select_child(nodes_[cur]);
+        const int c = forced >= 0 ? forced : select_child(nodes_[cur]);
+        forced = -1;
         apply_virtual_loss(nodes_[cur], c);
         trajectory_buffer_.push_back(NodeAndIdx{cur, uint16_t(c)});
         const int next = nodes_[cur].child[c];

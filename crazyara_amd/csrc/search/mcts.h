@@ -39,9 +39,13 @@ struct SearchSettings {
     // Board::operator= copies lastMoves only in MODE_CHESS / MODE_LICHESS binaries (board.cpp:106-108): in a crazyhouse
     // binary every leaf's move history restarts at the root clone.  -1 = follow the mode, 0/1 = force.
     int clone_keeps_last_moves = -1;
-    // not restated yet (the reference's rand()-driven exploration, searchthread.cpp:124-185): must stay 0
+    // epsilon exploration (searchthread.cpp:124-185, 451-473, 497-501): one simulation in `counter` starts with a random
+    // playout (or an unexplored checking move) from a random depth of the principal variation.  0 = off.  The reference draws
+    // from rand() (seeded with the time: not reproducible); here every tree owns a seeded ANSI-C LCG, so searches replay.
+    // UCI defaults: Centi_Epsilon_Greedy 5 -> 20, Centi_Epsilon_Checks 1 -> 100 (optionsuci.cpp:89-90, crazyara.cpp:748-749).
     int epsilon_greedy_counter = 0;
     int epsilon_checks_counter = 0;
+    uint32_t seed = 1;
 };
 
 struct Node {
@@ -60,7 +64,7 @@ struct Node {
     uint16_t no_visit_idx = 0;
     uint16_t plies = 0;
     int8_t node_type = NT_UNSOLVED;
-    bool terminal = false, has_nn = false, sorted = false, has_data = false;
+    bool terminal = false, has_nn = false, sorted = false, has_data = false, inspected = false;
     uint8_t stm = 0;
 
     float value() const { return float(value_sum / real_visits); }                         // node.cpp:595-598
@@ -121,6 +125,11 @@ private:
     void increment_no_visit_idx(Node& n);
     void fill_nn_result(Node& n, float value, const float* probs);
     int get_new_child_to_evaluate(NodeBackup& type, uint32_t& depth, BoardDesc* desc_out);
+    uint32_t next_rand();
+    size_t get_random_depth();
+    int get_starting_node(int cur, uint32_t& depth, int& child_idx, chess::Position& pos);
+    void random_playout(int cur, int& child_idx);
+    int select_enhanced_move(int cur, const chess::Position& pos);
 
     SearchSettings s_;
     chess::Position root_pos_;
@@ -131,6 +140,7 @@ private:
     std::vector<int32_t> new_nodes_;
     std::vector<Trajectory> new_trajectories_, collision_trajectories_;
     Trajectory trajectory_buffer_;
+    uint32_t rng_ = 1;
 };
 
 }  // namespace search

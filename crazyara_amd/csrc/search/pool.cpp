@@ -152,7 +152,9 @@ SearchPool::SearchPool(const SearchSettings& s, std::unique_ptr<Evaluator> lane_
 }
 
 int SearchPool::add_position(const chess::Position& pos) {
-    trees_.emplace_back(new Tree(pos, s_));
+    SearchSettings st = s_;
+    st.seed = s_.seed + uint32_t(trees_.size());     // every tree owns its exploration stream
+    trees_.emplace_back(new Tree(pos, st));
     const int id = int(trees_.size()) - 1;
     lanes_[id % lanes_.size()].trees.push_back(id);
     return id;

@@ -13,7 +13,8 @@ class SearchSettingsC(C.Structure):
     _fields_ = [("batch_size", C.c_int), ("cpuct_init", C.c_float), ("cpuct_base", C.c_float),
                 ("node_policy_temperature", C.c_float), ("virtual_style", C.c_int), ("virtual_mix_threshold", C.c_uint),
                 ("virtual_offset_strength", C.c_double), ("q_value_weight", C.c_float), ("q_veto_delta", C.c_float),
-                ("mode", C.c_int), ("version_major", C.c_int), ("is_policy_map", C.c_int), ("clone_keeps_last_moves", C.c_int)]
+                ("mode", C.c_int), ("version_major", C.c_int), ("is_policy_map", C.c_int), ("clone_keeps_last_moves", C.c_int),
+                ("epsilon_greedy_counter", C.c_int), ("epsilon_checks_counter", C.c_int), ("seed", C.c_uint)]
 
 
 class SearchStatsC(C.Structure):

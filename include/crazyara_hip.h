@@ -148,6 +148,11 @@ typedef struct mi_search_settings {        /* SearchSettings (engine/src/agents/
     int version_major;                     /* input representation of the net */
     int is_policy_map;
     int clone_keeps_last_moves;            /* -1 follow the build mode (board.cpp:106-108), 0 / 1 force */
+    /* epsilon exploration (searchthread.cpp:124-185): 1 simulation in `counter` starts with a random playout / an unexplored
+     * checking move from a random depth; 0 = off (mi_search_default_settings), reference UCI defaults 20 / 100
+     * (Centi_Epsilon_Greedy 5, Centi_Epsilon_Checks 1).  seed: per-pool seed of the trees' generators (tree i uses seed + i). */
+    int epsilon_greedy_counter, epsilon_checks_counter;
+    unsigned seed;
 } mi_search_settings;
 typedef struct mi_search_stats {
     unsigned long long nodes, nn_evals, batches, simulations;

@@ -18,8 +18,9 @@ taken from libm so that results are bit-identical to a C++ build on the same mac
 
 Parity status: the reference has NO unit test for this arithmetic ("parity unpinned") and its engine cannot be
 compiled here (Stockfish fork + blaze are empty submodules), so this file is a line-by-line restatement checked by
-hand-computed cases in tests/test_mcts.py, not by reference-generated vectors.  useMCGS (transposition merge), the MCTS
-solver and the rand()-driven epsilon exploration are not restated.
+hand-computed cases in tests/test_mcts.py, not by reference-generated vectors.  useMCGS (transposition merge) and the MCTS
+solver are not restated.  The epsilon exploration (searchthread.cpp:124-185, 451-473, 497-501) is restated with the reference's
+rand() replaced by a seeded ANSI-C LCG (the reference seeds rand() with the time, so its own runs do not replay either).
 """
 from __future__ import annotations
 
@@ -55,6 +56,9 @@ class Settings:
         self.q_veto_delta = F(0.4)
         self.mode = co.MODE_CRAZYHOUSE
         self.is_policy_map = True
+        self.epsilon_greedy_counter = 0      # 1 / Centi_Epsilon_Greedy: UCI default 20 (optionsuci.cpp:90, crazyara.cpp:749); 0 = off
+        self.epsilon_checks_counter = 0      # UCI default 100
+        self.seed = 1
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -79,6 +83,7 @@ class Node:
         self.has_nn = False
         self.sorted = False
         self.has_data = False
+        self.inspected = False
         self.visit_sum = 0
         self.free_visits = 0
         self.no_visit_idx = 0
@@ -114,6 +119,7 @@ class Tree:
         self.keep = (s.mode != co.MODE_CRAZYHOUSE) if clone_keeps_last_moves is None else clone_keeps_last_moves
         self.root = Node(board, self.pm, s)
         self.new_nodes, self.new_traj, self.coll_traj = [], [], []
+        self.rng = s.seed & 0xFFFFFFFF
 
     # ---------------------------------------------------------------------------------------------------------------
     def fill_nn_result(self, n: Node, value, probs):
@@ -217,14 +223,83 @@ class Tree:
             self.revert_virtual_loss_and_update(n, c, value, free_backup)
 
     # ---------------------------------------------------------------------------------------------------------------
+    # ---- epsilon exploration --------------------------------------------------------------------------------------
+    def next_rand(self):
+        """rand(): classic ANSI-C LCG, 15-bit output."""
+        self.rng = (self.rng * 1103515245 + 12345) & 0xFFFFFFFF
+        return (self.rng >> 16) & 0x7FFF
+
+    def get_random_depth(self):
+        """searchthread.cpp:497-501: ceil(-log2(1 - r/100) - 1), r uniform in 1..100."""
+        r = self.next_rand() % 100 + 1
+        if r == 100:
+            return 1 << 20
+        return int(math.ceil(-math.log2(1 - r / 100.0) - 1))
+
+    def get_starting_node(self, cur, board):
+        """searchthread.cpp:144-162: follow the most-visited line for a random number of plies (no virtual loss, no trajectory)."""
+        child_idx, depth = -1, 0
+        for _ in range(self.get_random_depth()):
+            best = 0
+            for i in range(1, cur.no_visit_idx):
+                if cur.child_visits[i] > cur.child_visits[best]:
+                    best = i
+            child_idx = best
+            nxt = cur.child[best] if cur.no_visit_idx else None
+            if nxt is None or not nxt.has_data or nxt.visit_sum < self.s.epsilon_greedy_counter or nxt.terminal:
+                break
+            board.push(cur.moves[best])
+            cur = nxt
+            depth += 1
+        return cur, child_idx
+
+    def random_playout(self, cur):
+        """searchthread.cpp:124-142"""
+        if cur.no_visit_idx == len(cur.moves):
+            idx = self.next_rand() % len(cur.moves)
+            child = cur.child[idx]
+            if child is None or not child.has_data:
+                return idx
+            if not child.terminal:          # node type UNSOLVED (no solver here: solved == terminal)
+                return idx
+            return -1
+        idx = min(cur.no_visit_idx, len(cur.moves) - 1)
+        self.increment_no_visit_idx(cur)
+        return idx
+
+    def select_enhanced_move(self, cur, board):
+        """searchthread.cpp:451-473: make sure a checking move has been tried once."""
+        if cur.has_data and not cur.inspected and not cur.terminal:
+            first = cur.no_visit_idx
+            for ci in range(first, len(cur.moves)):
+                b2 = board.copy()
+                b2.push(cur.moves[ci])
+                if b2.checkers():
+                    for _ in range(first, ci + 1):
+                        self.increment_no_visit_idx(cur)
+                    return ci
+            cur.inspected = True
+        return -1
+
     def get_new_child(self):
         cur = self.root
         board = self.root_board.copy()
         if not self.keep:
             board.last_moves = []
         traj = []
+        forced = -1
+        s = self.s
+        if s.epsilon_greedy_counter and self.root.has_data and self.next_rand() % s.epsilon_greedy_counter == 0:
+            cur, forced = self.get_starting_node(cur, board)
+            forced = self.random_playout(cur)
+        elif s.epsilon_checks_counter and self.root.has_data and self.next_rand() % s.epsilon_checks_counter == 0:
+            cur, forced = self.get_starting_node(cur, board)
+            forced = self.select_enhanced_move(cur, board)
+            if forced < 0:
+                forced = self.random_playout(cur)
         while True:
-            c = self.select_child(cur)
+            c = forced if forced >= 0 else self.select_child(cur)
+            forced = -1
             self.apply_virtual_loss(cur, c)
             traj.append((cur, c))
             nxt = cur.child[c]

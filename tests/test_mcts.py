@@ -134,6 +134,53 @@ def test_product_tree_equals_oracle_tree(hip_lib, variant, is960, fen, mode, sim
     pool.close()
 
 
+@pytest.mark.parametrize("variant,fen,mode,greedy,checks,seed", [
+    ("crazyhouse", "", 0, 20, 100, 7),                      # the reference's UCI defaults (Centi_Epsilon_Greedy 5, Centi_Epsilon_Checks 1)
+    ("crazyhouse", "r1bq1rk1/ppp2ppp/2np1n2/2b1p3/2B1P3/2NP1N2/PPP2PPP/R1BQ1RK1[] w - - 0 7", 0, 5, 0, 11),
+    ("chess", "r3k2r/pppq1ppp/2npbn2/2b1p3/2B1P3/2NPBN2/PPPQ1PPP/R3K2R w KQkq - 4 8", 1, 0, 3, 3),
+    ("3check", "1r4k1/1p2bp1p/3p2p1/PprPp2n/1R2PPq1/3Q4/1P1B1NPP/5RK1 b - - 1+1 2 22", 2, 4, 6, 99),
+])
+def test_epsilon_exploration_equals_oracle(hip_lib, variant, fen, mode, greedy, checks, seed):
+    """epsilon-greedy / epsilon-checks with the seeded generator: same random playouts, same checking-move probes, same tree."""
+    nbp, sims, quota = NB_POLICY[mode], 300, 8
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota,
+                                 epsilon_greedy_counter=greedy, epsilon_checks_counter=checks, seed=seed)
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=quota, fn_nb_policy=nbp)
+    t = pool.add_position(fen, False, variant)
+    pool.run(simulations=sims, threads=1)
+    moves, visits, q, _ = pool.root_children(t)
+    info = pool.tree_info(t)
+
+    os_ = mo.Settings(mode=mode, is_policy_map=True, batch_size=quota, epsilon_greedy_counter=greedy, epsilon_checks_counter=checks, seed=seed)
+    tree = mo.Tree(co.Board(fen or None, False, variant), os_)
+
+    def eval_boards(boards):
+        out = [_pseudo_net(key_from_board(b), nbp) for b in boards]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    mo.run_search(tree, eval_boards, sims, quota)
+    r = tree.root
+    p = env.Position(fen, False, variant)
+    assert [p.move_uci(m) for m in moves] == r.uci[:len(moves)]
+    assert visits == r.child_visits
+    assert np.array_equal(q, np.array(r.q, np.float32))
+    assert info["root_visits"] == r.visit_sum and info["node_count"] == tree.node_count()
+    assert pool.best_move(t) == tree.best_move()[0]
+    # the exploration must actually have changed the search: a run without it differs
+    st0 = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota)
+    pool0 = search.SearchPool(st0, eval_fn=eval_descs, fn_batch=quota, fn_nb_policy=nbp)
+    t0 = pool0.add_position(fen, False, variant)
+    pool0.run(simulations=sims, threads=1)
+    assert pool0.root_children(t0)[1] != visits
+    pool0.close()
+    pool.close()
+
+
 def test_pool_many_trees_two_lanes_matches_single_tree_runs(hip_lib):
     """Trees are independent: a pooled, two-lane, multi-threaded run must give each tree exactly the statistics it gets
     when searched alone with the same per-tree quota."""

@@ -34,6 +34,7 @@ SearchSettings convert(const mi_search_settings& m) {
     s.epsilon_greedy_counter = m.epsilon_greedy_counter;
     s.epsilon_checks_counter = m.epsilon_checks_counter;
     s.seed = m.seed;
+    s.mcts_solver = m.mcts_solver != 0;
     return s;
 }
 }  // namespace
@@ -59,6 +60,7 @@ void mi_search_default_settings(mi_search_settings* m) {
     m->epsilon_greedy_counter = s.epsilon_greedy_counter;
     m->epsilon_checks_counter = s.epsilon_checks_counter;
     m->seed = s.seed;
+    m->mcts_solver = s.mcts_solver ? 1 : 0;
 }
 
 mi_search* mi_search_create(const mi_search_settings* s, mi_net* net_a, mi_net* net_b, mi_eval_fn fn, void* user, int fn_batch, int fn_nb_policy) {
@@ -138,6 +140,16 @@ int mi_search_tree_info(mi_search* sp, int tree, unsigned* root_visits, unsigned
         if (node_count) *node_count = t.node_count();
         if (allocated_nodes) *allocated_nodes = unsigned(t.node_count_allocated());
         if (root_value) *root_value = t.root().real_visits ? t.root().value() : 0.0f;
+    });
+}
+
+int mi_search_root_solved(mi_search* sp, int tree, int* node_type, int* end_in_ply, int* checkmate_idx) {
+    if (!sp) { cra_set_error("null search"); return 1; }
+    return cra_guard([&] {
+        const Tree& t = sp->pool->tree(tree);
+        if (node_type) *node_type = t.root().node_type;
+        if (end_in_ply) *end_in_ply = t.root().end_in_ply;
+        if (checkmate_idx) *checkmate_idx = t.root().checkmate_idx;
     });
 }
 

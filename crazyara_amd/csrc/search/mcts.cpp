@@ -110,6 +110,8 @@ void Tree::prepare_node_for_visits(Node& n) {
         n.q.assign(1, Q_INIT);
         n.child.assign(1, -1);
         n.vl.assign(1, 0);
+        n.child_types.assign(1, NT_UNSOLVED);
+        n.unsolved_children = uint16_t(n.actions.size());                                 // NodeData(numberChildNodes), nodedata.cpp:70-75
     }
 }
 
@@ -120,6 +122,7 @@ void Tree::increment_no_visit_idx(Node& n) {                                    
         n.q.push_back(Q_INIT);
         n.child.push_back(-1);
         n.vl.push_back(0);
+        n.child_types.push_back(NT_UNSOLVED);
     }
 }
 
@@ -128,6 +131,7 @@ void Tree::increment_no_visit_idx(Node& n) {                                    
 int Tree::select_child(Node& n) {
     if (!n.sorted) prepare_node_for_visits(n);
     if (n.no_visit_idx == 1) return 0;
+    if (n.checkmate_idx >= 0) return n.checkmate_idx;                                     // has_forced_win
     const float cpuct = get_current_cput(float(n.visit_sum), s_);
     const double sq = std::sqrt(double(n.visit_sum));
     int best = 0;
@@ -162,7 +166,7 @@ void Tree::revert_virtual_loss(Node& n, int c) {                                
     --n.vl[c];
 }
 
-void Tree::revert_virtual_loss_and_update(Node& n, int c, float value, bool free_backup) {   // node.h:199-246
+void Tree::revert_virtual_loss_and_update(Node& n, int c, float value, bool free_backup, bool solve) {   // node.h:199-246
     n.value_sum += value;
     ++n.real_visits;
     if (n.child_visits[c] == 1) {
@@ -188,13 +192,73 @@ void Tree::revert_virtual_loss_and_update(Node& n, int c, float value, bool free
     }
     --n.vl[c];
     if (free_backup) ++n.free_visits;
+    if (solve) solve_for_terminal(n, c);
+}
+
+// Node::solve_for_terminal (node.cpp:365-453) without tablebases, MODE_TWO_PLAYER: a child's WIN is this node's LOSS.
+//   WIN  <- one child is a LOSS (solved_win, node.cpp:108-117); remembers the mating child in checkmate_idx
+//   LOSS <- every child is a WIN (solved_loss, node.cpp:155-172)
+//   DRAW <- every child is a WIN or a DRAW, at least one DRAW (solved_draw / at_least_one_drawn_child, node.cpp:119-148)
+// end_in_ply: define_end_ply_for_solved_terminal (node.cpp:268-289); update_solved_terminal (:291-297) overwrites the node
+// value (set_value counts one more real visit) and the edge's Q.
+bool Tree::solve_for_terminal(Node& n, int c) {
+    const int ci = n.child[c];
+    if (ci < 0 || !nodes_[ci].has_data) return false;                                     // !childNode->is_playout_node()
+    const Node& ch = nodes_[ci];
+    if (ch.node_type == NT_UNSOLVED) return false;
+    if (n.node_type != NT_UNSOLVED) return false;                                         // already solved
+    if (n.child_types[c] == NT_UNSOLVED) {
+        --n.unsolved_children;
+        n.child_types[c] = ch.node_type;
+        if (ch.node_type == NT_WIN) {                                                     // disable_action, node.cpp:1006-1010
+            n.priors[c] = 0.0f;
+            n.q[c] = float(-2147483647);
+        }
+    }
+    auto all_children = [&](auto&& pred) {
+        for (int i = 0; i < int(n.child.size()); ++i) {
+            if (n.child[i] < 0 || !pred(nodes_[n.child[i]])) return false;
+        }
+        return true;
+    };
+    if (ch.node_type == NT_LOSS) {
+        n.node_type = NT_WIN;
+        n.end_in_ply = uint16_t(ch.end_in_ply + 1);
+        n.set_value(WIN_VALUE);
+        n.q[c] = WIN_VALUE;
+        n.checkmate_idx = c;
+        return true;
+    }
+    if (n.unsolved_children == 0 && ch.node_type == NT_WIN && all_children([](const Node& k) { return k.node_type == NT_WIN; })) {
+        n.node_type = NT_LOSS;
+        for (int i : n.child) n.end_in_ply = std::max<uint16_t>(n.end_in_ply, uint16_t(nodes_[i].end_in_ply + 1));   // longest line
+        n.set_value(LOSS_VALUE);
+        n.q[c] = LOSS_VALUE;
+        return true;
+    }
+    if (n.unsolved_children == 0 && ch.node_type != NT_LOSS) {
+        bool drawn = false;
+        const bool ok = all_children([&](const Node& k) {
+            if (!k.has_data || (k.node_type != NT_DRAW && k.node_type != NT_WIN)) return false;
+            drawn |= k.node_type == NT_DRAW;
+            return true;
+        });
+        if (ok && drawn) {
+            n.node_type = NT_DRAW;
+            // shortest drawn line: `child.end + 1 < end` with end starting at 0 never fires (node.cpp:277-285): end_in_ply stays 0
+            n.set_value(DRAW_VALUE);
+            n.q[c] = DRAW_VALUE;
+            return true;
+        }
+    }
+    return false;
 }
 
 // backup_value<freeBackup> (node.h:819-843) for trees (no transposition nodes: targetQValue stays 0)
-void Tree::backup_value(float value, const Trajectory& t, bool free_backup) {
+void Tree::backup_value(float value, const Trajectory& t, bool free_backup, bool solve) {
     for (auto it = t.rbegin(); it != t.rend(); ++it) {
         value = -value;                                                                   // MODE_TWO_PLAYER
-        revert_virtual_loss_and_update(nodes_[it->node], it->child_idx, value, free_backup);
+        revert_virtual_loss_and_update(nodes_[it->node], it->child_idx, value, free_backup, solve);
     }
 }
 
@@ -212,15 +276,29 @@ size_t Tree::get_random_depth() {
     return size_t(std::ceil(-std::log2(1 - r / 100.0) - 1));
 }
 
+// get_best_action_index(fast = true) (node.cpp:1123-1148): the mating child, else (proven loss) the child that delays the mate
+// longest, else the most-visited child (first maximum)
+int Tree::best_action_index_fast(const Node& n) const {
+    if (n.checkmate_idx >= 0) return n.checkmate_idx;
+    int best = 0;
+    if (n.node_type == NT_LOSS) {
+        uint16_t longest = 0;
+        for (int i = 0; i < int(n.child.size()); ++i)
+            if (nodes_[n.child[i]].end_in_ply > longest) { longest = nodes_[n.child[i]].end_in_ply; best = i; }
+        return best;
+    }
+    for (int i = 1; i < int(n.no_visit_idx); ++i)
+        if (n.child_visits[i] > n.child_visits[best]) best = i;
+    return best;
+}
+
 // get_starting_node (searchthread.cpp:144-162): walk the most-visited line for a random number of plies.  No virtual loss and
 // no trajectory entries on the way down: the value found below is only backed up from the starting node.
 int Tree::get_starting_node(int cur, uint32_t& depth, int& child_idx, Position& pos) {
     const size_t d = get_random_depth();
     for (size_t cd = 0; cd < d; ++cd) {
         const Node& n = nodes_[cur];
-        int best = 0;                                            // get_best_action_index(fast): argmax of the child visits, first maximum
-        for (int i = 1; i < int(n.no_visit_idx); ++i)
-            if (n.child_visits[i] > n.child_visits[best]) best = i;
+        const int best = best_action_index_fast(n);
         child_idx = best;
         const int next = n.no_visit_idx ? n.child[best] : -1;
         if (next < 0 || !nodes_[next].has_data || nodes_[next].visit_sum < uint32_t(s_.epsilon_greedy_counter) ||
@@ -310,7 +388,7 @@ int Tree::collect(int quota, BoardDesc* descs) {
     size_t num_terminal = 0;
     const size_t terminal_cache = size_t(TERMINAL_NODE_CACHE_FACTOR) * size_t(std::max(quota, 1));
     int n_new = 0;
-    if (nodes_[0].terminal || !nodes_[0].has_nn) return 0;
+    if (nodes_[0].terminal || !nodes_[0].has_nn || root_solved()) return 0;                // is_root_node_unsolved, searchthread.cpp:333-340
     while (n_new < quota && collision_trajectories_.size() != size_t(quota) && num_terminal < terminal_cache) {
         trajectory_buffer_.clear();
         NodeBackup type;
@@ -320,7 +398,7 @@ int Tree::collect(int quota, BoardDesc* descs) {
         depth_max = std::max(depth_max, depth);
         if (type == NODE_TERMINAL) {
             ++num_terminal;
-            backup_value(nodes_[leaf].value(), trajectory_buffer_, true);   // backup_value<true>: terminal visits are free (searchthread.cpp:364-367)
+            backup_value(nodes_[leaf].value(), trajectory_buffer_, true, s_.mcts_solver);   // backup_value<true>: terminal visits are free (searchthread.cpp:364-367)
         } else if (type == NODE_COLLISION) {
             collision_trajectories_.push_back(trajectory_buffer_);
         } else {
@@ -342,13 +420,44 @@ void Tree::finish_batch(const float* values, const float* probs, int nb_policy) 
     collision_trajectories_.clear();
 }
 
-// Node::get_mcts_policy (node.cpp:1070-1109) for an UNSOLVED root without solved children
+// Node::get_mcts_policy (node.cpp:1070-1109)
 int Tree::best_move_index(std::vector<double>* policy_out) const {
     const Node& n = nodes_[0];
     if (!n.has_data || n.no_visit_idx == 0) return -1;
     const int m = n.no_visit_idx;
     std::vector<double> pol(m);
+    auto normalise = [&]() {
+        double sum = 0;
+        for (double v : pol) sum += v;
+        int best = 0;
+        for (int i = 0; i < m; ++i) {
+            pol[i] /= sum;
+            if (pol[i] > pol[best]) best = i;
+        }
+        if (policy_out) *policy_out = pol;
+        return best;
+    };
+    if (n.node_type == NT_WIN) {                                 // mcts_policy_based_on_wins (node.cpp:299-322): every mating child
+        for (int i = 0; i < m; ++i)
+            pol[i] = (n.child[i] >= 0 && nodes_[n.child[i]].has_data && nodes_[n.child[i]].node_type == NT_LOSS) ? 1.0 : 0.0;
+        return normalise();
+    }
+    if (n.node_type == NT_LOSS) {                                // mcts_policy_based_on_losses (node.cpp:324-341): delay the mate
+        int longest_idx = 0;
+        uint16_t longest = 0;
+        for (int i = 0; i < m; ++i)
+            if (n.child[i] >= 0 && nodes_[n.child[i]].has_data && nodes_[n.child[i]].end_in_ply > longest) {
+                longest = nodes_[n.child[i]].end_in_ply;
+                longest_idx = i;
+            }
+        pol[longest_idx] = 1.0;
+        return normalise();
+    }
     for (int i = 0; i < m; ++i) pol[i] = n.child_visits[i];
+    if (n.unsolved_children != n.actions.size()) {               // prune_losses_in_mcts_policy (node.cpp:343-363)
+        for (int i = 0; i < m; ++i)
+            if (n.child[i] >= 0 && nodes_[n.child[i]].has_data && nodes_[n.child[i]].node_type == NT_WIN) pol[i] = 0;
+    }
     int best_q = 0;
     for (int i = 1; i < m; ++i) if (n.q[i] > n.q[best_q]) best_q = i;
     // first_and_second_max (blazeutil.h:155-178): runner-up seeded with numeric_limits<double>::min()
@@ -366,15 +475,7 @@ int Tree::best_move_index(std::vector<double>* policy_out) const {
             pol[second_arg] += q_diff * s_.q_value_weight * pol[first_arg];
         }
     }
-    double sum = 0;
-    for (double v : pol) sum += v;
-    int best = 0;
-    for (int i = 0; i < m; ++i) {
-        pol[i] /= sum;
-        if (pol[i] > pol[best]) best = i;
-    }
-    if (policy_out) *policy_out = pol;
-    return best;
+    return normalise();
 }
 
 }  // namespace search

@@ -46,6 +46,11 @@ struct SearchSettings {
     int epsilon_greedy_counter = 0;
     int epsilon_checks_counter = 0;
     uint32_t seed = 1;
+    // MCTS_Solver (optionsuci.cpp:129, default true): terminal backups mark parents WIN / LOSS / DRAW once their children
+    // prove it (Node::solve_for_terminal, node.cpp:365-453); a solved root ends the search (searchthread.cpp:333-340).
+    // Search_Type "mcgs" needs no switch here: in the reference the transposition link of add_new_node_to_tree is
+    // unreachable (node.cpp:730-731 reads the candidate from the still-empty child slot), so mcgs and mcts search the same tree.
+    bool mcts_solver = true;
 };
 
 struct Node {
@@ -57,12 +62,16 @@ struct Node {
     std::vector<float> q;
     std::vector<int32_t> child;           // node index or -1
     std::vector<uint8_t> vl;              // virtualLossCounter
+    std::vector<int8_t> child_types;      // nodeTypes: what the solver has recorded about each expanded child
     double value_sum = 0.0;
     uint32_t real_visits = 0;
     uint32_t visit_sum = 0;
     uint32_t free_visits = 0;
     uint16_t no_visit_idx = 0;
     uint16_t plies = 0;
+    uint16_t unsolved_children = 0;       // numberUnsolvedChildNodes
+    uint16_t end_in_ply = 0;              // endInPly: distance to the proven terminal
+    int32_t checkmate_idx = -1;           // checkmateIdx (NO_CHECKMATE)
     int8_t node_type = NT_UNSOLVED;
     bool terminal = false, has_nn = false, sorted = false, has_data = false, inspected = false;
     uint8_t stm = 0;
@@ -116,8 +125,10 @@ public:
     int select_child(Node& n);
     void apply_virtual_loss(Node& n, int child_idx);
     void revert_virtual_loss(Node& n, int child_idx);
-    void revert_virtual_loss_and_update(Node& n, int child_idx, float value, bool free_backup);
-    void backup_value(float value, const Trajectory& t, bool free_backup);
+    void revert_virtual_loss_and_update(Node& n, int child_idx, float value, bool free_backup, bool solve = false);
+    void backup_value(float value, const Trajectory& t, bool free_backup, bool solve = false);
+    bool solve_for_terminal(Node& n, int child_idx);
+    bool root_solved() const { return nodes_[0].node_type != NT_UNSOLVED; }
 
 private:
     int new_node(const chess::Position& pos);
@@ -130,6 +141,7 @@ private:
     int get_starting_node(int cur, uint32_t& depth, int& child_idx, chess::Position& pos);
     void random_playout(int cur, int& child_idx);
     int select_enhanced_move(int cur, const chess::Position& pos);
+    int best_action_index_fast(const Node& n) const;
 
     SearchSettings s_;
     chess::Position root_pos_;

@@ -161,7 +161,7 @@ int SearchPool::add_position(const chess::Position& pos) {
 }
 
 bool SearchPool::tree_done(const Tree& t, uint32_t simulations, uint32_t nodes) const {
-    if (t.root().terminal) return true;
+    if (t.root().terminal || t.root_solved()) return true;
     if (simulations && t.root_visits() >= simulations) return true;
     if (nodes && t.node_count() >= nodes) return true;
     return false;
@@ -201,7 +201,7 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     // simulations/nodes limits are per `go`: measured from the pre-search counters (tree reuse keeps old visits)
     auto done = [&](int id) {
         const Tree& t = *trees_[id];
-        if (t.root().terminal) return true;
+        if (t.root().terminal || t.root_solved()) return true;      // is_root_node_unsolved(), searchthread.cpp:333-340
         if (simulations && t.root_visits() - visits_pre[id] >= simulations) return true;
         if (nodes && t.node_count() - nodes_pre[id] >= nodes) return true;
         return false;

@@ -14,7 +14,7 @@ class SearchSettingsC(C.Structure):
                 ("node_policy_temperature", C.c_float), ("virtual_style", C.c_int), ("virtual_mix_threshold", C.c_uint),
                 ("virtual_offset_strength", C.c_double), ("q_value_weight", C.c_float), ("q_veto_delta", C.c_float),
                 ("mode", C.c_int), ("version_major", C.c_int), ("is_policy_map", C.c_int), ("clone_keeps_last_moves", C.c_int),
-                ("epsilon_greedy_counter", C.c_int), ("epsilon_checks_counter", C.c_int), ("seed", C.c_uint)]
+                ("epsilon_greedy_counter", C.c_int), ("epsilon_checks_counter", C.c_int), ("seed", C.c_uint), ("mcts_solver", C.c_int)]
 
 
 class SearchStatsC(C.Structure):
@@ -81,6 +81,13 @@ class SearchPool:
         rv, nc, alloc, val = C.c_uint(), C.c_uint(), C.c_uint(), C.c_float()
         self._lib.mi_search_tree_info(self._h, tree, C.byref(rv), C.byref(nc), C.byref(alloc), C.byref(val))
         return dict(root_visits=rv.value, node_count=nc.value, allocated=alloc.value, root_value=val.value)
+
+    def root_solved(self, tree: int) -> dict:
+        """Solver verdict on the root: node_type 0 WIN / 1 DRAW / 2 LOSS / 6 UNSOLVED, plies to the end, mating child index."""
+        nt, ply, mate = C.c_int(), C.c_int(), C.c_int()
+        if self._lib.mi_search_root_solved(self._h, tree, C.byref(nt), C.byref(ply), C.byref(mate)):
+            raise RuntimeError(_capi.last_error())
+        return dict(node_type=nt.value, end_in_ply=ply.value, checkmate_idx=mate.value)
 
     def best_move(self, tree: int) -> str:
         buf = C.create_string_buffer(16)

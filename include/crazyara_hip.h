@@ -153,6 +153,9 @@ typedef struct mi_search_settings {        /* SearchSettings (engine/src/agents/
      * (Centi_Epsilon_Greedy 5, Centi_Epsilon_Checks 1).  seed: per-pool seed of the trees' generators (tree i uses seed + i). */
     int epsilon_greedy_counter, epsilon_checks_counter;
     unsigned seed;
+    /* MCTS_Solver (optionsuci.cpp:129, default on): terminal backups prove WIN / LOSS / DRAW up the tree
+     * (Node::solve_for_terminal, node.cpp:365-453); a proven root ends that tree's search. */
+    int mcts_solver;
 } mi_search_settings;
 typedef struct mi_search_stats {
     unsigned long long nodes, nn_evals, batches, simulations;
@@ -173,6 +176,9 @@ int mi_search_run(mi_search* sp, unsigned simulations, unsigned nodes, int threa
 /* root statistics of one tree, children in the node's (prior-sorted) order: returns number of expanded children */
 int mi_search_root_children(mi_search* sp, int tree, int cap, uint32_t* moves, uint32_t* visits, float* q, float* priors);
 int mi_search_tree_info(mi_search* sp, int tree, unsigned* root_visits, unsigned* node_count, unsigned* allocated_nodes, float* root_value);
+/* solver state of the root (NodeData::nodeType / endInPly / checkmateIdx, nodedata.h:88-121): node_type 0 WIN, 1 DRAW, 2 LOSS,
+ * 6 UNSOLVED (NodeType, nodedata.h:40-52); end_in_ply = plies to the proven terminal; checkmate_idx = mating child or -1 */
+int mi_search_root_solved(mi_search* sp, int tree, int* node_type, int* end_in_ply, int* checkmate_idx);
 int mi_search_best_move(mi_search* sp, int tree, char* uci, int cap);   /* argmax of Node::get_mcts_policy, node.cpp:1070-1109 */
 
 #ifdef __cplusplus

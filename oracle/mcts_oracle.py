@@ -12,14 +12,18 @@ Python restatement of the reference's MCTS leaf-collection arithmetic on top of 
   fill_nn_results: prior gather, temperature, value .......... searchthread.cpp:290-299, node.cpp:956-979, util/blazeutil.h:77-87
   sort_moves_by_probabilities (stable, index tie-break) ...... node.cpp:464-470
   get_mcts_policy / first_and_second_max ..................... node.cpp:1070-1109, blazeutil.h:155-178
+  solve_for_terminal, solved_win/loss/draw, end-in-ply ....... node.cpp:108-172, 268-297, 365-453
 
 float32 / float64 mixing follows the C++ expression types (blaze vectors of float, uint32 and double); logf / powf are
 taken from libm so that results are bit-identical to a C++ build on the same machine.
 
 Parity status: the reference has NO unit test for this arithmetic ("parity unpinned") and its engine cannot be
 compiled here (Stockfish fork + blaze are empty submodules), so this file is a line-by-line restatement checked by
-hand-computed cases in tests/test_mcts.py, not by reference-generated vectors.  useMCGS (transposition merge) and the MCTS
-solver are not restated.  The epsilon exploration (searchthread.cpp:124-185, 451-473, 497-501) is restated with the reference's
+hand-computed cases in tests/test_mcts.py, not by reference-generated vectors.  The MCTS solver (solve_for_terminal and friends,
+node.cpp:108-172, 268-297, 365-453; solved branches of get_mcts_policy / get_best_action_index, node.cpp:299-363, 1123-1148) is
+restated without tablebases.  useMCGS needs no restatement: the transposition link in Node::add_new_node_to_tree is unreachable
+(node.cpp:730-731 takes the candidate from the child slot that is still empty at that point), so NODE_TRANSPOSITION is never
+produced and "mcgs" searches the same tree as "mcts".  The epsilon exploration (searchthread.cpp:124-185, 451-473, 497-501) is restated with the reference's
 rand() replaced by a seeded ANSI-C LCG (the reference seeds rand() with the time, so its own runs do not replay either).
 """
 from __future__ import annotations
@@ -41,6 +45,7 @@ _libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
 F = np.float32
 Q_INIT = F(-1.0)
 VIRTUAL_LOSS, VIRTUAL_VISIT, VIRTUAL_OFFSET, VIRTUAL_MIX = 0, 1, 2, 3
+NT_WIN, NT_DRAW, NT_LOSS, NT_UNSOLVED = 0, 1, 2, 6      # NodeType, nodedata.h:42-52 (tablebase build numbering)
 
 
 class Settings:
@@ -59,6 +64,7 @@ class Settings:
         self.epsilon_greedy_counter = 0      # 1 / Centi_Epsilon_Greedy: UCI default 20 (optionsuci.cpp:90, crazyara.cpp:749); 0 = off
         self.epsilon_checks_counter = 0      # UCI default 100
         self.seed = 1
+        self.mcts_solver = True              # MCTS_Solver, optionsuci.cpp:129
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -87,18 +93,23 @@ class Node:
         self.visit_sum = 0
         self.free_visits = 0
         self.no_visit_idx = 0
+        self.node_type = NT_UNSOLVED
+        self.end_in_ply = 0
+        self.checkmate_idx = -1
+        self.unsolved_children = 0
         t = board.terminal()
         if t != co.TERMINAL_NONE:
             self.terminal = True
             self.has_data = True
             self.sorted = True
             self.set_value({co.TERMINAL_WIN: F(1), co.TERMINAL_DRAW: F(0), co.TERMINAL_LOSS: F(-1)}[t])
+            self.node_type = {co.TERMINAL_WIN: NT_WIN, co.TERMINAL_DRAW: NT_DRAW, co.TERMINAL_LOSS: NT_LOSS}[t]
             if t == co.TERMINAL_DRAW:
                 self.moves = []
         self.uci = [board.move_uci(m) for m in self.moves]
         self.priors = [F(0)] * len(self.moves)
         self.policy_idx = [] if self.terminal else [policy_map.index(board, m, s.is_policy_map) for m in self.moves]
-        self.child_visits, self.q, self.child, self.vl = [], [], [], []
+        self.child_visits, self.q, self.child, self.vl, self.child_types = [], [], [], [], []
 
     def set_value(self, v):
         self.real_visits += 1
@@ -149,7 +160,8 @@ class Tree:
         if not n.has_data:
             n.has_data = True
             n.no_visit_idx = 1
-            n.child_visits, n.q, n.child, n.vl = [0], [Q_INIT], [None], [0]
+            n.child_visits, n.q, n.child, n.vl, n.child_types = [0], [Q_INIT], [None], [0], [NT_UNSOLVED]
+            n.unsolved_children = len(n.moves)
 
     def increment_no_visit_idx(self, n: Node):
         if n.no_visit_idx < len(n.moves):
@@ -158,12 +170,15 @@ class Tree:
             n.q.append(Q_INIT)
             n.child.append(None)
             n.vl.append(0)
+            n.child_types.append(NT_UNSOLVED)
 
     def select_child(self, n: Node):
         if not n.sorted:
             self.prepare(n)
         if n.no_visit_idx == 1:
             return 0
+        if n.checkmate_idx >= 0:             # has_forced_win
+            return n.checkmate_idx
         cpuct = get_current_cput(n.visit_sum, self.s)
         sq = math.sqrt(float(n.visit_sum))
         best, best_v = 0, F(-np.inf)
@@ -194,7 +209,7 @@ class Tree:
         n.visit_sum -= 1
         n.vl[c] -= 1
 
-    def revert_virtual_loss_and_update(self, n: Node, c, value, free_backup):
+    def revert_virtual_loss_and_update(self, n: Node, c, value, free_backup, solve=False):
         value = F(value)
         n.value_sum += float(value)
         n.real_visits += 1
@@ -215,12 +230,71 @@ class Tree:
         n.vl[c] -= 1
         if free_backup:
             n.free_visits += 1
+        if solve:
+            self.solve_for_terminal(n, c)
 
-    def backup_value(self, value, traj, free_backup):
+    def solve_for_terminal(self, n: Node, c):
+        """Node::solve_for_terminal (node.cpp:365-453), two-player, no tablebases."""
+        ch = n.child[c]
+        if ch is None or not ch.has_data:
+            return False
+        if ch.node_type == NT_UNSOLVED:
+            return False
+        if n.node_type != NT_UNSOLVED:
+            return False
+        if n.child_types[c] == NT_UNSOLVED:
+            n.unsolved_children -= 1
+            n.child_types[c] = ch.node_type
+            if ch.node_type == NT_WIN:                       # disable_action (node.cpp:1006-1010)
+                n.priors[c] = F(0)
+                n.q[c] = F(-2147483647)
+        if ch.node_type == NT_LOSS:                          # solved_win
+            n.node_type = NT_WIN
+            n.end_in_ply = ch.end_in_ply + 1                 # define_end_ply_for_solved_terminal, WIN branch
+            n.set_value(F(1))                                # update_solved_terminal
+            n.q[c] = F(1)
+            n.checkmate_idx = c
+            return True
+        if n.unsolved_children == 0 and ch.node_type == NT_WIN and all(k.node_type == NT_WIN for k in n.child):   # solved_loss
+            n.node_type = NT_LOSS
+            for k in n.child:                                # longest line
+                if k.end_in_ply + 1 > n.end_in_ply:
+                    n.end_in_ply = k.end_in_ply + 1
+            n.set_value(F(-1))
+            n.q[c] = F(-1)
+            return True
+        if n.unsolved_children == 0 and ch.node_type != NT_LOSS:                                                  # solved_draw
+            if all(k.has_data and k.node_type in (NT_DRAW, NT_WIN) for k in n.child) and any(k.node_type == NT_DRAW for k in n.child):
+                n.node_type = NT_DRAW
+                for k in n.child:                            # "shortest" line: never below the initial 0 (node.cpp:277-285)
+                    if k.node_type == NT_DRAW and k.end_in_ply + 1 < n.end_in_ply:
+                        n.end_in_ply = k.end_in_ply + 1
+                n.set_value(F(0))
+                n.q[c] = F(0)
+                return True
+        return False
+
+    def backup_value(self, value, traj, free_backup, solve=False):
         value = F(value)
         for n, c in reversed(traj):
             value = F(-value)
-            self.revert_virtual_loss_and_update(n, c, value, free_backup)
+            self.revert_virtual_loss_and_update(n, c, value, free_backup, solve)
+
+    def best_action_index_fast(self, n: Node):
+        """get_best_action_index(fast=True), node.cpp:1123-1148"""
+        if n.checkmate_idx >= 0:
+            return n.checkmate_idx
+        best = 0
+        if n.node_type == NT_LOSS:
+            longest = 0
+            for i, k in enumerate(n.child):
+                if k.end_in_ply > longest:
+                    longest, best = k.end_in_ply, i
+            return best
+        for i in range(1, n.no_visit_idx):
+            if n.child_visits[i] > n.child_visits[best]:
+                best = i
+        return best
 
     # ---------------------------------------------------------------------------------------------------------------
     # ---- epsilon exploration --------------------------------------------------------------------------------------
@@ -240,13 +314,10 @@ class Tree:
         """searchthread.cpp:144-162: follow the most-visited line for a random number of plies (no virtual loss, no trajectory)."""
         child_idx, depth = -1, 0
         for _ in range(self.get_random_depth()):
-            best = 0
-            for i in range(1, cur.no_visit_idx):
-                if cur.child_visits[i] > cur.child_visits[best]:
-                    best = i
+            best = self.best_action_index_fast(cur)
             child_idx = best
             nxt = cur.child[best] if cur.no_visit_idx else None
-            if nxt is None or not nxt.has_data or nxt.visit_sum < self.s.epsilon_greedy_counter or nxt.terminal:
+            if nxt is None or not nxt.has_data or nxt.visit_sum < self.s.epsilon_greedy_counter or nxt.node_type != NT_UNSOLVED:
                 break
             board.push(cur.moves[best])
             cur = nxt
@@ -260,7 +331,7 @@ class Tree:
             child = cur.child[idx]
             if child is None or not child.has_data:
                 return idx
-            if not child.terminal:          # node type UNSOLVED (no solver here: solved == terminal)
+            if child.node_type == NT_UNSOLVED:
                 return idx
             return -1
         idx = min(cur.no_visit_idx, len(cur.moves) - 1)
@@ -322,13 +393,13 @@ class Tree:
         """-> list of boards to evaluate (one per new leaf)"""
         boards = []
         n_term = 0
-        if self.root.terminal or not self.root.has_nn:
+        if self.root.terminal or not self.root.has_nn or self.root.node_type != NT_UNSOLVED:
             return boards
         while len(boards) < quota and len(self.coll_traj) != quota and n_term < 2 * max(quota, 1):
             kind, node, traj, board = self.get_new_child()
             if kind == "terminal":
                 n_term += 1
-                self.backup_value(node.value(), traj, True)
+                self.backup_value(node.value(), traj, True, self.s.mcts_solver)
             elif kind == "collision":
                 self.coll_traj.append(traj)
             else:
@@ -354,7 +425,31 @@ class Tree:
     def best_move(self):
         n = self.root
         m = n.no_visit_idx
+
+        def finish(pol):
+            tot = sum(pol)
+            with np.errstate(all="ignore"):
+                pol = [float(np.float64(p) / np.float64(tot)) for p in pol]
+            best = 0
+            for i in range(m):
+                if pol[i] > pol[best]:
+                    best = i
+            return n.uci[best], pol
+
+        if n.node_type == NT_WIN:            # mcts_policy_based_on_wins, node.cpp:299-322
+            return finish([1.0 if (k is not None and k.has_data and k.node_type == NT_LOSS) else 0.0 for k in n.child[:m]])
+        if n.node_type == NT_LOSS:           # mcts_policy_based_on_losses, node.cpp:324-341
+            pol, longest, li = [0.0] * m, 0, 0
+            for i, k in enumerate(n.child[:m]):
+                if k is not None and k.has_data and k.end_in_ply > longest:
+                    longest, li = k.end_in_ply, i
+            pol[li] = 1.0
+            return finish(pol)
         pol = [float(v) for v in n.child_visits[:m]]
+        if n.unsolved_children != len(n.moves):          # prune_losses_in_mcts_policy, node.cpp:343-363
+            for i, k in enumerate(n.child[:m]):
+                if k is not None and k.has_data and k.node_type == NT_WIN:
+                    pol[i] = 0.0
         best_q = 0
         for i in range(1, m):
             if n.q[i] > n.q[best_q]:
@@ -372,9 +467,7 @@ class Tree:
             elif fa != sa and n.q[sa] > n.q[fa]:
                 q_diff = F(n.q[sa] - n.q[fa])
                 pol[sa] += float(F(q_diff * self.s.q_value_weight)) * pol[fa]
-        tot = sum(pol)
-        pol = [p / tot for p in pol]
-        return n.uci[int(np.argmax(pol))], pol
+        return finish(pol)
 
 
 def run_search(tree: Tree, evaluate, simulations, quota):
@@ -383,7 +476,7 @@ def run_search(tree: Tree, evaluate, simulations, quota):
         v, p = evaluate([tree.root_board])
         tree.set_root_result(v[0], p[0])
     pre = tree.root.visit_sum
-    while not tree.root.terminal and tree.root.visit_sum - pre < simulations:
+    while not tree.root.terminal and tree.root.node_type == NT_UNSOLVED and tree.root.visit_sum - pre < simulations:
         boards = tree.collect(quota)
         if boards:
             v, p = evaluate(boards)

@@ -80,6 +80,109 @@ def test_oracle_arithmetic_worked_examples():
     assert mo.virtual_style(mix, 1000) == mo.VIRTUAL_VISIT and mo.virtual_style(mix, 1001) == mo.VIRTUAL_LOSS
 
 
+def _fake_node(node_type=mo.NT_UNSOLVED, end_in_ply=0, n_moves=0):
+    n = mo.Node.__new__(mo.Node)
+    n.has_data, n.sorted, n.node_type, n.end_in_ply, n.checkmate_idx = True, True, node_type, end_in_ply, -1
+    n.moves = [None] * n_moves
+    n.unsolved_children = n_moves
+    n.priors = [np.float32(1.0 / max(n_moves, 1))] * n_moves
+    n.child_visits, n.q, n.vl = [1] * n_moves, [np.float32(0.1)] * n_moves, [0] * n_moves
+    n.child, n.child_types = [None] * n_moves, [mo.NT_UNSOLVED] * n_moves
+    n.value_sum, n.real_visits, n.visit_sum, n.free_visits, n.no_visit_idx = 0.0, 0, n_moves, 0, n_moves
+    return n
+
+
+def test_oracle_solver_worked_examples():
+    """Node::solve_for_terminal (node.cpp:365-453) on hand-built nodes: a child's LOSS proves a WIN at once; a LOSS needs every
+    child to be a WIN and takes the longest line; a DRAW needs every child WIN or DRAW with one DRAW; a child's WIN is disabled."""
+    t = mo.Tree.__new__(mo.Tree)
+    t.s = mo.Settings()
+    # WIN: the second child is a mated position (terminal LOSS, 0 plies to the end) -> mate in 1, remembered as checkmate_idx
+    n = _fake_node(n_moves=3)
+    n.child = [_fake_node(), _fake_node(mo.NT_LOSS, 0), None]
+    assert not t.solve_for_terminal(n, 0) and n.node_type == mo.NT_UNSOLVED and n.unsolved_children == 3
+    assert not t.solve_for_terminal(n, 2)                                # unexpanded child: not a playout node
+    assert t.solve_for_terminal(n, 1)
+    assert (n.node_type, n.end_in_ply, n.checkmate_idx, n.unsolved_children) == (mo.NT_WIN, 1, 1, 2)
+    assert float(n.q[1]) == 1.0 and float(n.value()) == 1.0 and n.real_visits == 1
+    assert t.select_child(n) == 1 and not t.solve_for_terminal(n, 1)     # forced line; solved nodes are final
+    # LOSS: both replies are proven WINs for the opponent (mate in 1 and mate in 3) -> mated in 4 plies along the longer line
+    n = _fake_node(n_moves=2)
+    n.child = [_fake_node(mo.NT_WIN, 1), _fake_node(mo.NT_WIN, 3)]
+    assert not t.solve_for_terminal(n, 0)
+    assert n.unsolved_children == 1 and float(n.priors[0]) == 0.0 and float(n.q[0]) == -2147483648.0   # disable_action
+    assert t.solve_for_terminal(n, 1)
+    assert (n.node_type, n.end_in_ply, n.checkmate_idx) == (mo.NT_LOSS, 4, -1) and float(n.q[1]) == -1.0
+    assert t.best_action_index_fast(n) == 1                              # delay the mate
+    # DRAW: one reply loses (child WIN), the other is a dead draw
+    n = _fake_node(n_moves=2)
+    n.child = [_fake_node(mo.NT_DRAW, 0), _fake_node(mo.NT_WIN, 1)]
+    assert not t.solve_for_terminal(n, 0)
+    assert t.solve_for_terminal(n, 1)
+    assert (n.node_type, n.end_in_ply) == (mo.NT_DRAW, 0) and float(n.q[1]) == 0.0 and float(n.value()) == 0.0
+    # not a draw while a sibling is still unsolved, and never through a child that loses for the opponent
+    n = _fake_node(n_moves=3)
+    n.child = [_fake_node(mo.NT_DRAW, 0), _fake_node(mo.NT_WIN, 1), _fake_node()]
+    assert not t.solve_for_terminal(n, 0) and not t.solve_for_terminal(n, 1) and n.node_type == mo.NT_UNSOLVED
+
+
+SOLVER_CASES = [
+    # variant, fen, mode, expected root verdict (node_type, end_in_ply) or None, expected best move or None
+    ("chess", "6k1/5ppp/8/8/8/8/8/R3K3 w - - 0 1", 1, (mo.NT_WIN, 1), "a1a8"),          # back-rank mate in 1
+    ("chess", "7k/8/6K1/8/8/8/8/Q7 b - - 0 1", 1, (mo.NT_LOSS, None), "h8g8"),          # only move, every reply line mates
+    ("chess", "k7/8/1K6/8/8/8/8/7R w - - 0 1", 1, (mo.NT_WIN, 1), "h1h8"),
+    ("crazyhouse", "4R2b/1N3rkb/1p2P1pp/p2P4/2P1P3/8/PP4Q1/3R3K[QRBBNNNPPPPpp] w - - 2 53", 0, None, None),
+    ("crazyhouse", "r1b2rk1/pppp1Npp/8/8/8/8/PPPPPPPP/RNBQKB1R[Qq] w KQ - 0 1", 0, None, None),
+]
+
+
+@pytest.mark.parametrize("variant,fen,mode,verdict,best", SOLVER_CASES)
+def test_mcts_solver_equals_oracle(hip_lib, variant, fen, mode, verdict, best):
+    nbp, sims, quota = NB_POLICY[mode], 600, 8
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota)
+    assert st.mcts_solver == 1                                            # MCTS_Solver defaults to on (optionsuci.cpp:129)
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    def eval_boards(boards):
+        out = [_pseudo_net(key_from_board(b), nbp) for b in boards]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=quota, fn_nb_policy=nbp)
+    t = pool.add_position(fen, False, variant)
+    pool.run(simulations=sims, threads=1)
+    moves, visits, q, _ = pool.root_children(t)
+    info, solved = pool.tree_info(t), pool.root_solved(t)
+
+    tree = mo.Tree(co.Board(fen, False, variant), mo.Settings(mode=mode, is_policy_map=True, batch_size=quota))
+    mo.run_search(tree, eval_boards, sims, quota)
+    r = tree.root
+    assert visits == r.child_visits
+    assert np.array_equal(q, np.array(r.q, np.float32))
+    assert info["root_visits"] == r.visit_sum and info["node_count"] == tree.node_count()
+    assert (solved["node_type"], solved["end_in_ply"], solved["checkmate_idx"]) == (r.node_type, r.end_in_ply, r.checkmate_idx)
+    assert pool.best_move(t) == tree.best_move()[0]
+    if verdict is not None:
+        assert solved["node_type"] == verdict[0]
+        if verdict[1] is not None:
+            assert solved["end_in_ply"] == verdict[1]
+        assert info["root_visits"] < sims + quota                        # a proven root ends the search early
+        assert pool.best_move(t) == best
+    # solver off: same positions keep searching to the limit
+    st0 = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota, mcts_solver=0)
+    pool0 = search.SearchPool(st0, eval_fn=eval_descs, fn_batch=quota, fn_nb_policy=nbp)
+    t0 = pool0.add_position(fen, False, variant)
+    pool0.run(simulations=sims, threads=1)
+    assert pool0.root_solved(t0)["node_type"] == mo.NT_UNSOLVED and pool0.tree_info(t0)["root_visits"] >= sims
+    tree0 = mo.Tree(co.Board(fen, False, variant), mo.Settings(mode=mode, is_policy_map=True, batch_size=quota, mcts_solver=False))
+    mo.run_search(tree0, eval_boards, sims, quota)
+    assert pool0.root_children(t0)[1] == tree0.root.child_visits
+    pool0.close()
+    pool.close()
+
+
 CASES = [
     # variant, is960, fen, mode, sims, quota(batch), virtual style, temperature
     ("crazyhouse", False, "", 0, 300, 8, 3, 1.7),

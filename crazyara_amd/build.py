@@ -27,7 +27,7 @@ def _stamp():
     for root, _, files in os.walk(CSRC):
         for f in sorted(files):
             p = os.path.join(root, f)
-            h.update(p.encode())
+            h.update(os.path.relpath(p, CSRC).encode())      # relative: the checkout may live elsewhere on the GPU box
             with open(p, "rb") as fh:
                 h.update(fh.read())
     with open(os.path.join(os.path.dirname(HERE), "include", "crazyara_hip.h"), "rb") as fh:

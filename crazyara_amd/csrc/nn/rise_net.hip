@@ -362,6 +362,19 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         for (size_t i = 0; i < v.size(); ++i) h[i] = half_t(v[i]);
         return h;
     };
+    // tower kernel, SE gate weights in thread order: thread t of 512 reads its 32 half2 weights as 8 coalesced 16-byte loads,
+    // load i of thread t at uint4 index i*512 + t (tower.hip: se_phase).  idx(t, k) = half2 index of thread t's k-th weight.
+    auto pack_se_threads = [](const std::vector<float>& src, auto idx) {
+        std::vector<half_t> out(size_t(8) * 512 * 8);
+        for (int i = 0; i < 8; ++i)
+            for (int t = 0; t < 512; ++t)
+                for (int j = 0; j < 4; ++j) {
+                    const size_t h2 = idx(t, 4 * i + j);
+                    out[((size_t(i) * 512 + t) * 4 + j) * 2 + 0] = half_t(src[2 * h2]);
+                    out[((size_t(i) * 512 + t) * 4 + j) * 2 + 1] = half_t(src[2 * h2 + 1]);
+                }
+        return out;
+    };
     for (size_t i = 0; i < cops.size(); ++i) {
         const std::string p = "body_spatial." + std::to_string(i + 1);
         const int cop = cops[i], k = ks[i];
@@ -377,8 +390,9 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             for (int c = 0; c < C; ++c) for (int j = 0; j < H; ++j) w2t[size_t(j) * C + c] = w2.data[size_t(c) * H + j];
             if (se_in_kernel) {
                 td.se_kind = 1;
-                td.se_w1 = im.upload(to_half(w1t));
-                td.se_w2 = im.upload(to_half(w2t));
+                // FC1: thread t -> outputs 2*(t%64), +1 over inputs c in [32*(t/64), +32); FC2: outputs 2*(t%128), +1 over j in [32*(t/128), +32)
+                td.se_w1 = im.upload(pack_se_threads(w1t, [](int t, int k) { return size_t((t >> 6) * 32 + k) * 64 + (t & 63); }));
+                td.se_w2 = im.upload(pack_se_threads(w2t, [](int t, int k) { return size_t((t >> 7) * 32 + k) * 128 + (t & 127); }));
             } else {
                 Op op;
                 op.se_kind = 1;
@@ -397,7 +411,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             for (int o = 0; o < C; ++o) b[o] = bs[o];
             if (se_in_kernel) {
                 td.se_kind = 2;
-                td.se_w1 = im.upload(to_half(wt));
+                // thread t -> outputs 2*(t%128), +1 over inputs i in [64*(t/128), +64): first 32 inputs, then the second 32
+                std::vector<half_t> pk = pack_se_threads(wt, [](int t, int k) { return size_t((t >> 7) * 64 + k) * 128 + (t & 127); });
+                const std::vector<half_t> pk2 = pack_se_threads(wt, [](int t, int k) { return size_t((t >> 7) * 64 + 32 + k) * 128 + (t & 127); });
+                pk.insert(pk.end(), pk2.begin(), pk2.end());
+                td.se_w1 = im.upload(pk);
                 td.se_b = im.upload(b);
             } else {
                 Op op;

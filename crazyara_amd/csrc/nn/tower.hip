@@ -44,9 +44,12 @@ constexpr int TW_T2_OFF = TW_T1_OFF + 2 * TW_T1_BYTES;
 constexpr int TW_POOL_OFF = TW_T2_OFF + 2 * TW_T2_BYTES;      // float [256] channel sums of the new stream
 constexpr int TW_SE_OFF = TW_POOL_OFF + 256 * 4;              // float mean[256], part[1024], h[128], gate[256]
 constexpr int TW_B3_OFF = TW_SE_OFF + (256 + 1024 + 128 + 256) * 4;   // float [256] BN3 bias of the current block
-constexpr int TW_PRM_OFF = TW_B3_OFF + 256 * 4;               // 4 vector waves x 2112 B: packed depthwise weights of a chunk
-constexpr int TW_PRM_LG = 528;                                // bytes between lane groups in a slice (512 + 16: distinct banks)
-constexpr int TW_LDS_BYTES = TW_PRM_OFF + 4 * 4 * TW_PRM_LG;
+constexpr int TW_DYN_LDS_BYTES = TW_B3_OFF + 256 * 4;         // the part above is the launch's dynamic LDS
+// Depthwise weights: a static LDS array, 4 vector waves x 2 buffers x 2 KiB, filled by LDS-DMA.
+constexpr int TW_PRM_LG = 512;                                // bytes between lane groups in a buffer
+constexpr int TW_PRM_BUF = 4 * TW_PRM_LG;
+constexpr int TW_PRM_BYTES = 4 * 2 * TW_PRM_BUF;
+constexpr int TW_LDS_BYTES = TW_DYN_LDS_BYTES + TW_PRM_BYTES;
 static_assert(TW_LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr int TW_AHEAD = 96;                          // L2 warm-up distance in fragments per stream (3 full intervals, 384 KiB)
 constexpr int TW_WIN = kTowerWindow;                  // weight fragments in flight per matrix wave (16 KiB)
@@ -79,7 +82,11 @@ struct WStream {
 // D(32x32) += A(32 x 16) * B(16 x 32): lane l holds A[row l%32][k = (l/32)*8 + j], B[k = (l/32)*8 + j][col l%32], j = 0..7;
 // D[row (v%4) + 8*(v/4) + 4*(l/32)][col l%32] in element v.
 __device__ __forceinline__ void mma32(const half8& a, const half8& b, f32x16& c) {
+#ifdef TW_DEV_NO_MFMA
+    asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+#else
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -115,8 +122,10 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) mma32(win[s * 2 + (i >> 1)], cur[i], accE[i & 1]);
+#ifndef TW_DEV_NO_WLOAD
 #pragma unroll
             for (int e = 0; e < 2; ++e) win[s * 2 + e] = sp.frag_at(s * 2 + e + TW_WIN);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         sp.pos += 16 * 1024;
@@ -151,8 +160,10 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) mma32(win[(s * 2 + kk) * 2 + rt], cur[kk * 2 + ct], accP[rt][ct]);
             if (do_e && s < 2) expand_epilogue(s);
+#ifndef TW_DEV_NO_WLOAD
 #pragma unroll
             for (int e = 0; e < 4; ++e) win[s * 4 + e] = sp.frag_at(s * 4 + e + TW_WIN);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         sp.pos += 16 * 1024;
@@ -170,8 +181,10 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
 //     two zero rows; file wrap-around is cancelled by zeroed weights), no cross-lane traffic, no conversions;
 //   * v_pk_fma_f16 accumulates two channels per instruction (f16 accumulate: +0.2e-3 on the logits against f32
 //     accumulation in the oracle's emulation, tolerance 6e-3 -- DESIGN.md), v_pk_max_f16 is the ReLU.
-// Weights: per chunk and wave 1 KiB in the stream = [lane group lg][16 entries: 9 taps, BN2 bias, 6 x pad][4 pairs] half2,
-// fetched one chunk ahead with ONE 16-byte load per lane, parked in a wave-private LDS slice, read back as 10 broadcast reads.
+// Weights: per chunk and wave 2 KiB in the stream = [lane group lg][32 entries: k*k taps, BN2 bias, pad][4 pairs] half2, brought
+// one chunk ahead straight into a wave-private LDS buffer by two LDS-DMA loads (no VGPRs in between), read back as 10 (26)
+// broadcast reads.  Neighbour rows are read one square tile ahead of the FMAs that use them; the bottom row of a tile is the
+// top row of the next (27 reads per chunk, not 36); the four channel-pair chains are interleaved tap by tap.
 // ---------------------------------------------------------------------------------------------------------------------
 struct VecAddr {
     const char* tap[9];  // (LDS) my neighbour row for tap (dy+1)*3 + (dx+1) in tile 0 of buffer 0, rank-valid case
@@ -179,25 +192,48 @@ struct VecAddr {
     const char* bot[3];  // tile 3, dy = +1: the zero row below the board for l15 >= 8 (pre-biased by -3 tiles)
 };
 
-// park this chunk's 2 KiB weight block in my LDS slice (lane l holds bytes [32 l, 32 l + 32)), request the next chunk's
-__device__ __forceinline__ void park_weights(uint4 (&pre)[2], const uint4* __restrict__& pp, char* prml, int lane) {
-    uint4* dst = reinterpret_cast<uint4*>(prml + (lane >> 4) * TW_PRM_LG + (lane & 15) * 32);
-    dst[0] = pre[0];
-    dst[1] = pre[1];
-    pp += 128;
-    pre[0] = pp[0];
-    pre[1] = pp[1];
-}
+// The wave's depthwise-weight stream: chunk g sits in LDS buffer g & 1 one interval before it is used.
+struct VParams {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t pos;        // byte position of the chunk that is being computed (wave-uniform)
+    uint32_t lane_off;   // lane * 16
+    uint32_t buf;        // LDS buffer of that chunk
+    char* lds;           // my two buffers
+    __device__ __forceinline__ void fetch(uint32_t chunk_pos, uint32_t b) const {     // 2 x (64 lanes x 16 B) -> buffer b
+        auto dst = (__attribute__((address_space(3))) void*)(lds + b * TW_PRM_BUF);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane_off, chunk_pos, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane_off, chunk_pos, 1024, 0);
+    }
+    // start of an interval: my chunk has landed (it was requested a whole interval ago)
+    __device__ __forceinline__ const char* open() const {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return lds + buf * TW_PRM_BUF;
+    }
+    // end of an interval: request the next chunk into the other buffer
+    __device__ __forceinline__ void fetch_next() {
+        pos += 2048;
+        buf ^= 1;
+        fetch(pos, buf);
+    }
+};
 
 template <int PARITY>
-__device__ __forceinline__ void vector_interval(uint4 (&pre)[2], const uint4* __restrict__& pp, char* prml, int lane, int lg, const VecAddr& va,
-                                                half_t* t2w, half2_t mLp, half2_t mRp) {
+__device__ __forceinline__ void vector_interval(VParams& vp, int lg, const VecAddr& va, half_t* t2w, half2_t mLp, half2_t mRp) {
     constexpr int T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
-    park_weights(pre, pp, prml, lane);
+    constexpr int TILE = 16 * T1ROW * 2;             // bytes between square tiles of a t1 buffer
+    const char* prm = vp.open() + lg * TW_PRM_LG;
+    // rows of neighbours: top(t) | mid(t) | bot(t), 3 reads each; bot(t) == top(t + 1)
+    uint4 top[3], mid[3], bot[3], nmid[3], nbot[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        top[i] = *reinterpret_cast<const uint4*>(va.top[i] + PARITY * TW_T1_BYTES);
+        mid[i] = *reinterpret_cast<const uint4*>(va.tap[3 + i] + PARITY * TW_T1_BYTES);
+        bot[i] = *reinterpret_cast<const uint4*>(va.tap[6 + i] + PARITY * TW_T1_BYTES);
+    }
     half2_t W[10][4];
 #pragma unroll
     for (int e = 0; e < 10; ++e) {
-        const uint4 u = *reinterpret_cast<const uint4*>(prml + lg * TW_PRM_LG + e * 16);
+        const uint4 u = *reinterpret_cast<const uint4*>(prm + e * 16);
         W[e][0] = __builtin_bit_cast(half2_t, u.x); W[e][1] = __builtin_bit_cast(half2_t, u.y);
         W[e][2] = __builtin_bit_cast(half2_t, u.z); W[e][3] = __builtin_bit_cast(half2_t, u.w);
     }
@@ -206,28 +242,42 @@ __device__ __forceinline__ void vector_interval(uint4 (&pre)[2], const uint4* __
         W[0][pi] *= mLp; W[3][pi] *= mLp; W[6][pi] *= mLp;
         W[2][pi] *= mRp; W[5][pi] *= mRp; W[8][pi] *= mRp;
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        uint4 R[9];
+        if (t < 3) {                                 // next tile's rows go out before this tile's FMAs
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const char* base = va.tap[tap];
-            if (t == 0 && tap < 3) base = va.top[tap];
-            if (t == 3 && tap >= 6) base = va.bot[tap - 6];
-            R[tap] = *reinterpret_cast<const uint4*>(base + PARITY * TW_T1_BYTES + t * 16 * T1ROW * 2);
+            for (int i = 0; i < 3; ++i) {
+                nmid[i] = *reinterpret_cast<const uint4*>(va.tap[3 + i] + PARITY * TW_T1_BYTES + (t + 1) * TILE);
+                nbot[i] = *reinterpret_cast<const uint4*>((t == 2 ? va.bot[i] : va.tap[6 + i]) + PARITY * TW_T1_BYTES + (t + 1) * TILE);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        half2_t acc[4] = {W[9][0], W[9][1], W[9][2], W[9][3]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi)
+                acc[pi] = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, reinterpret_cast<const uint32_t*>(&top[i])[pi]), W[i][pi], acc[pi]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi)
+                acc[pi] = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, reinterpret_cast<const uint32_t*>(&mid[i])[pi]), W[3 + i][pi], acc[pi]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi)
+                acc[pi] = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, reinterpret_cast<const uint32_t*>(&bot[i])[pi]), W[6 + i][pi], acc[pi]);
         uint32_t o[4];
 #pragma unroll
-        for (int pi = 0; pi < 4; ++pi) {
-            half2_t acc = W[9][pi];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-                acc = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, reinterpret_cast<const uint32_t*>(&R[tap])[pi]), W[tap][pi], acc);
-            acc = __builtin_elementwise_max(acc, half2_t{0, 0});
-            o[pi] = __builtin_bit_cast(uint32_t, acc);
-        }
+        for (int pi = 0; pi < 4; ++pi) o[pi] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(acc[pi], half2_t{0, 0}));
         *reinterpret_cast<uint4*>(t2w + PARITY * (TW_T2_BYTES / 2) + t * 16 * T2ROW) = uint4{o[0], o[1], o[2], o[3]};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { top[i] = bot[i]; mid[i] = nmid[i]; bot[i] = nbot[i]; }
     }
+    vp.fetch_next();                                 // last: the compiler orders every later LDS access behind a pending LDS-DMA
 }
 
 // 5 x 5 depthwise (RISEv3.3 blocks 7, 11, 12, 13): same scheme, 25 neighbour reads and 100 packed FMAs per square tile.
@@ -241,14 +291,13 @@ struct VecAddr5 {
 };
 
 template <int PARITY>
-__device__ __forceinline__ void vector_interval5(uint4 (&pre)[2], const uint4* __restrict__& pp, char* prml, int lane, int lg, const VecAddr5& va,
-                                                 half_t* t2w, const half2_t (&mk)[5]) {
+__device__ __forceinline__ void vector_interval5(VParams& vp, int lg, const VecAddr5& va, half_t* t2w, const half2_t (&mk)[5]) {
     constexpr int T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
-    park_weights(pre, pp, prml, lane);
+    const char* prm = vp.open() + lg * TW_PRM_LG;
     half2_t W[26][4];
 #pragma unroll
     for (int e = 0; e < 26; ++e) {
-        const uint4 u = *reinterpret_cast<const uint4*>(prml + lg * TW_PRM_LG + e * 16);
+        const uint4 u = *reinterpret_cast<const uint4*>(prm + e * 16);
         W[e][0] = __builtin_bit_cast(half2_t, u.x); W[e][1] = __builtin_bit_cast(half2_t, u.y);
         W[e][2] = __builtin_bit_cast(half2_t, u.z); W[e][3] = __builtin_bit_cast(half2_t, u.w);
     }
@@ -284,41 +333,77 @@ __device__ __forceinline__ void vector_interval5(uint4 (&pre)[2], const uint4* _
         for (int pi = 0; pi < 4; ++pi) o[pi] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(acc[pi], half2_t{0, 0}));
         *reinterpret_cast<uint4*>(t2w + PARITY * (TW_T2_BYTES / 2) + t * 16 * T2ROW) = uint4{o[0], o[1], o[2], o[3]};
     }
+    vp.fetch_next();
 }
 
 // SE gate of a block (squeeze over the residual stream in LDS, excitation MLP, scale in place); executed by all 512 threads
 __device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_t* xs, const float* pool_sum, float* se_mean,
-                                     float* se_part, float* se_h, float* se_gate) {
+                                     float* se_part, float* se_h, float* se_gate, unsigned long long* trc, int& trn) {
     constexpr int XROW = TW_XROW;
     {
-        {   // squeeze: mean over the 64 squares of the residual stream as it sits in LDS
-            const int c = tid & 255, h0 = (tid >> 8) * 32;
-            float sum = 0.f;
-#pragma unroll 8
-            for (int sq = 0; sq < 32; ++sq) sum += float(xs[(h0 + sq) * XROW + c]);
-            se_part[tid] = sum;
+        // The gate weights do not depend on the data: a thread's first 32 dwords go out before the squeeze and fly while it runs,
+        // the second 32 as soon as the first are consumed (64 at once do not fit beside the matrix role's weight window).
+        // Host-packed in thread order (rise_net.hip: pack_se_threads): 8 coalesced 16-byte loads per thread and matrix.
+        half2_t wa[32], wb[32];
+        auto load_thread_weights = [&](const void* base, half2_t (&dst)[32]) {
+            const uint4* pk = reinterpret_cast<const uint4*>(base) + tid;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 u = pk[i * 512];
+                dst[4 * i + 0] = __builtin_bit_cast(half2_t, u.x); dst[4 * i + 1] = __builtin_bit_cast(half2_t, u.y);
+                dst[4 * i + 2] = __builtin_bit_cast(half2_t, u.z); dst[4 * i + 3] = __builtin_bit_cast(half2_t, u.w);
+            }
+        };
+        // ca_se: FC1 outputs 2*j2, 2*j2+1 over c in [kq*32, +32); eca_se: centre-tap matrix, inputs i in [kq*64, +32)
+        load_thread_weights(d.se_w1, wa);
+        {   // squeeze: mean over the 64 squares of the residual stream as it sits in LDS.  A wave owns 32 channels: lane =
+            // (4 groups of 8 channels) x (16 groups of 4 squares); 16-byte reads, then a 16-lane DPP row reduction.
+            const int lane = tid & 63, wv = tid >> 6, cg = lane >> 4, sg = lane & 15;
+            float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float xv[8];
+                load8<half_t>(xs + (sg * 4 + q) * XROW + wv * 32 + cg * 8, xv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum[j] += xv[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sum[j] += dpp_mov<0x111>(sum[j]);    // row_shr:1
+                sum[j] += dpp_mov<0x112>(sum[j]);    // row_shr:2
+                sum[j] += dpp_mov<0x114>(sum[j]);    // row_shr:4
+                sum[j] += dpp_mov<0x118>(sum[j]);    // row_shr:8 -> lane 15 of the row holds the row's sum
+            }
+            if (sg == 15) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) se_mean[wv * 32 + cg * 8 + j] = sum[j] * (1.f / 64.f);
+            }
         }
         __syncthreads();
-        if (tid < 256) se_mean[tid] = (se_part[tid] + se_part[256 + tid]) * (1.f / 64.f);
-        __syncthreads();
+#ifdef TW_TRACE_SE
+        if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
+#endif
         if (d.se_kind == 1) {        // ca_se: relu(W1 mean) -> W2 -> hard-sigmoid (builder_util.py:83-114)
             {
-                const half2_t* w1 = reinterpret_cast<const half2_t*>(d.se_w1);     // [c][128] halves
-                const int j2 = tid & 63, kq = tid >> 6;                           // outputs 2*j2, 2*j2+1; c in [kq*32, +32)
-                half2_t wv[32];
-#pragma unroll
-                for (int k = 0; k < 32; ++k) wv[k] = w1[(kq * 32 + k) * 64 + j2];
+                const int j2 = tid & 63, kq = tid >> 6;
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 32; ++k) {
                     const float m = se_mean[kq * 32 + k];
-                    s0 = fmaf(float(wv[k][0]), m, s0);
-                    s1 = fmaf(float(wv[k][1]), m, s1);
+                    s0 = fmaf(float(wa[k][0]), m, s0);
+                    s1 = fmaf(float(wa[k][1]), m, s1);
                 }
+                load_thread_weights(d.se_w2, wb);                                 // FC2: outputs 2*c2, 2*c2+1 over j in [kq2*32, +32)
                 se_part[kq * 128 + 2 * j2] = s0;
                 se_part[kq * 128 + 2 * j2 + 1] = s1;
             }
             __syncthreads();
+#ifdef TW_TRACE_SE
+            if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef TW_TRACE_SE
+        if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
+#endif
             if (tid < 128) {
                 float s = 0.f;
 #pragma unroll
@@ -326,47 +411,64 @@ __device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_
                 se_h[tid] = fmaxf(s, 0.f);
             }
             __syncthreads();
+#ifdef TW_TRACE_SE
+            if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef TW_TRACE_SE
+        if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
+#endif
             {
-                const half2_t* w2 = reinterpret_cast<const half2_t*>(d.se_w2);     // [j][256] halves
                 const int c2 = tid & 127, kq = tid >> 7;                          // outputs 2*c2, 2*c2+1; j in [kq*32, +32)
-                half2_t wv[32];
-#pragma unroll
-                for (int k = 0; k < 32; ++k) wv[k] = w2[(kq * 32 + k) * 128 + c2];
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 32; ++k) {
                     const float h = se_h[kq * 32 + k];
-                    s0 = fmaf(float(wv[k][0]), h, s0);
-                    s1 = fmaf(float(wv[k][1]), h, s1);
+                    s0 = fmaf(float(wb[k][0]), h, s0);
+                    s1 = fmaf(float(wb[k][1]), h, s1);
                 }
                 se_part[kq * 256 + 2 * c2] = s0;
                 se_part[kq * 256 + 2 * c2 + 1] = s1;
             }
             __syncthreads();
+#ifdef TW_TRACE_SE
+            if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef TW_TRACE_SE
+        if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
+#endif
             if (tid < 256) se_gate[tid] = hard_sigmoid(se_part[tid] + se_part[256 + tid] + se_part[512 + tid] + se_part[768 + tid]);
         } else {                     // eca_se: centre-tap linear + bias -> hard-sigmoid (builder_util.py:49-80)
-            const half2_t* wc = reinterpret_cast<const half2_t*>(d.se_w1);         // [i][256] halves
-            const int c2 = tid & 127, kq = tid >> 7;                              // i in [kq*64, +64)
+            const int c2 = tid & 127, kq = tid >> 7;
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                half2_t wv[32];
+            for (int k = 0; k < 32; ++k) {
+                const float m = se_mean[kq * 64 + k];
+                s0 = fmaf(float(wa[k][0]), m, s0);
+                s1 = fmaf(float(wa[k][1]), m, s1);
+            }
+            load_thread_weights(reinterpret_cast<const char*>(d.se_w1) + 8 * 512 * 16, wb);   // inputs i in [kq*64 + 32, +32)
 #pragma unroll
-                for (int k = 0; k < 32; ++k) wv[k] = wc[(kq * 64 + h * 32 + k) * 128 + c2];
-#pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    const float m = se_mean[kq * 64 + h * 32 + k];
-                    s0 = fmaf(float(wv[k][0]), m, s0);
-                    s1 = fmaf(float(wv[k][1]), m, s1);
-                }
+            for (int k = 0; k < 32; ++k) {
+                const float m = se_mean[kq * 64 + 32 + k];
+                s0 = fmaf(float(wb[k][0]), m, s0);
+                s1 = fmaf(float(wb[k][1]), m, s1);
             }
             se_part[kq * 256 + 2 * c2] = s0;
             se_part[kq * 256 + 2 * c2 + 1] = s1;
             __syncthreads();
+#ifdef TW_TRACE_SE
+            if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef TW_TRACE_SE
+        if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
+#endif
             if (tid < 256)
                 se_gate[tid] = hard_sigmoid(d.se_b[tid] + se_part[tid] + se_part[256 + tid] + se_part[512 + tid] + se_part[768 + tid]);
         }
         __syncthreads();
+#ifdef TW_TRACE_SE
+        if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
+#endif
         for (int i = tid; i < 64 * 32; i += 512) {     // x := x * gate (the residual uses the gated x, builder_util.py:473-475)
             const int r = i >> 5, v = i & 31;
             float xv[8], gv[8];
@@ -377,6 +479,9 @@ __device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_
             store8<half_t>(xs + r * XROW + v * 8, xv);
         }
         __syncthreads();
+#ifdef TW_TRACE_SE
+        if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
+#endif
     }
 
 }
@@ -388,13 +493,13 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
     using frag = half8;
     constexpr int C = TW_C, XROW = TW_XROW, T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) char prm_lds[TW_PRM_BYTES];
     half_t* xs = reinterpret_cast<half_t*>(smem);
     float* pool_sum = reinterpret_cast<float*>(smem + TW_POOL_OFF);
     float* se_mean = reinterpret_cast<float*>(smem + TW_SE_OFF);
     float* se_part = se_mean + 256;
     float* se_h = se_part + 1024;
     float* se_gate = se_h + 128;
-    float* b3s = reinterpret_cast<float*>(smem + TW_B3_OFF);
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4, l31 = lane & 31, lh = lane >> 5;
@@ -460,63 +565,81 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
         const int t2off = l31 * T2ROW + lh * 8;
         for (int blk = 0; blk < a.nblocks; ++blk) {
             const TowerBlockDesc& d = a.blocks[blk];
-            if (blk > 0 && d.se_kind != 0) se_phase(d, tid, xs, pool_sum, se_mean, se_part, se_h, se_gate);
+            if (blk > 0 && d.se_kind != 0) se_phase(d, tid, xs, pool_sum, se_mean, se_part, se_h, se_gate, trc, trn);
             TW_STAMP();
             const int n = d.cop_pad / TW_CK;
-            b3s[tid] = d.b3[tid];        // (matrix waves are threads 0..255) read back in the epilogue, many barriers later
+            // project accumulators start at the BN3 bias of their cout: row (v%4) + 8*(v/4) + 4*lh of tile rt
             f32x16 accP[2][2];           // [cout tile rt][square tile ct]: couts w*64 + rt*32 + row, squares ct*32 + lane%32
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(d.b3 + w * 64 + rt * 32 + g4 * 8 + lh * 4);
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) accP[rt][ct][v] = 0.f;
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) accP[rt][ct][g4 * 4 + j] = bs[j];
+                }
             for (int k = -1; k <= n; ++k) {
                 half_t* t1w = t1 + ((k + 1) & 1) * (TW_T1_BYTES / 2) + t1off;
                 const half_t* t2r = t2 + ((k - 1) & 1) * (TW_T2_BYTES / 2) + t2off;
+#ifndef TW_DEV_NO_MATRIX
                 matrix_interval(k + 1 < n, k >= 1, accP, win, sp, bp, xsr, t1w, t2r);
-                if (trc) {                           // development: time spent waiting at the interval barriers
+#endif
+#ifdef TW_TRACE_BARRIERS
+                if (trc) {                           // development: time spent waiting at the interval barriers (perturbs the loop)
                     const unsigned long long w0 = __builtin_amdgcn_s_memtime();
                     __syncthreads();
                     bwait += __builtin_amdgcn_s_memtime() - w0;
-                } else {
+                } else
+#endif
                     __syncthreads();
-                }
             }
             if (trc) { trc[trn++] = __builtin_amdgcn_s_memtime() - bwait; bwait = 0; }   // loop end stamp minus barrier waits = busy time
             TW_STAMP();
             // ---- block epilogue: y = x + BN3(project), new residual stream back to LDS ----
             // 4 consecutive couts per step: rows 8*g4 + 4*lh + 0..3 = accumulator elements 4*g4 + 0..3; the f16 residual is read
-            // straight out of its packed register by the mix-precision FMA, which also rounds the sum (once, RNE) into place
+            // straight out of its packed register by the mix-precision FMA, which also rounds the sum (once, RNE) into place.
+            // All residual reads of a cout tile go out before its first store (a store would order the later reads behind it).
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < 2; ++rt) {
+                uint2 rv[4][2];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        rv[g4][ct] = *reinterpret_cast<const uint2*>(xs + (ct * 32 + l31) * XROW + w * 64 + rt * 32 + g4 * 8 + lh * 4);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int co0 = w * 64 + rt * 32 + g4 * 8 + lh * 4;
-                    const f32x4 bs = *reinterpret_cast<const f32x4*>(b3s + co0);
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
                         half_t* px = xs + (ct * 32 + l31) * XROW + co0;
-                        const uint2 rv = *reinterpret_cast<const uint2*>(px);
-                        const float t0 = accP[rt][ct][g4 * 4 + 0] + bs[0], t1 = accP[rt][ct][g4 * 4 + 1] + bs[1];
-                        const float t2 = accP[rt][ct][g4 * 4 + 2] + bs[2], t3 = accP[rt][ct][g4 * 4 + 3] + bs[3];
+                        const float t0 = accP[rt][ct][g4 * 4 + 0], t1 = accP[rt][ct][g4 * 4 + 1];
+                        const float t2 = accP[rt][ct][g4 * 4 + 2], t3 = accP[rt][ct][g4 * 4 + 3];
                         uint2 o;
                         asm("v_fma_mixlo_f16 %0, %2, 1.0, %6 op_sel_hi:[0,0,1]\n\t"
                             "v_fma_mixhi_f16 %0, %3, 1.0, %6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
                             "v_fma_mixlo_f16 %1, %4, 1.0, %7 op_sel_hi:[0,0,1]\n\t"
                             "v_fma_mixhi_f16 %1, %5, 1.0, %7 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
                             : "=&v"(o.x), "=&v"(o.y)
-                            : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(rv.x), "v"(rv.y));
+                            : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(rv[g4][ct].x), "v"(rv[g4][ct].y));
                         *reinterpret_cast<uint2*>(px) = o;
                     }
                 }
+            }
             __syncthreads();
             TW_STAMP();
         }
     } else {
-        const uint4* pp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.pstream) + size_t(w) * a.pstream_wave_bytes) + lane * 2;
-        char* prml = smem + TW_PRM_OFF + w * 4 * TW_PRM_LG;
-        uint4 pre[2] = {pp[0], pp[1]};   // my 32 bytes of the NEXT chunk's 2 KiB weight block
+        VParams vp;
+        vp.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.pstream)) + size_t(w) * a.pstream_wave_bytes, 0, 0x7fffffff, 0x00020000);
+        vp.pos = 0;
+        vp.lane_off = lane * 16;
+        vp.buf = 0;
+        vp.lds = prm_lds + w * 2 * TW_PRM_BUF;
+        vp.fetch(0, 0);                  // the first chunk's weights
         const bool hi = l15 >= 8;        // second board row of a 16-square tile
         const half2_t one2 = {half_t(1.f), half_t(1.f)}, zero2 = {half_t(0.f), half_t(0.f)};
         const half2_t mLp = (l15 & 7) != 0 ? one2 : zero2, mRp = (l15 & 7) != 7 ? one2 : zero2;
@@ -581,32 +704,49 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
         TW_STAMP();
         for (int blk = 0; blk < a.nblocks; ++blk) {
             const TowerBlockDesc& d = a.blocks[blk];
-            if (blk > 0 && d.se_kind != 0) se_phase(d, tid, xs, pool_sum, se_mean, se_part, se_h, se_gate);
+            if (blk > 0 && d.se_kind != 0) se_phase(d, tid, xs, pool_sum, se_mean, se_part, se_h, se_gate, trc, trn);
             TW_STAMP();
             const int n = d.cop_pad / TW_CK;
+            // the NEXT block's SE-gate weights (128 KiB, read by every workgroup at the same moment) get the same treatment:
+            // each workgroup of an XCD touches 32 of the 1024 lines a whole block early (vector wave 1, one load)
+            if (w == 1 && lane < 32 && blk + 1 < a.nblocks && a.blocks[blk + 1].se_kind != 0) {
+                const TowerBlockDesc& dn = a.blocks[blk + 1];
+                const int line = pf_slot * 32 + lane;                                   // 0..1023
+                const char* base = dn.se_kind == 1 && line >= 512 ? reinterpret_cast<const char*>(dn.se_w2) - 512 * 128
+                                                                  : reinterpret_cast<const char*>(dn.se_w1);
+                pf_sink ^= *reinterpret_cast<const int*>(base + line * 128);
+            }
             for (int k = -1; k <= n; ++k) {
                 {
                     const int adv = (k + 1 < n ? 16 : 0) + (k >= 1 ? 16 : 0);
                     pf_sink ^= pf_old;                         // last interval's load is consumed a whole interval later
+#ifndef TW_DEV_NO_WARMUP
                     pf_old = adv != 0 ? prefetch(mpos + TW_AHEAD, adv) : 0;
+#endif
                     mpos += adv;
                 }
-                if (k >= 0 && k < n) {
+#ifndef TW_DEV_NO_VECTOR
+                if (k >= 0 && k < n)
+#else
+                if (false)
+#endif
+                {
                     if (d.ks == 5) {
-                        if (k & 1) vector_interval5<1>(pre, pp, prml, lane, lg, va5, t2w, mk5);
-                        else vector_interval5<0>(pre, pp, prml, lane, lg, va5, t2w, mk5);
+                        if (k & 1) vector_interval5<1>(vp, lg, va5, t2w, mk5);
+                        else vector_interval5<0>(vp, lg, va5, t2w, mk5);
                     } else {
-                        if (k & 1) vector_interval<1>(pre, pp, prml, lane, lg, va, t2w, mLp, mRp);
-                        else vector_interval<0>(pre, pp, prml, lane, lg, va, t2w, mLp, mRp);
+                        if (k & 1) vector_interval<1>(vp, lg, va, t2w, mLp, mRp);
+                        else vector_interval<0>(vp, lg, va, t2w, mLp, mRp);
                     }
                 }
+#ifdef TW_TRACE_BARRIERS
                 if (trc) {
                     const unsigned long long w0 = __builtin_amdgcn_s_memtime();
                     __syncthreads();
                     bwait += __builtin_amdgcn_s_memtime() - w0;
-                } else {
+                } else
+#endif
                     __syncthreads();
-                }
             }
             if (trc) { trc[trn++] = __builtin_amdgcn_s_memtime() - bwait; bwait = 0; }
             TW_STAMP();
@@ -633,11 +773,11 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
 }
 
 void init_tower_kernel_attributes() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TW_DYN_LDS_BYTES);
 }
 
 void launch_tower(const TowerArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(tower_kernel, dim3(a.batch), dim3(512), TW_LDS_BYTES, s, a);
+    hipLaunchKernelGGL(tower_kernel, dim3(a.batch), dim3(512), TW_DYN_LDS_BYTES, s, a);
 }
 
 }  // namespace cra

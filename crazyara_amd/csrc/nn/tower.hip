@@ -217,6 +217,18 @@ struct VParams {
     }
 };
 
+// development switches (timing only): TW_DEV_VEC_NO_LDS replaces the neighbour reads by a register constant, TW_DEV_VEC_NO_VALU
+// keeps the reads and skips the FMAs
+__device__ __forceinline__ uint4 vec_row_read(const char* p) {
+#ifdef TW_DEV_VEC_NO_LDS
+    uint4 r;
+    asm volatile("v_mov_b32 %0, 0x3c003c00\n\tv_mov_b32 %1, 0x3c003c00\n\tv_mov_b32 %2, 0x3c003c00\n\tv_mov_b32 %3, 0x3c003c00" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w));
+    return r;
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+
 template <int PARITY>
 __device__ __forceinline__ void vector_interval(VParams& vp, int lg, const VecAddr& va, half_t* t2w, half2_t mLp, half2_t mRp) {
     constexpr int T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
@@ -226,9 +238,9 @@ __device__ __forceinline__ void vector_interval(VParams& vp, int lg, const VecAd
     uint4 top[3], mid[3], bot[3], nmid[3], nbot[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        top[i] = *reinterpret_cast<const uint4*>(va.top[i] + PARITY * TW_T1_BYTES);
-        mid[i] = *reinterpret_cast<const uint4*>(va.tap[3 + i] + PARITY * TW_T1_BYTES);
-        bot[i] = *reinterpret_cast<const uint4*>(va.tap[6 + i] + PARITY * TW_T1_BYTES);
+        top[i] = vec_row_read(va.top[i] + PARITY * TW_T1_BYTES);
+        mid[i] = vec_row_read(va.tap[3 + i] + PARITY * TW_T1_BYTES);
+        bot[i] = vec_row_read(va.tap[6 + i] + PARITY * TW_T1_BYTES);
     }
     half2_t W[10][4];
 #pragma unroll
@@ -248,12 +260,16 @@ __device__ __forceinline__ void vector_interval(VParams& vp, int lg, const VecAd
         if (t < 3) {                                 // next tile's rows go out before this tile's FMAs
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                nmid[i] = *reinterpret_cast<const uint4*>(va.tap[3 + i] + PARITY * TW_T1_BYTES + (t + 1) * TILE);
-                nbot[i] = *reinterpret_cast<const uint4*>((t == 2 ? va.bot[i] : va.tap[6 + i]) + PARITY * TW_T1_BYTES + (t + 1) * TILE);
+                nmid[i] = vec_row_read(va.tap[3 + i] + PARITY * TW_T1_BYTES + (t + 1) * TILE);
+                nbot[i] = vec_row_read((t == 2 ? va.bot[i] : va.tap[6 + i]) + PARITY * TW_T1_BYTES + (t + 1) * TILE);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         half2_t acc[4] = {W[9][0], W[9][1], W[9][2], W[9][3]};
+#ifdef TW_DEV_VEC_NO_VALU
+#pragma unroll
+        for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(top[i]), "v"(mid[i]), "v"(bot[i]));
+#else
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -269,6 +285,7 @@ __device__ __forceinline__ void vector_interval(VParams& vp, int lg, const VecAd
 #pragma unroll
             for (int pi = 0; pi < 4; ++pi)
                 acc[pi] = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, reinterpret_cast<const uint32_t*>(&bot[i])[pi]), W[6 + i][pi], acc[pi]);
+#endif
         uint32_t o[4];
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) o[pi] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(acc[pi], half2_t{0, 0}));
@@ -547,6 +564,9 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
     //   matrix: E(k+1) -> t1[(k+1)&1], then P(k-1) <- t2[(k-1)&1]        vector: D(k): t1[k&1] -> t2[k&1]
     // C_op is padded to whole chunks of 128 (zero weights), so every chunk is full.
     if (is_matrix) {
+#ifdef TW_DEV_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         // open the weight stream first: its window flies while the board tile comes in
         WStream sp;
         sp.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.wstream)) + size_t(w) * a.wstream_wave_frags * 1024, 0, 0x7fffffff, 0x00020000);

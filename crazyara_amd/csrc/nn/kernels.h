@@ -31,7 +31,7 @@ struct ConvArgs {
     int cout_real;
     int cout_ld;          // row pitch of `out` in elements (NHWC mode)
     int ks;               // 1 or 3
-    int relu;
+    int relu;             // 0 none, 1 after the residual add, 2 before it (ClassicalResidualBlock)
     int out_policy_f32;   // 1: write float logits channel-major
     int out_flat;         // 1: write T channel-major flat, out[b*flat_pitch + co*64 + sq] (the value head's .view(-1, nb_flatten))
     int flat_pitch;

@@ -91,13 +91,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[t][r] + bs[r];
+        if (a.relu == 2) {                           // activation is the body's last module, the shortcut is added after it
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
         if (a.resid) {
             float rv[4];
             load4<T>(reinterpret_cast<const T*>(a.resid) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, rv);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += rv[r];
         }
-        if (a.relu) {
+        if (a.relu == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }

@@ -187,6 +187,14 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     const bool wdl = nf.num("use_wdl") != 0 && nf.num("use_plys_to_end") != 0;
     std::vector<std::string> kernels = nf.list("kernels"), se_types = nf.list("se_types");
     if (kernels.empty() || kernels.size() != se_types.size()) throw std::runtime_error("kernels/se_types mismatch in model file");
+    // residual block family: RiseV3's mobile bottleneck (default), ClassicalResidualBlock (builder_util.py:401-434) or
+    // AlphaZeroResnet's ResidualBlock (a0_resnet.py:72-107); the last two are towers of dense 3x3 convolutions
+    const std::string conv_block = nf.str("conv_block", "mobile_bottlekneck_res_block");
+    const bool dense_blocks = conv_block == "classical_res_block" || conv_block == "a0_res_block";
+    if (!dense_blocks && conv_block != "mobile_bottlekneck_res_block") throw std::runtime_error("unsupported conv_block '" + conv_block + "'");
+    if (dense_blocks)
+        for (const std::string& t : se_types)
+            if (t != "none") throw std::runtime_error("SE inside dense residual blocks is not supported");
     if (C % 64 != 0 || C > 512) throw std::runtime_error("channels must be a multiple of 64 and <= 512");
     if (fc > 256 && fc % 256 != 0) throw std::runtime_error("unsupported value_fc_size");
 
@@ -225,7 +233,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
 
     double macs = 0;
     auto add_conv = [&](const std::string& conv, const std::string& bn, const T* x, T* out, const T* resid, int ci, int ci_pad,
-                        int co, int k, bool relu, float* out_policy) {
+                        int co, int k, int relu, float* out_policy) {
         Folded fd = fold_bn(nf, conv, bn);
         const int co_pad = round_up(co, 16);
         Op op;
@@ -375,7 +383,18 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 }
         return out;
     };
-    for (size_t i = 0; i < cops.size(); ++i) {
+    for (size_t i = 0; dense_blocks && i < cops.size(); ++i) {
+        // x -> conv3x3 + BN + ReLU -> conv3x3 + BN -> classical: x + ReLU(.)   a0: ReLU(x + .)
+        const std::string p = "body_spatial." + std::to_string(i + 1);
+        add_conv(p + ".body.0", p + ".body.1", cur, nxt, nullptr, C, C, C, 3, 1, nullptr);
+        T* out = e;                                   // e: scratch of at least C channels per square
+        add_conv(p + ".body.3", p + ".body.4", nxt, out, cur, C, C, C, 3, conv_block == "classical_res_block" ? 2 : 1, nullptr);
+        // keep (cur, nxt) = (block output, scratch): rotate the three buffers
+        T* old = cur;
+        cur = out;
+        e = old;
+    }
+    for (size_t i = 0; !dense_blocks && i < cops.size(); ++i) {
         const std::string p = "body_spatial." + std::to_string(i + 1);
         const int cop = cops[i], k = ks[i];
         const bool in_tower = tower_ok && (k == 3 || k == 5);

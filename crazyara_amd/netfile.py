@@ -77,10 +77,13 @@ def export_rise(path: str, cfg, state_dict, input_version: str = "1.0", variant:
         kernels=list(cfg.kernels), se_types=list(cfg.se_types),
         channels_value_head=cfg.channels_value_head, value_fc_size=cfg.value_fc_size,
         channels_policy_head=cfg.channels_policy_head, use_wdl=int(cfg.use_wdl), use_plys_to_end=int(cfg.use_plys_to_end),
+        conv_block=getattr(cfg, "conv_block", "mobile_bottlekneck_res_block"),
     )
     tensors = {}
     for k, v in state_dict.items():
         if k.endswith("num_batches_tracked"):
             continue
+        if k.startswith("body."):      # AlphaZeroResnet keeps stem + blocks in `body` (a0_resnet.py:142-144): one naming in the file
+            k = "body_spatial." + k[len("body."):]
         tensors[k] = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
     return write_cranet(path, meta, tensors)

@@ -29,6 +29,20 @@ class RiseConfig:
     use_wdl: bool = False
     use_plys_to_end: bool = False
     name: str = "risev2"
+    # residual block family:
+    #   "mobile_bottlekneck_res_block"  RiseV3 default: 1x1 expand, depthwise kxk, 1x1 project (builder_util.py:437-475)
+    #   "classical_res_block"           RiseV3(conv_block=...): x + ReLU(BN(conv3x3(ReLU(BN(conv3x3(x))))))  (builder_util.py:401-434)
+    #   "a0_res_block"                  AlphaZeroResnet: ReLU(x + BN(conv3x3(ReLU(BN(conv3x3(x))))))          (a0_resnet.py:72-183)
+    conv_block: str = "mobile_bottlekneck_res_block"
+
+    @property
+    def dense_blocks(self) -> bool:
+        return self.conv_block in ("classical_res_block", "a0_res_block")
+
+    @property
+    def key_prefix(self) -> str:
+        """state-dict prefix of stem + blocks: RiseV3.body_spatial, AlphaZeroResnet.body"""
+        return "body" if self.conv_block == "a0_res_block" else "body_spatial"
 
     def channels_operating(self) -> List[int]:
         """C_op per block, rise_mobile_v3.py:36-78 (kernel_5_channel_ratio=None branch)."""
@@ -73,6 +87,21 @@ def rise_v33_config(nb_input_channels: int = 52, channels_policy_head: int = 76,
                       channel_expansion=32, kernels=kernels, se_types=se,
                       channels_policy_head=channels_policy_head, use_wdl=wdlp, use_plys_to_end=wdlp,
                       name="risev3.3" + ("-wdlp" if wdlp else ""))
+
+
+def rise_classical_config(n_blocks: int = 19, nb_input_channels: int = 34, channels_policy_head: int = 81) -> RiseConfig:
+    """RiseV3(conv_block="classical_res_block"): a tower of dense 3x3 residual blocks (rise_mobile_v3.py:71-72)."""
+    return RiseConfig(nb_input_channels=nb_input_channels, channels=256, channels_operating_init=256, channel_expansion=0,
+                      kernels=[3] * n_blocks, se_types=[None] * n_blocks, channels_policy_head=channels_policy_head,
+                      conv_block="classical_res_block", name=f"rise-classical-{n_blocks}")
+
+
+def alpha_zero_config(n_blocks: int = 19, nb_input_channels: int = 34, channels_policy_head: int = 81,
+                      channels_value_head: int = 4) -> RiseConfig:
+    """AlphaZeroResnet as get_alpha_zero_model builds it (a0_resnet.py:172-183): 19 blocks, value head 4 channels."""
+    return RiseConfig(nb_input_channels=nb_input_channels, channels=256, channels_operating_init=256, channel_expansion=0,
+                      kernels=[3] * n_blocks, se_types=[None] * n_blocks, channels_value_head=channels_value_head,
+                      channels_policy_head=channels_policy_head, conv_block="a0_res_block", name=f"alphazero-{n_blocks}")
 
 
 def eca_kernel(channels: int, gamma: int = 2, b: int = 1) -> int:
@@ -130,11 +159,20 @@ def make_state_dict(cfg: RiseConfig, seed: int = 0, stress: bool = True) -> Dict
             sd[name + ".bias"] = torch.tensor(b, dtype=torch.float32)
 
     C = cfg.channels
-    conv("body_spatial.0.body.0", C, cfg.nb_input_channels, 3, gain=2.0)
-    bn("body_spatial.0.body.1", C)
+    pre = cfg.key_prefix
+    conv(pre + ".0.body.0", C, cfg.nb_input_channels, 3, gain=2.0)
+    bn(pre + ".0.body.1", C)
     nblk = len(cfg.kernels)
     for i, (k, cop, se) in enumerate(zip(cfg.kernels, cfg.channels_operating(), cfg.se_types)):
-        p = f"body_spatial.{i + 1}"
+        p = f"{pre}.{i + 1}"
+        if cfg.dense_blocks:
+            if se is not None:
+                raise ValueError("SE inside dense residual blocks is not supported")
+            conv(p + ".body.0", C, C, 3)
+            bn(p + ".body.1", C)
+            conv(p + ".body.3", C, C, 3)
+            bn(p + ".body.4", C, out_scale=(0.5 / math.sqrt(nblk)) if stress else 1.0)
+            continue
         if se in ("ca_se", "se"):
             linear(p + ".se.fc.0", C // 2, C, bias=False)
             linear(p + ".se.fc.2", C, C // 2, bias=False, gain=2.0)
@@ -152,7 +190,7 @@ def make_state_dict(cfg: RiseConfig, seed: int = 0, stress: bool = True) -> Dict
         bn(p + ".body.7", C, out_scale=(1.0 / math.sqrt(nblk)) if stress else 1.0)
     conv("policy_head.body.0", C, C, 3)
     bn("policy_head.body.1", C)
-    conv("policy_head.body.3", cfg.channels_policy_head, C, 3, gain=1.0)
+    conv("policy_head.body.3", cfg.channels_policy_head, C, 3, gain=0.35 if cfg.dense_blocks else 1.0)   # logits O(1) either way
     conv("value_head.body.0", cfg.channels_value_head, C, 1)
     bn("value_head.body.1", cfg.channels_value_head)
     nflat = 64 * cfg.channels_value_head

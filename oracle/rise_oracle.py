@@ -16,6 +16,8 @@ Follows (reference file:line, relative to /root/reference):
   * _ValueHead ........................... builder_util.py:246-326 (tanh head; WDL variant value=-softmax(wdl)[0]+softmax(wdl)[2])
   * process_value_policy_head ............ builder_util.py:385-398 (aux = cat(wdl, plys))
   * softmax contract of predict() ........ engine/src/nn/tensorrtapi.cpp:378-392, engine/src/nn/neuralnetapi.cpp:241-260
+  * ClassicalResidualBlock ............... builder_util.py:401-434 (second activation INSIDE the body, plain add)
+  * AlphaZeroResnet / ResidualBlock ...... pytorch/a0_resnet.py:72-183 (activation AFTER the add; state-dict prefix "body.")
 
 Pinning: `oracle/make_golden.py` (run in the build container where /root/reference exists) loads the SAME
 state dicts into the imported reference model and stores (input, value, policy logits, aux) under tests/golden/;
@@ -33,8 +35,8 @@ import torch.nn.functional as F
 BN_EPS = 1e-5  # torch.nn.BatchNorm2d default (reference never overrides it)
 
 
-from crazyara_amd.rise_config import (RiseConfig, rise_v2_config, rise_v33_config, eca_kernel,  # noqa: F401,E402
-                                      make_state_dict)
+from crazyara_amd.rise_config import (RiseConfig, rise_v2_config, rise_v33_config, rise_classical_config,  # noqa: F401,E402
+                                      alpha_zero_config, eca_kernel, make_state_dict)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -55,12 +57,23 @@ def forward(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, sim_d
     """Returns (value[B,1], policy_logits[B,P*64], aux[B,4] or None).  x: [B,C,8,8] fp32."""
     W = (lambda n: sd[n]) if sim_dtype is None else (lambda n: sd[n].to(sim_dtype).to(torch.float32))
     x = x.to(torch.float32)
-    h = F.relu(_bn(sd, "body_spatial.0.body.1", F.conv2d(_q(x, sim_dtype), W("body_spatial.0.body.0.weight"), padding=1)))
+    pre = cfg.key_prefix
+    h = F.relu(_bn(sd, pre + ".0.body.1", F.conv2d(_q(x, sim_dtype), W(pre + ".0.body.0.weight"), padding=1)))
     h = _q(h, sim_dtype)
     if taps is not None:
         taps["stem"] = h
     for i, (k, se) in enumerate(zip(cfg.kernels, cfg.se_types)):
-        p = f"body_spatial.{i + 1}"
+        p = f"{pre}.{i + 1}"
+        if cfg.dense_blocks:
+            t = _q(F.relu(_bn(sd, p + ".body.1", F.conv2d(h, W(p + ".body.0.weight"), padding=1))), sim_dtype)
+            t = _bn(sd, p + ".body.4", F.conv2d(t, W(p + ".body.3.weight"), padding=1))
+            if cfg.conv_block == "classical_res_block":
+                h = _q(h + F.relu(t), sim_dtype)         # builder_util.py:413-418,434: act is the body's last module
+            else:
+                h = _q(F.relu(h + t), sim_dtype)         # a0_resnet.py:104-107: final_act(x + out)
+            if taps is not None:
+                taps[f"block{i}"] = h
+            continue
         if se in ("ca_se", "se"):
             y = h.mean(dim=(2, 3))
             y = F.relu(F.linear(y, sd[p + ".se.fc.0.weight"]))
@@ -109,6 +122,9 @@ def flops_per_position(cfg: RiseConfig) -> float:
     C = cfg.channels
     macs = 64 * cfg.nb_input_channels * C * 9
     for k, cop, se in zip(cfg.kernels, cfg.channels_operating(), cfg.se_types):
+        if cfg.dense_blocks:
+            macs += 2 * 64 * C * C * 9
+            continue
         macs += 64 * C * cop * 2 + 64 * cop * k * k
         if se in ("ca_se", "se"):
             macs += 2 * C * (C // 2)

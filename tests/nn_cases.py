@@ -32,6 +32,10 @@ CASES = {
     "risev33": (lambda: ro.rise_v33_config(52, 76, False), 16, True, 4),        # BASELINE config 3
     "risev33-wdlp": (lambda: ro.rise_v33_config(52, 76, True), 17, True, 4),    # released ClassicAra head
     "risev2-13-lichess": (lambda: ro.rise_v2_config(13, 80, 84), 18, True, 2),  # MultiAra tables (config 5)
+    # dense 3x3 siblings of the same zoo
+    "rise-classical-4": (lambda: ro.rise_classical_config(4, 34, 81), 19, True, 4),
+    "alphazero-5": (lambda: ro.alpha_zero_config(5, 52, 76, 4), 20, True, 4),
+    "alphazero-3-cv8": (lambda: ro.alpha_zero_config(3, 34, 81, 8), 21, True, 3),
 }
 
 

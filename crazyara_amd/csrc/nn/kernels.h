@@ -153,6 +153,25 @@ void launch_head(const HeadArgs& a, hipStream_t s);
 void init_head_kernel_attributes();
 size_t head_lds_bytes();
 
+// Dense residual tower in one launch, one workgroup per board (restower.hip).  f16, C = 256.
+//   wstream  8 waves x per block { conv 1: [9 taps][16 k-steps] A fragments (rows = couts 32*wave + row, K = input channel),
+//            conv 2: the same with K position -> conv-1 channel (kpos/32)*32 + tower_row_of_position(kpos%32) }, then 16 zero fragments
+//   bstream  8 waves x per block { conv 1 BN bias [lane/32][16], conv 2 BN bias [lane/32][16] } in accumulator row order
+struct ResTowerArgs {
+    const void* x;            // [B][64][256] f16
+    void* y;
+    const void* wstream;
+    const float* bstream;
+    long long wstream_wave_frags;
+    long long bstream_wave_floats;
+    int nblocks;
+    int relu_after_add;       // 1: ReLU(x + body(x)) (AlphaZero ResidualBlock), 0: x + ReLU(body(x)) (ClassicalResidualBlock)
+    int batch;
+};
+void launch_restower(const ResTowerArgs& a, hipStream_t s);
+void init_restower_kernel_attributes();
+size_t restower_lds_bytes();
+
 // depthwise k x k (k = 3 or 5) + folded BN + ReLU.  w: [k*k][C] float, bias: [C] float
 template <typename T> void launch_depthwise(const T* x, T* y, const float* w, const float* bias, int batch, int C, int ks,
                                             hipStream_t s);

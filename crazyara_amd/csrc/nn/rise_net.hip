@@ -73,7 +73,7 @@ std::vector<T> pack_dense(const Folded& f, int cout, int cin, int ks, int cout_p
     return out;
 }
 
-enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem };
+enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower };
 
 struct Op {
     OpKind kind;
@@ -88,6 +88,7 @@ struct Op {
     ValueFinalArgs vf{};
     TowerArgs tw{};
     HeadArgs hd{};
+    ResTowerArgs rt{};
     StemArgs st{};
 };
 }  // namespace
@@ -383,7 +384,48 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 }
         return out;
     };
-    for (size_t i = 0; dense_blocks && i < cops.size(); ++i) {
+    if (dense_blocks && tower_ok) {
+        // all blocks in one launch (restower.hip; stream layouts in kernels.h: ResTowerArgs)
+        if constexpr (kHalf) {
+            std::vector<half_t> ws;
+            std::vector<float> bs;
+            for (int wv = 0; wv < 8; ++wv) {
+                for (size_t i = 0; i < cops.size(); ++i) {
+                    const std::string p = "body_spatial." + std::to_string(i + 1);
+                    Folded f1 = fold_bn(nf, p + ".body.0", p + ".body.1"), f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
+                    for (int cv2 = 0; cv2 < 2; ++cv2) {
+                        const Folded& fd = cv2 ? f2 : f1;
+                        for (int tap = 0; tap < 9; ++tap)
+                            for (int ksx = 0; ksx < 16; ++ksx)
+                                for (int l = 0; l < 64; ++l)
+                                    for (int j = 0; j < 8; ++j) {
+                                        const int co = wv * 32 + (l & 31), kpos = ksx * 16 + (l >> 5) * 8 + j;
+                                        const int ci = cv2 ? (kpos / 32) * 32 + tower_row_of_position(kpos % 32) : kpos;
+                                        ws.push_back(half_t(float(fd.w[(size_t(co) * C + ci) * 9 + tap])));
+                                    }
+                        for (int lh = 0; lh < 2; ++lh)
+                            for (int v = 0; v < 16; ++v) bs.push_back(float(fd.b[wv * 32 + (v % 4) + 8 * (v / 4) + 4 * lh]));
+                    }
+                }
+                ws.insert(ws.end(), size_t(16) * 512, half_t(0.f));
+            }
+            Op op;
+            op.kind = OpKind::ResTower;
+            op.rt.x = cur;
+            op.rt.y = nxt;
+            op.rt.wstream = im.upload(ws);
+            op.rt.bstream = im.upload(bs);
+            op.rt.wstream_wave_frags = (long long)(cops.size() * 2 * 9 * 16 + 16);
+            op.rt.bstream_wave_floats = (long long)(cops.size() * 64);
+            op.rt.nblocks = int(cops.size());
+            op.rt.relu_after_add = conv_block == "a0_res_block" ? 1 : 0;
+            op.rt.batch = B;
+            im.ops.push_back(op);
+            macs += double(cops.size()) * 2.0 * kSquares * C * C * 9;
+            std::swap(cur, nxt);
+        }
+    }
+    for (size_t i = 0; dense_blocks && !tower_ok && i < cops.size(); ++i) {
         // x -> conv3x3 + BN + ReLU -> conv3x3 + BN -> classical: x + ReLU(.)   a0: ReLU(x + .)
         const std::string p = "body_spatial." + std::to_string(i + 1);
         add_conv(p + ".body.0", p + ".body.1", cur, nxt, nullptr, C, C, C, 3, 1, nullptr);
@@ -782,6 +824,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     }   // !head_ok
     init_block_kernel_attributes<T>();
     init_tower_kernel_attributes();
+    init_restower_kernel_attributes();
     init_head_kernel_attributes();
     design_.flops_per_position = 2.0 * macs;
     launches_ = int(im.ops.size());
@@ -806,6 +849,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s) {
         case OpKind::ValueFinal: launch_value_final<T>(op.vf, s); break;
         case OpKind::Tower: launch_tower(op.tw, s); break;
         case OpKind::Head: launch_head(op.hd, s); break;
+        case OpKind::ResTower: launch_restower(op.rt, s); break;
         case OpKind::Stem: launch_stem(op.st, s); break;
         case OpKind::SEGate:
             launch_se_gate(static_cast<const float*>(op.x), static_cast<float*>(op.y), op.se_kind, op.w0, op.w1, op.b0, B, op.C, s);
@@ -832,6 +876,7 @@ const char* RiseNet::op_name(int i) const {
         case OpKind::SEGate: return "se_gate";
         case OpKind::Tower: return "tower";
         case OpKind::Head: return "head";
+        case OpKind::ResTower: return "restower";
         case OpKind::Stem: return "stem";
     }
     return "?";

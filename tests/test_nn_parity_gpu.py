@@ -62,13 +62,15 @@ def test_predict_matches_oracle_and_golden(tmp_path, hip_lib, name, precision):
         assert np.abs(aux.reshape(-1, 4) - o_aux.numpy()).max() < tol["aux"]
 
 
+@pytest.mark.parametrize("case", ["risev2-7", "alphazero-3-cv8"])
 @pytest.mark.parametrize("batch", [1, 3, 300])
-def test_tower_and_head_kernels_any_batch_size(tmp_path, hip_lib, batch):
-    """One workgroup per board: batch sizes below / not a multiple of / above the 256 CUs must all be exact per row."""
+def test_tower_and_head_kernels_any_batch_size(tmp_path, hip_lib, batch, case):
+    """One workgroup per board: batch sizes below / not a multiple of / above the 256 CUs must all be exact per row
+    (bottleneck tower and dense residual tower)."""
     from crazyara_amd.neuralnetapi import HipAPI
-    cfg, sd, _ = nn_cases.make_case("risev2-7")
+    cfg, sd, _ = nn_cases.make_case(case)
     x = nn_cases.synthetic_planes(batch, cfg.nb_input_channels, 4242)
-    d = nn_cases.export_case(tmp_path, "risev2-7", cfg, sd)
+    d = nn_cases.export_case(tmp_path, case, cfg, sd)
     net = HipAPI(0, batch, d, "float16")
     v, p = np.zeros(batch, np.float32), np.zeros(batch * cfg.nb_policy, np.float32)
     net.predict(np.ascontiguousarray(x.numpy()), v, p)

@@ -35,6 +35,8 @@ SearchSettings convert(const mi_search_settings& m) {
     s.epsilon_checks_counter = m.epsilon_checks_counter;
     s.seed = m.seed;
     s.mcts_solver = m.mcts_solver != 0;
+    s.dirichlet_epsilon = m.dirichlet_epsilon;
+    s.dirichlet_alpha = m.dirichlet_alpha;
     return s;
 }
 }  // namespace
@@ -61,6 +63,8 @@ void mi_search_default_settings(mi_search_settings* m) {
     m->epsilon_checks_counter = s.epsilon_checks_counter;
     m->seed = s.seed;
     m->mcts_solver = s.mcts_solver ? 1 : 0;
+    m->dirichlet_epsilon = s.dirichlet_epsilon;
+    m->dirichlet_alpha = s.dirichlet_alpha;
 }
 
 mi_search* mi_search_create(const mi_search_settings* s, mi_net* net_a, mi_net* net_b, mi_eval_fn fn, void* user, int fn_batch, int fn_nb_policy) {

@@ -30,6 +30,7 @@ VirtualStyle get_virtual_style(const SearchSettings& s, uint32_t visits) {
 Tree::Tree(const Position& root, const SearchSettings& settings) : s_(settings), root_pos_(root) {
     if (s_.epsilon_greedy_counter < 0 || s_.epsilon_checks_counter < 0) throw std::invalid_argument("epsilon counters must be >= 0");
     rng_ = s_.seed;
+    noise_rng_.seed(s_.seed);
     tables_ = &chess::policy_tables(s_.mode);
     layout_ = layout_for(s_.mode, s_.version_major);
     keep_last_moves_ = s_.clone_keeps_last_moves < 0 ? s_.mode != MODE_CRAZYHOUSE : s_.clone_keeps_last_moves != 0;
@@ -89,6 +90,28 @@ void Tree::fill_nn_result(Node& n, float value, const float* probs) {
 void Tree::set_root_result(float value, const float* probs) {
     fill_nn_result(nodes_[0], value, probs);
     prepare_node_for_visits(nodes_[0]);                                                   // mctsagent.cpp:195
+}
+
+// apply_dirichlet_noise_to_prior_policy (node.cpp:950-954) with get_dirichlet_noise (blazeutil.h:113-124: one fresh
+// std::gamma_distribution<float>(alpha, 1) per entry, normalised by the float sum), then fully_expand_node (node.cpp:582-593):
+// every child gets its NodeData slot and the current order is kept (the noised priors are no longer sorted).
+void Tree::begin_search() {
+    Node& n = nodes_[0];
+    if (!(s_.dirichlet_epsilon > 0.009f) || n.terminal || !n.has_nn || n.actions.empty()) return;
+    std::vector<float> noise(n.actions.size());
+    float sum = 0.0f;
+    for (float& v : noise) {
+        std::gamma_distribution<float> distribution(s_.dirichlet_alpha, 1.0f);
+        v = distribution(noise_rng_);
+        sum += v;
+    }
+    const float keep = 1 - s_.dirichlet_epsilon;
+    for (size_t i = 0; i < noise.size(); ++i) {
+        const float a = keep * n.priors[i], b = s_.dirichlet_epsilon * (noise[i] / sum);
+        n.priors[i] = a + b;
+    }
+    if (!n.sorted) prepare_node_for_visits(n);
+    while (size_t(n.no_visit_idx) < n.actions.size()) increment_no_visit_idx(n);
 }
 
 // sort_moves_by_probabilities + init_node_data (node.cpp:464-470, 634-643, nodedata.cpp:40-57).

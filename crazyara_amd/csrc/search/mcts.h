@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdint>
 #include <memory>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,12 @@ struct SearchSettings {
     // Search_Type "mcgs" needs no switch here: in the reference the transposition link of add_new_node_to_tree is
     // unreachable (node.cpp:730-731 reads the candidate from the still-empty child slot), so mcgs and mcts search the same tree.
     bool mcts_solver = true;
+    // Dirichlet noise on the root priors (mctsagent.cpp:311-316, node.cpp:950-954, blazeutil.h:113-124): applied at the start of
+    // every search when epsilon > 0.009, followed by fully_expand_node.  UCI defaults: Centi_Dirichlet_Epsilon 0 (25 in RL builds),
+    // Centi_Dirichlet_Alpha 20 (optionsuci.cpp:84-88).  The reference draws from a std::default_random_engine seeded by
+    // std::random_device; here each tree owns one seeded with `seed` + tree index.
+    float dirichlet_epsilon = 0.0f;
+    float dirichlet_alpha = 0.2f;
 };
 
 struct Node {
@@ -100,6 +107,8 @@ public:
     bool root_needs_eval() const { return !nodes_[0].has_nn && !nodes_[0].terminal; }
     void root_desc(BoardDesc& d) const;
     void set_root_result(float value, const float* probs);
+    // start of a `go` (MCTSAgent::evaluate_board_state, mctsagent.cpp:311-316): Dirichlet noise + full expansion of the root
+    void begin_search();
 
     // --- SearchThread::create_mini_batch (searchthread.cpp:347-380) with `quota` in the role of batchSize ---
     // Writes one BoardDesc per NEW leaf to descs[0..returned).  Terminals are backed up immediately, collisions are
@@ -153,6 +162,7 @@ private:
     std::vector<Trajectory> new_trajectories_, collision_trajectories_;
     Trajectory trajectory_buffer_;
     uint32_t rng_ = 1;
+    std::minstd_rand0 noise_rng_;              // std::default_random_engine of libstdc++ (randomgen.h:35)
 };
 
 }  // namespace search

@@ -195,6 +195,7 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         st.batches += (before + lane.eval->batch_size() - 1) / lane.eval->batch_size();
     }
     for (size_t i = 0; i < trees_.size(); ++i) {
+        trees_[i]->begin_search();                                  // Dirichlet noise + full expansion of the root (RL settings)
         nodes_pre[i] = trees_[i]->node_count();
         visits_pre[i] = trees_[i]->root_visits();
     }

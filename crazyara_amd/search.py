@@ -14,7 +14,8 @@ class SearchSettingsC(C.Structure):
                 ("node_policy_temperature", C.c_float), ("virtual_style", C.c_int), ("virtual_mix_threshold", C.c_uint),
                 ("virtual_offset_strength", C.c_double), ("q_value_weight", C.c_float), ("q_veto_delta", C.c_float),
                 ("mode", C.c_int), ("version_major", C.c_int), ("is_policy_map", C.c_int), ("clone_keeps_last_moves", C.c_int),
-                ("epsilon_greedy_counter", C.c_int), ("epsilon_checks_counter", C.c_int), ("seed", C.c_uint), ("mcts_solver", C.c_int)]
+                ("epsilon_greedy_counter", C.c_int), ("epsilon_checks_counter", C.c_int), ("seed", C.c_uint), ("mcts_solver", C.c_int),
+                ("dirichlet_epsilon", C.c_float), ("dirichlet_alpha", C.c_float)]
 
 
 class SearchStatsC(C.Structure):

@@ -156,6 +156,9 @@ typedef struct mi_search_settings {        /* SearchSettings (engine/src/agents/
     /* MCTS_Solver (optionsuci.cpp:129, default on): terminal backups prove WIN / LOSS / DRAW up the tree
      * (Node::solve_for_terminal, node.cpp:365-453); a proven root ends that tree's search. */
     int mcts_solver;
+    /* Dirichlet noise on the root priors at the start of every search when epsilon > 0.009, then full expansion of the root
+     * (mctsagent.cpp:311-316, node.cpp:950-954, blazeutil.h:113-124).  Defaults 0 / 0.2 (Centi_Dirichlet_Epsilon is 25 in RL builds). */
+    float dirichlet_epsilon, dirichlet_alpha;
 } mi_search_settings;
 typedef struct mi_search_stats {
     unsigned long long nodes, nn_evals, batches, simulations;

@@ -25,6 +25,8 @@ restated without tablebases.  useMCGS needs no restatement: the transposition li
 (node.cpp:730-731 takes the candidate from the child slot that is still empty at that point), so NODE_TRANSPOSITION is never
 produced and "mcgs" searches the same tree as "mcts".  The epsilon exploration (searchthread.cpp:124-185, 451-473, 497-501) is restated with the reference's
 rand() replaced by a seeded ANSI-C LCG (the reference seeds rand() with the time, so its own runs do not replay either).
+Dirichlet noise at the root (mctsagent.cpp:311-316, node.cpp:950-954, blazeutil.h:113-124) draws its gamma variates from the
+C++ standard library through oracle/stdgamma.cpp, seeded instead of std::random_device.
 """
 from __future__ import annotations
 
@@ -65,6 +67,8 @@ class Settings:
         self.epsilon_checks_counter = 0      # UCI default 100
         self.seed = 1
         self.mcts_solver = True              # MCTS_Solver, optionsuci.cpp:129
+        self.dirichlet_epsilon = F(0.0)      # Centi_Dirichlet_Epsilon: 0 (25 in RL builds), optionsuci.cpp:84-86
+        self.dirichlet_alpha = F(0.2)        # Centi_Dirichlet_Alpha 20
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -131,6 +135,7 @@ class Tree:
         self.root = Node(board, self.pm, s)
         self.new_nodes, self.new_traj, self.coll_traj = [], [], []
         self.rng = s.seed & 0xFFFFFFFF
+        self.noise_engine = None             # std::default_random_engine, created on first use (oracle/stdgamma.cpp)
 
     # ---------------------------------------------------------------------------------------------------------------
     def fill_nn_result(self, n: Node, value, probs):
@@ -150,6 +155,28 @@ class Tree:
     def set_root_result(self, value, probs):
         self.fill_nn_result(self.root, value, probs)
         self.prepare(self.root)
+
+    def begin_search(self):
+        """Start of a `go` (mctsagent.cpp:311-316): apply_dirichlet_noise_to_prior_policy (node.cpp:950-954) with
+        get_dirichlet_noise (blazeutil.h:113-124), then fully_expand_node (node.cpp:582-593)."""
+        n, s = self.root, self.s
+        if not (F(s.dirichlet_epsilon) > F(0.009)) or n.terminal or not n.has_nn or not n.moves:
+            return
+        lib = _stdgamma()
+        if self.noise_engine is None:
+            self.noise_engine = lib.stdgamma_new(ctypes.c_uint(s.seed & 0xFFFFFFFF))
+        buf = (ctypes.c_float * len(n.moves))()
+        lib.stdgamma_draw(self.noise_engine, ctypes.c_float(float(s.dirichlet_alpha)), len(n.moves), buf)
+        noise = [F(v) for v in buf]
+        tot = F(0)
+        for v in noise:
+            tot = F(tot + v)
+        keep = F(F(1) - F(s.dirichlet_epsilon))
+        n.priors = [F(F(keep * p) + F(F(s.dirichlet_epsilon) * F(v / tot))) for p, v in zip(n.priors, noise)]
+        if not n.sorted:
+            self.prepare(n)
+        while n.no_visit_idx < len(n.moves):
+            self.increment_no_visit_idx(n)
 
     def prepare(self, n: Node):
         order = sorted(range(len(n.moves)), key=lambda i: (-float(n.priors[i]), i))
@@ -470,11 +497,29 @@ class Tree:
         return finish(pol)
 
 
+_STDGAMMA = None
+
+
+def _stdgamma():
+    """ctypes handle on oracle/_build/libstdgamma.so (the C++ standard library's gamma_distribution, see stdgamma.cpp)."""
+    global _STDGAMMA
+    if _STDGAMMA is None:
+        from . import build_oracle
+        lib = ctypes.CDLL(build_oracle.build())
+        lib.stdgamma_new.restype = ctypes.c_void_p
+        lib.stdgamma_new.argtypes = [ctypes.c_uint]
+        lib.stdgamma_draw.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        lib.stdgamma_draw.restype = None
+        _STDGAMMA = lib
+    return _STDGAMMA
+
+
 def run_search(tree: Tree, evaluate, simulations, quota):
     """evaluate(list of Boards) -> (values, probs).  Mirrors SearchPool::run for a single tree / single lane."""
     if not tree.root.has_nn and not tree.root.terminal:
         v, p = evaluate([tree.root_board])
         tree.set_root_result(v[0], p[0])
+    tree.begin_search()
     pre = tree.root.visit_sum
     while not tree.root.terminal and tree.root.node_type == NT_UNSOLVED and tree.root.visit_sum - pre < simulations:
         boards = tree.collect(quota)

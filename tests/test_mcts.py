@@ -183,6 +183,52 @@ def test_mcts_solver_equals_oracle(hip_lib, variant, fen, mode, verdict, best):
     pool.close()
 
 
+@pytest.mark.parametrize("variant,fen,mode,eps,alpha,seed", [
+    ("crazyhouse", "", 0, 0.25, 0.2, 5),                    # the RL build's defaults (Centi_Dirichlet_Epsilon 25, Centi_Dirichlet_Alpha 20)
+    ("chess", "r3k2r/pppq1ppp/2npbn2/2b1p3/2B1P3/2NPBN2/PPPQ1PPP/R3K2R w KQkq - 4 8", 1, 0.4, 0.6, 77),
+])
+def test_dirichlet_noise_at_the_root_equals_oracle(hip_lib, variant, fen, mode, eps, alpha, seed):
+    """mctsagent.cpp:311-316: noise on the root priors at the start of every search, then the root is fully expanded.  Both sides
+    draw the gamma variates from the C++ standard library with the same seed."""
+    nbp, sims, quota = NB_POLICY[mode], 200, 8
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota,
+                                 dirichlet_epsilon=eps, dirichlet_alpha=alpha, seed=seed)
+    assert search.default_settings().dirichlet_epsilon == 0.0       # play builds: off (optionsuci.cpp:86)
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    def eval_boards(boards):
+        out = [_pseudo_net(key_from_board(b), nbp) for b in boards]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=quota, fn_nb_policy=nbp)
+    t = pool.add_position(fen, False, variant)
+    tree = mo.Tree(co.Board(fen or None, False, variant), mo.Settings(mode=mode, is_policy_map=True, batch_size=quota, seed=seed,
+                                                                      dirichlet_epsilon=np.float32(eps), dirichlet_alpha=np.float32(alpha)))
+    n_legal = len(tree.root.moves)
+    for go in range(2):                                     # the second `go` re-noises the already noised priors of the kept root
+        pool.run(simulations=sims, threads=1)
+        mo.run_search(tree, eval_boards, sims, quota)
+        moves, visits, q, pri = pool.root_children(t)
+        r = tree.root
+        assert len(moves) == n_legal == r.no_visit_idx      # fully expanded: every legal move has its slot
+        assert visits == r.child_visits
+        assert np.array_equal(q, np.array(r.q, np.float32))
+        assert np.allclose(pri, np.array(r.priors, np.float32), rtol=4e-7, atol=0)
+        assert abs(float(np.sum(pri)) - 1.0) < 1e-5
+        assert pool.best_move(t) == tree.best_move()[0]
+    # the noise changed the search: without it the root is not fully expanded after so few simulations
+    pool0 = search.SearchPool(search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota),
+                              eval_fn=eval_descs, fn_batch=quota, fn_nb_policy=nbp)
+    t0 = pool0.add_position(fen, False, variant)
+    pool0.run(simulations=sims, threads=1)
+    assert len(pool0.root_children(t0)[0]) < n_legal
+    pool0.close()
+    pool.close()
+
+
 CASES = [
     # variant, is960, fen, mode, sims, quota(batch), virtual style, temperature
     ("crazyhouse", False, "", 0, 300, 8, 3, 1.7),

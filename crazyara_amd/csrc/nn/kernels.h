@@ -35,6 +35,8 @@ struct ConvArgs {
     int out_policy_f32;   // 1: write float logits channel-major
     int out_flat;         // 1: write T channel-major flat, out[b*flat_pitch + co*64 + sq] (the value head's .view(-1, nb_flatten))
     int flat_pitch;
+    int out_rows_f32;     // 1: write float row-major out[(b*64 + sq) * cout_real + co] for rows < rows_valid (an FC over the batch)
+    int rows_valid;
 };
 
 template <typename T> void launch_conv_gemm(const ConvArgs& a, hipStream_t s);

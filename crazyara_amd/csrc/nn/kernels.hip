@@ -110,6 +110,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
+        } else if (a.out_rows_f32) {                 // FC over the batch: row = board, float logits [rows_valid][cout_real]
+            const int row = b * kSquares + sq;
+            if (row < a.rows_valid) {
+                float* o = reinterpret_cast<float*>(a.out) + size_t(row) * a.cout_real;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < a.cout_real) o[co0 + r] = v[r];
+            }
         } else if (a.out_flat) {
             T* o = reinterpret_cast<T*>(a.out) + size_t(b) * a.flat_pitch;
 #pragma unroll

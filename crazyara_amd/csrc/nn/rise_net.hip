@@ -200,7 +200,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     if (fc > 256 && fc % 256 != 0) throw std::runtime_error("unsupported value_fc_size");
 
     design_.nb_input_channels = cin;
-    design_.nb_policy = cp * kSquares;
+    // _PolicyHead form (builder_util.py:206-243): policy map (the P planes, channel-major) or flat labels (Linear on top)
+    const bool policy_map = nf.num("select_policy_from_plane", 1) != 0;
+    const int n_labels = int(nf.num("n_labels", 0));
+    if (!policy_map && (n_labels <= 0 || (cp * kSquares) % 32 != 0)) throw std::runtime_error("flat policy head needs n_labels and P*64 % 32 == 0");
+    design_.nb_policy = policy_map ? cp * kSquares : n_labels;
     design_.nb_aux = wdl ? 4 : 0;
     const int cin_pad = round_up(cin, 32);
     im.cin_pad = cin_pad;
@@ -610,7 +614,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
     }
     flush_tower();
-    const bool head_ok = tower_ok && cv == 8 && cp <= 96 && (wdl || fc == 256);
+    const bool head_ok = tower_ok && policy_map && cv == 8 && cp <= 96 && (wdl || fc == 256);
     if (head_ok) {
         // policy + value head in one launch (head.hip; stream layouts in kernels.h: HeadArgs)
         if constexpr (kHalf) {
@@ -695,7 +699,60 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     } else {
     // _PolicyHead (select_policy_from_plane), builder_util.py:206-243
     add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr);
-    add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_);
+    if (policy_map) {
+        add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_);
+    } else {
+        // flat labels: conv3x3(C->P) + BN + ReLU written channel-major flat (x.view(-1, nb_flatten)), then Linear(P*64 -> n_labels)
+        // as a GEMM over the BATCH (64 boards play the 64 "squares" of a workgroup tile), float logits row per board
+        const int nfl = cp * kSquares, Bpad = round_up(B, 64), co_pad = round_up(cp, 16);
+        T* pflat = static_cast<T*>(im.dalloc(size_t(Bpad) * nfl * sizeof(T)));
+        HIP_CHECK(hipMemset(pflat, 0, size_t(Bpad) * nfl * sizeof(T)));
+        {
+            Folded fd = fold_bn(nf, "policy_head.body.3", "policy_head.body2.0");
+            Op op;
+            op.kind = OpKind::Conv;
+            op.conv.x = nxt;
+            op.conv.wpk = im.upload(pack_dense<T>(fd, cp, C, 3, co_pad, C));
+            op.conv.bias = im.upload_d2f(fd.b, co_pad);
+            op.conv.out = pflat;
+            op.conv.batch = B;
+            op.conv.cin = C;
+            op.conv.cout_pad = co_pad;
+            op.conv.cout_real = cp;
+            op.conv.cout_ld = co_pad;
+            op.conv.ks = 3;
+            op.conv.relu = 1;
+            op.conv.out_flat = 1;
+            op.conv.flat_pitch = nfl;
+            im.ops.push_back(op);
+            macs += double(kSquares) * C * cp * 9;
+        }
+        {
+            const TensorView& w = nf.get("policy_head.body3.0.weight");
+            const float* bb = nf.get("policy_head.body3.0.bias").data;
+            Folded fl;
+            fl.w.assign(w.data, w.data + size_t(n_labels) * nfl);
+            fl.b.assign(bb, bb + n_labels);
+            const int nl_pad = round_up(n_labels, 16);
+            Op op;
+            op.kind = OpKind::Conv;
+            op.conv.x = pflat;
+            op.conv.wpk = im.upload(pack_dense<T>(fl, n_labels, nfl, 1, nl_pad, nfl));
+            op.conv.bias = im.upload_d2f(fl.b, nl_pad);
+            op.conv.out = d_logits_;
+            op.conv.batch = Bpad / 64;
+            op.conv.cin = nfl;
+            op.conv.cout_pad = nl_pad;
+            op.conv.cout_real = n_labels;
+            op.conv.cout_ld = nl_pad;
+            op.conv.ks = 1;
+            op.conv.relu = 0;
+            op.conv.out_rows_f32 = 1;
+            op.conv.rows_valid = B;
+            im.ops.push_back(op);
+            macs += double(nfl) * n_labels;
+        }
+    }
     {
         Op op;
         op.kind = OpKind::Softmax;

@@ -78,6 +78,7 @@ def export_rise(path: str, cfg, state_dict, input_version: str = "1.0", variant:
         channels_value_head=cfg.channels_value_head, value_fc_size=cfg.value_fc_size,
         channels_policy_head=cfg.channels_policy_head, use_wdl=int(cfg.use_wdl), use_plys_to_end=int(cfg.use_plys_to_end),
         conv_block=getattr(cfg, "conv_block", "mobile_bottlekneck_res_block"),
+        select_policy_from_plane=int(getattr(cfg, "select_policy_from_plane", True)), n_labels=getattr(cfg, "n_labels", 2272),
     )
     tensors = {}
     for k, v in state_dict.items():

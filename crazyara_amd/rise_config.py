@@ -34,6 +34,10 @@ class RiseConfig:
     #   "classical_res_block"           RiseV3(conv_block=...): x + ReLU(BN(conv3x3(ReLU(BN(conv3x3(x))))))  (builder_util.py:401-434)
     #   "a0_res_block"                  AlphaZeroResnet: ReLU(x + BN(conv3x3(ReLU(BN(conv3x3(x))))))          (a0_resnet.py:72-183)
     conv_block: str = "mobile_bottlekneck_res_block"
+    # policy head form (_PolicyHead, builder_util.py:206-243): True = policy map (logits = the P x 8 x 8 planes, channel-major);
+    # False = flat labels: BN + ReLU on the planes, then Linear(P*64 -> n_labels)
+    select_policy_from_plane: bool = True
+    n_labels: int = 2272
 
     @property
     def dense_blocks(self) -> bool:
@@ -55,7 +59,7 @@ class RiseConfig:
 
     @property
     def nb_policy(self) -> int:
-        return self.channels_policy_head * 64
+        return self.channels_policy_head * 64 if self.select_policy_from_plane else self.n_labels
 
     @property
     def nb_aux(self) -> int:
@@ -191,6 +195,9 @@ def make_state_dict(cfg: RiseConfig, seed: int = 0, stress: bool = True) -> Dict
     conv("policy_head.body.0", C, C, 3)
     bn("policy_head.body.1", C)
     conv("policy_head.body.3", cfg.channels_policy_head, C, 3, gain=0.35 if cfg.dense_blocks else 1.0)   # logits O(1) either way
+    if not cfg.select_policy_from_plane:
+        bn("policy_head.body2.0", cfg.channels_policy_head)
+        linear("policy_head.body3.0", cfg.n_labels, cfg.channels_policy_head * 64, gain=0.35)
     conv("value_head.body.0", cfg.channels_value_head, C, 1)
     bn("value_head.body.1", cfg.channels_value_head)
     nflat = 64 * cfg.channels_value_head

@@ -94,7 +94,12 @@ def forward(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, sim_d
             taps[f"block{i}"] = h
     # policy head
     ph = _q(F.relu(_bn(sd, "policy_head.body.1", F.conv2d(h, W("policy_head.body.0.weight"), padding=1))), sim_dtype)
-    pol = F.conv2d(ph, W("policy_head.body.3.weight"), padding=1).reshape(x.shape[0], -1)
+    pol = F.conv2d(ph, W("policy_head.body.3.weight"), padding=1)
+    if cfg.select_policy_from_plane:
+        pol = pol.reshape(x.shape[0], -1)                      # channel-major flatten = plane*64 + square
+    else:                                                      # builder_util.py:229-232,241-243: BN + act, view, Linear
+        pol = _q(F.relu(_bn(sd, "policy_head.body2.0", pol)), sim_dtype).reshape(x.shape[0], -1)
+        pol = F.linear(pol, W("policy_head.body3.0.weight"), sd["policy_head.body3.0.bias"])
     # value head
     vh = F.relu(_bn(sd, "value_head.body.1", F.conv2d(h, W("value_head.body.0.weight")))).reshape(x.shape[0], -1)
     aux = None
@@ -131,6 +136,8 @@ def flops_per_position(cfg: RiseConfig) -> float:
         elif se == "eca_se":
             macs += C * C
     macs += 64 * C * C * 9 + 64 * C * cfg.channels_policy_head * 9
+    if not cfg.select_policy_from_plane:
+        macs += 64 * cfg.channels_policy_head * cfg.n_labels
     macs += 64 * C * cfg.channels_value_head
     if cfg.use_wdl and cfg.use_plys_to_end:
         macs += 4 * 64 * cfg.channels_value_head

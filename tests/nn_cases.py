@@ -22,6 +22,14 @@ def small_risev2():
     return cfg
 
 
+def small_risev2_flat():
+    cfg = small_risev2()
+    cfg.select_policy_from_plane = False
+    cfg.n_labels = 2272
+    cfg.name = "risev2-3-flat"
+    return cfg
+
+
 CASES = {
     # name: (config factory, seed, stress-init, batch)
     "risev2-3": (small_risev2, 11, True, 4),
@@ -36,6 +44,8 @@ CASES = {
     "rise-classical-4": (lambda: ro.rise_classical_config(4, 34, 81), 19, True, 4),
     "alphazero-5": (lambda: ro.alpha_zero_config(5, 52, 76, 4), 20, True, 4),
     "alphazero-3-cv8": (lambda: ro.alpha_zero_config(3, 34, 81, 8), 21, True, 3),
+    # flat-label policy head (select_policy_from_plane=False): Linear(P*64 -> 2272 crazyhouse labels)
+    "risev2-3-flat": (small_risev2_flat, 22, True, 5),
 }
 
 

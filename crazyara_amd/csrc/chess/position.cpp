@@ -516,7 +516,7 @@ void Position::compute_repetition() {
     }
 }
 
-void Position::do_move(Move m) {
+void Position::do_move(Move m, const Key* known_key) {
     const Color us = stm_, them = Color(us ^ 1);
     const int to = to_sq(m), from = from_sq(m);
     const MoveKind kind = kind_of(m);
@@ -573,7 +573,7 @@ void Position::do_move(Move m) {
     stm_ = them;
     update_checkers();
     if (variant_ == V_THREECHECK && checkers_) ++checks_given_[us];
-    keys_.push_back(compute_key());
+    keys_.push_back(known_key ? *known_key : compute_key());
     rep_flags_.push_back(0);
     compute_repetition();
     rep_flags_.back() = repetition_ != 0;

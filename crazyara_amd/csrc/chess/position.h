@@ -93,7 +93,9 @@ public:
     void legal_moves(std::vector<Move>& out) const;            // MoveList<LEGAL>
     std::vector<Move> legal_moves() const { std::vector<Move> v; legal_moves(v); return v; }
     bool gives_check(Move m) const;
-    void do_move(Move m);
+    void do_move(Move m) { do_move(m, nullptr); }
+    // known_key: the position key after the move if the caller has it (a search tree node remembers its key): saves the recomputation
+    void do_move(Move m, const Key* known_key);
     Move uci_to_move(const std::string& uci) const;            // UCI::to_move; MOVE_NONE if not legal
     std::string move_to_uci(Move m) const;                     // UCI::move (castling: e1g1 classic, king-takes-rook in 960)
     // origin/destination as the policy labels see them (castling: classic -> king's two-step target, 960 -> rook square)

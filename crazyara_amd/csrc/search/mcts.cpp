@@ -32,9 +32,9 @@ Tree::Tree(const Position& root, const SearchSettings& settings) : s_(settings),
     rng_ = s_.seed;
     noise_rng_.seed(s_.seed);
     tables_ = &chess::policy_tables(s_.mode);
+    nodes_.reserve(8192);
     layout_ = layout_for(s_.mode, s_.version_major);
     keep_last_moves_ = s_.clone_keeps_last_moves < 0 ? s_.mode != MODE_CRAZYHOUSE : s_.clone_keeps_last_moves != 0;
-    nodes_.reserve(4096);
     new_node(root_pos_);
 }
 
@@ -44,6 +44,7 @@ int Tree::new_node(const Position& pos) {
     Node& n = nodes_.back();
     pos.legal_moves(n.actions);
     n.plies = uint16_t(pos.game_ply());
+    n.key = pos.key();
     n.stm = uint8_t(pos.side_to_move());
     const chess::TerminalType tt = pos.is_terminal(n.actions.size());
     if (tt != chess::TERMINAL_NONE) {
@@ -117,14 +118,18 @@ void Tree::begin_search() {
 // sort_moves_by_probabilities + init_node_data (node.cpp:464-470, 634-643, nodedata.cpp:40-57).
 // The reference uses an unstable std::sort with greater<float>; ties are broken by the original index here.
 void Tree::prepare_node_for_visits(Node& n) {
-    std::vector<int> perm(n.actions.size());
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return n.priors[a] > n.priors[b]; });
-    std::vector<Move> a2(n.actions.size());
-    std::vector<float> p2(n.priors.size());
-    for (size_t i = 0; i < perm.size(); ++i) { a2[i] = n.actions[perm[i]]; p2[i] = n.priors[perm[i]]; }
-    n.actions.swap(a2);
-    n.priors.swap(p2);
+    // stable insertion sort of the indices by descending prior (a few dozen moves; same order as std::stable_sort)
+    std::vector<int>& perm = sort_perm_;
+    perm.resize(n.actions.size());
+    for (int i = 0; i < int(perm.size()); ++i) {
+        const float p = n.priors[i];
+        int j = i;
+        while (j > 0 && n.priors[perm[j - 1]] < p) { perm[j] = perm[j - 1]; --j; }
+        perm[j] = i;
+    }
+    sort_moves_.assign(n.actions.begin(), n.actions.end());
+    sort_priors_.assign(n.priors.begin(), n.priors.end());
+    for (size_t i = 0; i < perm.size(); ++i) { n.actions[i] = sort_moves_[perm[i]]; n.priors[i] = sort_priors_[perm[i]]; }
     n.sorted = true;
     if (!n.has_data) {
         n.has_data = true;
@@ -157,13 +162,18 @@ int Tree::select_child(Node& n) {
     if (n.checkmate_idx >= 0) return n.checkmate_idx;                                     // has_forced_win
     const float cpuct = get_current_cput(float(n.visit_sum), s_);
     const double sq = std::sqrt(double(n.visit_sum));
+    const int m = int(n.no_visit_idx);
+    select_buf_.resize(size_t(m));
+    float* __restrict__ val = select_buf_.data();
+    const float* __restrict__ pr = n.priors.data();
+    const float* __restrict__ qv = n.q.data();
+    const uint32_t* __restrict__ cv = n.child_visits.data();
+    for (int i = 0; i < m; ++i)                      // element-wise, vectorisable; each element rounds exactly as the scalar form
+        val[i] = qv[i] + float(double(cpuct * pr[i]) * (sq / (double(cv[i]) + 1.0)));
     int best = 0;
     float best_v = -std::numeric_limits<float>::infinity();
-    for (int i = 0; i < int(n.no_visit_idx); ++i) {
-        const float u = float(double(cpuct * n.priors[i]) * (sq / (double(n.child_visits[i]) + 1.0)));
-        const float v = n.q[i] + u;
-        if (v > best_v) { best_v = v; best = i; }
-    }
+    for (int i = 0; i < m; ++i)
+        if (val[i] > best_v) { best_v = val[i]; best = i; }
     return best;
 }
 
@@ -327,7 +337,7 @@ int Tree::get_starting_node(int cur, uint32_t& depth, int& child_idx, Position& 
         if (next < 0 || !nodes_[next].has_data || nodes_[next].visit_sum < uint32_t(s_.epsilon_greedy_counter) ||
             nodes_[next].node_type != NT_UNSOLVED)
             break;
-        pos.do_move(n.actions[best]);
+        pos.do_move(n.actions[best], &nodes_[next].key);
         cur = next;
         ++depth;
     }
@@ -369,7 +379,8 @@ int Tree::select_enhanced_move(int cur, const Position& pos) {
 int Tree::get_new_child_to_evaluate(NodeBackup& type, uint32_t& depth, BoardDesc* desc_out) {
     depth = 0;
     int cur = 0;
-    Position pos(root_pos_);                     // rootState->clone()
+    Position& pos = scratch_pos_;
+    pos = root_pos_;                             // rootState->clone()
     if (!keep_last_moves_) pos.clear_last_moves();
     int forced = -1;                             // childIdx chosen by the exploration step (uint16_t(-1) = none)
     if (s_.epsilon_greedy_counter && nodes_[0].has_data && next_rand() % uint32_t(s_.epsilon_greedy_counter) == 0) {
@@ -402,7 +413,7 @@ int Tree::get_new_child_to_evaluate(NodeBackup& type, uint32_t& depth, BoardDesc
         }
         if (nodes_[next].terminal) { type = NODE_TERMINAL; return next; }
         if (!nodes_[next].has_nn) { type = NODE_COLLISION; return next; }
-        pos.do_move(nodes_[cur].actions[c]);     // actionsBuffer replay, done incrementally
+        pos.do_move(nodes_[cur].actions[c], &nodes_[next].key);     // actionsBuffer replay, done incrementally
         cur = next;
     }
 }

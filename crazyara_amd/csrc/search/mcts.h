@@ -75,6 +75,7 @@ struct Node {
     uint32_t visit_sum = 0;
     uint32_t free_visits = 0;
     uint16_t no_visit_idx = 0;
+    uint64_t key = 0;                     // hash key of the position (Node::key, node.cpp:84): lets the descent skip its recomputation
     uint16_t plies = 0;
     uint16_t unsolved_children = 0;       // numberUnsolvedChildNodes
     uint16_t end_in_ply = 0;              // endInPly: distance to the proven terminal
@@ -161,6 +162,11 @@ private:
     std::vector<int32_t> new_nodes_;
     std::vector<Trajectory> new_trajectories_, collision_trajectories_;
     Trajectory trajectory_buffer_;
+    chess::Position scratch_pos_;         // the simulation's running position (assigned from the root: keeps its buffers)
+    std::vector<int> sort_perm_;
+    std::vector<chess::Move> sort_moves_;
+    std::vector<float> sort_priors_;
+    std::vector<float> select_buf_;
     uint32_t rng_ = 1;
     std::minstd_rand0 noise_rng_;              // std::default_random_engine of libstdc++ (randomgen.h:35)
 };

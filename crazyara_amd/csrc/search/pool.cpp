@@ -1,7 +1,11 @@
 #include "pool.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <stdexcept>
@@ -86,35 +90,34 @@ std::unique_ptr<Evaluator> make_callback_evaluator(EvalFn fn, void* user, int ba
 // ---------------------------------------------------------------------------------------------------------------------
 // worker pool
 // ---------------------------------------------------------------------------------------------------------------------
-WorkerPool::WorkerPool(int threads) {
-    for (int i = 1; i < threads; ++i) workers_.emplace_back([this] { worker_loop(); });
+WorkerPool::WorkerPool(int threads) : nthreads_(std::max(1, threads)) {
+    workers_.reserve(size_t(nthreads_ - 1));
+    for (int i = 1; i < nthreads_; ++i) workers_.emplace_back([this, i] { worker_loop(i); });
+}
+void WorkerPool::run_items(int index) {
+    try {
+        for (int i = index; i < n_; i += nthreads_) (*fn_)(i);
+    } catch (...) {
+        std::lock_guard<std::mutex> lk(err_m_);
+        if (!err_) err_ = std::current_exception();
+    }
 }
 WorkerPool::~WorkerPool() {
-    {
-        std::lock_guard<std::mutex> lk(m_);
-        stop_ = true;
-    }
-    cv_.notify_all();
+    stop_.store(true, std::memory_order_release);
     for (auto& t : workers_) t.join();
 }
-void WorkerPool::worker_loop() {
+void WorkerPool::worker_loop(int index) {
     int seen = 0;
     while (true) {
-        const std::function<void(int)>* fn;
-        int n;
-        {
-            std::unique_lock<std::mutex> lk(m_);
-            cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
-            if (stop_) return;
-            seen = generation_;
-            fn = fn_;
-            n = n_;
+        int spins = 0;
+        while (generation_.load(std::memory_order_acquire) == seen) {
+            if (stop_.load(std::memory_order_acquire)) return;
+            if (++spins < 20000) __builtin_ia32_pause();
+            else std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
-        for (int i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            if (--active_ == 0) done_cv_.notify_all();
-        }
+        seen = generation_.load(std::memory_order_acquire);
+        run_items(index);
+        done_.fetch_add(1, std::memory_order_release);
     }
 }
 void WorkerPool::parallel_for(int n, const std::function<void(int)>& fn) {
@@ -123,18 +126,17 @@ void WorkerPool::parallel_for(int n, const std::function<void(int)>& fn) {
         for (int i = 0; i < n; ++i) fn(i);
         return;
     }
-    {
-        std::lock_guard<std::mutex> lk(m_);
-        fn_ = &fn;
-        n_ = n;
-        next_.store(0);
-        active_ = int(workers_.size());
-        ++generation_;
+    fn_ = &fn;
+    n_ = n;
+    done_.store(0, std::memory_order_relaxed);
+    generation_.fetch_add(1, std::memory_order_release);
+    run_items(0);
+    while (done_.load(std::memory_order_acquire) != int(workers_.size())) __builtin_ia32_pause();
+    if (err_) {
+        std::exception_ptr e = err_;
+        err_ = nullptr;
+        std::rethrow_exception(e);
     }
-    cv_.notify_all();
-    for (int i; (i = next_.fetch_add(1)) < n;) fn(i);
-    std::unique_lock<std::mutex> lk(m_);
-    done_cv_.wait(lk, [&] { return active_ == 0; });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -208,6 +210,8 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         return false;
     };
 
+    double t_par = 0, t_submit = 0, t_item_max = 0, t_item_sum = 0;
+    const bool timing = getenv("CRA_POOL_TIMING") != nullptr;
     auto collect_lane = [&](Lane& lane) -> bool {
         std::vector<int> active;
         for (int id : lane.trees)
@@ -224,9 +228,20 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         lane.n_new.assign(n_use, 0);
         std::vector<int> ids(active.begin(), active.begin() + n_use);
         for (int i = 0; i < n_use; ++i) { lane.slot_begin[i] = i * quota; lane.slot_count[i] = quota; }
+        const auto c0 = std::chrono::steady_clock::now();
+        std::vector<double> item_t(timing ? n_use : 0);
         workers.parallel_for(n_use, [&](int i) {
+            const auto i0 = std::chrono::steady_clock::now();
             lane.n_new[i] = trees_[ids[i]]->collect(lane.slot_count[i], ev.descs() + lane.slot_begin[i]);
+            if (timing) item_t[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
         });
+        if (timing) {
+            double mx = 0, sm = 0;
+            for (double v : item_t) { mx = std::max(mx, v); sm += v; }
+            t_item_max += mx;
+            t_item_sum += sm;
+        }
+        t_par += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
         // rotate so that waiting trees get their turn next round
         if (int(active.size()) > n_use) std::rotate(lane.trees.begin(), lane.trees.begin() + 1, lane.trees.end());
         int total_new = 0, last_used = 0;
@@ -240,15 +255,20 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
             workers.parallel_for(n_use, [&](int i) { trees_[ids[i]]->finish_batch(nullptr, nullptr, ev.nb_policy()); });
             return true;
         }
+        const auto s0 = std::chrono::steady_clock::now();
         ev.submit(last_used, layout_);
+        t_submit += std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
         lane.in_flight = true;
         st.nn_evals += total_new;
         ++st.batches;
         return true;
     };
+    double t_wait = 0;
     auto apply_lane = [&](Lane& lane) {
         Evaluator& ev = *lane.eval;
+        const auto w0 = std::chrono::steady_clock::now();
         ev.wait();
+        t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
         const int n_use = int(lane.slot_begin.size());
         workers.parallel_for(n_use, [&](int i) {
             const int id = lane.batch_ids[i];
@@ -257,14 +277,26 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         lane.in_flight = false;
     };
 
+    // development: CRA_POOL_TIMING=1 prints where the driver thread spends its time (wait = blocked on the GPU)
+    double t_apply = 0, t_collect = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
     bool any = true;
     while (any) {
         any = false;
         for (Lane& lane : lanes_) {
+            const auto a0 = now();
             if (lane.in_flight) apply_lane(lane);
+            const auto a1 = now();
             if (collect_lane(lane)) any = true;
+            if (timing) {
+                t_apply += std::chrono::duration<double>(a1 - a0).count();
+                t_collect += std::chrono::duration<double>(now() - a1).count();
+            }
         }
     }
+    if (timing) fprintf(stderr, "pool timing: wait %.1f ms, apply %.1f ms, collect+submit %.1f ms (parallel collect %.1f [items: sum %.1f, sum of per-batch max %.1f], submit %.1f), batches %llu\n",
+                        t_wait * 1e3, (t_apply - t_wait) * 1e3, t_collect * 1e3, t_par * 1e3, t_item_sum * 1e3, t_item_max * 1e3, t_submit * 1e3,
+                        (unsigned long long)st.batches);
     for (Lane& lane : lanes_)
         if (lane.in_flight) apply_lane(lane);
     st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

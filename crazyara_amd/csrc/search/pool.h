@@ -1,7 +1,8 @@
 // SearchPool: many independent trees feeding shared GPU batches through two pipeline lanes (see mcts.h header).
 #pragma once
 #include <atomic>
-#include <condition_variable>
+#include <exception>
+#include <mutex>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -46,21 +47,26 @@ struct SearchStats {
     uint32_t depth_max = 0;
 };
 
+// Fork/join over a fixed set of threads for work items of a few tens of microseconds (one tree's leaf collection).
+// Workers spin on a generation counter (a condition-variable wake-up costs more than the work) and fall back to short sleeps
+// when nothing arrives for a while; item i always runs on thread i % threads, so a tree stays in the caches of one core.
 class WorkerPool {
 public:
     explicit WorkerPool(int threads);
     ~WorkerPool();
-    void parallel_for(int n, const std::function<void(int)>& fn);   // blocks; fn(i) for i in [0,n)
-    int threads() const { return int(workers_.size()) + 1; }
+    void parallel_for(int n, const std::function<void(int)>& fn);   // blocks; fn(i) for i in [0,n); rethrows the first exception
+    int threads() const { return nthreads_; }
 private:
-    void worker_loop();
+    void worker_loop(int index);
+    void run_items(int index);
+    int nthreads_ = 1;
     std::vector<std::thread> workers_;
-    std::mutex m_;
-    std::condition_variable cv_, done_cv_;
     const std::function<void(int)>* fn_ = nullptr;
-    std::atomic<int> next_{0};
-    int n_ = 0, generation_ = 0, active_ = 0;
-    bool stop_ = false;
+    int n_ = 0;
+    std::mutex err_m_;
+    std::exception_ptr err_;
+    std::atomic<int> generation_{0}, done_{0};
+    std::atomic<bool> stop_{false};
 };
 
 class SearchPool {

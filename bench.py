@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--simulations", type=int, default=1600)
     ap.add_argument("--search-quota", type=int, default=16, help="leaves per tree per batch (reference Batch_Size default 16)")
     ap.add_argument("--search-threads", type=int, default=16)
+    ap.add_argument("--search-lanes", type=int, default=2, help="batches in flight (the reference: one per SearchThread, Threads default 2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -134,10 +135,13 @@ def main():
     mcts = None
     if not args.no_search:
         from crazyara_amd import openings, search
-        net_b = HipAPI(local_rank, args.batch, tmp, args.precision)
+        lanes = max(1, args.search_lanes)
+        extra_nets = [HipAPI(local_rank, args.batch, tmp, args.precision) for _ in range(lanes - 1)]
         st = search.default_settings(mode=0, version_major=1, batch_size=args.search_quota)
-        pool = search.SearchPool(st, net_a=net, net_b=net_b)
-        n_trees = 2 * max(1, args.batch // args.search_quota)
+        pool = search.SearchPool(st, net_a=net, net_b=extra_nets[0] if extra_nets else None)
+        for n_extra in extra_nets[1:]:
+            pool.add_lane(n_extra)
+        n_trees = lanes * max(1, args.batch // args.search_quota)
         fens = openings.position_fens("crazyhouse")
         for i in range(n_trees):
             pool.add_position(fens[(i * 7 + rank * 3) % len(fens)], False, "crazyhouse")
@@ -151,10 +155,11 @@ def main():
         mcts = {"mcts_nodes_per_sec": round(tot[0] / tot[3], 1), "mcts_nn_evals_per_sec": round(tot[1] / tot[3], 1),
                 "simulations_per_sec": round(tot[2] / tot[3], 1), "seconds": round(tot[3], 3),
                 "trees_per_gpu": n_trees, "simulations_per_tree": args.simulations, "per_tree_quota": args.search_quota,
-                "lanes": 2, "host_threads_per_gpu": threads, "avg_batch_fill": round(stt.nn_evals / max(1, stt.batches) / args.batch, 3),
+                "lanes": lanes, "host_threads_per_gpu": threads, "avg_batch_fill": round(stt.nn_evals / max(1, stt.batches) / args.batch, 3),
                 "depth_avg": round(stt.depth_avg, 2), "depth_max": int(stt.depth_max)}
         pool.close()
-        net_b.close()
+        for n_extra in extra_nets:
+            n_extra.close()
 
     out = None
     if rank == 0:

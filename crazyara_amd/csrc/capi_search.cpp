@@ -105,6 +105,11 @@ mi_search* mi_search_create(const mi_search_settings* s, mi_net* net_a, mi_net* 
     return h;
 }
 
+int mi_search_add_lane(mi_search* sp, mi_net* net) {
+    if (!sp || !net) { cra_set_error("null argument"); return 1; }
+    return cra_guard([&] { sp->pool->add_lane(make_hip_evaluator(&net->net)); });
+}
+
 void mi_search_destroy(mi_search* sp) { delete sp; }
 
 int mi_search_add_position(mi_search* sp, const char* fen, int is_chess960, const char* variant) {

@@ -153,6 +153,15 @@ SearchPool::SearchPool(const SearchSettings& s, std::unique_ptr<Evaluator> lane_
     }
 }
 
+void SearchPool::add_lane(std::unique_ptr<Evaluator> lane) {
+    if (!lane) throw std::invalid_argument("null evaluator lane");
+    if (!trees_.empty()) throw std::logic_error("lanes must be added before positions");
+    if (lane->batch_size() != lanes_[0].eval->batch_size() || lane->nb_policy() != lanes_[0].eval->nb_policy())
+        throw std::invalid_argument("evaluator lanes must agree in batch size and policy length");
+    lanes_.emplace_back();
+    lanes_.back().eval = std::move(lane);
+}
+
 int SearchPool::add_position(const chess::Position& pos) {
     SearchSettings st = s_;
     st.seed = s_.seed + uint32_t(trees_.size());     // every tree owns its exploration stream

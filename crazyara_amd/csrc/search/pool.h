@@ -72,6 +72,8 @@ private:
 class SearchPool {
 public:
     SearchPool(const SearchSettings& s, std::unique_ptr<Evaluator> lane_a, std::unique_ptr<Evaluator> lane_b);
+    // one more evaluator lane (before any position is added): one more batch in flight while the others are collected
+    void add_lane(std::unique_ptr<Evaluator> lane);
     int add_position(const chess::Position& pos);
     // runs until every tree reached `simulations` root visits (if > 0) and/or `nodes` counted nodes (if > 0)
     // (SearchThread::nodes_limits_ok, searchthread.cpp:326-331)

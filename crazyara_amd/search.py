@@ -51,7 +51,7 @@ class SearchPool:
                     print("evaluator callback raised:", repr(e))
                     return 1
             self._cb = EVAL_FN(_tramp)
-        self._nets = (net_a, net_b)
+        self._nets = [net_a, net_b]
         self._h = self._lib.mi_search_create(C.byref(settings), net_a._h if net_a else None, net_b._h if net_b else None,
                                              self._cb if self._cb else C.cast(None, EVAL_FN), None, fn_batch, fn_nb_policy)
         if not self._h:
@@ -82,6 +82,12 @@ class SearchPool:
         rv, nc, alloc, val = C.c_uint(), C.c_uint(), C.c_uint(), C.c_float()
         self._lib.mi_search_tree_info(self._h, tree, C.byref(rv), C.byref(nc), C.byref(alloc), C.byref(val))
         return dict(root_visits=rv.value, node_count=nc.value, allocated=alloc.value, root_value=val.value)
+
+    def add_lane(self, net) -> None:
+        """One more evaluator lane (call before add_position): one more batch in flight."""
+        if self._lib.mi_search_add_lane(self._h, net._h):
+            raise RuntimeError(_capi.last_error())
+        self._nets.append(net)
 
     def root_solved(self, tree: int) -> dict:
         """Solver verdict on the root: node_type 0 WIN / 1 DRAW / 2 LOSS / 6 UNSOLVED, plies to the end, mating child index."""

@@ -172,6 +172,9 @@ void mi_search_default_settings(mi_search_settings* s);                 /* UCI d
 /* lanes: net_a (required unless fn given), net_b optional second net instance on the same GPU -> collection of one half of
  * the trees overlaps evaluation of the other half.  With fn != NULL the nets are ignored and fn evaluates (batch, nb_policy given). */
 mi_search* mi_search_create(const mi_search_settings* s, mi_net* net_a, mi_net* net_b, mi_eval_fn fn, void* user, int fn_batch, int fn_nb_policy);
+/* one more evaluator lane (its own net handle: weights, stream, graph), to be added before the first position: with k lanes k
+ * batches are in flight, like k SearchThreads of the reference each blocked in its own predict() (searchthread.cpp:403-416) */
+int mi_search_add_lane(mi_search* sp, mi_net* net);
 void mi_search_destroy(mi_search* sp);
 int mi_search_add_position(mi_search* sp, const char* fen, int is_chess960, const char* variant);   /* returns tree id or -1 */
 /* go with Simulations / Nodes limits per tree (searchthread.cpp:326-331); threads = host collector threads */

@@ -66,3 +66,30 @@ def test_two_lane_pool_on_opening_set(tmp_path, hip_lib):
     pool.close()
     a.close()
     b.close()
+
+
+def test_lane_count_does_not_change_the_trees(tmp_path, hip_lib):
+    """A tree only ever sees its own fixed quota of every batch, so the searches of the first four trees are the same whether
+    the pool runs 1, 2 or 3 evaluator lanes (mi_search_add_lane; 4 trees per lane -> quota 16 each).  Solver and root Dirichlet
+    noise are switched on so that those paths run against the real network as well."""
+    cfg, sd, _ = nn_cases.make_case("risev2-3")
+    d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
+    fens = openings.position_fens("crazyhouse")[5:17]
+    results = []
+    for lanes in (1, 2, 3):
+        nets = [HipAPI(0, 64, d, "float32") for _ in range(lanes)]
+        st = search.default_settings(mode=0, version_major=1, batch_size=16, dirichlet_epsilon=0.25, seed=9)
+        pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1] if lanes > 1 else None)
+        for n in nets[2:]:
+            pool.add_lane(n)
+        for f in fens[:4 * lanes]:
+            pool.add_position(f, False, "crazyhouse")
+        pool.run(simulations=160, threads=3)
+        results.append([(pool.root_children(i)[1], pool.best_move(i)) for i in range(4)])
+        pool.close()
+        for n in nets:
+            n.close()
+    assert results[0] == results[1] == results[2]
+    for (visits, bm), f in zip(results[0], fens):
+        assert sum(visits) >= 160 and bm in env.Position(f, False, "crazyhouse").legal_uci()
+        assert len(visits) == len(env.Position(f, False, "crazyhouse").legal_uci())      # Dirichlet: root fully expanded

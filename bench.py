@@ -58,9 +58,35 @@ def cpu_baseline(cfg, sd, x, budget_s=15.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 16 * x.shape[0]:
             break
-    return {"value": round(n / el, 1), "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": f"{n} positions (batches of {x.shape[0]}) of the same synthetic workload, oracle/rise_oracle.predict "
-                      f"(torch fp32 CPU restatement of the reference RiseV3 module), {el:.1f} s"}
+    out = {"value": round(n / el, 1), "unit": "evals/s", "cores": cores, "kind": "port",
+           "sample": f"{n} positions (batches of {x.shape[0]}) of the same synthetic workload, oracle/rise_oracle.predict "
+                     f"(torch fp32 CPU restatement of the reference RiseV3 module), {el:.1f} s"}
+    out.update(cpu_baseline_mcts(cfg, sd, cores))
+    return out
+
+
+def cpu_baseline_mcts(cfg, sd, cores, trees=16, quota=16, simulations=48):
+    """Metric 2 on the CPU path: the SAME C++ leaf collector with the CPU net plugged in behind the evaluator
+    boundary -- descriptors -> host plane builder -> oracle network.  Bounded: 16 trees x 48 simulations, one lane, batch 256."""
+    from crazyara_amd import env, openings, search
+    from oracle import rise_oracle as ro
+    st = search.default_settings(mode=0, version_major=1, batch_size=quota)
+    layout = env._capi.load().mi_planes_layout(0, 1)
+
+    def eval_descs(descs):
+        planes = env.planes_from_descs_host(b"".join(descs), len(descs), layout, True)
+        v, p, _ = ro.predict(cfg, sd, torch.from_numpy(planes))
+        return v.numpy(), p.numpy()
+
+    pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=trees * quota, fn_nb_policy=cfg.nb_policy)
+    fens = openings.position_fens("crazyhouse")
+    for i in range(trees):
+        pool.add_position(fens[(i * 7) % len(fens)], False, "crazyhouse")
+    stt = pool.run(simulations=simulations, threads=min(cores, trees))
+    pool.close()
+    return {"mcts_nodes_per_sec": round(stt.nodes / stt.seconds, 1), "mcts_nn_evals_per_sec": round(stt.nn_evals / stt.seconds, 1),
+            "mcts_sample": f"{trees} trees x {simulations} simulations of the opening set, C++ leaf collector + oracle CPU net "
+                           f"behind the evaluator callback, {stt.seconds:.1f} s"}
 
 
 def main():

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mi_planes_channels": (C.c_int, [C.c_int]),
     "mi_pos_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mi_pos_desc": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi_planes_from_descs_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p]),
     "mi_planes_from_descs_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     # policy
     "mi_policy_nb_labels": (C.c_int, [C.c_int]),

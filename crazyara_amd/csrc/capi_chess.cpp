@@ -89,6 +89,17 @@ int mi_pos_desc(const mi_pos* pos, void* desc192) {
     pack_desc(pos->pos, *static_cast<BoardDesc*>(desc192));
     return 0;
 }
+int mi_planes_from_descs_host(const void* descs, int n, int layout, int normalize, float* out) {
+    if (!descs || !out || n < 0) { cra_set_error("bad argument"); return 1; }
+    return cra_guard([&] {
+        const int C = layout_channels(layout);
+        if (C <= 0) throw std::invalid_argument("unknown plane layout");
+        const BoardDesc* d = static_cast<const BoardDesc*>(descs);
+        for (int b = 0; b < n; ++b)
+            for (int i = 0; i < C * 64; ++i) out[size_t(b) * C * 64 + i] = plane_value(d[b], layout, normalize != 0, i >> 6, i & 63);
+    });
+}
+
 int mi_planes_from_descs_device(const void* descs_host, int n, int layout, int normalize, float* d_planes, int device_id) {
     if (!descs_host || !d_planes || n <= 0 || layout_channels(layout) == 0) { cra_set_error("bad argument"); return 1; }
     return cra_guard([&] {

@@ -112,3 +112,13 @@ def planes_from_descs_device(descs: bytes, n: int, layout: int, normalize: bool,
     lib = _capi.load()
     if lib.mi_planes_from_descs_device(descs, n, layout, int(normalize), d_planes_ptr, device_id):
         raise RuntimeError(_capi.last_error())
+
+
+def planes_from_descs_host(descs: bytes, n: int, layout: int, normalize: bool = True) -> np.ndarray:
+    """n 192-byte descriptors -> float planes [n][C][8][8] on the host (the input of a CPU net behind the same leaf collector)."""
+    lib = _capi.load()
+    c = lib.mi_planes_channels(layout)
+    out = np.empty((n, c, 8, 8), np.float32)
+    if lib.mi_planes_from_descs_host(descs, n, layout, int(normalize), out.ctypes.data_as(_capi.c_float_p)):
+        raise RuntimeError(_capi.last_error())
+    return out

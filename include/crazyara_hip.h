@@ -113,6 +113,8 @@ int mi_planes_channels(int layout);                       /* NB_CHANNELS_TOTAL o
 int mi_pos_planes(const mi_pos* pos, int layout, int normalize, int repetitions, float* out);
 /* compact 192-byte descriptor of the position (struct BoardDesc, crazyara_amd/csrc/chess/planes.h) */
 int mi_pos_desc(const mi_pos* pos, void* desc192);
+/* host builder from descriptors: out[n][C*64] floats (what a CPU NeuralNetAPI behind the same leaf collector is fed) */
+int mi_planes_from_descs_host(const void* descs, int n, int layout, int normalize, float* out);
 /* GPU builder: n host descriptors -> d_planes (device) [n][C][64] float, blocking */
 int mi_planes_from_descs_device(const void* descs_host, int n, int layout, int normalize, float* d_planes, int device_id);
 /* predict() fed by descriptors instead of float planes: H2D of 192 B/board, planes built on the GPU straight into the

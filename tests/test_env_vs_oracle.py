@@ -137,3 +137,21 @@ def test_reference_calibration_games_replay_identically(variant, hip_lib):
                 mode = 0 if variant == "crazyhouse" else 1
                 assert np.array_equal(p.planes(mode, 3, True), co.board_to_planes(b, mode, 3, True))
     assert len(openings.position_fens("crazyhouse")) > 200
+
+
+def test_host_planes_from_descriptors_equal_position_planes(hip_lib):
+    """mi_planes_from_descs_host (the CPU evaluator's input builder) == board_to_planes of the positions, all layouts of a mode."""
+    fens = [("r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] b KQkq - 0 8", "crazyhouse", 0, (1, 2, 3)),
+            ("r3k2r/pppq1ppp/2npbn2/2b1p3/2B1P3/2NPBN2/PPPQ1PPP/R3K2R w KQkq - 4 8", "chess", 1, (3,)),
+            ("1r4k1/1p2bp1p/3p2p1/PprPp2n/1R2PPq1/3Q4/1P1B1NPP/5RK1 b - - 1+1 2 22", "3check", 2, (1, 3))]
+    lib = env._capi.load()
+    for fen, variant, mode, versions in fens:
+        p = env.Position(fen, False, variant)
+        p.push(p.legal_moves()[0])
+        q = p.clone()
+        q.push(q.legal_moves()[-1])
+        for v in versions:
+            layout = lib.mi_planes_layout(mode, v)
+            got = env.planes_from_descs_host(p.desc() + q.desc(), 2, layout, True)
+            assert np.array_equal(got[0].reshape(-1), p.planes(mode, v, True).reshape(-1))
+            assert np.array_equal(got[1].reshape(-1), q.planes(mode, v, True).reshape(-1))

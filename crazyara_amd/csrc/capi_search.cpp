@@ -124,6 +124,26 @@ int mi_search_add_position(mi_search* sp, const char* fen, int is_chess960, cons
     return id;
 }
 
+int mi_search_apply_move(mi_search* sp, int tree, const char* uci, int* kept) {
+    if (!sp || !uci) { cra_set_error("null argument"); return 1; }
+    return cra_guard([&] {
+        Tree& t = sp->pool->tree(tree);
+        const chess::Move m = t.root_position().uci_to_move(uci);
+        if (m == chess::MOVE_NONE) throw std::invalid_argument(std::string("not a legal move here: ") + uci);
+        const bool k = t.apply_move(m);
+        if (kept) *kept = k ? 1 : 0;
+    });
+}
+
+int mi_search_tree_fen(mi_search* sp, int tree, char* fen, int cap) {
+    if (!sp || !fen) { cra_set_error("null argument"); return 1; }
+    return cra_guard([&] {
+        const std::string s = sp->pool->tree(tree).root_position().fen();
+        if (int(s.size()) + 1 > cap) throw std::invalid_argument("fen buffer too small");
+        std::memcpy(fen, s.c_str(), s.size() + 1);
+    });
+}
+
 int mi_search_run(mi_search* sp, unsigned simulations, unsigned nodes, int threads, mi_search_stats* stats) {
     if (!sp) { cra_set_error("null search"); return 1; }
     return cra_guard([&] {

@@ -115,6 +115,48 @@ void Tree::begin_search() {
     while (size_t(n.no_visit_idx) < n.actions.size()) increment_no_visit_idx(n);
 }
 
+// Tree reuse.  The reference keeps shared_ptr subtrees (pick_next_node) and lets the rest of the old tree die; here the kept
+// subtree is copied breadth-first into a fresh node array (indices are the links), everything else is dropped.
+bool Tree::apply_move(Move m) {
+    if (!new_nodes_.empty() || !collision_trajectories_.empty()) throw std::logic_error("apply_move with a batch in flight");
+    const Node& r = nodes_[0];
+    int child = -1;
+    if (r.has_data) {
+        for (int i = 0; i < int(r.no_visit_idx); ++i)
+            if (r.actions[i] == m) { child = r.child[i]; break; }
+    }
+    bool legal = false;
+    for (Move a : r.actions) legal |= a == m;
+    if (!legal && !r.terminal) {
+        std::vector<Move> lm;
+        root_pos_.legal_moves(lm);
+        for (Move a : lm) legal |= a == m;
+    }
+    if (!legal) throw std::invalid_argument("apply_move: illegal move " + root_pos_.move_to_uci(m));
+    root_pos_.do_move(m);
+    // get_root_node_from_tree: the candidate must be a playout node (has NodeData) with at least one visit below it
+    const bool keep = child >= 0 && nodes_[child].has_data && nodes_[child].has_nn && !nodes_[child].terminal && nodes_[child].visit_sum > 0;
+    std::vector<Node> fresh;
+    if (keep) {
+        std::vector<int> order{child};               // breadth-first copy; remap[i] = new index of old node order[i]
+        fresh.reserve(8192);
+        for (size_t head = 0; head < order.size(); ++head) {
+            fresh.push_back(std::move(nodes_[order[head]]));
+            Node& n = fresh.back();
+            for (int32_t& c : n.child)
+                if (c >= 0) { order.push_back(c); c = int32_t(order.size()) - 1; }
+        }
+        nodes_.swap(fresh);
+    } else {
+        nodes_.clear();
+        nodes_.reserve(8192);
+        new_node(root_pos_);
+    }
+    depth_sum = 0;
+    depth_max = 0;
+    return keep;
+}
+
 // sort_moves_by_probabilities + init_node_data (node.cpp:464-470, 634-643, nodedata.cpp:40-57).
 // The reference uses an unstable std::sort with greater<float>; ties are broken by the original index here.
 void Tree::prepare_node_for_visits(Node& n) {

@@ -110,6 +110,12 @@ public:
     void set_root_result(float value, const float* probs);
     // start of a `go` (MCTSAgent::evaluate_board_state, mctsagent.cpp:311-316): Dirichlet noise + full expansion of the root
     void begin_search();
+    // A move was played on the board (MCTSAgent::apply_move_to_tree + get_root_node_from_tree, mctsagent.cpp:230-247,130-164):
+    // the subtree below that move becomes the tree if the child is a playout node with visits, otherwise the tree restarts
+    // from the new position.  Returns true when the subtree was kept.  The move must be legal in the root position.
+    bool apply_move(chess::Move m);
+    // replace the search settings for the following searches (quick-search switches of self-play, selfplay.cpp:217-222)
+    void set_search_settings(const SearchSettings& s) { s_ = s; }
 
     // --- SearchThread::create_mini_batch (searchthread.cpp:347-380) with `quota` in the role of batchSize ---
     // Writes one BoardDesc per NEW leaf to descs[0..returned).  Terminals are backed up immediately, collisions are

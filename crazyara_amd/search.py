@@ -83,6 +83,19 @@ class SearchPool:
         self._lib.mi_search_tree_info(self._h, tree, C.byref(rv), C.byref(nc), C.byref(alloc), C.byref(val))
         return dict(root_visits=rv.value, node_count=nc.value, allocated=alloc.value, root_value=val.value)
 
+    def apply_move(self, tree: int, uci: str) -> bool:
+        """A move was played on the tree's board: keep the searched subtree below it (True) or restart from the new position."""
+        kept = C.c_int()
+        if self._lib.mi_search_apply_move(self._h, tree, uci.encode(), C.byref(kept)):
+            raise ValueError(_capi.last_error())
+        return bool(kept.value)
+
+    def fen(self, tree: int) -> str:
+        buf = C.create_string_buffer(256)
+        if self._lib.mi_search_tree_fen(self._h, tree, buf, 256):
+            raise RuntimeError(_capi.last_error())
+        return buf.value.decode()
+
     def add_lane(self, net) -> None:
         """One more evaluator lane (call before add_position): one more batch in flight."""
         if self._lib.mi_search_add_lane(self._h, net._h):

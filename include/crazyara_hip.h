@@ -180,6 +180,11 @@ int mi_search_add_lane(mi_search* sp, mi_net* net);
 void mi_search_destroy(mi_search* sp);
 int mi_search_add_position(mi_search* sp, const char* fen, int is_chess960, const char* variant);   /* returns tree id or -1 */
 /* go with Simulations / Nodes limits per tree (searchthread.cpp:326-331); threads = host collector threads */
+/* a move was played on the board of tree `tree` (own move or the opponent's reply): keep the subtree below it as the new tree
+ * if it was searched, else restart from the new position -- MCTSAgent::apply_move_to_tree + get_root_node_from_tree
+ * (mctsagent.cpp:130-164,230-247).  *kept = 1 if the subtree was reused.  uci must be a legal move of the tree's root position. */
+int mi_search_apply_move(mi_search* sp, int tree, const char* uci, int* kept);
+int mi_search_tree_fen(mi_search* sp, int tree, char* fen, int cap);   /* FEN of the tree's root position */
 int mi_search_run(mi_search* sp, unsigned simulations, unsigned nodes, int threads, mi_search_stats* stats);
 /* root statistics of one tree, children in the node's (prior-sorted) order: returns number of expanded children */
 int mi_search_root_children(mi_search* sp, int tree, int cap, uint32_t* moves, uint32_t* visits, float* q, float* priors);

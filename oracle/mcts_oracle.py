@@ -178,6 +178,30 @@ class Tree:
         while n.no_visit_idx < len(n.moves):
             self.increment_no_visit_idx(n)
 
+    def apply_move(self, uci):
+        """MCTSAgent::apply_move_to_tree + get_root_node_from_tree (mctsagent.cpp:130-164,230-247): the subtree below the played
+        move becomes the tree if that child is a playout node with visits; otherwise the tree restarts at the new position."""
+        r = self.root
+        move = None
+        for m in (r.moves if r.moves else self.root_board.legal_moves()):
+            if self.root_board.move_uci(m) == uci:
+                move = m
+        if move is None:
+            for m in self.root_board.legal_moves():
+                if self.root_board.move_uci(m) == uci:
+                    move = m
+        assert move is not None, "illegal move " + uci
+        child = None
+        if r.has_data:
+            for i in range(r.no_visit_idx):
+                if r.uci[i] == uci:
+                    child = r.child[i]
+        self.root_board = self.root_board.copy()
+        self.root_board.push(move)
+        keep = child is not None and child.has_data and child.has_nn and not child.terminal and child.visit_sum > 0
+        self.root = child if keep else Node(self.root_board, self.pm, self.s)
+        return keep
+
     def prepare(self, n: Node):
         order = sorted(range(len(n.moves)), key=lambda i: (-float(n.priors[i]), i))
         n.moves = [n.moves[i] for i in order]

@@ -382,3 +382,56 @@ def test_search_limits_and_terminal_root(hip_lib):
     with pytest.raises(RuntimeError):
         pool.run(0, 0, 1)
     pool.close()
+
+
+@pytest.mark.parametrize("variant,is960,fen,mode,plies,sims", [
+    ("crazyhouse", False, "", 0, 10, 120),
+    ("chess", True, "bnnrkbrq/pppppppp/8/8/8/8/PPPPPPPP/BNNRKBRQ w GDgd - 0 1", 1, 8, 100),
+    ("3check", False, "1r4k1/1p2bp1p/3p2p1/PprPp2n/1R2PPq1/3Q4/1P1B1NPP/5RK1 b - - 1+1 2 22", 2, 8, 100),
+])
+def test_tree_reuse_across_played_moves_equals_oracle(hip_lib, variant, is960, fen, mode, plies, sims):
+    """A game fragment: search, play the chosen move (mi_search_apply_move keeps the subtree below it), search again from the
+    kept subtree ... -- the statistics must stay bit-identical to the oracle's tree, which simply follows its child pointer.
+    Every second move is an unsearched "opponent surprise" (the least visited legal move), which forces a restart."""
+    nbp, quota = NB_POLICY[mode], 8
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota)
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    def eval_boards(boards):
+        out = [_pseudo_net(key_from_board(b), nbp) for b in boards]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=quota, fn_nb_policy=nbp)
+    t = pool.add_position(fen, is960, variant)
+    tree = mo.Tree(co.Board(fen or None, is960, variant), mo.Settings(mode=mode, is_policy_map=True, batch_size=quota))
+    kept_any = restarted_any = False
+    for ply in range(plies):
+        pool.run(simulations=sims, threads=1)
+        mo.run_search(tree, eval_boards, sims, quota)
+        if tree.root.terminal:
+            break
+        moves, visits, q, _ = pool.root_children(t)
+        r = tree.root
+        assert visits == r.child_visits and np.array_equal(q, np.array(r.q, np.float32))
+        assert pool.tree_info(t)["root_visits"] == r.visit_sum and pool.tree_info(t)["node_count"] == tree.node_count()
+        best = pool.best_move(t)
+        assert best == tree.best_move()[0]
+        if ply % 3 == 2:                                   # a reply the search never expanded
+            legal = env.Position(pool.fen(t), is960, variant).legal_uci()
+            expanded = set(r.uci[:r.no_visit_idx])
+            surprise = [u for u in legal if u not in expanded]
+            best = surprise[0] if surprise else best
+        kept = pool.apply_move(t, best)
+        assert kept == tree.apply_move(best)
+        kept_any |= kept
+        restarted_any |= not kept
+        assert pool.fen(t) == env.Position(tree.root_board.fen(), is960, variant).fen()
+        if kept:                                           # the kept subtree starts the next search with its visits
+            assert pool.tree_info(t)["root_visits"] == tree.root.visit_sum > 0
+    assert kept_any and restarted_any
+    with pytest.raises(ValueError):
+        pool.apply_move(t, "a1a1")
+    pool.close()

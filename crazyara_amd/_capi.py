@@ -45,6 +45,8 @@ SIGNATURES = {
     "mi_pos_do_move": (C.c_int, [C.c_void_p, C.c_uint32]),
     "mi_pos_terminal": (C.c_int, [C.c_void_p]),
     "mi_pos_number_repetitions": (C.c_int, [C.c_void_p]),
+    "mi_pos_in_check": (C.c_int, [C.c_void_p]),
+    "mi_pos_move_to_san": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int]),
     "mi_pos_perft": (C.c_ulonglong, [C.c_void_p, C.c_int]),
     "mi_chess960_start_fen": (C.c_char_p, [C.c_int]),
     # planes
@@ -68,6 +70,8 @@ SIGNATURES = {
     "mi_search_run": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_void_p]),
     "mi_search_root_children": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), c_float_p, c_float_p]),
     "mi_search_tree_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), c_float_p]),
+    "mi_search_root_policy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), c_float_p]),
+    "mi_search_reset_position": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p]),
     "mi_search_apply_move": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_int)]),
     "mi_search_tree_fen": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "mi_search_add_lane": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -69,6 +69,20 @@ int mi_pos_terminal(const mi_pos* pos) {
     pos->pos.legal_moves(v);
     return int(pos->pos.is_terminal(v.size()));
 }
+int mi_pos_move_to_san(const mi_pos* pos, uint32_t move, char* buf, int cap) {
+    if (!pos || !buf) return -1;
+    int n = -1;
+    cra_guard([&] {
+        const std::string s = pos->pos.move_to_san(move);
+        if (int(s.size()) + 1 > cap) throw std::invalid_argument("buffer too small");
+        std::memcpy(buf, s.c_str(), s.size() + 1);
+        n = int(s.size());
+    });
+    return n;
+}
+
+int mi_pos_in_check(const mi_pos* pos) { return pos && pos->pos.checkers() != 0 ? 1 : 0; }
+
 int mi_pos_number_repetitions(const mi_pos* pos) { return pos ? pos->pos.number_repetitions() : -1; }
 unsigned long long mi_pos_perft(const mi_pos* pos, int depth) { return pos ? pos->pos.perft(depth) : 0; }
 const char* mi_chess960_start_fen(int idx) {

@@ -4,6 +4,7 @@
 #include <malloc.h>
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -195,6 +196,32 @@ int mi_search_root_solved(mi_search* sp, int tree, int* node_type, int* end_in_p
         if (node_type) *node_type = t.root().node_type;
         if (end_in_ply) *end_in_ply = t.root().end_in_ply;
         if (checkmate_idx) *checkmate_idx = t.root().checkmate_idx;
+    });
+}
+
+int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, float* best_move_q) {
+    int n = -1;
+    if (!sp) { cra_set_error("null search"); return n; }
+    cra_guard([&] {
+        Tree& t = sp->pool->tree(tree);
+        std::vector<double> pol;
+        const int b = t.best_move_index(&pol);
+        if (b < 0) { n = 0; return; }
+        if (int(pol.size()) > cap) throw std::invalid_argument("policy buffer too small");
+        if (policy) std::copy(pol.begin(), pol.end(), policy);
+        if (best_move_q) *best_move_q = t.root().q[b];
+        n = int(pol.size());
+    });
+    return n;
+}
+
+int mi_search_reset_position(mi_search* sp, int tree, const char* fen, int is_chess960, const char* variant) {
+    if (!sp) { cra_set_error("null search"); return 1; }
+    return cra_guard([&] {
+        const chess::Variant v = chess::variant_from_name(variant && *variant ? variant : "chess");
+        chess::Position p;
+        p.set(fen && *fen ? std::string(fen) : chess::start_fen(v), is_chess960 != 0, v);
+        sp->pool->reset_position(tree, p);
     });
 }
 

@@ -601,6 +601,42 @@ std::string Position::move_to_uci(Move m) const {
     return s;
 }
 
+std::string Position::move_to_san(Move m) const {
+    if (m == MOVE_NONE) return "(none)";
+    const int from = from_sq(m), to = to_sq(m);
+    const MoveKind kind = kind_of(m);
+    std::string s;
+    if (kind == CASTLING) {
+        s = file_of(from) < file_of(to) ? "O-O" : "O-O-O";         // king-takes-rook encoding: the rook's file tells the side
+    } else if (kind == DROP) {
+        s = std::string{kPieceChars[piece_of(m)], '@'} + sq_str(to);
+    } else {
+        const int piece = board_[from], type = piece & 7;
+        const bool capture = board_[to] != 0 || kind == ENPASSANT;
+        std::string amb;
+        if (type != PAWN) {
+            bool ambiguous = false, same_file = false, same_rank = false;
+            std::vector<Move> moves;
+            legal_moves(moves);
+            for (Move o : moves) {
+                if (kind_of(o) == DROP) continue;
+                const int of = from_sq(o);
+                if (to_sq(o) == to && of != from && board_[of] == piece) {
+                    ambiguous = true;
+                    same_file |= file_of(of) == file_of(from);
+                    same_rank |= rank_of(of) == rank_of(from);
+                }
+            }
+            if (ambiguous) amb = same_file && same_rank ? sq_str(from) : same_file ? std::string(1, char('1' + rank_of(from))) : std::string(1, char('a' + file_of(from)));
+        }
+        if (type == PAWN) s = capture ? std::string(1, char('a' + file_of(from))) + "x" + sq_str(to) : sq_str(to);
+        else s = std::string(1, kPieceChars[type]) + amb + (capture ? "x" : "") + sq_str(to);
+        if (kind == PROMOTION) s += kPieceChars[piece_of(m)];
+    }
+    if (gives_check(m)) s += "+";
+    return s;
+}
+
 Move Position::uci_to_move(const std::string& uci) const {
     std::string s = uci;
     if (s.size() == 5) s[4] = char(std::tolower(static_cast<unsigned char>(s[4])));

@@ -97,6 +97,9 @@ public:
     // known_key: the position key after the move if the caller has it (a search tree node remembers its key): saves the recomputation
     void do_move(Move m, const Key* known_key);
     Move uci_to_move(const std::string& uci) const;            // UCI::to_move; MOVE_NONE if not legal
+    // pgn_move (board.cpp:277-359) without the {book} / '#' decorations: the reference's own SAN dialect -- promotions without
+    // '=', pawn drops as "P@e4", disambiguation by is_pgn_move_ambiguous (board.cpp:362-383), '+' when the move gives check
+    std::string move_to_san(Move m) const;
     std::string move_to_uci(Move m) const;                     // UCI::move (castling: e1g1 classic, king-takes-rook in 960)
     // origin/destination as the policy labels see them (castling: classic -> king's two-step target, 960 -> rook square)
     void label_squares(Move m, int& from, int& to) const;

@@ -171,6 +171,12 @@ int SearchPool::add_position(const chess::Position& pos) {
     return id;
 }
 
+void SearchPool::reset_position(int i, const chess::Position& pos) {
+    SearchSettings st = s_;
+    st.seed = s_.seed + uint32_t(i);
+    trees_.at(i).reset(new Tree(pos, st));
+}
+
 bool SearchPool::tree_done(const Tree& t, uint32_t simulations, uint32_t nodes) const {
     if (t.root().terminal || t.root_solved()) return true;
     if (simulations && t.root_visits() >= simulations) return true;

@@ -79,6 +79,7 @@ public:
     // (SearchThread::nodes_limits_ok, searchthread.cpp:326-331)
     void run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats);
     Tree& tree(int i) { return *trees_.at(i); }
+    void reset_position(int i, const chess::Position& pos);   // a new game in slot i (same lane, same exploration stream seed)
     int n_trees() const { return int(trees_.size()); }
     const SearchSettings& settings() const { return s_; }
 

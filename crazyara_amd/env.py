@@ -42,6 +42,12 @@ class Position:
         self._lib.mi_pos_move_to_uci(self._h, move, buf, 16)
         return buf.value.decode()
 
+    def move_san(self, move: int) -> str:
+        buf = C.create_string_buffer(16)
+        if self._lib.mi_pos_move_to_san(self._h, move, buf, 16) < 0:
+            raise ValueError(_capi.last_error())
+        return buf.value.decode()
+
     def legal_uci(self) -> List[str]:
         return sorted(self.move_uci(m) for m in self.legal_moves())
 
@@ -61,6 +67,9 @@ class Position:
 
     def terminal(self) -> int:
         return self._lib.mi_pos_terminal(self._h)
+
+    def in_check(self) -> bool:
+        return bool(self._lib.mi_pos_in_check(self._h))
 
     def number_repetitions(self) -> int:
         return self._lib.mi_pos_number_repetitions(self._h)

@@ -96,6 +96,19 @@ class SearchPool:
             raise RuntimeError(_capi.last_error())
         return buf.value.decode()
 
+    def root_policy(self, tree: int):
+        """(policy over the expanded root children as Node::get_mcts_policy returns it, Q of the best move)."""
+        buf = (C.c_double * 512)()
+        q = C.c_float()
+        n = self._lib.mi_search_root_policy(self._h, tree, 512, buf, C.byref(q))
+        if n < 0:
+            raise RuntimeError(_capi.last_error())
+        return np.array(buf[:n], np.float64), float(q.value)
+
+    def reset_position(self, tree: int, fen: str = "", is960: bool = False, variant: str = "crazyhouse") -> None:
+        if self._lib.mi_search_reset_position(self._h, tree, (fen or "").encode(), int(is960), variant.encode()):
+            raise ValueError(_capi.last_error())
+
     def add_lane(self, net) -> None:
         """One more evaluator lane (call before add_position): one more batch in flight."""
         if self._lib.mi_search_add_lane(self._h, net._h):

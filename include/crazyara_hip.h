@@ -98,9 +98,12 @@ int mi_pos_side_to_move(const mi_pos* pos);                            /* 0 whit
 int mi_pos_legal_moves(const mi_pos* pos, uint32_t* moves, int cap);   /* BoardState::legal_actions; returns count */
 uint32_t mi_pos_uci_to_move(const mi_pos* pos, const char* uci);       /* uci_to_action; 0 if not legal */
 int mi_pos_move_to_uci(const mi_pos* pos, uint32_t move, char* buf, int cap);  /* StateConstants::action_to_uci */
+/* SAN in the reference's dialect (pgn_move, board.cpp:277-359): "Nbd7", "exd5", "e8Q", "P@e4", "O-O", '+' on check */
+int mi_pos_move_to_san(const mi_pos* pos, uint32_t move, char* buf, int cap);
 int mi_pos_do_move(mi_pos* pos, uint32_t move);                        /* do_action */
 int mi_pos_terminal(const mi_pos* pos);                                /* is_terminal(legal count) -> MI_TERMINAL_* */
 int mi_pos_number_repetitions(const mi_pos* pos);
+int mi_pos_in_check(const mi_pos* pos);                                /* 1 if the side to move is in check (Position::checkers) */
 unsigned long long mi_pos_perft(const mi_pos* pos, int depth);
 const char* mi_chess960_start_fen(int scharnagl_index);                /* deterministic stand-in for chess960fen() */
 
@@ -192,7 +195,12 @@ int mi_search_tree_info(mi_search* sp, int tree, unsigned* root_visits, unsigned
 /* solver state of the root (NodeData::nodeType / endInPly / checkmateIdx, nodedata.h:88-121): node_type 0 WIN, 1 DRAW, 2 LOSS,
  * 6 UNSOLVED (NodeType, nodedata.h:40-52); end_in_ply = plies to the proven terminal; checkmate_idx = mating child or -1 */
 int mi_search_root_solved(mi_search* sp, int tree, int* node_type, int* end_in_ply, int* checkmate_idx);
-int mi_search_best_move(mi_search* sp, int tree, char* uci, int cap);   /* argmax of Node::get_mcts_policy, node.cpp:1070-1109 */
+int mi_search_best_move(mi_search* sp, int tree, char* uci, int cap);
+/* the whole Node::get_mcts_policy vector of the root (EvalInfo::policyProbSmall, one entry per expanded child in the order of
+ * mi_search_root_children) and the Q value of the best move (EvalInfo::bestMoveQ); returns the number of entries or -1 */
+int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, float* best_move_q);
+/* start a new game on an existing tree slot: the tree restarts from this position (clean_up / clear_game_history, selfplay.cpp:305-309) */
+int mi_search_reset_position(mi_search* sp, int tree, const char* fen, int is_chess960, const char* variant);   /* argmax of Node::get_mcts_policy, node.cpp:1070-1109 */
 
 #ifdef __cplusplus
 }

@@ -93,3 +93,30 @@ def test_lane_count_does_not_change_the_trees(tmp_path, hip_lib):
     for (visits, bm), f in zip(results[0], fens):
         assert sum(visits) >= 160 and bm in env.Position(f, False, "crazyhouse").legal_uci()
         assert len(visits) == len(env.Position(f, False, "crazyhouse").legal_uci())      # Dirichlet: root fully expanded
+
+
+def test_selfplay_loop_on_the_gpu_chess960(tmp_path, hip_lib):
+    """BASELINE config 4 in miniature: concurrent chess960 self-play games on one GPU with a real (random-init) net: raw-policy
+    opening plies, temperature sampling, tree reuse; every recorded move is legal and every game ends."""
+    from crazyara_amd import _capi, selfplay
+    cfg, sd, _ = nn_cases.make_case("risev33")
+    d = nn_cases.export_case(tmp_path, "risev33", cfg, sd, version="3.0")
+    a, b, raw = (HipAPI(0, 32, d, "float16") for _ in range(3))
+    st = search.default_settings(mode=1, version_major=3, batch_size=8, seed=4)
+    pool = search.SearchPool(st, net_a=a, net_b=b)
+    s = selfplay.SelfPlaySettings(variant="chess", is960=True, simulations=40, max_plies=40, mean_init_ply=3.0,
+                                  init_temperature=0.8, temperature_moves=6, temperature_decay=0.9, seed=2)
+    lib = _capi.load()
+    loop = selfplay.SelfPlay(pool, s, 8, start_fen=lambda i: lib.mi_chess960_start_fen((i * 91 + 5) % 960).decode(),
+                             raw_policy=selfplay.net_raw_policy(raw, 1, 3))
+    games = loop.play(10, threads=4)
+    assert len(games) == 10 and loop.stats["kept_subtrees"] > 0 and loop.stats["nn_evals"] > 0
+    assert len({g.start_fen for g in games}) > 1
+    for g in games:
+        p = env.Position(g.start_fen, True, "chess")
+        for u in g.uci:
+            assert p.push_uci(u), (g.start_fen, g.uci, u)
+        assert g.result in (1, 0, -1) and g.variant == "chess960" and (p.terminal() != env.TERMINAL_NONE) == (g.termination == "terminal")
+    pool.close()
+    for n in (a, b, raw):
+        n.close()

@@ -1,0 +1,120 @@
+"""Self-play game loop (crazyara_amd/selfplay.py) on the CPU with the deterministic pseudo-network: games are legal move by
+move (replayed on the oracle board), results agree with the oracle's terminal verdict, the run replays, PGN has the reference's
+shape; SAN follows the reference's dialect (pgn_move, board.cpp:277-359)."""
+import zlib
+
+import numpy as np
+import pytest
+
+from crazyara_amd import env, search, selfplay
+from oracle import chess_oracle as co
+
+from test_mcts import NB_POLICY, _pseudo_net, key_from_desc
+
+
+@pytest.mark.parametrize("fen,variant,uci,san", [
+    ("r1bqkb1r/pppp1ppp/2n2n2/4p3/4P3/2N2N2/PPPP1PPP/R1BQKB1R w KQkq - 4 4", "chess", "f1b5", "Bb5"),
+    ("rnbqkbnr/ppp1pppp/8/3p4/4P3/8/PPPP1PPP/RNBQKBNR w KQkq d6 0 2", "chess", "e4d5", "exd5"),
+    ("rnbqkbnr/ppp1p1pp/8/3pPp2/8/8/PPPP1PPP/RNBQKBNR w KQkq f6 0 3", "chess", "e5f6", "exf6"),                # en passant
+    ("r1bqkbnr/pppp1ppp/2n5/4p3/4P3/5N2/PPPP1PPP/RNBQKB1R w KQkq - 2 3", "chess", "b1c3", "Nc3"),              # only one knight reaches c3
+    ("r2qkbnr/ppp2ppp/2np4/4p3/4P1b1/2NP1N2/PPP2PPP/R1BQKB1R w KQkq - 1 5", "chess", "c3e2", "Ne2"),           # f3 knight is pinned
+    ("4k3/8/8/8/8/8/8/RN2K1NR w KQ - 0 1", "chess", "g1f3", "Nf3"),
+    ("4k3/8/8/8/8/2N5/8/4K1N1 w - - 0 1", "chess", "c3e2", "Nce2"),                                            # file disambiguation
+    ("4k3/8/8/8/R7/8/8/R3K3 w Q - 0 1", "chess", "a1a3", "R1a3"),                                              # same file -> rank
+    ("6k1/8/8/8/Q2Q4/8/8/Q3K3 w - - 0 1", "chess", "a4d1", "Qa4d1"),    # a1 shares the file, d4 the rank with a4 -> full square
+    ("3k4/4P3/8/8/8/8/8/4K3 w - - 0 1", "chess", "e7e8q", "e8Q+"),                                             # promotion without '='
+    ("r3k2r/8/8/8/8/8/8/R3K2R w KQkq - 0 1", "chess", "e1g1", "O-O"),
+    ("r3k2r/8/8/8/8/8/8/R3K2R b KQkq - 0 1", "chess", "e8c8", "O-O-O"),
+    ("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR[Nn] w KQkq - 0 1", "crazyhouse", "N@f3", "N@f3"),
+    ("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR[Pp] w KQkq - 0 1", "crazyhouse", "P@e4", "P@e4"),
+    ("6k1/5ppp/8/8/8/8/8/R3K3 w Q - 0 1", "chess", "a1a8", "Ra8+"),                                           # '+': the game loop turns it into '#'
+])
+def test_san_dialect(hip_lib, fen, variant, uci, san):
+    p = env.Position(fen, False, variant)
+    m = p.uci_to_move(uci)
+    assert m != 0, (fen, uci)
+    assert p.move_san(m) == san
+
+
+def _pool(mode, quota, n_slots_batch):
+    nbp = NB_POLICY[mode]
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota)
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    return search.SearchPool(st, eval_fn=eval_descs, fn_batch=n_slots_batch, fn_nb_policy=nbp)
+
+
+def _raw_policy_from_pseudo_net(mode):
+    nbp = NB_POLICY[mode]
+
+    def evaluate(positions):
+        out = []
+        for p in positions:
+            probs = _pseudo_net(key_from_desc(p.desc()), nbp)[1]
+            out.append(np.array([probs[p.policy_index(m, mode, True)] for m in p.legal_moves()], np.float64))
+        return out
+    return evaluate
+
+
+def _play(variant, mode, n_games, concurrent, **kw):
+    pool = _pool(mode, 8, 8 * concurrent)
+    s = selfplay.SelfPlaySettings(variant=variant, simulations=48, max_plies=60, seed=3, **kw)
+    loop = selfplay.SelfPlay(pool, s, concurrent, raw_policy=_raw_policy_from_pseudo_net(mode))
+    games = loop.play(n_games, threads=2)
+    stats = dict(loop.stats)
+    pool.close()
+    return games, stats
+
+
+@pytest.mark.parametrize("variant,mode,kw", [
+    ("crazyhouse", 0, dict(mean_init_ply=4.0, raw_policy_prob_temperature=0.5, init_temperature=0.8, temperature_moves=6,
+                           temperature_decay=0.9, quantile_clipping=0.25)),
+    ("chess", 1, dict()),
+    ("3check", 2, dict(resign_probability=1.0, resign_threshold=0.05)),
+])
+def test_games_are_legal_finish_and_replay(hip_lib, variant, mode, kw):
+    games, stats = _play(variant, mode, 5, 3, **kw)
+    assert len(games) == 5 and stats["moves"] > 0 and stats["nodes"] > 0 and stats["kept_subtrees"] > 0
+    for g in games:
+        b = co.Board(g.start_fen, False, variant)
+        for u in g.uci:                                           # every move legal on the oracle board, in order
+            legal = {b.move_uci(m): m for m in b.legal_moves()}
+            assert u in legal, (g.start_fen, g.uci, u)
+            b.push(legal[u])
+        assert g.result in (1, 0, -1) and g.termination in ("terminal", "resignation", "ply limit")
+        t = b.terminal()
+        if g.termination == "terminal":
+            assert t != co.TERMINAL_NONE
+            if t == co.TERMINAL_DRAW:
+                assert g.result == 0
+            else:
+                loser_is_stm = t == co.TERMINAL_LOSS
+                stm_white = b.stm == 0
+                assert g.result == ((-1 if stm_white else 1) if loser_is_stm else (1 if stm_white else -1))
+                assert g.san[-1].endswith("#")
+        else:
+            assert t == co.TERMINAL_NONE
+        if g.termination == "ply limit":
+            assert len(g.uci) >= 60 and g.result == 0
+        assert len(g.san) == len(g.uci) and all(s.endswith(" {book}") for s in g.san[:g.book_plies])
+        pgn = g.pgn()
+        assert pgn.startswith('[Variant "') and f'[PlyCount "{len(g.san)}"]' in pgn and "1. " in pgn
+        assert pgn.rstrip().endswith(selfplay.RESULT_STR[g.result])
+    again, _ = _play(variant, mode, 5, 3, **kw)
+    assert [(g.uci, g.result) for g in again] == [(g.uci, g.result) for g in games]       # seeded: the run replays
+    if kw.get("resign_probability"):
+        assert any(g.termination == "resignation" for g in games)
+    if kw.get("mean_init_ply"):
+        assert any(g.book_plies > 0 for g in games)
+
+
+def test_sampling_helpers():
+    p = np.array([0.5, 0.3, 0.15, 0.05])
+    assert np.allclose(selfplay.apply_temperature(p, 1.0), p)
+    q = selfplay.apply_temperature(p, 0.5)
+    assert np.allclose(q, p ** 2 / (p ** 2).sum()) and q[0] > p[0]
+    c = selfplay.apply_quantile_clipping(0.25, p)                 # the smallest entries covering < 25 % of the mass are dropped
+    assert c[3] == 0 and c[2] == 0 and abs(c.sum() - 1) < 1e-12 and np.allclose(c[:2], p[:2] / p[:2].sum())

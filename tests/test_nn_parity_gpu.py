@@ -76,7 +76,10 @@ def test_tower_and_head_kernels_any_batch_size(tmp_path, hip_lib, batch, case):
     net.predict(np.ascontiguousarray(x.numpy()), v, p)
     net.close()
     o_value, o_logits, _ = ro.forward(cfg, sd, x)
-    assert np.abs(v - o_value.numpy().reshape(-1)).max() < TOL["float16"]["value"]
+    # dense 3x3 towers contract K = 2304 f16 products per output (9x the 1x1 tower): the oracle's own f16 emulation
+    # (sim_dtype=float16) puts the worst of these 300 boards at 0.98e-3 for the value (risev2-7: 0.35e-3) -> 2e-3 here
+    value_tol = 2e-3 if cfg.dense_blocks else TOL["float16"]["value"]
+    assert np.abs(v - o_value.numpy().reshape(-1)).max() < value_tol
     assert np.abs(p.reshape(batch, -1) - torch.softmax(o_logits, 1).numpy()).max() < TOL["float16"]["prob"]
 
 

@@ -100,6 +100,7 @@ def apply_quantile_clipping(quantile: float, p: np.ndarray) -> np.ndarray:
 class _Game:
     def __init__(self, slot: int, record: GameRecord, pos: env.Position, rng: np.random.Generator, allow_resign: bool):
         self.slot, self.record, self.pos, self.rng, self.allow_resign = slot, record, pos, rng, allow_resign
+        self.samples = []               # (position clone, moves, policy, best_move_q) until the game's result is known
 
 
 class SelfPlay:
@@ -110,8 +111,12 @@ class SelfPlay:
 
     def __init__(self, pool: search.SearchPool, settings: SelfPlaySettings, concurrent: int,
                  start_fen: Optional[Callable[[int], str]] = None,
-                 raw_policy: Optional[Callable[[Sequence[env.Position]], List[np.ndarray]]] = None):
+                 raw_policy: Optional[Callable[[Sequence[env.Position]], List[np.ndarray]]] = None,
+                 exporter=None):
+        """exporter: a traindata.TrainDataExporter; every searched position becomes a training sample (generate_game,
+        selfplay.cpp:237-248) -- the concurrent games buffer their samples and are written game by game as they finish."""
         self.pool, self.s, self.concurrent = pool, settings, concurrent
+        self.exporter = exporter
         self.start_fen = start_fen or (lambda i: "")
         self.raw_policy = raw_policy
         self.games: List[Optional[_Game]] = [None] * concurrent
@@ -180,6 +185,13 @@ class SelfPlay:
 
     def _finish(self, g: _Game, result: int, why: str):
         g.record.result, g.record.termination = result, why
+        if self.exporter is not None:
+            self.exporter.new_game()
+            for p, moves, policy, q in g.samples:
+                self.exporter.save_sample(p, moves, policy, q)
+                p.close()
+            self.stats["samples"] = self.stats.get("samples", 0) + self.exporter.export_game_samples(result)
+            g.samples = []
         self.finished.append(g.record)
         g.pos.close()
         self.games[g.slot] = None
@@ -206,6 +218,10 @@ class SelfPlay:
             self.stats["nn_evals"] += st.nn_evals
             for g in active:
                 mv, best_q = self._choose(g)
+                if self.exporter is not None:                                  # save_sample(state, evalInfo) before the move
+                    moves_all, _, _, _ = self.pool.root_children(g.slot)
+                    policy_all, _ = self.pool.root_policy(g.slot)
+                    g.samples.append((g.pos.clone(), moves_all, policy_all, best_q))
                 uci = g.pos.move_uci(mv)
                 san = g.pos.move_san(mv)
                 g.pos.push(mv)

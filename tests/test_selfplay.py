@@ -118,3 +118,41 @@ def test_sampling_helpers():
     assert np.allclose(q, p ** 2 / (p ** 2).sum()) and q[0] > p[0]
     c = selfplay.apply_quantile_clipping(0.25, p)                 # the smallest entries covering < 25 % of the mass are dropped
     assert c[3] == 0 and c[2] == 0 and abs(c.sum() - 1) < 1e-12 and np.allclose(c[:2], p[:2] / p[:2].sum())
+
+
+def test_training_samples_of_selfplay_games(hip_lib, tmp_path):
+    """traindataexporter.cpp's arrays for the games of a self-play run: un-normalised int16 planes of every searched position,
+    the MCTS policy on the flat label index (mirrored for Black), value = result from the side to move, plies to the end."""
+    from crazyara_amd import traindata
+    mode, variant = 0, "crazyhouse"
+    pool = _pool(mode, 8, 8 * 3)
+    exp = traindata.TrainDataExporter(str(tmp_path / "data.zarr"), mode, 1, nb_labels=2272, number_chunks=4, chunk_size=64)
+    s = selfplay.SelfPlaySettings(variant=variant, simulations=32, max_plies=30, seed=5, mean_init_ply=2.0)
+    loop = selfplay.SelfPlay(pool, s, 3, raw_policy=_raw_policy_from_pseudo_net(mode), exporter=exp)
+    games = loop.play(4, threads=2)
+    pool.close()
+    root = str(tmp_path / "data.zarr")
+    x, val, pol = (traindata.read_array(root, n) for n in ("x", "y_value", "y_policy"))
+    q, plys, start, phase = (traindata.read_array(root, n) for n in ("y_best_move_q", "plys_to_end", "start_indices", "phase_vector"))
+    assert x.shape == (256, 34, 8, 8) and x.dtype == np.int16 and pol.shape == (256, 2272) and start.dtype == np.int32
+    n_total = sum(len(g.uci) - g.book_plies for g in games)
+    assert loop.stats["samples"] == n_total == int(start[len(games)])
+    assert list(start[:len(games) + 1]) == list(np.cumsum([0] + [len(g.uci) - g.book_plies for g in games]))
+    row = 0
+    for g in games:                                      # games are exported in the order they finished = the order of `games`
+        p = env.Position(g.start_fen, False, variant)
+        for u in g.uci[:g.book_plies]:
+            p.push_uci(u)
+        n = len(g.uci) - g.book_plies
+        for i, u in enumerate(g.uci[g.book_plies:]):
+            assert np.array_equal(x[row], p.planes(mode, 1, False).astype(np.int16).reshape(34, 8, 8))
+            stm = 1 if p.side_to_move() == 0 else -1
+            assert val[row] == stm * g.result and plys[row] == n - i and phase[row] == 0
+            assert abs(float(pol[row].sum()) - 1.0) < 1e-5 and -1.0 <= q[row] <= 1.0
+            legal_idx = {p.policy_index(m, mode, False) for m in p.legal_moves()}
+            assert set(np.nonzero(pol[row])[0]) <= legal_idx       # probability only on labels of legal moves
+            played = p.policy_index(p.uci_to_move(u), mode, False)
+            assert pol[row, played] > 0                            # the played (best) move carries mass
+            p.push_uci(u)
+            row += 1
+    assert not x[row:].any() and not pol[row:].any()

@@ -614,7 +614,8 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
     }
     flush_tower();
-    const bool head_ok = tower_ok && policy_map && cv == 8 && cp <= 96 && (wdl || fc == 256);
+    // value heads with fewer than 8 channels (AlphaZeroResnet: 4) run as 8 with zero rows: ReLU(0) = 0 meets zero FC weights
+    const bool head_ok = tower_ok && policy_map && cv >= 1 && cv <= 8 && cp <= 96 && (wdl || fc == 256);
     if (head_ok) {
         // policy + value head in one launch (head.hip; stream layouts in kernels.h: HeadArgs)
         if constexpr (kHalf) {
@@ -673,9 +674,9 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             const int nfl = kSquares * cv;
             if (wdl) {
                 const TensorView &ww = nf.get("value_head.body_wdl.0.weight"), &wp = nf.get("value_head.body_plys.0.weight");
-                std::vector<float> w4(size_t(4) * nfl);
-                std::copy(ww.data, ww.data + 3 * nfl, w4.begin());
-                std::copy(wp.data, wp.data + nfl, w4.begin() + 3 * nfl);
+                std::vector<float> w4(size_t(4) * 512, 0.f);                      // [4][512], rows zero-padded beyond nfl
+                for (int r = 0; r < 3; ++r) std::copy(ww.data + size_t(r) * nfl, ww.data + size_t(r + 1) * nfl, w4.begin() + size_t(r) * 512);
+                std::copy(wp.data, wp.data + nfl, w4.begin() + size_t(3) * 512);
                 const float* bw = nf.get("value_head.body_wdl.0.bias").data;
                 h.fc1_w = im.upload(w4);
                 h.wdl_b[0] = bw[0]; h.wdl_b[1] = bw[1]; h.wdl_b[2] = bw[2];
@@ -684,7 +685,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 macs += 4.0 * nfl;
             } else {
                 const TensorView &w1 = nf.get("value_head.body_final.0.weight"), &w2 = nf.get("value_head.body_final.2.weight");
-                std::vector<half_t> w1t(size_t(nfl) * fc);
+                std::vector<half_t> w1t(size_t(512) * fc, half_t(0.f));           // [512][fc], rows zero beyond nfl
                 for (int j = 0; j < fc; ++j) for (int k = 0; k < nfl; ++k) w1t[size_t(k) * fc + j] = half_t(w1.data[size_t(j) * nfl + k]);
                 const float* bb = nf.get("value_head.body_final.0.bias").data;
                 h.fc1_w = im.upload(w1t);

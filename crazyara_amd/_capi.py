@@ -71,6 +71,7 @@ SIGNATURES = {
     "mi_search_root_children": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), c_float_p, c_float_p]),
     "mi_search_tree_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), c_float_p]),
     "mi_search_root_policy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), c_float_p]),
+    "mi_search_set_active": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mi_search_reset_position": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p]),
     "mi_search_apply_move": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_int)]),
     "mi_search_tree_fen": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),

@@ -215,6 +215,11 @@ int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, floa
     return n;
 }
 
+int mi_search_set_active(mi_search* sp, int tree, int active) {
+    if (!sp) { cra_set_error("null search"); return 1; }
+    return cra_guard([&] { sp->pool->set_active(tree, active != 0); });
+}
+
 int mi_search_reset_position(mi_search* sp, int tree, const char* fen, int is_chess960, const char* variant) {
     if (!sp) { cra_set_error("null search"); return 1; }
     return cra_guard([&] {

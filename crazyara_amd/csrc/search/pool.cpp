@@ -177,6 +177,12 @@ void SearchPool::reset_position(int i, const chess::Position& pos) {
     trees_.at(i).reset(new Tree(pos, st));
 }
 
+void SearchPool::set_active(int i, bool active) {
+    (void)trees_.at(i);
+    if (paused_.size() < trees_.size()) paused_.resize(trees_.size(), 0);
+    paused_[i] = active ? 0 : 1;
+}
+
 bool SearchPool::tree_done(const Tree& t, uint32_t simulations, uint32_t nodes) const {
     if (t.root().terminal || t.root_solved()) return true;
     if (simulations && t.root_visits() >= simulations) return true;
@@ -188,7 +194,7 @@ void SearchPool::evaluate_roots(Lane& lane) {
     Evaluator& ev = *lane.eval;
     std::vector<int> todo;
     for (int id : lane.trees)
-        if (trees_[id]->root_needs_eval()) todo.push_back(id);
+        if (trees_[id]->root_needs_eval() && !is_paused(id)) todo.push_back(id);
     for (size_t off = 0; off < todo.size(); off += ev.batch_size()) {
         const int n = int(std::min(todo.size() - off, size_t(ev.batch_size())));
         for (int i = 0; i < n; ++i) trees_[todo[off + i]]->root_desc(ev.descs()[i]);
@@ -206,18 +212,19 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     const auto t0 = std::chrono::steady_clock::now();
     for (Lane& lane : lanes_) {
         size_t before = 0;
-        for (int id : lane.trees) before += trees_[id]->root_needs_eval();
+        for (int id : lane.trees) before += trees_[id]->root_needs_eval() && !is_paused(id);
         evaluate_roots(lane);
         st.nn_evals += before;
         st.batches += (before + lane.eval->batch_size() - 1) / lane.eval->batch_size();
     }
     for (size_t i = 0; i < trees_.size(); ++i) {
-        trees_[i]->begin_search();                                  // Dirichlet noise + full expansion of the root (RL settings)
+        if (!is_paused(int(i))) trees_[i]->begin_search();          // Dirichlet noise + full expansion of the root (RL settings)
         nodes_pre[i] = trees_[i]->node_count();
         visits_pre[i] = trees_[i]->root_visits();
     }
     // simulations/nodes limits are per `go`: measured from the pre-search counters (tree reuse keeps old visits)
     auto done = [&](int id) {
+        if (is_paused(id)) return true;
         const Tree& t = *trees_[id];
         if (t.root().terminal || t.root_solved()) return true;      // is_root_node_unsolved(), searchthread.cpp:333-340
         if (simulations && t.root_visits() - visits_pre[id] >= simulations) return true;

@@ -80,6 +80,8 @@ public:
     void run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats);
     Tree& tree(int i) { return *trees_.at(i); }
     void reset_position(int i, const chess::Position& pos);   // a new game in slot i (same lane, same exploration stream seed)
+    // trees that sit out the following runs (an arena game whose other player is to move): they keep their state
+    void set_active(int i, bool active);
     int n_trees() const { return int(trees_.size()); }
     const SearchSettings& settings() const { return s_; }
 
@@ -96,6 +98,8 @@ private:
     int layout_;
     std::vector<std::unique_ptr<Tree>> trees_;
     std::vector<Lane> lanes_;
+    std::vector<uint8_t> paused_;
+    bool is_paused(int id) const { return size_t(id) < paused_.size() && paused_[id] != 0; }
 };
 
 }  // namespace search

@@ -105,6 +105,10 @@ class SearchPool:
             raise RuntimeError(_capi.last_error())
         return np.array(buf[:n], np.float64), float(q.value)
 
+    def set_active(self, tree: int, active: bool) -> None:
+        if self._lib.mi_search_set_active(self._h, tree, int(active)):
+            raise ValueError(_capi.last_error())
+
     def reset_position(self, tree: int, fen: str = "", is960: bool = False, variant: str = "crazyhouse") -> None:
         if self._lib.mi_search_reset_position(self._h, tree, (fen or "").encode(), int(is960), variant.encode()):
             raise ValueError(_capi.last_error())

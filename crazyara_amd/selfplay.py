@@ -285,3 +285,105 @@ def net_raw_policy(net, mode: int, version_major: int, is_policy_map: bool = Tru
         return out
 
     return evaluate
+
+
+@dataclass
+class TournamentResult:
+    """TournamentResult of go_arena (selfplay.cpp:387-424): seen from the contender (player A)."""
+    player_a: str = "A"
+    player_b: str = "B"
+    wins: int = 0
+    draws: int = 0
+    losses: int = 0
+
+    def score(self) -> float:
+        n = self.wins + self.draws + self.losses
+        return (self.wins + 0.5 * self.draws) / n if n else 0.0
+
+
+class Arena:
+    """Two players (search pools with their own nets) play `n_games` against each other, `concurrent` games at a time.
+
+    go_arena (selfplay.cpp:387-424): game 2i has the contender A as White from a fresh start position, game 2i+1 replays the SAME
+    start position with colours swapped.  generate_arena_game (:267-308): the player to move searches, both players apply the move
+    to their trees (own move / opponent's move), always the best move (no temperature), no resignation.  Each game owns tree slot g
+    in BOTH pools; the pool of the player that is not to move pauses that tree (mi_search_set_active)."""
+
+    def __init__(self, pool_a: search.SearchPool, pool_b: search.SearchPool, settings: SelfPlaySettings, concurrent: int,
+                 start_fen: Optional[Callable[[int], str]] = None, names=("contender", "champion")):
+        self.pools, self.s, self.concurrent, self.names = (pool_a, pool_b), settings, concurrent, names
+        self.start_fen = start_fen or (lambda i: "")
+        for slot in range(concurrent):
+            for p in self.pools:
+                assert p.add_position("", settings.is960, settings.variant) == slot
+        self.stats = dict(moves=0, nodes=0, seconds=0.0)
+
+    def play(self, n_games: int, threads: int = 16):
+        s = self.s
+        res = TournamentResult(self.names[0], self.names[1])
+        games: List[Optional[dict]] = [None] * self.concurrent
+        records: List[GameRecord] = []
+        started, pair_fen = 0, {}
+        t0 = time.perf_counter()
+        while len(records) < n_games:
+            for slot in range(self.concurrent):
+                if games[slot] is None and started < n_games:
+                    idx = started
+                    started += 1
+                    if idx % 2 == 0:
+                        pos = env.Position(self.start_fen(idx // 2), s.is960, s.variant)
+                        pair_fen[idx // 2] = pos.fen()
+                    else:
+                        pos = env.Position(pair_fen[idx // 2], s.is960, s.variant)       # gamePGN.fen of the game before
+                    a_white = idx % 2 == 0
+                    rec = GameRecord(start_fen=pos.fen(), variant=s.variant + ("960" if s.is960 else ""), event="Arena",
+                                     white=self.names[0 if a_white else 1], black=self.names[1 if a_white else 0])
+                    for p in self.pools:
+                        p.reset_position(slot, rec.start_fen, s.is960, s.variant)
+                    games[slot] = dict(idx=idx, pos=pos, rec=rec, a_white=a_white)
+            active = [(slot, g) for slot, g in enumerate(games) if g is not None]
+            if not active:
+                break
+            mover = {}
+            for slot, g in active:                       # which player searches this game now
+                white_to_move = g["pos"].side_to_move() == 0
+                mover[slot] = 0 if white_to_move == g["a_white"] else 1
+            for pi, p in enumerate(self.pools):
+                for slot in range(self.concurrent):
+                    p.set_active(slot, games[slot] is not None and mover.get(slot) == pi)
+                if any(mover[slot] == pi for slot, _ in active):
+                    st = p.run(simulations=s.simulations, nodes=s.nodes, threads=threads)
+                    self.stats["nodes"] += st.nodes
+            for slot, g in active:
+                p = self.pools[mover[slot]]
+                moves, _, _, _ = p.root_children(slot)
+                policy, _ = p.root_policy(slot)
+                mv = moves[int(np.argmax(policy))]
+                uci, san = g["pos"].move_uci(mv), g["pos"].move_san(mv)
+                g["pos"].push(mv)
+                t = g["pos"].terminal()
+                if t in (env.TERMINAL_WIN, env.TERMINAL_LOSS):
+                    san = san[:-1] + "#" if san.endswith("+") else san + "#"
+                g["rec"].san.append(san)
+                g["rec"].uci.append(uci)
+                self.stats["moves"] += 1
+                over = t != env.TERMINAL_NONE or len(g["rec"].uci) >= s.max_plies
+                if not over:
+                    for q in self.pools:                 # own move in one tree, the opponent's move in the other
+                        q.apply_move(slot, uci)
+                    continue
+                stm_white = g["pos"].side_to_move() == 0
+                result = 0 if t in (env.TERMINAL_DRAW, env.TERMINAL_NONE) else ((-1 if stm_white else 1) if t == env.TERMINAL_LOSS else (1 if stm_white else -1))
+                g["rec"].result, g["rec"].termination = result, "terminal" if t != env.TERMINAL_NONE else "ply limit"
+                a_score = result if g["a_white"] else -result
+                if a_score > 0:
+                    res.wins += 1
+                elif a_score < 0:
+                    res.losses += 1
+                else:
+                    res.draws += 1
+                records.append(g["rec"])
+                g["pos"].close()
+                games[slot] = None
+        self.stats["seconds"] = time.perf_counter() - t0
+        return res, records

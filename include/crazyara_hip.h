@@ -199,6 +199,9 @@ int mi_search_best_move(mi_search* sp, int tree, char* uci, int cap);
 /* the whole Node::get_mcts_policy vector of the root (EvalInfo::policyProbSmall, one entry per expanded child in the order of
  * mi_search_root_children) and the Q value of the best move (EvalInfo::bestMoveQ); returns the number of entries or -1 */
 int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, float* best_move_q);
+/* active = 0: the tree sits out the following mi_search_run calls and keeps its state (the player that is not to move in an
+ * arena game, generate_arena_game, selfplay.cpp:267-308); trees start active */
+int mi_search_set_active(mi_search* sp, int tree, int active);
 /* start a new game on an existing tree slot: the tree restarts from this position (clean_up / clear_game_history, selfplay.cpp:305-309) */
 int mi_search_reset_position(mi_search* sp, int tree, const char* fen, int is_chess960, const char* variant);   /* argmax of Node::get_mcts_policy, node.cpp:1070-1109 */
 

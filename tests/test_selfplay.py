@@ -156,3 +156,40 @@ def test_training_samples_of_selfplay_games(hip_lib, tmp_path):
             p.push_uci(u)
             row += 1
     assert not x[row:].any() and not pol[row:].any()
+
+
+def test_arena_colour_alternation_and_scoring(hip_lib):
+    """go_arena: games come in pairs from the same start position with colours swapped; each player searches only on its own turn
+    (the other pool's tree is paused and then follows the move); the tournament result is counted for the contender."""
+    mode, variant = 0, "crazyhouse"
+    nbp = NB_POLICY[mode]
+
+    def make_pool(salt):
+        st = search.default_settings(mode=mode, version_major=1, is_policy_map=1, batch_size=8)
+
+        def eval_descs(descs):                            # two different "networks": the salt changes every evaluation
+            out = [_pseudo_net(key_from_desc(d) + salt, nbp) for d in descs]
+            return [o[0] for o in out], [o[1] for o in out]
+        return search.SearchPool(st, eval_fn=eval_descs, fn_batch=8 * 3, fn_nb_policy=nbp)
+
+    pa, pb = make_pool(b"A"), make_pool(b"B")
+    fens = ["", "r1bqkb1r/pppp1ppp/2n2n2/4p3/4P3/2N2N2/PPPP1PPP/R1BQKB1R[] w KQkq - 4 4"]
+    s = selfplay.SelfPlaySettings(variant=variant, simulations=40, max_plies=24)
+    arena = selfplay.Arena(pa, pb, s, 3, start_fen=lambda i: fens[i % 2])
+    res, games = arena.play(6, threads=2)
+    assert res.wins + res.draws + res.losses == 6 and len(games) == 6 and 0.0 <= res.score() <= 1.0
+    by_fen = {}
+    for g in games:
+        by_fen.setdefault(g.start_fen, []).append(g)
+        b = co.Board(g.start_fen, False, variant)
+        for u in g.uci:
+            legal = {b.move_uci(m): m for m in b.legal_moves()}
+            assert u in legal
+            b.push(legal[u])
+        assert g.event == "Arena" and {g.white, g.black} == {"contender", "champion"}
+    for fen, pair in by_fen.items():                     # every start position is played with both colour assignments equally often
+        assert sum(g.white == "contender" for g in pair) == sum(g.white == "champion" for g in pair)
+    # the two players really differ: from the start position the contender's and the champion's first moves as White differ or not,
+    # but a game is never the same when the colours are swapped unless both nets agree everywhere
+    pa.close()
+    pb.close()

@@ -256,7 +256,11 @@ __device__ __forceinline__ void vector_interval(VParams& vp, int lg, const VecAd
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
+#ifdef TW_DEV_VEC_TILES
+    for (int t = 0; t < TW_DEV_VEC_TILES; ++t) {     // development: only part of the depthwise work (timing experiment)
+#else
     for (int t = 0; t < 4; ++t) {
+#endif
         if (t < 3) {                                 // next tile's rows go out before this tile's FMAs
 #pragma unroll
             for (int i = 0; i < 3; ++i) {

@@ -7,13 +7,13 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NL, int ND>
+template <int NL, int ND, int SHARE>
 __global__ __launch_bounds__(256) void k(const char* src, float* out, unsigned long long* cyc, int steps, unsigned stream_bytes) {
     __shared__ half8 lds[2048];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = half8{1, 1, 1, 1, 1, 1, 1, 1};
     __syncthreads();
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src) + size_t(wave) * stream_bytes, 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src) + size_t(SHARE ? (wave >> 1) : wave) * stream_bytes, 0, 0x7fffffff, 0x00020000);
     half8 win[16];
     unsigned pos = 0;
     for (int q = 0; q < 16; ++q) win[q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, pos + q * 1024, 0));
@@ -50,15 +50,15 @@ __global__ __launch_bounds__(256) void k(const char* src, float* out, unsigned l
     if (blockIdx.x == 0 && lane == 0) cyc[wave] = t1 - t0;
 }
 
-template <int NL, int ND>
+template <int NL, int ND, int SHARE = 0>
 void run(const char* s, float* o, unsigned long long* c, unsigned stream_bytes) {
     const int steps = 4000;
-    k<NL, ND><<<256, 256>>>(s, o, c, 80, stream_bytes);
-    k<NL, ND><<<256, 256>>>(s, o, c, steps, stream_bytes);
+    k<NL, ND, SHARE><<<256, 256>>>(s, o, c, 80, stream_bytes);
+    k<NL, ND, SHARE><<<256, 256>>>(s, o, c, steps, stream_bytes);
     (void)hipDeviceSynchronize();
     unsigned long long h[4];
     (void)hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost);
-    printf("per step: 4 MFMA + %d buffer_load_b128 + %d ds_read_b128 : %7.1f cycles/step (wave 0), %7.1f (wave 3)\n", NL, ND, double(h[0]) / steps, double(h[3]) / steps);
+    printf("%sper step: 4 MFMA + %d buffer_load_b128 + %d ds_read_b128 : %7.1f cycles/step (wave 0), %7.1f (wave 3)\n", SHARE ? "[pairs of waves share a stream] " : "", NL, ND, double(h[0]) / steps, double(h[3]) / steps);
 }
 
 int main() {
@@ -80,5 +80,9 @@ int main() {
     run<0, 8>(s, o, c, stream_bytes);
     run<0, 12>(s, o, c, stream_bytes);
     run<2, 2>(s, o, c, stream_bytes);
+    run<2, 0, 1>(s, o, c, stream_bytes);
+    run<2, 4, 1>(s, o, c, stream_bytes);
+    run<4, 0, 0>(s, o, c, stream_bytes);
+    run<4, 0, 1>(s, o, c, stream_bytes);
     return 0;
 }

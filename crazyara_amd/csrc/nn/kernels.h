@@ -156,9 +156,10 @@ void init_head_kernel_attributes();
 size_t head_lds_bytes();
 
 // Dense residual tower in one launch, one workgroup per board (restower.hip).  f16, C = 256.
-//   wstream  8 waves x per block { conv 1: [9 taps][16 k-steps] A fragments (rows = couts 32*wave + row, K = input channel),
-//            conv 2: the same with K position -> conv-1 channel (kpos/32)*32 + tower_row_of_position(kpos%32) }, then 16 zero fragments
-//   bstream  8 waves x per block { conv 1 BN bias [lane/32][16], conv 2 BN bias [lane/32][16] } in accumulator row order
+//   wstream  (8 / NR) waves x per block { conv 1: [9 taps][16 k-steps][NR cout tiles] A fragments (rows = couts
+//            32*(NR*wave + rt) + row, K = input channel), conv 2: the same with K position -> conv-1 channel
+//            (kpos/32)*32 + tower_row_of_position(kpos%32) }, then 16 zero fragments;  NR = cout_tiles_per_wave
+//   bstream  (8 / NR) waves x per block { conv 1 BN bias [rt][lane/32][16], conv 2 BN bias [rt][lane/32][16] } in accumulator row order
 struct ResTowerArgs {
     const void* x;            // [B][64][256] f16
     void* y;
@@ -169,6 +170,8 @@ struct ResTowerArgs {
     int nblocks;
     int relu_after_add;       // 1: ReLU(x + body(x)) (AlphaZero ResidualBlock), 0: x + ReLU(body(x)) (ClassicalResidualBlock)
     int batch;
+    int boards_per_workgroup; // 1 or 2 (restower.hip: a weight fragment feeds 2 or 4 MFMAs)
+    int cout_tiles_per_wave;  // 1: 8 waves x 32 couts, 2: 4 waves x 64 couts (a tile fragment feeds 1 or 2 MFMAs); fixes the stream layout
 };
 void launch_restower(const ResTowerArgs& a, hipStream_t s);
 void init_restower_kernel_attributes();

@@ -123,6 +123,15 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     : device_(device_id), impl_(new Impl) {
     if (batch_size <= 0) throw std::invalid_argument("batch size must be positive");
     std::string prec = precision;
+    // "-1b" / "-2b": boards per workgroup of the dense residual tower (restower.hip); default by batch size
+    if (prec.size() > 3 && prec.compare(prec.size() - 3, 3, "-8w") == 0) {   // dense tower: 8 thin waves instead of 4 fat ones
+        rt_thin_waves_ = true;
+        prec.resize(prec.size() - 3);
+    }
+    if (prec.size() > 3 && (prec.compare(prec.size() - 3, 3, "-1b") == 0 || prec.compare(prec.size() - 3, 3, "-2b") == 0)) {
+        boards_per_wg_ = prec[prec.size() - 2] - '0';
+        prec.resize(prec.size() - 3);
+    }
     const std::string unfused_tag = "-unfused";   // layer-granular kernels (A/B reference for the fused block kernel)
     const std::string perblock_tag = "-perblock"; // one launch per bottleneck block (A/B reference for the tower kernel)
     if (prec.size() > unfused_tag.size() && prec.compare(prec.size() - unfused_tag.size(), unfused_tag.size(), unfused_tag) == 0) {
@@ -391,24 +400,32 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     if (dense_blocks && tower_ok) {
         // all blocks in one launch (restower.hip; stream layouts in kernels.h: ResTowerArgs)
         if constexpr (kHalf) {
+            // wave shape (restower.hip): 4 fat waves of 64 couts by default, "-8w" = 8 waves of 32 couts (the first version)
+            const int NR = rt_thin_waves_ ? 1 : 2, n_waves = 8 / NR;
             std::vector<half_t> ws;
             std::vector<float> bs;
-            for (int wv = 0; wv < 8; ++wv) {
+            std::vector<Folded> f1s, f2s;
+            for (size_t i = 0; i < cops.size(); ++i) {
+                const std::string p = "body_spatial." + std::to_string(i + 1);
+                f1s.push_back(fold_bn(nf, p + ".body.0", p + ".body.1"));
+                f2s.push_back(fold_bn(nf, p + ".body.3", p + ".body.4"));
+            }
+            for (int wv = 0; wv < n_waves; ++wv) {
                 for (size_t i = 0; i < cops.size(); ++i) {
-                    const std::string p = "body_spatial." + std::to_string(i + 1);
-                    Folded f1 = fold_bn(nf, p + ".body.0", p + ".body.1"), f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
                     for (int cv2 = 0; cv2 < 2; ++cv2) {
-                        const Folded& fd = cv2 ? f2 : f1;
+                        const Folded& fd = cv2 ? f2s[i] : f1s[i];
                         for (int tap = 0; tap < 9; ++tap)
                             for (int ksx = 0; ksx < 16; ++ksx)
-                                for (int l = 0; l < 64; ++l)
-                                    for (int j = 0; j < 8; ++j) {
-                                        const int co = wv * 32 + (l & 31), kpos = ksx * 16 + (l >> 5) * 8 + j;
-                                        const int ci = cv2 ? (kpos / 32) * 32 + tower_row_of_position(kpos % 32) : kpos;
-                                        ws.push_back(half_t(float(fd.w[(size_t(co) * C + ci) * 9 + tap])));
-                                    }
-                        for (int lh = 0; lh < 2; ++lh)
-                            for (int v = 0; v < 16; ++v) bs.push_back(float(fd.b[wv * 32 + (v % 4) + 8 * (v / 4) + 4 * lh]));
+                                for (int rt = 0; rt < NR; ++rt)
+                                    for (int l = 0; l < 64; ++l)
+                                        for (int j = 0; j < 8; ++j) {
+                                            const int co = (wv * NR + rt) * 32 + (l & 31), kpos = ksx * 16 + (l >> 5) * 8 + j;
+                                            const int ci = cv2 ? (kpos / 32) * 32 + tower_row_of_position(kpos % 32) : kpos;
+                                            ws.push_back(half_t(float(fd.w[(size_t(co) * C + ci) * 9 + tap])));
+                                        }
+                        for (int rt = 0; rt < NR; ++rt)
+                            for (int lh = 0; lh < 2; ++lh)
+                                for (int v = 0; v < 16; ++v) bs.push_back(float(fd.b[(wv * NR + rt) * 32 + (v % 4) + 8 * (v / 4) + 4 * lh]));
                     }
                 }
                 ws.insert(ws.end(), size_t(16) * 512, half_t(0.f));
@@ -419,11 +436,15 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             op.rt.y = nxt;
             op.rt.wstream = im.upload(ws);
             op.rt.bstream = im.upload(bs);
-            op.rt.wstream_wave_frags = (long long)(cops.size() * 2 * 9 * 16 + 16);
-            op.rt.bstream_wave_floats = (long long)(cops.size() * 64);
+            op.rt.wstream_wave_frags = (long long)(cops.size() * 2 * 9 * 16 * NR + 16);
+            op.rt.bstream_wave_floats = (long long)(cops.size() * 64 * NR);
+            op.rt.cout_tiles_per_wave = NR;
             op.rt.nblocks = int(cops.size());
             op.rt.relu_after_add = conv_block == "a0_res_block" ? 1 : 0;
             op.rt.batch = B;
+            // two boards per workgroup halve the weight stream per board but fill only B/2 CUs: from 512 boards on, or on request
+            // (two evaluator lanes of 256 keep 512 boards in flight)
+            op.rt.boards_per_workgroup = boards_per_wg_ ? boards_per_wg_ : (B >= 512 ? 2 : 1);
             im.ops.push_back(op);
             macs += double(cops.size()) * 2.0 * kSquares * C * C * 9;
             std::swap(cur, nxt);

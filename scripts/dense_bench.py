@@ -12,7 +12,7 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 cfg = ro.alpha_zero_config(nblk, 34, 81, 8) if kind == "alphazero" else ro.rise_classical_config(nblk, 34, 81)
 sd = ro.make_state_dict(cfg, seed=1)
 d = nn_cases.export_case(tempfile.mkdtemp(), "b", cfg, sd)
-for prec in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("float16", "float16-perblock")):
+for prec in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("float16-1b-8w", "float16-1b", "float16-2b-8w", "float16-2b")):
     net = HipAPI(0, B, d, prec)
     x = nn_cases.synthetic_planes(B, 34, 5)
     torch.as_tensor(net.device_buffers()["planes"], device="cuda").copy_(x.cuda()); torch.cuda.synchronize()

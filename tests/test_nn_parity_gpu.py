@@ -24,6 +24,7 @@ TOL = {"float32": dict(logit=1e-4, value=1e-4, prob=1e-6, aux=1e-4),
 TOL["float32-unfused"] = TOL["float32"]
 TOL["float16-unfused"] = TOL["float16"]
 TOL["float16-perblock"] = TOL["float16"]
+TOL["float16-2b"] = TOL["float16"]      # dense residual tower with two boards per workgroup (other nets: same as float16)
 
 
 def _run(tmp_path, hip_lib, name, precision):
@@ -60,6 +61,18 @@ def test_predict_matches_oracle_and_golden(tmp_path, hip_lib, name, precision):
     assert np.allclose(probs.sum(axis=1), 1.0, atol=1e-4)
     if cfg.nb_aux:
         assert np.abs(aux.reshape(-1, 4) - o_aux.numpy()).max() < tol["aux"]
+
+
+@pytest.mark.parametrize("variant", ["float16-2b", "float16-1b-8w", "float16-2b-8w"])
+@pytest.mark.parametrize("name", ["rise-classical-4", "alphazero-5", "alphazero-3-cv8"])
+def test_dense_tower_kernel_shapes(tmp_path, hip_lib, name, variant):
+    """restower_kernel<NB, NR>: the same fixtures through two boards per workgroup (odd batch 3 included: the last workgroup's
+    second board is empty) and through the 8-thin-waves shape; plain float16 = one board, 4 fat waves."""
+    cfg, sd, x, value, probs, aux, logits = _run(tmp_path, hip_lib, name, variant)
+    tol = TOL["float16"]
+    g = np.load(os.path.join(nn_cases.GOLDEN_DIR, f"nn_{name}.npz"))
+    assert np.abs(value - g["value"].reshape(-1)).max() < tol["value"]
+    assert np.abs(logits - g["logits"]).max() < tol["logit"]
 
 
 @pytest.mark.parametrize("case", ["risev2-7", "alphazero-3-cv8"])

@@ -117,8 +117,15 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
             frag (&cur)[4] = (s & 1) ? bfb : bfa;
             frag (&nxt)[4] = (s & 1) ? bfa : bfb;
             if (s + 1 < 8) {
+#ifdef TW_DEV_HALF_E_READS
+                // development (wrong results): half of the B-fragment reads of the expand phase, to time the operand traffic
+#pragma unroll
+                for (int i = 0; i < 2; ++i) nxt[i] = *reinterpret_cast<const frag*>(xsr + (i & 1) * 32 * XROW + ((s + 1) * 2 + (i >> 1)) * 16);
+                nxt[2] = nxt[0]; nxt[3] = nxt[1];
+#else
 #pragma unroll
                 for (int i = 0; i < 4; ++i) nxt[i] = *reinterpret_cast<const frag*>(xsr + (i & 1) * 32 * XROW + ((s + 1) * 2 + (i >> 1)) * 16);
+#endif
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) mma32(win[s * 2 + (i >> 1)], cur[i], accE[i & 1]);

@@ -112,8 +112,9 @@ void WorkerPool::worker_loop(int index) {
         int spins = 0;
         while (generation_.load(std::memory_order_acquire) == seen) {
             if (stop_.load(std::memory_order_acquire)) return;
-            if (++spins < 20000) __builtin_ia32_pause();
-            else std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (++spins < 20000) __builtin_ia32_pause();                                       // ~100 us: between two jobs of a run
+            else if (spins < 22000) std::this_thread::sleep_for(std::chrono::microseconds(50));  // ~100 ms: between two runs of a game loop
+            else std::this_thread::sleep_for(std::chrono::milliseconds(2));                      // idle pool
         }
         seen = generation_.load(std::memory_order_acquire);
         run_items(index);
@@ -206,7 +207,8 @@ void SearchPool::evaluate_roots(Lane& lane) {
 
 void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats) {
     if (!simulations && !nodes) throw std::invalid_argument("run needs a simulations or a nodes limit");
-    WorkerPool workers(std::max(1, threads));
+    if (!workers_ || workers_->threads() != std::max(1, threads)) workers_.reset(new WorkerPool(std::max(1, threads)));
+    WorkerPool& workers = *workers_;
     SearchStats st;
     std::vector<uint32_t> nodes_pre(trees_.size()), visits_pre(trees_.size());
     const auto t0 = std::chrono::steady_clock::now();

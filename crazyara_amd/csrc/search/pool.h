@@ -99,6 +99,7 @@ private:
     std::vector<std::unique_ptr<Tree>> trees_;
     std::vector<Lane> lanes_;
     std::vector<uint8_t> paused_;
+    std::unique_ptr<WorkerPool> workers_;   // kept between runs (a game loop calls run() once per move)
     bool is_paused(int id) const { return size_t(id) < paused_.size() && paused_[id] != 0; }
 };
 

@@ -237,10 +237,10 @@ __device__ __forceinline__ uint4 vec_row_read(const char* p) {
 }
 
 template <int PARITY>
-__device__ __forceinline__ void vector_interval(VParams& vp, int lg, const VecAddr& va, half_t* t2w, half2_t mLp, half2_t mRp) {
+__device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf, int lg, const VecAddr& va, half_t* t2w, half2_t mLp, half2_t mRp) {
     constexpr int T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
     constexpr int TILE = 16 * T1ROW * 2;             // bytes between square tiles of a t1 buffer
-    const char* prm = vp.open() + lg * TW_PRM_LG;
+    const char* prm = prm_buf + lg * TW_PRM_LG;
     // rows of neighbours: top(t) | mid(t) | bot(t), 3 reads each; bot(t) == top(t + 1)
     uint4 top[3], mid[3], bot[3], nmid[3], nbot[3];
 #pragma unroll
@@ -319,9 +319,9 @@ struct VecAddr5 {
 };
 
 template <int PARITY>
-__device__ __forceinline__ void vector_interval5(VParams& vp, int lg, const VecAddr5& va, half_t* t2w, const half2_t (&mk)[5]) {
+__device__ __forceinline__ void vector_interval5(VParams& vp, const char* prm_buf, int lg, const VecAddr5& va, half_t* t2w, const half2_t (&mk)[5]) {
     constexpr int T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
-    const char* prm = vp.open() + lg * TW_PRM_LG;
+    const char* prm = prm_buf + lg * TW_PRM_LG;
     half2_t W[26][4];
 #pragma unroll
     for (int e = 0; e < 26; ++e) {
@@ -747,27 +747,35 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
                                                                   : reinterpret_cast<const char*>(dn.se_w1);
                 pf_sink ^= *reinterpret_cast<const int*>(base + line * 128);
             }
+            const bool five = __builtin_amdgcn_readfirstlane(d.ks) == 5;    // read ONCE per block: inside the loop the compiler re-loads it
+                                                                            // from global memory every interval and waits for vmcnt(0),
+                                                                            // i.e. also for the L2 warm-up load it has just issued
             for (int k = -1; k <= n; ++k) {
+                // Vector-memory returns retire in order, so a wait for ANY load also waits for every older one.  The warm-up touch is
+                // a cold miss by design: it is issued right AFTER the interval's only vmcnt wait (the depthwise weights' DMA of an
+                // interval ago, vp.open()) and consumed a whole interval later; issued before that wait it stalled this wave for a full
+                // miss latency in every interval.
+                pf_sink ^= pf_old;
+#ifndef TW_DEV_NO_VECTOR
+                const bool work = k >= 0 && k < n;
+#else
+                const bool work = false;
+#endif
+                const char* prm_buf = work ? vp.open() : nullptr;
                 {
                     const int adv = (k + 1 < n ? 16 : 0) + (k >= 1 ? 16 : 0);
-                    pf_sink ^= pf_old;                         // last interval's load is consumed a whole interval later
 #ifndef TW_DEV_NO_WARMUP
                     pf_old = adv != 0 ? prefetch(mpos + TW_AHEAD, adv) : 0;
 #endif
                     mpos += adv;
                 }
-#ifndef TW_DEV_NO_VECTOR
-                if (k >= 0 && k < n)
-#else
-                if (false)
-#endif
-                {
-                    if (d.ks == 5) {
-                        if (k & 1) vector_interval5<1>(vp, lg, va5, t2w, mk5);
-                        else vector_interval5<0>(vp, lg, va5, t2w, mk5);
+                if (work) {
+                    if (five) {
+                        if (k & 1) vector_interval5<1>(vp, prm_buf, lg, va5, t2w, mk5);
+                        else vector_interval5<0>(vp, prm_buf, lg, va5, t2w, mk5);
                     } else {
-                        if (k & 1) vector_interval<1>(vp, lg, va, t2w, mLp, mRp);
-                        else vector_interval<0>(vp, lg, va, t2w, mLp, mRp);
+                        if (k & 1) vector_interval<1>(vp, prm_buf, lg, va, t2w, mLp, mRp);
+                        else vector_interval<0>(vp, prm_buf, lg, va, t2w, mLp, mRp);
                     }
                 }
 #ifdef TW_TRACE_BARRIERS

@@ -69,7 +69,7 @@ def read_cranet(path: str):
 
 
 def export_rise(path: str, cfg, state_dict, input_version: str = "1.0", variant: str = "crazyhouse") -> str:
-    """cfg: any object with the RiseV3 constructor fields (see oracle/rise_oracle.py:RiseConfig for the list)."""
+    """cfg: any object with the RiseV3 constructor fields (crazyara_amd/rise_config.py:RiseConfig)."""
     meta = dict(
         arch="rise", variant=variant, input_version=input_version,
         nb_input_channels=cfg.nb_input_channels, channels=cfg.channels,

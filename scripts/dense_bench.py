@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import nn_cases
-from oracle import rise_oracle as ro
+from crazyara_amd import rise_config as ro
 from crazyara_amd.neuralnetapi import HipAPI
 kind = sys.argv[1] if len(sys.argv) > 1 else "alphazero"
 nblk = int(sys.argv[2]) if len(sys.argv) > 2 else 19

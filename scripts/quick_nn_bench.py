@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import nn_cases
-from oracle import rise_oracle as ro
+from crazyara_amd import rise_config as ro
 from crazyara_amd.neuralnetapi import HipAPI
 from crazyara_amd import build
 build.build()

@@ -184,6 +184,26 @@ def main():
                 "lanes": lanes, "host_threads_per_gpu": threads, "avg_batch_fill": round(stt.nn_evals / max(1, stt.batches) / args.batch, 3),
                 "depth_avg": round(stt.depth_avg, 2), "depth_max": int(stt.depth_max)}
         pool.close()
+        if extra_nets:
+            # informational: two batches of 256 in flight, as two SearchThreads of the reference keep them (own weights, own stream
+            # each): the launches of one forward overlap the tail of the other.  Never `value`.
+            import threading
+            pair, half = (net, extra_nets[0]), max(1, args.steps // 2)
+            for n2 in pair:
+                n2.forward_device()
+                n2.sync()
+
+            def replay(n2):
+                for _ in range(half):
+                    n2.forward_device()
+                n2.sync()
+            ths = [threading.Thread(target=replay, args=(n2,)) for n2 in pair]
+            t2 = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            mcts["nn_two_batches_in_flight_evals_per_sec"] = round(2 * half * args.batch / (time.perf_counter() - t2), 1)
         for n_extra in extra_nets:
             n_extra.close()
 

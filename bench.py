@@ -172,6 +172,11 @@ def main():
         for i in range(n_trees):
             pool.add_position(fens[(i * 7 + rank * 3) % len(fens)], False, "crazyhouse")
         threads = max(1, min(args.search_threads, (os.cpu_count() or 1) // max(1, world)))
+        # untimed warm-up (worker threads, allocator, clocks), then every tree restarts from its opening position
+        tree_fens = [fens[(i * 7 + rank * 3) % len(fens)] for i in range(n_trees)]
+        pool.run(simulations=min(200, args.simulations), threads=threads)
+        for i, f in enumerate(tree_fens):
+            pool.reset_position(i, f, False, "crazyhouse")
         stt = pool.run(simulations=args.simulations, threads=threads)
         # RCCL sum of {nodes, evals, simulations}, max of seconds
         nodes_t, sec_t, ex = replicas.reduce_stats(replicas.ReplicaStats(units=float(stt.nodes), seconds=stt.seconds,

@@ -27,6 +27,9 @@ from test_mcts import NB_POLICY, _pseudo_net, key_from_desc
     ("r3k2r/8/8/8/8/8/8/R3K2R b KQkq - 0 1", "chess", "e8c8", "O-O-O"),
     ("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR[Nn] w KQkq - 0 1", "crazyhouse", "N@f3", "N@f3"),
     ("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR[Pp] w KQkq - 0 1", "crazyhouse", "P@e4", "P@e4"),
+    # the reference's own PGN_Move_Ambiguity case (engine/tests/tests.cpp:178-201): knights b3 and f3 both reach d2 -> same rank,
+    # not the same file -> disambiguated by the file
+    ("r1bq1rk1/ppppbppp/2n2n2/4p3/4P3/1N1P1N2/PPP2PPP/R1BQKB1R w KQ - 5 6", "chess", "f3d2", "Nfd2"),
     ("6k1/5ppp/8/8/8/8/8/R3K3 w Q - 0 1", "chess", "a1a8", "Ra8+"),                                           # '+': the game loop turns it into '#'
 ])
 def test_san_dialect(hip_lib, fen, variant, uci, san):

@@ -42,6 +42,38 @@ def synthetic_planes(batch, channels, seed):
     return torch.from_numpy(x)
 
 
+def committed_pmc_traffic(kernel: str):
+    """roofline.traffic: fabric-side bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs, scripts/gpu_round.sh; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads on gfx950; both counters are KiB).  PMC passes cannot run
+    inside the timed process, so this is the newest committed measurement of the same workload, or null."""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    sets = sorted(glob.glob(os.path.join(root, "r*", "*_pmc_tcc1.txt")))
+    if not sets:
+        return {"traffic": None}
+    f1 = sets[-1]
+    f2 = f1.replace("_pmc_tcc1.txt", "_pmc_tcc2.txt")
+
+    def counter(path, name):
+        if not os.path.exists(path):
+            return None
+        block = False
+        for line in open(path):
+            if line.startswith("=="):
+                block = f"{kernel}_kernel" in line
+            elif block and line.split()[:1] == [name]:
+                m = re.search(r"mean\s+([0-9.]+)", line)
+                return float(m.group(1)) if m else None
+        return None
+    fetch, write = counter(f1, "FETCH_SIZE"), counter(f2, "WRITE_SIZE")
+    if fetch is None or write is None:
+        return {"traffic": None}
+    return {"traffic": round((2.0 * fetch + write) * 1024.0), "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
+            "traffic_source": os.path.relpath(f1, os.path.dirname(root))}
+
+
 def cpu_baseline(cfg, sd, x, budget_s=15.0):
     """Reference CPU path timed beside the GPU: the oracle restatement of the reference PyTorch model (same torch ops,
     fp32, eval, softmax included) on the host cores.  Bounded sample: whole batches of 256 until ~budget_s elapsed."""
@@ -237,7 +269,7 @@ def main():
         achieved = dom_flops / (agg[dom] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": dom, "launches_per_step": cnt[dom],
                     "avg_launch_ms": round(agg[dom] / cnt[dom], 5), "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), **committed_pmc_traffic(dom),
                     "whole_forward": {"event_ms_per_step": round(ev_ms, 4),
                                       "achieved": round(flops_total / (ev_ms * 1e-3) / 1e12, 2),
                                       "frac": round(flops_total / (ev_ms * 1e-3) / 1e12 / peak, 4)},

@@ -58,11 +58,11 @@ static_assert(TW_WIN == 16, "one E or P phase consumes exactly one window");
 typedef half_t half2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// (a + ca, b + cb) -> ReLU -> packed f16 pair, 3 VALU: the mix forms add in f32 and round once (RNE) into one half of the
-// destination; max(f16(x), 0) == f16(max(x, 0)).  Inline asm: the caller keeps MFMA results >= 18 wait states away.
-__device__ __forceinline__ uint32_t pack_relu_h2(float a, float ca, float b, float cb) {
+// (a, b) -> ReLU -> packed f16 pair, 2 VALU: v_cvt_pk_f16_f32 (gfx950) rounds both to nearest even; the BN bias is already in the
+// accumulator (the expand accumulators START at the bias).
+__device__ __forceinline__ uint32_t pack_relu_cvt(float a, float b) {
     uint32_t r;
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, %2\n\tv_fma_mixhi_f16 %0, %3, 1.0, %4\n\tv_pk_max_f16 %0, %0, 0" : "=&v"(r) : "v"(a), "v"(ca), "v"(b), "v"(cb));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=&v"(r) : "v"(a), "v"(b));
     return r;
 }
 
@@ -108,7 +108,7 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) accE[ct][v] = 0.f;
+            for (int v = 0; v < 16; ++v) accE[ct][v] = bias[v >> 2][v & 3];      // accumulate on top of the BN1 bias
         frag bfa[4], bfb[4];                         // [k-step parity within the step][square tile]
 #pragma unroll
         for (int i = 0; i < 4; ++i) bfa[i] = *reinterpret_cast<const frag*>(xsr + (i & 1) * 32 * XROW + (i >> 1) * 16);
@@ -143,7 +143,7 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
     auto expand_epilogue = [&](int ct) {
         uint32_t o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = pack_relu_h2(accE[ct][2 * i], bias[i >> 1][(2 * i) & 3], accE[ct][2 * i + 1], bias[i >> 1][(2 * i + 1) & 3]);
+        for (int i = 0; i < 8; ++i) o[i] = pack_relu_cvt(accE[ct][2 * i], accE[ct][2 * i + 1]);
         uint4* dst = reinterpret_cast<uint4*>(t1w + ct * 32 * T1ROW);
         dst[0] = uint4{o[0], o[1], o[2], o[3]};
         dst[1] = uint4{o[4], o[5], o[6], o[7]};

@@ -382,13 +382,14 @@ Bitboard Position::attackers_to(int sq, Bitboard occ) const {
 
 void Position::update_checkers() {
     const int ksq = king_square(stm_);
-    checkers_ = ksq == SQ_NONE ? 0 : attackers_to(ksq, pieces()) & pieces(Color(stm_ ^ 1));
+    // antichess: the king is an ordinary piece, there is no check; horde: White has no king
+    checkers_ = (ksq == SQ_NONE || variant_ == V_ANTI) ? 0 : attackers_to(ksq, pieces()) & pieces(Color(stm_ ^ 1));
 }
 
 bool Position::pseudo_is_legal(Move m) const {
     const Color us = stm_, them = Color(us ^ 1);
     const int ksq = king_square(us);
-    if (ksq == SQ_NONE) return true;
+    if (ksq == SQ_NONE || variant_ == V_ANTI) return true;
     const Bitboard occ = pieces();
     const int to = to_sq(m);
     switch (kind_of(m)) {
@@ -420,6 +421,7 @@ void Position::gen_pseudo(std::vector<Move>& out) const {
     auto add_pawn = [&](int from, int to) {
         if (rank_of(to) == promo_rank) {
             for (PieceType pt : {QUEEN, ROOK, BISHOP, KNIGHT}) out.push_back(make_move(from, to, PROMOTION, pt));
+            if (variant_ == V_ANTI) out.push_back(make_move(from, to, PROMOTION, KING));     // antichess: promotion to a king
         } else {
             out.push_back(make_move(from, to));
         }
@@ -429,7 +431,9 @@ void Position::gen_pseudo(std::vector<Move>& out) const {
         const int one = from + up;
         if (one >= 0 && one < 64 && !(occ & sq_bb(one))) {
             add_pawn(from, one);
-            if (rank_of(from) == start_rank && !(occ & sq_bb(one + up))) out.push_back(make_move(from, one + up));
+            // horde: the white pawns of the first rank may also advance two squares
+            const bool two = rank_of(from) == start_rank || (variant_ == V_HORDE && us == WHITE && rank_of(from) == 0);
+            if (two && !(occ & sq_bb(one + up))) out.push_back(make_move(from, one + up));
         }
         Bitboard caps = g_pawn_att[us][from] & enemy;
         while (caps) add_pawn(from, pop_lsb(caps));
@@ -450,8 +454,8 @@ void Position::gen_pseudo(std::vector<Move>& out) const {
     b = pieces(us, KING);
     while (b) { const int s = pop_lsb(b); add_targets(s, g_king[s]); }
 
-    // castling (king-takes-rook encoding), legality checked here the way Stockfish's legal() does
-    if (castling_ && !checkers_) {
+    // castling (king-takes-rook encoding), legality checked here the way Stockfish's legal() does; none in antichess
+    if (castling_ && !checkers_ && variant_ != V_ANTI) {
         const int ksq = king_square(us);
         for (int side = 0; side < 2; ++side) {
             const int cr = (us == WHITE ? 1 : 4) << side;
@@ -487,8 +491,18 @@ void Position::legal_moves(std::vector<Move>& out) const {
     std::vector<Move> pseudo;
     pseudo.reserve(96);
     gen_pseudo(pseudo);
-    for (Move m : pseudo)
-        if (pseudo_is_legal(m)) out.push_back(m);
+    if (variant_ == V_ANTI) {                        // antichess: if a capture exists, a capture must be played
+        bool any_capture = false;
+        for (Move m : pseudo) any_capture |= kind_of(m) == ENPASSANT || board_[to_sq(m)] != 0;
+        for (Move m : pseudo)
+            if (!any_capture || kind_of(m) == ENPASSANT || board_[to_sq(m)] != 0) out.push_back(m);
+        return;
+    }
+    for (Move m : pseudo) {
+        if (!pseudo_is_legal(m)) continue;
+        if (variant_ == V_RACE && gives_check(m)) continue;     // racing kings: giving check is forbidden
+        out.push_back(m);
+    }
 }
 
 bool Position::gives_check(Move m) const {
@@ -557,7 +571,8 @@ void Position::do_move(Move m, const Key* known_key) {
         if (promoted_ & sq_bb(from)) promoted_ = (promoted_ & ~sq_bb(from)) | sq_bb(to);
         if (moving == PAWN) {
             rule50_ = 0;
-            if ((to ^ from) == 16) {
+            // horde: a double step from the first rank cannot be captured en passant
+            if ((to ^ from) == 16 && !(variant_ == V_HORDE && rank_of(from) == (us == WHITE ? 0 : 7))) {
                 const int mid = (to + from) / 2;
                 if (g_pawn_att[us][mid] & pieces(them, PAWN)) new_ep = mid;
             }
@@ -665,6 +680,27 @@ bool Position::draw_by_insufficient_material() const {             // board.cpp:
 }
 
 TerminalType Position::is_terminal(size_t n_legal) const {          // boardstate.cpp:143-226
+    const Color them = Color(stm_ ^ 1);
+    if (variant_ == V_ANTI) {                                       // is_anti_win / is_anti_loss: whoever has no piece left has won
+        if (!pieces(stm_)) return TERMINAL_WIN;
+        if (!pieces(them)) return TERMINAL_LOSS;
+    }
+    if (variant_ == V_HORDE) {                                      // is_horde_loss: the side without a king has lost all its pieces
+        const Color horde = pieces(WHITE, KING) ? BLACK : WHITE;
+        if (horde == stm_ && !pieces(horde)) return TERMINAL_LOSS;
+    }
+    if (variant_ == V_RACE && pieces(stm_, KING) && pieces(them, KING)) {   // is_race_win / _draw / _loss
+        const int mine = king_square(stm_), theirs = king_square(them);
+        if (rank_of(mine) == 7) return rank_of(theirs) == 7 ? TERMINAL_DRAW : TERMINAL_WIN;
+        if (rank_of(theirs) == 7) {
+            // White arrived first: Black may still equalise if its king can step to the eighth rank right now
+            if (rank_of(mine) < (stm_ == WHITE ? 7 : 6)) return TERMINAL_LOSS;
+            Bitboard b = g_king[mine] & (0xFFull << 56) & ~pieces(stm_);
+            bool can_follow = false;
+            while (b) can_follow |= !(attackers_to(pop_lsb(b), pieces()) & pieces(them));
+            if (!can_follow) return TERMINAL_LOSS;
+        }
+    }
     if (variant_ == V_KOTH) {
         if (pieces(stm_, KING) & kCenter) return TERMINAL_WIN;
         if (pieces(Color(stm_ ^ 1), KING) & kCenter) return TERMINAL_LOSS;
@@ -673,7 +709,10 @@ TerminalType Position::is_terminal(size_t n_legal) const {          // boardstat
         if (checks_given_[stm_] >= 3) return TERMINAL_WIN;
         if (checks_given_[stm_ ^ 1] >= 3) return TERMINAL_LOSS;
     }
-    if (n_legal == 0) return checkers_ ? TERMINAL_LOSS : TERMINAL_DRAW;
+    if (n_legal == 0) {
+        if (variant_ == V_ANTI) return TERMINAL_WIN;                // a stalemate is a win in antichess
+        return checkers_ ? TERMINAL_LOSS : TERMINAL_DRAW;
+    }
     if (can_claim_3fold_repetition() || is_50_move_rule_draw(n_legal) || draw_by_insufficient_material()) return TERMINAL_DRAW;
     return TERMINAL_NONE;
 }

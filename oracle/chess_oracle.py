@@ -247,7 +247,9 @@ class Board:
 
     def checkers(self):
         ks = self.king_sq(self.stm == 0)
-        return [] if ks is None else self.attacked_by(ks, self.stm != 0)
+        if ks is None or self.variant == 4:          # horde: White has no king; antichess: no check at all
+            return []
+        return self.attacked_by(ks, self.stm != 0)
 
     # ------------------------------------------------------------------------------------------------ move generation
     def _pseudo(self):
@@ -267,7 +269,8 @@ class Board:
                 targets = []
                 if 0 <= r + dr < 8 and self.b[sq(f, r + dr)] is None:
                     targets.append((sq(f, r + dr), "normal"))
-                    if r == (1 if white else 6) and self.b[sq(f, r + 2 * dr)] is None:
+                    two = r == (1 if white else 6) or (self.variant == 6 and white and r == 0)   # horde: first-rank pawns too
+                    if two and self.b[sq(f, r + 2 * dr)] is None:
                         targets.append((sq(f, r + 2 * dr), "normal"))
                 for df in (-1, 1):
                     if 0 <= f + df < 8 and 0 <= r + dr < 8:
@@ -278,7 +281,7 @@ class Board:
                             targets.append((d, "ep"))
                 for d, kind in targets:
                     if (d >> 3) == promo_r:
-                        for pc in "qrbn":
+                        for pc in ("qrbnk" if self.variant == 4 else "qrbn"):      # antichess: promotion to a king
                             yield (s, d, "promo", pc)
                     else:
                         yield (s, d, kind, None)
@@ -301,7 +304,7 @@ class Board:
                         nr += dr
         # castling
         ks = self.king_sq(white)
-        if ks is not None and not self.attacked_by(ks, not white):
+        if ks is not None and self.variant != 4 and not self.attacked_by(ks, not white):      # no castling in antichess
             back = 0 if white else 56
             for key, oo in ((("K" if white else "k"), True), (("Q" if white else "q"), False)):
                 if key not in self.castle:
@@ -359,13 +362,22 @@ class Board:
 
     def legal_moves(self):
         white = self.stm == 0
+        if self.variant == 4:                         # antichess: every pseudo-legal move, captures compulsory when there is one
+            pseudo = list(self._pseudo())
+            caps = [m for m in pseudo if m[2] == "ep" or self.b[m[1]] is not None]
+            return caps if caps else pseudo
         out = []
         for mv in self._pseudo():
             b2 = list(self.b)
             self._apply(mv, b2)
             ks = self.king_sq(white, b2)
-            if ks is None or not self.attacked_by(ks, not white, b2):
-                out.append(mv)
+            if ks is not None and self.attacked_by(ks, not white, b2):
+                continue
+            if self.variant == 7:                     # racing kings: a move that gives check is illegal
+                ok = self.king_sq(not white, b2)
+                if ok is not None and self.attacked_by(ok, white, b2):
+                    continue
+            out.append(mv)
         return out
 
     def move_uci(self, mv) -> str:
@@ -428,7 +440,7 @@ class Board:
                 self.promoted.add(to)
             if moving.upper() == "P":
                 self.rule50 = 0
-                if abs(to - frm) == 16:
+                if abs(to - frm) == 16 and not (self.variant == 6 and (frm >> 3) == (0 if white else 7)):   # horde: none from rank 1
                     mid = (to + frm) // 2
                     if self._ep_valid_after_push(mid, white):
                         new_ep = mid
@@ -477,9 +489,40 @@ class Board:
         return 0 if self.repetition == 0 else 1
 
     def terminal(self):
-        """BoardState::is_terminal (boardstate.cpp:143-226) for chess / crazyhouse / koth / 3check."""
+        """BoardState::is_terminal (boardstate.cpp:143-226) for chess / crazyhouse / koth / 3check / antichess / horde / racing kings
+        (the variant predicates are those of the multi-variant Stockfish fork the reference links: is_anti_win, is_horde_loss,
+        is_race_win/draw/loss)."""
         n = len(self.legal_moves())
         me_white = self.stm == 0
+        mine = [p for p in self.b if p is not None and p.isupper() == me_white]
+        theirs = [p for p in self.b if p is not None and p.isupper() != me_white]
+        if self.variant == 4:                         # is_anti_win / is_anti_loss
+            if not mine:
+                return TERMINAL_WIN
+            if not theirs:
+                return TERMINAL_LOSS
+        if self.variant == 6:                         # is_horde_loss: the kingless side has nothing left and is to move
+            horde_white = self.king_sq(True) is None
+            if horde_white == me_white and not mine:
+                return TERMINAL_LOSS
+        if self.variant == 7:                         # is_race_win / is_race_draw / is_race_loss
+            km, kt = self.king_sq(me_white), self.king_sq(not me_white)
+            if km is not None and kt is not None:
+                if (km >> 3) == 7:
+                    return TERMINAL_DRAW if (kt >> 3) == 7 else TERMINAL_WIN
+                if (kt >> 3) == 7:
+                    if (km >> 3) < (7 if me_white else 6):
+                        return TERMINAL_LOSS
+                    can_follow = False
+                    for df, dr in KING_D:
+                        nf, nr = (km & 7) + df, (km >> 3) + dr
+                        if nr == 7 and 0 <= nf < 8:
+                            d = sq(nf, nr)
+                            own_there = self.b[d] is not None and self.b[d].isupper() == me_white
+                            if not own_there and not self.attacked_by(d, not me_white):
+                                can_follow = True
+                    if not can_follow:
+                        return TERMINAL_LOSS
         if self.variant == 2:
             center = (27, 28, 35, 36)
             if self.king_sq(me_white) in center:
@@ -492,6 +535,8 @@ class Board:
             if self.checks_given[self.stm ^ 1] >= 3:
                 return TERMINAL_LOSS
         if n == 0:
+            if self.variant == 4:
+                return TERMINAL_WIN                   # a stalemate is a win in antichess
             return TERMINAL_LOSS if self.checkers() else TERMINAL_DRAW
         if self.repetition < 0:
             return TERMINAL_DRAW

@@ -382,14 +382,28 @@ Bitboard Position::attackers_to(int sq, Bitboard occ) const {
 
 void Position::update_checkers() {
     const int ksq = king_square(stm_);
-    // antichess: the king is an ordinary piece, there is no check; horde: White has no king
-    checkers_ = (ksq == SQ_NONE || variant_ == V_ANTI) ? 0 : attackers_to(ksq, pieces()) & pieces(Color(stm_ ^ 1));
+    // antichess: the king is an ordinary piece, there is no check; horde: White has no king; atomic: a king next to the enemy
+    // king cannot be captured (the capture would blow up the capturer's own king), so it is never in check there
+    const bool exempt = ksq == SQ_NONE || variant_ == V_ANTI ||
+                        (variant_ == V_ATOMIC && (g_king[ksq] & pieces(Color(stm_ ^ 1), KING)));
+    checkers_ = exempt ? 0 : attackers_to(ksq, pieces()) & pieces(Color(stm_ ^ 1));
 }
 
 bool Position::pseudo_is_legal(Move m) const {
     const Color us = stm_, them = Color(us ^ 1);
     const int ksq = king_square(us);
     if (ksq == SQ_NONE || variant_ == V_ANTI) return true;
+    if (variant_ == V_ATOMIC && kind_of(m) != CASTLING) {
+        // play it on a copy (captures explode): my king must survive; blowing up the enemy king wins on the spot and overrides any
+        // check; otherwise my king must not be attacked -- unless the kings stand next to each other
+        Position p(*this);
+        p.do_move(m);
+        const int k2 = p.king_square(us);
+        if (k2 == SQ_NONE) return false;
+        if (p.king_square(them) == SQ_NONE) return true;
+        if (g_king[k2] & p.pieces(them, KING)) return true;
+        return !(p.attackers_to(k2, p.pieces()) & p.pieces(them));
+    }
     const Bitboard occ = pieces();
     const int to = to_sq(m);
     switch (kind_of(m)) {
@@ -452,7 +466,7 @@ void Position::gen_pseudo(std::vector<Move>& out) const {
     b = pieces(us, QUEEN);
     while (b) { const int s = pop_lsb(b); add_targets(s, bishop_attacks(s, occ) | rook_attacks(s, occ)); }
     b = pieces(us, KING);
-    while (b) { const int s = pop_lsb(b); add_targets(s, g_king[s]); }
+    while (b) { const int s = pop_lsb(b); add_targets(s, variant_ == V_ATOMIC ? g_king[s] & ~enemy : g_king[s]); }   // atomic kings never capture
 
     // castling (king-takes-rook encoding), legality checked here the way Stockfish's legal() does; none in antichess
     if (castling_ && !checkers_ && variant_ != V_ANTI) {
@@ -557,6 +571,7 @@ void Position::do_move(Move m, const Key* known_key) {
         const int moving = board_[from] & 7;
         int capsq = to;
         if (kind == ENPASSANT) capsq = us == WHITE ? to - 8 : to + 8;
+        const bool atomic_blast = variant_ == V_ATOMIC && board_[capsq] != 0;
         if (board_[capsq]) {
             int cap_type = board_[capsq] & 7;
             if (is_house()) {
@@ -583,6 +598,17 @@ void Position::do_move(Move m, const Key* known_key) {
             }
         }
         castling_ &= ~(castling_mask_[from] | castling_mask_[to]);
+        if (atomic_blast) {
+            // atomic: the capturing piece and every non-pawn piece on the squares around the destination are removed as well
+            remove_piece(to);
+            Bitboard ring = g_king[to] & pieces() & ~by_type_[PAWN];
+            while (ring) {
+                const int sq = pop_lsb(ring);
+                castling_ &= ~castling_mask_[sq];
+                remove_piece(sq);
+            }
+            new_ep = SQ_NONE;
+        }
     }
     ep_ = new_ep;
     stm_ = them;
@@ -681,6 +707,10 @@ bool Position::draw_by_insufficient_material() const {             // board.cpp:
 
 TerminalType Position::is_terminal(size_t n_legal) const {          // boardstate.cpp:143-226
     const Color them = Color(stm_ ^ 1);
+    if (variant_ == V_ATOMIC) {                                     // is_atomic_win / is_atomic_loss: a king has been blown up
+        if (!pieces(them, KING)) return TERMINAL_WIN;
+        if (!pieces(stm_, KING)) return TERMINAL_LOSS;
+    }
     if (variant_ == V_ANTI) {                                       // is_anti_win / is_anti_loss: whoever has no piece left has won
         if (!pieces(stm_)) return TERMINAL_WIN;
         if (!pieces(them)) return TERMINAL_LOSS;

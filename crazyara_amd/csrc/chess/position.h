@@ -20,7 +20,8 @@ enum MoveKind : int { NORMAL = 0, PROMOTION = 1, ENPASSANT = 2, CASTLING = 3, DR
 enum Variant : int { V_CHESS = 0, V_CRAZYHOUSE = 1, V_KOTH = 2, V_THREECHECK = 3,
                      // lichess variants of the MultiAra build: antichess (captures compulsory, no check, king promotion,
                      // win by losing everything or being stalemated), horde (White = 36 pawns without a king), racing kings
-                     // (no checks, first king on the eighth rank); atomic: FEN / input planes only, no explosion rules yet
+                     // (no checks, first king on the eighth rank), atomic (captures explode, kings never capture, touching kings
+                     // are immune to check, blowing up the enemy king wins at once)
                      V_ANTI = 4, V_ATOMIC = 5, V_HORDE = 6, V_RACE = 7 };
 enum CastlingRight : int { WHITE_OO = 1, WHITE_OOO = 2, BLACK_OO = 4, BLACK_OOO = 8 };
 enum TerminalType : int { TERMINAL_LOSS = 0, TERMINAL_DRAW = 1, TERMINAL_WIN = 2, TERMINAL_CUSTOM = 3, TERMINAL_NONE = 4 };  // state.h

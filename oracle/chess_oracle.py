@@ -245,9 +245,15 @@ class Board:
                 return i
         return None
 
+    def _kings_touch(self, board=None):
+        a, b = self.king_sq(True, board), self.king_sq(False, board)
+        return a is not None and b is not None and max(abs((a & 7) - (b & 7)), abs((a >> 3) - (b >> 3))) == 1
+
     def checkers(self):
         ks = self.king_sq(self.stm == 0)
         if ks is None or self.variant == 4:          # horde: White has no king; antichess: no check at all
+            return []
+        if self.variant == 5 and self._kings_touch():   # atomic: touching kings cannot be captured, hence never in check
             return []
         return self.attacked_by(ks, self.stm != 0)
 
@@ -358,6 +364,16 @@ class Board:
             board[frm] = None
             if kind == "promo":
                 board[to] = extra.upper() if white else extra.lower()
+            self._blast = []
+            if self.variant == 5 and cap is not None:      # atomic: the capturer and every non-pawn piece around `to` go as well
+                board[to] = None
+                f, r = to & 7, to >> 3
+                for df, dr in KING_D:
+                    if 0 <= f + df < 8 and 0 <= r + dr < 8:
+                        d = sq(f + df, r + dr)
+                        if board[d] is not None and board[d].upper() != "P":
+                            board[d] = None
+                            self._blast.append(d)
         return cap
 
     def legal_moves(self):
@@ -367,7 +383,20 @@ class Board:
             caps = [m for m in pseudo if m[2] == "ep" or self.b[m[1]] is not None]
             return caps if caps else pseudo
         out = []
+        if self.variant == 5 and self.king_sq(white) is None:
+            return list(self._pseudo())               # my king is already gone (the game is over): nothing left to protect
         for mv in self._pseudo():
+            if self.variant == 5:                     # atomic
+                if mv[2] != "castle" and self.b[mv[0]].upper() == "K" and self.b[mv[1]] is not None:
+                    continue                          # kings never capture
+                b2 = list(self.b)
+                self._apply(mv, b2)
+                ks, ko = self.king_sq(white, b2), self.king_sq(not white, b2)
+                if ks is None:
+                    continue                          # my own king would blow up
+                if ko is None or self._kings_touch(b2) or not self.attacked_by(ks, not white, b2):
+                    out.append(mv)                    # enemy king blown up (overrides check), touching kings, or simply safe
+                continue
             b2 = list(self.b)
             self._apply(mv, b2)
             ks = self.king_sq(white, b2)
@@ -446,8 +475,8 @@ class Board:
                         new_ep = mid
                 if kind == "promo" and self.variant == 1:
                     self.promoted.add(to)
-        # castling rights: lost when something moves from / to the king's or that rook's original square
-        for s_ in (frm, to):
+        # castling rights: lost when something moves from / to the king's or that rook's original square (atomic: or is blown up)
+        for s_ in (frm, to) + tuple(getattr(self, "_blast", ()) if kind not in ("drop", "castle") else ()):
             for key in self.castle_mask.get(s_, ()):
                 self.castle.pop(key, None)
         self.ep = new_ep
@@ -496,6 +525,11 @@ class Board:
         me_white = self.stm == 0
         mine = [p for p in self.b if p is not None and p.isupper() == me_white]
         theirs = [p for p in self.b if p is not None and p.isupper() != me_white]
+        if self.variant == 5:                         # is_atomic_win / is_atomic_loss
+            if self.king_sq(not me_white) is None:
+                return TERMINAL_WIN
+            if self.king_sq(me_white) is None:
+                return TERMINAL_LOSS
         if self.variant == 4:                         # is_anti_win / is_anti_loss
             if not mine:
                 return TERMINAL_WIN

@@ -1,5 +1,5 @@
-"""Rules of the lichess variants of the MultiAra build (antichess, horde, racing kings): the reference's own known-answer tests
-(engine/tests/tests.cpp: Variants_Horde :1000-1137, Racing_Kings :1186-1218, Antichess :1408-1448) against the product Position
+"""Rules of the lichess variants of the MultiAra build (antichess, atomic, horde, racing kings): the reference's own known-answer tests
+(engine/tests/tests.cpp: Variants_Horde :1000-1137, Racing_Kings :1186-1218, Atomic :1220-1295, Antichess :1408-1448) against the product Position
 (through the C ABI) AND the oracle board, plus random playouts product == oracle."""
 import random
 
@@ -151,7 +151,46 @@ def test_antichess_reference_cases(hip_lib, impl):
     assert "e8c8" not in impl("r3kbnr/p2pp1pp/bp3p2/8/3P4/P1P5/1B1P1PPP/RN1QK2R b - - 0 9", v).legal()
 
 
-@pytest.mark.parametrize("variant,seed", [("antichess", 1), ("horde", 2), ("racingkings", 3), ("antichess", 4), ("horde", 5), ("racingkings", 6)])
+@pytest.mark.parametrize("impl", IMPLS)
+def test_atomic_reference_cases(hip_lib, impl):
+    """engine/tests/tests.cpp:1220-1295"""
+    v = "atomic"
+    assert impl("", v).fen() == "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"
+    # capturer and captured always die; everything within one square explodes, except pawns
+    for fen, mv, after in (
+            ("rn1qkb1r/p1p3pp/b3pp1n/3pP3/1P1P1P2/7P/P5P1/RNBQKBNR w KQkq - 1 7", "f1a6", "rn1qkb1r/p1p3pp/4pp1n/3pP3/1P1P1P2/7P/P5P1/RNBQK1NR b KQkq - 0 7"),
+            ("1r1qk2r/2p3pp/p1n1pp1n/1P1pP3/1b1P1P2/P6P/4Q1P1/RNB1K1NR w KQk - 1 11", "a3b4", "1r1qk2r/2p3pp/p1n1pp1n/1P1pP3/3P1P2/7P/4Q1P1/RNB1K1NR b KQk - 0 11"),
+            ("1r2k2r/R1p3pp/7n/2npp3/1B1P1PP1/1q5P/2Q4R/1N3KN1 w k - 2 22", "c2b3", "1r2k2r/R1p3pp/7n/2npp3/3P1PP1/7P/7R/1N3KN1 b k - 0 22"),
+            ("1r3rk1/R1p3p1/6Pp/2nppn2/3P1P2/7P/7R/1N3KN1 w - - 0 25", "a7c7", "5rk1/6p1/6Pp/2nppn2/3P1P2/7P/7R/1N3KN1 b - - 0 25"),
+            ("2r3k1/6p1/6Pp/3pp3/3P1P2/2N3nP/1n5R/2K3N1 b - - 8 29", "e5d4", "2r3k1/6p1/6Pp/3p4/5P2/6nP/1n5R/2K3N1 w - - 0 30"),
+            ("6k1/6p1/6Pp/3p4/5P2/6nP/Kn5R/2r3N1 b - - 3 31", "c1g1", "6k1/6p1/6Pp/3p4/5P2/6nP/Kn6/8 w - - 0 32")):
+        x = impl(fen, v)
+        x.push(mv)
+        assert x.fen() == after, (fen, mv)
+    # nuking the opposite king wins at once ...
+    x = impl("6k1/5Kp1/2q3P1/5n1p/5P1P/8/1n6/8 b - - 1 40", v)
+    x.push("c6g6")
+    assert x.result() == BLACK_WIN
+    # ... overriding checks ...
+    x = impl("8/1q6/8/8/8/5k2/1R4n1/1K6 w - - 0 1", v)
+    assert "b2g2" in x.legal()
+    x.push("b2g2")
+    assert x.result() == WHITE_WIN
+    # ... and checkmates
+    x = impl("8/1q6/r7/8/8/5k2/R5n1/K7 w - - 0 1", v)
+    assert "a2g2" in x.legal()
+    x.push("a2g2")
+    assert x.result() == WHITE_WIN
+    # checkmate: the mating piece cannot be taken by the king, nor by others if the own king would explode
+    assert impl("3q4/6Qk/4r3/p7/6Pp/7P/8/1R2R1K1 b - - 8 29", v).result() == WHITE_WIN
+    assert impl("8/kQ3r2/6p1/2P3Pp/7P/4p3/1K2B3/n7 b - - 3 39", v).result() == WHITE_WIN
+    # kings may stand next to each other but never capture
+    assert "e6f7" in impl("6k1/6p1/4K1Pp/5n2/5P2/7P/1n6/3q4 w - - 0 37", v).legal()
+    assert "g8f8" not in impl("5Kk1/6p1/2q3Pp/5n2/5P1P/8/1n6/8 b - - 2 39", v).legal()
+
+
+@pytest.mark.parametrize("variant,seed", [("antichess", 1), ("horde", 2), ("racingkings", 3), ("antichess", 4), ("horde", 5), ("racingkings", 6),
+                                          ("atomic", 7), ("atomic", 8), ("atomic", 9)])
 def test_random_playouts_product_equals_oracle(hip_lib, variant, seed):
     """Same legal move sets, FENs and terminal verdicts along seeded random games; lichess input planes (v1 and v3) and the policy
     index of every legal move agree as well."""

@@ -240,6 +240,14 @@ CASES = [
     ("chess", True, "bnnrkbrq/pppppppp/8/8/8/8/PPPPPPPP/BNNRKBRQ w GDgd - 0 1", 1, 150, 4, 3, 1.3),
     ("3check", False, "1r4k1/1p2bp1p/3p2p1/PprPp2n/1R2PPq1/3Q4/1P1B1NPP/5RK1 b - - 1+1 2 22", 2, 200, 8, 3, 1.7),
     ("kingofthehill", False, "rnbq1bnr/pppp1ppp/4k3/8/4P3/3K4/PPPP1PPP/RNBQ1BNR w - - 4 5", 2, 150, 8, 3, 1.7),
+    # the other lichess variants of the MultiAra build: their terminals (stalemate = win, blown-up king, eighth rank) inside the tree
+    ("antichess", False, "rnb1kbnr/pp1ppppp/8/q1p5/8/2P1P3/PP1PNPPP/RNBQKB1R b - - 0 3", 2, 200, 8, 3, 1.7),
+    ("antichess", False, "8/8/6p1/7q/8/8/5P2/8 b - - 0 39", 2, 120, 8, 3, 1.7),
+    ("atomic", False, "rn1qkb1r/p1p3pp/b3pp1n/3pP3/1P1P1P2/7P/P5P1/RNBQKBNR w KQkq - 1 7", 2, 200, 8, 3, 1.7),
+    ("atomic", False, "8/1q6/8/8/8/5k2/1R4n1/1K6 w - - 0 1", 2, 150, 8, 3, 1.7),
+    ("horde", False, "", 2, 150, 8, 3, 1.7),
+    ("racingkings", False, "", 2, 200, 8, 3, 1.7),
+    ("racingkings", False, "2r2N2/kn2R1K1/8/8/8/8/8/8 w - - 8 26", 2, 150, 8, 3, 1.7),
 ]
 
 

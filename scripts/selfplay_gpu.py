@@ -20,8 +20,9 @@ import torch  # noqa: E402
 from crazyara_amd import build, netfile, replicas, rise_config, search, selfplay  # noqa: E402
 from crazyara_amd.neuralnetapi import HipAPI  # noqa: E402
 
-MODES = {"crazyhouse": (0, 1, 34, 81, "1.0"), "chess": (1, 3, 52, 76, "3.0"), "3check": (2, 3, 80, 84, "3.0"),
-         "kingofthehill": (2, 3, 80, 84, "3.0")}
+LICHESS = (2, 3, 80, 84, "3.0")        # MODE_LICHESS tables: 80-channel v3 planes, 84 policy channels
+MODES = {"crazyhouse": (0, 1, 34, 81, "1.0"), "chess": (1, 3, 52, 76, "3.0"), "3check": LICHESS, "kingofthehill": LICHESS,
+         "antichess": LICHESS, "atomic": LICHESS, "horde": LICHESS, "racingkings": LICHESS}
 
 
 def main():

@@ -7,6 +7,7 @@
 #include <string>
 
 #include "capi_common.h"
+#include "nn/onnx_import.h"
 #include "nn/rise_net.h"
 
 namespace {
@@ -52,6 +53,15 @@ mi_net* mi_net_create(const char* model_dir, int device_id, int batch_size, cons
     return h;
 }
 void mi_net_destroy(mi_net* net) { delete net; }
+
+int mi_onnx_to_cranet(const char* onnx_path, const char* cranet_path) {
+    if (!onnx_path || !cranet_path) { g_err = "null argument to mi_onnx_to_cranet"; return 1; }
+    return guard([&] {
+        cra::NetFile nf;
+        cra::import_onnx(onnx_path, nf);
+        cra::write_cranet(nf, cranet_path);
+    });
+}
 
 int mi_net_design(const mi_net* net, int in_shape[4], int* nb_policy, int* nb_aux, int* version, int* game_phase) {
     if (!net) { g_err = "null net"; return 1; }

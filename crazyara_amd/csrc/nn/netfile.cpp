@@ -78,6 +78,20 @@ static bool has_suffix(const std::string& s, const std::string& suf) {
     return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
 }
 
+static std::string pick_model_file(const std::vector<std::string>& files, const std::string& model_dir, int batch_size, const std::string& ext) {
+    const std::string want = "-bsize-" + std::to_string(batch_size) + ext;
+    for (auto& f : files) if (has_suffix(f, want)) return f;
+    for (auto& f : files) {
+        if (has_suffix(f, ext)) {
+            if (f.find("-bsize-") != std::string::npos)
+                throw std::invalid_argument("The given directory at " + model_dir + " should either contain a " + ext.substr(1) +
+                    " file supporting the current batch size or one without -bsize-");
+            return f;
+        }
+    }
+    return "";
+}
+
 std::string find_model_file(const std::string& model_dir, int batch_size) {
     std::vector<std::string> files;
     if (DIR* d = opendir(model_dir.c_str())) {
@@ -87,17 +101,12 @@ std::string find_model_file(const std::string& model_dir, int batch_size) {
         throw std::invalid_argument("The given directory at " + model_dir + " cannot be opened");
     }
     std::sort(files.begin(), files.end());
-    const std::string want = "-bsize-" + std::to_string(batch_size) + ".cranet";
-    for (auto& f : files) if (has_suffix(f, want)) return f;
-    for (auto& f : files) {
-        if (has_suffix(f, ".cranet")) {
-            if (f.find("-bsize-") != std::string::npos)
-                throw std::invalid_argument("The given directory at " + model_dir +
-                    " should either contain a cranet file supporting the current batch size or one without -bsize-");
-            return f;
-        }
+    // a converted container wins over the ONNX it came from (as the reference prefers its cached .trt engine, tensorrtapi.cpp:297-332)
+    for (const char* ext : {".cranet", ".onnx"}) {
+        std::string f = pick_model_file(files, model_dir, batch_size, ext);
+        if (!f.empty()) return f;
     }
-    throw std::invalid_argument("The given directory at " + model_dir + " doesn't contain a file ending with .cranet");
+    throw std::invalid_argument("The given directory at " + model_dir + " doesn't contain a file ending with .cranet or .onnx");
 }
 
 int read_version_from_string(const std::string& s) {

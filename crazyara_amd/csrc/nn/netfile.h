@@ -32,8 +32,8 @@ struct NetFile {
     std::vector<std::string> list(const std::string& key) const;   // comma separated
 };
 
-// Mirrors get_onnx_model_name() (engine/src/nn/neuralnetapi.cpp:57-73) for "*.cranet" files:
-// prefers "*-bsize-<B>.cranet", else the first "*.cranet" without "-bsize-"; throws invalid_argument otherwise.
+// get_onnx_model_name() (engine/src/nn/neuralnetapi.cpp:57-73) for "*.cranet" and, when the directory holds none, "*.onnx":
+// prefers "*-bsize-<B><ext>", else the first "*<ext>" without "-bsize-"; throws invalid_argument otherwise.
 std::string find_model_file(const std::string& model_dir, int batch_size);
 
 // Mirrors read_version_from_string() (neuralnetapi.cpp:194-227): "-v<maj>.<min>" -> make_version(maj,min,0)

@@ -8,6 +8,7 @@
 #include <stdexcept>
 
 #include "kernels.h"
+#include "onnx_import.h"
 #include "../chess/planes_host.h"
 
 namespace cra {
@@ -149,7 +150,8 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
 
     // model discovery (TensorrtAPI ctor, tensorrtapi.cpp:53-58)
     std::string dir, file;
-    if (model_path.size() > 7 && model_path.compare(model_path.size() - 7, 7, ".cranet") == 0) {
+    auto ends_with = [&](const char* ext) { const size_t n = strlen(ext); return model_path.size() > n && model_path.compare(model_path.size() - n, n, ext) == 0; };
+    if (ends_with(".cranet") || ends_with(".onnx")) {
         const size_t sl = model_path.find_last_of('/');
         dir = sl == std::string::npos ? "./" : model_path.substr(0, sl + 1);
         file = sl == std::string::npos ? model_path : model_path.substr(sl + 1);
@@ -168,8 +170,9 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     if (device_id < 0 || device_id >= ndev) throw std::invalid_argument("device id out of range");
     HIP_CHECK(hipSetDevice(device_id));
 
-    NetFile nf;                                  // load_model
-    nf.load(model_file_path_);
+    NetFile nf;                                  // load_model: our container, or the reference's ONNX parsed in place (onnx_import.h)
+    if (model_file_path_.size() > 5 && model_file_path_.compare(model_file_path_.size() - 5, 5, ".onnx") == 0) import_onnx(model_file_path_, nf);
+    else nf.load(model_file_path_);
     if (nf.str("arch") != "rise") throw std::runtime_error("unsupported arch '" + nf.str("arch") + "' in " + model_file_path_);
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     if (fp16_) build<half_t>(nf); else build<float>(nf);   // init_nn_design + load_parameters + buffers
@@ -221,10 +224,12 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     // C_op schedule: rise_mobile_v3.py:36-78 (kernel_5_channel_ratio=None)
     std::vector<int> cops, ks;
     int cop_run = cop_init, cop_max = 32;
+    const std::vector<std::string> cop_list = nf.list("channels_operating");     // imported models carry the widths they were found with
+    if (!cop_list.empty() && cop_list.size() != kernels.size()) throw std::runtime_error("channels_operating/kernels mismatch in model file");
     for (size_t i = 0; i < kernels.size(); ++i) {
         const int k = std::stoi(kernels[i]);
         if (k != 3 && k != 5) throw std::runtime_error("unsupported depthwise kernel size " + kernels[i]);
-        const int c = k == 5 ? cop_run - 32 * int(i / 2) : cop_run;
+        const int c = !cop_list.empty() ? std::stoi(cop_list[i]) : k == 5 ? cop_run - 32 * int(i / 2) : cop_run;
         if (c % 32 != 0 || c <= 0) throw std::runtime_error("channels_operating must be a positive multiple of 32");
         cops.push_back(c);
         ks.push_back(k);

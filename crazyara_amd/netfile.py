@@ -88,3 +88,14 @@ def export_rise(path: str, cfg, state_dict, input_version: str = "1.0", variant:
             k = "body_spatial." + k[len("body."):]
         tensors[k] = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
     return write_cranet(path, meta, tensors)
+
+
+def onnx_to_cranet(onnx_path: str, cranet_path: str = "") -> str:
+    """Convert one of the reference's ONNX model files (trainer_agent_pytorch.py:588-633) to the container, through the library's
+    own importer (csrc/nn/onnx_import.cpp; `mi_net_create` reads .onnx files with the same code).  Host only."""
+    from . import _capi
+    if not cranet_path:
+        cranet_path = os.path.splitext(onnx_path)[0] + ".cranet"
+    if _capi.load().mi_onnx_to_cranet(onnx_path.encode(), cranet_path.encode()):
+        raise ValueError(_capi.last_error())
+    return cranet_path

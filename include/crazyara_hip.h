@@ -39,10 +39,17 @@ typedef struct mi_net mi_net;
 
 /* TensorrtAPI::TensorrtAPI(deviceID, batchSize, modelDirectory, strPrecision) + initialize()
  * (engine/src/nn/tensorrtapi.cpp:43-63; neuralnetapi.cpp:93-99).  model_dir: directory holding a "*.cranet" file
- * (chosen like get_onnx_model_name(), neuralnetapi.cpp:57-73) or a direct path to one.
+ * or, as the reference's model directories do, an "*.onnx" file (chosen like get_onnx_model_name(), neuralnetapi.cpp:57-73:
+ * "-bsize-<B>" first, else the one without "-bsize-"; a .cranet wins over an .onnx), or a direct path to either.
+ * ONNX files are read in place (the graphs of the reference's model zoo, see csrc/nn/onnx_import.h), the "-v<maj>.<min>"
+ * part of the name is the input-representation version (read_version_from_string, neuralnetapi.cpp:194-227).
  * precision: "float32" | "float16" (UCI option Precision, optionsuci.cpp:143-147). */
 mi_net* mi_net_create(const char* model_dir, int device_id, int batch_size, const char* precision);
 void mi_net_destroy(mi_net* net);
+
+/* Offline form of the same import: parse the ONNX file and write it as a .cranet container (what TensorrtAPI caches as a
+ * serialized engine next to the ONNX, tensorrtapi.cpp:297-332).  Host only, no GPU needed.  0 on success. */
+int mi_onnx_to_cranet(const char* onnx_path, const char* cranet_path);
 
 /* nnDesign + derived getters (neuralnetapi.cpp:81-91, neuralnetapi.h:252-299):
  * in_shape = {batch, C, 8, 8}; nb_policy = get_nb_policy_values(); nb_aux = get_nb_auxiliary_outputs();

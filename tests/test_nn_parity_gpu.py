@@ -219,3 +219,36 @@ def test_predict_from_board_descriptors_equals_predict_from_planes(tmp_path, hip
     # wrong layout for this net is rejected loudly
     assert lib.mi_net_submit_boards(net._h, descs, 8, lib.mi_planes_layout(0, 3), v2.ctypes.data, p2.ctypes.data, None) != 0
     net.close()
+
+
+@pytest.mark.parametrize("flavour", [dict(fold_bn=True, linear="gemm"), dict(fold_bn=False, linear="matmul")])
+@pytest.mark.parametrize("name", ["risev2-3", "risev33-wdlp", "rise-classical-4", "alphazero-3-cv8", "risev2-3-flat"])
+def test_onnx_model_directory_loads_and_matches_golden(tmp_path, hip_lib, name, flavour):
+    """a model directory holding only the reference's file format ("<prefix>-v<ver>.onnx") goes through
+    mi_net_create (ONNX parsed in place, csrc/nn/onnx_import.cpp) and reproduces the reference model's outputs (committed goldens)."""
+    import onnx_writer
+    from crazyara_amd.neuralnetapi import HipAPI, make_version
+    cfg, sd, x = nn_cases.make_case(name)
+    d = os.path.join(str(tmp_path), "model")
+    os.makedirs(d)
+    fname = f"{cfg.name}-v3.0-bsize-{x.shape[0]}.onnx" if flavour["fold_bn"] else f"{cfg.name}-v3.0.onnx"
+    with open(os.path.join(d, fname), "wb") as f:
+        f.write(onnx_writer.rise_to_onnx(cfg, sd, batch=x.shape[0] if flavour["fold_bn"] else None, **flavour))
+    B = x.shape[0]
+    tol = TOL["float16"]
+    g = np.load(os.path.join(nn_cases.GOLDEN_DIR, f"nn_{name}.npz"))
+    for precision in ("float32", "float16"):
+        net = HipAPI(0, B, d, precision)
+        assert net.get_model_name() == fname and net.get_version() == make_version(3, 0)
+        assert net.get_nb_policy_values() == cfg.nb_policy and net.get_nb_auxiliary_outputs() == cfg.nb_aux
+        assert abs(net.flops_per_position() - ro.flops_per_position(cfg)) < 1.0
+        value, probs = np.zeros(B, np.float32), np.zeros(B * cfg.nb_policy, np.float32)
+        aux = np.zeros(B * 4, np.float32) if cfg.nb_aux else None
+        net.predict(np.ascontiguousarray(x.numpy()), value, probs, aux)
+        logits = torch.as_tensor(net.device_buffers()["logits"], device="cuda").cpu().numpy()
+        net.close()
+        tol = TOL[precision]
+        assert np.abs(value - g["value"].reshape(-1)).max() < tol["value"]
+        assert np.abs(logits - g["logits"]).max() < tol["logit"]
+        if cfg.nb_aux:
+            assert np.abs(aux.reshape(-1, 4) - g["aux"]).max() < tol["aux"]

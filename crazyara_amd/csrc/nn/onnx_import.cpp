@@ -147,6 +147,7 @@ Tensor parse_tensor(Slice s, std::string* name_out) {
         }
     }
     if (name_out) *name_out = name;
+    for (int64_t d : t.dims) if (d < 0 || d > (int64_t(1) << 32)) fail("tensor " + name + " has an implausible dimension");
     const int64_t n = t.numel();
     auto check = [&](size_t have) { if (int64_t(have) != n) fail("tensor " + name + " has " + std::to_string(have) + " elements for its dims"); };
     switch (dtype) {
@@ -155,14 +156,16 @@ Tensor parse_tensor(Slice s, std::string* name_out) {
             else { check(floats.size()); t.f = std::move(floats); }
             break;
         case 10:  // FLOAT16 (raw, or bit patterns in int32_data)
+            check(has_raw ? raw.n / 2 : ints.size());
             t.f.resize(size_t(n));
-            if (has_raw) { check(raw.n / 2); for (int64_t k = 0; k < n; ++k) { uint16_t h; std::memcpy(&h, raw.p + 2 * k, 2); t.f[size_t(k)] = half_to_float(h); } }
-            else { check(ints.size()); for (int64_t k = 0; k < n; ++k) t.f[size_t(k)] = half_to_float(uint16_t(ints[size_t(k)])); }
+            if (has_raw) { for (int64_t k = 0; k < n; ++k) { uint16_t h; std::memcpy(&h, raw.p + 2 * k, 2); t.f[size_t(k)] = half_to_float(h); } }
+            else { for (int64_t k = 0; k < n; ++k) t.f[size_t(k)] = half_to_float(uint16_t(ints[size_t(k)])); }
             break;
         case 11:  // DOUBLE
+            check(has_raw ? raw.n / 8 : doubles.size());
             t.f.resize(size_t(n));
-            if (has_raw) { check(raw.n / 8); for (int64_t k = 0; k < n; ++k) { double d; std::memcpy(&d, raw.p + 8 * k, 8); t.f[size_t(k)] = float(d); } }
-            else { check(doubles.size()); for (int64_t k = 0; k < n; ++k) t.f[size_t(k)] = float(doubles[size_t(k)]); }
+            if (has_raw) { for (int64_t k = 0; k < n; ++k) { double d; std::memcpy(&d, raw.p + 8 * k, 8); t.f[size_t(k)] = float(d); } }
+            else { for (int64_t k = 0; k < n; ++k) t.f[size_t(k)] = float(doubles[size_t(k)]); }
             break;
         case 7:   // INT64
             if (has_raw) { check(raw.n / 8); t.i.resize(size_t(n)); std::memcpy(t.i.data(), raw.p, size_t(n) * 8); }

@@ -195,3 +195,31 @@ def test_model_directory_rules_of_the_reference(lib, tmp_path):
     open(os.path.join(d, "net-v1.0-bsize-4.onnx"), "wb").close()
     with pytest.raises(ValueError, match="should either contain a onnx file supporting the current batch size"):
         HipAPI(0, 8, d, "float16")
+
+
+def test_damaged_files_raise_and_never_crash(lib, tmp_path):
+    """Byte damage anywhere in an exporter file (node table = the first KiBs, weights after it) ends in an error or a valid import."""
+    import random
+    with open(os.path.join(ONNX_DIR, "mobile-tanh-v1.0-bsize-2.onnx"), "rb") as f:
+        good = f.read()
+    rng = random.Random(7)
+    src, dst = os.path.join(str(tmp_path), "fz-v1.0.onnx"), os.path.join(str(tmp_path), "fz.cranet")
+    outcomes = {True: 0, False: 0}
+    for it in range(400):
+        b = bytearray(good)
+        if it % 3 == 0:
+            b = b[:rng.randrange(len(b))]
+        elif it % 3 == 1:
+            for _ in range(rng.randint(1, 3)):
+                b[rng.randrange(min(len(b), 12000))] = rng.randrange(256)
+        else:
+            i = rng.randrange(len(b))
+            del b[i:i + rng.randint(1, 48)]
+        with open(src, "wb") as f:
+            f.write(bytes(b))
+        try:
+            netfile.onnx_to_cranet(src, dst)
+            outcomes[True] += 1
+        except ValueError:
+            outcomes[False] += 1
+    assert outcomes[False] > 100

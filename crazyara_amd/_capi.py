@@ -52,9 +52,11 @@ SIGNATURES = {
     "mi_chess960_start_fen": (C.c_char_p, [C.c_int]),
     # planes
     "mi_planes_layout": (C.c_int, [C.c_int, C.c_int]),
+    "mi_planes_layout_minor": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mi_planes_channels": (C.c_int, [C.c_int]),
     "mi_pos_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mi_pos_desc": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi_pos_desc_for": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mi_planes_from_descs_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p]),
     "mi_planes_from_descs_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     # policy

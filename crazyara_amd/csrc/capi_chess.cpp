@@ -92,6 +92,7 @@ const char* mi_chess960_start_fen(int idx) {
 }
 
 int mi_planes_layout(int mode, int version_major) { return layout_for(mode, version_major); }
+int mi_planes_layout_minor(int mode, int version_major, int version_minor) { return layout_for(mode, version_major, version_minor); }
 int mi_planes_channels(int layout) { return layout_channels(layout); }
 int mi_pos_planes(const mi_pos* pos, int layout, int normalize, int repetitions, float* out) {
     if (!pos || !out || layout_channels(layout) == 0) { cra_set_error("bad argument to mi_pos_planes"); return 1; }
@@ -101,6 +102,11 @@ int mi_pos_planes(const mi_pos* pos, int layout, int normalize, int repetitions,
 int mi_pos_desc(const mi_pos* pos, void* desc192) {
     if (!pos || !desc192) { cra_set_error("null argument"); return 1; }
     pack_desc(pos->pos, *static_cast<BoardDesc*>(desc192));
+    return 0;
+}
+int mi_pos_desc_for(const mi_pos* pos, int layout, void* desc192) {
+    if (!pos || !desc192 || layout_channels(layout) == 0) { cra_set_error("bad argument to mi_pos_desc_for"); return 1; }
+    pack_desc(pos->pos, *static_cast<BoardDesc*>(desc192), layout_needs_move_features(layout));
     return 0;
 }
 int mi_planes_from_descs_host(const void* descs, int n, int layout, int normalize, float* out) {

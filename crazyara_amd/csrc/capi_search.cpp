@@ -34,6 +34,7 @@ SearchSettings convert(const mi_search_settings& m) {
     s.q_veto_delta = m.q_veto_delta;
     s.mode = m.mode;
     s.version_major = m.version_major;
+    s.version_minor = m.version_minor;
     s.is_policy_map = m.is_policy_map != 0;
     s.clone_keeps_last_moves = m.clone_keeps_last_moves;
     s.epsilon_greedy_counter = m.epsilon_greedy_counter;
@@ -62,6 +63,7 @@ void mi_search_default_settings(mi_search_settings* m) {
     m->q_veto_delta = s.q_veto_delta;
     m->mode = s.mode;
     m->version_major = s.version_major;
+    m->version_minor = s.version_minor;
     m->is_policy_map = s.is_policy_map ? 1 : 0;
     m->clone_keeps_last_moves = s.clone_keeps_last_moves;
     m->epsilon_greedy_counter = s.epsilon_greedy_counter;

@@ -29,7 +29,9 @@ enum PlaneLayout : int {
     LAYOUT_CHESS_V3 = 4,   // 52 ch  board_to_planes_chess_v3                       (:536-566)
     LAYOUT_LICHESS_V2 = 5, // 63 ch  default_board_to_planes, MODE_LICHESS (v1/v2)
     LAYOUT_LICHESS_V3 = 6, // 80 ch  board_to_planes_lichess_v3                     (:599-624)
-    LAYOUT_NB = 7
+    LAYOUT_CHESS_V27 = 7,  // 33 ch  board_to_planes_chess_v_2_7                     (:503-524)  needs the move features of the descriptor
+    LAYOUT_CHESS_V28 = 8,  // 38 ch  board_to_planes_chess_v_2_8                     (:526-533)  v2.7 + material count
+    LAYOUT_NB = 9
 };
 
 CRA_HD int layout_channels(int layout) {
@@ -41,14 +43,23 @@ CRA_HD int layout_channels(int layout) {
         case LAYOUT_CHESS_V3: return 52;
         case LAYOUT_LICHESS_V2: return 63;
         case LAYOUT_LICHESS_V3: return 80;
+        case LAYOUT_CHESS_V27: return 33;
+        case LAYOUT_CHESS_V28: return 38;
     }
     return 0;
 }
 
-inline int layout_for(int mode, int version_major) {
+// layouts whose planes depend on the legal moves of the position (check-giving moves, mobility): pack_desc fills those
+// descriptor fields only on request, they cost a gives_check() per legal move
+CRA_HD bool layout_needs_move_features(int layout) { return layout == LAYOUT_CHESS_V27 || layout == LAYOUT_CHESS_V28; }
+
+// dispatch of board_to_planes (:628-680); chess 2.x: make_version<2,7,0> / <2,8,0>
+inline int layout_for(int mode, int version_major, int version_minor = 0) {
     switch (mode) {
         case MODE_CRAZYHOUSE: return version_major == 2 ? LAYOUT_CZ_V2 : version_major == 3 ? LAYOUT_CZ_V3 : LAYOUT_CZ_V1;
-        case MODE_CHESS: return version_major == 3 ? LAYOUT_CHESS_V3 : LAYOUT_CHESS_V1;
+        case MODE_CHESS:
+            if (version_major == 2) return version_minor == 8 ? LAYOUT_CHESS_V28 : LAYOUT_CHESS_V27;
+            return version_major == 3 ? LAYOUT_CHESS_V3 : LAYOUT_CHESS_V1;
         default: return version_major == 3 ? LAYOUT_LICHESS_V3 : LAYOUT_LICHESS_V2;
     }
 }
@@ -71,7 +82,12 @@ struct BoardDesc {               // 192 bytes, 8-byte aligned; absolute colours,
     uint8_t pad0;
     uint16_t rule50;
     uint16_t fullmove;           // game_ply / 2 + 1
-    uint8_t pad1[40];
+    // move features (chess v2.7 / v2.8 only; zero unless requested from pack_desc): origin / destination squares of the legal
+    // moves that give check (set_check_moves, :382-393) and the number of legal moves (set_mobility, :395-398)
+    uint64_t check_from;
+    uint64_t check_to;
+    uint8_t mobility;
+    uint8_t pad1[23];
 };
 static_assert(sizeof(BoardDesc) == 192, "BoardDesc must be 192 bytes");
 
@@ -182,6 +198,10 @@ CRA_HD float g_opposite_bishops(const Ctx& c) {          // :401-406, Position::
 }
 CRA_HD float g_checkers(const Ctx& c) { return bit_plane(c, c.d->checkers); }                 // :376-379
 CRA_HD float g_material_count(const Ctx& c, int k) { return rel_count(c, popc(c.d->bb[c.me * 6 + k])); }   // :407-424
+CRA_HD float g_check_moves(const Ctx& c, int k) { return bit_plane(c, k == 0 ? c.d->check_from : c.d->check_to); }   // :382-393
+CRA_HD float g_mobility(const Ctx& c) {                                                        // :395-398, NORMALIZE_MOBILITY 64
+    return c.normalize ? c.d->mobility / 64.0f : float(c.d->mobility);
+}
 
 }  // namespace planes_detail
 
@@ -238,6 +258,22 @@ CRA_HD float plane_value(const BoardDesc& d, int layout, bool normalize, int ch,
             if (ch < 52) return g_material_count(c, ch - 47);
             if (ch < 62) return g_pockets(c, ch - 52, 32.0f);
             return g_promoted(c, ch - 62);
+        }
+        case LAYOUT_CHESS_V27:
+        case LAYOUT_CHESS_V28: {           // no repetition, colour, move-count or no-progress planes; one move of history
+            if (ch < 12) return g_pieces(c, ch);
+            if (ch == 12) return g_ep(c);
+            if (ch < 17) return g_castling(c, ch - 13);
+            if (ch < 19) return g_last_moves(c, ch - 17);
+            if (ch == 19) return g_is960(c);
+            if (ch < 22) return g_piece_masks(c, ch - 20);
+            if (ch == 22) return g_checkerboard(c);
+            if (ch < 28) return g_material_diff(c, ch - 23);
+            if (ch == 28) return g_opposite_bishops(c);
+            if (ch == 29) return g_checkers(c);
+            if (ch < 32) return g_check_moves(c, ch - 30);
+            if (ch == 32) return g_mobility(c);
+            return g_material_count(c, ch - 33);
         }
         case LAYOUT_LICHESS_V2:
         case LAYOUT_LICHESS_V3: {

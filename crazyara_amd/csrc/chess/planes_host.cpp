@@ -5,8 +5,21 @@
 namespace cra {
 namespace chess {
 
-void pack_desc(const Position& pos, BoardDesc& d) {
+void pack_desc(const Position& pos, BoardDesc& d, bool move_features, const std::vector<Move>* legal) {
     std::memset(&d, 0, sizeof(d));
+    if (move_features) {
+        std::vector<Move> own;
+        if (!legal) {
+            pos.legal_moves(own);
+            legal = &own;
+        }
+        for (Move m : *legal)
+            if (pos.gives_check(m)) {        // castling counts with the king-takes-rook squares of the fork's Move, as for the last moves
+                d.check_from |= sq_bb(from_sq(m));
+                d.check_to |= sq_bb(to_sq(m));
+            }
+        d.mobility = uint8_t(legal->size() > 255 ? 255 : legal->size());
+    }
     for (int c = 0; c < 2; ++c)
         for (int pt = PAWN; pt <= KING; ++pt) d.bb[c * 6 + pt - 1] = pos.pieces(Color(c), PieceType(pt));
     d.promoted = pos.promoted_pieces();
@@ -34,7 +47,7 @@ void pack_desc(const Position& pos, BoardDesc& d) {
 
 void board_to_planes(const Position& pos, int layout, bool normalize, float* out, int repetitions) {
     BoardDesc d;
-    pack_desc(pos, d);
+    pack_desc(pos, d, layout_needs_move_features(layout));
     if (repetitions >= 0) d.repetitions = uint8_t(repetitions);
     const int C = layout_channels(layout);
     for (int ch = 0; ch < C; ++ch)

@@ -6,7 +6,9 @@
 namespace cra {
 namespace chess {
 
-void pack_desc(const Position& pos, BoardDesc& d);
+// move_features: also fill the legal-move fields the chess v2.7 / v2.8 layouts read (layout_needs_move_features); `legal` = the
+// position's legal moves when the caller has them already (a search leaf being expanded), else they are generated here
+void pack_desc(const Position& pos, BoardDesc& d, bool move_features = false, const std::vector<Move>* legal = nullptr);
 
 // board_to_planes(pos, boardRepetition, normalize, inputPlanes, version) (inputrepresentation.cpp:628-680):
 // writes layout_channels(layout)*64 floats, NCHW.  repetitions < 0: use pos.number_repetitions().

@@ -33,7 +33,7 @@ Tree::Tree(const Position& root, const SearchSettings& settings) : s_(settings),
     noise_rng_.seed(s_.seed);
     tables_ = &chess::policy_tables(s_.mode);
     nodes_.reserve(8192);
-    layout_ = layout_for(s_.mode, s_.version_major);
+    layout_ = layout_for(s_.mode, s_.version_major, s_.version_minor);
     keep_last_moves_ = s_.clone_keeps_last_moves < 0 ? s_.mode != MODE_CRAZYHOUSE : s_.clone_keeps_last_moves != 0;
     new_node(root_pos_);
 }
@@ -71,7 +71,7 @@ int Tree::new_node(const Position& pos) {
     return int(nodes_.size()) - 1;
 }
 
-void Tree::root_desc(BoardDesc& d) const { chess::pack_desc(root_pos_, d); }
+void Tree::root_desc(BoardDesc& d) const { chess::pack_desc(root_pos_, d, layout_needs_move_features(layout_)); }
 
 // fill_nn_results (searchthread.cpp:290-299): gather priors, temperature, value
 void Tree::fill_nn_result(Node& n, float value, const float* probs) {
@@ -449,7 +449,8 @@ int Tree::get_new_child_to_evaluate(NodeBackup& type, uint32_t& depth, BoardDesc
                 type = NODE_TERMINAL;
                 return nn;
             }
-            chess::pack_desc(pos, *desc_out);    // newState->get_state_planes(true, ...), searchthread.cpp:229
+            // newState->get_state_planes(true, ...), searchthread.cpp:229; the new node holds the legal moves already
+            chess::pack_desc(pos, *desc_out, layout_needs_move_features(layout_), &nodes_[nn].actions);
             type = NODE_NEW_NODE;
             return nn;
         }

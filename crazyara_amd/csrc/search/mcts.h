@@ -36,6 +36,7 @@ struct SearchSettings {
     float q_veto_delta = 0.4f;            // Centi_Q_Veto_Delta 40
     int mode = MODE_CRAZYHOUSE;           // build flavour: label set + plane layout family
     int version_major = 1;                // input representation version of the loaded net
+    int version_minor = 0;                //   (chess 2.7 / 2.8 differ in the minor number)
     bool is_policy_map = true;
     // Board::operator= copies lastMoves only in MODE_CHESS / MODE_LICHESS binaries (board.cpp:106-108): in a crazyhouse
     // binary every leaf's move history restarts at the root clone.  -1 = follow the mode, 0/1 = force.

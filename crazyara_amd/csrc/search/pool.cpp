@@ -144,7 +144,7 @@ void WorkerPool::parallel_for(int n, const std::function<void(int)>& fn) {
 // pool
 // ---------------------------------------------------------------------------------------------------------------------
 SearchPool::SearchPool(const SearchSettings& s, std::unique_ptr<Evaluator> lane_a, std::unique_ptr<Evaluator> lane_b) : s_(s) {
-    layout_ = layout_for(s.mode, s.version_major);
+    layout_ = layout_for(s.mode, s.version_major, s.version_minor);
     if (!lane_a) throw std::invalid_argument("SearchPool needs at least one evaluator lane");
     lanes_.emplace_back();
     lanes_.back().eval = std::move(lane_a);

@@ -14,6 +14,19 @@ MODE_CRAZYHOUSE, MODE_CHESS, MODE_LICHESS = 0, 1, 2
 TERMINAL_LOSS, TERMINAL_DRAW, TERMINAL_WIN, TERMINAL_CUSTOM, TERMINAL_NONE = 0, 1, 2, 3, 4
 
 
+def split_version(version):
+    """3 -> (3, 0); "2.8" / 2.8 -> (2, 8)."""
+    if isinstance(version, (int, np.integer)):
+        return int(version), 0
+    major, _, minor = str(version).partition(".")
+    return int(major), int(minor or 0)
+
+
+def planes_layout(mode: int, version) -> int:
+    major, minor = split_version(version)
+    return _capi.load().mi_planes_layout_minor(mode, major, minor)
+
+
 class Position:
     def __init__(self, fen: str = "", is960: bool = False, variant: str = "chess", _handle=None):
         self._lib = _capi.load()
@@ -77,17 +90,19 @@ class Position:
     def perft(self, depth: int) -> int:
         return int(self._lib.mi_pos_perft(self._h, depth))
 
-    def planes(self, mode: int, version_major: int, normalize: bool = True, repetitions: int = -1) -> np.ndarray:
-        layout = self._lib.mi_planes_layout(mode, version_major)
+    def planes(self, mode: int, version_major, normalize: bool = True, repetitions: int = -1) -> np.ndarray:
+        """version_major: the major number, or "maj.min" (chess "2.7" / "2.8" are distinct layouts)."""
+        layout = planes_layout(mode, version_major)
         c = self._lib.mi_planes_channels(layout)
         out = np.empty((c, 8, 8), np.float32)
         if self._lib.mi_pos_planes(self._h, layout, int(normalize), repetitions, out.ctypes.data):
             raise RuntimeError(_capi.last_error())
         return out
 
-    def desc(self) -> bytes:
+    def desc(self, layout: int = -1) -> bytes:
+        """192-byte board descriptor; pass the layout when it reads the legal-move features (chess 2.7 / 2.8)."""
         buf = C.create_string_buffer(192)
-        if self._lib.mi_pos_desc(self._h, buf):
+        if (self._lib.mi_pos_desc(self._h, buf) if layout < 0 else self._lib.mi_pos_desc_for(self._h, layout, buf)):
             raise RuntimeError(_capi.last_error())
         return buf.raw
 

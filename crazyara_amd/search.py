@@ -15,7 +15,7 @@ class SearchSettingsC(C.Structure):
                 ("virtual_offset_strength", C.c_double), ("q_value_weight", C.c_float), ("q_veto_delta", C.c_float),
                 ("mode", C.c_int), ("version_major", C.c_int), ("is_policy_map", C.c_int), ("clone_keeps_last_moves", C.c_int),
                 ("epsilon_greedy_counter", C.c_int), ("epsilon_checks_counter", C.c_int), ("seed", C.c_uint), ("mcts_solver", C.c_int),
-                ("dirichlet_epsilon", C.c_float), ("dirichlet_alpha", C.c_float)]
+                ("dirichlet_epsilon", C.c_float), ("dirichlet_alpha", C.c_float), ("version_minor", C.c_int)]
 
 
 class SearchStatsC(C.Structure):

@@ -77,8 +77,7 @@ class TrainDataExporter:
         self.path, self.mode, self.version = path, mode, version_major
         self.nb_labels, self.chunk_size = nb_labels, chunk_size
         self.number_samples = number_chunks * chunk_size
-        lib = env._capi.load()
-        self.channels = lib.mi_planes_channels(lib.mi_planes_layout(mode, version_major))
+        self.channels = env._capi.load().mi_planes_channels(env.planes_layout(mode, version_major))
         os.makedirs(path, exist_ok=True)
         with open(os.path.join(path, ".zgroup"), "w") as f:
             json.dump({"zarr_format": 2}, f)

@@ -118,11 +118,16 @@ const char* mi_chess960_start_fen(int scharnagl_index);                /* determ
  * Input planes: board_to_planes (engine/src/environments/chess_related/inputrepresentation.cpp:628-680)
  * ---------------------------------------------------------------------------------------------------------------- */
 int mi_planes_layout(int mode, int version_major);        /* layout id used below */
+/* the same with the minor number: MI_MODE_CHESS 2.7 / 2.8 (board_to_planes_chess_v_2_7 / _2_8, inputrepresentation.cpp:503-533) */
+int mi_planes_layout_minor(int mode, int version_major, int version_minor);
 int mi_planes_channels(int layout);                       /* NB_CHANNELS_TOTAL of that layout */
 /* host builder: out[C*64] floats NCHW.  repetitions < 0 -> Board::number_repetitions() */
 int mi_pos_planes(const mi_pos* pos, int layout, int normalize, int repetitions, float* out);
 /* compact 192-byte descriptor of the position (struct BoardDesc, crazyara_amd/csrc/chess/planes.h) */
 int mi_pos_desc(const mi_pos* pos, void* desc192);
+/* descriptor for one layout: also fills the legal-move features (check-giving moves, mobility) when the layout reads them
+ * (chess 2.7 / 2.8); for every other layout identical to mi_pos_desc */
+int mi_pos_desc_for(const mi_pos* pos, int layout, void* desc192);
 /* host builder from descriptors: out[n][C*64] floats (what a CPU NeuralNetAPI behind the same leaf collector is fed) */
 int mi_planes_from_descs_host(const void* descs, int n, int layout, int normalize, float* out);
 /* GPU builder: n host descriptors -> d_planes (device) [n][C][64] float, blocking */
@@ -171,6 +176,7 @@ typedef struct mi_search_settings {        /* SearchSettings (engine/src/agents/
     /* Dirichlet noise on the root priors at the start of every search when epsilon > 0.009, then full expansion of the root
      * (mctsagent.cpp:311-316, node.cpp:950-954, blazeutil.h:113-124).  Defaults 0 / 0.2 (Centi_Dirichlet_Epsilon is 25 in RL builds). */
     float dirichlet_epsilon, dirichlet_alpha;
+    int version_minor;                     /* chess input representation 2.7 / 2.8 (make_version<2,7,0>, <2,8,0>); 0 otherwise */
 } mi_search_settings;
 typedef struct mi_search_stats {
     unsigned long long nodes, nn_evals, batches, simulations;

@@ -603,6 +603,7 @@ class Board:
 LAYOUTS = {  # (mode, version major) -> name, channels
     (MODE_CRAZYHOUSE, 1): ("cz_v1", 34), (MODE_CRAZYHOUSE, 2): ("cz_v2", 51), (MODE_CRAZYHOUSE, 3): ("cz_v3", 64),
     (MODE_CHESS, 1): ("chess_v1", 39), (MODE_CHESS, 3): ("chess_v3", 52),
+    (MODE_CHESS, "2.7"): ("chess_v27", 33), (MODE_CHESS, "2.8"): ("chess_v28", 38),     # make_version<2,7,0> / <2,8,0>
     (MODE_LICHESS, 2): ("lichess_v2", 63), (MODE_LICHESS, 3): ("lichess_v3", 80),
 }
 
@@ -711,15 +712,27 @@ class _Planes:
         self.x[self.c + slot, :] = 1.0
         self.c += 9
 
-    def last_moves(self):                                            # :266-282
+    def last_moves(self, nb_last_moves=8):                           # :266-282; NB_LAST_MOVES: 8, chess 2.x builds 1 (boardstate.h:171-176)
         pre = self.c
-        for frm, to in self.bd.last_moves:
+        for frm, to in self.bd.last_moves[:nb_last_moves]:
             if frm is None:
                 self.c += 1
             else:
                 self.single(frm)
             self.single(to)
-        self.c = pre + 16
+        self.c = pre + 2 * nb_last_moves
+
+    def check_moves(self, legal):                                    # :382-393: origins / destinations of the legal moves that give check
+        for mv in legal:
+            nxt = self.bd.copy()
+            nxt.push(mv)
+            if nxt.checkers():
+                self.x[self.c, self.fsq(mv[0])] = 1.0                # castling: king square -> rook square (the fork's Move encoding)
+                self.x[self.c + 1, self.fsq(mv[1])] = 1.0
+        self.c += 2
+
+    def mobility(self, legal):                                       # :395-398, NORMALIZE_MOBILITY 64 (boardstate.h:243-245)
+        self.plane_value(np.float32(len(legal)) / np.float32(64) if self.normalize else len(legal))
 
     def is960(self):                                                 # :284-290
         if self.bd.is960:
@@ -766,11 +779,16 @@ class _Planes:
             self._rel(self._cnt(self.me_white, t))
 
 
-def board_to_planes(board: Board, mode: int, version_major: int, normalize: bool, repetitions: Optional[int] = None):
-    """-> float32 [C, 8, 8].  Dispatch of inputrepresentation.cpp:628-680."""
+def board_to_planes(board: Board, mode: int, version_major, normalize: bool, repetitions: Optional[int] = None):
+    """-> float32 [C, 8, 8].  Dispatch of inputrepresentation.cpp:628-680.  version_major: the major number, or "2.7" / "2.8" (chess)."""
+    if not isinstance(version_major, int):
+        major, _, minor = str(version_major).partition(".")
+        version_major = int(major)
+        if mode == MODE_CHESS and version_major == 2:
+            version_major = "2.8" if int(minor or 0) == 8 else "2.7"
     if mode == MODE_CRAZYHOUSE and version_major not in (2, 3):
         version_major = 1
-    if mode == MODE_CHESS and version_major != 3:
+    if mode == MODE_CHESS and version_major not in (3, "2.7", "2.8"):
         version_major = 1
     if mode == MODE_LICHESS and version_major != 3:
         version_major = 2
@@ -785,6 +803,12 @@ def board_to_planes(board: Board, mode: int, version_major: int, normalize: bool
     elif name == "chess_v1":
         p.pieces(); p.repetition(rep); p.ep(); p.color(); p.total_moves(); p.castling(); p.no_progress(50); p.is960()
         p.last_moves()
+    elif name in ("chess_v27", "chess_v28"):                      # :503-533
+        legal = board.legal_moves()
+        p.pieces(); p.ep(); p.castling(); p.last_moves(1); p.is960(); p.piece_masks(); p.checkerboard(); p.material_diff()
+        p.opposite_bishops(); p.checkers(); p.check_moves(legal); p.mobility(legal)
+        if name == "chess_v28":
+            p.material_count()
     elif name in ("chess_v3", "cz_v3"):
         p.pieces(); p.repetition(rep); p.ep(); p.castling(); p.no_progress(40 if name == "cz_v3" else 50); p.last_moves()
         p.is960(); p.piece_masks(); p.checkerboard(); p.material_diff(); p.opposite_bishops(); p.checkers()

@@ -72,8 +72,8 @@ def test_product_labels_and_flat_plane_idx_equal_reference_tables(mode, name, hi
 PLAYOUTS = [
     # (variant, is960, fen, mode, versions, n games, max plies)
     ("crazyhouse", False, "", 0, (1, 2, 3), 6, 90),
-    ("chess", False, "", 1, (1, 3), 4, 80),
-    ("chess", True, "bnnrkbrq/pppppppp/8/8/8/8/PPPPPPPP/BNNRKBRQ w GDgd - 0 1", 1, (3,), 3, 70),
+    ("chess", False, "", 1, (1, 3, "2.7", "2.8"), 4, 80),
+    ("chess", True, "bnnrkbrq/pppppppp/8/8/8/8/PPPPPPPP/BNNRKBRQ w GDgd - 0 1", 1, (3, "2.8"), 3, 70),
     ("chess", True, "nrbbqnkr/pppppppp/8/8/8/8/PPPPPPPP/NRBBQNKR w HBhb - 0 1", 1, (3,), 2, 60),
     ("3check", False, "", 2, (2, 3), 3, 70),
     ("kingofthehill", False, "", 2, (2, 3), 3, 70),
@@ -142,7 +142,8 @@ def test_reference_calibration_games_replay_identically(variant, hip_lib):
 def test_host_planes_from_descriptors_equal_position_planes(hip_lib):
     """mi_planes_from_descs_host (the CPU evaluator's input builder) == board_to_planes of the positions, all layouts of a mode."""
     fens = [("r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] b KQkq - 0 8", "crazyhouse", 0, (1, 2, 3)),
-            ("r3k2r/pppq1ppp/2npbn2/2b1p3/2B1P3/2NPBN2/PPPQ1PPP/R3K2R w KQkq - 4 8", "chess", 1, (3,)),
+            ("r3k2r/pppq1ppp/2npbn2/2b1p3/2B1P3/2NPBN2/PPPQ1PPP/R3K2R w KQkq - 4 8", "chess", 1, (3, "2.7", "2.8")),
+            ("r1br2k1/p4ppp/2p2n2/Q1b1p3/8/NP3N1P/P1P1BPP1/R1B1K2R b KQ - 0 12", "chess", 1, ("2.7", "2.8")),
             ("1r4k1/1p2bp1p/3p2p1/PprPp2n/1R2PPq1/3Q4/1P1B1NPP/5RK1 b - - 1+1 2 22", "3check", 2, (1, 3))]
     lib = env._capi.load()
     for fen, variant, mode, versions in fens:
@@ -151,7 +152,7 @@ def test_host_planes_from_descriptors_equal_position_planes(hip_lib):
         q = p.clone()
         q.push(q.legal_moves()[-1])
         for v in versions:
-            layout = lib.mi_planes_layout(mode, v)
-            got = env.planes_from_descs_host(p.desc() + q.desc(), 2, layout, True)
+            layout = env.planes_layout(mode, v)
+            got = env.planes_from_descs_host(p.desc(layout) + q.desc(layout), 2, layout, True)
             assert np.array_equal(got[0].reshape(-1), p.planes(mode, v, True).reshape(-1))
             assert np.array_equal(got[1].reshape(-1), q.planes(mode, v, True).reshape(-1))

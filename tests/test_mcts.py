@@ -443,3 +443,64 @@ def test_tree_reuse_across_played_moves_equals_oracle(hip_lib, variant, is960, f
     with pytest.raises(ValueError):
         pool.apply_move(t, "a1a1")
     pool.close()
+
+
+def _fen_from_desc(d: bytes) -> str:
+    """The descriptor holds the whole position (struct BoardDesc, planes.h): rebuild the FEN of a standard-chess board."""
+    bbs = struct.unpack("<12Q", d[0:96])
+    rows = []
+    for r in range(7, -1, -1):
+        row, empty = "", 0
+        for f in range(8):
+            ch = next(("PNBRQKpnbrqk"[i] for i in range(12) if bbs[i] >> (r * 8 + f) & 1), None)
+            if ch is None:
+                empty += 1
+            else:
+                row += (str(empty) if empty else "") + ch
+                empty = 0
+        rows.append(row + (str(empty) if empty else ""))
+    castle = "".join(c for i, c in enumerate("KQkq") if d[123] >> i & 1) or "-"
+    ep = "-" if d[124] >= 64 else "abcdefgh"[d[124] & 7] + str((d[124] >> 3) + 1)
+    rule50, fullmove = struct.unpack("<HH", d[148:152])
+    return f'{"/".join(rows)} {"wb"[d[122]]} {castle} {ep} {rule50} {fullmove}'
+
+
+def test_chess_v28_leaf_descriptors_carry_the_move_features(hip_lib):
+    """Chess input representation 2.7 / 2.8 reads the legal moves (check-giving moves, mobility; inputrepresentation.cpp:382-398).
+    The collector fills those descriptor fields from the move list the new node already holds: every descriptor it hands to the
+    evaluator must equal the one built from scratch for the same position, and its planes the oracle's."""
+    nbp, quota = NB_POLICY[1], 8
+    st = search.default_settings(mode=1, version_major=2, version_minor=8, is_policy_map=1, batch_size=quota)
+    layout = env.planes_layout(1, "2.8")
+    seen = []
+
+    def eval_descs(descs):
+        seen.extend(descs)
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=quota, fn_nb_policy=nbp)
+    pool.add_position("r1br2k1/p4ppp/2p2n2/Q1b1p3/8/NP3N1P/P1P1BPP1/R1B1K2R b KQ - 0 12", False, "chess")
+    pool.run(simulations=150, threads=1)
+    assert len(seen) > 100
+    with_checks = 0
+    for d in seen:
+        p = env.Position(_fen_from_desc(d), False, "chess")
+        fresh = p.desc(layout)
+        assert d[152:169] == fresh[152:169]                               # check_from, check_to, mobility
+        assert d[168] == len(p.legal_moves())
+        with_checks += d[152:160] != bytes(8)
+    assert with_checks > 10
+    d = seen[-1]
+    b = co.Board(_fen_from_desc(d), False, "chess")
+    x = env.planes_from_descs_host(d, 1, layout, True)[0]
+    xo = co.board_to_planes(b, 1, "2.8", True)
+    keep = [c for c in range(38) if c not in (17, 18)]                    # the FEN does not carry the last move
+    assert np.array_equal(x.reshape(38, 64)[keep], xo.reshape(38, 64)[keep])
+    # other layouts leave the fields empty (nothing to pay for)
+    st3 = search.default_settings(mode=1, version_major=3, is_policy_map=1, batch_size=quota)
+    seen.clear()
+    pool3 = search.SearchPool(st3, eval_fn=eval_descs, fn_batch=quota, fn_nb_policy=nbp)
+    pool3.add_position("", False, "chess")
+    pool3.run(simulations=40, threads=1)
+    assert seen and all(d[152:169] == bytes(17) for d in seen)

@@ -177,7 +177,7 @@ def _random_positions(variant, is960, fen, n, seed):
 
 @pytest.mark.parametrize("variant,is960,fen,mode,version", [
     ("crazyhouse", False, "", 0, 1), ("crazyhouse", False, "", 0, 2), ("crazyhouse", False, "", 0, 3),
-    ("chess", False, "", 1, 1), ("chess", False, "", 1, 3),
+    ("chess", False, "", 1, 1), ("chess", False, "", 1, 3), ("chess", False, "", 1, "2.7"), ("chess", False, "", 1, "2.8"),
     ("chess", True, "bnnrkbrq/pppppppp/8/8/8/8/PPPPPPPP/BNNRKBRQ w GDgd - 0 1", 1, 3),
     ("3check", False, "", 2, 2), ("kingofthehill", False, "", 2, 3), ("crazyhouse", False, "", 2, 3),
 ])
@@ -186,9 +186,9 @@ def test_gpu_plane_builder_bit_exact(hip_lib, variant, is960, fen, mode, version
     from oracle import chess_oracle as co
     lib = _capi.load()
     pos = _random_positions(variant, is960, fen, 24, seed=hash((variant, mode, version)) & 0xFFF)
-    layout = lib.mi_planes_layout(mode, version)
+    layout = env.planes_layout(mode, version)
     C_ = lib.mi_planes_channels(layout)
-    descs = b"".join(p.desc() for p, _ in pos)
+    descs = b"".join(p.desc(layout) for p, _ in pos)
     for normalize in (True, False):
         out = torch.empty((len(pos), C_, 8, 8), dtype=torch.float32, device="cuda")
         env.planes_from_descs_device(descs, len(pos), layout, normalize, out.data_ptr(), 0)

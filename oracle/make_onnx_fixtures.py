@@ -29,9 +29,13 @@ def main():
     RiseV3 = make_golden.import_reference()
     out_dir = os.path.join(ROOT, "tests", "golden", "onnx")
     os.makedirs(out_dir, exist_ok=True)
-    for name, (cfg, seed, fname, batch) in onnx_cases.CASES.items():
+    only = sys.argv[1:]
+    for name in onnx_cases.CASES:
+        if only and name not in only:
+            continue
+        cfg, seed, fname, batch, stress = onnx_cases.unpack(name)
         model = make_golden.reference_model(RiseV3, cfg)
-        sd = make_state_dict(cfg, seed=seed)
+        sd = make_state_dict(cfg, seed=seed, stress=stress)
         if cfg.conv_block == "a0_res_block":
             sd = {("body." + k[len("body_spatial."):] if k.startswith("body_spatial.") else k): v for k, v in sd.items()}
         model.load_state_dict(sd, strict=True)

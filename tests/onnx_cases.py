@@ -13,7 +13,7 @@ def _cfg(**kw):
     return RiseConfig(**base)
 
 
-# name: (config, seed, file name, exported batch or None for the dynamic axis)
+# name: (config, seed, file name, exported batch or None for the dynamic axis[, stress-init (default True)])
 CASES = {
     # RISEv3.3-shaped: 5x5 depthwise, both gate types, WDL + plies-to-end head, all five outputs, dynamic batch
     "mobile-se-wdlp": (_cfg(kernels=[3, 5, 3], se_types=[None, "eca_se", "ca_se"], use_wdl=True, use_plys_to_end=True, name="mobile-se-wdlp"),
@@ -25,4 +25,12 @@ CASES = {
                   34, "classical-v1.0.onnx", None),
     "alphazero": (_cfg(channels_operating_init=16, channel_expansion=0, conv_block="a0_res_block", channels_value_head=1, name="alphazero"),
                   35, "alphazero-v3.0.onnx", None),
+    # torch-default initialisation: every BatchNorm has the same statistics, the exporter shares them through Identity nodes
+    "mobile-shared-constants": (_cfg(kernels=[3, 5, 3], se_types=[None, "eca_se", "ca_se"], use_wdl=True, use_plys_to_end=True,
+                                     name="mobile-shared-constants"), 36, "mobile-shared-constants-v3.0.onnx", None, False),
 }
+
+
+def unpack(name):
+    c = CASES[name]
+    return c[0], c[1], c[2], c[3], (c[4] if len(c) > 4 else True)

@@ -361,10 +361,17 @@ void Importer::index() {
     // view ops: the tensor a reshape-like node forwards is the one it reads; shape arithmetic (everything downstream of a Shape
     // node that only mixes shapes and constants) is plumbing for those views and takes no part in the match
     static const std::set<std::string> views = {"Reshape", "Flatten", "Expand", "Squeeze", "Unsqueeze", "Identity", "Dropout", "Cast"};
+    static const std::map<std::string, size_t> min_inputs = {{"Conv", 2}, {"BatchNormalization", 5}, {"Gemm", 2}, {"MatMul", 2}, {"Add", 2},
+                                                             {"Mul", 2}, {"Relu", 1}, {"HardSigmoid", 1}, {"Sigmoid", 1}, {"Tanh", 1},
+                                                             {"GlobalAveragePool", 1}, {"ReduceMean", 1}, {"AveragePool", 1}};
     std::set<std::string> shape_valued;
     for (size_t idx = 0; idx < nodes_.size(); ++idx) {
         const Node& n = nodes_[idx];
         if (n.op == "Constant" || n.out.empty()) continue;
+        {
+            auto mi = min_inputs.find(n.op);
+            if (mi != min_inputs.end() && n.in.size() < mi->second) fail(n.label() + " has too few inputs");
+        }
         bool any_shape = false, all_shape_or_const = true;
         for (const std::string& i : n.in) {
             if (i.empty()) continue;

@@ -203,11 +203,14 @@ def test_damaged_files_raise_and_never_crash(lib, tmp_path):
     """Byte damage anywhere in an exporter file (node table = the first KiBs, weights after it) ends in an error or a valid import."""
     import random
     with open(os.path.join(ONNX_DIR, "mobile-tanh-v1.0-bsize-2.onnx"), "rb") as f:
-        good = f.read()
+        exported = f.read()
+    cfg, seed, _, _, _ = onnx_cases.unpack("mobile-se-wdlp")            # the other node types: BatchNormalization, MatMul + Add, gates
+    written = onnx_writer.rise_to_onnx(cfg, make_state_dict(cfg, seed=seed), fold_bn=False, linear="matmul")
     rng = random.Random(7)
     src, dst = os.path.join(str(tmp_path), "fz-v1.0.onnx"), os.path.join(str(tmp_path), "fz.cranet")
     outcomes = {True: 0, False: 0}
-    for it in range(400):
+    for it in range(600):
+        good = exported if it % 2 else written
         b = bytearray(good)
         if it % 3 == 0:
             b = b[:rng.randrange(len(b))]
@@ -224,4 +227,4 @@ def test_damaged_files_raise_and_never_crash(lib, tmp_path):
             outcomes[True] += 1
         except ValueError:
             outcomes[False] += 1
-    assert outcomes[False] > 100
+    assert outcomes[False] > 150

@@ -252,3 +252,37 @@ def test_onnx_model_directory_loads_and_matches_golden(tmp_path, hip_lib, name, 
         assert np.abs(logits - g["logits"]).max() < tol["logit"]
         if cfg.nb_aux:
             assert np.abs(aux.reshape(-1, 4) - g["aux"]).max() < tol["aux"]
+
+
+def test_headline_configuration_at_full_size(tmp_path, hip_lib):
+    """BASELINE.json config 2 as bench.py runs it: RISEv2-19, batch 256, Precision float16.  Beyond the per-row parity above:
+    rows 0-3 are the committed reference golden's inputs (they must come out as in the 4-board fixture), every row matches the oracle,
+    and the size-independent properties hold: probabilities sum to one, values inside the tanh range, a permuted batch gives the
+    permuted outputs bit for bit (one workgroup per board, no cross-row arithmetic)."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, xg = nn_cases.make_case("risev2-19")
+    B = 256
+    x = nn_cases.synthetic_planes(B, cfg.nb_input_channels, 777).numpy()
+    x[:4] = xg.numpy()
+    d = nn_cases.export_case(tmp_path, "risev2-19", cfg, sd)
+    net = HipAPI(0, B, d, "float16")
+    v, p = np.zeros(B, np.float32), np.zeros(B * cfg.nb_policy, np.float32)
+    net.predict(np.ascontiguousarray(x), v, p)
+    logits = torch.as_tensor(net.device_buffers()["logits"], device="cuda").cpu().numpy().copy()
+    p = p.reshape(B, -1)
+    g = np.load(os.path.join(nn_cases.GOLDEN_DIR, "nn_risev2-19.npz"))
+    tol = TOL["float16"]
+    assert np.abs(v[:4] - g["value"].reshape(-1)).max() < tol["value"]
+    assert np.abs(logits[:4] - g["logits"]).max() < tol["logit"]
+    o_value, o_logits, _ = ro.forward(cfg, sd, torch.from_numpy(x))
+    assert np.abs(v - o_value.numpy().reshape(-1)).max() < tol["value"]
+    assert np.abs(p - torch.softmax(o_logits, 1).numpy()).max() < tol["prob"]
+    assert np.allclose(p.sum(axis=1), 1.0, atol=1e-4) and (p >= 0).all() and np.abs(v).max() <= 1.0
+    perm = np.random.default_rng(5).permutation(B)
+    v2, p2 = np.zeros(B, np.float32), np.zeros(B * cfg.nb_policy, np.float32)
+    net.predict(np.ascontiguousarray(x[perm]), v2, p2)
+    assert np.array_equal(v2, v[perm]) and np.array_equal(p2.reshape(B, -1), p[perm])
+    v3, p3 = np.zeros(B, np.float32), np.zeros(B * cfg.nb_policy, np.float32)
+    net.predict(np.ascontiguousarray(x[perm]), v3, p3)                    # and replays are deterministic
+    assert np.array_equal(v3, v2) and np.array_equal(p3, p2)
+    net.close()

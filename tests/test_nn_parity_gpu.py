@@ -252,6 +252,17 @@ def test_onnx_model_directory_loads_and_matches_golden(tmp_path, hip_lib, name, 
         assert np.abs(logits - g["logits"]).max() < tol["logit"]
         if cfg.nb_aux:
             assert np.abs(aux.reshape(-1, 4) - g["aux"]).max() < tol["aux"]
+        if precision == "float16":
+            # the offline conversion (mi_onnx_to_cranet) is the same import kept as a file: a directory with the .cranet beside the
+            # .onnx picks the container and gives the same numbers bit for bit
+            from crazyara_amd import netfile
+            converted = netfile.onnx_to_cranet(os.path.join(d, fname))
+            net = HipAPI(0, B, d, precision)
+            assert net.get_model_name() == os.path.basename(converted)
+            v2, p2 = np.zeros(B, np.float32), np.zeros(B * cfg.nb_policy, np.float32)
+            net.predict(np.ascontiguousarray(x.numpy()), v2, p2, np.zeros(B * 4, np.float32) if cfg.nb_aux else None)
+            net.close()
+            assert np.array_equal(v2, value) and np.array_equal(p2, probs)
 
 
 def test_headline_configuration_at_full_size(tmp_path, hip_lib):

@@ -147,7 +147,14 @@ Tensor parse_tensor(Slice s, std::string* name_out) {
         }
     }
     if (name_out) *name_out = name;
-    for (int64_t d : t.dims) if (d < 0 || d > (int64_t(1) << 32)) fail("tensor " + name + " has an implausible dimension");
+    {
+        int64_t total = 1;                                        // bounded product: dims of a damaged file must not overflow numel()
+        for (int64_t d : t.dims) {
+            if (d < 0 || d > (int64_t(1) << 31)) fail("tensor " + name + " has an implausible dimension");
+            total *= std::max<int64_t>(d, 1);
+            if (total > (int64_t(1) << 31)) fail("tensor " + name + " is implausibly large");
+        }
+    }
     const int64_t n = t.numel();
     auto check = [&](size_t have) { if (int64_t(have) != n) fail("tensor " + name + " has " + std::to_string(have) + " elements for its dims"); };
     switch (dtype) {

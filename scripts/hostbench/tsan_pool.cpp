@@ -1,0 +1,56 @@
+// Development: the search pool (spinning fork/join workers, two lanes, many trees) under ThreadSanitizer with the callback evaluator.
+// The HIP lane is stubbed out (never constructed):
+//   g++ -std=c++17 -O1 -g -fsanitize=thread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include scripts/hostbench/tsan_pool.cpp \
+//       crazyara_amd/csrc/search/{pool,mcts}.cpp crazyara_amd/csrc/chess/{position,policy,planes_host}.cpp -lpthread -o /tmp/tsan_pool
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "../../crazyara_amd/csrc/nn/rise_net.h"
+#include "../../crazyara_amd/csrc/search/pool.h"
+
+// link-time stubs for the symbols pool.cpp's HIP lane references
+extern "C" hipError_t hipHostMalloc(void**, size_t, unsigned) { return hipErrorNotSupported; }
+extern "C" hipError_t hipHostFree(void*) { return hipSuccess; }
+namespace cra {
+void RiseNet::submit_boards(const void*, int, int, float*, float*, float*) {}
+void RiseNet::wait() {}
+}  // namespace cra
+
+using namespace cra;
+using namespace cra::search;
+
+static int eval(void*, const void* descs, int n, float* value, float* probs) {
+    const BoardDesc* d = static_cast<const BoardDesc*>(descs);
+    for (int i = 0; i < n; ++i) {
+        uint64_t h = 1469598103934665603ull;
+        for (int k = 0; k < 12; ++k) h = (h ^ d[i].bb[k]) * 1099511628211ull;
+        std::minstd_rand0 r(uint32_t(h) | 1u);
+        value[i] = float(r() % 2000) / 1000.f - 1.f;
+        for (int k = 0; k < 5184; ++k) probs[size_t(i) * 5184 + k] = float(r() % 1000) * 1e-6f;
+    }
+    return 0;
+}
+
+int main() {
+    SearchSettings s;
+    s.batch_size = 8;
+    s.epsilon_greedy_counter = 9;
+    s.dirichlet_epsilon = 0.25f;
+    SearchPool pool(s, make_callback_evaluator(eval, nullptr, 64, 5184), make_callback_evaluator(eval, nullptr, 64, 5184));
+    chess::Position p;
+    p.set(chess::start_fen(chess::V_CRAZYHOUSE), false, chess::V_CRAZYHOUSE);
+    for (int i = 0; i < 16; ++i) pool.add_position(p);
+    SearchStats st;
+    for (int round = 0; round < 3; ++round) {
+        pool.run(120 * (round + 1), 0, 6, &st);
+        std::printf("round %d: %llu nodes, %llu batches\n", round, (unsigned long long)st.nodes, (unsigned long long)st.batches);
+        for (int i = 0; i < 16; i += 2) {
+            const int best = pool.tree(i).best_move_index();
+            if (best >= 0) pool.tree(i).apply_move(pool.tree(i).root().actions[size_t(best)]);
+        }
+        pool.set_active(1, round == 0);
+    }
+    std::printf("done\n");
+    return 0;
+}

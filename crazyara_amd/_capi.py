@@ -47,6 +47,8 @@ SIGNATURES = {
     "mi_pos_terminal": (C.c_int, [C.c_void_p]),
     "mi_pos_number_repetitions": (C.c_int, [C.c_void_p]),
     "mi_pos_in_check": (C.c_int, [C.c_void_p]),
+    "mi_pos_insufficient_material": (C.c_int, [C.c_void_p]),
+    "mi_pos_plies_from_null": (C.c_int, [C.c_void_p]),
     "mi_pos_move_to_san": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int]),
     "mi_pos_perft": (C.c_ulonglong, [C.c_void_p, C.c_int]),
     "mi_chess960_start_fen": (C.c_char_p, [C.c_int]),

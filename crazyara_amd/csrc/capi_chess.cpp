@@ -81,6 +81,8 @@ int mi_pos_move_to_san(const mi_pos* pos, uint32_t move, char* buf, int cap) {
     return n;
 }
 
+int mi_pos_insufficient_material(const mi_pos* pos) { return pos && pos->pos.draw_by_insufficient_material() ? 1 : 0; }
+int mi_pos_plies_from_null(const mi_pos* pos) { return pos ? pos->pos.plies_from_null() : 0; }
 int mi_pos_in_check(const mi_pos* pos) { return pos && pos->pos.checkers() != 0 ? 1 : 0; }
 
 int mi_pos_number_repetitions(const mi_pos* pos) { return pos ? pos->pos.number_repetitions() : -1; }

@@ -84,6 +84,12 @@ class Position:
     def in_check(self) -> bool:
         return bool(self._lib.mi_pos_in_check(self._h))
 
+    def insufficient_material(self) -> bool:
+        return bool(self._lib.mi_pos_insufficient_material(self._h))
+
+    def steps_from_null(self) -> int:
+        return self._lib.mi_pos_plies_from_null(self._h)
+
     def number_repetitions(self) -> int:
         return self._lib.mi_pos_number_repetitions(self._h)
 

@@ -110,6 +110,8 @@ int mi_pos_move_to_san(const mi_pos* pos, uint32_t move, char* buf, int cap);
 int mi_pos_do_move(mi_pos* pos, uint32_t move);                        /* do_action */
 int mi_pos_terminal(const mi_pos* pos);                                /* is_terminal(legal count) -> MI_TERMINAL_* */
 int mi_pos_number_repetitions(const mi_pos* pos);
+int mi_pos_insufficient_material(const mi_pos* pos);                  /* Board::draw_by_insufficient_material (board.cpp:175-221) */
+int mi_pos_plies_from_null(const mi_pos* pos);                        /* State::steps_from_null (boardstate.h) */
 int mi_pos_in_check(const mi_pos* pos);                                /* 1 if the side to move is in check (Position::checkers) */
 unsigned long long mi_pos_perft(const mi_pos* pos, int depth);
 const char* mi_chess960_start_fen(int scharnagl_index);                /* deterministic stand-in for chess960fen() */

@@ -126,6 +126,18 @@ class Node:
         return self.child_visits[c] - self.vl[c]
 
 
+def first_and_second_max(values):
+    """first_and_second_max (blazeutil.h:155-178): (max, runner-up, argmax, arg of the runner-up); the runner-up starts at
+    numeric_limits<T>::min(), the smallest POSITIVE number.  Pinned by the reference's own test (engine/tests/tests.cpp:626-646)."""
+    first, second, fa, sa = values[0], 2.2250738585072014e-308, 0, 0
+    for i in range(1, len(values)):
+        if values[i] > first:
+            second, sa, first, fa = first, fa, values[i], i
+        elif values[i] > second:
+            second, sa = values[i], i
+    return first, second, fa, sa
+
+
 class Tree:
     def __init__(self, board: co.Board, s: Settings, clone_keeps_last_moves=None):
         self.s = s
@@ -505,12 +517,7 @@ class Tree:
         for i in range(1, m):
             if n.q[i] > n.q[best_q]:
                 best_q = i
-        first, second, fa, sa = pol[0], 2.2250738585072014e-308, 0, 0
-        for i in range(1, m):
-            if pol[i] > first:
-                second, sa, first, fa = first, fa, pol[i], i
-            elif pol[i] > second:
-                second, sa = pol[i], i
+        first, second, fa, sa = first_and_second_max(pol)
         if self.s.q_value_weight > 0:
             if self.s.q_veto_delta != 0 and best_q != fa and n.q[best_q] > F(n.q[fa] + self.s.q_veto_delta) and n.child_visits[best_q] > 1:
                 if pol[fa] > pol[best_q]:

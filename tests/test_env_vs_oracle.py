@@ -156,3 +156,46 @@ def test_host_planes_from_descriptors_equal_position_planes(hip_lib):
             got = env.planes_from_descs_host(p.desc(layout) + q.desc(layout), 2, layout, True)
             assert np.array_equal(got[0].reshape(-1), p.planes(mode, v, True).reshape(-1))
             assert np.array_equal(got[1].reshape(-1), q.planes(mode, v, True).reshape(-1))
+
+
+INSUFFICIENT = [  # engine/tests/tests.cpp:203-252 "Draw_by_insufficient_material"
+    ("8/8/2k5/8/8/4K3/8/8 w - - 0 1", "chess", True), ("8/8/2k5/8/5B2/4K3/8/8 w - - 0 1", "chess", True),
+    ("8/8/2k5/8/5N2/4K3/8/8 w - - 0 1", "chess", True), ("8/8/2k5/8/8/3NKN2/8/8 w - - 0 1", "chess", True),
+    ("kn6/8/NK6/8/8/8/8/8 w - - 0 2", "chess", False), ("rnbqkb1r/pp2pppp/3p1n2/8/3NP3/8/PPP2PPP/RNBQKB1R w KQkq - 1 5", "chess", False),
+    ("8/8/2k5/8/8/4K3/8/8 w - - 0 1", "kingofthehill", False), ("8/8/2k5/8/5B2/4K3/8/8 w - - 0 1", "racingkings", False),
+    ("8/8/2k5/8/5N2/4K3/8/8 w - - 0 1", "antichess", False), ("8/8/2k5/8/8/3NKN2/8/8 w - - 0 1", "horde", False),
+    ("8/8/3k4/8/4P3/8/8/8 w - - 0 1", "horde", False),
+]
+
+
+@pytest.mark.parametrize("fen,variant,expected", INSUFFICIENT)
+def test_draw_by_insufficient_material_reference_cases(hip_lib, fen, variant, expected):
+    p = env.Position(fen, False, variant)
+    assert p.insufficient_material() == expected
+    if variant == "chess":                                              # the oracle folds the rule into its terminal verdict
+        assert (co.Board(fen, False, variant).terminal() == 1) == expected and (p.terminal() == 1) == expected
+
+
+@pytest.mark.parametrize("variant,seed", [("crazyhouse", 42), ("chess", 543), ("crazyhouse", 1048), ("atomic", 7), ("antichess", 8)])
+def test_state_tests_of_the_reference_random_games(hip_lib, variant, seed):
+    """engine/tests/tests.cpp:641-740 "State: steps_from_null / Reach terminal state / check_result / clone": random games count their
+    plies, end within 10000 moves, a finished game has a result that agrees with the terminal type, and a clone has the same FEN."""
+    rng = random.Random(seed)
+    p = env.Position("", False, variant)
+    assert p.steps_from_null() == 0
+    applied = 0
+    while applied < 10000:
+        assert p.steps_from_null() == applied
+        moves = p.legal_moves()
+        if p.terminal() != 4:
+            break
+        p.push(rng.choice(moves))
+        applied += 1
+        if applied == 7:
+            assert p.clone().fen() == p.fen()
+    t = p.terminal()
+    assert t != 4                                                       # reached a terminal state
+    b = co.Board(p.fen(), False, variant)
+    assert b.terminal() == t                                            # the oracle agrees on the verdict of the final position
+    if t == 0:
+        assert not moves or variant in ("atomic", "antichess", "horde", "racingkings", "kingofthehill", "3check")   # LOSS: mated or variant rule

@@ -504,3 +504,9 @@ def test_chess_v28_leaf_descriptors_carry_the_move_features(hip_lib):
     pool3.add_position("", False, "chess")
     pool3.run(simulations=40, threads=1)
     assert seen and all(d[152:169] == bytes(17) for d in seen)
+
+
+def test_first_and_second_max_reference_cases():
+    """engine/tests/tests.cpp:626-646 "Blaze: first_and_second_max()"."""
+    assert mo.first_and_second_max([3, 42, 1, 3, 99, 8, 7]) == (99, 42, 4, 1)
+    assert mo.first_and_second_max([99, 3, 1, 3, 42, 8, 7]) == (99, 42, 0, 4)

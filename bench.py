@@ -265,6 +265,17 @@ def main():
             dom_flops = 2.0 * 64 * 9 * (cfg.nb_input_channels * 256 + 256 * 256 + 256 * cfg.channels_policy_head) * args.batch
         else:
             dom_flops = flops_total
+        per_op_three = None
+        if dom == "forward":
+            # the whole forward is one launch (forward.hip); the same net as three launches gives the split per stage (informational)
+            net3 = HipAPI(local_rank, args.batch, tmp, args.precision + "-3k")
+            torch.as_tensor(net3.device_buffers()["planes"], device="cuda").copy_(x.cuda())
+            net3.time_ops(2)
+            a3 = {}
+            for name, ms in net3.time_ops(5):
+                a3[name] = a3.get(name, 0.0) + ms
+            per_op_three = {k: round(v, 4) for k, v in a3.items()}
+            net3.close()
         peak = PEAK_F16_TFLOPS if args.precision == "float16" else PEAK_F32_TFLOPS
         achieved = dom_flops / (agg[dom] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": dom, "launches_per_step": cnt[dom],
@@ -274,6 +285,8 @@ def main():
                                       "achieved": round(flops_total / (ev_ms * 1e-3) / 1e12, 2),
                                       "frac": round(flops_total / (ev_ms * 1e-3) / 1e12 / peak, 4)},
                     "per_op_ms": {k: round(v, 4) for k, v in agg.items()}}
+        if per_op_three:
+            roofline["per_op_ms_as_three_launches"] = per_op_three
         # ---- PCIe-inclusive rate (the reference `inference` command includes H2D/D2H each call) ----
         from crazyara_amd.neuralnetapi import NeuralNetAPIUser
         user = NeuralNetAPIUser([net])

@@ -38,7 +38,7 @@ __device__ __forceinline__ uint32_t pack_relu_h2(float a, float ca, float b, flo
     asm("v_fma_mixlo_f16 %0, %1, 1.0, %2\n\tv_fma_mixhi_f16 %0, %3, 1.0, %4\n\tv_pk_max_f16 %0, %0, 0" : "=&v"(r) : "v"(a), "v"(ca), "v"(b), "v"(cb));
     return r;
 }
-__device__ __forceinline__ void mma32(const half8& a, const half8& b, f32x16& c) {
+__device__ __forceinline__ void hd_mma32(const half8& a, const half8& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 // LDS row of the neighbour of square sq for tap (dy, dx), or the zero row 64
@@ -62,9 +62,12 @@ __device__ __forceinline__ float block_reduce_512(float v, float* red, bool is_m
 }
 }  // namespace
 
+#ifndef CRA_FORWARD_TU
 size_t head_lds_bytes() { return HD_LDS_BYTES; }
+#endif
 
-__global__ __launch_bounds__(512) void head_kernel(const HeadArgs a) {
+// x_in_lds: the board tile is already at offset 0 of the dynamic LDS segment ([64][HD_ROW] f16, the tower's residual-stream tile)
+__device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds) {
     using frag = half8;
     constexpr int ROW = HD_ROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,10 +92,12 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs a) {
 #pragma unroll
     for (int q = 0; q < HD_WIN; ++q) win[q] = sp[q * 64];
     {
-        const half_t* xb = reinterpret_cast<const half_t*>(a.x) + size_t(b) * 64 * HD_C;
-        for (int i = tid; i < 64 * 32; i += 512) {
-            const int r = i >> 5, v = i & 31;
-            *reinterpret_cast<uint4*>(X + r * ROW + v * 8) = *reinterpret_cast<const uint4*>(xb + size_t(r) * HD_C + v * 8);
+        if (!x_in_lds) {
+            const half_t* xb = reinterpret_cast<const half_t*>(a.x) + size_t(b) * 64 * HD_C;
+            for (int i = tid; i < 64 * 32; i += 512) {
+                const int r = i >> 5, v = i & 31;
+                *reinterpret_cast<uint4*>(X + r * ROW + v * 8) = *reinterpret_cast<const uint4*>(xb + size_t(r) * HD_C + v * 8);
+            }
         }
         if (tid < ROW / 2) {                          // zero rows of both tiles
             reinterpret_cast<uint32_t*>(X + 64 * ROW)[tid] = 0u;
@@ -142,10 +147,10 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs a) {
                 }
                 if (tap < 9) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) mma32(win[s * 2 + (i >> 1)], cur[i], acc[i & 1]);
+                    for (int i = 0; i < 4; ++i) hd_mma32(win[s * 2 + (i >> 1)], cur[i], acc[i & 1]);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) mma32(win[s * 2 + (i >> 1)], cur[i], accv[i & 1]);
+                    for (int i = 0; i < 4; ++i) hd_mma32(win[s * 2 + (i >> 1)], cur[i], accv[i & 1]);
                 }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) win[s * 2 + e] = sp[(s * 2 + e + HD_WIN) * 64];
@@ -209,8 +214,8 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs a) {
                 if (i + 1 < 18) read_b(wv * 18 + i + 1, bq[(q6 + 1) & 1]);
 #pragma unroll
                 for (int rt = 0; rt < 3; ++rt) {
-                    mma32(wf[q][rt], bq[q6 & 1][0], acc[rt][0]);
-                    mma32(wf[q][rt], bq[q6 & 1][1], acc[rt][1]);
+                    hd_mma32(wf[q][rt], bq[q6 & 1][0], acc[rt][0]);
+                    hd_mma32(wf[q][rt], bq[q6 & 1][1], acc[rt][1]);
                 }
 #pragma unroll
                 for (int rt = 0; rt < 3; ++rt) wf[q][rt] = s2[((i + 3) * 3 + rt) * 64];
@@ -321,10 +326,15 @@ __global__ __launch_bounds__(512) void head_kernel(const HeadArgs a) {
     HD_STAMP();
 }
 
+#ifndef CRA_FORWARD_TU
+__global__ __launch_bounds__(512) void head_kernel(const HeadArgs a) { head_body(a, false); }
+
 void init_head_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HD_LDS_BYTES);
 }
 
 void launch_head(const HeadArgs& a, hipStream_t s) { hipLaunchKernelGGL(head_kernel, dim3(a.batch), dim3(512), HD_LDS_BYTES, s, a); }
+
+#endif  // CRA_FORWARD_TU
 
 }  // namespace cra

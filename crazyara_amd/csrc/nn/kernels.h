@@ -155,6 +155,11 @@ void launch_head(const HeadArgs& a, hipStream_t s);
 void init_head_kernel_attributes();
 size_t head_lds_bytes();
 
+// Stem + tower + head of a board in one launch (forward.hip): the board tile stays in LDS across both seams.  Needs a tower launch
+// that covers every block (gate_in == pool_out == nullptr); x / y of the three argument sets are not touched.
+void launch_forward(const StemArgs& sa, const TowerArgs& ta, const HeadArgs& ha, hipStream_t s);
+void init_forward_kernel_attributes();
+
 // Dense residual tower in one launch, one workgroup per board (restower.hip).  f16, C = 256.
 //   wstream  (8 / NR) waves x per block { conv 1: [9 taps][16 k-steps][NR cout tiles] A fragments (rows = couts
 //            32*(NR*wave + rt) + row, K = input channel), conv 2: the same with K position -> conv-1 channel

@@ -74,7 +74,7 @@ std::vector<T> pack_dense(const Folded& f, int cout, int cin, int ks, int cout_p
     return out;
 }
 
-enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower };
+enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower, Forward };
 
 struct Op {
     OpKind kind;
@@ -124,6 +124,11 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     : device_(device_id), impl_(new Impl) {
     if (batch_size <= 0) throw std::invalid_argument("batch size must be positive");
     std::string prec = precision;
+    // "-3k": stem, tower and head as three launches instead of one (forward.hip); per-kernel timing and A/B reference
+    if (prec.size() > 3 && prec.compare(prec.size() - 3, 3, "-3k") == 0) {
+        one_launch_ = false;
+        prec.resize(prec.size() - 3);
+    }
     // "-1b" / "-2b": boards per workgroup of the dense residual tower (restower.hip); default by batch size
     if (prec.size() > 3 && prec.compare(prec.size() - 3, 3, "-8w") == 0) {   // dense tower: 8 thin waves instead of 4 fat ones
         rt_thin_waves_ = true;
@@ -910,6 +915,17 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     init_tower_kernel_attributes();
     init_restower_kernel_attributes();
     init_head_kernel_attributes();
+    // stem -> tower -> head with nothing in between and nothing handed to other launches: one launch, the board tile stays in LDS
+    if (one_launch_ && im.ops.size() == 3 && im.ops[0].kind == OpKind::Stem && im.ops[1].kind == OpKind::Tower && im.ops[2].kind == OpKind::Head &&
+        im.ops[1].tw.gate_in == nullptr && im.ops[1].tw.pool_out == nullptr) {
+        Op op;
+        op.kind = OpKind::Forward;
+        op.st = im.ops[0].st;
+        op.tw = im.ops[1].tw;
+        op.hd = im.ops[2].hd;
+        im.ops.assign(1, op);
+        init_forward_kernel_attributes();
+    }
     design_.flops_per_position = 2.0 * macs;
     launches_ = int(im.ops.size());
 }
@@ -935,6 +951,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s) {
         case OpKind::Head: launch_head(op.hd, s); break;
         case OpKind::ResTower: launch_restower(op.rt, s); break;
         case OpKind::Stem: launch_stem(op.st, s); break;
+        case OpKind::Forward: launch_forward(op.st, op.tw, op.hd, s); break;
         case OpKind::SEGate:
             launch_se_gate(static_cast<const float*>(op.x), static_cast<float*>(op.y), op.se_kind, op.w0, op.w1, op.b0, B, op.C, s);
             break;
@@ -962,6 +979,7 @@ const char* RiseNet::op_name(int i) const {
         case OpKind::Head: return "head";
         case OpKind::ResTower: return "restower";
         case OpKind::Stem: return "stem";
+        case OpKind::Forward: return "forward";
     }
     return "?";
 }
@@ -985,7 +1003,7 @@ void RiseNet::time_ops(int iters, float* ms) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     for (const Op& op : impl_->ops)
-        if (op.kind == OpKind::Head && op.hd.trace) {
+        if ((op.kind == OpKind::Head || op.kind == OpKind::Forward) && op.hd.trace) {
             unsigned long long h[16];
             HIP_CHECK(hipMemcpy(h, op.hd.trace, sizeof(h), hipMemcpyDeviceToHost));
             fprintf(stderr, "head trace (load, conv1, pack, conv2, atomics, softmax, value):");
@@ -993,7 +1011,7 @@ void RiseNet::time_ops(int iters, float* ms) {
             fprintf(stderr, "\n");
         }
     for (const Op& op : impl_->ops)
-        if (op.kind == OpKind::Tower && op.tw.trace) {
+        if ((op.kind == OpKind::Tower || op.kind == OpKind::Forward) && op.tw.trace) {
             std::vector<unsigned long long> h(512);
             HIP_CHECK(hipMemcpy(h.data(), op.tw.trace, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             for (int wv = 0; wv < 2; ++wv) {

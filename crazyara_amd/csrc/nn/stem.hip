@@ -25,8 +25,10 @@ __device__ __forceinline__ uint32_t st_pack_relu_h2(float a, float ca, float b, 
 }
 }  // namespace
 
+// to_global = false: the result stays in LDS as the [64][ST_OROW] tile at offset 0 of the dynamic segment, which is exactly the
+// residual-stream tile the tower opens with (forward.hip runs stem, tower and head of a board in one launch)
 template <int NKS>
-__global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) {
+__device__ __forceinline__ void stem_body(const StemArgs& a, const bool to_global) {
     using frag = half8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* ot = reinterpret_cast<half_t*>(smem);                    // [64][ST_OROW] output staging
@@ -88,12 +90,17 @@ __global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) {
             *reinterpret_cast<uint2*>(ot + (ct * 32 + l31) * ST_OROW + wv * 32 + g4 * 8 + lh * 4) = o;
         }
     __syncthreads();
+    if (!to_global) return;
     half_t* xb = reinterpret_cast<half_t*>(a.x) + size_t(b) * 64 * 256;
     for (int i = tid; i < 64 * 32; i += 512) {
         const int r = i >> 5, v = i & 31;
         *reinterpret_cast<uint4*>(xb + size_t(r) * 256 + v * 8) = *reinterpret_cast<const uint4*>(ot + r * ST_OROW + v * 8);
     }
 }
+
+#ifndef CRA_FORWARD_TU
+template <int NKS>
+__global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) { stem_body<NKS>(a, true); }
 
 void launch_stem(const StemArgs& a, hipStream_t s) {
     const int nks = a.cin_pad / 16;
@@ -105,5 +112,7 @@ void launch_stem(const StemArgs& a, hipStream_t s) {
         default: hipLaunchKernelGGL(stem_kernel<6>, dim3(a.batch), dim3(512), lds, s, a); break;
     }
 }
+
+#endif  // CRA_FORWARD_TU
 
 }  // namespace cra

@@ -515,9 +515,13 @@ __device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_
 }
 }  // namespace
 
+#ifndef CRA_FORWARD_TU
 size_t tower_lds_bytes() { return TW_LDS_BYTES; }
+#endif
 
-__global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
+// x_in_lds: the board's residual-stream tile is already at offset 0 of the dynamic LDS segment (left there by the stem of the same
+// launch, forward.hip); y_to_global = false: it stays there for the head of the same launch.  Both need gate_in == pool_out == nullptr.
+__device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_lds, const bool y_to_global) {
     using frag = half8;
     constexpr int C = TW_C, XROW = TW_XROW, T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -547,6 +551,7 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
             const int rowi = tid / (T1ROW / 2), col = tid % (T1ROW / 2);
             reinterpret_cast<uint32_t*>(smem + TW_T1_OFF + (rowi >> 1) * TW_T1_BYTES + (rowi & 1) * 65 * T1ROW * 2)[col] = 0u;
         }
+        if (x_in_lds) return;
         const half_t* xb = reinterpret_cast<const half_t*>(a.x) + size_t(b) * 64 * C;
         if (a.gate_in == nullptr) {
             for (int i = tid; i < 64 * 32; i += 512) {
@@ -797,7 +802,7 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
     }
 
     // ---- residual stream -> HBM; channel sums for an SE gate computed by a later launch ----
-    {
+    if (y_to_global) {
         half_t* yb = reinterpret_cast<half_t*>(a.y) + size_t(b) * 64 * C;
         for (int i = tid; i < 64 * 32; i += 512) {
             const int r = i >> 5, v = i & 31;
@@ -811,6 +816,9 @@ __global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) {
     }
 }
 
+#ifndef CRA_FORWARD_TU
+__global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) { tower_body(a, false, true); }
+
 void init_tower_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TW_DYN_LDS_BYTES);
 }
@@ -818,5 +826,7 @@ void init_tower_kernel_attributes() {
 void launch_tower(const TowerArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(tower_kernel, dim3(a.batch), dim3(512), TW_DYN_LDS_BYTES, s, a);
 }
+
+#endif  // CRA_FORWARD_TU
 
 }  // namespace cra

@@ -80,7 +80,8 @@ def cpu_baseline(cfg, sd, x, budget_s=15.0):
     from oracle import rise_oracle as ro
     # measured on the MI355X host (256 logical CPUs): torch CPU inference peaks at 16 threads (8: 183, 16: 474, 32: 374,
     # 64: 198, 128: 80 evals/s on this model) -- more threads oversubscribe the 8x8 convolutions
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    from crazyara_amd import replicas
+    cores = min(16, replicas.available_cpus())
     torch.set_num_threads(cores)
     ro.predict(cfg, sd, x[:32])  # warm-up
     n, t0 = 0, time.perf_counter()
@@ -203,13 +204,17 @@ def main():
         fens = openings.position_fens("crazyhouse")
         for i in range(n_trees):
             pool.add_position(fens[(i * 7 + rank * 3) % len(fens)], False, "crazyhouse")
-        threads = max(1, min(args.search_threads, (os.cpu_count() or 1) // max(1, world)))
+        # one CPU is left to the thread that drives the lanes (the workers spin while a search runs)
+        cpus = replicas.available_cpus()
+        threads = max(1, min(args.search_threads, max(1, cpus // max(1, world) - 1)))
         # untimed warm-up (worker threads, allocator, clocks), then every tree restarts from its opening position
         tree_fens = [fens[(i * 7 + rank * 3) % len(fens)] for i in range(n_trees)]
         pool.run(simulations=min(200, args.simulations), threads=threads)
         for i, f in enumerate(tree_fens):
             pool.reset_position(i, f, False, "crazyhouse")
+        thr0 = replicas.cgroup_throttled_usec()
         stt = pool.run(simulations=args.simulations, threads=threads)
+        thr1 = replicas.cgroup_throttled_usec()
         # RCCL sum of {nodes, evals, simulations}, max of seconds
         nodes_t, sec_t, ex = replicas.reduce_stats(replicas.ReplicaStats(units=float(stt.nodes), seconds=stt.seconds,
                                                                            extra=(float(stt.nn_evals), float(stt.simulations))),
@@ -218,7 +223,8 @@ def main():
         mcts = {"mcts_nodes_per_sec": round(tot[0] / tot[3], 1), "mcts_nn_evals_per_sec": round(tot[1] / tot[3], 1),
                 "simulations_per_sec": round(tot[2] / tot[3], 1), "seconds": round(tot[3], 3),
                 "trees_per_gpu": n_trees, "simulations_per_tree": args.simulations, "per_tree_quota": args.search_quota,
-                "lanes": lanes, "host_threads_per_gpu": threads, "avg_batch_fill": round(stt.nn_evals / max(1, stt.batches) / args.batch, 3),
+                "lanes": lanes, "host_threads_per_gpu": threads, "host_cpus_available": cpus,
+                "host_cgroup_throttled_ms_during_search": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 2), "avg_batch_fill": round(stt.nn_evals / max(1, stt.batches) / args.batch, 3),
                 "depth_avg": round(stt.depth_avg, 2), "depth_max": int(stt.depth_max)}
         pool.close()
         if extra_nets:

@@ -34,6 +34,8 @@ SIGNATURES = {
     "mi_net_op_count": (C.c_int, [C.c_void_p]),
     "mi_net_time_ops": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), c_float_p]),
     "mi_net_submit_boards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_net_submit_boards_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p,
+                                                C.c_void_p, C.c_void_p]),
     # environment
     "mi_pos_create": (C.c_void_p, [C.c_char_p, C.c_int, C.c_char_p]),
     "mi_pos_clone": (C.c_void_p, [C.c_void_p]),

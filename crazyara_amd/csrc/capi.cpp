@@ -88,6 +88,11 @@ int mi_net_submit_boards(mi_net* net, const void* descs_host, int n_valid, int l
     if (!net || (!descs_host && n_valid > 0) || !value || !probs) { g_err = "null argument to mi_net_submit_boards"; return 1; }
     return guard([&] { net->net.submit_boards(descs_host, n_valid, layout, value, probs, aux); });
 }
+int mi_net_submit_boards_gathered(mi_net* net, const void* descs_host, int n_valid, int layout, const unsigned short* idx,
+                                  const unsigned* cnt, unsigned stride, float* value, float* gathered, float* aux) {
+    if (!net || (n_valid > 0 && (!descs_host || !idx || !cnt || !gathered)) || !value) { g_err = "null argument to mi_net_submit_boards_gathered"; return 1; }
+    return guard([&] { net->net.submit_boards_gathered(descs_host, n_valid, layout, idx, cnt, stride, value, gathered, aux); });
+}
 int mi_net_wait(mi_net* net) {
     if (!net) { g_err = "null net"; return 1; }
     return guard([&] { net->net.wait(); });

@@ -231,6 +231,13 @@ struct ValueFinalArgs {
 };
 template <typename T> void launch_value_final(const ValueFinalArgs& a, hipStream_t s);
 
+// out[s][j] = probs[s][idx[s][j]] for j < cnt[s], s < n_slots (rows of `stride` entries): the priors of the legal moves of each new
+// search node, gathered next to the network output (set_probabilities_for_moves, node.cpp:961-979, reads exactly these entries).
+// idx / cnt / out / value_out / aux_out may be pinned host memory (read and written in place over PCIe); the same launch copies
+// the batch's values (and aux) out.
+void launch_gather_probs(const float* probs, int nb_policy, const uint16_t* idx, const uint32_t* cnt, int stride, int n_slots, float* out,
+                         const float* value_dev, float* value_out, int batch, const float* aux_dev, float* aux_out, hipStream_t s);
+
 // row softmax over n logits per board (tensorrtapi.cpp:378-392 appends exactly this to policy_out)
 void launch_softmax(const float* logits, float* probs, int batch, int n, hipStream_t s);
 

@@ -479,6 +479,31 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ 
     for (int i = tid; i < n; i += 256) out[i] = expf(in[i] - c);
 }
 
+// one workgroup per slot; a slot has at most `stride` entries, the reads hit the row of probabilities the forward just wrote;
+// the last workgroup carries the values (and aux) of the whole batch
+__global__ void gather_probs_kernel(const float* __restrict__ probs, int nb_policy, const uint16_t* __restrict__ idx,
+                                    const uint32_t* __restrict__ cnt, int stride, int n_slots, float* __restrict__ out,
+                                    const float* __restrict__ value_dev, float* __restrict__ value_out, int batch,
+                                    const float* __restrict__ aux_dev, float* __restrict__ aux_out) {
+    const int slot = blockIdx.x;
+    if (slot == n_slots) {
+        for (int i = threadIdx.x; i < batch; i += blockDim.x) value_out[i] = value_dev[i];
+        if (aux_dev != nullptr)
+            for (int i = threadIdx.x; i < batch * 4; i += blockDim.x) aux_out[i] = aux_dev[i];
+        return;
+    }
+    const uint32_t n = cnt[slot];
+    const float* row = probs + size_t(slot) * nb_policy;
+    const size_t base = size_t(slot) * stride;
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) out[base + j] = row[idx[base + j]];
+}
+
+void launch_gather_probs(const float* probs, int nb_policy, const uint16_t* idx, const uint32_t* cnt, int stride, int n_slots, float* out,
+                         const float* value_dev, float* value_out, int batch, const float* aux_dev, float* aux_out, hipStream_t s) {
+    hipLaunchKernelGGL(gather_probs_kernel, dim3(n_slots + 1), dim3(64), 0, s, probs, nb_policy, idx, cnt, stride, n_slots, out, value_dev,
+                       value_out, batch, aux_dev, aux_out);
+}
+
 void launch_softmax(const float* logits, float* probs, int batch, int n, hipStream_t s) {
     hipLaunchKernelGGL(softmax_kernel, dim3(batch), dim3(256), 0, s, logits, probs, n);
 }

@@ -50,6 +50,11 @@ public:
     void wait();
     // descriptor-fed variant: 192-byte BoardDesc per position, planes expanded on the GPU (csrc/chess/planes_kernel.hip)
     void submit_boards(const void* descs_host, int n_valid, int layout, float* value, float* probs, float* aux);
+    // the same, but only the probabilities the search will read come back: idx[s * stride .. + cnt[s]) are the policy indices of slot s's
+    // legal moves, gathered[] (same layout) receives probs[s][idx].  Every host buffer (descs, idx, cnt, value, gathered, aux) must come
+    // from mi_host_alloc / hipHostMalloc: the kernels read and write them in place, there is no copy.
+    void submit_boards_gathered(const void* descs_host, int n_valid, int layout, const uint16_t* idx, const uint32_t* cnt, uint32_t stride,
+                                float* value, float* gathered, float* aux);
 
     // Device-resident path: the captured forward reads d_planes() and writes d_value()/d_probs()/d_aux()/d_logits().
     float* d_planes() const { return d_planes_; }     // [B][C][64] float (NCHW, as predict() takes it)

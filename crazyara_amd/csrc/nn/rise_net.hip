@@ -1085,7 +1085,41 @@ void RiseNet::submit_boards(const void* descs_host, int n_valid, int layout, flo
     if (d_aux_ && aux) HIP_CHECK(hipMemcpyAsync(aux, d_aux_, B * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
 }
 
-void RiseNet::wait() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int layout, const uint16_t* idx, const uint32_t* cnt, uint32_t stride,
+                                     float* value, float* gathered, float* aux) {
+    HIP_CHECK(hipSetDevice(device_));
+    const size_t B = design_.batch;
+    if (n_valid < 0 || size_t(n_valid) > B) throw std::invalid_argument("n_valid out of range");
+    if (stride == 0) throw std::invalid_argument("gather stride must be positive");
+    if (layout_channels(layout) != design_.nb_input_channels)
+        throw std::invalid_argument("plane layout has " + std::to_string(layout_channels(layout)) + " channels, net expects " +
+                                    std::to_string(design_.nb_input_channels));
+    // No copy commands at all: the descriptors and the gather lists are read by the kernels straight from the caller's pinned
+    // (device-visible, coherent) buffers, and the gather kernel writes values, gathered priors and aux straight into them.  A batch
+    // moves ~50 KB in and ~170 KB out, so PCIe bandwidth is irrelevant; what a copy costs is the hand-over between the DMA engine
+    // and the compute queue -- five copies around three kernel groups were 0.1-0.5 ms of latency per batch (host dependent), more
+    // than the forward itself on a loaded host.  One queue, three launches back to back; the host polls the stream.
+    (void)stride;
+    if (n_valid > 0) launch_planes_from_desc(static_cast<const BoardDesc*>(descs_host), n_valid, layout, 1, d_planes_, stream_);
+    HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
+    launch_gather_probs(d_probs_, design_.nb_policy, idx, cnt, int(stride), n_valid, gathered, d_value_, value, int(B),
+                        (d_aux_ && aux) ? d_aux_ : nullptr, aux, stream_);
+}
+
+void RiseNet::wait() {
+    // CRA_WAIT_POLL=1 polls hipStreamQuery instead (development: on the hosts measured so far the runtime's own wait was not the
+    // source of the per-batch latency; both give the same pipeline rate)
+    static const bool poll = getenv("CRA_WAIT_POLL") != nullptr;
+    if (poll) {
+        for (;;) {
+            const hipError_t e = hipStreamQuery(stream_);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) HIP_CHECK(e);
+            __builtin_ia32_pause();
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
 
 void RiseNet::predict(const float* in_planes, float* value, float* probs, float* aux) {
     submit(in_planes, value, probs, aux);

@@ -76,6 +76,15 @@ void Tree::root_desc(BoardDesc& d) const { chess::pack_desc(root_pos_, d, layout
 // fill_nn_results (searchthread.cpp:290-299): gather priors, temperature, value
 void Tree::fill_nn_result(Node& n, float value, const float* probs) {
     for (size_t i = 0; i < n.actions.size(); ++i) n.priors[i] = probs[n.policy_idx[i]];   // set_probabilities_for_moves, node.cpp:961-979
+    finish_node(n, value);
+}
+
+void Tree::fill_nn_result_gathered(Node& n, float value, const float* priors) {
+    for (size_t i = 0; i < n.actions.size(); ++i) n.priors[i] = priors[i];               // the same values, gathered before the copy back
+    finish_node(n, value);
+}
+
+void Tree::finish_node(Node& n, float value) {
     std::vector<uint16_t>().swap(n.policy_idx);
     const float t = s_.node_policy_temperature;                                           // apply_temperature, blazeutil.h:77-87
     if (t != 1) {
@@ -487,8 +496,23 @@ int Tree::collect(int quota, BoardDesc* descs) {
     return n_new;
 }
 
+void Tree::pending_policy_indices(int k, const uint16_t** idx, int* count) const {
+    const Node& n = nodes_[new_nodes_.at(size_t(k))];
+    *idx = n.policy_idx.data();
+    *count = int(n.policy_idx.size());
+}
+
 void Tree::finish_batch(const float* values, const float* probs, int nb_policy) {
     for (size_t i = 0; i < new_nodes_.size(); ++i) fill_nn_result(nodes_[new_nodes_[i]], values[i], probs + i * size_t(nb_policy));
+    backup_batch();
+}
+
+void Tree::finish_batch_gathered(const float* values, const float* gathered, uint32_t stride) {
+    for (size_t i = 0; i < new_nodes_.size(); ++i) fill_nn_result_gathered(nodes_[new_nodes_[i]], values[i], gathered + i * size_t(stride));
+    backup_batch();
+}
+
+void Tree::backup_batch() {
     for (size_t i = 0; i < new_nodes_.size(); ++i) backup_value(nodes_[new_nodes_[i]].value(), new_trajectories_[i], false);
     new_nodes_.clear();
     new_trajectories_.clear();

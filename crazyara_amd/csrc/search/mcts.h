@@ -124,6 +124,11 @@ public:
     int collect(int quota, BoardDesc* descs);
     // set_nn_results_to_child_nodes + backup_value_outputs + backup_collisions (searchthread.cpp:301-324)
     void finish_batch(const float* values, const float* probs, int nb_policy);
+    // The same with the priors already gathered (on the GPU) for the legal moves of each new node:
+    // pending_policy_indices(k) = the policy indices of the k-th new node of the last collect(), in move order; `gathered + k * stride`
+    // holds probs[index] for exactly those (what set_probabilities_for_moves reads, node.cpp:961-979).
+    void pending_policy_indices(int k, const uint16_t** idx, int* count) const;
+    void finish_batch_gathered(const float* values, const float* gathered, uint32_t stride);
 
     // --- queries ---
     const Node& root() const { return nodes_[0]; }
@@ -152,6 +157,9 @@ private:
     void prepare_node_for_visits(Node& n);
     void increment_no_visit_idx(Node& n);
     void fill_nn_result(Node& n, float value, const float* probs);
+    void fill_nn_result_gathered(Node& n, float value, const float* priors);
+    void finish_node(Node& n, float value);
+    void backup_batch();
     int get_new_child_to_evaluate(NodeBackup& type, uint32_t& depth, BoardDesc* desc_out);
     uint32_t next_rand();
     size_t get_random_depth();

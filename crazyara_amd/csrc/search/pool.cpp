@@ -19,6 +19,14 @@ namespace search {
 // evaluators
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
+// room for the gathered priors of a slot: 160 legal moves (crazyhouse middlegames have 40-120; a batch with a position that has
+// more falls back to the full probability vectors)
+constexpr uint32_t kGatherPerSlotDefault = 160;
+uint32_t gather_per_slot() {            // CRA_GATHER_PER_SLOT: 0 = always whole probability vectors (A/B, tests), n = room per slot
+    const char* e = getenv("CRA_GATHER_PER_SLOT");
+    return e ? uint32_t(std::max(0, atoi(e))) : kGatherPerSlotDefault;
+}
+
 class HipEvaluator : public Evaluator {
 public:
     explicit HipEvaluator(RiseNet* net) : net_(net) {
@@ -35,12 +43,20 @@ public:
         values_ = static_cast<float*>(pinned(sizeof(float) * batch_));
         probs_ = static_cast<float*>(pinned(sizeof(float) * size_t(batch_) * nb_policy_));
         aux_ = d.nb_aux ? static_cast<float*>(pinned(sizeof(float) * size_t(batch_) * d.nb_aux)) : nullptr;
+        gstride_ = gather_per_slot();
+        const size_t gcap = std::max<size_t>(size_t(batch_) * gstride_, 1);
+        gidx_ = static_cast<uint16_t*>(pinned(sizeof(uint16_t) * gcap));
+        gcnt_ = static_cast<uint32_t*>(pinned(sizeof(uint32_t) * size_t(batch_)));
+        gout_ = static_cast<float*>(pinned(sizeof(float) * gcap));
     }
     ~HipEvaluator() override {
         (void)hipHostFree(descs_);
         (void)hipHostFree(values_);
         (void)hipHostFree(probs_);
         if (aux_) (void)hipHostFree(aux_);
+        (void)hipHostFree(gidx_);
+        (void)hipHostFree(gcnt_);
+        (void)hipHostFree(gout_);
     }
     int batch_size() const override { return batch_; }
     int nb_policy() const override { return nb_policy_; }
@@ -49,18 +65,30 @@ public:
     const float* probs() override { return probs_; }
     void submit(int n_valid, int layout) override { net_->submit_boards(descs_, n_valid, layout, values_, probs_, aux_); }
     void wait() override { net_->wait(); }
+    uint32_t gather_stride() const override { return gstride_; }
+    uint16_t* gather_idx() override { return gidx_; }
+    uint32_t* gather_cnt() override { return gcnt_; }
+    const float* gathered() override { return gout_; }
+    void submit_gathered(int n_valid, int layout) override {
+        net_->submit_boards_gathered(descs_, n_valid, layout, gidx_, gcnt_, gstride_, values_, gout_, aux_);
+    }
 
 private:
     RiseNet* net_;
     int batch_ = 0, nb_policy_ = 0;
     BoardDesc* descs_ = nullptr;
     float *values_ = nullptr, *probs_ = nullptr, *aux_ = nullptr;
+    uint32_t gstride_ = 0;
+    uint16_t* gidx_ = nullptr;
+    uint32_t* gcnt_ = nullptr;
+    float* gout_ = nullptr;
 };
 
 class CallbackEvaluator : public Evaluator {
 public:
     CallbackEvaluator(EvalFn fn, void* user, int batch, int nb_policy)
-        : fn_(fn), user_(user), batch_(batch), nb_policy_(nb_policy), descs_(batch), values_(batch), probs_(size_t(batch) * nb_policy) {
+        : fn_(fn), user_(user), batch_(batch), nb_policy_(nb_policy), descs_(batch), values_(batch), probs_(size_t(batch) * nb_policy),
+          gstride_(gather_per_slot()), gidx_(size_t(batch) * gstride_), gcnt_(size_t(batch)), gout_(size_t(batch) * gstride_) {
         std::memset(descs_.data(), 0, sizeof(BoardDesc) * batch);
     }
     int batch_size() const override { return batch_; }
@@ -72,6 +100,18 @@ public:
         if (fn_(user_, descs_.data(), n_valid, values_.data(), probs_.data()) != 0) throw std::runtime_error("evaluator callback failed");
     }
     void wait() override {}
+    // the callback fills whole probability vectors; the gather the HIP lane runs on the GPU happens here on the host, so that
+    // every pool driven by a callback (the CPU tests, the CPU baseline) takes the same path through the pool as the GPU lanes
+    uint32_t gather_stride() const override { return gstride_; }
+    uint16_t* gather_idx() override { return gidx_.data(); }
+    uint32_t* gather_cnt() override { return gcnt_.data(); }
+    const float* gathered() override { return gout_.data(); }
+    void submit_gathered(int n_valid, int layout) override {
+        submit(n_valid, layout);
+        for (int s = 0; s < n_valid; ++s)
+            for (uint32_t j = 0; j < gcnt_[size_t(s)]; ++j)
+                gout_[size_t(s) * gstride_ + j] = probs_[size_t(s) * nb_policy_ + gidx_[size_t(s) * gstride_ + j]];
+    }
 
 private:
     EvalFn fn_;
@@ -79,6 +119,10 @@ private:
     int batch_, nb_policy_;
     std::vector<BoardDesc> descs_;
     std::vector<float> values_, probs_;
+    uint32_t gstride_;
+    std::vector<uint16_t> gidx_;
+    std::vector<uint32_t> gcnt_;
+    std::vector<float> gout_;
 };
 }  // namespace
 
@@ -254,9 +298,29 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         for (int i = 0; i < n_use; ++i) { lane.slot_begin[i] = i * quota; lane.slot_count[i] = quota; }
         const auto c0 = std::chrono::steady_clock::now();
         std::vector<double> item_t(timing ? n_use : 0);
+        const uint32_t gstride = ev.gather_stride();
+        std::atomic<bool> gather_overflow{false};
         workers.parallel_for(n_use, [&](int i) {
             const auto i0 = std::chrono::steady_clock::now();
             lane.n_new[i] = trees_[ids[i]]->collect(lane.slot_count[i], ev.descs() + lane.slot_begin[i]);
+            // the policy indices of the new nodes' legal moves go straight into the lane's gather list (this thread just wrote them)
+            if (gstride) {
+                for (int k = 0; k < lane.slot_count[i]; ++k) {
+                    const size_t slot = size_t(lane.slot_begin[i] + k);
+                    uint32_t cnt = 0;
+                    if (k < lane.n_new[i]) {
+                        const uint16_t* src = nullptr;
+                        int c = 0;
+                        trees_[ids[i]]->pending_policy_indices(k, &src, &c);
+                        if (uint32_t(c) > gstride) gather_overflow.store(true, std::memory_order_relaxed);
+                        else {
+                            std::memcpy(ev.gather_idx() + slot * gstride, src, size_t(c) * sizeof(uint16_t));
+                            cnt = uint32_t(c);
+                        }
+                    }
+                    ev.gather_cnt()[slot] = cnt;
+                }
+            }
             if (timing) item_t[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
         });
         if (timing) {
@@ -280,7 +344,9 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
             return true;
         }
         const auto s0 = std::chrono::steady_clock::now();
-        ev.submit(last_used, layout_);
+        lane.gathered = ev.gather_stride() > 0 && !gather_overflow.load(std::memory_order_relaxed);
+        if (lane.gathered) ev.submit_gathered(last_used, layout_);
+        else ev.submit(last_used, layout_);
         t_submit += std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
         lane.in_flight = true;
         st.nn_evals += total_new;
@@ -296,7 +362,8 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         const int n_use = int(lane.slot_begin.size());
         workers.parallel_for(n_use, [&](int i) {
             const int id = lane.batch_ids[i];
-            trees_[id]->finish_batch(ev.values() + lane.slot_begin[i], ev.probs() + size_t(lane.slot_begin[i]) * ev.nb_policy(), ev.nb_policy());
+            if (lane.gathered) trees_[id]->finish_batch_gathered(ev.values() + lane.slot_begin[i], ev.gathered() + size_t(lane.slot_begin[i]) * ev.gather_stride(), ev.gather_stride());
+            else trees_[id]->finish_batch(ev.values() + lane.slot_begin[i], ev.probs() + size_t(lane.slot_begin[i]) * ev.nb_policy(), ev.nb_policy());
         });
         lane.in_flight = false;
     };

@@ -27,6 +27,15 @@ public:
     virtual const float* probs() = 0;      // [batch][nb_policy]
     virtual void submit(int n_valid, int layout) = 0;
     virtual void wait() = 0;
+    // Gathered priors: instead of bringing all nb_policy probabilities of every slot back to the host (5.3 MB per batch of 256
+    // crazyhouse boards) the lane receives the policy indices of the new nodes' legal moves and returns just those entries.
+    // Slot s owns gather_idx()[s * stride .. + gather_cnt()[s]) and the same range of gathered(): fixed stride, so that the trees
+    // of a batch write their slots in parallel and nothing has to be compacted.  stride 0 = the lane does not gather.
+    virtual uint32_t gather_stride() const = 0;
+    virtual uint16_t* gather_idx() = 0;                // [batch][stride]
+    virtual uint32_t* gather_cnt() = 0;                // [batch]
+    virtual const float* gathered() = 0;               // [batch][stride]
+    virtual void submit_gathered(int n_valid, int layout) = 0;   // values() and gathered() are valid after wait(); probs() is not
 };
 
 // HIP lane: RiseNet::submit_boards on the net's side stream (192 B/position H2D, planes built on the GPU, D2H of results)
@@ -91,6 +100,7 @@ private:
         std::vector<int> trees;            // tree ids assigned to this lane
         std::vector<int> slot_begin, slot_count, n_new, batch_ids;
         bool in_flight = false;
+        bool gathered = false;             // the batch in flight returns gathered priors
     };
     bool tree_done(const Tree& t, uint32_t simulations, uint32_t nodes) const;
     void evaluate_roots(Lane& lane);

@@ -37,3 +37,46 @@ def reduce_stats(local: ReplicaStats, dist=None, device: Optional[torch.device] 
 def throughput(local: ReplicaStats, dist=None, device: Optional[torch.device] = None) -> float:
     units, seconds, _ = reduce_stats(local, dist, device)
     return units / seconds if seconds > 0 else 0.0
+
+
+def available_cpus() -> int:
+    """CPUs this process can really use: the affinity mask, cut down by a cgroup CPU quota when there is one (containers report
+    the host's count in os.cpu_count()).  The search pool's workers spin while a search runs, so asking for more threads than
+    this starves the thread that drives the GPU."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:     # cgroup v1
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
+def cgroup_throttled_usec():
+    """Microseconds this container has spent throttled by its CPU quota so far (cgroup v2 cpu.stat), or None."""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            for line in f:
+                k, _, v = line.partition(" ")
+                if k == "throttled_usec":
+                    return int(v)
+    except (OSError, ValueError):
+        pass
+    return None

@@ -14,6 +14,7 @@ extern "C" hipError_t hipHostMalloc(void**, size_t, unsigned) { return hipErrorN
 extern "C" hipError_t hipHostFree(void*) { return hipSuccess; }
 namespace cra {
 void RiseNet::submit_boards(const void*, int, int, float*, float*, float*) {}
+void RiseNet::submit_boards_gathered(const void*, int, int, const uint16_t*, const uint32_t*, uint32_t, float*, float*, float*) {}
 void RiseNet::wait() {}
 }  // namespace cra
 

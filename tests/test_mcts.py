@@ -510,3 +510,29 @@ def test_first_and_second_max_reference_cases():
     """engine/tests/tests.cpp:626-646 "Blaze: first_and_second_max()"."""
     assert mo.first_and_second_max([3, 42, 1, 3, 99, 8, 7]) == (99, 42, 4, 1)
     assert mo.first_and_second_max([99, 3, 1, 3, 42, 8, 7]) == (99, 42, 0, 4)
+
+
+def test_gathered_priors_and_whole_vectors_give_the_same_trees(hip_lib, monkeypatch):
+    """The pool asks its lanes for the priors of the new nodes' legal moves only (gathered next to the network output; a batch
+    that does not fit the gather buffer falls back to whole probability vectors).  Three settings -- default room, room for 4
+    entries per slot (nearly every batch falls back), gather off -- must build bit-identical trees."""
+    nbp, quota, sims = NB_POLICY[0], 8, 300
+    fen = "r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] b KQkq - 0 8"
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    results = []
+    for setting in (None, "4", "0"):
+        if setting is None:
+            monkeypatch.delenv("CRA_GATHER_PER_SLOT", raising=False)
+        else:
+            monkeypatch.setenv("CRA_GATHER_PER_SLOT", setting)
+        st = search.default_settings(mode=0, version_major=1, is_policy_map=1, batch_size=quota, epsilon_greedy_counter=13)
+        pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=2 * quota, fn_nb_policy=nbp)
+        ids = [pool.add_position(fen, False, "crazyhouse"), pool.add_position("", False, "crazyhouse")]
+        pool.run(simulations=sims, threads=2)
+        results.append([(pool.root_children(t)[0], pool.root_children(t)[1], pool.root_children(t)[2].tolist(), pool.tree_info(t)) for t in ids])
+        pool.close()
+    assert results[0] == results[1] == results[2]

@@ -95,6 +95,33 @@ def test_lane_count_does_not_change_the_trees(tmp_path, hip_lib):
         assert len(visits) == len(env.Position(f, False, "crazyhouse").legal_uci())      # Dirichlet: root fully expanded
 
 
+def test_priors_gathered_on_the_gpu_equal_whole_probability_vectors(tmp_path, hip_lib, monkeypatch):
+    """The HIP lanes bring back only the probabilities of the new nodes' legal moves (gather kernel behind the forward, ~40 KB per
+    batch instead of 5.3 MB).  The same searches with the gather switched off, and with room for 4 entries per slot (fallback on
+    nearly every batch), must give the same trees down to the last Q bit."""
+    cfg, sd, _ = nn_cases.make_case("risev2-3")
+    d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
+    fens = openings.position_fens("crazyhouse")[20:28]
+    results = []
+    for setting in (None, "0", "4"):
+        if setting is None:
+            monkeypatch.delenv("CRA_GATHER_PER_SLOT", raising=False)
+        else:
+            monkeypatch.setenv("CRA_GATHER_PER_SLOT", setting)
+        nets = [HipAPI(0, 64, d, "float16") for _ in range(2)]
+        st = search.default_settings(mode=0, version_major=1, batch_size=16, seed=3)
+        pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1])
+        for f in fens:
+            pool.add_position(f, False, "crazyhouse")
+        pool.run(simulations=240, threads=4)
+        results.append([(pool.root_children(i)[1], pool.root_children(i)[2].tolist(), pool.tree_info(i)) for i in range(len(fens))])
+        pool.close()
+        for n in nets:
+            n.close()
+    assert results[0] == results[1] == results[2]
+    assert all(sum(r[0]) >= 239 for r in results[0])
+
+
 def test_selfplay_loop_on_the_gpu_chess960(tmp_path, hip_lib):
     """BASELINE config 4 in miniature: concurrent chess960 self-play games on one GPU with a real (random-init) net: raw-policy
     opening plies, temperature sampling, tree reuse; every recorded move is legal and every game ends."""

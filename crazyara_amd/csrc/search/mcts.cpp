@@ -185,6 +185,10 @@ void Tree::prepare_node_for_visits(Node& n) {
     if (!n.has_data) {
         n.has_data = true;
         n.no_visit_idx = 1;
+        {   // room for the first few children at once: most nodes expand 2-6 of them, one allocation each instead of 3 regrowths
+            const size_t room = std::min<size_t>(n.actions.size(), 6);
+            n.child_visits.reserve(room); n.q.reserve(room); n.child.reserve(room); n.vl.reserve(room); n.child_types.reserve(room);
+        }
         n.child_visits.assign(1, 0u);
         n.q.assign(1, Q_INIT);
         n.child.assign(1, -1);

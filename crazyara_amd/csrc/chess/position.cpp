@@ -506,12 +506,14 @@ void Position::legal_moves(std::vector<Move>& out) const {
     pseudo.clear();
     gen_pseudo(pseudo);
     if (variant_ == V_ANTI) {                        // antichess: if a capture exists, a capture must be played
+        out.reserve(pseudo.size());
         bool any_capture = false;
         for (Move m : pseudo) any_capture |= kind_of(m) == ENPASSANT || board_[to_sq(m)] != 0;
         for (Move m : pseudo)
             if (!any_capture || kind_of(m) == ENPASSANT || board_[to_sq(m)] != 0) out.push_back(m);
         return;
     }
+    out.reserve(pseudo.size());                      // one allocation for a fresh vector instead of a doubling chain
     // Not in check: a move of a piece that is neither the king nor pinned to it cannot expose the king, and a drop never does --
     // only king moves, moves of pinned pieces and en-passant captures need the attack test (with ~3 instead of ~30 per position).
     // Atomic has its own legality (explosions), positions without a king (horde's white side) have nothing to protect.

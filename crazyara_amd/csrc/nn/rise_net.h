@@ -62,7 +62,8 @@ public:
     float* d_probs() const { return d_probs_; }       // [B][nb_policy]
     float* d_logits() const { return d_logits_; }     // [B][nb_policy] pre-softmax policy_out
     float* d_aux() const { return d_aux_; }           // [B][nb_aux] or nullptr
-    void forward_async();                              // graph replay on stream(); no copies, no sync
+    void forward_async();
+    void launch_forward_in_stream();     // the forward as part of a stream's in-order work (submit*, see rise_net.hip)                              // graph replay on stream(); no copies, no sync
     // same forward enqueued kernel-by-kernel on a caller stream (no graph) -- used for profiling / event timing
     void forward_on(hipStream_t s);
 

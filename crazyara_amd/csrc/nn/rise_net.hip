@@ -1058,11 +1058,21 @@ void RiseNet::forward_on(hipStream_t s) {
 
 void RiseNet::forward_async() { HIP_CHECK(hipGraphLaunch(graph_exec_, stream_)); }
 
+// The forward between other work of the same stream (descriptor expansion before, gather / copies after).  A graph launch runs its
+// nodes on the graph's own queue and is tied to the launching stream by cross-queue dependencies, which this runtime resolves from
+// the host: measured, a lane's next kernel did not start until the host called into the runtime again (0.09-0.15 ms per batch lost
+// whenever the host was busy collecting).  With the whole forward in one to three kernels there is nothing left for a graph to save,
+// so these paths put the kernels straight into the stream: one queue, in-order, no host in the loop.
+void RiseNet::launch_forward_in_stream() {
+    if (launches_ <= 4 && getenv("CRA_LANE_GRAPH") == nullptr) forward_on(stream_);
+    else HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
+}
+
 void RiseNet::submit(const float* in_planes, float* value, float* probs, float* aux) {
     HIP_CHECK(hipSetDevice(device_));   // every predict selects its device, tensorrtapi.cpp:198
     const size_t B = design_.batch;
     HIP_CHECK(hipMemcpyAsync(d_planes_, in_planes, B * design_.nb_input_channels * kSquares * sizeof(float), hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
+    launch_forward_in_stream();
     HIP_CHECK(hipMemcpyAsync(value, d_value_, B * sizeof(float), hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipMemcpyAsync(probs, d_probs_, B * design_.nb_policy * sizeof(float), hipMemcpyDeviceToHost, stream_));
     if (d_aux_ && aux) HIP_CHECK(hipMemcpyAsync(aux, d_aux_, B * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
@@ -1079,7 +1089,7 @@ void RiseNet::submit_boards(const void* descs_host, int n_valid, int layout, flo
         HIP_CHECK(hipMemcpyAsync(d_desc_, descs_host, size_t(n_valid) * sizeof(BoardDesc), hipMemcpyHostToDevice, stream_));
         launch_planes_from_desc(static_cast<const BoardDesc*>(d_desc_), n_valid, layout, 1, d_planes_, stream_);
     }
-    HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
+    launch_forward_in_stream();
     HIP_CHECK(hipMemcpyAsync(value, d_value_, B * sizeof(float), hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipMemcpyAsync(probs, d_probs_, B * design_.nb_policy * sizeof(float), hipMemcpyDeviceToHost, stream_));
     if (d_aux_ && aux) HIP_CHECK(hipMemcpyAsync(aux, d_aux_, B * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
@@ -1101,7 +1111,7 @@ void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int la
     // than the forward itself on a loaded host.  One queue, three launches back to back; the host polls the stream.
     (void)stride;
     if (n_valid > 0) launch_planes_from_desc(static_cast<const BoardDesc*>(descs_host), n_valid, layout, 1, d_planes_, stream_);
-    HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
+    launch_forward_in_stream();
     launch_gather_probs(d_probs_, design_.nb_policy, idx, cnt, int(stride), n_valid, gathered, d_value_, value, int(B),
                         (d_aux_ && aux) ? d_aux_ : nullptr, aux, stream_);
 }

@@ -278,8 +278,70 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         return false;
     };
 
-    double t_par = 0, t_submit = 0, t_item_max = 0, t_item_sum = 0;
+    double t_par = 0, t_submit = 0, t_item_max = 0, t_item_sum = 0, t_wait = 0;
     const bool timing = getenv("CRA_POOL_TIMING") != nullptr;
+    std::atomic<bool> gather_overflow{false};
+    // one tree's share of a batch: leaves into its slots; the policy indices of the new nodes' legal moves go straight into the
+    // lane's gather list (this thread just wrote them)
+    auto collect_item = [&](Lane& lane, int i, int id) {
+        Evaluator& ev = *lane.eval;
+        const uint32_t gstride = ev.gather_stride();
+        lane.n_new[i] = trees_[id]->collect(lane.slot_count[i], ev.descs() + lane.slot_begin[i]);
+        if (gstride) {
+            for (int k = 0; k < lane.slot_count[i]; ++k) {
+                const size_t slot = size_t(lane.slot_begin[i] + k);
+                uint32_t cnt = 0;
+                if (k < lane.n_new[i]) {
+                    const uint16_t* src = nullptr;
+                    int c = 0;
+                    trees_[id]->pending_policy_indices(k, &src, &c);
+                    if (uint32_t(c) > gstride) gather_overflow.store(true, std::memory_order_relaxed);
+                    else {
+                        std::memcpy(ev.gather_idx() + slot * gstride, src, size_t(c) * sizeof(uint16_t));
+                        cnt = uint32_t(c);
+                    }
+                }
+                ev.gather_cnt()[slot] = cnt;
+            }
+        }
+    };
+    // the results of the batch a tree took part in: priors + values into its new nodes, backups
+    auto finish_item = [&](Lane& lane, bool gathered, int i, int id) {
+        Evaluator& ev = *lane.eval;
+        if (gathered) trees_[id]->finish_batch_gathered(ev.values() + lane.slot_begin[i], ev.gathered() + size_t(lane.slot_begin[i]) * ev.gather_stride(), ev.gather_stride());
+        else trees_[id]->finish_batch(ev.values() + lane.slot_begin[i], ev.probs() + size_t(lane.slot_begin[i]) * ev.nb_policy(), ev.nb_policy());
+    };
+    // after the trees of `ids` have collected: count, submit (or finish at once when there is nothing to evaluate)
+    auto submit_batch = [&](Lane& lane, const std::vector<int>& ids) {
+        Evaluator& ev = *lane.eval;
+        const int n_use = int(ids.size());
+        int total_new = 0, last_used = 0;
+        for (int i = 0; i < n_use; ++i) {
+            total_new += lane.n_new[i];
+            if (lane.n_new[i]) last_used = lane.slot_begin[i] + lane.n_new[i];
+        }
+        lane.batch_ids = ids;   // which tree owns which slot range, for the apply step
+        lane.in_flight = false;
+        if (total_new == 0) {
+            // nothing to evaluate (all terminal / collisions): finish immediately
+            workers.parallel_for(n_use, [&](int i) { trees_[ids[i]]->finish_batch(nullptr, nullptr, ev.nb_policy()); });
+            return;
+        }
+        const auto s0 = std::chrono::steady_clock::now();
+        lane.gathered = ev.gather_stride() > 0 && !gather_overflow.load(std::memory_order_relaxed);
+        if (lane.gathered) ev.submit_gathered(last_used, layout_);
+        else ev.submit(last_used, layout_);
+        t_submit += std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
+        lane.in_flight = true;
+        st.nn_evals += total_new;
+        ++st.batches;
+    };
+    auto note_items = [&](const std::vector<double>& item_t) {
+        double mx = 0, sm = 0;
+        for (double v : item_t) { mx = std::max(mx, v); sm += v; }
+        t_item_max += mx;
+        t_item_sum += sm;
+    };
     auto collect_lane = [&](Lane& lane) -> bool {
         std::vector<int> active;
         for (int id : lane.trees)
@@ -298,74 +360,66 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         for (int i = 0; i < n_use; ++i) { lane.slot_begin[i] = i * quota; lane.slot_count[i] = quota; }
         const auto c0 = std::chrono::steady_clock::now();
         std::vector<double> item_t(timing ? n_use : 0);
-        const uint32_t gstride = ev.gather_stride();
-        std::atomic<bool> gather_overflow{false};
+        gather_overflow.store(false, std::memory_order_relaxed);
         workers.parallel_for(n_use, [&](int i) {
             const auto i0 = std::chrono::steady_clock::now();
-            lane.n_new[i] = trees_[ids[i]]->collect(lane.slot_count[i], ev.descs() + lane.slot_begin[i]);
-            // the policy indices of the new nodes' legal moves go straight into the lane's gather list (this thread just wrote them)
-            if (gstride) {
-                for (int k = 0; k < lane.slot_count[i]; ++k) {
-                    const size_t slot = size_t(lane.slot_begin[i] + k);
-                    uint32_t cnt = 0;
-                    if (k < lane.n_new[i]) {
-                        const uint16_t* src = nullptr;
-                        int c = 0;
-                        trees_[ids[i]]->pending_policy_indices(k, &src, &c);
-                        if (uint32_t(c) > gstride) gather_overflow.store(true, std::memory_order_relaxed);
-                        else {
-                            std::memcpy(ev.gather_idx() + slot * gstride, src, size_t(c) * sizeof(uint16_t));
-                            cnt = uint32_t(c);
-                        }
-                    }
-                    ev.gather_cnt()[slot] = cnt;
-                }
-            }
+            collect_item(lane, i, ids[i]);
             if (timing) item_t[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
         });
-        if (timing) {
-            double mx = 0, sm = 0;
-            for (double v : item_t) { mx = std::max(mx, v); sm += v; }
-            t_item_max += mx;
-            t_item_sum += sm;
-        }
+        if (timing) note_items(item_t);
         t_par += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
         // rotate so that waiting trees get their turn next round
-        if (int(active.size()) > n_use) std::rotate(lane.trees.begin(), lane.trees.begin() + 1, lane.trees.end());
-        int total_new = 0, last_used = 0;
-        for (int i = 0; i < n_use; ++i) {
-            total_new += lane.n_new[i];
-            if (lane.n_new[i]) last_used = lane.slot_begin[i] + lane.n_new[i];
-        }
-        lane.batch_ids = ids;   // which tree owns which slot range, for the apply step
-        if (total_new == 0) {
-            // nothing to evaluate (all terminal / collisions): finish immediately
-            workers.parallel_for(n_use, [&](int i) { trees_[ids[i]]->finish_batch(nullptr, nullptr, ev.nb_policy()); });
-            return true;
-        }
-        const auto s0 = std::chrono::steady_clock::now();
-        lane.gathered = ev.gather_stride() > 0 && !gather_overflow.load(std::memory_order_relaxed);
-        if (lane.gathered) ev.submit_gathered(last_used, layout_);
-        else ev.submit(last_used, layout_);
-        t_submit += std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();
-        lane.in_flight = true;
-        st.nn_evals += total_new;
-        ++st.batches;
+        const bool rotated = int(active.size()) > n_use;
+        if (rotated) std::rotate(lane.trees.begin(), lane.trees.begin() + 1, lane.trees.end());
+        lane.same_trees_next = !rotated;       // the next batch of this lane can keep trees and slots (fused step below)
+        submit_batch(lane, ids);
         return true;
     };
-    double t_wait = 0;
     auto apply_lane = [&](Lane& lane) {
         Evaluator& ev = *lane.eval;
         const auto w0 = std::chrono::steady_clock::now();
         ev.wait();
         t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
         const int n_use = int(lane.slot_begin.size());
-        workers.parallel_for(n_use, [&](int i) {
-            const int id = lane.batch_ids[i];
-            if (lane.gathered) trees_[id]->finish_batch_gathered(ev.values() + lane.slot_begin[i], ev.gathered() + size_t(lane.slot_begin[i]) * ev.gather_stride(), ev.gather_stride());
-            else trees_[id]->finish_batch(ev.values() + lane.slot_begin[i], ev.probs() + size_t(lane.slot_begin[i]) * ev.nb_policy(), ev.nb_policy());
-        });
+        workers.parallel_for(n_use, [&](int i) { finish_item(lane, lane.gathered, i, lane.batch_ids[i]); });
         lane.in_flight = false;
+    };
+    // The usual step of a lane whose trees all fit into one batch: results of the batch in flight and the next leaf collection in
+    // ONE fork/join -- every tree finishes its share and collects again at once (same thread, its nodes still in that core's
+    // cache), keeping its slots.  A tree that reaches its limit leaves its slots empty; the step after that goes the long way
+    // (apply_lane + collect_lane), which compacts the remaining trees to the front.
+    auto fused_step = [&](Lane& lane) -> bool {
+        Evaluator& ev = *lane.eval;
+        const auto w0 = std::chrono::steady_clock::now();
+        ev.wait();
+        const auto c0 = std::chrono::steady_clock::now();
+        t_wait += std::chrono::duration<double>(c0 - w0).count();
+        const std::vector<int> ids = lane.batch_ids;
+        const int n_use = int(ids.size());
+        const bool was_gathered = lane.gathered;
+        std::vector<double> item_t(timing ? n_use : 0);
+        std::atomic<int> still_running{0};
+        gather_overflow.store(false, std::memory_order_relaxed);
+        workers.parallel_for(n_use, [&](int i) {
+            const auto i0 = std::chrono::steady_clock::now();
+            const int id = ids[i];
+            finish_item(lane, was_gathered, i, id);
+            if (done(id)) {
+                lane.n_new[i] = 0;
+                if (ev.gather_stride())
+                    for (int k = 0; k < lane.slot_count[i]; ++k) ev.gather_cnt()[size_t(lane.slot_begin[i] + k)] = 0;
+            } else {
+                still_running.fetch_add(1, std::memory_order_relaxed);
+                collect_item(lane, i, id);
+            }
+            if (timing) item_t[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - i0).count();
+        });
+        if (timing) note_items(item_t);
+        t_par += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+        const int running = still_running.load();
+        lane.same_trees_next = running == n_use;
+        submit_batch(lane, ids);
+        return running > 0;
     };
 
     // development: CRA_POOL_TIMING=1 prints where the driver thread spends its time (wait = blocked on the GPU)
@@ -376,6 +430,15 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         any = false;
         for (Lane& lane : lanes_) {
             const auto a0 = now();
+            if (lane.in_flight && lane.same_trees_next && getenv("CRA_POOL_TWO_STEP") == nullptr) {
+                const double w_before = t_wait;
+                if (fused_step(lane)) any = true;
+                if (timing) {
+                    t_apply += t_wait - w_before;
+                    t_collect += std::chrono::duration<double>(now() - a0).count() - (t_wait - w_before);
+                }
+                continue;
+            }
             if (lane.in_flight) apply_lane(lane);
             const auto a1 = now();
             if (collect_lane(lane)) any = true;

@@ -101,6 +101,7 @@ private:
         std::vector<int> slot_begin, slot_count, n_new, batch_ids;
         bool in_flight = false;
         bool gathered = false;             // the batch in flight returns gathered priors
+        bool same_trees_next = false;      // the next batch can keep this batch's trees and slots (no rotation, no tree finished)
     };
     bool tree_done(const Tree& t, uint32_t simulations, uint32_t nodes) const;
     void evaluate_roots(Lane& lane);

@@ -536,3 +536,33 @@ def test_gathered_priors_and_whole_vectors_give_the_same_trees(hip_lib, monkeypa
         results.append([(pool.root_children(t)[0], pool.root_children(t)[1], pool.root_children(t)[2].tolist(), pool.tree_info(t)) for t in ids])
         pool.close()
     assert results[0] == results[1] == results[2]
+
+
+@pytest.mark.parametrize("n_trees", [3, 7])
+def test_fused_lane_step_equals_two_step(hip_lib, monkeypatch, n_trees):
+    """A lane whose trees all fit into its batch finishes the batch in flight and collects the next one in a single fork/join
+    (every tree keeps its slots); with more trees than slots (7 trees, 2 lanes of 2 slots) the pool rotates and goes the long way.
+    Both, and the forced two-step order, must produce the same trees; trees finish at different times (different limits reached)."""
+    nbp, quota = NB_POLICY[0], 8
+    fens = ["", "r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] b KQkq - 0 8",
+            "4R2b/1N3rkb/1p2P1pp/p2P4/2P1P3/8/PP4Q1/3R3K[QRBBNNNPPPPpp] w - - 2 53", "r1b2rk1/pppp1Npp/8/8/8/8/PPPPPPPP/RNBQKB1R[Qq] w KQ - 0 1",
+            "", "r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] b KQkq - 0 8", ""]
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    results = []
+    for two_step in (False, True):
+        if two_step:
+            monkeypatch.setenv("CRA_POOL_TWO_STEP", "1")
+        else:
+            monkeypatch.delenv("CRA_POOL_TWO_STEP", raising=False)
+        st = search.default_settings(mode=0, version_major=1, is_policy_map=1, batch_size=quota)
+        pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=2 * quota, fn_nb_policy=nbp)
+        ids = [pool.add_position(f, False, "crazyhouse") for f in fens[:n_trees]]
+        pool.run(simulations=260, threads=3)
+        pool.run(simulations=90, threads=3)                                   # a second go on the kept trees
+        results.append([(pool.root_children(t)[0], pool.root_children(t)[1], pool.root_children(t)[2].tolist(), pool.tree_info(t)) for t in ids])
+        pool.close()
+    assert results[0] == results[1]

@@ -153,12 +153,24 @@ WorkerPool::~WorkerPool() {
 void WorkerPool::worker_loop(int index) {
     int seen = 0;
     while (true) {
+        // Idle policy by elapsed time (a `pause` is 10-60 ns depending on the core, so counting them is not a clock): spin for
+        // 0.8 ms -- longer than a forward, so within a run a worker never sleeps between the jobs of consecutive batches (a nap
+        // costs its wake-up latency on the next batch's critical path) --, then 50 us naps for 100 ms (between two runs of a game
+        // loop), then 2 ms naps (idle pool).
         int spins = 0;
+        auto idle_since = std::chrono::steady_clock::now();
+        int phase = 0;
         while (generation_.load(std::memory_order_acquire) == seen) {
             if (stop_.load(std::memory_order_acquire)) return;
-            if (++spins < 20000) __builtin_ia32_pause();                                       // ~100 us: between two jobs of a run
-            else if (spins < 22000) std::this_thread::sleep_for(std::chrono::microseconds(50));  // ~100 ms: between two runs of a game loop
-            else std::this_thread::sleep_for(std::chrono::milliseconds(2));                      // idle pool
+            if (phase == 0) {
+                __builtin_ia32_pause();
+                if ((++spins & 63) == 0 && std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(800)) phase = 1;
+            } else if (phase == 1) {
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+                if (std::chrono::steady_clock::now() - idle_since > std::chrono::milliseconds(100)) phase = 2;
+            } else {
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
         }
         seen = generation_.load(std::memory_order_acquire);
         run_items(index);

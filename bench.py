@@ -204,9 +204,10 @@ def main():
         fens = openings.position_fens("crazyhouse")
         for i in range(n_trees):
             pool.add_position(fens[(i * 7 + rank * 3) % len(fens)], False, "crazyhouse")
-        # one CPU is left to the thread that drives the lanes (the workers spin while a search runs)
+        # `threads` counts the driving thread (it takes its share of every fork/join); one tree of a lane per thread is the
+        # fastest split, so with 16 trees per lane anything below 16 makes one thread do two trees per batch
         cpus = replicas.available_cpus()
-        threads = max(1, min(args.search_threads, max(1, cpus // max(1, world) - 1)))
+        threads = max(1, min(args.search_threads, max(1, cpus // max(1, world))))
         # untimed warm-up (worker threads, allocator, clocks), then every tree restarts from its opening position
         tree_fens = [fens[(i * 7 + rank * 3) % len(fens)] for i in range(n_trees)]
         pool.run(simulations=min(200, args.simulations), threads=threads)

@@ -47,3 +47,13 @@ def test_single_rank_is_identity():
     local = replicas.ReplicaStats(units=42.0, seconds=2.0, extra=(1.0,))
     assert replicas.reduce_stats(local) == (42.0, 2.0, [1.0])
     assert replicas.throughput(local) == 21.0
+
+
+def test_host_cpu_probes():
+    """bench.py sizes the search pool by the CPUs the process may really use (affinity mask cut by a cgroup quota) and reports how long
+    the container was throttled during the search; both probes must degrade to sane values on any host."""
+    from crazyara_amd import replicas
+    n = replicas.available_cpus()
+    assert isinstance(n, int) and 1 <= n <= (os.cpu_count() or 1)
+    t = replicas.cgroup_throttled_usec()
+    assert t is None or (isinstance(t, int) and t >= 0)

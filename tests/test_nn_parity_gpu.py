@@ -1,10 +1,13 @@
 """GPU parity of the HIP NN path (through the C ABI) against the oracle and the committed reference goldens.
 
 Tolerances (BASELINE.json north_star: "value/policy logits within 1e-3 fp32"):
-  Precision float32 (exact-f32 MFMA): |logit| err < 1e-4, |value| err < 1e-4, |prob| err < 1e-6
+  Precision float32 (exact-f32 MFMA): |logit| err < 1e-4, |value| err < 1e-4, |prob| err < 1e-6 (measured on an MI355X:
+      5.0e-6 / 4.9e-7 / 1.2e-8, profiles/r02/a_error_scan.txt) -- THE mode that satisfies north_star's 1e-3 on the logits.
   Precision float16 (f16 MFMA operands, f32 accumulate -- the reference TensorRT default): predict() outputs
-      |value| err < 1e-3, |prob| err < 1e-3 (measured ~1e-5); logits < 6e-3 (f16 operand rounding, predicted by the
-      oracle's sim_dtype=float16 mode at ~2e-3 for |logit| ~ 1.4).
+      |value| err < 1e-3 (measured <= 6.9e-4), |prob| err < 1e-5 (measured <= 3.1e-6).  The LOGITS do not meet 1e-3 with f16
+      operands: rounding the weights alone to f16 moves them by 1.6e-3 (scripts/error_budget.py, profiles/r02/a_error_budget.txt),
+      the whole path measures 1.07e-3 ... 1.73e-3 x max|logit| over the cases of this file (worst: the 256-board headline test,
+      3.31e-3 at max|logit| 1.91).  The bound here is 1.25 x that: 2.2e-3 x max|logit| of the case, never above 4.8e-3.
 """
 import os
 
@@ -17,8 +20,17 @@ from oracle import rise_oracle as ro
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"float32": dict(logit=1e-4, value=1e-4, prob=1e-6, aux=1e-4),
-       "float16": dict(logit=6e-3, value=1e-3, prob=1e-3, aux=5e-3)}
+TOL = {"float32": dict(logit=1e-4, logit_rel=None, value=1e-4, prob=1e-6, aux=1e-4),
+       "float16": dict(logit=4.8e-3, logit_rel=2.2e-3, value=1e-3, prob=1e-5, aux=1e-3)}
+
+
+def logit_tol(tol, ref_logits):
+    """absolute bound on the logit error of one case: the mode's cap, scaled down by the size of the case's logits"""
+    if tol["logit_rel"] is None:
+        return tol["logit"]
+    return min(tol["logit"], max(2e-4, tol["logit_rel"] * float(np.abs(np.asarray(ref_logits)).max())))
+
+
 # float16 runs the residual-tower kernel (runs of 3x3 blocks in one launch); "-perblock" = one fused launch per bottleneck
 # block, "-unfused" = layer-granular kernels (conv GEMM / depthwise / project as separate launches): three implementations
 TOL["float32-unfused"] = TOL["float32"]
@@ -57,7 +69,7 @@ def test_predict_matches_oracle_and_golden(tmp_path, hip_lib, name, precision):
     g = np.load(os.path.join(nn_cases.GOLDEN_DIR, f"nn_{name}.npz"))
     for ref_v, ref_l in ((o_value.numpy().reshape(-1), o_logits.numpy()), (g["value"].reshape(-1), g["logits"])):
         assert np.abs(value - ref_v).max() < tol["value"]
-        assert np.abs(logits - ref_l).max() < tol["logit"]
+        assert np.abs(logits - ref_l).max() < logit_tol(tol, ref_l)
     assert np.abs(probs - o_probs).max() < tol["prob"]
     assert np.allclose(probs.sum(axis=1), 1.0, atol=1e-4)
     if cfg.nb_aux:
@@ -73,7 +85,7 @@ def test_dense_tower_kernel_shapes(tmp_path, hip_lib, name, variant):
     tol = TOL["float16"]
     g = np.load(os.path.join(nn_cases.GOLDEN_DIR, f"nn_{name}.npz"))
     assert np.abs(value - g["value"].reshape(-1)).max() < tol["value"]
-    assert np.abs(logits - g["logits"]).max() < tol["logit"]
+    assert np.abs(logits - g["logits"]).max() < logit_tol(tol, g["logits"])
 
 
 @pytest.mark.parametrize("case", ["risev2-7", "alphazero-3-cv8"])
@@ -250,7 +262,7 @@ def test_onnx_model_directory_loads_and_matches_golden(tmp_path, hip_lib, name, 
         net.close()
         tol = TOL[precision]
         assert np.abs(value - g["value"].reshape(-1)).max() < tol["value"]
-        assert np.abs(logits - g["logits"]).max() < tol["logit"]
+        assert np.abs(logits - g["logits"]).max() < logit_tol(tol, g["logits"])
         if cfg.nb_aux:
             assert np.abs(aux.reshape(-1, 4) - g["aux"]).max() < tol["aux"]
         if precision == "float16":
@@ -285,8 +297,9 @@ def test_headline_configuration_at_full_size(tmp_path, hip_lib):
     g = np.load(os.path.join(nn_cases.GOLDEN_DIR, "nn_risev2-19.npz"))
     tol = TOL["float16"]
     assert np.abs(v[:4] - g["value"].reshape(-1)).max() < tol["value"]
-    assert np.abs(logits[:4] - g["logits"]).max() < tol["logit"]
+    assert np.abs(logits[:4] - g["logits"]).max() < logit_tol(tol, g["logits"])
     o_value, o_logits, _ = ro.forward(cfg, sd, torch.from_numpy(x))
+    assert np.abs(logits - o_logits.numpy()).max() < logit_tol(tol, o_logits.numpy())     # measured 3.31e-3 (bound 4.2e-3)
     assert np.abs(v - o_value.numpy().reshape(-1)).max() < tol["value"]
     assert np.abs(p - torch.softmax(o_logits, 1).numpy()).max() < tol["prob"]
     assert np.allclose(p.sum(axis=1), 1.0, atol=1e-4) and (p >= 0).all() and np.abs(v).max() <= 1.0
@@ -332,4 +345,4 @@ def test_other_trunk_widths_run_on_the_layer_kernels(tmp_path, hip_lib, channels
     # float16 here = f16 storage after every layer (no fused tower): the oracle's own f16 emulation (sim_dtype) moves these values by
     # up to 0.5e-3, the worst board measured 1.2e-3 -> 2e-3; the float32 precision mode holds the 1e-4 of the other tests
     assert np.abs(v - o_value.numpy().reshape(-1)).max() < (2e-3 if precision == "float16" else tol["value"])
-    assert np.abs(logits - o_logits.numpy()).max() < tol["logit"]
+    assert np.abs(logits - o_logits.numpy()).max() < logit_tol(tol, o_logits.numpy())

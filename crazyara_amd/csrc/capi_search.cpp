@@ -211,8 +211,21 @@ int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, floa
         if (b < 0) { n = 0; return; }
         if (int(pol.size()) > cap) throw std::invalid_argument("policy buffer too small");
         if (policy) std::copy(pol.begin(), pol.end(), policy);
-        if (best_move_q) *best_move_q = t.root().q[b];
+        if (best_move_q) *best_move_q = t.eval_best_move_q();
         n = int(pol.size());
+    });
+    return n;
+}
+
+long mi_search_tree_dump(mi_search* sp, int tree, uint32_t* out, long cap) {
+    long n = -1;
+    if (!sp) { cra_set_error("null search"); return n; }
+    cra_guard([&] {
+        std::vector<uint32_t> words;
+        sp->pool->tree(tree).dump(words);
+        if (long(words.size()) > cap) throw std::invalid_argument("tree dump buffer too small");
+        if (out) std::copy(words.begin(), words.end(), out);
+        n = long(words.size());
     });
     return n;
 }

@@ -33,11 +33,21 @@ void NetFile::load(const std::string& path) {
             std::string name;
             int nd = 0;
             ls >> name >> nd;
+            if (!ls || nd < 0 || nd > 8) throw std::runtime_error("bad tensor record in " + path + ": " + line);
             TensorView tv;
-            for (int i = 0; i < nd; ++i) { int64_t d; ls >> d; tv.shape.push_back(d); }
+            uint64_t numel = 1;
+            for (int i = 0; i < nd; ++i) {
+                int64_t d = -1;
+                ls >> d;
+                if (!ls || d < 0 || d > (int64_t(1) << 31)) throw std::runtime_error("bad dimension of tensor " + name + " in " + path);
+                tv.shape.push_back(d);
+                numel *= uint64_t(d);
+                if (numel > (uint64_t(1) << 34)) throw std::runtime_error("tensor " + name + " is implausibly large in " + path);
+            }
             uint64_t off = 0;
             ls >> off;
-            if (off + uint64_t(tv.numel()) * 4 > blob.size())
+            // no wrap-around: compare against what is left behind the offset
+            if (!ls || off % 4 != 0 || off > blob.size() || numel * 4 > blob.size() - off)
                 throw std::runtime_error("tensor " + name + " exceeds blob in " + path);
             tv.data = reinterpret_cast<const float*>(blob.data() + off);
             tensors[name] = tv;

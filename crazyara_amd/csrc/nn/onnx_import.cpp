@@ -392,7 +392,9 @@ void Importer::index() {
         }
         if (views.count(n.op)) {
             if (n.in.empty()) fail(n.label() + " has no input");
-            alias_[n.out[0]] = resolve(n.in[0]);
+            const std::string target = resolve(n.in[0]);
+            if (target == n.out[0]) fail(n.label() + " aliases its own output");     // a damaged file: resolve() would never end
+            alias_[n.out[0]] = target;
             continue;
         }
         for (const std::string& i : n.in) {

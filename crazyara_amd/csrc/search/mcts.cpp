@@ -1,5 +1,7 @@
 #include "mcts.h"
 
+#include <cstring>
+
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -357,10 +359,12 @@ uint32_t Tree::next_rand() {
     return (rng_ >> 16) & 0x7fffu;
 }
 
-// get_random_depth (searchthread.cpp:497-501): ceil(-log2(1 - r/100) - 1), r uniform in 1..100 (r = 100: "infinitely deep")
+// get_random_depth (searchthread.cpp:497-501): ceil(-log2(1 - r/100) - 1), r uniform in 1..100.  r = 100 makes that +infinity, and
+// the reference converts it to size_t -- undefined behaviour; the x86-64 code GCC emits for the conversion yields 0 (measured on the
+// reference's own function, oracle/_ref), i.e. the playout starts at the root, and that is what is restated here
 size_t Tree::get_random_depth() {
     const int r = int(next_rand() % 100u) + 1;
-    if (r == 100) return size_t(1) << 20;
+    if (r == 100) return 0;
     return size_t(std::ceil(-std::log2(1 - r / 100.0) - 1));
 }
 
@@ -534,6 +538,12 @@ int Tree::best_move_index(std::vector<double>* policy_out) const {
     auto normalise = [&]() {
         double sum = 0;
         for (double v : pol) sum += v;
+        if (sum == 0) {
+            // every visited child is a proven win for the opponent while unvisited ones remain: the reference divides 0 / 0 here
+            // (node.cpp:1107) and plays index 0 off a NaN policy; fall back to the plain visit counts instead
+            for (int i = 0; i < m; ++i) { pol[i] = n.child_visits[i]; sum += pol[i]; }
+            if (sum == 0) { pol.assign(size_t(m), 1.0 / m); sum = 1.0; }
+        }
         int best = 0;
         for (int i = 0; i < m; ++i) {
             pol[i] /= sum;
@@ -581,6 +591,77 @@ int Tree::best_move_index(std::vector<double>* policy_out) const {
         }
     }
     return normalise();
+}
+
+void Tree::handle_single_move() {                               // mctsagent.cpp:277-290
+    Node& r = nodes_[0];
+    float target = last_value_eval_;
+    if (last_stm_ != r.stm) target = -last_value_eval_;
+    r.set_value(target);
+    if (r.has_data && !r.q.empty()) r.q[0] = target;
+}
+
+float Tree::eval_best_move_q() const {
+    const Node& r = nodes_[0];
+    if (r.actions.size() == 1 && r.visit_sum == 0) {            // evalinfo.cpp:218-224: single move, blank root -> get_value_display
+        if (r.has_data && r.node_type == NT_WIN) return WIN_VALUE;
+        if (r.has_data && r.node_type == NT_LOSS) return LOSS_VALUE;
+        if (r.has_data && r.node_type == NT_DRAW) return DRAW_VALUE;
+        return r.real_visits ? r.value() : Q_INIT;
+    }
+    return best_move_q(best_move_index());
+}
+
+void Tree::end_search() {                                       // tail of evaluate_board_state (mctsagent.cpp:337-339) over update_eval_info
+    const Node& r = nodes_[0];
+    if (r.terminal || r.actions.empty()) return;
+    last_value_eval_ = eval_best_move_q();
+    last_stm_ = r.stm;
+}
+
+float Tree::best_move_q(int b) const {
+    const Node& r = nodes_[0];
+    if (b < 0 || !r.has_data || b >= int(r.child.size()) || r.child[b] < 0) return Q_INIT;
+    const Node& c = nodes_[r.child[b]];
+    if (c.has_data) {                                           // Node::get_value_display (node.cpp:600-612)
+        if (c.node_type == NT_WIN) return -float(WIN_VALUE);
+        if (c.node_type == NT_LOSS) return -float(LOSS_VALUE);
+        if (c.node_type == NT_DRAW) return -float(DRAW_VALUE);
+    }
+    return -c.value();
+}
+
+void Tree::dump(std::vector<uint32_t>& out) const {
+    auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    std::vector<int32_t> stack{0};
+    if (!nodes_[0].has_data) return;
+    std::vector<int32_t> follow;
+    while (!stack.empty()) {
+        const Node& n = nodes_[stack.back()];
+        stack.pop_back();
+        const int m = n.terminal ? 0 : int(n.no_visit_idx);
+        out.push_back(uint32_t(m));
+        out.push_back(n.visit_sum);
+        out.push_back(n.real_visits);
+        out.push_back(n.free_visits);
+        out.push_back(uint32_t(n.node_type));
+        out.push_back(uint32_t(n.end_in_ply));
+        out.push_back(n.terminal ? 1u : 0u);
+        out.push_back(fbits(n.real_visits ? n.value() : 0.0f));
+        follow.clear();
+        for (int i = 0; i < m; ++i) {
+            out.push_back(n.actions[i]);
+            out.push_back(n.child_visits[i]);
+            out.push_back(n.vl[i]);
+            out.push_back(fbits(n.q[i]));
+            out.push_back(fbits(n.priors[i]));
+            const int32_t c = n.child[i];
+            const uint32_t st = c < 0 ? 0u : nodes_[c].has_data ? 2u : 1u;
+            out.push_back(st);
+            if (st == 2u) follow.push_back(c);
+        }
+        for (auto it = follow.rbegin(); it != follow.rend(); ++it) stack.push_back(*it);   // preorder: first child's record next
+    }
 }
 
 }  // namespace search

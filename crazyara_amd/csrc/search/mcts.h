@@ -115,6 +115,12 @@ public:
     // the subtree below that move becomes the tree if the child is a playout node with visits, otherwise the tree restarts
     // from the new position.  Returns true when the subtree was kept.  The move must be legal in the root position.
     bool apply_move(chess::Move m);
+    // MCTSAgent::evaluate_board_state around the search proper (mctsagent.cpp:292-342): a root with ONE legal move is not searched
+    // ("Only single move available -> early stopping"): handle_single_move (:277-290) gives it the value of the previous search
+    // (lastValueEval, from the side that is now to move) instead; end_search records lastValueEval = bestMoveQ[0] and the side.
+    bool single_move_root() const { return nodes_[0].actions.size() == 1 && !nodes_[0].terminal; }
+    void handle_single_move();
+    void end_search();
     // replace the search settings for the following searches (quick-search switches of self-play, selfplay.cpp:217-222)
     void set_search_settings(const SearchSettings& s) { s_ = s; }
 
@@ -138,10 +144,22 @@ public:
     uint32_t node_count() const { return nodes_[0].visit_sum - nodes_[0].free_visits; }   // Node::get_node_count, node.cpp:1303-1306
     const chess::Position& root_position() const { return root_pos_; }
     int pending_new() const { return int(new_nodes_.size()); }
+    int pending_collisions() const { return int(collision_trajectories_.size()); }
     // Node::get_mcts_policy + argmax (node.cpp:1070-1109): best child index of the root and the visit policy
     int best_move_index(std::vector<double>* policy = nullptr) const;
+    // EvalInfo::bestMoveQ of root child b (set_eval_for_single_pv + get_best_move_q, evalinfo.cpp:110-182): the negated value of
+    // the CHILD NODE (its proven result if solved, else valueSum / realVisits) -- not the edge's Q; Q_INIT without a child node
+    float best_move_q(int b) const;
+    // EvalInfo::bestMoveQ[0] as update_eval_info leaves it (evalinfo.cpp:184-243): best_move_q of the chosen child, or the root's own
+    // value for a single-move root that was not searched
+    float eval_best_move_q() const;
     uint64_t depth_sum = 0;
     uint32_t depth_max = 0;
+    // Whole tree as a flat word list (inspection / parity tests; the reference's counterpart is MCTSAgent::export_search_tree,
+    // mctsagent.cpp:420-448): depth-first preorder over the expanded children, one record per node that owns NodeData:
+    // [n_expanded, visit_sum, real_visits, free_visits, node_type, end_in_ply, terminal, bits(value)] then per expanded child
+    // [move, visits, virtual-loss counter, bits(Q), bits(prior), state 0 no node / 1 node without data / 2 record follows]
+    void dump(std::vector<uint32_t>& out) const;
 
     // exposed for the arithmetic parity tests
     int select_child(Node& n);
@@ -183,6 +201,8 @@ private:
     std::vector<float> sort_priors_;
     std::vector<float> select_buf_;
     uint32_t rng_ = 1;
+    float last_value_eval_ = -1.0f;            // MCTSAgent::lastValueEval (mctsagent.cpp:47), reset with the game (clear_game_history)
+    uint8_t last_stm_ = 0;                     // MCTSAgent::lastSideToMove
     std::minstd_rand0 noise_rng_;              // std::default_random_engine of libstdc++ (randomgen.h:35)
 };
 

@@ -267,6 +267,7 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     WorkerPool& workers = *workers_;
     SearchStats st;
     std::vector<uint32_t> nodes_pre(trees_.size()), visits_pre(trees_.size());
+    std::vector<uint64_t> depth_pre(trees_.size());
     const auto t0 = std::chrono::steady_clock::now();
     for (Lane& lane : lanes_) {
         size_t before = 0;
@@ -275,19 +276,29 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         st.nn_evals += before;
         st.batches += (before + lane.eval->batch_size() - 1) / lane.eval->batch_size();
     }
+    std::vector<char> single_move(trees_.size(), 0);
     for (size_t i = 0; i < trees_.size(); ++i) {
-        if (!is_paused(int(i))) trees_[i]->begin_search();          // Dirichlet noise + full expansion of the root (RL settings)
+        if (!is_paused(int(i))) {
+            if (trees_[i]->single_move_root()) {                    // "Only single move available -> early stopping", mctsagent.cpp:303-307
+                trees_[i]->handle_single_move();
+                single_move[i] = 1;
+            } else {
+                trees_[i]->begin_search();                          // Dirichlet noise + full expansion of the root (RL settings)
+            }
+        }
         nodes_pre[i] = trees_[i]->node_count();
         visits_pre[i] = trees_[i]->root_visits();
+        depth_pre[i] = trees_[i]->depth_sum;
+        trees_[i]->depth_max = 0;                                   // reset_stats() at the start of a go (searchthread.cpp:283-288)
     }
-    // simulations/nodes limits are per `go`: measured from the pre-search counters (tree reuse keeps old visits)
+    // simulations / nodes limits are ABSOLUTE on the root's counters, as SearchThread::nodes_limits_ok has them
+    // (searchthread.cpp:326-331: rootNode->get_visits() < simulations, get_node_count() < nodes): visits inherited through tree
+    // reuse count towards the limit of the next go
     auto done = [&](int id) {
-        if (is_paused(id)) return true;
+        if (is_paused(id) || single_move[id]) return true;
         const Tree& t = *trees_[id];
         if (t.root().terminal || t.root_solved()) return true;      // is_root_node_unsolved(), searchthread.cpp:333-340
-        if (simulations && t.root_visits() - visits_pre[id] >= simulations) return true;
-        if (nodes && t.node_count() - nodes_pre[id] >= nodes) return true;
-        return false;
+        return tree_done(t, simulations, nodes);
     };
 
     double t_par = 0, t_submit = 0, t_item_max = 0, t_item_sum = 0, t_wait = 0;
@@ -438,6 +449,21 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     double t_apply = 0, t_collect = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     bool any = true;
+    // A failure in the middle of a run (evaluator callback, device error, allocation) must not leave half-applied batches behind:
+    // every lane is drained, and a tree that still holds leaves without results or unreverted virtual losses restarts from its
+    // root position -- its statistics would be wrong otherwise, and Tree::apply_move would refuse it from then on.
+    auto recover = [&]() {
+        for (Lane& lane : lanes_) {
+            if (lane.in_flight) {
+                try { lane.eval->wait(); } catch (...) {}
+                lane.in_flight = false;
+            }
+            lane.same_trees_next = false;
+        }
+        for (size_t i = 0; i < trees_.size(); ++i)
+            if (trees_[i]->pending_new() > 0 || trees_[i]->pending_collisions() > 0) reset_position(int(i), trees_[i]->root_position());
+    };
+    try {
     while (any) {
         any = false;
         for (Lane& lane : lanes_) {
@@ -465,12 +491,18 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
                         (unsigned long long)st.batches);
     for (Lane& lane : lanes_)
         if (lane.in_flight) apply_lane(lane);
+    } catch (...) {
+        recover();
+        throw;
+    }
+    for (size_t i = 0; i < trees_.size(); ++i)
+        if (!is_paused(int(i))) trees_[i]->end_search();
     st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     uint64_t dsum = 0;
     for (size_t i = 0; i < trees_.size(); ++i) {
         st.nodes += trees_[i]->node_count() - nodes_pre[i];
         st.simulations += trees_[i]->root_visits() - visits_pre[i];
-        dsum += trees_[i]->depth_sum;
+        dsum += trees_[i]->depth_sum - depth_pre[i];
         st.depth_max = std::max(st.depth_max, trees_[i]->depth_max);
     }
     st.depth_avg = st.simulations ? double(dsum) / double(st.simulations) : 0.0;

@@ -105,6 +105,15 @@ class SearchPool:
             raise RuntimeError(_capi.last_error())
         return np.array(buf[:n], np.float64), float(q.value)
 
+    def tree_dump(self, tree: int) -> np.ndarray:
+        """The whole tree as the flat word list of mi_search_tree_dump (depth-first records of every selected node)."""
+        cap = 1 << 22
+        buf = (C.c_uint32 * cap)()
+        n = self._lib.mi_search_tree_dump(self._h, tree, buf, cap)
+        if n < 0:
+            raise RuntimeError(_capi.last_error())
+        return np.ctypeslib.as_array(buf)[:n].copy()
+
     def set_active(self, tree: int, active: bool) -> None:
         if self._lib.mi_search_set_active(self._h, tree, int(active)):
             raise ValueError(_capi.last_error())

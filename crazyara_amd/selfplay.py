@@ -84,17 +84,26 @@ def apply_temperature(p: np.ndarray, t: float) -> np.ndarray:
     return q / q.sum()
 
 
-def apply_quantile_clipping(quantile: float, p: np.ndarray) -> np.ndarray:
-    """agent.cpp:121-130 with get_quantile (blazeutil.h): entries below the quantile's value are zeroed, then renormalised."""
-    order = np.sort(p)
-    acc, thresh = 0.0, 0.0
-    for v in order:
-        acc += v
+def get_quantile(p: np.ndarray, quantile: float) -> float:
+    """get_quantile (blazeutil.h:188-212), literally: sort ascending; 0 if the smallest entry already reaches the quantile; else
+    accumulate (in float32) from the SECOND smallest entry and return the entry BEFORE the one that crosses the quantile, plus
+    FLT_EPSILON.  Checked against the compiled reference function in tests/test_mcts_reference_build.py."""
+    order = np.sort(np.asarray(p, np.float64))
+    if order[0] >= quantile:
+        return 0.0
+    acc = np.float32(0.0)
+    for idx in range(1, len(order)):
+        acc = np.float32(np.float64(acc) + order[idx])
         if acc >= quantile:
-            thresh = v
-            break
+            return float(order[idx - 1] + np.finfo(np.float32).eps)
+    return -1.0       # quantile above the mass behind the smallest entry: the reference asserts(false), release builds return -1 (nothing clipped)
+
+
+def apply_quantile_clipping(quantile: float, p: np.ndarray) -> np.ndarray:
+    """agent.cpp:121-130: entries below get_quantile's threshold are zeroed, then renormalised."""
+    thresh = get_quantile(p, quantile)
     q = np.where(p < thresh, 0.0, p)
-    return q / q.sum()
+    return q / np.cumsum(q)[-1]                 # sequential double sum, as the reference's loop adds it
 
 
 class _Game:
@@ -162,6 +171,7 @@ class SelfPlay:
                 pos = nxt
             rec.book_plies = len(rec.uci)
         self.pool.reset_position(slot, rec.start_fen, s.is960, s.variant)
+        self.pool.set_active(slot, True)
         for u in rec.uci:
             self.pool.apply_move(slot, u)
         allow_resign = s.resign_probability >= 0.01 and rng.random() < s.resign_probability
@@ -195,6 +205,9 @@ class SelfPlay:
         self.finished.append(g.record)
         g.pos.close()
         self.games[g.slot] = None
+        # the slot's tree sits out the following pool.run calls until a new game takes it (otherwise a finished game's tree would be
+        # searched to the full budget every round and its visits counted as nodes)
+        self.pool.set_active(g.slot, False)
 
     def play(self, n_games: int, threads: int = 16) -> List[GameRecord]:
         s = self.s

@@ -221,6 +221,12 @@ int mi_search_best_move(mi_search* sp, int tree, char* uci, int cap);
 /* the whole Node::get_mcts_policy vector of the root (EvalInfo::policyProbSmall, one entry per expanded child in the order of
  * mi_search_root_children) and the Q value of the best move (EvalInfo::bestMoveQ); returns the number of entries or -1 */
 int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, float* best_move_q);
+/* the whole tree as a flat word list, for inspection and the parity tests (the reference's counterpart: MCTSAgent::export_search_tree,
+ * mctsagent.cpp:420-448): depth-first preorder over the expanded children, one record per node that was selected at least once:
+ * [n_expanded, visit_sum, real_visits, free_visits, node_type, end_in_ply, terminal, float bits of value], then per expanded child
+ * [move, visits, virtual-loss counter, float bits of Q, float bits of prior, state: 0 no node / 1 evaluated, never selected /
+ * 2 its record follows].  Returns the number of 32-bit words written, -1 on error (buffer too small). */
+long mi_search_tree_dump(mi_search* sp, int tree, uint32_t* out, long cap);
 /* active = 0: the tree sits out the following mi_search_run calls and keeps its state (the player that is not to move in an
  * arena game, generate_arena_game, selfplay.cpp:267-308); trees start active */
 int mi_search_set_active(mi_search* sp, int tree, int active);

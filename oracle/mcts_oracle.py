@@ -370,7 +370,7 @@ class Tree:
         """searchthread.cpp:497-501: ceil(-log2(1 - r/100) - 1), r uniform in 1..100."""
         r = self.next_rand() % 100 + 1
         if r == 100:
-            return 1 << 20
+            return 0          # size_t(+inf) in the reference: undefined behaviour, 0 with the x86-64 code GCC emits (checked on oracle/_ref)
         return int(math.ceil(-math.log2(1 - r / 100.0) - 1))
 
     def get_starting_node(self, cur, board):
@@ -550,9 +550,14 @@ def run_search(tree: Tree, evaluate, simulations, quota):
     if not tree.root.has_nn and not tree.root.terminal:
         v, p = evaluate([tree.root_board])
         tree.set_root_result(v[0], p[0])
+    if len(tree.root.moves) == 1 and not tree.root.terminal:
+        # MCTSAgent::evaluate_board_state (mctsagent.cpp:303-307): "Only single move available -> early stopping" -- no search.
+        # handle_single_move's value hand-over from the previous search is agent state the tests of this oracle do not reach;
+        # the reference build (oracle/_ref, tests/test_mcts_reference_build.py) covers it.
+        return
     tree.begin_search()
-    pre = tree.root.visit_sum
-    while not tree.root.terminal and tree.root.node_type == NT_UNSOLVED and tree.root.visit_sum - pre < simulations:
+    # nodes_limits_ok (searchthread.cpp:326-331): the limit is absolute on the root's visit counter (reused visits count)
+    while not tree.root.terminal and tree.root.node_type == NT_UNSOLVED and tree.root.visit_sum < simulations:
         boards = tree.collect(quota)
         if boards:
             v, p = evaluate(boards)

@@ -1,0 +1,111 @@
+"""oracle/_ref: the REFERENCE'S OWN search code, compiled from the sources where they lie under /root/reference.
+
+Test infrastructure only (never imported by the product).  Recipe, not sources: nothing from the reference is copied into this
+repository; the outputs go to oracle/_ref/ (git-ignored, shipped to the GPU box with the other built files).
+
+What is compiled (engine/src, unmodified):
+    node.cpp (through node_tu.cpp), nodedata.cpp, searchthread.cpp, evalinfo.cpp, state.cpp, stateobj.cpp,
+    util/{blazeutil,communication,randomgen}.cpp, agents/{agent,mctsagent}.cpp, agents/util/gcthread.cpp,
+    agents/config/{searchsettings,searchlimits,playsettings}.cpp, manager/{threadmanager,timemanager,treemanager}.cpp,
+    nn/{neuralnetapi,neuralnetapiuser,neuralnetdesign}.cpp
+against
+    shim/blaze/Math.h       stand-in for the absent blaze submodule (natural-order element-wise semantics, see its header)
+    shim/pommermanstate.h   the reference's MODE_POMMERMAN hook (stateobj.h:39-40,53-55) filled with a State over this repository's
+                            chess Position (the reference's own BoardState needs the absent Stockfish fork)
+    ref_driver.cpp          extern "C" entry points for the tests
+
+The reference's build system is not run.  `python oracle/ref/build_ref.py` rebuilds; build() returns the library path, or None when
+/root/reference is absent and no prebuilt library exists (the GPU box uses the prebuilt file).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("CRA_REFERENCE_ROOT", "/root/reference")
+SRC = os.path.join(REF, "engine", "src")
+OUT = os.path.join(os.path.dirname(HERE), "_ref")
+LIB = os.path.join(OUT, "libcrazyara_ref.so")
+
+REFERENCE_SOURCES = [
+    "nodedata.cpp", "searchthread.cpp", "evalinfo.cpp", "state.cpp", "stateobj.cpp",
+    "util/blazeutil.cpp", "util/communication.cpp", "util/randomgen.cpp",
+    "agents/agent.cpp", "agents/mctsagent.cpp", "agents/util/gcthread.cpp",
+    "agents/config/searchsettings.cpp", "agents/config/searchlimits.cpp", "agents/config/playsettings.cpp",
+    "manager/threadmanager.cpp", "manager/timemanager.cpp", "manager/treemanager.cpp",
+    "nn/neuralnetapi.cpp", "nn/neuralnetapiuser.cpp", "nn/neuralnetdesign.cpp",
+]
+SHIM_SOURCES = ["node_tu.cpp", "ref_driver.cpp"]                      # node_tu.cpp = #include "node.cpp" + a seeding hook
+PRODUCT_ENV_SOURCES = ["chess/position.cpp", "chess/policy.cpp", "chess/planes_host.cpp"]   # the environment behind the State adapter
+
+FLAGS = ["-std=c++17", "-O2", "-fPIC", "-DMODE_POMMERMAN", "-DDISABLE_UCI_INFO", "-w"]
+
+
+def reference_present() -> bool:
+    return os.path.isfile(os.path.join(SRC, "node.cpp"))
+
+
+def _inputs():
+    files = [os.path.join(SRC, s) for s in REFERENCE_SOURCES] + [os.path.join(SRC, "node.cpp"), os.path.join(SRC, "node.h")]
+    files += [os.path.join(HERE, s) for s in SHIM_SOURCES] + [os.path.join(HERE, "shim", "pommermanstate.h"),
+                                                              os.path.join(HERE, "shim", "blaze", "Math.h"), __file__]
+    files += [os.path.join(ROOT, "crazyara_amd", "csrc", s) for s in PRODUCT_ENV_SOURCES]
+    files += [os.path.join(ROOT, "crazyara_amd", "csrc", "chess", h) for h in ("position.h", "policy.h", "planes.h", "planes_host.h")]
+    files.append(os.path.join(ROOT, "include", "crazyara_hip.h"))
+    return files
+
+
+def _stamp() -> str:
+    h = hashlib.sha256()
+    for f in _inputs():
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False):
+    if not reference_present():
+        return LIB if os.path.exists(LIB) else None
+    os.makedirs(OUT, exist_ok=True)
+    stamp_file = LIB + ".stamp"
+    stamp = _stamp()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return LIB
+    gxx = shutil.which("g++")
+    if gxx is None:
+        raise RuntimeError("g++ not found")
+    inc = ["-I", os.path.join(HERE, "shim"), "-I", SRC, "-I", os.path.join(SRC, "nn"), "-I", os.path.join(SRC, "agents"),
+           "-I", os.path.join(ROOT, "crazyara_amd", "csrc")]
+    objdir = os.path.join(OUT, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for base, names in ((SRC, REFERENCE_SOURCES), (HERE, SHIM_SOURCES), (os.path.join(ROOT, "crazyara_amd", "csrc"), PRODUCT_ENV_SOURCES)):
+        for n in names:
+            obj = os.path.join(objdir, n.replace("/", "_") + ".o")
+            cmd = [gxx] + FLAGS + inc + ["-c", os.path.join(base, n), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((n, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    objs = []
+    for n, obj, p in jobs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"g++ failed on {n}:\n{out}")
+        objs.append(obj)
+    # -Bsymbolic: the rand() / srand() of ref_driver.cpp bind the reference's calls inside this library (seeded exploration)
+    r = subprocess.run([gxx, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB] + objs + ["-lpthread"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout)
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -129,7 +129,7 @@ def test_oracle_solver_worked_examples():
 SOLVER_CASES = [
     # variant, fen, mode, expected root verdict (node_type, end_in_ply) or None, expected best move or None
     ("chess", "6k1/5ppp/8/8/8/8/8/R3K3 w - - 0 1", 1, (mo.NT_WIN, 1), "a1a8"),          # back-rank mate in 1
-    ("chess", "7k/8/6K1/8/8/8/8/Q7 b - - 0 1", 1, (mo.NT_LOSS, None), "h8g8"),          # only move, every reply line mates
+    ("antichess", "8/8/8/8/8/4p3/5P1q/8 b - - 0 1", 2, (mo.NT_LOSS, 1), None),           # both (forced) captures take White's last piece: White wins
     ("chess", "k7/8/1K6/8/8/8/8/7R w - - 0 1", 1, (mo.NT_WIN, 1), "h1h8"),
     ("crazyhouse", "4R2b/1N3rkb/1p2P1pp/p2P4/2P1P3/8/PP4Q1/3R3K[QRBBNNNPPPPpp] w - - 2 53", 0, None, None),
     ("crazyhouse", "r1b2rk1/pppp1Npp/8/8/8/8/PPPPPPPP/RNBQKB1R[Qq] w KQ - 0 1", 0, None, None),
@@ -169,7 +169,7 @@ def test_mcts_solver_equals_oracle(hip_lib, variant, fen, mode, verdict, best):
         if verdict[1] is not None:
             assert solved["end_in_ply"] == verdict[1]
         assert info["root_visits"] < sims + quota                        # a proven root ends the search early
-        assert pool.best_move(t) == best
+        assert best is None or pool.best_move(t) == best
     # solver off: same positions keep searching to the limit
     st0 = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota, mcts_solver=0)
     pool0 = search.SearchPool(st0, eval_fn=eval_descs, fn_batch=quota, fn_nb_policy=nbp)
@@ -360,7 +360,9 @@ def test_pool_many_trees_two_lanes_matches_single_tree_runs(hip_lib):
     # single lane in callback mode, so 4 trees share 16 slots -> quota 4
     stats = pool.run(simulations=120, threads=3)
     pooled = [pool.root_children(i) for i in range(4)]
-    assert stats.simulations >= 4 * 120
+    # the last position has a single legal move: "Only single move available -> early stopping" (mctsagent.cpp:303-307), not searched
+    assert [len(p[0]) > 0 and sum(p[1]) >= 120 for p in pooled] == [True, True, True, False] and sum(pooled[3][1]) == 0
+    assert stats.simulations >= 3 * 120
     for i, f in enumerate(fens):
         solo = search.SearchPool(st, eval_fn=eval_descs, fn_batch=4, fn_nb_policy=nbp)
         solo.add_position(f, False, "crazyhouse")
@@ -566,3 +568,34 @@ def test_fused_lane_step_equals_two_step(hip_lib, monkeypatch, n_trees):
         results.append([(pool.root_children(t)[0], pool.root_children(t)[1], pool.root_children(t)[2].tolist(), pool.tree_info(t)) for t in ids])
         pool.close()
     assert results[0] == results[1]
+
+
+def test_run_survives_a_failing_evaluator(hip_lib, capsys):
+    """A failure in the middle of mi_search_run (here: the evaluator callback) leaves no half-applied batch behind: the call
+    reports the error, the tree restarts from its position, later searches and moves work and equal a fresh tree's."""
+    nbp, calls = NB_POLICY[0], [0]
+
+    def flaky(descs):
+        calls[0] += 1
+        if calls[0] == 5:
+            raise ValueError("boom")
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    st = search.default_settings(mode=0, version_major=1, batch_size=8)
+    pool = search.SearchPool(st, eval_fn=flaky, fn_batch=8, fn_nb_policy=nbp)
+    t = pool.add_position("", False, "crazyhouse")
+    with pytest.raises(RuntimeError):
+        pool.run(simulations=200, threads=1)
+    capsys.readouterr()
+    stats = pool.run(simulations=200, threads=1)                   # the tree restarted: a full search from the root position
+    assert pool.tree_info(t)["root_visits"] >= 200 and stats.depth_avg > 0
+    fresh = search.SearchPool(st, eval_fn=lambda d: flaky(d), fn_batch=8, fn_nb_policy=nbp)
+    fresh.add_position("", False, "crazyhouse")
+    fresh.run(simulations=200, threads=1)
+    assert pool.root_children(t)[1] == fresh.root_children(0)[1]
+    pool.apply_move(t, pool.best_move(t))                          # no "batch in flight" left over
+    s2 = pool.run(simulations=260, threads=1)
+    assert s2.depth_avg > 0 and s2.depth_max >= 1                  # depth statistics are per run
+    pool.close()
+    fresh.close()

@@ -1,0 +1,255 @@
+"""The product's leaf collector (csrc/search/mcts.cpp through `mi_search_*`) against THE REFERENCE'S OWN search code.
+
+oracle/_ref/libcrazyara_ref.so is built by oracle/ref/build_ref.py from /root/reference/engine/src (MCTSAgent, SearchThread, Node,
+NodeData, EvalInfo, blazeutil, NeuralNetAPI -- unmodified sources; the environment behind the State interface and the blaze
+stand-in are ours, see oracle/ref/shim/).  Both sides search the same position with the same settings struct and one evaluator
+callback (a deterministic pseudo-network keyed on the position), single-threaded, so every float of every node must agree:
+SURVEY 8a rows M1-M10 pinned to the reference's code, not to a restatement of it.
+
+Not comparable, by the reference's own doing:
+  * MCTS_Virtual_Style "virtual_offset": revert_virtual_loss_and_update reads an uninitialised `childRealVisit` in that branch
+    (node.h:225-229) -- undefined behaviour, the product implements the evidently intended formula (real visits).
+  * std::sort tie order of equal priors (node.cpp:464-470): the product's sort is stable; the pseudo-network has no ties.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+from crazyara_amd import env, search
+from oracle import ref_mcts
+
+pytestmark = pytest.mark.skipif(not ref_mcts.available(), reason="oracle/_ref not built and /root/reference absent")
+
+NB_POLICY = {0: 5184, 1: 4864, 2: 5376}
+REF_UNSOLVED, PRODUCT_UNSOLVED = 3, 6            # NodeType without / with the tablebase entries (nodedata.h:40-52)
+
+
+def _pseudo_net(key: bytes, nb_policy: int):
+    rs = np.random.Generator(np.random.PCG64(zlib.crc32(key)))
+    p = rs.random(nb_policy, dtype=np.float32) ** np.float32(6.0)
+    p = p / p.sum(dtype=np.float32)
+    return np.float32(rs.random() * 1.6 - 0.8), p
+
+
+def _evaluator(nbp, log=None):
+    def eval_descs(descs):
+        if log is not None:
+            log.append(len(descs))
+        out = [_pseudo_net(d[0:96] + d[112:123], nbp) for d in descs]     # bitboards + pockets + side to move (struct BoardDesc)
+        return [o[0] for o in out], [o[1] for o in out]
+    return eval_descs
+
+
+def _normalise_ref_dump(words: np.ndarray) -> np.ndarray:
+    """node_type field of every record: the reference build (no tablebases) numbers UNSOLVED 3, the product 6"""
+    w = words.copy()
+    i = 0
+    while i < len(w):
+        m = int(w[i])
+        if w[i + 4] == REF_UNSOLVED:
+            w[i + 4] = PRODUCT_UNSOLVED
+        i += 8 + 6 * m
+    assert i == len(w)
+    return w
+
+
+def _compare(pool, t, ra, check_best=True):
+    moves, visits, q, pri = pool.root_children(t)
+    m2, v2, q2, p2 = ra.root_children()
+    assert moves == m2                                         # same moves in the same (prior-sorted) order
+    assert visits == v2
+    assert np.array_equal(q, q2)                               # float32 bit equality
+    assert np.array_equal(pri, p2)
+    info, rinfo = pool.tree_info(t), ra.root_info()
+    assert info["root_visits"] == rinfo["root_visits"] and info["node_count"] == rinfo["node_count"]
+    assert np.float32(info["root_value"]) == np.float32(rinfo["root_value"])
+    solved = pool.root_solved(t)
+    assert solved["node_type"] == (PRODUCT_UNSOLVED if rinfo["node_type"] == REF_UNSOLVED else rinfo["node_type"])
+    assert solved["end_in_ply"] == rinfo["end_in_ply"] and solved["checkmate_idx"] == rinfo["checkmate_idx"]
+    # the whole tree, node by node
+    assert np.array_equal(pool.tree_dump(t), _normalise_ref_dump(ra.tree_dump()))
+    if check_best:
+        ev = ra.eval_info()
+        assert pool.best_move(t) == ev["best_move"]
+        pol, best_q = pool.root_policy(t)
+        assert np.array_equal(pol, ev["policy"][:len(pol)]) and not ev["policy"][len(pol):].any()   # EvalInfo pads unexpanded moves with 0
+        assert np.float32(best_q) == np.float32(ev["best_q"]) or rinfo["node_type"] != REF_UNSOLVED
+        assert ev["nodes"] == info["node_count"]
+
+
+CASES = [
+    # variant, is960, fen, mode, simulations, batch, temperature
+    ("crazyhouse", False, "", 0, 400, 8, 1.7),
+    ("crazyhouse", False, "", 0, 300, 16, 1.0),
+    ("crazyhouse", False, "r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] w KQkq - 0 8", 0, 300, 8, 1.7),
+    ("crazyhouse", False, "5r2/ppp2pkp/3p4/2bP4/2Pnp1N1/3P2pP/PP2n1P1/R2Q1R1K[PBRQnbb] w - - 0 28", 0, 300, 8, 1.7),
+    ("crazyhouse", False, "4R2b/1N3rkb/1p2P1pp/p2P4/2P1P3/8/PP4Q1/3R3K[QRBBNNNPPPPpp] w - - 2 53", 0, 250, 8, 1.7),     # mates in the tree
+    ("chess", False, "", 1, 300, 8, 1.7),
+    ("chess", False, "r3k2r/pppq1ppp/2npbn2/2b1p3/2B1P3/2NPBN2/PPPQ1PPP/R3K2R b KQkq - 4 8", 1, 300, 8, 1.7),         # black to move: mirrored policy
+    ("chess", True, "bnnrkbrq/pppppppp/8/8/8/8/PPPPPPPP/BNNRKBRQ w GDgd - 0 1", 1, 200, 4, 1.3),
+    ("3check", False, "1r4k1/1p2bp1p/3p2p1/PprPp2n/1R2PPq1/3Q4/1P1B1NPP/5RK1 b - - 1+1 2 22", 2, 250, 8, 1.7),
+    ("kingofthehill", False, "rnbq1bnr/pppp1ppp/4k3/8/4P3/3K4/PPPP1PPP/RNBQ1BNR w - - 4 5", 2, 200, 8, 1.7),
+    ("racingkings", False, "", 2, 200, 8, 1.7),                                                                     # never mirrored
+    ("antichess", False, "rnb1kbnr/pp1ppppp/8/q1p5/8/2P1P3/PP1PNPPP/RNBQKB1R b - - 0 3", 2, 200, 8, 1.7),
+]
+
+
+@pytest.mark.parametrize("vstyle", [3, 0, 1], ids=["mix", "loss", "visit"])
+@pytest.mark.parametrize("variant,is960,fen,mode,sims,quota,temp", CASES)
+def test_product_tree_equals_reference_build(hip_lib, variant, is960, fen, mode, sims, quota, temp, vstyle):
+    nbp = NB_POLICY[mode]
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, virtual_style=vstyle,
+                                 node_policy_temperature=temp, batch_size=quota)
+    if vstyle == 3:
+        st.virtual_mix_threshold = 40                           # so that both branches of VIRTUAL_MIX run (default 1000)
+    plog, rlog = [], []
+    pool = search.SearchPool(st, eval_fn=_evaluator(nbp, plog), fn_batch=quota, fn_nb_policy=nbp)
+    t = pool.add_position(fen, is960, variant)
+    pool.run(simulations=sims, threads=1)
+    ra = ref_mcts.RefAgent(st, _evaluator(nbp, rlog), nbp)
+    ra.set_position(fen, is960, variant)
+    ra.go(simulations=sims)
+    assert plog == rlog                                         # same batches: root alone, then the same leaf counts per mini-batch
+    _compare(pool, t, ra)
+    pool.close()
+    ra.close()
+
+
+@pytest.mark.parametrize("variant,fen,mode,verdict,best", [
+    ("chess", "6k1/5ppp/8/8/8/8/8/R3K3 w - - 0 1", 1, (0, 1), "a1a8"),                  # back-rank mate in 1: WIN in 1
+    ("antichess", "8/8/8/8/8/4p3/5P1q/8 b - - 0 1", 2, (2, 1), None),                    # both forced captures take White's last piece: LOSS in 1
+    ("chess", "7k/R7/1R6/7p/8/8/8/K7 b - - 0 1", 1, None, None),                        # two moves, both answered by Rb8#
+    ("chess", "k7/8/1K6/8/8/8/8/7R w - - 0 1", 1, (0, 1), "h1h8"),
+    ("crazyhouse", "4R2b/1N3rkb/1p2P1pp/p2P4/2P1P3/8/PP4Q1/3R3K[QRBBNNNPPPPpp] w - - 2 53", 0, None, None),
+    ("crazyhouse", "r1b2rk1/pppp1Npp/8/8/8/8/PPPPPPPP/RNBQKB1R[Qq] w KQ - 0 1", 0, None, None),
+])
+@pytest.mark.parametrize("solver", [1, 0])
+def test_solver_equals_reference_build(hip_lib, variant, fen, mode, verdict, best, solver):
+    """Node::solve_for_terminal and the solved branches of get_mcts_policy / get_best_action_index (node.cpp:299-453,1070-1148)"""
+    nbp, sims, quota = NB_POLICY[mode], 600, 8
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota, mcts_solver=solver)
+    pool = search.SearchPool(st, eval_fn=_evaluator(nbp), fn_batch=quota, fn_nb_policy=nbp)
+    t = pool.add_position(fen, False, variant)
+    pool.run(simulations=sims, threads=1)
+    ra = ref_mcts.RefAgent(st, _evaluator(nbp), nbp)
+    ra.set_position(fen, False, variant)
+    ra.go(simulations=sims)
+    _compare(pool, t, ra)
+    rinfo = ra.root_info()
+    if solver and verdict is not None:
+        assert rinfo["node_type"] == verdict[0] and (verdict[1] is None or rinfo["end_in_ply"] == verdict[1])
+        assert rinfo["root_visits"] < sims + quota and best in (None, ra.eval_info()["best_move"])   # a proven root ends the search
+    if not solver:
+        assert rinfo["node_type"] == REF_UNSOLVED and rinfo["root_visits"] >= sims
+    pool.close()
+    ra.close()
+
+
+@pytest.mark.parametrize("variant,fen,mode,eps,alpha,seed", [
+    ("crazyhouse", "", 0, 0.25, 0.2, 5),                        # RL defaults (Centi_Dirichlet_Epsilon 25, Centi_Dirichlet_Alpha 20)
+    ("chess", "r3k2r/pppq1ppp/2npbn2/2b1p3/2B1P3/2NPBN2/PPPQ1PPP/R3K2R w KQkq - 4 8", 1, 0.4, 0.6, 77),
+])
+def test_dirichlet_noise_equals_reference_build(hip_lib, variant, fen, mode, eps, alpha, seed):
+    """mctsagent.cpp:311-316 + node.cpp:950-954 + blazeutil.h:113-124: noise at the start of every go, root fully expanded; the
+    reference's generator (std::default_random_engine of node.cpp's translation unit) is seeded like the product tree's."""
+    nbp, sims, quota = NB_POLICY[mode], 200, 8
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota,
+                                 dirichlet_epsilon=eps, dirichlet_alpha=alpha, seed=seed)
+    pool = search.SearchPool(st, eval_fn=_evaluator(nbp), fn_batch=quota, fn_nb_policy=nbp)
+    t = pool.add_position(fen, False, variant)
+    ra = ref_mcts.RefAgent(st, _evaluator(nbp), nbp)
+    ra.set_position(fen, False, variant)
+    for go in range(2):                                         # the second go re-noises the kept root ("reuse the full tree")
+        pool.run(simulations=sims, threads=1)
+        ra.go(simulations=sims)
+        _compare(pool, t, ra)
+        assert len(ra.root_children()[0]) == ra.root_info()["n_legal"]
+    pool.close()
+    ra.close()
+
+
+@pytest.mark.parametrize("variant,fen,mode,greedy,checks,seed", [
+    ("crazyhouse", "", 0, 20, 100, 7),                          # UCI defaults (Centi_Epsilon_Greedy 5, Centi_Epsilon_Checks 1)
+    ("crazyhouse", "r1bq1rk1/ppp2ppp/2np1n2/2b1p3/2B1P3/2NP1N2/PPP2PPP/R1BQ1RK1[] w - - 0 7", 0, 5, 0, 11),
+    ("chess", "r3k2r/pppq1ppp/2npbn2/2b1p3/2B1P3/2NPBN2/PPPQ1PPP/R3K2R w KQkq - 4 8", 1, 0, 3, 3),
+    ("3check", "1r4k1/1p2bp1p/3p2p1/PprPp2n/1R2PPq1/3Q4/1P1B1NPP/5RK1 b - - 1+1 2 22", 2, 4, 6, 99),
+])
+def test_epsilon_exploration_equals_reference_build(hip_lib, variant, fen, mode, greedy, checks, seed):
+    """searchthread.cpp:124-185,451-501 with rand() bound to the generator every product tree owns (oracle/ref/ref_driver.cpp)"""
+    nbp, sims, quota = NB_POLICY[mode], 400, 8
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota,
+                                 epsilon_greedy_counter=greedy, epsilon_checks_counter=checks, seed=seed)
+    pool = search.SearchPool(st, eval_fn=_evaluator(nbp), fn_batch=quota, fn_nb_policy=nbp)
+    t = pool.add_position(fen, False, variant)
+    pool.run(simulations=sims, threads=1)
+    ra = ref_mcts.RefAgent(st, _evaluator(nbp), nbp)
+    ra.set_position(fen, False, variant)
+    ra.go(simulations=sims)
+    _compare(pool, t, ra)
+    pool.close()
+    ra.close()
+
+
+@pytest.mark.parametrize("variant,is960,fen,mode", [
+    ("crazyhouse", False, "", 0),
+    ("chess", True, "bnnrkbrq/pppppppp/8/8/8/8/PPPPPPPP/BNNRKBRQ w GDgd - 0 1", 1),
+    ("3check", False, "", 2),
+])
+def test_tree_reuse_across_played_moves_equals_reference_build(hip_lib, variant, is960, fen, mode):
+    """MCTSAgent::apply_move_to_tree + get_root_node_from_tree (mctsagent.cpp:130-164,230-247): one engine plays both sides of a
+    game fragment; after every go the best move is played and the subtree below it is the next root (or the tree restarts)."""
+    nbp, sims, quota = NB_POLICY[mode], 120, 8
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=quota)
+    pool = search.SearchPool(st, eval_fn=_evaluator(nbp), fn_batch=quota, fn_nb_policy=nbp)
+    t = pool.add_position(fen, is960, variant)
+    ra = ref_mcts.RefAgent(st, _evaluator(nbp), nbp)
+    ra.set_position(fen, is960, variant)
+    kept_any = False
+    for ply in range(8):
+        pool.run(simulations=sims, threads=1)
+        ra.go(simulations=sims)
+        _compare(pool, t, ra)
+        mv = ra.eval_info()["best_move"]
+        kept_any |= pool.apply_move(t, mv)
+        ra.apply_move(mv)
+        assert pool.fen(t) == ra.fen()
+    assert kept_any
+    pool.close()
+    ra.close()
+
+
+def test_reference_helpers_worked_examples():
+    """Single functions of the compiled reference against hand-computed values and the reference's own test
+    (first_and_second_max, engine/tests/tests.cpp:626-646)."""
+    import ctypes as C
+    lib = ref_mcts.load()
+    assert abs(lib.ref_get_current_cput(0.0, 2.5, 19652.0) - (np.log(19653.0 / 19652.0) + 2.5)) < 1e-6      # node.cpp:1243-1246
+    v = np.array([5, 3, 7, 1, 9, 2], np.float32)               # tests.cpp:629-636 shape: first 9 at 4, second 7 at 2
+    f, s, fa, sa = C.c_float(), C.c_float(), C.c_int(), C.c_int()
+    lib.ref_first_and_second_max(v.ctypes.data_as(C.POINTER(C.c_float)), 6, 6, C.byref(f), C.byref(s), C.byref(fa), C.byref(sa))
+    assert (f.value, s.value, fa.value, sa.value) == (9.0, 7.0, 4, 2)
+    # get_quantile (blazeutil.h:188-212): sorts, returns 0 if the smallest entry already reaches the quantile, else accumulates from
+    # the SECOND smallest and returns the previous entry + FLT_EPSILON
+    p = np.array([0.1, 0.2, 0.7], np.float64)
+    assert lib.ref_get_quantile(p.ctypes.data_as(C.POINTER(C.c_double)), 3, 0.05) == 0.0
+    q = lib.ref_get_quantile(p.ctypes.data_as(C.POINTER(C.c_double)), 3, 0.25)
+    assert abs(q - (0.2 + np.finfo(np.float32).eps)) < 1e-7     # sum: 0.2 (<0.25), 0.9 (>=0.25) -> previous entry 0.2
+    lib.ref_apply_quantile_clipping(p.ctypes.data_as(C.POINTER(C.c_double)), 3, 0.25)
+    assert np.allclose(p, [0.0, 0.0, 1.0])
+    assert lib.ref_value_to_centipawn(1.0) == 9999 and lib.ref_value_to_centipawn(0.0) == 0
+    # the product's port of the two (crazyara_amd/selfplay.py, used by Agent::set_best_move's sampling) against the compiled functions
+    from crazyara_amd import selfplay
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        n = int(rng.integers(2, 40))
+        p = rng.random(n) ** 3
+        p /= p.sum()
+        quant = float(rng.choice([0.05, 0.25, 0.5, 0.9]))
+        if 1.0 - p.min() < quant + 1e-3:
+            continue                                            # the compiled function would hit its assert(false), blazeutil.h:211
+        ref_q = lib.ref_get_quantile(p.ctypes.data_as(C.POINTER(C.c_double)), n, quant)
+        assert np.float32(selfplay.get_quantile(p, quant)) == np.float32(ref_q)
+        clipped = p.copy()
+        lib.ref_apply_quantile_clipping(clipped.ctypes.data_as(C.POINTER(C.c_double)), n, quant)
+        assert np.array_equal(selfplay.apply_quantile_clipping(quant, p), clipped)

@@ -122,6 +122,58 @@ def cpu_baseline_mcts(cfg, sd, cores, trees=16, quota=16, simulations=48):
                            f"behind the evaluator callback, {stt.seconds:.1f} s"}
 
 
+def config_search_legs(args, device, threads):
+    """nodes/sec of the BASELINE.json configurations that are not the headline, each with its own network family, batch size,
+    simulation limit and position set: config 1 = one position, one tree, batch 8 -- a single UCI `go`."""
+    from crazyara_amd import netfile, openings, rise_config, search, searchbench
+    from crazyara_amd.neuralnetapi import HipAPI
+    out = {}
+
+    def nets_for(cfg, version, batch, lanes, seed):
+        sd = rise_config.make_state_dict(cfg, seed=seed, stress=True)
+        d = tempfile.mkdtemp(prefix="cra_bench_cfg_")
+        netfile.export_rise(os.path.join(d, f"{cfg.name}-v{version}.cranet"), cfg, sd, input_version=version)
+        return [HipAPI(device, batch, d, args.precision) for _ in range(lanes)]
+
+    def leg(name, workload, cfg, version, mode, batch, lanes, quota, sims, positions, trees):
+        nets = nets_for(cfg, version, batch, lanes, seed=31)
+        st = search.default_settings(mode=mode, version_major=int(version.split(".")[0]), batch_size=quota)
+        r = searchbench.timed_search_leg(st, nets, positions, trees, sims, min(threads, max(1, trees // max(1, lanes))),
+                                         min_seconds=args.search_seconds, repeats=args.search_repeats)
+        r.pop("_median_totals")
+        r.pop("_spread")
+        r["workload"] = workload
+        r["per_tree_quota"] = quota
+        out[name] = r
+        for n in nets:
+            n.close()
+
+    cz = [(f, False, "crazyhouse") for f in openings.position_fens("crazyhouse")]
+    # config 1: the crazyhouse start position (then the rest of the opening set, one position per round), ONE tree, batch 8
+    leg("config1", "crazyhouse start position + opening set one at a time, RISEv2-7, batch 8, 800 simulations, ONE tree (a single UCI go)",
+        rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 1, 8, 800, cz, 1)
+    # the single-position reading of config 2: one tree fills the whole batch of 256 by itself
+    leg("config2_one_tree", "one crazyhouse position at a time, RISEv2-19, batch 256 collected from ONE tree, 1600 simulations",
+        rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 1, 256, 1600, cz, 1)
+    chess = [(f, False, "chess") for f in openings.position_fens("chess")]
+    leg("config3", "standard chess calibration-game positions, RISEv3.3, batch 512, 3200 simulations, 2 lanes x 32 trees",
+        rise_config.rise_v33_config(52, 76, False), "3.0", 1, 512, 2, 16, 3200, chess, 64)
+    from crazyara_amd import _capi
+    lib = _capi.load()
+    c960 = [(lib.mi_chess960_start_fen((i * 97 + 13) % 960).decode(), True, "chess") for i in range(96)]
+    leg("config4_one_gpu", "chess960 start positions (Scharnagl numbers), 8 concurrent games' trees, RISEv3.3, batch 256, 1600 simulations "
+        "(the one-GPU slice of config 4)", rise_config.rise_v33_config(52, 76, False), "3.0", 1, 256, 2, 64, 1600, c960, 8)
+    mixed = []
+    a, b = searchbench.variant_positions("3check"), searchbench.variant_positions("kingofthehill")
+    for i in range(max(len(a), len(b))):
+        mixed.append(a[i % len(a)])
+        mixed.append(b[i % len(b)])
+    leg("config5_one_gpu", "3check + king-of-the-hill positions alternating, lichess tables (80-channel planes, 5376 policy), RISEv2-13, "
+        "batch 1024, 1600 simulations, 2 lanes x 64 trees (the one-GPU slice of config 5)",
+        rise_config.rise_v2_config(13, 80, 84), "3.0", 2, 1024, 2, 16, 1600, mixed, 128)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +188,9 @@ def main():
     ap.add_argument("--search-quota", type=int, default=16, help="leaves per tree per batch (reference Batch_Size default 16)")
     ap.add_argument("--search-threads", type=int, default=16)
     ap.add_argument("--search-lanes", type=int, default=2, help="batches in flight (the reference: one per SearchThread, Threads default 2)")
+    ap.add_argument("--search-seconds", type=float, default=1.0, help="minimum timed region of one repeat of a search leg")
+    ap.add_argument("--search-repeats", type=int, default=3)
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the search legs of BASELINE configs 1, 3, 4, 5")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,6 +198,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is the HIP library, there is no CPU fallback")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: for N > 1 launch one rank per GPU with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}`")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible -- refusing to "
+                         f"share a GPU between replicas (the numbers would mean nothing)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -191,43 +252,43 @@ def main():
     value = evals / elapsed
 
     # ---- MCTS leg (BASELINE config 2: batch 256, 1600 simulations per search, fixed opening set) ----
+    # Timed region >= 1 s: rounds of "every tree restarts from its next opening position and is searched to 1600 simulations" until
+    # the pool's own run times add up to a second; median / min / max over three such repeats (crazyara_amd/searchbench.py).
     mcts = None
+    mcts_configs = None
     if not args.no_search:
-        from crazyara_amd import openings, search
+        from crazyara_amd import openings, search, searchbench
         lanes = max(1, args.search_lanes)
         extra_nets = [HipAPI(local_rank, args.batch, tmp, args.precision) for _ in range(lanes - 1)]
         st = search.default_settings(mode=0, version_major=1, batch_size=args.search_quota)
-        pool = search.SearchPool(st, net_a=net, net_b=extra_nets[0] if extra_nets else None)
-        for n_extra in extra_nets[1:]:
-            pool.add_lane(n_extra)
         n_trees = lanes * max(1, args.batch // args.search_quota)
-        fens = openings.position_fens("crazyhouse")
-        for i in range(n_trees):
-            pool.add_position(fens[(i * 7 + rank * 3) % len(fens)], False, "crazyhouse")
-        # `threads` counts the driving thread (it takes its share of every fork/join); one tree of a lane per thread is the
-        # fastest split, so with 16 trees per lane anything below 16 makes one thread do two trees per batch
-        cpus = replicas.available_cpus()
-        threads = max(1, min(args.search_threads, max(1, cpus // max(1, world))))
-        # untimed warm-up (worker threads, allocator, clocks), then every tree restarts from its opening position
-        tree_fens = [fens[(i * 7 + rank * 3) % len(fens)] for i in range(n_trees)]
-        pool.run(simulations=min(200, args.simulations), threads=threads)
-        for i, f in enumerate(tree_fens):
-            pool.reset_position(i, f, False, "crazyhouse")
-        thr0 = replicas.cgroup_throttled_usec()
-        stt = pool.run(simulations=args.simulations, threads=threads)
-        thr1 = replicas.cgroup_throttled_usec()
-        # RCCL sum of {nodes, evals, simulations}, max of seconds
-        nodes_t, sec_t, ex = replicas.reduce_stats(replicas.ReplicaStats(units=float(stt.nodes), seconds=stt.seconds,
-                                                                           extra=(float(stt.nn_evals), float(stt.simulations))),
+        positions = [(f, False, "crazyhouse") for f in openings.position_fens("crazyhouse")]
+        # host budget of this rank: its slice of the node's CPUs (near its GPU when the topology is known), threads <= that slice.
+        # `threads` counts the driving thread; one tree of a lane per thread is the fastest split, so with 16 trees per lane anything
+        # below 16 makes one thread do two trees per batch
+        cpus_avail = replicas.available_cpus()
+        _, budget_threads = replicas.pin_rank_to_cpus(world, local_rank)
+        threads = max(1, min(args.search_threads, budget_threads))
+        leg = searchbench.timed_search_leg(st, [net] + extra_nets, positions, n_trees, args.simulations, threads,
+                                           min_seconds=args.search_seconds, repeats=args.search_repeats, offset=rank * 37)
+        nodes_m, evals_m, sims_m, sec_m = leg.pop("_median_totals")
+        leg.pop("_spread")
+        # RCCL sum of {nodes, evals, simulations}, max of seconds over the ranks' median repeats
+        nodes_t, sec_t, ex = replicas.reduce_stats(replicas.ReplicaStats(units=float(nodes_m), seconds=sec_m,
+                                                                           extra=(float(evals_m), float(sims_m))),
                                                      dist, torch.device("cuda", local_rank))
-        tot = [nodes_t, ex[0], ex[1], sec_t]
-        mcts = {"mcts_nodes_per_sec": round(tot[0] / tot[3], 1), "mcts_nn_evals_per_sec": round(tot[1] / tot[3], 1),
-                "simulations_per_sec": round(tot[2] / tot[3], 1), "seconds": round(tot[3], 3),
-                "trees_per_gpu": n_trees, "simulations_per_tree": args.simulations, "per_tree_quota": args.search_quota,
-                "lanes": lanes, "host_threads_per_gpu": threads, "host_cpus_available": cpus,
-                "host_cgroup_throttled_ms_during_search": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 2), "avg_batch_fill": round(stt.nn_evals / max(1, stt.batches) / args.batch, 3),
-                "depth_avg": round(stt.depth_avg, 2), "depth_max": int(stt.depth_max)}
-        pool.close()
+        mcts = dict(leg)
+        mcts.update({"mcts_nodes_per_sec": round(nodes_t / sec_t, 1), "mcts_nn_evals_per_sec": round(ex[0] / sec_t, 1),
+                     "simulations_per_sec": round(ex[1] / sec_t, 1), "seconds": round(sec_t, 3), "per_tree_quota": args.search_quota,
+                     "host_cpus_available": cpus_avail,
+                     "workload": "BASELINE config 2: crazyhouse opening set, RISEv2-19, batch 256, 1600 simulations per tree"})
+        if world > 1:
+            # every rank's own rate next to the aggregate: a host-starved rank is visible (one more all_gather of a scalar)
+            mine = torch.tensor([nodes_m / sec_m, float(threads)], dtype=torch.float64, device=torch.device("cuda", local_rank))
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            mcts["per_rank_nodes_per_sec"] = [round(float(v[0]), 1) for v in allr]
+            mcts["per_rank_host_threads"] = [int(v[1]) for v in allr]
         if extra_nets:
             # informational: two batches of 256 in flight, as two SearchThreads of the reference keep them (own weights, own stream
             # each): the launches of one forward overlap the tail of the other.  Never `value`.
@@ -250,6 +311,9 @@ def main():
             mcts["nn_two_batches_in_flight_evals_per_sec"] = round(2 * half * args.batch / (time.perf_counter() - t2), 1)
         for n_extra in extra_nets:
             n_extra.close()
+        # ---- the other BASELINE configurations, searched (single GPU; extra keys, never `value`) ----
+        if world == 1 and not args.no_config_legs:
+            mcts_configs = config_search_legs(args, local_rank, threads)
 
     out = None
     if rank == 0:
@@ -345,6 +409,8 @@ def main():
             out["float32"] = float32
         if mcts:
             out["mcts"] = mcts
+        if mcts_configs:
+            out["mcts_configs"] = mcts_configs
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, x)
     net.close()

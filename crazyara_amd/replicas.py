@@ -80,3 +80,86 @@ def cgroup_throttled_usec():
     except (OSError, ValueError):
         pass
     return None
+
+
+# ---- host budget of a rank: the search pool of one GPU wants its collector threads on cores near that GPU ------------------------
+def _parse_cpulist(text: str):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-")
+            cpus.update(range(int(a), int(b) + 1))
+        else:
+            cpus.add(int(part))
+    return cpus
+
+
+def gpu_numa_cpus(device_index: int):
+    """CPUs of the NUMA node the GPU hangs off (sysfs: the PCI device's numa_node -> that node's cpulist), or None if unknown."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read())
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            return _parse_cpulist(f.read())
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+        return None
+
+
+def plan_rank_cpus(allowed, world: int, local_rank: int, numa_cpus_of_rank=None):
+    """The CPUs rank `local_rank` of `world` ranks on this node should run its threads on: an equal, disjoint slice of the allowed
+    set.  numa_cpus_of_rank[r] = the CPUs of the NUMA node of rank r's GPU (every rank sees all GPUs of the node, so every rank
+    computes the same table without talking): ranks whose GPUs share a node split that node's allowed CPUs in rank order, as long as
+    this gives nobody less than the plain even split would."""
+    allowed = sorted(allowed)
+    if world <= 1:
+        return allowed
+    per = max(1, len(allowed) // world)
+    if numa_cpus_of_rank and len(numa_cpus_of_rank) == world and all(n for n in numa_cpus_of_rank):
+        groups = {}
+        for r, n in enumerate(numa_cpus_of_rank):
+            groups.setdefault(frozenset(n), []).append(r)
+        ok = True
+        plan = {}
+        for node, ranks in groups.items():
+            near = [c for c in allowed if c in node]
+            share = len(near) // len(ranks)
+            if share < per:
+                ok = False
+                break
+            for k, r in enumerate(ranks):
+                plan[r] = near[k * share:(k + 1) * share]
+        if ok:
+            return plan[local_rank]
+    return allowed[local_rank * per:(local_rank + 1) * per] or allowed[-per:]
+
+
+def pin_rank_to_cpus(world: int, local_rank: int, use_gpu_topology: bool = True):
+    """Restrict this process (and the threads it starts later) to its slice of the node's CPUs.  Returns (cpus, threads) where
+    `threads` is what the search pool should be given; warns on stderr when a rank gets fewer than 8."""
+    import os
+    import sys
+    try:
+        allowed = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        return None, available_cpus()
+    budget = available_cpus()                                   # a cgroup quota may be tighter than the affinity mask
+    numa = None
+    if use_gpu_topology and world > 1 and torch.cuda.is_available() and torch.cuda.device_count() >= world:
+        numa = [gpu_numa_cpus(r) for r in range(world)]
+    cpus = plan_rank_cpus(allowed, world, local_rank, numa)
+    if world > 1:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            pass
+    threads = max(1, min(len(cpus), budget // max(1, world)))
+    if threads < 8:
+        print(f"[crazyara_amd] rank {local_rank}: only {threads} host threads for the search pool of this GPU "
+              f"({len(allowed)} CPUs allowed, quota {budget}, {world} ranks): nodes/sec will be host-bound", file=sys.stderr)
+    return cpus, threads

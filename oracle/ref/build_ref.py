@@ -31,6 +31,7 @@ REF = os.environ.get("CRA_REFERENCE_ROOT", "/root/reference")
 SRC = os.path.join(REF, "engine", "src")
 OUT = os.path.join(os.path.dirname(HERE), "_ref")
 LIB = os.path.join(OUT, "libcrazyara_ref.so")
+LIB_HIP = os.path.join(OUT, "libcrazyara_ref_hip.so")     # + integration/hipapi.h, linked against the product library
 
 REFERENCE_SOURCES = [
     "nodedata.cpp", "searchthread.cpp", "evalinfo.cpp", "state.cpp", "stateobj.cpp",
@@ -57,6 +58,7 @@ def _inputs():
     files += [os.path.join(ROOT, "crazyara_amd", "csrc", s) for s in PRODUCT_ENV_SOURCES]
     files += [os.path.join(ROOT, "crazyara_amd", "csrc", "chess", h) for h in ("position.h", "policy.h", "planes.h", "planes_host.h")]
     files.append(os.path.join(ROOT, "include", "crazyara_hip.h"))
+    files.append(os.path.join(ROOT, "integration", "hipapi.h"))
     return files
 
 
@@ -102,6 +104,20 @@ def build(force: bool = False, verbose: bool = False):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)
+    # the same objects + the driver compiled with the HipAPI section, linked against the product library (found through an rpath
+    # relative to this file's location, so the pair travels to the GPU box)
+    product_lib_dir = os.path.join(ROOT, "crazyara_amd", "lib")
+    if os.path.exists(os.path.join(product_lib_dir, "libcrazyara_hip.so")):
+        drv = os.path.join(objdir, "ref_driver_hip.o")
+        r = subprocess.run([gxx] + FLAGS + inc + ["-DREF_WITH_HIPAPI", "-I", os.path.join(ROOT, "include"), "-c",
+                            os.path.join(HERE, "ref_driver.cpp"), "-o", drv], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("g++ failed on ref_driver.cpp (HipAPI build):\n" + r.stdout)
+        others = [o for o in objs if not o.endswith("ref_driver.cpp.o")]
+        r = subprocess.run([gxx, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB_HIP] + others + [drv, "-L", product_lib_dir, "-lcrazyara_hip",
+                            "-Wl,-rpath,$ORIGIN/../../crazyara_amd/lib", "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed (HipAPI build):\n" + r.stdout)
     with open(stamp_file, "w") as f:
         f.write(stamp)
     return LIB

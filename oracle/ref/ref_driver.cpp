@@ -10,6 +10,7 @@
 //   move made  run_agent_thread (agent.cpp:107-112) + CrazyAra::position (apply_move_to_tree for both sides)
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -20,6 +21,10 @@
 #include "pommermanstate.h"
 
 #include "../../include/crazyara_hip.h"      // mi_search_settings (one settings struct for both sides of the comparison), mi_eval_fn
+
+#ifdef REF_WITH_HIPAPI
+#include "../../integration/hipapi.h"        // the reference-side binding of the product library, compiled against the reference's base class
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // environment-side globals of the shim
@@ -161,8 +166,11 @@ extern "C" {
 
 const char* ref_last_error(void) { return g_error.c_str(); }
 
+}  // extern "C"
+
 // SearchSettings / PlaySettings exactly as CrazyAra::init_search_settings fills them, from the product's settings struct
-ref_agent* ref_agent_create(const mi_search_settings* s, mi_eval_fn fn, void* user, int nb_policy) {
+template <typename MakeNet>
+static ref_agent* create_agent(const mi_search_settings* s, MakeNet&& make_net) {
     ref_agent* a = nullptr;
     if (guard([&] {
             refshim::Config& c = refshim::config();
@@ -202,11 +210,9 @@ ref_agent* ref_agent_create(const mi_search_settings* s, mi_eval_fn fn, void* us
             a->ps.temperatureMoves = 0;
             a->ps.temperatureDecayFactor = 1.0;
             a->ps.quantileClipping = 0.0;
-            const int channels = cra::layout_channels(c.layout);
-            const std::string name = "callback-v" + std::to_string(s->version_major) + "." + std::to_string(s->version_minor);
-            a->netSingle.emplace_back(new CallbackNet(1, channels, nb_policy, name, fn, user));
+            a->netSingle.emplace_back(make_net(1u));            // crazyara.cpp:548-563: batch-1 net for the agent, batch-N per SearchThread
             a->netBatches.emplace_back();
-            a->netBatches[0].emplace_back(new CallbackNet(unsigned(s->batch_size), channels, nb_policy, name, fn, user));
+            a->netBatches[0].emplace_back(make_net(unsigned(s->batch_size)));
             StateConstants::init(a->netSingle[0]->is_policy_map(), false);
             a->agent.reset(new MCTSAgent(a->netSingle, a->netBatches, &a->ss, &a->ps));
             g_rand_state = s->seed;
@@ -216,6 +222,14 @@ ref_agent* ref_agent_create(const mi_search_settings* s, mi_eval_fn fn, void* us
         return nullptr;
     }
     return a;
+}
+
+extern "C" {
+
+ref_agent* ref_agent_create(const mi_search_settings* s, mi_eval_fn fn, void* user, int nb_policy) {
+    const int channels = cra::layout_channels(cra::layout_for(s->mode, s->version_major, s->version_minor));
+    const std::string name = "callback-v" + std::to_string(s->version_major) + "." + std::to_string(s->version_minor);
+    return create_agent(s, [&](unsigned batch) { return new CallbackNet(batch, channels, nb_policy, name, fn, user); });
 }
 
 void ref_agent_destroy(ref_agent* a) { delete a; }
@@ -360,8 +374,9 @@ long ref_agent_tree_dump(ref_agent* a, uint32_t* out, long cap) {
 
 // counters of the two evaluator nets: predict() calls and positions evaluated (root net, batch net)
 void ref_agent_net_counters(ref_agent* a, unsigned long long* out4) {
-    const CallbackNet* s = static_cast<const CallbackNet*>(a->netSingle[0].get());
-    const CallbackNet* b = static_cast<const CallbackNet*>(a->netBatches[0][0].get());
+    const CallbackNet* s = dynamic_cast<const CallbackNet*>(a->netSingle[0].get());
+    const CallbackNet* b = dynamic_cast<const CallbackNet*>(a->netBatches[0][0].get());
+    if (!s || !b) { out4[0] = out4[1] = out4[2] = out4[3] = 0; return; }
     out4[0] = s->calls;
     out4[1] = s->evals;
     out4[2] = b->calls;
@@ -402,5 +417,99 @@ void ref_apply_quantile_clipping(double* v, int n, float quantile) {
 }
 
 int ref_value_to_centipawn(float v) { return value_to_centipawn(v); }
+
+#ifdef REF_WITH_HIPAPI
+// ---- integration/hipapi.h exercised through the reference's own base class and users -----------------------------------------
+// the reference's MCTSAgent / SearchThread on HipAPI nets: `go` computes on the GPU through mi_net_predict
+ref_agent* ref_agent_create_hip(const mi_search_settings* s, const char* model_dir, int device_id, const char* precision) {
+    return create_agent(s, [&](unsigned batch) { return new HipAPI(device_id, batch, model_dir, precision); });
+}
+
+struct ref_hipapi {
+    std::vector<std::unique_ptr<NeuralNetAPI>> nets;
+};
+
+// `mode` fixes the label set the reference binary would have been built with (MODE_CRAZYHOUSE / MODE_CHESS / MODE_LICHESS)
+ref_hipapi* ref_hipapi_create(const char* model_dir, int device_id, unsigned batch, const char* precision, int mode) {
+    ref_hipapi* h = nullptr;
+    if (guard([&] {
+            refshim::config().mode = mode;
+            h = new ref_hipapi;
+            h->nets.emplace_back(new HipAPI(device_id, batch, model_dir, precision));
+            const Version v = h->nets[0]->get_version();
+            refshim::config().version_major = int(version::get_major(v));
+            refshim::config().version_minor = int(version::get_minor(v));
+            refshim::config().layout = cra::layout_for(mode, int(version::get_major(v)), int(version::get_minor(v)));
+        })) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+void ref_hipapi_destroy(ref_hipapi* h) {
+    if (h) {
+        for (auto& n : h->nets) delete static_cast<HipAPI*>(n.release());      // the base class has no virtual destructor
+        delete h;
+    }
+}
+
+// out[0..8): version, is_policy_map, nb_input_values_total, nb_policy_values, batch_size, nb_auxiliary_outputs, has_auxiliary_outputs,
+// game_phase -- all through the BASE CLASS getters (neuralnetapi.h:230-299)
+void ref_hipapi_info(ref_hipapi* h, long* out) {
+    const NeuralNetAPI* n = h->nets[0].get();
+    out[0] = long(n->get_version());
+    out[1] = n->is_policy_map() ? 1 : 0;
+    out[2] = long(n->get_nb_input_values_total());
+    out[3] = long(n->get_nb_policy_values());
+    out[4] = long(n->get_batch_size());
+    out[5] = long(n->get_nb_auxiliary_outputs());
+    out[6] = n->has_auxiliary_outputs() ? 1 : 0;
+    out[7] = long(n->get_game_phase());
+}
+
+int ref_hipapi_model_name(ref_hipapi* h, char* out, int cap) {
+    const std::string s = h->nets[0]->get_model_name();
+    if (int(s.size()) + 1 > cap) return 1;
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    return 0;
+}
+
+// NeuralNetAPI::validate_neural_network (neuralnetapi.cpp:137-162) logs its findings and returns void; the same conditions are
+// re-evaluated here with the reference's check_condition so that the test sees the verdict: number of failed conditions
+int ref_hipapi_validate(ref_hipapi* h) {
+    NeuralNetAPI* n = h->nets[0].get();
+    n->validate_neural_network();
+    int failed = 0;
+    failed += !check_condition(unsigned(n->get_nb_input_values_total()), StateConstants::NB_VALUES_TOTAL(), "nbNNInputValues", "NB_VALUES_TOTAL()");
+    failed += !check_condition(unsigned(n->get_nb_policy_values()),
+                               n->is_policy_map() ? StateConstants::NB_LABELS_POLICY_MAP() : StateConstants::NB_LABELS(), "nbPolicyValues", "labels");
+    return failed;
+}
+
+// the reference's `inference` loop (crazyara.cpp:156-181): NeuralNetAPIUser owns the host buffers and calls predict back to back
+struct ExposedUser : public NeuralNetAPIUser {
+    using NeuralNetAPIUser::NeuralNetAPIUser;
+    float* in() { return inputPlanes; }
+    float* value() { return valueOutputs; }
+    float* probs() { return probOutputs; }
+    float* aux() { return auxiliaryOutputs; }
+};
+
+int ref_hipapi_run_inference(ref_hipapi* h, int iterations, const float* planes, float* value, float* probs, float* aux, double* seconds) {
+    return guard([&] {
+        ExposedUser user(h->nets);
+        const NeuralNetAPI* n = h->nets[0].get();
+        const size_t B = n->get_batch_size();
+        std::memcpy(user.in(), planes, B * n->get_nb_input_values_total() * sizeof(float));
+        const auto t0 = std::chrono::steady_clock::now();
+        user.run_inference(uint_fast16_t(iterations));                      // neuralnetapiuser.cpp:104-109
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::memcpy(value, user.value(), B * sizeof(float));
+        std::memcpy(probs, user.probs(), B * n->get_nb_policy_values() * sizeof(float));
+        if (aux && n->has_auxiliary_outputs()) std::memcpy(aux, user.aux(), B * n->get_nb_auxiliary_outputs() * sizeof(float));
+    });
+}
+#endif  // REF_WITH_HIPAPI
 
 }  // extern "C"

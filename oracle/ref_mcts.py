@@ -40,6 +40,12 @@ def load():
     if path is None:
         raise RuntimeError("oracle/_ref is not built and /root/reference is absent")
     lib = C.CDLL(path)
+    _declare(lib)
+    _lib = lib
+    return lib
+
+
+def _declare(lib):
     lib.ref_last_error.restype = C.c_char_p
     lib.ref_agent_create.restype = C.c_void_p
     lib.ref_agent_create.argtypes = [C.POINTER(SearchSettingsC), EVAL_FN, C.c_void_p, C.c_int]
@@ -66,12 +72,89 @@ def load():
     lib.ref_apply_quantile_clipping.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_float]
     lib.ref_value_to_centipawn.restype = C.c_int
     lib.ref_value_to_centipawn.argtypes = [C.c_float]
-    _lib = lib
+
+
+LIB_HIP_PATH = os.path.join(HERE, "_ref", "libcrazyara_ref_hip.so")
+_lib_hip = None
+
+
+def hip_available() -> bool:
+    from oracle.ref import build_ref
+    return os.path.exists(LIB_HIP_PATH) or build_ref.reference_present()
+
+
+def load_hip():
+    """The same library with integration/hipapi.h compiled in (the reference-side binding of the product library)."""
+    global _lib_hip
+    if _lib_hip is not None:
+        return _lib_hip
+    from oracle.ref import build_ref
+    build_ref.build()
+    if not os.path.exists(LIB_HIP_PATH):
+        raise RuntimeError("oracle/_ref/libcrazyara_ref_hip.so is not built")
+    from crazyara_amd import _capi
+    _capi.load()                                  # the product library first (RTLD_GLOBAL), then the binding that links against it
+    lib = C.CDLL(LIB_HIP_PATH)
+    _declare(lib)
+    lib.ref_agent_create_hip.restype = C.c_void_p
+    lib.ref_agent_create_hip.argtypes = [C.POINTER(SearchSettingsC), C.c_char_p, C.c_int, C.c_char_p]
+    lib.ref_hipapi_create.restype = C.c_void_p
+    lib.ref_hipapi_create.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.c_char_p, C.c_int]
+    lib.ref_hipapi_destroy.argtypes = [C.c_void_p]
+    lib.ref_hipapi_info.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+    lib.ref_hipapi_model_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.ref_hipapi_validate.argtypes = [C.c_void_p]
+    lib.ref_hipapi_run_inference.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                             C.POINTER(C.c_float), C.POINTER(C.c_double)]
+    _lib_hip = lib
     return lib
 
 
-def _err():
-    return (load().ref_last_error() or b"").decode()
+def _err(lib=None):
+    return ((lib or load()).ref_last_error() or b"").decode()
+
+
+class RefHipAPI:
+    """integration/hipapi.h's HipAPI constructed and used through the reference's NeuralNetAPI base class / NeuralNetAPIUser."""
+
+    def __init__(self, model_dir: str, device_id: int, batch: int, precision: str, mode: int):
+        self._lib = load_hip()
+        self._h = self._lib.ref_hipapi_create(model_dir.encode(), device_id, batch, precision.encode(), mode)
+        if not self._h:
+            raise RuntimeError(_err(self._lib))
+
+    def info(self) -> dict:
+        out = (C.c_long * 8)()
+        self._lib.ref_hipapi_info(self._h, out)
+        keys = ("version", "is_policy_map", "nb_input_values_total", "nb_policy_values", "batch_size", "nb_auxiliary_outputs",
+                "has_auxiliary_outputs", "game_phase")
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def model_name(self) -> str:
+        buf = C.create_string_buffer(512)
+        self._lib.ref_hipapi_model_name(self._h, buf, 512)
+        return buf.value.decode()
+
+    def validate(self) -> int:
+        return self._lib.ref_hipapi_validate(self._h)
+
+    def run_inference(self, planes: np.ndarray, iterations: int = 1):
+        i = self.info()
+        B = i["batch_size"]
+        planes = np.ascontiguousarray(planes, np.float32)
+        assert planes.size == B * i["nb_input_values_total"]
+        value, probs = np.zeros(B, np.float32), np.zeros(B * i["nb_policy_values"], np.float32)
+        aux = np.zeros(max(1, B * i["nb_auxiliary_outputs"]), np.float32)
+        sec = C.c_double()
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        if self._lib.ref_hipapi_run_inference(self._h, iterations, fp(planes), fp(value), fp(probs), fp(aux), C.byref(sec)):
+            raise RuntimeError(_err(self._lib))
+        return value, probs.reshape(B, -1), aux, sec.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ref_hipapi_destroy(self._h)
+            self._h = None
 
 
 class RefAgent:
@@ -79,9 +162,17 @@ class RefAgent:
 
     eval_fn(list of 192-byte board descriptors) -> (values, probs[n][nb_policy]) -- the signature the product's callback lane uses."""
 
-    def __init__(self, settings: SearchSettingsC, eval_fn: Callable, nb_policy: int):
-        self._lib = load()
+    def __init__(self, settings: SearchSettingsC, eval_fn: Callable = None, nb_policy: int = 0, hip_model_dir: str = None,
+                 device_id: int = 0, precision: str = "float16"):
         self.nb_policy = nb_policy
+        if hip_model_dir is not None:                       # the agent's nets are HipAPI objects: `go` evaluates on the GPU
+            self._lib = load_hip()
+            self._cb = None
+            self._h = self._lib.ref_agent_create_hip(C.byref(settings), hip_model_dir.encode(), device_id, precision.encode())
+            if not self._h:
+                raise RuntimeError(_err(self._lib))
+            return
+        self._lib = load()
 
         def _tramp(user, descs, n, value, probs):
             try:
@@ -96,19 +187,19 @@ class RefAgent:
         self._cb = EVAL_FN(_tramp)
         self._h = self._lib.ref_agent_create(C.byref(settings), self._cb, None, nb_policy)
         if not self._h:
-            raise RuntimeError(_err())
+            raise RuntimeError(_err(self._lib))
 
     def set_position(self, fen: str = "", is960: bool = False, variant: str = "crazyhouse"):
         if self._lib.ref_agent_set_position(self._h, (fen or "").encode(), int(is960), variant.encode()):
-            raise ValueError(_err())
+            raise ValueError(_err(self._lib))
 
     def go(self, simulations: int = 0, nodes: int = 0):
         if self._lib.ref_agent_go(self._h, simulations, nodes):
-            raise RuntimeError(_err())
+            raise RuntimeError(_err(self._lib))
 
     def apply_move(self, uci: str):
         if self._lib.ref_agent_apply_move(self._h, uci.encode()):
-            raise ValueError(_err())
+            raise ValueError(_err(self._lib))
 
     def fen(self) -> str:
         buf = C.create_string_buffer(256)

@@ -24,3 +24,26 @@ def test_errors_are_loud_without_gpu(hip_lib):
     if lib.mi_device_count() == 0:
         h = lib.mi_net_create(b"/nonexistent", 0, 8, b"float16")
         assert not h and len(_capi.last_error()) > 0
+
+
+def test_header_is_plain_c99_and_struct_layouts_match_the_python_binding(hip_lib, tmp_path):
+    """include/crazyara_hip.h compiled as C (not C++) by a translation unit outside the library, -std=c99 -Wall -Werror -pedantic;
+    the struct sizes / offsets a C consumer sees equal those of the ctypes mirror (crazyara_amd/search.py)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from crazyara_amd import search
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    so = os.path.join(str(tmp_path), "libhdrcheck.so")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_header_check.c"), "-o", so, _capi.LIB_PATH], check=True)
+    chk = C.CDLL(so)
+    for fn in ("cra_sizeof_search_settings", "cra_sizeof_search_stats", "cra_offsetof_settings_virtual_offset_strength",
+               "cra_offsetof_settings_version_minor", "cra_offsetof_stats_depth_max"):
+        getattr(chk, fn).restype = C.c_size_t
+    assert chk.cra_sizeof_search_settings() == C.sizeof(search.SearchSettingsC)
+    assert chk.cra_sizeof_search_stats() == C.sizeof(search.SearchStatsC)
+    assert chk.cra_offsetof_settings_virtual_offset_strength() == search.SearchSettingsC.virtual_offset_strength.offset
+    assert chk.cra_offsetof_settings_version_minor() == search.SearchSettingsC.version_minor.offset
+    assert chk.cra_offsetof_stats_depth_max() == search.SearchStatsC.depth_max.offset

@@ -57,3 +57,51 @@ def test_host_cpu_probes():
     assert isinstance(n, int) and 1 <= n <= (os.cpu_count() or 1)
     t = replicas.cgroup_throttled_usec()
     assert t is None or (isinstance(t, int) and t >= 0)
+
+
+def test_rank_cpu_plan_is_a_disjoint_partition():
+    """Host budget per rank (bench.py pins each rank's search threads): equal disjoint slices of the allowed CPUs; with the GPUs' NUMA
+    nodes known, each rank's slice lies on its GPU's node as long as nobody gets less than the plain split."""
+    allowed = list(range(256))
+    n0 = set(range(0, 64)) | set(range(128, 192))
+    n1 = set(range(64, 128)) | set(range(192, 256))
+    numa = [n0] * 4 + [n1] * 4
+    plans = [replicas.plan_rank_cpus(allowed, 8, r, numa) for r in range(8)]
+    assert all(len(p) == 32 for p in plans)
+    assert len(set().union(*map(set, plans))) == 256                                  # disjoint and complete
+    assert all(set(plans[r]) <= numa[r] for r in range(8))                            # near the rank's GPU
+    flat = [replicas.plan_rank_cpus(range(16), 8, r) for r in range(8)]               # the 16-CPU slice of a GPU box: 2 per rank
+    assert [len(p) for p in flat] == [2] * 8 and sorted(sum(flat, [])) == list(range(16))
+    tight = [replicas.plan_rank_cpus(range(16), 8, r, numa) for r in range(8)]        # topology known but no room on one node: even split
+    assert sorted(sum(tight, [])) == list(range(16))
+    assert replicas.plan_rank_cpus(range(10), 1, 0) == list(range(10))
+
+
+def _pin_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    before = sorted(os.sched_getaffinity(0))
+    cpus, threads = replicas.pin_rank_to_cpus(world, rank, use_gpu_topology=False)
+    after = sorted(os.sched_getaffinity(0))
+    mine = torch.tensor([float(threads), 1000.0 * (rank + 1)], dtype=torch.float64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)                                    # the per-rank nodes/sec report of bench.py --gpus N
+    dist.barrier()
+    dist.destroy_process_group()
+    out[rank] = (before, list(cpus), after, threads, [list(map(float, v)) for v in allr])
+
+
+def test_two_ranks_split_the_host_threads_and_report_per_rank():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_pin_worker, args=(world, port, out), nprocs=world, join=True)
+    b0, c0, a0, t0, g0 = out[0]
+    b1, c1, a1, t1, g1 = out[1]
+    if len(b0) >= 2:
+        assert a0 == sorted(c0) and a1 == sorted(c1) and not set(c0) & set(c1)        # each rank is pinned to its own slice
+        assert set(c0) | set(c1) <= set(b0)
+    assert t0 >= 1 and t1 >= 1 and t0 <= max(1, len(b0) // 2)
+    assert g0 == g1 and [v[1] for v in g0] == [1000.0, 2000.0]

@@ -383,16 +383,45 @@ def main():
                        "frac": round(tf32 / PEAK_F32_TFLOPS, 4), "per_op_ms": {k: round(v, 4) for k, v in a32.items()},
                        "logit_tolerance_met": "1e-3 (tests bound 1e-4; measured 5e-6)"}
             net32.close()
-        # ---- PCIe-inclusive rate (the reference `inference` command includes H2D/D2H each call) ----
+        # ---- PCIe-inclusive rate: the reference's `inference` command (crazyara.cpp:156-181) = back-to-back blocking predict() on the
+        # NeuralNetAPIUser's pinned buffers, planes in and value / probabilities out through PCIe on every call.  With pinned buffers
+        # predict issues no copy commands (kernels read / write the host buffers in place); the copy path is timed beside it, and two
+        # users on two nets (two SearchThreads, crazyara.cpp:548-563) show what the engine gets with its default Threads = 2. ----
+        import threading
         from crazyara_amd.neuralnetapi import NeuralNetAPIUser
-        user = NeuralNetAPIUser([net])
-        user.input_planes[:] = x.numpy().reshape(-1)
-        user.run_inference(5)
-        t1 = time.perf_counter()
-        it = max(20, args.steps // 4)
-        user.run_inference(it)
-        pcie_rate = it * args.batch / (time.perf_counter() - t1)
-        user.close()
+        it = max(60, args.steps // 2)
+
+        def pcie_rate(nets_):
+            users = [NeuralNetAPIUser([n_]) for n_ in nets_]
+            for u in users:
+                u.input_planes[:] = x.numpy().reshape(-1)
+                u.run_inference(5)
+            ths = [threading.Thread(target=u.run_inference, args=(it,)) for u in users]
+            t1 = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            el = time.perf_counter() - t1
+            zc = all(n_.last_submit_zero_copy() for n_ in nets_)
+            for u in users:
+                u.close()
+            return len(users) * it * args.batch / el, zc
+        net_b = HipAPI(local_rank, args.batch, tmp, args.precision)
+        pcie_rate_1, zc1 = pcie_rate([net])
+        pcie_rate_2, zc2 = pcie_rate([net, net_b])
+        os.environ["CRA_PREDICT_COPY"] = "1"
+        pcie_copy_1, _ = pcie_rate([net])
+        pcie_copy_2, _ = pcie_rate([net, net_b])
+        del os.environ["CRA_PREDICT_COPY"]
+        net_b.close()
+        pcie = {"one_net_evals_per_sec": round(pcie_rate_1, 1), "two_nets_in_flight_evals_per_sec": round(pcie_rate_2, 1),
+                "zero_copy": bool(zc1 and zc2), "copy_path_one_net_evals_per_sec": round(pcie_copy_1, 1),
+                "copy_path_two_nets_evals_per_sec": round(pcie_copy_2, 1), "iterations": it,
+                "bytes_per_batch": {"planes_in": args.batch * cfg.nb_input_channels * 256, "probs_out": args.batch * cfg.nb_policy * 4,
+                                    "value_out": args.batch * 4},
+                "fraction_of_value_two_nets": round(pcie_rate_2 / value, 4)}
+        pcie_rate = pcie_rate_1
         out = {
             "metric": "nn_evals_per_sec", "value": round(value, 1), "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -403,6 +432,7 @@ def main():
                        "batch": args.batch, "parallelism": f"replicas x{world}",
                        "flops_per_position": net.flops_per_position()},
             "pcie_inclusive_evals_per_sec": round(pcie_rate, 1),
+            "pcie_inclusive": pcie,
             "roofline": roofline,
         }
         if float32:

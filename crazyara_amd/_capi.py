@@ -25,6 +25,7 @@ SIGNATURES = {
     "mi_net_flops_per_position": (C.c_double, [C.c_void_p]),
     "mi_net_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_net_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_net_last_submit_zero_copy": (C.c_int, [C.c_void_p]),
     "mi_net_wait": (C.c_int, [C.c_void_p]),
     "mi_net_device_buffers": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5),
     "mi_net_forward_device": (C.c_int, [C.c_void_p]),

@@ -97,6 +97,7 @@ int mi_net_wait(mi_net* net) {
     if (!net) { g_err = "null net"; return 1; }
     return guard([&] { net->net.wait(); });
 }
+int mi_net_last_submit_zero_copy(const mi_net* net) { return net && net->net.last_submit_was_zero_copy() ? 1 : 0; }
 
 int mi_net_device_buffers(mi_net* net, float** d_planes, float** d_value, float** d_probs, float** d_logits, float** d_aux) {
     if (!net) { g_err = "null net"; return 1; }

@@ -73,12 +73,27 @@ public:
     void time_ops(int iters, float* ms);               // ms[i] += elapsed of op i, summed over iters (un-graphed launches)
     float time_forward(int iters);                     // graph replays between two events, returns ms
 
+    // predict()/submit() with ALL of the caller's buffers in pinned host memory (mi_host_alloc / hipHostMalloc / hipHostRegister, as
+    // NeuralNetAPIUser allocates them under its TENSORRT branch, neuralnetapiuser.cpp:50-60): no copy commands -- the first kernel reads
+    // the planes and the last kernels write value / probabilities / aux straight through PCIe, one queue, nothing handed to the DMA
+    // engines and back.  Pageable buffers keep the three hipMemcpyAsync.  CRA_PREDICT_COPY=1 forces the copies (A/B measurements).
+    struct IoOverride {
+        const float* planes = nullptr;
+        float* value = nullptr;
+        float* probs = nullptr;
+        float* aux = nullptr;
+    };
+    bool last_submit_was_zero_copy() const { return last_zero_copy_; }
+
 private:
     struct Impl;
     template <typename T> void build(const NetFile& nf);
-    template <typename T> void enqueue(hipStream_t s);
-    template <typename T> void launch_op(int i, hipStream_t s);
+    template <typename T> void enqueue(hipStream_t s, const IoOverride* io = nullptr);
+    template <typename T> void launch_op(int i, hipStream_t s, const IoOverride* io = nullptr);
     void capture();
+    bool buffers_are_pinned(const float* in_planes, float* value, float* probs, float* aux);
+    bool last_zero_copy_ = false;
+    const void* pinned_seen_[4] = {nullptr, nullptr, nullptr, nullptr};   // the last buffer set found pinned (a NeuralNetAPIUser reuses its four)
 
     RiseDesign design_;
     std::string model_name_, model_file_path_;

@@ -107,6 +107,10 @@ class HipAPI:
         if self._lib.mi_net_wait(self._h):
             raise RuntimeError(_capi.last_error())
 
+    def last_submit_zero_copy(self) -> bool:
+        """True if the last predict / submit found all its buffers pinned and issued no copy commands (mi_net_last_submit_zero_copy)."""
+        return bool(self._lib.mi_net_last_submit_zero_copy(self._h))
+
     # ---- device-resident path ----
     def device_buffers(self):
         """dict of zero-copy device views usable with torch.as_tensor(view, device='cuda')."""

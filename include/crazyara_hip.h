@@ -68,6 +68,11 @@ int mi_net_predict(mi_net* net, const float* in_planes, float* value, float* pro
  * side stream, wait blocks until the host buffers are valid. */
 int mi_net_submit(mi_net* net, const float* in_planes, float* value, float* probs, float* aux);
 int mi_net_wait(mi_net* net);
+/* predict / submit with EVERY buffer of the call in pinned host memory (mi_host_alloc, or any hipHostMalloc / hipHostRegister
+ * memory -- what NeuralNetAPIUser owns under its TENSORRT branch, neuralnetapiuser.cpp:50-60) issue no copy commands: the forward's
+ * first kernel reads the planes and its last kernels write value / probabilities / aux in place over PCIe (one queue, no hand-over
+ * to the DMA engines).  Pageable buffers are copied as before.  Returns 1 if the last predict / submit of this net took that path. */
+int mi_net_last_submit_zero_copy(const mi_net* net);
 
 /* Device-resident path (no PCIe): pointers to the buffers the captured forward reads/writes.
  * d_planes [B][C][64] float, d_value [B], d_probs [B][nb_policy], d_logits [B][nb_policy] (pre-softmax policy_out),

@@ -44,7 +44,8 @@ REFERENCE_SOURCES = [
 SHIM_SOURCES = ["node_tu.cpp", "ref_driver.cpp"]                      # node_tu.cpp = #include "node.cpp" + a seeding hook
 PRODUCT_ENV_SOURCES = ["chess/position.cpp", "chess/policy.cpp", "chess/planes_host.cpp"]   # the environment behind the State adapter
 
-FLAGS = ["-std=c++17", "-O2", "-fPIC", "-DMODE_POMMERMAN", "-DDISABLE_UCI_INFO", "-w"]
+# DYNAMIC_NN_ARCH: the reference's default (engine/CMakeLists.txt:14,99-100): buffer sizes come from the loaded net, not from constants
+FLAGS = ["-std=c++17", "-O2", "-fPIC", "-DMODE_POMMERMAN", "-DDISABLE_UCI_INFO", "-DDYNAMIC_NN_ARCH", "-w"]
 
 
 def reference_present() -> bool:

@@ -507,7 +507,7 @@ int ref_hipapi_run_inference(ref_hipapi* h, int iterations, const float* planes,
         if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::memcpy(value, user.value(), B * sizeof(float));
         std::memcpy(probs, user.probs(), B * n->get_nb_policy_values() * sizeof(float));
-        if (aux && n->has_auxiliary_outputs()) std::memcpy(aux, user.aux(), B * n->get_nb_auxiliary_outputs() * sizeof(float));
+        if (aux && user.aux() && n->has_auxiliary_outputs()) std::memcpy(aux, user.aux(), B * n->get_nb_auxiliary_outputs() * sizeof(float));
     });
 }
 #endif  // REF_WITH_HIPAPI

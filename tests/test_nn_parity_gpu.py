@@ -152,6 +152,41 @@ def test_submit_wait_and_device_resident_paths_agree(tmp_path, hip_lib):
     net.close()
 
 
+@pytest.mark.parametrize("name,precision", [("risev2-7", "float16"), ("risev33-wdlp", "float16"), ("risev2-3-flat", "float16"),
+                                            ("alphazero-5", "float16"), ("risev2-7", "float32")])
+def test_zero_copy_predict_equals_copied_predict(tmp_path, hip_lib, name, precision):
+    """predict() with the caller's buffers in pinned memory (NeuralNetAPIUser, neuralnetapiuser.cpp:50-60) issues no copy commands: the
+    kernels read the planes and write value / probabilities / aux in place.  Same bits as the copy path (pageable numpy buffers),
+    every net family (one-launch forward, separate launches, flat policy head, WDLP aux, float32 layer kernels)."""
+    from crazyara_amd.neuralnetapi import HipAPI, NeuralNetAPIUser
+    cfg, sd, x = nn_cases.make_case(name)
+    d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
+    B = x.shape[0]
+    net = HipAPI(0, B, d, precision)
+    v1, p1 = np.full(B, 7.0, np.float32), np.full(B * cfg.nb_policy, 7.0, np.float32)
+    a1 = np.full(B * 4, 7.0, np.float32) if cfg.nb_aux else None
+    net.predict(np.ascontiguousarray(x.numpy()), v1, p1, a1)                 # pageable: H2D copy, forward, D2H copies
+    assert not net.last_submit_zero_copy()
+    user = NeuralNetAPIUser([net])
+    user.input_planes[:] = x.numpy().reshape(-1)
+    user.value_outputs[:] = 7.0
+    user.prob_outputs[:] = 7.0
+    user.run_inference(2)                                                    # pinned: in place
+    assert net.last_submit_zero_copy()
+    assert np.array_equal(user.value_outputs, v1) and np.array_equal(user.prob_outputs, p1)
+    if cfg.nb_aux:
+        assert np.array_equal(user.auxiliary_outputs, a1)
+    # the device-side tensors were not the target of that forward: a device-resident replay still works and agrees
+    bufs = net.device_buffers()
+    torch.as_tensor(bufs["planes"], device="cuda").copy_(x.cuda())
+    torch.cuda.synchronize()
+    net.forward_device()
+    net.sync()
+    assert np.array_equal(torch.as_tensor(bufs["probs"], device="cuda").cpu().numpy().reshape(-1), p1)
+    user.close()
+    net.close()
+
+
 def test_constructor_errors(tmp_path, hip_lib):
     from crazyara_amd.neuralnetapi import HipAPI
     with pytest.raises(ValueError):

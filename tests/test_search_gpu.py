@@ -60,9 +60,11 @@ def test_two_lane_pool_on_opening_set(tmp_path, hip_lib):
         info = pool.tree_info(i)
         assert info["root_visits"] >= 200 and info["node_count"] <= info["root_visits"]
         assert pool.best_move(i) in env.Position(f, False, "crazyhouse").legal_uci()
-    # second `go` on the same pool reuses the trees (tree reuse, mctsagent.cpp:136-164): limits count from the new start
-    stats2 = pool.run(simulations=50, threads=4)
-    assert stats2.simulations >= 16 * 50
+    # second `go` on the same pool reuses the trees (tree reuse, mctsagent.cpp:136-164); the limit is absolute on the root's visits
+    # (nodes_limits_ok, searchthread.cpp:326-331): a go to 50 finds every root beyond it, a go to 250 adds the missing visits
+    assert pool.run(simulations=50, threads=4).simulations == 0
+    stats2 = pool.run(simulations=250, threads=4)
+    assert stats2.simulations >= 16 * 40 and all(pool.tree_info(i)["root_visits"] >= 250 for i in range(16))
     pool.close()
     a.close()
     b.close()

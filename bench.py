@@ -135,11 +135,12 @@ def config_search_legs(args, device, threads):
         netfile.export_rise(os.path.join(d, f"{cfg.name}-v{version}.cranet"), cfg, sd, input_version=version)
         return [HipAPI(device, batch, d, args.precision) for _ in range(lanes)]
 
-    def leg(name, workload, cfg, version, mode, batch, lanes, quota, sims, positions, trees):
+    def leg(name, workload, cfg, version, mode, batch, lanes, quota, sims, positions, trees, shared=0):
         nets = nets_for(cfg, version, batch, lanes, seed=31)
         st = search.default_settings(mode=mode, version_major=int(version.split(".")[0]), batch_size=quota)
-        r = searchbench.timed_search_leg(st, nets, positions, trees, sims, min(threads, max(1, trees // max(1, lanes))),
-                                         min_seconds=args.search_seconds, repeats=args.search_repeats)
+        leg_threads = min(threads, shared * lanes) if shared else min(threads, max(1, trees // max(1, lanes)))
+        r = searchbench.timed_search_leg(st, nets, positions, trees, sims, max(1, leg_threads),
+                                         min_seconds=args.search_seconds, repeats=args.search_repeats, shared_collectors=shared)
         r.pop("_median_totals")
         r.pop("_spread")
         r["workload"] = workload
@@ -152,9 +153,16 @@ def config_search_legs(args, device, threads):
     # config 1: the crazyhouse start position (then the rest of the opening set, one position per round), ONE tree, batch 8
     leg("config1", "crazyhouse start position + opening set one at a time, RISEv2-7, batch 8, 800 simulations, ONE tree (a single UCI go)",
         rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 1, 8, 800, cz, 1)
+    leg("config1_two_search_threads", "the same with the reference's default Threads = 2: two collectors (one per lane, batch 8 each) "
+        "share the one tree", rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 2, 8, 800, cz, 1, shared=1)
     # the single-position reading of config 2: one tree fills the whole batch of 256 by itself
-    leg("config2_one_tree", "one crazyhouse position at a time, RISEv2-19, batch 256 collected from ONE tree, 1600 simulations",
-        rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 1, 256, 1600, cz, 1)
+    leg("config2_one_tree", "one crazyhouse position at a time, RISEv2-19, batch 256 collected from ONE tree by one collector, "
+        "1600 simulations", rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 1, 256, 1600, cz, 1)
+    leg("config2_one_tree_shared", "one crazyhouse position at a time, RISEv2-19, 2 lanes x batch 256, ONE tree shared by 8 collectors "
+        "per lane (32 leaves each) under per-node locks, 1600 simulations", rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 2, 32,
+        1600, cz, 1, shared=8)
+    leg("config2_one_tree_shared_6400", "the same with 6400 simulations per go (a longer think)",
+        rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 2, 32, 6400, cz, 1, shared=8)
     chess = [(f, False, "chess") for f in openings.position_fens("chess")]
     leg("config3", "standard chess calibration-game positions, RISEv3.3, batch 512, 3200 simulations, 2 lanes x 32 trees",
         rise_config.rise_v33_config(52, 76, False), "3.0", 1, 512, 2, 16, 3200, chess, 64)

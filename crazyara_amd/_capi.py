@@ -86,6 +86,7 @@ SIGNATURES = {
     "mi_search_add_lane": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi_search_root_solved": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mi_search_best_move": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
+    "mi_search_set_shared_collectors": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_search_tree_dump": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_long]),
 }
 

@@ -230,6 +230,11 @@ long mi_search_tree_dump(mi_search* sp, int tree, uint32_t* out, long cap) {
     return n;
 }
 
+int mi_search_set_shared_collectors(mi_search* sp, int k) {
+    if (!sp) { cra_set_error("null search"); return 1; }
+    return cra_guard([&] { sp->pool->set_shared_collectors(k); });
+}
+
 int mi_search_set_active(mi_search* sp, int tree, int active) {
     if (!sp) { cra_set_error("null search"); return 1; }
     return cra_guard([&] { sp->pool->set_active(tree, active != 0); });

@@ -25,6 +25,15 @@
 
 #include <type_traits>
 
+// The TW_DEV_* / TW_TRACE_* switches below exist to TIME parts of this kernel (scripts/build_variant.sh); several of them compute wrong
+// results on purpose.  They only compile in a development build: a stray -DTW_DEV_... in a product build is a compile error, not a
+// silently broken library.
+#if !defined(CRA_DEVELOPMENT) && (defined(TW_DEV_NO_MFMA) || defined(TW_DEV_HALF_E_READS) || defined(TW_DEV_NO_WLOAD) || \
+    defined(TW_DEV_VEC_NO_LDS) || defined(TW_DEV_VEC_NO_VALU) || defined(TW_DEV_VEC_TILES) || defined(TW_DEV_PRIO) || \
+    defined(TW_DEV_NO_MATRIX) || defined(TW_DEV_NO_VECTOR) || defined(TW_DEV_NO_WARMUP) || defined(TW_TRACE_SE) || defined(TW_TRACE_BARRIERS))
+#error "TW_DEV_* / TW_TRACE_* are development switches (some compute wrong results): build with -DCRA_DEVELOPMENT, see scripts/build_variant.sh"
+#endif
+
 namespace cra {
 
 namespace {

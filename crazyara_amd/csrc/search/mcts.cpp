@@ -20,6 +20,63 @@ constexpr float Q_INIT = -1.0f;                 // constants.h:85
 constexpr float LOSS_VALUE = -1.0f, DRAW_VALUE = 0.0f, WIN_VALUE = 1.0f;   // constants.h:78-80
 constexpr int TERMINAL_NODE_CACHE_FACTOR = 2;   // SearchThread: terminalNodeCache = 2 * batchSize
 
+constexpr int32_t CHILD_NONE = -1;              // no node behind this move yet
+constexpr int32_t CHILD_PENDING = -2;           // a collector is creating the node right now (shared trees): a collision for everybody else
+
+// ---- shared trees --------------------------------------------------------------------------------------------------------------
+// Fields of a node that OTHER nodes' owners read without that node's lock (the reference reads them the same way, unsynchronised:
+// node.cpp:108-172 child->d->nodeType, searchthread.cpp:151 nextNode->get_visits(), :239 has_nn_results()): accessed through
+// relaxed / acquire-release atomics so that the shared tree is free of data races (ThreadSanitizer: scripts/hostbench/tsan_pool.cpp).
+namespace {
+inline int8_t ld_type(const Node& n) { return __atomic_load_n(&n.node_type, __ATOMIC_RELAXED); }
+inline uint16_t ld_end(const Node& n) { return __atomic_load_n(&n.end_in_ply, __ATOMIC_RELAXED); }
+inline void st_end(Node& n, uint16_t v) { __atomic_store_n(&n.end_in_ply, v, __ATOMIC_RELAXED); }
+inline bool ld_has_data(const Node& n) { return __atomic_load_n(&n.has_data, __ATOMIC_ACQUIRE); }
+inline bool ld_has_nn(const Node& n) { return __atomic_load_n(&n.has_nn, __ATOMIC_ACQUIRE); }
+inline uint32_t ld_visits(const Node& n) { return __atomic_load_n(&n.visit_sum, __ATOMIC_RELAXED); }
+
+struct NodeLock {                                // Node::lock() / unlock() (node.cpp:936-944); a no-op for single-collector trees
+    Node* n;
+    NodeLock(Node& node, bool on) : n(on ? &node : nullptr) {
+        if (n)
+            while (__atomic_test_and_set(&n->lock, __ATOMIC_ACQUIRE))
+                while (__atomic_load_n(&n->lock, __ATOMIC_RELAXED)) __builtin_ia32_pause();
+    }
+    ~NodeLock() { if (n) __atomic_clear(&n->lock, __ATOMIC_RELEASE); }
+    NodeLock(const NodeLock&) = delete;
+    NodeLock& operator=(const NodeLock&) = delete;
+};
+}  // namespace
+
+NodeArena::NodeArena() : table_(new std::atomic<Node*>[kMaxChunks]) {
+    for (int i = 0; i < kMaxChunks; ++i) table_[i].store(nullptr, std::memory_order_relaxed);
+}
+NodeArena::~NodeArena() { clear(); }
+void NodeArena::clear() {
+    const size_t chunks = (size_t(size_.load()) + kChunk - 1) >> kChunkBits;
+    for (size_t c = 0; c < size_t(kMaxChunks) && (c < chunks || table_[c].load(std::memory_order_relaxed)); ++c) {
+        delete[] table_[c].load(std::memory_order_relaxed);
+        table_[c].store(nullptr, std::memory_order_relaxed);
+    }
+    size_.store(0);
+}
+void NodeArena::swap(NodeArena& o) {
+    table_.swap(o.table_);
+    const uint32_t a = size_.load(), b = o.size_.load();
+    size_.store(b);
+    o.size_.store(a);
+}
+int NodeArena::emplace_back() {
+    const uint32_t i = size_.fetch_add(1, std::memory_order_acq_rel);
+    const size_t c = size_t(i) >> kChunkBits;
+    if (c >= size_t(kMaxChunks)) throw std::length_error("search tree: node arena exhausted");
+    if (table_[c].load(std::memory_order_acquire) == nullptr) {
+        std::lock_guard<std::mutex> lk(grow_);
+        if (table_[c].load(std::memory_order_acquire) == nullptr) table_[c].store(new Node[kChunk], std::memory_order_release);
+    }
+    return int(i);
+}
+
 float get_current_cput(float visits, const SearchSettings& s) {
     return std::log((visits + s.cpuct_base + 1) / s.cpuct_base) + s.cpuct_init;
 }
@@ -31,10 +88,10 @@ VirtualStyle get_virtual_style(const SearchSettings& s, uint32_t visits) {
 
 Tree::Tree(const Position& root, const SearchSettings& settings) : s_(settings), root_pos_(root) {
     if (s_.epsilon_greedy_counter < 0 || s_.epsilon_checks_counter < 0) throw std::invalid_argument("epsilon counters must be >= 0");
-    rng_ = s_.seed;
+    collectors_.emplace_back(new Collector);
+    collectors_[0]->rng = s_.seed;
     noise_rng_.seed(s_.seed);
     tables_ = &chess::policy_tables(s_.mode);
-    nodes_.reserve(8192);
     layout_ = layout_for(s_.mode, s_.version_major, s_.version_minor);
     keep_last_moves_ = s_.clone_keeps_last_moves < 0 ? s_.mode != MODE_CRAZYHOUSE : s_.clone_keeps_last_moves != 0;
     new_node(root_pos_);
@@ -42,8 +99,8 @@ Tree::Tree(const Position& root, const SearchSettings& settings) : s_(settings),
 
 // Node::Node + check_for_terminal (node.cpp:82-106, 880-904)
 int Tree::new_node(const Position& pos) {
-    nodes_.emplace_back();
-    Node& n = nodes_.back();
+    const int index = nodes_.emplace_back();
+    Node& n = nodes_[index];
     pos.legal_moves(n.actions);
     n.plies = uint16_t(pos.game_ply());
     n.key = pos.key();
@@ -70,7 +127,44 @@ int Tree::new_node(const Position& pos) {
             n.policy_idx[i] = uint16_t(idx);
         }
     }
-    return int(nodes_.size()) - 1;
+    return index;
+}
+
+void Tree::set_collectors(int k) {
+    if (pending_new() > 0 || pending_collisions() > 0) throw std::logic_error("set_collectors with a batch in flight");
+    k = std::max(1, k);
+    while (int(collectors_.size()) > k) collectors_.pop_back();
+    while (int(collectors_.size()) < k) {
+        collectors_.emplace_back(new Collector);
+        collectors_.back()->rng = s_.seed + 7919u * uint32_t(collectors_.size() - 1);      // every collector its own exploration stream
+    }
+    concurrent_ = k > 1;
+}
+
+int Tree::pending_new(int ctx) const {
+    if (ctx >= 0) return int(collectors_.at(size_t(ctx))->new_nodes.size());
+    int n = 0;
+    for (const auto& c : collectors_) n += int(c->new_nodes.size());
+    return n;
+}
+int Tree::pending_collisions(int ctx) const {
+    if (ctx >= 0) return int(collectors_.at(size_t(ctx))->collision_trajectories.size());
+    int n = 0;
+    for (const auto& c : collectors_) n += int(c->collision_trajectories.size());
+    return n;
+}
+uint64_t Tree::depth_sum() const {
+    uint64_t v = 0;
+    for (const auto& c : collectors_) v += c->depth_sum;
+    return v;
+}
+uint32_t Tree::depth_max() const {
+    uint32_t v = 0;
+    for (const auto& c : collectors_) v = std::max(v, c->depth_max);
+    return v;
+}
+void Tree::reset_depth_max() {
+    for (auto& c : collectors_) c->depth_max = 0;
 }
 
 void Tree::root_desc(BoardDesc& d) const { chess::pack_desc(root_pos_, d, layout_needs_move_features(layout_)); }
@@ -96,12 +190,12 @@ void Tree::finish_node(Node& n, float value) {
         for (float& p : n.priors) p /= sum;
     }
     n.set_value(value);                                                                   // node_assign_value, searchthread.cpp:475-489
-    n.has_nn = true;
+    __atomic_store_n(&n.has_nn, true, __ATOMIC_RELEASE);      // last: from here on other collectors walk through this node
 }
 
 void Tree::set_root_result(float value, const float* probs) {
     fill_nn_result(nodes_[0], value, probs);
-    prepare_node_for_visits(nodes_[0]);                                                   // mctsagent.cpp:195
+    prepare_node_for_visits(nodes_[0], *collectors_[0]);                                                   // mctsagent.cpp:195
 }
 
 // apply_dirichlet_noise_to_prior_policy (node.cpp:950-954) with get_dirichlet_noise (blazeutil.h:113-124: one fresh
@@ -122,14 +216,14 @@ void Tree::begin_search() {
         const float a = keep * n.priors[i], b = s_.dirichlet_epsilon * (noise[i] / sum);
         n.priors[i] = a + b;
     }
-    if (!n.sorted) prepare_node_for_visits(n);
+    if (!n.sorted) prepare_node_for_visits(n, *collectors_[0]);
     while (size_t(n.no_visit_idx) < n.actions.size()) increment_no_visit_idx(n);
 }
 
 // Tree reuse.  The reference keeps shared_ptr subtrees (pick_next_node) and lets the rest of the old tree die; here the kept
 // subtree is copied breadth-first into a fresh node array (indices are the links), everything else is dropped.
 bool Tree::apply_move(Move m) {
-    if (!new_nodes_.empty() || !collision_trajectories_.empty()) throw std::logic_error("apply_move with a batch in flight");
+    if (pending_new() > 0 || pending_collisions() > 0) throw std::logic_error("apply_move with a batch in flight");
     const Node& r = nodes_[0];
     int child = -1;
     if (r.has_data) {
@@ -147,32 +241,31 @@ bool Tree::apply_move(Move m) {
     root_pos_.do_move(m);
     // get_root_node_from_tree: the candidate must be a playout node (has NodeData) with at least one visit below it
     const bool keep = child >= 0 && nodes_[child].has_data && nodes_[child].has_nn && !nodes_[child].terminal && nodes_[child].visit_sum > 0;
-    std::vector<Node> fresh;
     if (keep) {
+        NodeArena fresh;
         std::vector<int> order{child};               // breadth-first copy; remap[i] = new index of old node order[i]
-        fresh.reserve(8192);
         for (size_t head = 0; head < order.size(); ++head) {
-            fresh.push_back(std::move(nodes_[order[head]]));
-            Node& n = fresh.back();
+            Node& n = fresh[fresh.emplace_back()];
+            n = std::move(nodes_[order[head]]);
             for (int32_t& c : n.child)
                 if (c >= 0) { order.push_back(c); c = int32_t(order.size()) - 1; }
         }
         nodes_.swap(fresh);
     } else {
         nodes_.clear();
-        nodes_.reserve(8192);
         new_node(root_pos_);
     }
-    depth_sum = 0;
-    depth_max = 0;
+    for (auto& c : collectors_) { c->depth_sum = 0; c->depth_max = 0; }
     return keep;
 }
 
 // sort_moves_by_probabilities + init_node_data (node.cpp:464-470, 634-643, nodedata.cpp:40-57).
 // The reference uses an unstable std::sort with greater<float>; ties are broken by the original index here.
-void Tree::prepare_node_for_visits(Node& n) {
+void Tree::prepare_node_for_visits(Node& n, Collector& col) {
     // stable insertion sort of the indices by descending prior (a few dozen moves; same order as std::stable_sort)
-    std::vector<int>& perm = sort_perm_;
+    std::vector<int>& perm = col.sort_perm;
+    std::vector<Move>& sort_moves_ = col.sort_moves;
+    std::vector<float>& sort_priors_ = col.sort_priors;
     perm.resize(n.actions.size());
     for (int i = 0; i < int(perm.size()); ++i) {
         const float p = n.priors[i];
@@ -185,7 +278,6 @@ void Tree::prepare_node_for_visits(Node& n) {
     for (size_t i = 0; i < perm.size(); ++i) { n.actions[i] = sort_moves_[perm[i]]; n.priors[i] = sort_priors_[perm[i]]; }
     n.sorted = true;
     if (!n.has_data) {
-        n.has_data = true;
         n.no_visit_idx = 1;
         {   // room for the first few children at once: most nodes expand 2-6 of them, one allocation each instead of 3 regrowths
             const size_t room = std::min<size_t>(n.actions.size(), 6);
@@ -193,10 +285,11 @@ void Tree::prepare_node_for_visits(Node& n) {
         }
         n.child_visits.assign(1, 0u);
         n.q.assign(1, Q_INIT);
-        n.child.assign(1, -1);
+        n.child.assign(1, CHILD_NONE);
         n.vl.assign(1, 0);
         n.child_types.assign(1, NT_UNSOLVED);
         n.unsolved_children = uint16_t(n.actions.size());                                 // NodeData(numberChildNodes), nodedata.cpp:70-75
+        __atomic_store_n(&n.has_data, true, __ATOMIC_RELEASE);                            // last: parents test it without this node's lock
     }
 }
 
@@ -205,7 +298,7 @@ void Tree::increment_no_visit_idx(Node& n) {                                    
         ++n.no_visit_idx;
         n.child_visits.push_back(0u);
         n.q.push_back(Q_INIT);
-        n.child.push_back(-1);
+        n.child.push_back(CHILD_NONE);
         n.vl.push_back(0);
         n.child_types.push_back(NT_UNSOLVED);
     }
@@ -213,15 +306,15 @@ void Tree::increment_no_visit_idx(Node& n) {                                    
 
 // Node::select_child_node + get_current_u_values (node.cpp:1056-1063, 1150-1167):
 //   argmax_i<noVisitIdx ( Q_i + float( double(cpuct * P_i) * (sqrt(double(N)) / (n_i + 1.0)) ) ), first maximum wins.
-int Tree::select_child(Node& n) {
-    if (!n.sorted) prepare_node_for_visits(n);
+int Tree::select_child(Node& n, Collector& col) {
+    if (!n.sorted) prepare_node_for_visits(n, col);
     if (n.no_visit_idx == 1) return 0;
     if (n.checkmate_idx >= 0) return n.checkmate_idx;                                     // has_forced_win
     const float cpuct = get_current_cput(float(n.visit_sum), s_);
     const double sq = std::sqrt(double(n.visit_sum));
     const int m = int(n.no_visit_idx);
-    select_buf_.resize(size_t(m));
-    float* __restrict__ val = select_buf_.data();
+    col.select_buf.resize(size_t(m));
+    float* __restrict__ val = col.select_buf.data();
     const float* __restrict__ pr = n.priors.data();
     const float* __restrict__ qv = n.q.data();
     const uint32_t* __restrict__ cv = n.child_visits.data();
@@ -241,7 +334,7 @@ void Tree::apply_virtual_loss(Node& n, int c) {                                 
         default: break;
     }
     ++n.child_visits[c];
-    ++n.visit_sum;
+    __atomic_store_n(&n.visit_sum, n.visit_sum + 1, __ATOMIC_RELAXED);       // written under the node's lock, read by limit checks without
     ++n.vl[c];
 }
 
@@ -252,7 +345,7 @@ void Tree::revert_virtual_loss(Node& n, int c) {                                
         default: break;
     }
     --n.child_visits[c];
-    --n.visit_sum;
+    __atomic_store_n(&n.visit_sum, n.visit_sum - 1, __ATOMIC_RELAXED);
     --n.vl[c];
 }
 
@@ -281,7 +374,7 @@ void Tree::revert_virtual_loss_and_update(Node& n, int c, float value, bool free
         }
     }
     --n.vl[c];
-    if (free_backup) ++n.free_visits;
+    if (free_backup) __atomic_store_n(&n.free_visits, n.free_visits + 1, __ATOMIC_RELAXED);
     if (solve) solve_for_terminal(n, c);
 }
 
@@ -293,14 +386,18 @@ void Tree::revert_virtual_loss_and_update(Node& n, int c, float value, bool free
 // value (set_value counts one more real visit) and the edge's Q.
 bool Tree::solve_for_terminal(Node& n, int c) {
     const int ci = n.child[c];
-    if (ci < 0 || !nodes_[ci].has_data) return false;                                     // !childNode->is_playout_node()
+    if (ci < 0 || !ld_has_data(nodes_[ci])) return false;                                 // !childNode->is_playout_node()
     const Node& ch = nodes_[ci];
-    if (ch.node_type == NT_UNSOLVED) return false;
+    // one look at the child's verdict (another collector may be proving it right now): type first, then the distance that was
+    // stored before it
+    const int8_t ch_type = __atomic_load_n(&ch.node_type, __ATOMIC_ACQUIRE);
+    const uint16_t ch_end = ld_end(ch);
+    if (ch_type == NT_UNSOLVED) return false;
     if (n.node_type != NT_UNSOLVED) return false;                                         // already solved
     if (n.child_types[c] == NT_UNSOLVED) {
         --n.unsolved_children;
-        n.child_types[c] = ch.node_type;
-        if (ch.node_type == NT_WIN) {                                                     // disable_action, node.cpp:1006-1010
+        n.child_types[c] = ch_type;
+        if (ch_type == NT_WIN) {                                                          // disable_action, node.cpp:1006-1010
             n.priors[c] = 0.0f;
             n.q[c] = float(-2147483647);
         }
@@ -311,31 +408,36 @@ bool Tree::solve_for_terminal(Node& n, int c) {
         }
         return true;
     };
-    if (ch.node_type == NT_LOSS) {
-        n.node_type = NT_WIN;
-        n.end_in_ply = uint16_t(ch.end_in_ply + 1);
+    auto solved = [&](int8_t type, uint16_t end_in_ply) {                                 // distance first, verdict last (release)
+        st_end(n, end_in_ply);
+        __atomic_store_n(&n.node_type, type, __ATOMIC_RELEASE);
+    };
+    if (ch_type == NT_LOSS) {
+        solved(NT_WIN, uint16_t(ch_end + 1));
         n.set_value(WIN_VALUE);
         n.q[c] = WIN_VALUE;
         n.checkmate_idx = c;
         return true;
     }
-    if (n.unsolved_children == 0 && ch.node_type == NT_WIN && all_children([](const Node& k) { return k.node_type == NT_WIN; })) {
-        n.node_type = NT_LOSS;
-        for (int i : n.child) n.end_in_ply = std::max<uint16_t>(n.end_in_ply, uint16_t(nodes_[i].end_in_ply + 1));   // longest line
+    if (n.unsolved_children == 0 && ch_type == NT_WIN && all_children([](const Node& k) { return ld_type(k) == NT_WIN; })) {
+        uint16_t longest = n.end_in_ply;
+        for (int i : n.child) longest = std::max<uint16_t>(longest, uint16_t(ld_end(nodes_[i]) + 1));   // longest line
+        solved(NT_LOSS, longest);
         n.set_value(LOSS_VALUE);
         n.q[c] = LOSS_VALUE;
         return true;
     }
-    if (n.unsolved_children == 0 && ch.node_type != NT_LOSS) {
+    if (n.unsolved_children == 0 && ch_type != NT_LOSS) {
         bool drawn = false;
         const bool ok = all_children([&](const Node& k) {
-            if (!k.has_data || (k.node_type != NT_DRAW && k.node_type != NT_WIN)) return false;
-            drawn |= k.node_type == NT_DRAW;
+            const int8_t kt = ld_type(k);
+            if (!ld_has_data(k) || (kt != NT_DRAW && kt != NT_WIN)) return false;
+            drawn |= kt == NT_DRAW;
             return true;
         });
         if (ok && drawn) {
-            n.node_type = NT_DRAW;
             // shortest drawn line: `child.end + 1 < end` with end starting at 0 never fires (node.cpp:277-285): end_in_ply stays 0
+            solved(NT_DRAW, n.end_in_ply);
             n.set_value(DRAW_VALUE);
             n.q[c] = DRAW_VALUE;
             return true;
@@ -348,22 +450,24 @@ bool Tree::solve_for_terminal(Node& n, int c) {
 void Tree::backup_value(float value, const Trajectory& t, bool free_backup, bool solve) {
     for (auto it = t.rbegin(); it != t.rend(); ++it) {
         value = -value;                                                                   // MODE_TWO_PLAYER
-        revert_virtual_loss_and_update(nodes_[it->node], it->child_idx, value, free_backup, solve);
+        Node& n = nodes_[it->node];
+        NodeLock lk(n, concurrent_);                                                      // revert_virtual_loss_and_update locks, node.h:201,244
+        revert_virtual_loss_and_update(n, it->child_idx, value, free_backup, solve);
     }
 }
 
 // ---- epsilon exploration helpers ----------------------------------------------------------------------------------
 // rand(): the classic ANSI-C generator, one stream per tree
-uint32_t Tree::next_rand() {
-    rng_ = rng_ * 1103515245u + 12345u;
-    return (rng_ >> 16) & 0x7fffu;
+uint32_t Tree::next_rand(Collector& col) {
+    col.rng = col.rng * 1103515245u + 12345u;
+    return (col.rng >> 16) & 0x7fffu;
 }
 
 // get_random_depth (searchthread.cpp:497-501): ceil(-log2(1 - r/100) - 1), r uniform in 1..100.  r = 100 makes that +infinity, and
 // the reference converts it to size_t -- undefined behaviour; the x86-64 code GCC emits for the conversion yields 0 (measured on the
 // reference's own function, oracle/_ref), i.e. the playout starts at the root, and that is what is restated here
-size_t Tree::get_random_depth() {
-    const int r = int(next_rand() % 100u) + 1;
+size_t Tree::get_random_depth(Collector& col) {
+    const int r = int(next_rand(col) % 100u) + 1;
     if (r == 100) return 0;
     return size_t(std::ceil(-std::log2(1 - r / 100.0) - 1));
 }
@@ -376,7 +480,7 @@ int Tree::best_action_index_fast(const Node& n) const {
     if (n.node_type == NT_LOSS) {
         uint16_t longest = 0;
         for (int i = 0; i < int(n.child.size()); ++i)
-            if (nodes_[n.child[i]].end_in_ply > longest) { longest = nodes_[n.child[i]].end_in_ply; best = i; }
+            if (n.child[i] >= 0 && ld_end(nodes_[n.child[i]]) > longest) { longest = ld_end(nodes_[n.child[i]]); best = i; }
         return best;
     }
     for (int i = 1; i < int(n.no_visit_idx); ++i)
@@ -386,31 +490,37 @@ int Tree::best_action_index_fast(const Node& n) const {
 
 // get_starting_node (searchthread.cpp:144-162): walk the most-visited line for a random number of plies.  No virtual loss and
 // no trajectory entries on the way down: the value found below is only backed up from the starting node.
-int Tree::get_starting_node(int cur, uint32_t& depth, int& child_idx, Position& pos) {
-    const size_t d = get_random_depth();
+int Tree::get_starting_node(Collector& col, int cur, uint32_t& depth, int& child_idx, Position& pos) {
+    const size_t d = get_random_depth(col);
     for (size_t cd = 0; cd < d; ++cd) {
-        const Node& n = nodes_[cur];
-        const int best = best_action_index_fast(n);
-        child_idx = best;
-        const int next = n.no_visit_idx ? n.child[best] : -1;
-        if (next < 0 || !nodes_[next].has_data || nodes_[next].visit_sum < uint32_t(s_.epsilon_greedy_counter) ||
-            nodes_[next].node_type != NT_UNSOLVED)
+        Node& n = nodes_[cur];
+        int next;
+        Move mv = chess::MOVE_NONE;
+        {
+            NodeLock lk(n, concurrent_);                     // currentNode->lock(), searchthread.cpp:148
+            const int best = best_action_index_fast(n);
+            child_idx = best;
+            next = n.no_visit_idx ? n.child[best] : -1;
+            if (next >= 0) mv = n.actions[best];
+        }
+        if (next < 0 || !ld_has_data(nodes_[next]) || ld_visits(nodes_[next]) < uint32_t(s_.epsilon_greedy_counter) ||
+            ld_type(nodes_[next]) != NT_UNSOLVED)
             break;
-        pos.do_move(n.actions[best], &nodes_[next].key);
+        pos.do_move(mv, &nodes_[next].key);
         cur = next;
         ++depth;
     }
     return cur;
 }
 
-// random_playout (searchthread.cpp:124-142)
-void Tree::random_playout(int cur, int& child_idx) {
+// random_playout (searchthread.cpp:124-142); the caller holds the node's lock
+void Tree::random_playout(Collector& col, int cur, int& child_idx) {
     Node& n = nodes_[cur];
     if (size_t(n.no_visit_idx) == n.actions.size()) {            // is_fully_expanded
-        const int idx = int(next_rand() % uint32_t(n.actions.size()));
+        const int idx = int(next_rand(col) % uint32_t(n.actions.size()));
         const int child = n.child[idx];
-        if (child < 0 || !nodes_[child].has_data) { child_idx = idx; return; }
-        if (nodes_[child].node_type == NT_UNSOLVED) { child_idx = idx; return; }
+        if (child < 0 || !ld_has_data(nodes_[child])) { child_idx = idx; return; }
+        if (ld_type(nodes_[child]) == NT_UNSOLVED) { child_idx = idx; return; }
         child_idx = -1;
     } else {
         child_idx = int(std::min(size_t(n.no_visit_idx), n.actions.size() - 1));
@@ -418,7 +528,7 @@ void Tree::random_playout(int cur, int& child_idx) {
     }
 }
 
-// select_enhanced_move (searchthread.cpp:451-473): make sure a checking move has been tried once
+// select_enhanced_move (searchthread.cpp:451-473): make sure a checking move has been tried once; the caller holds the node's lock
 int Tree::select_enhanced_move(int cur, const Position& pos) {
     Node& n = nodes_[cur];
     if (n.has_data && !n.inspected && !n.terminal) {
@@ -434,34 +544,54 @@ int Tree::select_enhanced_move(int cur, const Position& pos) {
     return -1;
 }
 
-// SearchThread::get_new_child_to_evaluate (searchthread.cpp:164-271), tree variant (useMCGS = false)
-int Tree::get_new_child_to_evaluate(NodeBackup& type, uint32_t& depth, BoardDesc* desc_out) {
+// SearchThread::get_new_child_to_evaluate (searchthread.cpp:164-271), tree variant (useMCGS = false).  With several collectors the
+// bookkeeping of a step -- selection, virtual loss, the trajectory entry, reading / reserving the child link -- happens under the
+// node's lock as in the reference; the expansion itself (do_move, move generation, terminal test, policy indices) does not: the
+// child link is marked CHILD_PENDING meanwhile, and a collector that runs into it has a collision exactly as if it had found the
+// node without network results (what the reference's second thread finds once it gets the lock).
+int Tree::get_new_child_to_evaluate(Collector& col, NodeBackup& type, uint32_t& depth, BoardDesc* desc_out) {
     depth = 0;
     int cur = 0;
-    Position& pos = scratch_pos_;
+    Position& pos = col.scratch_pos;
     pos = root_pos_;                             // rootState->clone()
     if (!keep_last_moves_) pos.clear_last_moves();
     int forced = -1;                             // childIdx chosen by the exploration step (uint16_t(-1) = none)
-    if (s_.epsilon_greedy_counter && nodes_[0].has_data && next_rand() % uint32_t(s_.epsilon_greedy_counter) == 0) {
-        cur = get_starting_node(cur, depth, forced, pos);
-        random_playout(cur, forced);
-    } else if (s_.epsilon_checks_counter && nodes_[0].has_data && next_rand() % uint32_t(s_.epsilon_checks_counter) == 0) {
-        cur = get_starting_node(cur, depth, forced, pos);
+    if (s_.epsilon_greedy_counter && nodes_[0].has_data && next_rand(col) % uint32_t(s_.epsilon_greedy_counter) == 0) {
+        cur = get_starting_node(col, cur, depth, forced, pos);
+        NodeLock lk(nodes_[cur], concurrent_);
+        random_playout(col, cur, forced);
+    } else if (s_.epsilon_checks_counter && nodes_[0].has_data && next_rand(col) % uint32_t(s_.epsilon_checks_counter) == 0) {
+        cur = get_starting_node(col, cur, depth, forced, pos);
+        NodeLock lk(nodes_[cur], concurrent_);
         forced = select_enhanced_move(cur, pos);
-        if (forced < 0) random_playout(cur, forced);
+        if (forced < 0) random_playout(col, cur, forced);
     }
     while (true) {
-        const int c = forced >= 0 ? forced : select_child(nodes_[cur]);
-        forced = -1;
-        apply_virtual_loss(nodes_[cur], c);
-        trajectory_buffer_.push_back(NodeAndIdx{cur, uint16_t(c)});
-        const int next = nodes_[cur].child[c];
-        ++depth;
-        if (next < 0) {
-            pos.do_move(nodes_[cur].actions[c]);
-            increment_no_visit_idx(nodes_[cur]);
-            const int nn = new_node(pos);        // may reallocate nodes_: no references held across this call
-            nodes_[cur].child[c] = nn;
+        int c, next;
+        Move mv;
+        {
+            Node& n = nodes_[cur];
+            NodeLock lk(n, concurrent_);
+            c = forced >= 0 ? forced : select_child(n, col);
+            forced = -1;
+            apply_virtual_loss(n, c);
+            col.trajectory_buffer.push_back(NodeAndIdx{cur, uint16_t(c)});
+            next = n.child[c];
+            mv = n.actions[c];
+            ++depth;
+            if (next == CHILD_NONE) {
+                if (concurrent_) n.child[c] = CHILD_PENDING;
+                increment_no_visit_idx(n);
+            }
+        }
+        if (next == CHILD_NONE) {
+            pos.do_move(mv);
+            const int nn = new_node(pos);
+            {
+                Node& n = nodes_[cur];
+                NodeLock lk(n, concurrent_);
+                n.child[c] = nn;
+            }
             if (nodes_[nn].terminal) {           // SearchThread::add_new_node_to_tree, searchthread.cpp:93-96
                 type = NODE_TERMINAL;
                 return nn;
@@ -471,62 +601,70 @@ int Tree::get_new_child_to_evaluate(NodeBackup& type, uint32_t& depth, BoardDesc
             type = NODE_NEW_NODE;
             return nn;
         }
+        if (next == CHILD_PENDING) { type = NODE_COLLISION; return -1; }
         if (nodes_[next].terminal) { type = NODE_TERMINAL; return next; }
-        if (!nodes_[next].has_nn) { type = NODE_COLLISION; return next; }
-        pos.do_move(nodes_[cur].actions[c], &nodes_[next].key);     // actionsBuffer replay, done incrementally
+        if (!ld_has_nn(nodes_[next])) { type = NODE_COLLISION; return next; }
+        pos.do_move(mv, &nodes_[next].key);      // actionsBuffer replay, done incrementally
         cur = next;
     }
 }
 
-int Tree::collect(int quota, BoardDesc* descs) {
+int Tree::collect(int quota, BoardDesc* descs, int ctx) {
+    Collector& col = *collectors_.at(size_t(ctx));
     size_t num_terminal = 0;
     const size_t terminal_cache = size_t(TERMINAL_NODE_CACHE_FACTOR) * size_t(std::max(quota, 1));
     int n_new = 0;
     if (nodes_[0].terminal || !nodes_[0].has_nn || root_solved()) return 0;                // is_root_node_unsolved, searchthread.cpp:333-340
-    while (n_new < quota && collision_trajectories_.size() != size_t(quota) && num_terminal < terminal_cache) {
-        trajectory_buffer_.clear();
+    while (n_new < quota && col.collision_trajectories.size() != size_t(quota) && num_terminal < terminal_cache) {
+        col.trajectory_buffer.clear();
         NodeBackup type;
         uint32_t depth;
-        const int leaf = get_new_child_to_evaluate(type, depth, descs + n_new);
-        depth_sum += depth;
-        depth_max = std::max(depth_max, depth);
+        const int leaf = get_new_child_to_evaluate(col, type, depth, descs + n_new);
+        col.depth_sum += depth;
+        col.depth_max = std::max(col.depth_max, depth);
         if (type == NODE_TERMINAL) {
             ++num_terminal;
-            backup_value(nodes_[leaf].value(), trajectory_buffer_, true, s_.mcts_solver);   // backup_value<true>: terminal visits are free (searchthread.cpp:364-367)
+            backup_value(nodes_[leaf].value(), col.trajectory_buffer, true, s_.mcts_solver);   // backup_value<true>: terminal visits are free (searchthread.cpp:364-367)
         } else if (type == NODE_COLLISION) {
-            collision_trajectories_.push_back(trajectory_buffer_);
+            col.collision_trajectories.push_back(col.trajectory_buffer);
         } else {
-            new_nodes_.push_back(leaf);
-            new_trajectories_.push_back(trajectory_buffer_);
+            col.new_nodes.push_back(leaf);
+            col.new_trajectories.push_back(col.trajectory_buffer);
             ++n_new;
         }
     }
     return n_new;
 }
 
-void Tree::pending_policy_indices(int k, const uint16_t** idx, int* count) const {
-    const Node& n = nodes_[new_nodes_.at(size_t(k))];
+void Tree::pending_policy_indices(int k, const uint16_t** idx, int* count, int ctx) const {
+    const Node& n = nodes_[collectors_.at(size_t(ctx))->new_nodes.at(size_t(k))];
     *idx = n.policy_idx.data();
     *count = int(n.policy_idx.size());
 }
 
-void Tree::finish_batch(const float* values, const float* probs, int nb_policy) {
-    for (size_t i = 0; i < new_nodes_.size(); ++i) fill_nn_result(nodes_[new_nodes_[i]], values[i], probs + i * size_t(nb_policy));
-    backup_batch();
+void Tree::finish_batch(const float* values, const float* probs, int nb_policy, int ctx) {
+    Collector& col = *collectors_.at(size_t(ctx));
+    for (size_t i = 0; i < col.new_nodes.size(); ++i) fill_nn_result(nodes_[col.new_nodes[i]], values[i], probs + i * size_t(nb_policy));
+    backup_batch(col);
 }
 
-void Tree::finish_batch_gathered(const float* values, const float* gathered, uint32_t stride) {
-    for (size_t i = 0; i < new_nodes_.size(); ++i) fill_nn_result_gathered(nodes_[new_nodes_[i]], values[i], gathered + i * size_t(stride));
-    backup_batch();
+void Tree::finish_batch_gathered(const float* values, const float* gathered, uint32_t stride, int ctx) {
+    Collector& col = *collectors_.at(size_t(ctx));
+    for (size_t i = 0; i < col.new_nodes.size(); ++i) fill_nn_result_gathered(nodes_[col.new_nodes[i]], values[i], gathered + i * size_t(stride));
+    backup_batch(col);
 }
 
-void Tree::backup_batch() {
-    for (size_t i = 0; i < new_nodes_.size(); ++i) backup_value(nodes_[new_nodes_[i]].value(), new_trajectories_[i], false);
-    new_nodes_.clear();
-    new_trajectories_.clear();
-    for (const Trajectory& t : collision_trajectories_)                                   // backup_collision, node.cpp:655-659
-        for (auto it = t.rbegin(); it != t.rend(); ++it) revert_virtual_loss(nodes_[it->node], it->child_idx);
-    collision_trajectories_.clear();
+void Tree::backup_batch(Collector& col) {
+    for (size_t i = 0; i < col.new_nodes.size(); ++i) backup_value(nodes_[col.new_nodes[i]].value(), col.new_trajectories[i], false);
+    col.new_nodes.clear();
+    col.new_trajectories.clear();
+    for (const Trajectory& t : col.collision_trajectories)                                // backup_collision, node.cpp:655-659
+        for (auto it = t.rbegin(); it != t.rend(); ++it) {
+            Node& n = nodes_[it->node];
+            NodeLock lk(n, concurrent_);                                                  // Node::revert_virtual_loss locks, node.cpp:663
+            revert_virtual_loss(n, it->child_idx);
+        }
+    col.collision_trajectories.clear();
 }
 
 // Node::get_mcts_policy (node.cpp:1070-1109)

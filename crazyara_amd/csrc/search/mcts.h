@@ -7,8 +7,10 @@
 // other half's batch is on the GPU (side stream, pinned async copies, 192-byte descriptors instead of float planes).
 // Every tree is touched by exactly one thread at a time -> no per-node mutex, no global hash-table mutex.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <string>
 #include <vector>
@@ -84,6 +86,7 @@ struct Node {
     int8_t node_type = NT_UNSOLVED;
     bool terminal = false, has_nn = false, sorted = false, has_data = false, inspected = false;
     uint8_t stm = 0;
+    uint8_t lock = 0;                     // per-node spin lock (Node::mtx, node.h:100): taken only by trees with several collectors
 
     float value() const { return float(value_sum / real_visits); }                         // node.cpp:595-598
     void set_value(float v) { ++real_visits; value_sum = double(v * float(real_visits)); } // node.cpp:716-720
@@ -100,6 +103,44 @@ enum NodeBackup { NODE_COLLISION, NODE_TERMINAL, NODE_NEW_NODE, NODE_TRANSPOSITI
 
 float get_current_cput(float visits, const SearchSettings& s);                             // node.cpp:1243-1246
 VirtualStyle get_virtual_style(const SearchSettings& s, uint32_t visits);                  // node.h:87-95
+
+// What one SearchThread of the reference owns (searchthread.h:52-80): the trajectories of its mini-batch in flight, its running
+// position and scratch buffers, its exploration stream.  A tree searched by ONE collector (the pool's many-trees mode) has exactly one;
+// a tree shared by k collectors -- k SearchThreads on one tree, crazyara.cpp:555-561 -- has k, and takes the per-node locks.
+struct Collector {
+    Trajectory trajectory_buffer;
+    std::vector<int32_t> new_nodes;
+    std::vector<Trajectory> new_trajectories, collision_trajectories;
+    chess::Position scratch_pos;          // the simulation's running position (assigned from the root: keeps its buffers)
+    std::vector<int> sort_perm;
+    std::vector<chess::Move> sort_moves;
+    std::vector<float> sort_priors;
+    std::vector<float> select_buf;
+    uint32_t rng = 1;
+    uint64_t depth_sum = 0;
+    uint32_t depth_max = 0;
+};
+
+// Node storage with stable addresses and lock-free indexing: chunks of 1024 nodes behind a fixed table of chunk pointers, so that
+// collectors can allocate nodes while others walk the tree (a std::vector would move every node on growth).
+class NodeArena {
+public:
+    static constexpr int kChunkBits = 10, kChunk = 1 << kChunkBits, kMaxChunks = 1 << 15;      // room for 33.5 M nodes
+    NodeArena();
+    ~NodeArena();
+    NodeArena(const NodeArena&) = delete;
+    NodeArena& operator=(const NodeArena&) = delete;
+    Node& operator[](int i) { return table_[size_t(i) >> kChunkBits].load(std::memory_order_acquire)[i & (kChunk - 1)]; }
+    const Node& operator[](int i) const { return table_[size_t(i) >> kChunkBits].load(std::memory_order_acquire)[i & (kChunk - 1)]; }
+    int emplace_back();                   // thread-safe; the node is default-constructed
+    size_t size() const { return size_.load(std::memory_order_acquire); }
+    void clear();                         // single-threaded phases only
+    void swap(NodeArena& o);              // single-threaded phases only
+private:
+    std::unique_ptr<std::atomic<Node*>[]> table_;
+    std::atomic<uint32_t> size_{0};
+    std::mutex grow_;
+};
 
 class Tree {
 public:
@@ -127,24 +168,37 @@ public:
     // --- SearchThread::create_mini_batch (searchthread.cpp:347-380) with `quota` in the role of batchSize ---
     // Writes one BoardDesc per NEW leaf to descs[0..returned).  Terminals are backed up immediately, collisions are
     // remembered and reverted in finish_batch().
-    int collect(int quota, BoardDesc* descs);
+    // `ctx` = which collector of the tree (0 for a tree with one): concurrent calls with DIFFERENT ctx are allowed once
+    // set_collectors(k > 1) was called -- the k SearchThreads of the reference sharing one tree.
+    int collect(int quota, BoardDesc* descs, int ctx = 0);
     // set_nn_results_to_child_nodes + backup_value_outputs + backup_collisions (searchthread.cpp:301-324)
-    void finish_batch(const float* values, const float* probs, int nb_policy);
+    void finish_batch(const float* values, const float* probs, int nb_policy, int ctx = 0);
+    // number of collectors (>= 1).  More than one switches the per-node locks on: select / virtual loss / expansion bookkeeping and the
+    // backups of a node happen under that node's lock, as in the reference (searchthread.cpp:187-267, node.h:199-246); the expensive
+    // part of an expansion (move generation, legality, terminal test, policy indices) runs outside any lock.
+    void set_collectors(int k);
+    int n_collectors() const { return int(collectors_.size()); }
     // The same with the priors already gathered (on the GPU) for the legal moves of each new node:
     // pending_policy_indices(k) = the policy indices of the k-th new node of the last collect(), in move order; `gathered + k * stride`
     // holds probs[index] for exactly those (what set_probabilities_for_moves reads, node.cpp:961-979).
-    void pending_policy_indices(int k, const uint16_t** idx, int* count) const;
-    void finish_batch_gathered(const float* values, const float* gathered, uint32_t stride);
+    void pending_policy_indices(int k, const uint16_t** idx, int* count, int ctx = 0) const;
+    void finish_batch_gathered(const float* values, const float* gathered, uint32_t stride, int ctx = 0);
 
     // --- queries ---
     const Node& root() const { return nodes_[0]; }
     const Node& node(int i) const { return nodes_[i]; }
     size_t node_count_allocated() const { return nodes_.size(); }
-    uint32_t root_visits() const { return nodes_[0].visit_sum; }
-    uint32_t node_count() const { return nodes_[0].visit_sum - nodes_[0].free_visits; }   // Node::get_node_count, node.cpp:1303-1306
+    // read by the pool's limit checks while collectors run: relaxed atomic loads of the root's counters
+    uint32_t root_visits() const { return __atomic_load_n(&nodes_[0].visit_sum, __ATOMIC_RELAXED); }
+    uint32_t node_count() const {                                                          // Node::get_node_count, node.cpp:1303-1306
+        return __atomic_load_n(&nodes_[0].visit_sum, __ATOMIC_RELAXED) - __atomic_load_n(&nodes_[0].free_visits, __ATOMIC_RELAXED);
+    }
     const chess::Position& root_position() const { return root_pos_; }
-    int pending_new() const { return int(new_nodes_.size()); }
-    int pending_collisions() const { return int(collision_trajectories_.size()); }
+    int pending_new(int ctx = -1) const;           // new nodes without results; ctx < 0: over all collectors
+    int pending_collisions(int ctx = -1) const;
+    uint64_t depth_sum() const;                    // summed over the collectors
+    uint32_t depth_max() const;
+    void reset_depth_max();
     // Node::get_mcts_policy + argmax (node.cpp:1070-1109): best child index of the root and the visit policy
     int best_move_index(std::vector<double>* policy = nullptr) const;
     // EvalInfo::bestMoveQ of root child b (set_eval_for_single_pv + get_best_move_q, evalinfo.cpp:110-182): the negated value of
@@ -153,8 +207,6 @@ public:
     // EvalInfo::bestMoveQ[0] as update_eval_info leaves it (evalinfo.cpp:184-243): best_move_q of the chosen child, or the root's own
     // value for a single-move root that was not searched
     float eval_best_move_q() const;
-    uint64_t depth_sum = 0;
-    uint32_t depth_max = 0;
     // Whole tree as a flat word list (inspection / parity tests; the reference's counterpart is MCTSAgent::export_search_tree,
     // mctsagent.cpp:420-448): depth-first preorder over the expanded children, one record per node that owns NodeData:
     // [n_expanded, visit_sum, real_visits, free_visits, node_type, end_in_ply, terminal, bits(value)] then per expanded child
@@ -162,27 +214,28 @@ public:
     void dump(std::vector<uint32_t>& out) const;
 
     // exposed for the arithmetic parity tests
-    int select_child(Node& n);
+    int select_child(Node& n) { return select_child(n, *collectors_[0]); }
+    int select_child(Node& n, Collector& col);
     void apply_virtual_loss(Node& n, int child_idx);
     void revert_virtual_loss(Node& n, int child_idx);
     void revert_virtual_loss_and_update(Node& n, int child_idx, float value, bool free_backup, bool solve = false);
     void backup_value(float value, const Trajectory& t, bool free_backup, bool solve = false);
     bool solve_for_terminal(Node& n, int child_idx);
-    bool root_solved() const { return nodes_[0].node_type != NT_UNSOLVED; }
+    bool root_solved() const { return __atomic_load_n(&nodes_[0].node_type, __ATOMIC_RELAXED) != NT_UNSOLVED; }
 
 private:
     int new_node(const chess::Position& pos);
-    void prepare_node_for_visits(Node& n);
+    void prepare_node_for_visits(Node& n, Collector& col);
     void increment_no_visit_idx(Node& n);
     void fill_nn_result(Node& n, float value, const float* probs);
     void fill_nn_result_gathered(Node& n, float value, const float* priors);
     void finish_node(Node& n, float value);
-    void backup_batch();
-    int get_new_child_to_evaluate(NodeBackup& type, uint32_t& depth, BoardDesc* desc_out);
-    uint32_t next_rand();
-    size_t get_random_depth();
-    int get_starting_node(int cur, uint32_t& depth, int& child_idx, chess::Position& pos);
-    void random_playout(int cur, int& child_idx);
+    void backup_batch(Collector& col);
+    int get_new_child_to_evaluate(Collector& col, NodeBackup& type, uint32_t& depth, BoardDesc* desc_out);
+    uint32_t next_rand(Collector& col);
+    size_t get_random_depth(Collector& col);
+    int get_starting_node(Collector& col, int cur, uint32_t& depth, int& child_idx, chess::Position& pos);
+    void random_playout(Collector& col, int cur, int& child_idx);
     int select_enhanced_move(int cur, const chess::Position& pos);
     int best_action_index_fast(const Node& n) const;
 
@@ -191,16 +244,9 @@ private:
     const chess::PolicyTables* tables_;
     int layout_;
     bool keep_last_moves_;
-    std::vector<Node> nodes_;
-    std::vector<int32_t> new_nodes_;
-    std::vector<Trajectory> new_trajectories_, collision_trajectories_;
-    Trajectory trajectory_buffer_;
-    chess::Position scratch_pos_;         // the simulation's running position (assigned from the root: keeps its buffers)
-    std::vector<int> sort_perm_;
-    std::vector<chess::Move> sort_moves_;
-    std::vector<float> sort_priors_;
-    std::vector<float> select_buf_;
-    uint32_t rng_ = 1;
+    NodeArena nodes_;
+    std::vector<std::unique_ptr<Collector>> collectors_;   // [0] always exists
+    bool concurrent_ = false;                               // several collectors: per-node locks are taken
     float last_value_eval_ = -1.0f;            // MCTSAgent::lastValueEval (mctsagent.cpp:47), reset with the game (clear_game_history)
     uint8_t last_stm_ = 0;                     // MCTSAgent::lastSideToMove
     std::minstd_rand0 noise_rng_;              // std::default_random_engine of libstdc++ (randomgen.h:35)

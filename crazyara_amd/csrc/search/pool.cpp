@@ -223,15 +223,45 @@ int SearchPool::add_position(const chess::Position& pos) {
     SearchSettings st = s_;
     st.seed = s_.seed + uint32_t(trees_.size());     // every tree owns its exploration stream
     trees_.emplace_back(new Tree(pos, st));
-    const int id = int(trees_.size()) - 1;
-    lanes_[id % lanes_.size()].trees.push_back(id);
-    return id;
+    rebuild_items();
+    return int(trees_.size()) - 1;
 }
 
 void SearchPool::reset_position(int i, const chess::Position& pos) {
     SearchSettings st = s_;
     st.seed = s_.seed + uint32_t(i);
     trees_.at(i).reset(new Tree(pos, st));
+    if (shared_k_ > 0) trees_[i]->set_collectors(shared_k_ * int(lanes_.size()));
+}
+
+void SearchPool::set_shared_collectors(int k) {
+    if (k < 0 || k > 256) throw std::invalid_argument("shared collectors per tree and lane must be in [0, 256]");
+    for (const Lane& lane : lanes_)
+        if (lane.in_flight) throw std::logic_error("set_shared_collectors with a batch in flight");
+    shared_k_ = k;
+    rebuild_items();
+}
+
+// items = (tree, collector) pairs and their lanes.  Many-trees mode (k = 0): one item per tree, tree t in lane t % lanes.  Shared mode
+// (k >= 1): every tree has k collectors in every lane (collector index = lane * k + j).
+void SearchPool::rebuild_items() {
+    items_.clear();
+    for (Lane& lane : lanes_) lane.trees.clear();
+    const int L = int(lanes_.size());
+    for (int t = 0; t < int(trees_.size()); ++t) {
+        if (shared_k_ <= 0) {
+            trees_[t]->set_collectors(1);
+            items_.push_back(Item{t, 0});
+            lanes_[size_t(t % L)].trees.push_back(int(items_.size()) - 1);
+        } else {
+            trees_[t]->set_collectors(shared_k_ * L);
+            for (int l = 0; l < L; ++l)
+                for (int j = 0; j < shared_k_; ++j) {
+                    items_.push_back(Item{t, l * shared_k_ + j});
+                    lanes_[size_t(l)].trees.push_back(int(items_.size()) - 1);
+                }
+        }
+    }
 }
 
 void SearchPool::set_active(int i, bool active) {
@@ -247,10 +277,11 @@ bool SearchPool::tree_done(const Tree& t, uint32_t simulations, uint32_t nodes) 
     return false;
 }
 
-void SearchPool::evaluate_roots(Lane& lane) {
-    Evaluator& ev = *lane.eval;
+// roots without network results (new games, restarted trees): evaluated through the first lane, a batch at a time
+void SearchPool::evaluate_roots(uint64_t* evals, uint64_t* batches) {
+    Evaluator& ev = *lanes_[0].eval;
     std::vector<int> todo;
-    for (int id : lane.trees)
+    for (int id = 0; id < int(trees_.size()); ++id)
         if (trees_[id]->root_needs_eval() && !is_paused(id)) todo.push_back(id);
     for (size_t off = 0; off < todo.size(); off += ev.batch_size()) {
         const int n = int(std::min(todo.size() - off, size_t(ev.batch_size())));
@@ -258,7 +289,9 @@ void SearchPool::evaluate_roots(Lane& lane) {
         ev.submit(n, layout_);
         ev.wait();
         for (int i = 0; i < n; ++i) trees_[todo[off + i]]->set_root_result(ev.values()[i], ev.probs() + size_t(i) * ev.nb_policy());
+        ++*batches;
     }
+    *evals += todo.size();
 }
 
 void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats) {
@@ -269,13 +302,7 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     std::vector<uint32_t> nodes_pre(trees_.size()), visits_pre(trees_.size());
     std::vector<uint64_t> depth_pre(trees_.size());
     const auto t0 = std::chrono::steady_clock::now();
-    for (Lane& lane : lanes_) {
-        size_t before = 0;
-        for (int id : lane.trees) before += trees_[id]->root_needs_eval() && !is_paused(id);
-        evaluate_roots(lane);
-        st.nn_evals += before;
-        st.batches += (before + lane.eval->batch_size() - 1) / lane.eval->batch_size();
-    }
+    evaluate_roots(&st.nn_evals, &st.batches);
     std::vector<char> single_move(trees_.size(), 0);
     for (size_t i = 0; i < trees_.size(); ++i) {
         if (!is_paused(int(i))) {
@@ -288,13 +315,14 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         }
         nodes_pre[i] = trees_[i]->node_count();
         visits_pre[i] = trees_[i]->root_visits();
-        depth_pre[i] = trees_[i]->depth_sum;
-        trees_[i]->depth_max = 0;                                   // reset_stats() at the start of a go (searchthread.cpp:283-288)
+        depth_pre[i] = trees_[i]->depth_sum();
+        trees_[i]->reset_depth_max();                               // reset_stats() at the start of a go (searchthread.cpp:283-288)
     }
     // simulations / nodes limits are ABSOLUTE on the root's counters, as SearchThread::nodes_limits_ok has them
     // (searchthread.cpp:326-331: rootNode->get_visits() < simulations, get_node_count() < nodes): visits inherited through tree
     // reuse count towards the limit of the next go
-    auto done = [&](int id) {
+    auto done = [&](int item) {                                     // per item = per (tree, collector): the tree's verdict
+        const int id = items_[size_t(item)].tree;
         if (is_paused(id) || single_move[id]) return true;
         const Tree& t = *trees_[id];
         if (t.root().terminal || t.root_solved()) return true;      // is_root_node_unsolved(), searchthread.cpp:333-340
@@ -309,7 +337,9 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     auto collect_item = [&](Lane& lane, int i, int id) {
         Evaluator& ev = *lane.eval;
         const uint32_t gstride = ev.gather_stride();
-        lane.n_new[i] = trees_[id]->collect(lane.slot_count[i], ev.descs() + lane.slot_begin[i]);
+        Tree& tree = item_tree(id);
+        const int ctx = item_ctx(id);
+        lane.n_new[i] = tree.collect(lane.slot_count[i], ev.descs() + lane.slot_begin[i], ctx);
         if (gstride) {
             for (int k = 0; k < lane.slot_count[i]; ++k) {
                 const size_t slot = size_t(lane.slot_begin[i] + k);
@@ -317,7 +347,7 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
                 if (k < lane.n_new[i]) {
                     const uint16_t* src = nullptr;
                     int c = 0;
-                    trees_[id]->pending_policy_indices(k, &src, &c);
+                    tree.pending_policy_indices(k, &src, &c, ctx);
                     if (uint32_t(c) > gstride) gather_overflow.store(true, std::memory_order_relaxed);
                     else {
                         std::memcpy(ev.gather_idx() + slot * gstride, src, size_t(c) * sizeof(uint16_t));
@@ -331,8 +361,8 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     // the results of the batch a tree took part in: priors + values into its new nodes, backups
     auto finish_item = [&](Lane& lane, bool gathered, int i, int id) {
         Evaluator& ev = *lane.eval;
-        if (gathered) trees_[id]->finish_batch_gathered(ev.values() + lane.slot_begin[i], ev.gathered() + size_t(lane.slot_begin[i]) * ev.gather_stride(), ev.gather_stride());
-        else trees_[id]->finish_batch(ev.values() + lane.slot_begin[i], ev.probs() + size_t(lane.slot_begin[i]) * ev.nb_policy(), ev.nb_policy());
+        if (gathered) item_tree(id).finish_batch_gathered(ev.values() + lane.slot_begin[i], ev.gathered() + size_t(lane.slot_begin[i]) * ev.gather_stride(), ev.gather_stride(), item_ctx(id));
+        else item_tree(id).finish_batch(ev.values() + lane.slot_begin[i], ev.probs() + size_t(lane.slot_begin[i]) * ev.nb_policy(), ev.nb_policy(), item_ctx(id));
     };
     // after the trees of `ids` have collected: count, submit (or finish at once when there is nothing to evaluate)
     auto submit_batch = [&](Lane& lane, const std::vector<int>& ids) {
@@ -347,7 +377,7 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         lane.in_flight = false;
         if (total_new == 0) {
             // nothing to evaluate (all terminal / collisions): finish immediately
-            workers.parallel_for(n_use, [&](int i) { trees_[ids[i]]->finish_batch(nullptr, nullptr, ev.nb_policy()); });
+            workers.parallel_for(n_use, [&](int i) { item_tree(ids[i]).finish_batch(nullptr, nullptr, ev.nb_policy(), item_ctx(ids[i])); });
             return;
         }
         const auto s0 = std::chrono::steady_clock::now();
@@ -502,8 +532,8 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     for (size_t i = 0; i < trees_.size(); ++i) {
         st.nodes += trees_[i]->node_count() - nodes_pre[i];
         st.simulations += trees_[i]->root_visits() - visits_pre[i];
-        dsum += trees_[i]->depth_sum - depth_pre[i];
-        st.depth_max = std::max(st.depth_max, trees_[i]->depth_max);
+        dsum += trees_[i]->depth_sum() - depth_pre[i];
+        st.depth_max = std::max(st.depth_max, trees_[i]->depth_max());
     }
     st.depth_avg = st.simulations ? double(dsum) / double(st.simulations) : 0.0;
     if (stats) *stats = st;

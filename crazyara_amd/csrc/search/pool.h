@@ -91,20 +91,32 @@ public:
     void reset_position(int i, const chess::Position& pos);   // a new game in slot i (same lane, same exploration stream seed)
     // trees that sit out the following runs (an arena game whose other player is to move): they keep their state
     void set_active(int i, bool active);
+    // One tree, many collectors -- the reference's `Threads` SearchThreads on ONE tree (crazyara.cpp:555-561, searchthread.cpp:403-416):
+    // every tree gets k >= 1 collectors IN EVERY LANE; a lane's batch is the concatenation of its collectors' mini-batches, collected in
+    // parallel on the worker threads under per-node locks with virtual loss keeping them apart.  k = 0 (default): every tree has one
+    // collector and lives in one lane (the many-trees mode: no locks).  Call between runs.
+    void set_shared_collectors(int k);
+    int shared_collectors() const { return shared_k_; }
     int n_trees() const { return int(trees_.size()); }
     const SearchSettings& settings() const { return s_; }
 
 private:
+    struct Item { int tree; int ctx; };    // one collector of one tree: the unit that owns a slot range of a batch
     struct Lane {
         std::unique_ptr<Evaluator> eval;
-        std::vector<int> trees;            // tree ids assigned to this lane
+        std::vector<int> trees;            // item ids (collectors) assigned to this lane; one per tree unless trees are shared
         std::vector<int> slot_begin, slot_count, n_new, batch_ids;
         bool in_flight = false;
         bool gathered = false;             // the batch in flight returns gathered priors
         bool same_trees_next = false;      // the next batch can keep this batch's trees and slots (no rotation, no tree finished)
     };
     bool tree_done(const Tree& t, uint32_t simulations, uint32_t nodes) const;
-    void evaluate_roots(Lane& lane);
+    void evaluate_roots(uint64_t* evals, uint64_t* batches);
+    void rebuild_items();
+    Tree& item_tree(int item) { return *trees_[size_t(items_[size_t(item)].tree)]; }
+    int item_ctx(int item) const { return items_[size_t(item)].ctx; }
+    std::vector<Item> items_;
+    int shared_k_ = 0;
     SearchSettings s_;
     int layout_;
     std::vector<std::unique_ptr<Tree>> trees_;

@@ -114,6 +114,12 @@ class SearchPool:
             raise RuntimeError(_capi.last_error())
         return np.ctypeslib.as_array(buf)[:n].copy()
 
+    def set_shared_collectors(self, k: int) -> None:
+        """k >= 1 collectors per tree in every lane (SearchThreads sharing one tree, crazyara.cpp:555-561): the single-`go` mode.
+        0 = many-trees mode (one collector per tree, each tree in one lane)."""
+        if self._lib.mi_search_set_shared_collectors(self._h, int(k)):
+            raise ValueError(_capi.last_error())
+
     def set_active(self, tree: int, active: bool) -> None:
         if self._lib.mi_search_set_active(self._h, tree, int(active)):
             raise ValueError(_capi.last_error())

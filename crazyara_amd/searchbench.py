@@ -14,14 +14,18 @@ from . import replicas, search
 
 
 def timed_search_leg(st, nets: Sequence, positions: List[Tuple[str, bool, str]], trees: int, simulations: int, threads: int,
-                     min_seconds: float = 1.0, repeats: int = 3, warmup_simulations: int = 200, offset: int = 0) -> dict:
-    """positions: (fen, is960, variant) triples; tree i of round r starts from positions[(offset + r * trees + i) % len]."""
+                     min_seconds: float = 1.0, repeats: int = 3, warmup_simulations: int = 200, offset: int = 0,
+                     shared_collectors: int = 0) -> dict:
+    """positions: (fen, is960, variant) triples; tree i of round r starts from positions[(offset + r * trees + i) % len].
+    shared_collectors >= 1: every tree is searched by that many collectors in every lane (SearchThreads sharing a tree)."""
     pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1] if len(nets) > 1 else None)
     for n in nets[2:]:
         pool.add_lane(n)
     for i in range(trees):
         f, is960, variant = positions[(offset + i) % len(positions)]
         pool.add_position(f, is960, variant)
+    if shared_collectors:
+        pool.set_shared_collectors(shared_collectors)
     pool.run(simulations=min(warmup_simulations, simulations), threads=threads)       # untimed: worker threads, allocator, clocks
     cursor = offset
     reps = []
@@ -54,7 +58,7 @@ def timed_search_leg(st, nets: Sequence, positions: List[Tuple[str, bool, str]],
             "nodes_per_sec_repeats": [round(v, 1) for v in nps], "statistic": f"median of {len(reps)} repeats",
             "mcts_nn_evals_per_sec": round(r["evals"] / r["seconds"], 1), "simulations_per_sec": round(r["simulations"] / r["seconds"], 1),
             "seconds": round(r["seconds"], 3), "rounds": r["rounds"], "trees_per_gpu": trees, "simulations_per_tree": simulations,
-            "lanes": len(nets), "batch": batch, "host_threads_per_gpu": threads,
+            "lanes": len(nets), "batch": batch, "host_threads_per_gpu": threads, "collectors_per_tree_and_lane": shared_collectors or None,
             "avg_batch_fill": round(r["evals"] / max(1, r["batches"]) / batch, 3), "depth_avg": round(r["depth_avg"], 2),
             "depth_max": r["depth_max"],
             "host_cgroup_throttled_ms_during_search": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 2),

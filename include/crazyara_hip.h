@@ -226,6 +226,14 @@ int mi_search_best_move(mi_search* sp, int tree, char* uci, int cap);
 /* the whole Node::get_mcts_policy vector of the root (EvalInfo::policyProbSmall, one entry per expanded child in the order of
  * mi_search_root_children) and the Q value of the best move (EvalInfo::bestMoveQ); returns the number of entries or -1 */
 int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, float* best_move_q);
+/* One tree, many collectors: the reference runs `Threads` SearchThreads on ONE tree (engine/src/uci/crazyara.cpp:555-561,734;
+ * searchthread.cpp:403-416; per-node mutex node.h:100) -- the case of a single UCI `go`.  k >= 1 gives every tree k collectors in
+ * EVERY lane: a lane's batch is the concatenation of its collectors' mini-batches (batch / (k * trees) leaves each), collected in
+ * parallel by the threads of mi_search_run under per-node locks, virtual loss keeping the descents apart; results are applied and
+ * the next leaves collected while the other lanes' batches are on the GPU.  k = 0 (default): one collector per tree, each tree in
+ * one lane, no locks (many trees fill the batches instead).  With more than one collector per tree the trees are no longer a
+ * deterministic function of the seed (thread timing), exactly as in the reference.  Call between runs. */
+int mi_search_set_shared_collectors(mi_search* sp, int k);
 /* the whole tree as a flat word list, for inspection and the parity tests (the reference's counterpart: MCTSAgent::export_search_tree,
  * mctsagent.cpp:420-448): depth-first preorder over the expanded children, one record per node that was selected at least once:
  * [n_expanded, visit_sum, real_visits, free_visits, node_type, end_in_ply, terminal, float bits of value], then per expanded child

@@ -7,7 +7,7 @@ name=$1; shift
 python -c "from crazyara_amd import build; build.build()" >/dev/null
 mkdir -p crazyara_amd/lib/variants
 obj=crazyara_amd/build/variant_$name.o
-(cd /tmp && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result "$@" -x hip -c /root/repo/crazyara_amd/csrc/nn/tower.hip -o /root/repo/$obj)
+(cd /tmp && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -DCRA_DEVELOPMENT "$@" -x hip -c /root/repo/crazyara_amd/csrc/nn/tower.hip -o /root/repo/$obj)
 objs=$(ls crazyara_amd/build/*.o | grep -v variant_ | grep -v nn_tower.hip.o)
 hipcc --offload-arch=gfx950 -shared -fPIC -o crazyara_amd/lib/variants/$name.so $objs $obj -lpthread
 echo built crazyara_amd/lib/variants/$name.so

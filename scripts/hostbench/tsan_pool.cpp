@@ -52,6 +52,36 @@ int main() {
         }
         pool.set_active(1, round == 0);
     }
+    // one tree, many collectors (the reference's SearchThreads on one tree): per-node locks, CHILD_PENDING expansion, atomics on the
+    // fields other nodes' owners read -- two lanes x 4 collectors on 8 threads, solver and exploration on, tree reuse in between
+    {
+        SearchPool shared(s, make_callback_evaluator(eval, nullptr, 64, 5184), make_callback_evaluator(eval, nullptr, 64, 5184));
+        shared.add_position(p);
+        chess::Position mate;
+        mate.set("4R2b/1N3rkb/1p2P1pp/p2P4/2P1P3/8/PP4Q1/3R3K[QRBBNNNPPPPpp] w - - 2 53", false, chess::V_CRAZYHOUSE);
+        shared.add_position(mate);
+        shared.set_shared_collectors(4);
+        for (int round = 0; round < 3; ++round) {
+            shared.run(1500 * (round + 1), 0, 8, &st);
+            std::printf("shared round %d: %llu nodes, %llu batches, root visits %u / %u\n", round, (unsigned long long)st.nodes,
+                        (unsigned long long)st.batches, shared.tree(0).root_visits(), shared.tree(1).root_visits());
+            const int best = shared.tree(0).best_move_index();
+            if (best >= 0) shared.tree(0).apply_move(shared.tree(0).root().actions[size_t(best)]);
+        }
+        // visit conservation after quiescence
+        std::vector<uint32_t> words;
+        shared.tree(0).dump(words);
+        for (size_t i = 0; i < words.size();) {
+            const uint32_t m = words[i], visit_sum = words[i + 1];
+            uint32_t sum = 0;
+            for (uint32_t c = 0; c < m; ++c) {
+                sum += words[i + 8 + 6 * c + 1];
+                if (words[i + 8 + 6 * c + 2] != 0) { std::printf("virtual loss left behind\n"); return 1; }
+            }
+            if (sum != visit_sum) { std::printf("visit counts do not add up\n"); return 1; }
+            i += 8 + 6 * m;
+        }
+    }
     std::printf("done\n");
     return 0;
 }

@@ -599,3 +599,92 @@ def test_run_survives_a_failing_evaluator(hip_lib, capsys):
     assert s2.depth_avg > 0 and s2.depth_max >= 1                  # depth statistics are per run
     pool.close()
     fresh.close()
+
+
+def _check_tree_invariants(words, allow_virtual=False):
+    """Walks a mi_search_tree_dump: per node the children's visits add up to the node's visit counter, no virtual loss is left,
+    every record is reachable exactly once.  Returns (records, total visits below the root)."""
+    i, records = 0, 0
+    root_visits = None
+    while i < len(words):
+        m, visit_sum, real_visits = int(words[i]), int(words[i + 1]), int(words[i + 2])
+        child = words[i + 8:i + 8 + 6 * m].reshape(m, 6)
+        assert int(child[:, 1].sum()) == visit_sum, (records, child[:, 1], visit_sum)
+        if not allow_virtual:
+            assert not child[:, 2].any()                               # virtual-loss counters are back to zero
+        assert set(np.unique(child[:, 5])) <= {0, 1, 2}
+        assert ((child[:, 5] == 0) <= (child[:, 1] == 0)).all()        # no node yet -> no visits through that move
+        if root_visits is None:
+            root_visits = visit_sum
+        records += 1
+        i += 8 + 6 * m
+    assert i == len(words)
+    return records, root_visits
+
+
+@pytest.mark.parametrize("k,threads", [(2, 1), (4, 4), (8, 8)])
+def test_shared_tree_many_collectors_keeps_the_tree_consistent(hip_lib, k, threads):
+    """One tree, k collectors (the reference's Threads SearchThreads on one tree, crazyara.cpp:555-561): per-node locks and virtual
+    loss; after the run no virtual loss is left, every node's child visits add up, the limit is met, terminals and mates are found."""
+    nbp = NB_POLICY[0]
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    st = search.default_settings(mode=0, version_major=1, batch_size=8)
+    for fen in ("", "4R2b/1N3rkb/1p2P1pp/p2P4/2P1P3/8/PP4Q1/3R3K[QRBBNNNPPPPpp] w - - 2 53"):
+        pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=32, fn_nb_policy=nbp)
+        t = pool.add_position(fen, False, "crazyhouse")
+        pool.set_shared_collectors(k)
+        stats = pool.run(simulations=600, threads=threads)
+        info = pool.tree_info(t)
+        records, root_visits = _check_tree_invariants(pool.tree_dump(t))
+        assert root_visits == info["root_visits"] >= 600 or pool.root_solved(t)["node_type"] != 6
+        assert stats.simulations == info["root_visits"] and stats.nodes == info["node_count"] and records > 50
+        assert pool.best_move(t) in env.Position(fen, False, "crazyhouse").legal_uci()
+        # a second go on the kept tree, then a played move with tree reuse: the shared tree goes through the same life cycle
+        pool.run(simulations=900, threads=threads)
+        _check_tree_invariants(pool.tree_dump(t))
+        pool.apply_move(t, pool.best_move(t))
+        pool.run(simulations=400, threads=threads)
+        _check_tree_invariants(pool.tree_dump(t))
+        pool.close()
+
+
+def test_shared_tree_with_one_collector_is_the_plain_tree(hip_lib):
+    nbp = NB_POLICY[0]
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    st = search.default_settings(mode=0, version_major=1, batch_size=8)
+    dumps = []
+    for k in (None, 0):
+        pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=8, fn_nb_policy=nbp)
+        t = pool.add_position("", False, "crazyhouse")
+        if k is not None:
+            pool.set_shared_collectors(2)
+            pool.set_shared_collectors(0)                           # back to one collector: locks off, same arithmetic
+        pool.run(simulations=300, threads=2)
+        dumps.append(pool.tree_dump(t))
+        pool.close()
+    assert np.array_equal(dumps[0], dumps[1])
+
+
+def test_shared_tree_finds_the_mate_with_the_solver(hip_lib):
+    nbp = NB_POLICY[1]
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    st = search.default_settings(mode=1, version_major=3, batch_size=8)
+    pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=32, fn_nb_policy=nbp)
+    t = pool.add_position("6k1/5ppp/8/8/8/8/8/R3K3 w - - 0 1", False, "chess")
+    pool.set_shared_collectors(4)
+    pool.run(simulations=2000, threads=4)
+    assert pool.root_solved(t)["node_type"] == mo.NT_WIN and pool.best_move(t) == "a1a8"
+    _check_tree_invariants(pool.tree_dump(t), allow_virtual=True)       # a proven root ends the search with batches still applied
+    pool.close()

@@ -141,8 +141,8 @@ def test_fp16_weights_and_pruned_plys_branch(lib, tmp_path):
 
 
 def test_python_reader_sees_the_same_graph(lib):
-    """crazyara_amd/onnx_reader.py (inspection tool) decodes the exporter's file: same initializers as the C++ importer consumed."""
-    from crazyara_amd.onnx_reader import read_onnx
+    """tests/onnx_reader.py (a second, independent decoder of the wire format, test-side only) decodes the exporter's file: same initializers as the C++ importer consumed."""
+    from onnx_reader import read_onnx
     cfg, seed, fname, _, _ = onnx_cases.unpack("mobile-se-wdlp")
     g = read_onnx(os.path.join(ONNX_DIR, fname))
     assert g.producer == "pytorch" and [v.name for v in g.inputs] == ["data"] and g.inputs[0].shape == ["batch_size", 12, 8, 8]

@@ -149,3 +149,30 @@ def test_selfplay_loop_on_the_gpu_chess960(tmp_path, hip_lib):
     pool.close()
     for n in (a, b, raw):
         n.close()
+
+
+def test_one_tree_many_collectors_on_the_gpu(tmp_path, hip_lib):
+    """The single-`go` mode on real lanes: ONE tree, two nets in flight, 4 collectors per lane collecting in parallel under per-node
+    locks (the reference: Threads SearchThreads on one tree, crazyara.cpp:555-561).  The tree stays consistent (no virtual loss left,
+    child visits add up), the limit is met and the move is legal; one collector per lane on one thread is still a valid search."""
+    from test_mcts import _check_tree_invariants
+    cfg, sd, _ = nn_cases.make_case("risev2-3")
+    d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
+    a, b = HipAPI(0, 64, d, "float16"), HipAPI(0, 64, d, "float16")
+    st = search.default_settings(mode=0, version_major=1)
+    for k, threads in ((4, 8), (1, 1)):
+        pool = search.SearchPool(st, net_a=a, net_b=b)
+        t = pool.add_position("", False, "crazyhouse")
+        pool.set_shared_collectors(k)
+        stats = pool.run(simulations=3000, threads=threads)
+        info = pool.tree_info(t)
+        records, root_visits = _check_tree_invariants(pool.tree_dump(t))
+        assert root_visits == info["root_visits"] >= 3000 and stats.nodes == info["node_count"] and records > 200
+        assert stats.nn_evals / max(1, stats.batches) > (32 if k == 4 else 8)          # batches are filled from one tree
+        assert pool.best_move(t) in env.Position("", False, "crazyhouse").legal_uci()
+        pool.apply_move(t, pool.best_move(t))
+        pool.run(simulations=3000, threads=threads)
+        _check_tree_invariants(pool.tree_dump(t))
+        pool.close()
+    a.close()
+    b.close()

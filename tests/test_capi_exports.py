@@ -47,3 +47,10 @@ def test_header_is_plain_c99_and_struct_layouts_match_the_python_binding(hip_lib
     assert chk.cra_offsetof_settings_virtual_offset_strength() == search.SearchSettingsC.virtual_offset_strength.offset
     assert chk.cra_offsetof_settings_version_minor() == search.SearchSettingsC.version_minor.offset
     assert chk.cra_offsetof_stats_depth_max() == search.SearchStatsC.depth_max.offset
+
+
+def test_integration_md_quotes_the_compiled_shim_verbatim():
+    """INTEGRATION.md section 2 must be the file that is compiled against the reference (integration/hipapi.h), not a paraphrase."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shim = open(os.path.join(ROOT, "integration", "hipapi.h")).read()
+    assert "```cpp\n" + shim + "```" in md

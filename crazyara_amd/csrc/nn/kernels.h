@@ -188,8 +188,9 @@ template <typename T> void launch_depthwise(const T* x, T* y, const float* w, co
 
 // squeeze-excitation, in place on x [B][64][C].  kind 1 = ca_se: w1t [C][C/2], w2t [C/2][C] (both transposed, no bias);
 // kind 2 = eca_se: w1t [C][C] transposed centre tap, b1 [C].  hard-sigmoid gate (builder_util.py:452).
-template <typename T> void launch_se(T* x, int kind, const float* w1t, const float* w2t, const float* b1, int batch, int C,
-                                     hipStream_t s);
+// kind_flags: 1 ca_se / se, 2 eca_se, + 16 plain sigmoid; res: optional shortcut, x = relu(res + x * gate)
+template <typename T> void launch_se(T* x, int kind_flags, const float* w1t, const float* w2t, const float* b1, int batch, int C,
+                                     hipStream_t s, const T* res = nullptr);
 
 // SE gate MLP on pooled sums (the squeeze already happened in the producer's epilogue): gate[b][c] = hard_sigmoid(...)
 //  kind 1 (ca_se):  relu(W1 mean) -> W2 -> hard-sigmoid   w1t [C][C/2], w2t [C/2][C]

@@ -183,9 +183,16 @@ template void launch_depthwise<float>(const float*, float*, const float*, const 
 // Squeeze-excitation gate, in place.  One workgroup per board.
 // ================================================================================================================
 
+// kind: 1 ca_se / se (two bias-free FCs), 2 eca_se (centre-tap linear + bias); + 16 = plain sigmoid instead of hard-sigmoid
+// (AlphaZero's ResidualBlock builds its gate with use_hard_sigmoid=False, a0_resnet.py:95).  res != nullptr: the gated tensor is the
+// body of a residual block and the shortcut is added here: x = relu(res + x * gate) (a0_resnet.py:104-107).
 template <typename T>
-__global__ __launch_bounds__(256) void se_kernel(T* __restrict__ x, int kind, const float* __restrict__ w1t,
-                                                 const float* __restrict__ w2t, const float* __restrict__ b1, int C) {
+__global__ __launch_bounds__(256) void se_kernel(T* __restrict__ x, int kind_flags, const float* __restrict__ w1t,
+                                                 const float* __restrict__ w2t, const float* __restrict__ b1, int C,
+                                                 const T* __restrict__ res) {
+    const int kind = kind_flags & 15;
+    const bool plain_sigmoid = (kind_flags & 16) != 0;
+    auto gate_act = [&](float v) { return plain_sigmoid ? 1.f / (1.f + expf(-v)) : hard_sigmoid(v); };
     __shared__ float s_mean[512];
     __shared__ float s_h[512];
     __shared__ float s_y[512];
@@ -208,23 +215,30 @@ __global__ __launch_bounds__(256) void se_kernel(T* __restrict__ x, int kind, co
         for (int c = tid; c < C; c += 256) {
             float sum = 0.f;
             for (int j = 0; j < H; ++j) sum = fmaf(w2t[size_t(j) * C + c], s_h[j], sum);
-            s_y[c] = hard_sigmoid(sum);
+            s_y[c] = gate_act(sum);
         }
     } else {
         for (int c = tid; c < C; c += 256) {
             float sum = b1[c];
             for (int i = 0; i < C; ++i) sum = fmaf(w1t[size_t(i) * C + c], s_mean[i], sum);
-            s_y[c] = hard_sigmoid(sum);
+            s_y[c] = gate_act(sum);
         }
     }
     __syncthreads();
     const int nvec = kSquares * C / 8;
+    const T* rb = res ? res + size_t(blockIdx.x) * kSquares * C : nullptr;
     for (int i = tid; i < nvec; i += 256) {
         const int c0 = (i * 8) % C;
         float v[8];
         load8<T>(xb + size_t(i) * 8, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= s_y[c0 + j];
+        if (rb) {
+            float r[8];
+            load8<T>(rb + size_t(i) * 8, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] + r[j], 0.f);
+        }
         store8<T>(xb + size_t(i) * 8, v);
     }
 }
@@ -326,11 +340,11 @@ void launch_se_gate(const float* pool, float* gate, int kind, const float* w1t, 
 }
 
 template <typename T>
-void launch_se(T* x, int kind, const float* w1t, const float* w2t, const float* b1, int batch, int C, hipStream_t s) {
-    hipLaunchKernelGGL((se_kernel<T>), dim3(batch), dim3(256), 0, s, x, kind, w1t, w2t, b1, C);
+void launch_se(T* x, int kind_flags, const float* w1t, const float* w2t, const float* b1, int batch, int C, hipStream_t s, const T* res) {
+    hipLaunchKernelGGL((se_kernel<T>), dim3(batch), dim3(256), 0, s, x, kind_flags, w1t, w2t, b1, C, res);
 }
-template void launch_se<half_t>(half_t*, int, const float*, const float*, const float*, int, int, hipStream_t);
-template void launch_se<float>(float*, int, const float*, const float*, const float*, int, int, hipStream_t);
+template void launch_se<half_t>(half_t*, int, const float*, const float*, const float*, int, int, hipStream_t, const half_t*);
+template void launch_se<float>(float*, int, const float*, const float*, const float*, int, int, hipStream_t, const float*);
 
 // ================================================================================================================
 // Value head: conv1x1(C->cv)+BN+ReLU -> channel-major flatten -> FC(fc)+ReLU -> FC(1) -> tanh

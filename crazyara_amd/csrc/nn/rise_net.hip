@@ -210,9 +210,12 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     const std::string conv_block = nf.str("conv_block", "mobile_bottlekneck_res_block");
     const bool dense_blocks = conv_block == "classical_res_block" || conv_block == "a0_res_block";
     if (!dense_blocks && conv_block != "mobile_bottlekneck_res_block") throw std::runtime_error("unsupported conv_block '" + conv_block + "'");
+    // SE inside dense residual blocks (ClassicalResidualBlock(se_type), builder_util.py:401-434: gate on the block INPUT, hard-sigmoid;
+    // AlphaZero ResidualBlock(use_se), a0_resnet.py:72-107: gate on the body OUTPUT, plain sigmoid): such nets run their blocks on the
+    // layer kernels (conv GEMM + SE kernel), not on the one-launch dense tower
+    bool dense_se = false;
     if (dense_blocks)
-        for (const std::string& t : se_types)
-            if (t != "none") throw std::runtime_error("SE inside dense residual blocks is not supported");
+        for (const std::string& t : se_types) dense_se |= !(t == "none" || t.empty());
     if (C % 64 != 0 || C > 512) throw std::runtime_error("channels must be a multiple of 64 and <= 512");
     if (fc > 256 && fc % 256 != 0) throw std::runtime_error("unsupported value_fc_size");
 
@@ -329,7 +332,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     const float* pending_gate = nullptr;
     int prod_op = -1;                 // last op that produced the residual stream and can emit its channel sums
     constexpr bool kHalf = std::is_same<T, half_t>::value;
-    const bool tower_ok = tower_ && fused_ && kHalf && C == 256;
+    const bool tower_ok = tower_ && fused_ && kHalf && C == 256 && !dense_se;
     std::vector<TowerBlockDesc> tower_blocks;
     std::vector<half_t> tower_ws[4];          // per matrix wave: MFMA A fragments in consumption order (kernels.h: TowerArgs)
     std::vector<float> tower_bs[4];
@@ -460,12 +463,55 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             std::swap(cur, nxt);
         }
     }
+    // gate of a dense block as an in-place SE op on `target` (+ optional shortcut `res`: target = relu(res + target * gate))
+    auto dense_se_op = [&](const std::string& p, const std::string& type, T* target, const T* res, bool plain_sigmoid) {
+        Op op;
+        op.kind = OpKind::SE;
+        op.C = C;
+        op.y = target;
+        op.x = res;
+        if (type == "ca_se" || type == "se") {
+            const TensorView &w1 = nf.get(p + ".se.fc.0.weight"), &w2 = nf.get(p + ".se.fc.2.weight");
+            const int H = C / 2;
+            std::vector<float> w1t(size_t(C) * H), w2t(size_t(H) * C);
+            for (int j = 0; j < H; ++j) for (int c = 0; c < C; ++c) w1t[size_t(c) * H + j] = w1.data[size_t(j) * C + c];
+            for (int c = 0; c < C; ++c) for (int j = 0; j < H; ++j) w2t[size_t(j) * C + c] = w2.data[size_t(c) * H + j];
+            op.se_kind = 1;
+            op.w0 = im.upload(w1t);
+            op.w1 = im.upload(w2t);
+            macs += 2.0 * C * H;
+        } else if (type == "eca_se") {
+            const TensorView& w = nf.get(p + ".se.body.0.weight");
+            const int kk = int(w.shape[2]), mid = kk / 2;
+            std::vector<float> wt(size_t(C) * C), b(C);
+            for (int o = 0; o < C; ++o) for (int c = 0; c < C; ++c) wt[size_t(c) * C + o] = w.data[(size_t(o) * C + c) * kk + mid];
+            const float* bs = nf.get(p + ".se.body.0.bias").data;
+            for (int o = 0; o < C; ++o) b[o] = bs[o];
+            op.se_kind = 2;
+            op.w0 = im.upload(wt);
+            op.b0 = im.upload(b);
+            macs += double(C) * C;
+        } else {
+            throw std::runtime_error("unsupported se_type " + type);
+        }
+        if (plain_sigmoid) op.se_kind |= 16;
+        im.ops.push_back(op);
+    };
     for (size_t i = 0; dense_blocks && !tower_ok && i < cops.size(); ++i) {
         // x -> conv3x3 + BN + ReLU -> conv3x3 + BN -> classical: x + ReLU(.)   a0: ReLU(x + .)
         const std::string p = "body_spatial." + std::to_string(i + 1);
+        const bool gated = !(se_types[i] == "none" || se_types[i].empty());
+        const bool a0 = conv_block == "a0_res_block";
+        if (gated && !a0) dense_se_op(p, se_types[i], cur, nullptr, false);       // classical: x = se(x) first (builder_util.py:431-433)
         add_conv(p + ".body.0", p + ".body.1", cur, nxt, nullptr, C, C, C, 3, 1, nullptr);
         T* out = e;                                   // e: scratch of at least C channels per square
-        add_conv(p + ".body.3", p + ".body.4", nxt, out, cur, C, C, C, 3, conv_block == "classical_res_block" ? 2 : 1, nullptr);
+        if (gated && a0) {
+            // out = BN(conv(.)) without shortcut, then out = relu(x + se(out)) in the gate kernel (a0_resnet.py:104-107)
+            add_conv(p + ".body.3", p + ".body.4", nxt, out, nullptr, C, C, C, 3, 0, nullptr);
+            dense_se_op(p, se_types[i], out, cur, true);
+        } else {
+            add_conv(p + ".body.3", p + ".body.4", nxt, out, cur, C, C, C, 3, conv_block == "classical_res_block" ? 2 : 1, nullptr);
+        }
         // keep (cur, nxt) = (block output, scratch): rotate the three buffers
         T* old = cur;
         cur = out;
@@ -947,7 +993,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
         case OpKind::Depthwise:
             launch_depthwise<T>(static_cast<const T*>(op.x), static_cast<T*>(op.y), op.w0, op.b0, B, op.C, op.ks, s);
             break;
-        case OpKind::SE: launch_se<T>(static_cast<T*>(op.y), op.se_kind, op.w0, op.w1, op.b0, B, op.C, s); break;
+        case OpKind::SE: launch_se<T>(static_cast<T*>(op.y), op.se_kind, op.w0, op.w1, op.b0, B, op.C, s, static_cast<const T*>(op.x)); break;
         case OpKind::ValueHead: {
             ValueHeadArgs v = op.vh;
             v.value = value;

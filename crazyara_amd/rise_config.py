@@ -93,19 +93,24 @@ def rise_v33_config(nb_input_channels: int = 52, channels_policy_head: int = 76,
                       name="risev3.3" + ("-wdlp" if wdlp else ""))
 
 
-def rise_classical_config(n_blocks: int = 19, nb_input_channels: int = 34, channels_policy_head: int = 81) -> RiseConfig:
-    """RiseV3(conv_block="classical_res_block"): a tower of dense 3x3 residual blocks (rise_mobile_v3.py:71-72)."""
+def rise_classical_config(n_blocks: int = 19, nb_input_channels: int = 34, channels_policy_head: int = 81,
+                          se_types: Optional[List[Optional[str]]] = None) -> RiseConfig:
+    """RiseV3(conv_block="classical_res_block"): a tower of dense 3x3 residual blocks (rise_mobile_v3.py:71-72).  se_types[i] gates the
+    INPUT of block i (hard-sigmoid), ClassicalResidualBlock.forward, builder_util.py:425-434."""
     return RiseConfig(nb_input_channels=nb_input_channels, channels=256, channels_operating_init=256, channel_expansion=0,
-                      kernels=[3] * n_blocks, se_types=[None] * n_blocks, channels_policy_head=channels_policy_head,
-                      conv_block="classical_res_block", name=f"rise-classical-{n_blocks}")
+                      kernels=[3] * n_blocks, se_types=list(se_types) if se_types else [None] * n_blocks,
+                      channels_policy_head=channels_policy_head,
+                      conv_block="classical_res_block", name=f"rise-classical-{n_blocks}" + ("-se" if se_types else ""))
 
 
 def alpha_zero_config(n_blocks: int = 19, nb_input_channels: int = 34, channels_policy_head: int = 81,
-                      channels_value_head: int = 4) -> RiseConfig:
-    """AlphaZeroResnet as get_alpha_zero_model builds it (a0_resnet.py:172-183): 19 blocks, value head 4 channels."""
+                      channels_value_head: int = 4, use_se: bool = False) -> RiseConfig:
+    """AlphaZeroResnet as get_alpha_zero_model builds it (a0_resnet.py:172-183): 19 blocks, value head 4 channels.  use_se: every
+    ResidualBlock gates its body OUTPUT with get_se("se", use_hard_sigmoid=False) before the shortcut (a0_resnet.py:94-107)."""
     return RiseConfig(nb_input_channels=nb_input_channels, channels=256, channels_operating_init=256, channel_expansion=0,
-                      kernels=[3] * n_blocks, se_types=[None] * n_blocks, channels_value_head=channels_value_head,
-                      channels_policy_head=channels_policy_head, conv_block="a0_res_block", name=f"alphazero-{n_blocks}")
+                      kernels=[3] * n_blocks, se_types=(["se"] if use_se else [None]) * n_blocks, channels_value_head=channels_value_head,
+                      channels_policy_head=channels_policy_head, conv_block="a0_res_block",
+                      name=f"alphazero-{n_blocks}" + ("-se" if use_se else ""))
 
 
 def eca_kernel(channels: int, gamma: int = 2, b: int = 1) -> int:
@@ -170,8 +175,14 @@ def make_state_dict(cfg: RiseConfig, seed: int = 0, stress: bool = True) -> Dict
     for i, (k, cop, se) in enumerate(zip(cfg.kernels, cfg.channels_operating(), cfg.se_types)):
         p = f"{pre}.{i + 1}"
         if cfg.dense_blocks:
-            if se is not None:
-                raise ValueError("SE inside dense residual blocks is not supported")
+            if se in ("ca_se", "se"):
+                linear(p + ".se.fc.0", C // 2, C, bias=False)
+                linear(p + ".se.fc.2", C, C // 2, bias=False, gain=2.0)
+            elif se == "eca_se":
+                kk = eca_kernel(C)
+                w = rng.standard_normal((C, C, kk)) * (2.0 * math.sqrt(2.0 / C) if stress else 1.0 / math.sqrt(C * kk))
+                sd[p + ".se.body.0.weight"] = torch.tensor(w, dtype=torch.float32)
+                sd[p + ".se.body.0.bias"] = torch.tensor(rng.normal(0, 0.5 if stress else 0.01, C), dtype=torch.float32)
             conv(p + ".body.0", C, C, 3)
             bn(p + ".body.1", C)
             conv(p + ".body.3", C, C, 3)

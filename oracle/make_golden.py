@@ -40,7 +40,8 @@ def reference_model(RiseV3, cfg):
                                channels_value_head=cfg.channels_value_head, channels_policy_head=cfg.channels_policy_head,
                                num_res_blocks=n, value_fc_size=cfg.value_fc_size, act_type="relu",
                                select_policy_from_plane=cfg.select_policy_from_plane,
-                               use_wdl=cfg.use_wdl, use_plys_to_end=cfg.use_plys_to_end, use_mlp_wdl_ply=False, use_se=False).eval()
+                               use_wdl=cfg.use_wdl, use_plys_to_end=cfg.use_plys_to_end, use_mlp_wdl_ply=False,
+                               use_se=any(t is not None for t in cfg.se_types)).eval()
     return RiseV3(nb_input_channels=cfg.nb_input_channels, board_height=8, board_width=8, channels=cfg.channels,
                   channels_operating_init=cfg.channels_operating_init, channel_expansion=cfg.channel_expansion,
                   act_types=["relu"] * n, channels_value_head=cfg.channels_value_head, value_fc_size=cfg.value_fc_size,

@@ -18,6 +18,8 @@ Follows (reference file:line, relative to /root/reference):
   * softmax contract of predict() ........ engine/src/nn/tensorrtapi.cpp:378-392, engine/src/nn/neuralnetapi.cpp:241-260
   * ClassicalResidualBlock ............... builder_util.py:401-434 (second activation INSIDE the body, plain add)
   * AlphaZeroResnet / ResidualBlock ...... pytorch/a0_resnet.py:72-183 (activation AFTER the add; state-dict prefix "body.")
+  * SE inside the dense blocks ........... ClassicalResidualBlock(se_type): gate on the block INPUT, hard-sigmoid (builder_util.py:416,431-433);
+                                           ResidualBlock(use_se): gate on the body OUTPUT, plain sigmoid (a0_resnet.py:94-95,104-106)
 
 Pinning: `oracle/make_golden.py` (run in the build container where /root/reference exists) loads the SAME
 state dicts into the imported reference model and stores (input, value, policy logits, aux) under tests/golden/;
@@ -65,11 +67,24 @@ def forward(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, sim_d
     for i, (k, se) in enumerate(zip(cfg.kernels, cfg.se_types)):
         p = f"{pre}.{i + 1}"
         if cfg.dense_blocks:
+            def gate(z, hard):                           # get_se(...): _ChannelAttentionModule / _EfficientChannelAttentionModule
+                y = z.mean(dim=(2, 3))
+                if se in ("ca_se", "se"):
+                    y = F.linear(F.relu(F.linear(y, sd[p + ".se.fc.0.weight"])), sd[p + ".se.fc.2.weight"])
+                else:
+                    w = sd[p + ".se.body.0.weight"]
+                    y = F.conv1d(y[:, :, None], w, sd[p + ".se.body.0.bias"], padding=w.shape[2] // 2)[:, :, 0]
+                y = F.hardsigmoid(y) if hard else torch.sigmoid(y)
+                return z * y[:, :, None, None]
+            if se is not None and cfg.conv_block == "classical_res_block":
+                h = _q(gate(h, True), sim_dtype)         # builder_util.py:431-433: x = se(x) (use_hard_sigmoid=True, :416)
             t = _q(F.relu(_bn(sd, p + ".body.1", F.conv2d(h, W(p + ".body.0.weight"), padding=1))), sim_dtype)
             t = _bn(sd, p + ".body.4", F.conv2d(t, W(p + ".body.3.weight"), padding=1))
             if cfg.conv_block == "classical_res_block":
                 h = _q(h + F.relu(t), sim_dtype)         # builder_util.py:413-418,434: act is the body's last module
             else:
+                if se is not None:
+                    t = gate(_q(t, sim_dtype), False)    # a0_resnet.py:94-95,104-106: out = se(out), use_hard_sigmoid=False
                 h = _q(F.relu(h + t), sim_dtype)         # a0_resnet.py:104-107: final_act(x + out)
             if taps is not None:
                 taps[f"block{i}"] = h
@@ -129,6 +144,10 @@ def flops_per_position(cfg: RiseConfig) -> float:
     for k, cop, se in zip(cfg.kernels, cfg.channels_operating(), cfg.se_types):
         if cfg.dense_blocks:
             macs += 2 * 64 * C * C * 9
+            if se in ("ca_se", "se"):
+                macs += 2 * C * (C // 2)
+            elif se == "eca_se":
+                macs += C * C
             continue
         macs += 64 * C * cop * 2 + 64 * cop * k * k
         if se in ("ca_se", "se"):

@@ -44,6 +44,10 @@ CASES = {
     "rise-classical-4": (lambda: ro.rise_classical_config(4, 34, 81), 19, True, 4),
     "alphazero-5": (lambda: ro.alpha_zero_config(5, 52, 76, 4), 20, True, 4),
     "alphazero-3-cv8": (lambda: ro.alpha_zero_config(3, 34, 81, 8), 21, True, 3),
+    # SE gates inside the dense blocks: on the block input with hard-sigmoid (ClassicalResidualBlock(se_type)), on the body output with
+    # plain sigmoid (AlphaZero ResidualBlock(use_se))
+    "rise-classical-3-se": (lambda: ro.rise_classical_config(3, 34, 81, se_types=[None, "ca_se", "eca_se"]), 23, True, 4),
+    "alphazero-3-se": (lambda: ro.alpha_zero_config(3, 34, 81, 4, use_se=True), 24, True, 4),
     # flat-label policy head (select_policy_from_plane=False): Linear(P*64 -> 2272 crazyhouse labels)
     "risev2-3-flat": (small_risev2_flat, 22, True, 5),
 }

@@ -86,6 +86,14 @@ SIGNATURES = {
     "mi_search_add_lane": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi_search_root_solved": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mi_search_best_move": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
+    "mi_traindata_create": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint]),
+    "mi_traindata_destroy": (None, [C.c_void_p]),
+    "mi_traindata_new_game": (C.c_int, [C.c_void_p]),
+    "mi_traindata_save_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_float]),
+    "mi_search_save_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mi_traindata_export_game_samples": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint)]),
+    "mi_traindata_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mi_search_set_shared_collectors": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_search_tree_dump": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_long]),
 }

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "capi_common.h"
+#include "capi_traindata.h"
 #include "chess/planes_host.h"
 #include "chess/policy.h"
 #include "chess/position.h"
@@ -169,6 +170,50 @@ int mi_pos_policy_index(const mi_pos* pos, uint32_t move, int mode, int is_polic
     if (!pos) return n;
     cra_guard([&] { n = policy_index(policy_tables(mode), pos->pos, move, is_policy_map != 0); });
     return n;
+}
+
+// ---- training-sample exporter (engine/src/rl/traindataexporter.cpp) ----
+mi_traindata* mi_traindata_create(const char* path, int mode, int version_major, int version_minor, unsigned number_chunks, unsigned chunk_size) {
+    mi_traindata* t = nullptr;
+    if (cra_guard([&] {
+            if (!path || !*path) throw std::invalid_argument("mi_traindata_create: empty path");
+            t = new mi_traindata(path, mode, version_major, version_minor, number_chunks, chunk_size);
+        })) {
+        return nullptr;
+    }
+    return t;
+}
+void mi_traindata_destroy(mi_traindata* t) { delete t; }
+int mi_traindata_new_game(mi_traindata* t) {
+    if (!t) { cra_set_error("null exporter"); return 1; }
+    return cra_guard([&] { t->exp.new_game(); });
+}
+int mi_traindata_save_sample(mi_traindata* t, const mi_pos* pos, const uint32_t* moves, int n_moves, const double* policy, int n_policy,
+                             float best_move_q) {
+    if (!t || !pos || (n_moves > 0 && !moves) || (n_policy > 0 && !policy)) { cra_set_error("null argument"); return 1; }
+    return cra_guard([&] {
+        std::vector<Move> mv(moves, moves + n_moves);
+        t->exp.save_sample(pos->pos, mv, policy, size_t(n_policy), best_move_q);
+    });
+}
+int mi_traindata_export_game_samples(mi_traindata* t, int result, unsigned* written) {
+    if (!t) { cra_set_error("null exporter"); return 1; }
+    return cra_guard([&] {
+        if (result < 0 || result > 2) throw std::invalid_argument("result must be 0 DRAWN, 1 WHITE_WIN or 2 BLACK_WIN");
+        const size_t n = t->exp.export_game_samples(result);
+        if (written) *written = unsigned(n);
+    });
+}
+int mi_traindata_info(const mi_traindata* t, unsigned* number_samples, unsigned* start_index, unsigned* game_index, int* nb_labels, int* channels,
+                      int* is_full) {
+    if (!t) { cra_set_error("null exporter"); return 1; }
+    if (number_samples) *number_samples = unsigned(t->exp.get_number_samples());
+    if (start_index) *start_index = unsigned(t->exp.start_index());
+    if (game_index) *game_index = unsigned(t->exp.game_index());
+    if (nb_labels) *nb_labels = t->exp.nb_labels();
+    if (channels) *channels = t->exp.channels();
+    if (is_full) *is_full = t->exp.is_file_full() ? 1 : 0;
+    return 0;
 }
 
 }  // extern "C"

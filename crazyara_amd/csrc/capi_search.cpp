@@ -11,6 +11,7 @@
 
 #include "capi_common.h"
 #include "capi_net.h"
+#include "capi_traindata.h"
 #include "search/pool.h"
 
 using namespace cra;
@@ -228,6 +229,19 @@ long mi_search_tree_dump(mi_search* sp, int tree, uint32_t* out, long cap) {
         n = long(words.size());
     });
     return n;
+}
+
+// save_sample(state, evalInfo) of the self-play loop (selfplay.cpp:150-160) taken straight from a searched tree: the root position,
+// its legal moves in the root's order, EvalInfo::policyProbSmall (Node::get_mcts_policy, unexpanded moves 0) and bestMoveQ
+int mi_search_save_sample(mi_search* sp, int tree, mi_traindata* td) {
+    if (!sp || !td) { cra_set_error("null argument"); return 1; }
+    return cra_guard([&] {
+        Tree& t = sp->pool->tree(tree);
+        std::vector<double> pol;
+        const int b = t.best_move_index(&pol);
+        if (b < 0) throw std::logic_error("mi_search_save_sample: the tree has not been searched");
+        td->exp.save_sample(t.root_position(), t.root().actions, pol.data(), pol.size(), t.eval_best_move_q());
+    });
 }
 
 int mi_search_set_shared_collectors(mi_search* sp, int k) {

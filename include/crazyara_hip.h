@@ -246,6 +246,27 @@ int mi_search_set_active(mi_search* sp, int tree, int active);
 /* start a new game on an existing tree slot: the tree restarts from this position (clean_up / clear_game_history, selfplay.cpp:305-309) */
 int mi_search_reset_position(mi_search* sp, int tree, const char* fen, int is_chess960, const char* variant);   /* argmax of Node::get_mcts_policy, node.cpp:1070-1109 */
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training-sample exporter of the self-play loop: TrainDataExporter (engine/src/rl/traindataexporter.{h,cpp}).  One zarr
+ * (format 2) group with the arrays x int16 [N][C][8][8] (un-normalised planes), y_value int16 [N], y_policy float32 [N][NB_LABELS]
+ * (classic label index, mirrored for Black), y_best_move_q float32 [N], plys_to_end int16 [N], phase_vector int16 [N],
+ * start_indices int32 [N]; N = number_chunks * chunk_size, chunked along N, raw little-endian chunks as z5's default writes them
+ * (traindataexporter.cpp:262-283).  mode / version fix the plane layout and the label set (the reference's build flavour).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct mi_traindata mi_traindata;
+mi_traindata* mi_traindata_create(const char* path, int mode, int version_major, int version_minor, unsigned number_chunks, unsigned chunk_size);
+void mi_traindata_destroy(mi_traindata* t);
+int mi_traindata_new_game(mi_traindata* t);                                     /* new_game(), :167-171 */
+/* save_sample(pos, evalInfo), :33-47: moves = EvalInfo::legalMoves, policy = policyProbSmall (entries beyond n_policy count as 0) */
+int mi_traindata_save_sample(mi_traindata* t, const mi_pos* pos, const uint32_t* moves, int n_moves, const double* policy, int n_policy,
+                             float best_move_q);
+/* the same taken from a searched tree of a pool: root position, its moves, Node::get_mcts_policy, EvalInfo::bestMoveQ */
+int mi_search_save_sample(mi_search* sp, int tree, mi_traindata* t);
+/* export_game_samples(result), :110-134; result: 0 DRAWN, 1 WHITE_WIN, 2 BLACK_WIN (enum Result, state.h); *written = samples stored */
+int mi_traindata_export_game_samples(mi_traindata* t, int result, unsigned* written);
+int mi_traindata_info(const mi_traindata* t, unsigned* number_samples, unsigned* start_index, unsigned* game_index, int* nb_labels, int* channels,
+                      int* is_full);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,8 +135,10 @@ def test_training_samples_of_selfplay_games(hip_lib, tmp_path):
     games = loop.play(4, threads=2)
     pool.close()
     root = str(tmp_path / "data.zarr")
-    x, val, pol = (traindata.read_array(root, n) for n in ("x", "y_value", "y_policy"))
-    q, plys, start, phase = (traindata.read_array(root, n) for n in ("y_best_move_q", "plys_to_end", "start_indices", "phase_vector"))
+    import zarr_v2_reader as zr                     # an independent reader written from the zarr v2 storage specification
+    assert zr.open_group(root) == sorted(["x", "y_value", "y_policy", "y_best_move_q", "plys_to_end", "phase_vector", "start_indices"])
+    x, val, pol = (zr.read_array(root, n) for n in ("x", "y_value", "y_policy"))
+    q, plys, start, phase = (zr.read_array(root, n) for n in ("y_best_move_q", "plys_to_end", "start_indices", "phase_vector"))
     assert x.shape == (256, 34, 8, 8) and x.dtype == np.int16 and pol.shape == (256, 2272) and start.dtype == np.int32
     n_total = sum(len(g.uci) - g.book_plies for g in games)
     assert loop.stats["samples"] == n_total == int(start[len(games)])
@@ -196,3 +198,64 @@ def test_arena_colour_alternation_and_scoring(hip_lib):
     # but a game is never the same when the colours are swapped unless both nets agree everywhere
     pa.close()
     pb.close()
+
+
+def test_zarr_reader_reads_what_the_specification_allows(tmp_path):
+    """The independent reader (tests/zarr_v2_reader.py) on hand-made arrays: edge chunks padded to the full chunk shape, an absent
+    chunk = fill value, Fortran chunk order, big-endian dtype, zlib codec -- none of which the exporter under test produces."""
+    import json
+    import os
+    import zlib
+    import zarr_v2_reader as zr
+    root = str(tmp_path / "g")
+    os.makedirs(os.path.join(root, "a"))
+    json.dump({"zarr_format": 2}, open(os.path.join(root, ".zgroup"), "w"))
+    want = np.arange(5 * 7, dtype=">i4").reshape(5, 7)
+    meta = {"zarr_format": 2, "shape": [5, 7], "chunks": [2, 4], "dtype": ">i4", "compressor": {"id": "zlib", "level": 1},
+            "fill_value": -3, "order": "F", "filters": None}
+    json.dump(meta, open(os.path.join(root, "a", ".zarray"), "w"))
+    for ci in range(3):
+        for cj in range(2):
+            if (ci, cj) == (1, 1):
+                continue                                            # absent chunk
+            chunk = np.full((2, 4), -3, ">i4")
+            part = want[ci * 2:ci * 2 + 2, cj * 4:cj * 4 + 4]
+            chunk[:part.shape[0], :part.shape[1]] = part
+            open(os.path.join(root, "a", f"{ci}.{cj}"), "wb").write(zlib.compress(chunk.tobytes(order="F")))
+    got = zr.read_array(root, "a")
+    exp = want.copy()
+    exp[2:4, 4:7] = -3
+    assert zr.open_group(root) == ["a"] and got.dtype == np.dtype(">i4") and np.array_equal(got, exp)
+
+
+def test_exporter_sample_from_a_searched_tree_equals_the_explicit_call(hip_lib, tmp_path):
+    """mi_search_save_sample (root position, moves, Node::get_mcts_policy, EvalInfo::bestMoveQ taken inside the library) writes the
+    rows mi_traindata_save_sample writes from the same values; a second exporter on the same path overwrites from sample 0."""
+    import zarr_v2_reader as zr
+    from crazyara_amd import traindata
+    mode = 0
+    pool = _pool(mode, 8, 8)
+    t = pool.add_position("r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] b KQkq - 0 8", False, "crazyhouse")
+    pool.run(simulations=120, threads=1)
+    a = traindata.TrainDataExporter(str(tmp_path / "a.zarr"), mode, 1, number_chunks=2, chunk_size=4)
+    b = traindata.TrainDataExporter(str(tmp_path / "b.zarr"), mode, 1, number_chunks=2, chunk_size=4)
+    moves, _, _, _ = pool.root_children(t)
+    policy, best_q = pool.root_policy(t)
+    pos = env.Position(pool.fen(t), False, "crazyhouse")
+    all_moves = moves + [m for m in pos.legal_moves() if m not in moves]      # unexpanded moves: policy 0
+    for rep in range(3):                                                      # three samples: one whole chunk is never complete
+        a.save_search_sample(pool, t)
+        b.save_sample(pos, all_moves, policy, best_q)
+    assert a.export_game_samples(traindata.BLACK_WIN) == 3 == b.export_game_samples(traindata.BLACK_WIN)
+    for name in zr.open_group(str(tmp_path / "a.zarr")):
+        assert np.array_equal(zr.read_array(str(tmp_path / "a.zarr"), name), zr.read_array(str(tmp_path / "b.zarr"), name)), name
+    pol = zr.read_array(str(tmp_path / "a.zarr"), "y_policy")
+    assert abs(float(pol[0].sum()) - 1.0) < 1e-6 and (pol[3:] == 0).all()
+    assert list(zr.read_array(str(tmp_path / "a.zarr"), "y_value")[:4]) == [1, 1, 1, 0]       # Black to move, Black won
+    assert list(zr.read_array(str(tmp_path / "a.zarr"), "plys_to_end")[:3]) == [3, 2, 1]
+    assert list(zr.read_array(str(tmp_path / "a.zarr"), "start_indices")[:2]) == [0, 3]
+    again = traindata.TrainDataExporter(str(tmp_path / "a.zarr"), mode, 1, number_chunks=2, chunk_size=4)    # "will be overwritten"
+    again.save_search_sample(pool, t)
+    assert again.export_game_samples(traindata.DRAWN) == 1
+    assert list(zr.read_array(str(tmp_path / "a.zarr"), "y_value")[:2]) == [0, 1] and again.info()["start_index"] == 1
+    pool.close()

@@ -74,6 +74,51 @@ def committed_pmc_traffic(kernel: str):
             "traffic_source": os.path.relpath(f1, os.path.dirname(root))}
 
 
+def live_pmc_traffic(kernel: str, blocks: int, batch: int, precision: str, timeout_s: int = 150):
+    """roofline.traffic measured NOW, on this box: two `rocprofv3 --pmc` passes (counters only, no trace domains) of
+    scripts/prof_forward.py -- the same network, batch and device-resident forward as the timed region -- in child processes, summed
+    per dispatch of the dominant kernel: 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for 16-byte-per-lane streaming reads on gfx950).  Returns None when rocprofv3 is missing, times out or reports nothing
+    (the caller then falls back to the newest committed pass and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None:
+        return None
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counters in (["FETCH_SIZE", "TCC_HIT_sum"], ["WRITE_SIZE", "TCC_MISS_sum"]):
+        d = tempfile.mkdtemp(prefix="cra_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.join(ROOT, "scripts", "prof_forward.py"), str(blocks), str(batch), precision, "3"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+        except (subprocess.TimeoutExpired, OSError):
+            shutil.rmtree(d, ignore_errors=True)
+            return None
+        if r.returncode != 0:
+            shutil.rmtree(d, ignore_errors=True)
+            return None
+        vals = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if f"{kernel}_kernel" in row["Kernel_Name"]:
+                    vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
+        for c in counters:
+            if c not in vals:
+                return None
+            out[c] = sum(vals[c]) / len(vals[c])
+    return {"traffic": round((2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0),
+            "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
+            "traffic_source": "live: rocprofv3 --pmc passes of scripts/prof_forward.py run by this bench.py on this box",
+            "pmc": {"FETCH_SIZE_KiB": round(out["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(out["WRITE_SIZE"], 1),
+                    "TCC_HIT_sum": round(out["TCC_HIT_sum"]), "TCC_MISS_sum": round(out["TCC_MISS_sum"]),
+                    "l2_to_cu_bytes_per_launch": round(out["TCC_HIT_sum"] * 128.0)}}
+
+
 def cpu_baseline(cfg, sd, x, budget_s=15.0):
     """Reference CPU path timed beside the GPU: the oracle restatement of the reference PyTorch model (same torch ops,
     fp32, eval, softmax included) on the host cores.  Bounded sample: whole batches of 256 until ~budget_s elapsed."""
@@ -199,6 +244,7 @@ def main():
     ap.add_argument("--search-seconds", type=float, default=1.0, help="minimum timed region of one repeat of a search leg")
     ap.add_argument("--search-repeats", type=int, default=3)
     ap.add_argument("--no-config-legs", action="store_true", help="skip the search legs of BASELINE configs 1, 3, 4, 5")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the newest committed PMC pass instead of live passes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -357,9 +403,12 @@ def main():
             net3.close()
         peak = PEAK_F16_TFLOPS if args.precision == "float16" else PEAK_F32_TFLOPS
         achieved = dom_flops / (agg[dom] * 1e-3) / 1e12
+        traffic = None if args.no_live_pmc else live_pmc_traffic(dom, args.blocks, args.batch, args.precision)
+        if traffic is None:
+            traffic = committed_pmc_traffic(dom)
         roofline = {"bound": "mfma", "kernel": dom, "launches_per_step": cnt[dom],
                     "avg_launch_ms": round(agg[dom] / cnt[dom], 5), "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), **committed_pmc_traffic(dom),
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), **traffic,
                     "whole_forward": {"event_ms_per_step": round(ev_ms, 4),
                                       "achieved": round(flops_total / (ev_ms * 1e-3) / 1e12, 2),
                                       "frac": round(flops_total / (ev_ms * 1e-3) / 1e12 / peak, 4)},

@@ -145,6 +145,9 @@ __device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds
                     nxt[0] = *reinterpret_cast<const frag*>(r0 + (s + 1) * 32);      nxt[1] = *reinterpret_cast<const frag*>(r1 + (s + 1) * 32);
                     nxt[2] = *reinterpret_cast<const frag*>(r0 + (s + 1) * 32 + 16); nxt[3] = *reinterpret_cast<const frag*>(r1 + (s + 1) * 32 + 16);
                 }
+                // next step's reads are ISSUED before this step's MFMAs (tower.hip, matrix_interval: without the fence the scheduler sinks
+                // them to the end of the step, right in front of their consumers, and every step waits out an LDS latency)
+                __builtin_amdgcn_sched_barrier(0);
                 if (tap < 9) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hd_mma32(win[s * 2 + (i >> 1)], cur[i], acc[i & 1]);
@@ -212,6 +215,7 @@ __device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds
             for (int q6 = 0; q6 < 6; ++q6) {
                 const int i = i0 + q6, q = q6 % 3;
                 if (i + 1 < 18) read_b(wv * 18 + i + 1, bq[(q6 + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);   // reads of the next unit before this unit's MFMAs
 #pragma unroll
                 for (int rt = 0; rt < 3; ++rt) {
                     hd_mma32(wf[q][rt], bq[q6 & 1][0], acc[rt][0]);

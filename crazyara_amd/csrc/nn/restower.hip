@@ -127,6 +127,8 @@ __global__ __launch_bounds__(512 / NR) void restower_kernel(const ResTowerArgs a
                         nxt[NT + t] = *reinterpret_cast<const frag*>(rows[t] + (s + 1) * 32 + 16);
                     }
                 }
+                // next step's tile fragments are ISSUED before this step's MFMAs (tower.hip, matrix_interval explains the fence)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll

@@ -136,6 +136,10 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
                 for (int i = 0; i < 4; ++i) nxt[i] = *reinterpret_cast<const frag*>(xsr + (i & 1) * 32 * XROW + ((s + 1) * 2 + (i >> 1)) * 16);
 #endif
             }
+            // The reads of the NEXT step's B fragments must be ISSUED before this step's MFMAs (they then have a whole step to land).
+            // Without this fence the scheduler sinks them below the MFMAs to save registers -- to the end of the step, directly in
+            // front of the MFMAs that consume them -- and every step waits out a full LDS latency (measured: 179 cycles per step).
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) mma32(win[s * 2 + (i >> 1)], cur[i], accE[i & 1]);
 #ifndef TW_DEV_NO_WLOAD
@@ -169,6 +173,7 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
 #pragma unroll
                 for (int i = 0; i < 4; ++i) nxt[i] = *reinterpret_cast<const frag*>(t2r + (i & 1) * 32 * T2ROW + ((s + 1) * 2 + (i >> 1)) * 16);
             }
+            __builtin_amdgcn_sched_barrier(0);       // as in the expand loop: next step's reads are issued before this step's MFMAs
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll

@@ -245,7 +245,13 @@ def main():
     ap.add_argument("--search-repeats", type=int, default=3)
     ap.add_argument("--no-config-legs", action="store_true", help="skip the search legs of BASELINE configs 1, 3, 4, 5")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the newest committed PMC pass instead of live passes")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="only the headline's timed region and its per-kernel events: no float32 / PCIe / search / CPU legs, no PMC child "
+                         "passes (the command scripts/gpu_round.sh runs under rocprofv3 --kernel-trace --stats, so that the trace holds "
+                         "nothing but the launches the roofline is quoted on)")
     args = ap.parse_args()
+    if args.timed_only:
+        args.no_search = args.no_cpu_baseline = args.no_live_pmc = True
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -418,7 +424,7 @@ def main():
         # ---- the same workload in Precision float32: the mode that meets north_star's 1e-3 on the logits (f16 operands cannot:
         # tests/test_nn_parity_gpu.py).  Exact-f32 MFMA (v_mfma_f32_16x16x4_f32), peak 157.3 TFLOP/s. ----
         float32 = None
-        if args.precision == "float16":
+        if args.precision == "float16" and not args.timed_only:
             net32 = HipAPI(local_rank, args.batch, tmp, "float32")
             torch.as_tensor(net32.device_buffers()["planes"], device="cuda").copy_(x.cuda())
             torch.cuda.synchronize()
@@ -464,20 +470,22 @@ def main():
             for u in users:
                 u.close()
             return len(users) * it * args.batch / el, zc
-        net_b = HipAPI(local_rank, args.batch, tmp, args.precision)
-        pcie_rate_1, zc1 = pcie_rate([net])
-        pcie_rate_2, zc2 = pcie_rate([net, net_b])
-        os.environ["CRA_PREDICT_COPY"] = "1"
-        pcie_copy_1, _ = pcie_rate([net])
-        pcie_copy_2, _ = pcie_rate([net, net_b])
-        del os.environ["CRA_PREDICT_COPY"]
-        net_b.close()
-        pcie = {"one_net_evals_per_sec": round(pcie_rate_1, 1), "two_nets_in_flight_evals_per_sec": round(pcie_rate_2, 1),
-                "zero_copy": bool(zc1 and zc2), "copy_path_one_net_evals_per_sec": round(pcie_copy_1, 1),
-                "copy_path_two_nets_evals_per_sec": round(pcie_copy_2, 1), "iterations": it,
-                "bytes_per_batch": {"planes_in": args.batch * cfg.nb_input_channels * 256, "probs_out": args.batch * cfg.nb_policy * 4,
-                                    "value_out": args.batch * 4},
-                "fraction_of_value_two_nets": round(pcie_rate_2 / value, 4)}
+        pcie, pcie_rate_1 = None, None
+        if not args.timed_only:
+            net_b = HipAPI(local_rank, args.batch, tmp, args.precision)
+            pcie_rate_1, zc1 = pcie_rate([net])
+            pcie_rate_2, zc2 = pcie_rate([net, net_b])
+            os.environ["CRA_PREDICT_COPY"] = "1"
+            pcie_copy_1, _ = pcie_rate([net])
+            pcie_copy_2, _ = pcie_rate([net, net_b])
+            del os.environ["CRA_PREDICT_COPY"]
+            net_b.close()
+            pcie = {"one_net_evals_per_sec": round(pcie_rate_1, 1), "two_nets_in_flight_evals_per_sec": round(pcie_rate_2, 1),
+                    "zero_copy": bool(zc1 and zc2), "copy_path_one_net_evals_per_sec": round(pcie_copy_1, 1),
+                    "copy_path_two_nets_evals_per_sec": round(pcie_copy_2, 1), "iterations": it,
+                    "bytes_per_batch": {"planes_in": args.batch * cfg.nb_input_channels * 256, "probs_out": args.batch * cfg.nb_policy * 4,
+                                        "value_out": args.batch * 4},
+                    "fraction_of_value_two_nets": round(pcie_rate_2 / value, 4)}
         pcie_rate = pcie_rate_1
         out = {
             "metric": "nn_evals_per_sec", "value": round(value, 1), "unit": "evals/s", "n_gpus": world,
@@ -488,10 +496,11 @@ def main():
                                    f"batch={args.batch}, inputs resident in HBM, random-init seeded weights",
                        "batch": args.batch, "parallelism": f"replicas x{world}",
                        "flops_per_position": net.flops_per_position()},
-            "pcie_inclusive_evals_per_sec": round(pcie_rate, 1),
-            "pcie_inclusive": pcie,
             "roofline": roofline,
         }
+        if pcie is not None:
+            out["pcie_inclusive_evals_per_sec"] = round(pcie_rate, 1)
+            out["pcie_inclusive"] = pcie
         if float32:
             out["float32"] = float32
         if mcts:

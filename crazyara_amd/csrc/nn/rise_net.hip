@@ -609,9 +609,10 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                                 const int ch = c * 128 + w * 32 + (v % 4) + 8 * (v / 4) + 4 * lh;
                                 tower_bs[w].push_back(ch < cop ? float(f1.b[ch]) : 0.f);
                             }
-                        // depthwise weights [lg][32 entries: k*k taps, BN2 bias, pad][pair pi][2] for K positions w*32 + lg*8 + pi*2 + {0,1}
-                        for (int lgk = 0; lgk < 4; ++lgk)
-                            for (int ent = 0; ent < 32; ++ent)
+                        // depthwise weights [32 entries: k*k taps, BN2 bias, pad][lg][pair pi][2] for K positions w*32 + lg*8 + pi*2 + {0,1}
+                        // (entry-major: the four lane groups of one broadcast read sit in four different 16-byte bank slots)
+                        for (int ent = 0; ent < 32; ++ent)
+                            for (int lgk = 0; lgk < 4; ++lgk)
                                 for (int pi = 0; pi < 4; ++pi)
                                     for (int hh = 0; hh < 2; ++hh) {
                                         const int ch = tower_k_channel(c * 128 + w * 32 + lgk * 8 + pi * 2 + hh);

@@ -55,8 +55,8 @@ constexpr int TW_SE_OFF = TW_POOL_OFF + 256 * 4;              // float mean[256]
 constexpr int TW_B3_OFF = TW_SE_OFF + (256 + 1024 + 128 + 256) * 4;   // float [256] BN3 bias of the current block
 constexpr int TW_DYN_LDS_BYTES = TW_B3_OFF + 256 * 4;         // the part above is the launch's dynamic LDS
 // Depthwise weights: a static LDS array, 4 vector waves x 2 buffers x 2 KiB, filled by LDS-DMA.
-constexpr int TW_PRM_LG = 512;                                // bytes between lane groups in a buffer
-constexpr int TW_PRM_BUF = 4 * TW_PRM_LG;
+constexpr int TW_PRM_ENT = 64;                                // bytes per entry of a buffer: [entry][lane group][16 B]
+constexpr int TW_PRM_BUF = 32 * TW_PRM_ENT;
 constexpr int TW_PRM_BYTES = 4 * 2 * TW_PRM_BUF;
 constexpr int TW_LDS_BYTES = TW_DYN_LDS_BYTES + TW_PRM_BYTES;
 static_assert(TW_LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -105,15 +105,15 @@ __device__ __forceinline__ void mma32(const half8& a, const half8& b, f32x16& c)
 //   A step = 4 MFMAs + the LDS reads of the NEXT step's B fragments + 2 refills; nothing is scheduled across step boundaries.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&accP)[2][2], half8 (&win)[TW_WIN], WStream& sp,
-                                                const float* __restrict__& bp, const half_t* xsr, half_t* t1w, const half_t* t2r) {
+                                                f32x4 (&bias)[4], const float* __restrict__& bp, const half_t* xsr, half_t* t1w,
+                                                const half_t* t2r) {
     using frag = half8;
     constexpr int XROW = TW_XROW, T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
     f32x16 accE[2];                                  // [square tile of 32]
-    f32x4 bias[4];                                   // BN1 bias of my 16 rows (v%4) + 8*(v/4) + 4*(lane/32)
+    // bias: BN1 bias of my 16 rows (v%4) + 8*(v/4) + 4*(lane/32) for THIS expand phase, loaded one phase ahead (below).  Loaded at
+    // the start of the phase that uses it, the wave would have to drain every weight load in flight (vmcnt counts in order) and
+    // then sit out an L2 round trip before its first MFMA, once per interval.
     if (do_e) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias[i] = reinterpret_cast<const f32x4*>(bp)[i];
-        bp += 32;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -146,6 +146,11 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
 #pragma unroll
             for (int e = 0; e < 2; ++e) win[s * 2 + e] = sp.frag_at(s * 2 + e + TW_WIN);
 #endif
+            if (s == 0) {                            // the first MFMAs have read the bias registers: fetch the next phase's
+                bp += 32;                            // (the stream is closed with one chunk of zeros, rise_net.hip)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bias[i] = reinterpret_cast<const f32x4*>(bp)[i];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         sp.pos += 16 * 1024;
@@ -202,7 +207,7 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
 //     two zero rows; file wrap-around is cancelled by zeroed weights), no cross-lane traffic, no conversions;
 //   * v_pk_fma_f16 accumulates two channels per instruction (f16 accumulate: +0.2e-3 on the logits against f32
 //     accumulation in the oracle's emulation, tolerance 6e-3 -- DESIGN.md), v_pk_max_f16 is the ReLU.
-// Weights: per chunk and wave 2 KiB in the stream = [lane group lg][32 entries: k*k taps, BN2 bias, pad][4 pairs] half2, brought
+// Weights: per chunk and wave 2 KiB in the stream = [32 entries: k*k taps, BN2 bias, pad][lane group lg][4 pairs] half2, brought
 // one chunk ahead straight into a wave-private LDS buffer by two LDS-DMA loads (no VGPRs in between), read back as 10 (26)
 // broadcast reads.  Neighbour rows are read one square tile ahead of the FMAs that use them; the bottom row of a tile is the
 // top row of the next (27 reads per chunk, not 36); the four channel-pair chains are interleaved tap by tap.
@@ -254,7 +259,7 @@ template <int PARITY>
 __device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf, int lg, const VecAddr& va, half_t* t2w, half2_t mLp, half2_t mRp) {
     constexpr int T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
     constexpr int TILE = 16 * T1ROW * 2;             // bytes between square tiles of a t1 buffer
-    const char* prm = prm_buf + lg * TW_PRM_LG;
+    const char* prm = prm_buf + lg * 16;
     // rows of neighbours: top(t) | mid(t) | bot(t), 3 reads each; bot(t) == top(t + 1)
     uint4 top[3], mid[3], bot[3], nmid[3], nbot[3];
 #pragma unroll
@@ -266,7 +271,7 @@ __device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf
     half2_t W[10][4];
 #pragma unroll
     for (int e = 0; e < 10; ++e) {
-        const uint4 u = *reinterpret_cast<const uint4*>(prm + e * 16);
+        const uint4 u = *reinterpret_cast<const uint4*>(prm + e * TW_PRM_ENT);
         W[e][0] = __builtin_bit_cast(half2_t, u.x); W[e][1] = __builtin_bit_cast(half2_t, u.y);
         W[e][2] = __builtin_bit_cast(half2_t, u.z); W[e][3] = __builtin_bit_cast(half2_t, u.w);
     }
@@ -335,11 +340,11 @@ struct VecAddr5 {
 template <int PARITY>
 __device__ __forceinline__ void vector_interval5(VParams& vp, const char* prm_buf, int lg, const VecAddr5& va, half_t* t2w, const half2_t (&mk)[5]) {
     constexpr int T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
-    const char* prm = prm_buf + lg * TW_PRM_LG;
+    const char* prm = prm_buf + lg * 16;
     half2_t W[26][4];
 #pragma unroll
     for (int e = 0; e < 26; ++e) {
-        const uint4 u = *reinterpret_cast<const uint4*>(prm + e * 16);
+        const uint4 u = *reinterpret_cast<const uint4*>(prm + e * TW_PRM_ENT);
         W[e][0] = __builtin_bit_cast(half2_t, u.x); W[e][1] = __builtin_bit_cast(half2_t, u.y);
         W[e][2] = __builtin_bit_cast(half2_t, u.z); W[e][3] = __builtin_bit_cast(half2_t, u.w);
     }
@@ -606,6 +611,9 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
         frag win[TW_WIN];
 #pragma unroll
         for (int q = 0; q < TW_WIN; ++q) win[q] = sp.frag_at(q);
+        f32x4 bias[4];                               // BN1 bias of the next expand phase (matrix_interval)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[i] = reinterpret_cast<const f32x4*>(bp)[i];
         load_board();
         __syncthreads();
         TW_STAMP();
@@ -634,7 +642,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                 half_t* t1w = t1 + ((k + 1) & 1) * (TW_T1_BYTES / 2) + t1off;
                 const half_t* t2r = t2 + ((k - 1) & 1) * (TW_T2_BYTES / 2) + t2off;
 #ifndef TW_DEV_NO_MATRIX
-                matrix_interval(k + 1 < n, k >= 1, accP, win, sp, bp, xsr, t1w, t2r);
+                matrix_interval(k + 1 < n, k >= 1, accP, win, sp, bias, bp, xsr, t1w, t2r);
 #endif
 #ifdef TW_TRACE_BARRIERS
                 if (trc) {                           // development: time spent waiting at the interval barriers (perturbs the loop)

@@ -15,7 +15,7 @@ fi
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 3000 $OUT/bench.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --no-search --no-cpu-baseline --steps 100 --warmup 10 > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --timed-only --steps 300 --warmup 30 > $OUT/trace.log 2>&1
 cd $REPO
 find $OUT/trace -name "*kernel_stats.csv" | head -3
 if [ "${3:-pmc}" = "pmc" ]; then

@@ -14,15 +14,16 @@ namespace cra {
 
 namespace {
 constexpr int FW_STEM_LDS = ST_OUT_BYTES + 65 * (96 + 8) * 2;        // largest stem: cin_pad 96
-constexpr int FW_DYN_LDS = TW_DYN_LDS_BYTES > HD_LDS_BYTES ? (TW_DYN_LDS_BYTES > FW_STEM_LDS ? TW_DYN_LDS_BYTES : FW_STEM_LDS)
-                                                            : (HD_LDS_BYTES > FW_STEM_LDS ? HD_LDS_BYTES : FW_STEM_LDS);
+constexpr int fw_max(int a, int b) { return a > b ? a : b; }
+constexpr int FW_DYN_LDS = fw_max(TW_DYN_LDS_BYTES, fw_max(HD_LDS_BYTES, FW_STEM_LDS));
+constexpr int FW_DYN_LDS_F8 = fw_max(TW_DYN_LDS_BYTES_F8, fw_max(HD_LDS_BYTES, FW_STEM_LDS));
 static_assert(ST_OROW == TW_XROW && TW_XROW == HD_ROW, "the three kernels must agree on the pitch of the board tile");
 }  // namespace
 
-template <int NKS>
+template <int NKS, bool F8 = false>
 __global__ __launch_bounds__(512) void forward_kernel(const StemArgs sa, const TowerArgs ta, const HeadArgs ha) {
     stem_body<NKS>(sa, false);           // ends in a workgroup barrier: the tile is complete
-    tower_body(ta, true, false);         // every role ends in the barrier after the last block's epilogue
+    tower_body<F8>(ta, true, false);     // every role ends in the barrier after the last block's epilogue
     head_body(ha, true);
 }
 
@@ -31,9 +32,22 @@ void init_forward_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
 }
 
 void launch_forward(const StemArgs& sa, const TowerArgs& ta, const HeadArgs& ha, hipStream_t s) {
+    if (ta.fp8) {
+        switch (sa.cin_pad / 16) {
+            case 3: hipLaunchKernelGGL((forward_kernel<3, true>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+            case 4: hipLaunchKernelGGL((forward_kernel<4, true>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+            case 5: hipLaunchKernelGGL((forward_kernel<5, true>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+            default: hipLaunchKernelGGL((forward_kernel<6, true>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+        }
+        return;
+    }
     switch (sa.cin_pad / 16) {
         case 3: hipLaunchKernelGGL(forward_kernel<3>, dim3(sa.batch), dim3(512), FW_DYN_LDS, s, sa, ta, ha); break;
         case 4: hipLaunchKernelGGL(forward_kernel<4>, dim3(sa.batch), dim3(512), FW_DYN_LDS, s, sa, ta, ha); break;

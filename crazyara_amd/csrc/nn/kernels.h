@@ -77,7 +77,8 @@ template <typename T> int block_chunk_channels();   // C_op must be padded to a 
 //            one chunk of padding at the end
 constexpr int kTowerWindow = 16;
 struct TowerBlockDesc {
-    const float* b3;      // [256] BN3 bias
+    const float* b3;      // [256] BN3 bias (Precision fp8: divided by s3)
+    const float* s3;      // Precision fp8: [256] power-of-two scale of the project weights per cout (y = x + s3 * acc); else nullptr
     const void* se_w1;    // f16: ca_se W1 transposed [256][128]; eca_se centre tap transposed [256][256]; or nullptr
     const void* se_w2;    // f16: ca_se W2 transposed [128][256]
     const float* se_b;    // eca_se bias [256]
@@ -98,6 +99,12 @@ struct TowerArgs {
     const float* gate_in; // optional [B][256]: SE gate of blocks[0] computed by a previous launch (blocks[0].se_kind is ignored)
     float* pool_out;      // optional [B][256]: sum over the 64 squares of y (feeds an SE gate computed by a later launch)
     unsigned long long* trace;   // development: s_memtime stamps of workgroup 0 (CRA_TOWER_TRACE), [wave 0 | wave 4][256]
+    int fp8;              // Precision fp8: e4m3 GEMM operands (v_mfma_f32_32x32x64_f8f6f4).  wstream = bytes; a matrix wave's region holds TWO
+                          // streams of 1 KiB loads: [0, wstream_e_frags) expand, per chunk 8 loads [k-step of 64][half][lane][16 B] (lane l = row
+                          // l%32, bytes k = ks*64 + (l/32)*32 + half*16 + t), then project, per chunk 8 loads [k-step][row tile][half][lane][16 B];
+                          // each closed by 8 loads of zeros.  Weights divided by a power of two per row (max |w_q| in [1, 2)): the expand
+                          // scale is folded into the depthwise weights, bstream = b1 / s1, b3 = b3 / s3
+    long long wstream_e_frags;
 };
 void launch_tower(const TowerArgs& a, hipStream_t s);
 void init_tower_kernel_attributes();

@@ -22,10 +22,15 @@ struct RiseDesign {
     double flops_per_position = 0; // 2*MACs, recomputed from the layer list
 };
 
+// the host-side weight quantiser of Precision fp8: float -> OCP e4m3fn byte, round to nearest even, clamped at +-448
+uint8_t float_to_e4m3(float v);
+
 class RiseNet {
 public:
     // model_path: a .cranet file, or a directory searched like get_onnx_model_name() (neuralnetapi.cpp:57-73).
     // precision: "float16" (f16 MFMA operands, f32 accumulate; the reference TensorRT default, optionsuci.cpp:143-147)
+    //            or "fp8" ("float8"; "int8" is accepted as the reference's name for its reduced-precision mode): float16 with e4m3
+    //            operands in the GEMMs of the residual tower (256-channel bottleneck nets only)
     //            or "float32" (exact f32 MFMA); float16 runs the residual tower kernel (tower.hip: runs of 3x3 blocks in one launch);
     //            suffix "-perblock" selects one fused launch per bottleneck block, "-unfused" the layer-granular kernels
     //            (both kept for A/B measurements and as independent implementations in the parity tests).   Throws std::invalid_argument / std::runtime_error.
@@ -98,6 +103,7 @@ private:
     RiseDesign design_;
     std::string model_name_, model_file_path_;
     bool fp16_ = true;
+    bool fp8_tower_ = false;     // Precision fp8 (alias int8): e4m3 operands in the residual tower's GEMMs, everything else as float16
     bool fused_ = true;
     bool tower_ = true;
     bool one_launch_ = true;     // stem + tower + head in one launch when the net is exactly that chain ("-3k": three launches)

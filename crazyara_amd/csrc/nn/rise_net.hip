@@ -31,6 +31,36 @@ struct Folded {
     std::vector<double> b;   // [cout]
 };
 
+// float -> OCP e4m3fn byte: round to nearest even, subnormals down to 2^-9, beyond +-448 clamps (the device conversion runs with
+// MODE.FP16_OVFL = 1 and does the same)
+uint8_t to_e4m3(double v) {
+    const uint8_t sign = std::signbit(v) ? 0x80 : 0;
+    double a = std::fabs(v);
+    if (!(a == a)) return uint8_t(sign | 0x7f);
+    if (a >= 448.0) return uint8_t(sign | 0x7e);
+    if (a < std::ldexp(1.0, -10)) return sign;                   // below half the smallest subnormal (a tie at 2^-10 rounds to even = 0)
+    int e;
+    (void)std::frexp(a, &e);                                     // a = m * 2^e, m in [0.5, 1)
+    int ex = e - 1;                                              // a = (1 + f) * 2^ex
+    if (ex < -6) ex = -6;                                        // subnormal range: fixed quantum 2^-9
+    const double q = std::ldexp(1.0, ex - 3);                    // spacing of representable values around a
+    double n = std::nearbyint(a / q);                            // default rounding mode: nearest even
+    int mant = int(n);                                           // in units of q: normal numbers 8..16, subnormals 0..8
+    if (ex == -6 && mant < 8) return uint8_t(sign | mant);
+    if (mant == 16) { mant = 8; ++ex; }
+    if (ex > 8 || (ex == 8 && mant - 8 > 6)) return uint8_t(sign | 0x7e);
+    return uint8_t(sign | ((ex + 7) << 3) | (mant - 8));
+}
+// power of two that brings max |w| of a row into [1, 2); 1 for an all-zero row
+double row_scale_pow2(double max_abs) {
+    if (!(max_abs > 0.0)) return 1.0;
+    int e;
+    (void)std::frexp(max_abs, &e);
+    e -= 1;
+    if (e < -24) e = -24;
+    return std::ldexp(1.0, e);
+}
+
 Folded fold_bn(const NetFile& nf, const std::string& conv, const std::string& bn) {
     const TensorView& w = nf.get(conv + ".weight");
     const int64_t cout = w.shape[0], per = w.numel() / cout;
@@ -149,6 +179,11 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
         prec.resize(prec.size() - perblock_tag.size());
     }
     if (prec == "float16" || prec == "fp16" || prec == "half") fp16_ = true;
+    // The reference's reduced-precision mode is TensorRT INT8 (tensorrtapi.cpp:229-248, UCI option Precision = int8).  On gfx950 the
+    // 8-bit format with a one-instruction conversion from f16 and a matrix instruction at twice the f16 rate is e4m3, so that is what
+    // the mode runs on: the GEMMs of the residual tower take e4m3 operands (no calibration file: per-row power-of-two weight scales,
+    // f32 accumulation, the residual stream itself stays f16); stem and heads stay f16.  "int8" is accepted as the reference's name for it.
+    else if (prec == "fp8" || prec == "float8" || prec == "int8") { fp16_ = true; fp8_tower_ = true; }
     else if (prec == "float32" || prec == "fp32") fp16_ = false;
     else throw std::invalid_argument("unsupported precision '" + precision + "' (float16 | float32)");
     design_.batch = batch_size;
@@ -333,10 +368,13 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     int prod_op = -1;                 // last op that produced the residual stream and can emit its channel sums
     constexpr bool kHalf = std::is_same<T, half_t>::value;
     const bool tower_ok = tower_ && fused_ && kHalf && C == 256 && !dense_se;
+    if (fp8_tower_ && (!tower_ok || dense_blocks))
+        throw std::runtime_error("Precision fp8 runs on the one-launch bottleneck tower only (256-channel RISE nets): use float16 for this model");
     std::vector<TowerBlockDesc> tower_blocks;
     std::vector<half_t> tower_ws[4];          // per matrix wave: MFMA A fragments in consumption order (kernels.h: TowerArgs)
     std::vector<float> tower_bs[4];
     std::vector<half_t> tower_ps[4];          // per vector wave: packed f16 depthwise weights (kernels.h: pstream)
+    std::vector<uint8_t> tower_w8e[4], tower_w8p[4];   // Precision fp8: per matrix wave the expand / project streams (kernels.h: TowerArgs::fp8)
     const float* tower_gate = nullptr;
     auto flush_tower = [&]() {
         if (tower_blocks.empty()) return;
@@ -349,6 +387,17 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         {   // close the streams: the kernel's windows run one window / one chunk past the end
             std::vector<half_t> ws, ps;
             std::vector<float> bs;
+            std::vector<uint8_t> w8;
+            if (fp8_tower_) {
+                for (int w = 0; w < 4; ++w) {        // [expand stream + a window of zeros][project stream + a window of zeros]
+                    tower_w8e[w].resize(tower_w8e[w].size() + 8 * 1024, 0);
+                    tower_w8p[w].resize(tower_w8p[w].size() + 8 * 1024, 0);
+                    w8.insert(w8.end(), tower_w8e[w].begin(), tower_w8e[w].end());
+                    w8.insert(w8.end(), tower_w8p[w].begin(), tower_w8p[w].end());
+                }
+                op.tw.fp8 = 1;
+                op.tw.wstream_e_frags = (long long)(tower_w8e[0].size() / 1024);
+            }
             for (int w = 0; w < 4; ++w) {
                 tower_ws[w].resize(tower_ws[w].size() + size_t(kTowerWindow) * 512, half_t(0.f));
                 tower_ps[w].resize(tower_ps[w].size() + 1024, half_t(0.f));
@@ -357,13 +406,14 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 bs.insert(bs.end(), tower_bs[w].begin(), tower_bs[w].end());
                 ps.insert(ps.end(), tower_ps[w].begin(), tower_ps[w].end());
             }
-            op.tw.wstream = im.upload(ws);
+            if (fp8_tower_) op.tw.wstream = im.upload(w8);
+            else op.tw.wstream = im.upload(ws);
             op.tw.bstream = im.upload(bs);
             op.tw.pstream = im.upload(ps);
-            op.tw.wstream_wave_frags = (long long)(tower_ws[0].size() / 512);
+            op.tw.wstream_wave_frags = fp8_tower_ ? (long long)((tower_w8e[0].size() + tower_w8p[0].size()) / 1024) : (long long)(tower_ws[0].size() / 512);
             op.tw.bstream_wave_floats = (long long)tower_bs[0].size();
             op.tw.pstream_wave_bytes = (long long)(tower_ps[0].size() * sizeof(half_t));
-            for (int w = 0; w < 4; ++w) { tower_ws[w].clear(); tower_bs[w].clear(); tower_ps[w].clear(); }
+            for (int w = 0; w < 4; ++w) { tower_ws[w].clear(); tower_bs[w].clear(); tower_ps[w].clear(); tower_w8e[w].clear(); tower_w8p[w].clear(); }
         }
         op.tw.batch = B;
         op.tw.gate_in = tower_gate;
@@ -579,6 +629,43 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 Folded f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
                 Folded f3 = fold_bn(nf, p + ".body.6", p + ".body.7");
                 const int n = cop_pad / 128;
+                // Precision fp8: power-of-two scale per expand channel / per cout; s1 goes into the depthwise weights (ReLU commutes with
+                // a positive factor), b1 / s1 is where the expand accumulator starts, y = x + s3 * (acc + b3 / s3)
+                std::vector<double> s1(size_t(cop_pad), 1.0), s3(size_t(C), 1.0);
+                if (fp8_tower_) {
+                    for (int ch = 0; ch < cop; ++ch) {
+                        double m = 0;
+                        for (int k2 = 0; k2 < C; ++k2) m = std::max(m, std::fabs(f1.w[size_t(ch) * C + k2]));
+                        s1[ch] = row_scale_pow2(m);
+                    }
+                    for (int co = 0; co < C; ++co) {
+                        double m = 0;
+                        for (int ch = 0; ch < cop; ++ch) m = std::max(m, std::fabs(f3.w[size_t(co) * cop + ch]));
+                        s3[co] = row_scale_pow2(m);
+                    }
+                    for (int w = 0; w < 4; ++w)
+                        for (int c = 0; c < n; ++c) {
+                            for (int ks = 0; ks < 4; ++ks)           // expand: [k-step of 64][half][lane][16 B]
+                                for (int hf = 0; hf < 2; ++hf)
+                                    for (int l = 0; l < 64; ++l)
+                                        for (int t = 0; t < 16; ++t) {
+                                            const int ch = c * 128 + w * 32 + (l & 31), k2 = ks * 64 + (l >> 5) * 32 + hf * 16 + t;
+                                            tower_w8e[w].push_back(ch < cop ? to_e4m3(f1.w[size_t(ch) * C + k2] / s1[ch]) : uint8_t(0));
+                                        }
+                            for (int ks = 0; ks < 2; ++ks)           // project: [k-step of 64][row tile][half][lane][16 B]
+                                for (int rt = 0; rt < 2; ++rt)
+                                    for (int hf = 0; hf < 2; ++hf)
+                                        for (int l = 0; l < 64; ++l)
+                                            for (int t = 0; t < 16; ++t) {
+                                                const int co = w * 64 + rt * 32 + (l & 31);
+                                                const int ch = tower_k_channel(c * 128 + ks * 64 + (l >> 5) * 32 + hf * 16 + t);
+                                                tower_w8p[w].push_back(ch < cop ? to_e4m3(f3.w[size_t(co) * cop + ch] / s3[co]) : uint8_t(0));
+                                            }
+                        }
+                    for (int co = 0; co < C; ++co) f3.b[co] /= s3[co];
+                    std::vector<float> s3f(s3.begin(), s3.end());
+                    td.s3 = im.upload(s3f);
+                }
                 for (int w = 0; w < 4; ++w) {
                     std::vector<half_t>& ws = tower_ws[w];
                     for (int kk = -1; kk <= n; ++kk) {                 // interval: E(kk+1) then P(kk-1)
@@ -607,7 +694,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                         for (int lh = 0; lh < 2; ++lh)                  // BN1 biases [lane/32][accumulator element v]
                             for (int v = 0; v < 16; ++v) {
                                 const int ch = c * 128 + w * 32 + (v % 4) + 8 * (v / 4) + 4 * lh;
-                                tower_bs[w].push_back(ch < cop ? float(f1.b[ch]) : 0.f);
+                                tower_bs[w].push_back(ch < cop ? float(f1.b[ch] / s1[ch]) : 0.f);
                             }
                         // depthwise weights [32 entries: k*k taps, BN2 bias, pad][lg][pair pi][2] for K positions w*32 + lg*8 + pi*2 + {0,1}
                         // (entry-major: the four lane groups of one broadcast read sit in four different 16-byte bank slots)
@@ -617,7 +704,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                                     for (int hh = 0; hh < 2; ++hh) {
                                         const int ch = tower_k_channel(c * 128 + w * 32 + lgk * 8 + pi * 2 + hh);
                                         double v = 0.0;
-                                        if (ch < cop && ent <= k * k) v = ent < k * k ? f2.w[size_t(ch) * k * k + ent] : f2.b[ch];
+                                        if (ch < cop && ent <= k * k) v = ent < k * k ? f2.w[size_t(ch) * k * k + ent] * s1[ch] : f2.b[ch];
                                         tower_ps[w].push_back(half_t(float(v)));
                                     }
                     }
@@ -1249,5 +1336,7 @@ void RiseNet::predict(const float* in_planes, float* value, float* probs, float*
     submit(in_planes, value, probs, aux);
     wait();
 }
+
+uint8_t float_to_e4m3(float v) { return to_e4m3(double(v)); }
 
 }  // namespace cra

@@ -53,13 +53,21 @@ constexpr int TW_T2_OFF = TW_T1_OFF + 2 * TW_T1_BYTES;
 constexpr int TW_POOL_OFF = TW_T2_OFF + 2 * TW_T2_BYTES;      // float [256] channel sums of the new stream
 constexpr int TW_SE_OFF = TW_POOL_OFF + 256 * 4;              // float mean[256], part[1024], h[128], gate[256]
 constexpr int TW_B3_OFF = TW_SE_OFF + (256 + 1024 + 128 + 256) * 4;   // float [256] BN3 bias of the current block
-constexpr int TW_DYN_LDS_BYTES = TW_B3_OFF + 256 * 4;         // the part above is the launch's dynamic LDS
+constexpr int TW_DYN_LDS_BYTES = TW_B3_OFF + 256 * 4;         // the part above is the launch's dynamic LDS (Precision float16)
+// Precision fp8 (F8 = true below): the two GEMMs of a block run on v_mfma_f32_32x32x64_f8f6f4 with e4m3 operands.  The residual stream
+// stays f16 (xs); an e4m3 copy of it (xq) is the expand GEMM's B operand, and the depthwise writes its output t2 as e4m3 (rows of
+// 128 bytes in the same two t2 regions).  Row pitches: an odd number of 16-byte slots, as for the f16 tiles.
+constexpr int TW_XQROW = TW_C + 16;                           // bytes: 17 slots
+constexpr int TW_T2ROW8 = TW_CK + 16;                         // bytes: 9 slots
+constexpr int TW_XQ_OFF = TW_DYN_LDS_BYTES;
+constexpr int TW_XQ_BYTES = 64 * TW_XQROW;                    // 17408
+constexpr int TW_DYN_LDS_BYTES_F8 = TW_XQ_OFF + TW_XQ_BYTES;
 // Depthwise weights: a static LDS array, 4 vector waves x 2 buffers x 2 KiB, filled by LDS-DMA.
 constexpr int TW_PRM_ENT = 64;                                // bytes per entry of a buffer: [entry][lane group][16 B]
 constexpr int TW_PRM_BUF = 32 * TW_PRM_ENT;
 constexpr int TW_PRM_BYTES = 4 * 2 * TW_PRM_BUF;
 constexpr int TW_LDS_BYTES = TW_DYN_LDS_BYTES + TW_PRM_BYTES;
-static_assert(TW_LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(TW_LDS_BYTES <= 160 * 1024 && TW_DYN_LDS_BYTES_F8 + TW_PRM_BYTES <= 160 * 1024, "LDS budget");
 constexpr int TW_AHEAD = 96;                          // L2 warm-up distance in fragments per stream (3 full intervals, 384 KiB)
 constexpr int TW_WIN = kTowerWindow;                  // weight fragments in flight per matrix wave (16 KiB)
 static_assert(TW_WIN == 16, "one E or P phase consumes exactly one window");
@@ -96,6 +104,100 @@ __device__ __forceinline__ void mma32(const half8& a, const half8& b, f32x16& c)
 #else
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 #endif
+}
+
+// ---- Precision fp8 ----
+// D(32x32) += A(32 x 64) * B(64 x 32), e4m3 operands: lane l holds row / column l % 32 and the 32 bytes k = (l/32)*32 + t of a k-step
+// (any labelling of k that is the same on both sides gives the same sum; scripts/ubench/fp8_probe.hip checks this one), D as above.
+// 64 cycles: twice the MACs per cycle of the f16 instruction.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x8 cat32(const half8& lo, const half8& hi) {
+    const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
+    return i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__device__ __forceinline__ void mma64(const i32x8& a, const i32x8& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
+}
+// four packed f16 pairs -> 8 e4m3 bytes (round to nearest even; the kernel runs with MODE.FP16_OVFL = 1, so values beyond +-448 clamp
+// instead of becoming NaN): v_cvt_scalef32_pk_fp8_f16 fills one 16-bit half of its destination per instruction
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f16x4_to_e4m3(uint32_t lo, uint32_t hi) {
+    s16x2 q = {0, 0};
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_bit_cast(half2_t, lo), 1.0f, false);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_bit_cast(half2_t, hi), 1.0f, true);
+    return __builtin_bit_cast(uint32_t, q);
+}
+__device__ __forceinline__ uint2 f16x8_to_e4m3(const uint4& h) { return uint2{f16x4_to_e4m3(h.x, h.y), f16x4_to_e4m3(h.z, h.w)}; }
+
+// matrix role, Precision fp8, one phase.  A fragment (32 rows x 64 k) is two loads of 1 KiB ([half][lane][16 B]: a lane's bytes 0..15
+// and 16..31), so a phase needs 8 loads where the f16 phase needs 16.  The expand and the project fragments therefore come as TWO streams
+// per wave, each with its own window of 8 loads (16 KiB in flight as before): a phase consumes exactly its window and refills it for
+// the next phase of its kind, whatever the other kind does in between (the first and last intervals of a block run only one of them).
+//   expand : 4 k-steps x {1 fragment, 2 square tiles}: 8 MFMAs          project: 2 k-steps x {2 row tiles, 2 square tiles}: 8 MFMAs
+constexpr int TW_WIN8 = 8;
+__device__ __forceinline__ void expand_phase8(f32x16 (&accE)[2], half8 (&win)[TW_WIN8], WStream& sp, f32x4 (&bias)[4],
+                                              const float* __restrict__& bp, const char* xqr) {
+    constexpr int BASE = 0;
+    using frag = half8;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) accE[ct][v] = bias[v >> 2][v & 3];
+    frag ba[4], bb[4];                               // [square tile][16-byte half] of a k-step
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ba[i] = *reinterpret_cast<const frag*>(xqr + (i >> 1) * 32 * TW_XQROW + (i & 1) * 16);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        frag (&cur)[4] = (s & 1) ? bb : ba;
+        frag (&nxt)[4] = (s & 1) ? ba : bb;
+        if (s + 1 < 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nxt[i] = *reinterpret_cast<const frag*>(xqr + (i >> 1) * 32 * TW_XQROW + (s + 1) * 64 + (i & 1) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const i32x8 a = cat32(win[BASE + 2 * s], win[BASE + 2 * s + 1]);
+        mma64(a, cat32(cur[0], cur[1]), accE[0]);
+        mma64(a, cat32(cur[2], cur[3]), accE[1]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) win[BASE + 2 * s + e] = sp.frag_at(2 * s + e + TW_WIN8);
+        if (s == 0) {
+            bp += 32;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bias[i] = reinterpret_cast<const f32x4*>(bp)[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    sp.pos += 8 * 1024;
+}
+template <typename EPI>
+__device__ __forceinline__ void project_phase8(f32x16 (&accP)[2][2], half8 (&win)[TW_WIN8], WStream& sp, const char* t2r, const EPI& epilogue) {
+    using frag = half8;
+    constexpr int BASE = 0;
+    frag ba[4], bb[4];                               // [square tile][16-byte half]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ba[i] = *reinterpret_cast<const frag*>(t2r + (i >> 1) * 32 * TW_T2ROW8 + (i & 1) * 16);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {                    // k-step s: loads [row tile rt][half]
+        frag (&cur)[4] = (s & 1) ? bb : ba;
+        frag (&nxt)[4] = (s & 1) ? ba : bb;
+        if (s + 1 < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nxt[i] = *reinterpret_cast<const frag*>(t2r + (i >> 1) * 32 * TW_T2ROW8 + (s + 1) * 64 + (i & 1) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const i32x8 a = cat32(win[BASE + s * 4 + rt * 2], win[BASE + s * 4 + rt * 2 + 1]);
+            mma64(a, cat32(cur[0], cur[1]), accP[rt][0]);
+            mma64(a, cat32(cur[2], cur[3]), accP[rt][1]);
+        }
+        epilogue(s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) win[BASE + s * 4 + e] = sp.frag_at(s * 4 + e + TW_WIN8);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    sp.pos += 8 * 1024;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -200,6 +302,31 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
     }
 }
 
+// the same interval in Precision fp8 (window halves: [0, 8) expand stream, [8, 16) project stream)
+__device__ __forceinline__ void matrix_interval8(bool do_e, bool do_p, f32x16 (&accP)[2][2], half8 (&winE)[TW_WIN8], half8 (&winP)[TW_WIN8],
+                                                 WStream& spE, WStream& spP, f32x4 (&bias)[4], const float* __restrict__& bp, const char* xqr,
+                                                 half_t* t1w, const char* t2r) {
+    constexpr int T1ROW = TW_T1ROW;
+    f32x16 accE[2];
+    if (do_e) expand_phase8(accE, winE, spE, bias, bp, xqr);
+    auto expand_epilogue = [&](int ct) {             // as in matrix_interval: the accumulators started at the (scaled) BN1 bias
+        uint32_t o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = pack_relu_cvt(accE[ct][2 * i], accE[ct][2 * i + 1]);
+        uint4* dst = reinterpret_cast<uint4*>(t1w + ct * 32 * T1ROW);
+        dst[0] = uint4{o[0], o[1], o[2], o[3]};
+        dst[1] = uint4{o[4], o[5], o[6], o[7]};
+    };
+    if (do_p) {
+        auto epi = [&](int s) { if (do_e) expand_epilogue(s); };
+        project_phase8(accP, winP, spP, t2r, epi);
+    } else if (do_e) {
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last expand MFMAs (64 cycles) retire first
+        expand_epilogue(0);
+        expand_epilogue(1);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // vector role, one interval: D(chunk) for this wave's 32 channels, packed f16 math.
 //   * a lane owns square (tile t of 16, l15) and 8 consecutive K positions = 4 channel PAIRS held as packed halves;
@@ -255,9 +382,16 @@ __device__ __forceinline__ uint4 vec_row_read(const char* p) {
 #endif
 }
 
-template <int PARITY>
-__device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf, int lg, const VecAddr& va, half_t* t2w, half2_t mLp, half2_t mRp) {
-    constexpr int T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
+// t2w: byte address of my output slot in tile 0 of t2 buffer 0 (f16: row pitch T2ROW halves, 16 bytes; fp8: TW_T2ROW8 bytes, 8 bytes)
+template <bool F8>
+__device__ __forceinline__ void vector_store(char* t2w, int parity, int t, const uint32_t (&o)[4]) {
+    if constexpr (F8) *reinterpret_cast<uint2*>(t2w + parity * TW_T2_BYTES + t * 16 * TW_T2ROW8) = uint2{f16x4_to_e4m3(o[0], o[1]), f16x4_to_e4m3(o[2], o[3])};
+    else *reinterpret_cast<uint4*>(t2w + parity * TW_T2_BYTES + t * 16 * TW_T2ROW * 2) = uint4{o[0], o[1], o[2], o[3]};
+}
+
+template <int PARITY, bool F8>
+__device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf, int lg, const VecAddr& va, char* t2w, half2_t mLp, half2_t mRp) {
+    constexpr int T1ROW = TW_T1ROW;
     constexpr int TILE = 16 * T1ROW * 2;             // bytes between square tiles of a t1 buffer
     const char* prm = prm_buf + lg * 16;
     // rows of neighbours: top(t) | mid(t) | bot(t), 3 reads each; bot(t) == top(t + 1)
@@ -319,7 +453,7 @@ __device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf
         uint32_t o[4];
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) o[pi] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(acc[pi], half2_t{0, 0}));
-        *reinterpret_cast<uint4*>(t2w + PARITY * (TW_T2_BYTES / 2) + t * 16 * T2ROW) = uint4{o[0], o[1], o[2], o[3]};
+        vector_store<F8>(t2w, PARITY, t, o);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) { top[i] = bot[i]; mid[i] = nmid[i]; bot[i] = nbot[i]; }
@@ -337,9 +471,9 @@ struct VecAddr5 {
     const char* zero3;   // the zero row below the board at my columns, pre-biased by -3 tiles
 };
 
-template <int PARITY>
-__device__ __forceinline__ void vector_interval5(VParams& vp, const char* prm_buf, int lg, const VecAddr5& va, half_t* t2w, const half2_t (&mk)[5]) {
-    constexpr int T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
+template <int PARITY, bool F8>
+__device__ __forceinline__ void vector_interval5(VParams& vp, const char* prm_buf, int lg, const VecAddr5& va, char* t2w, const half2_t (&mk)[5]) {
+    constexpr int T1ROW = TW_T1ROW;
     const char* prm = prm_buf + lg * 16;
     half2_t W[26][4];
 #pragma unroll
@@ -378,13 +512,14 @@ __device__ __forceinline__ void vector_interval5(VParams& vp, const char* prm_bu
         uint32_t o[4];
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) o[pi] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(acc[pi], half2_t{0, 0}));
-        *reinterpret_cast<uint4*>(t2w + PARITY * (TW_T2_BYTES / 2) + t * 16 * T2ROW) = uint4{o[0], o[1], o[2], o[3]};
+        vector_store<F8>(t2w, PARITY, t, o);
     }
     vp.fetch_next();
 }
 
 // SE gate of a block (squeeze over the residual stream in LDS, excitation MLP, scale in place); executed by all 512 threads
-__device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_t* xs, const float* pool_sum, float* se_mean,
+template <bool F8>
+__device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_t* xs, char* xq, const float* pool_sum, float* se_mean,
                                      float* se_part, float* se_h, float* se_gate, unsigned long long* trc, int& trn) {
     constexpr int XROW = TW_XROW;
     {
@@ -524,6 +659,8 @@ __device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_
 #pragma unroll
             for (int j = 0; j < 8; ++j) xv[j] *= gv[j];
             store8<half_t>(xs + r * XROW + v * 8, xv);
+            if constexpr (F8)                        // the e4m3 copy follows the ROUNDED f16 values (what the oracle's emulation quantises)
+                *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_e4m3(*reinterpret_cast<const uint4*>(xs + r * XROW + v * 8));
         }
         __syncthreads();
 #ifdef TW_TRACE_SE
@@ -540,12 +677,15 @@ size_t tower_lds_bytes() { return TW_LDS_BYTES; }
 
 // x_in_lds: the board's residual-stream tile is already at offset 0 of the dynamic LDS segment (left there by the stem of the same
 // launch, forward.hip); y_to_global = false: it stays there for the head of the same launch.  Both need gate_in == pool_out == nullptr.
+template <bool F8>
 __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_lds, const bool y_to_global) {
     using frag = half8;
+    if constexpr (F8) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // MODE.FP16_OVFL: conversions to f16 / e4m3 clamp instead of overflowing
     constexpr int C = TW_C, XROW = TW_XROW, T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ __attribute__((aligned(16))) char prm_lds[TW_PRM_BYTES];
     half_t* xs = reinterpret_cast<half_t*>(smem);
+    char* xq = smem + TW_XQ_OFF;                     // Precision fp8 only
     float* pool_sum = reinterpret_cast<float*>(smem + TW_POOL_OFF);
     float* se_mean = reinterpret_cast<float*>(smem + TW_SE_OFF);
     float* se_part = se_mean + 256;
@@ -570,12 +710,22 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
             const int rowi = tid / (T1ROW / 2), col = tid % (T1ROW / 2);
             reinterpret_cast<uint32_t*>(smem + TW_T1_OFF + (rowi >> 1) * TW_T1_BYTES + (rowi & 1) * 65 * T1ROW * 2)[col] = 0u;
         }
-        if (x_in_lds) return;
+        if (x_in_lds) {
+            if constexpr (F8) {                      // the stem of this launch left the f16 tile: make its e4m3 copy
+                for (int i = tid; i < 64 * 32; i += 512) {
+                    const int r = i >> 5, v = i & 31;
+                    *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_e4m3(*reinterpret_cast<const uint4*>(xs + r * XROW + v * 8));
+                }
+            }
+            return;
+        }
         const half_t* xb = reinterpret_cast<const half_t*>(a.x) + size_t(b) * 64 * C;
         if (a.gate_in == nullptr) {
             for (int i = tid; i < 64 * 32; i += 512) {
                 const int r = i >> 5, v = i & 31;
-                *reinterpret_cast<uint4*>(xs + r * XROW + v * 8) = *reinterpret_cast<const uint4*>(xb + size_t(r) * C + v * 8);
+                const uint4 u = *reinterpret_cast<const uint4*>(xb + size_t(r) * C + v * 8);
+                *reinterpret_cast<uint4*>(xs + r * XROW + v * 8) = u;
+                if constexpr (F8) *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_e4m3(u);
             }
         } else {
             const float* gt = a.gate_in + size_t(b) * C;
@@ -587,6 +737,8 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] *= gv[j];
                 store8<half_t>(xs + r * XROW + v * 8, xv);
+                if constexpr (F8)
+                    *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_e4m3(*reinterpret_cast<const uint4*>(xs + r * XROW + v * 8));
             }
         }
     };
@@ -608,9 +760,12 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
         sp.pos = 0;
         sp.lane_off = lane * 16;
         const float* bp = a.bstream + size_t(w) * a.bstream_wave_floats + lh * 16;
+        // Precision fp8: two streams (expand loads first, project loads from a.wstream_e_frags on), a window of 8 loads each
+        WStream spP = sp;
+        spP.pos = uint32_t(a.wstream_e_frags) * 1024u;
         frag win[TW_WIN];
 #pragma unroll
-        for (int q = 0; q < TW_WIN; ++q) win[q] = sp.frag_at(q);
+        for (int q = 0; q < TW_WIN; ++q) win[q] = (F8 && q >= TW_WIN8) ? spP.frag_at(q - TW_WIN8) : sp.frag_at(q);
         f32x4 bias[4];                               // BN1 bias of the next expand phase (matrix_interval)
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias[i] = reinterpret_cast<const f32x4*>(bp)[i];
@@ -621,9 +776,12 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
         const half_t* xsr = xs + l31 * XROW + lh * 8;
         const int t1off = (1 + l31) * T1ROW + w * 32 + lh * 16;        // + 1: row 0 of a t1 buffer is a zero row
         const int t2off = l31 * T2ROW + lh * 8;
+        // Precision fp8: a lane's 32 bytes of a k-step in its row of the e4m3 tiles; window slot of the next phase's first load
+        const char* xqr = xq + l31 * TW_XQROW + lh * 32;
+        const int t2off8 = l31 * TW_T2ROW8 + lh * 32;
         for (int blk = 0; blk < a.nblocks; ++blk) {
             const TowerBlockDesc& d = a.blocks[blk];
-            if (blk > 0 && d.se_kind != 0) se_phase(d, tid, xs, pool_sum, se_mean, se_part, se_h, se_gate, trc, trn);
+            if (blk > 0 && d.se_kind != 0) se_phase<F8>(d, tid, xs, xq, pool_sum, se_mean, se_part, se_h, se_gate, trc, trn);
             TW_STAMP();
             const int n = d.cop_pad / TW_CK;
             // project accumulators start at the BN3 bias of their cout: row (v%4) + 8*(v/4) + 4*lh of tile rt
@@ -642,7 +800,11 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                 half_t* t1w = t1 + ((k + 1) & 1) * (TW_T1_BYTES / 2) + t1off;
                 const half_t* t2r = t2 + ((k - 1) & 1) * (TW_T2_BYTES / 2) + t2off;
 #ifndef TW_DEV_NO_MATRIX
-                matrix_interval(k + 1 < n, k >= 1, accP, win, sp, bias, bp, xsr, t1w, t2r);
+                if constexpr (F8)
+                    matrix_interval8(k + 1 < n, k >= 1, accP, reinterpret_cast<frag(&)[TW_WIN8]>(win[0]), reinterpret_cast<frag(&)[TW_WIN8]>(win[TW_WIN8]),
+                                     sp, spP, bias, bp, xqr, t1w, smem + TW_T2_OFF + ((k - 1) & 1) * TW_T2_BYTES + t2off8);
+                else
+                    matrix_interval(k + 1 < n, k >= 1, accP, win, sp, bias, bp, xsr, t1w, t2r);
 #endif
 #ifdef TW_TRACE_BARRIERS
                 if (trc) {                           // development: time spent waiting at the interval barriers (perturbs the loop)
@@ -659,14 +821,19 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
             // 4 consecutive couts per step: rows 8*g4 + 4*lh + 0..3 = accumulator elements 4*g4 + 0..3; the f16 residual is read
             // straight out of its packed register by the mix-precision FMA, which also rounds the sum (once, RNE) into place.
             // All residual reads of a cout tile go out before its first store (a store would order the later reads behind it).
+            // Precision fp8: the accumulators are in units of the cout's weight scale (they started at b3 / s3): y = x + s3 * acc, and the
+            // new stream's e4m3 copy is made from the rounded f16 values.
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 uint2 rv[4][2];
+                f32x4 sc[4];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    if constexpr (F8) sc[g4] = *reinterpret_cast<const f32x4*>(d.s3 + w * 64 + rt * 32 + g4 * 8 + lh * 4);
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
                         rv[g4][ct] = *reinterpret_cast<const uint2*>(xs + (ct * 32 + l31) * XROW + w * 64 + rt * 32 + g4 * 8 + lh * 4);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -677,12 +844,23 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                         const float t0 = accP[rt][ct][g4 * 4 + 0], t1 = accP[rt][ct][g4 * 4 + 1];
                         const float t2 = accP[rt][ct][g4 * 4 + 2], t3 = accP[rt][ct][g4 * 4 + 3];
                         uint2 o;
-                        asm("v_fma_mixlo_f16 %0, %2, 1.0, %6 op_sel_hi:[0,0,1]\n\t"
-                            "v_fma_mixhi_f16 %0, %3, 1.0, %6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-                            "v_fma_mixlo_f16 %1, %4, 1.0, %7 op_sel_hi:[0,0,1]\n\t"
-                            "v_fma_mixhi_f16 %1, %5, 1.0, %7 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                            : "=&v"(o.x), "=&v"(o.y)
-                            : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(rv[g4][ct].x), "v"(rv[g4][ct].y));
+                        if constexpr (F8) {
+                            asm("v_fma_mixlo_f16 %0, %2, %8, %6 op_sel_hi:[0,0,1]\n\t"
+                                "v_fma_mixhi_f16 %0, %3, %9, %6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                                "v_fma_mixlo_f16 %1, %4, %10, %7 op_sel_hi:[0,0,1]\n\t"
+                                "v_fma_mixhi_f16 %1, %5, %11, %7 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                                : "=&v"(o.x), "=&v"(o.y)
+                                : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(rv[g4][ct].x), "v"(rv[g4][ct].y), "v"(sc[g4][0]), "v"(sc[g4][1]),
+                                  "v"(sc[g4][2]), "v"(sc[g4][3]));
+                            *reinterpret_cast<uint32_t*>(xq + (ct * 32 + l31) * TW_XQROW + co0) = f16x4_to_e4m3(o.x, o.y);
+                        } else {
+                            asm("v_fma_mixlo_f16 %0, %2, 1.0, %6 op_sel_hi:[0,0,1]\n\t"
+                                "v_fma_mixhi_f16 %0, %3, 1.0, %6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                                "v_fma_mixlo_f16 %1, %4, 1.0, %7 op_sel_hi:[0,0,1]\n\t"
+                                "v_fma_mixhi_f16 %1, %5, 1.0, %7 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                                : "=&v"(o.x), "=&v"(o.y)
+                                : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(rv[g4][ct].x), "v"(rv[g4][ct].y));
+                        }
                         *reinterpret_cast<uint2*>(px) = o;
                     }
                 }
@@ -717,7 +895,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                 va.bot[i] = hi ? t1b + ((65 - 48) * T1ROW + w * 32 + lg * 8) * 2 : va.tap[6 + i];            // + 3 tiles (48 rows) = row 65
             }
         }
-        half_t* t2w = t2 + l15 * T2ROW + w * 32 + lg * 8;
+        char* t2w = F8 ? smem + TW_T2_OFF + l15 * TW_T2ROW8 + w * 32 + lg * 8 : reinterpret_cast<char*>(t2 + l15 * T2ROW + w * 32 + lg * 8);
         // the same for the 5 x 5 blocks (addresses only: 36 more VGPRs, this role has them to spare)
         VecAddr5 va5;
         half2_t mk5[5];
@@ -744,25 +922,29 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
         const char* wsb = reinterpret_cast<const char*>(a.wstream);
         const long long wsF = a.wstream_wave_frags;
         const int pf_slot = (b >> 3) & 31;
-        long long mpos = 0;              // fragments the matrix waves have consumed (same arithmetic as theirs)
+        long long mpos = 0, mposP = 0;   // loads the matrix waves have consumed (same arithmetic as theirs; fp8: per stream)
         int pf_old = 0, pf_sink = 0;
-        auto prefetch = [&](long long first, int nfr) -> int {   // fragments [first, first + nfr) of all 4 streams, nfr = 16 or 32
+        auto prefetch = [&](long long first, int nfr) -> int {   // loads [first, first + nfr) of all 4 waves' streams, nfr = 8, 16 or 32
             int v = 0;
             if (w == 0 && lane < 32) {
-                const int idx = lane * 32 + pf_slot, sh = nfr == 32 ? 8 : 7;
+                const int idx = lane * 32 + pf_slot, sh = nfr == 32 ? 8 : nfr == 16 ? 7 : 6;
                 const int wq = idx >> sh, rem = idx & ((1 << sh) - 1);
                 const long long fr = first + (rem >> 3);
                 if (wq < 4 && fr < wsF) v = *reinterpret_cast<const int*>(wsb + ((wq * wsF + fr) << 10) + ((rem & 7) << 7));
             }
             return v;
         };
-        for (int f0 = 0; f0 < TW_AHEAD; f0 += 32) pf_sink ^= prefetch(f0, 32);
+        if constexpr (F8) {
+            for (int f0 = 0; f0 < TW_AHEAD / 2; f0 += 16) pf_sink ^= prefetch(f0, 16) ^ prefetch(a.wstream_e_frags + f0, 16);
+        } else {
+            for (int f0 = 0; f0 < TW_AHEAD; f0 += 32) pf_sink ^= prefetch(f0, 32);
+        }
         load_board();
         __syncthreads();
         TW_STAMP();
         for (int blk = 0; blk < a.nblocks; ++blk) {
             const TowerBlockDesc& d = a.blocks[blk];
-            if (blk > 0 && d.se_kind != 0) se_phase(d, tid, xs, pool_sum, se_mean, se_part, se_h, se_gate, trc, trn);
+            if (blk > 0 && d.se_kind != 0) se_phase<F8>(d, tid, xs, xq, pool_sum, se_mean, se_part, se_h, se_gate, trc, trn);
             TW_STAMP();
             const int n = d.cop_pad / TW_CK;
             // the NEXT block's SE-gate weights (128 KiB, read by every workgroup at the same moment) get the same treatment:
@@ -790,19 +972,27 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
 #endif
                 const char* prm_buf = work ? vp.open() : nullptr;
                 {
-                    const int adv = (k + 1 < n ? 16 : 0) + (k >= 1 ? 16 : 0);
+                    if constexpr (F8) {              // two streams: the expand loads, then (from wstream_e_frags on) the project loads
 #ifndef TW_DEV_NO_WARMUP
-                    pf_old = adv != 0 ? prefetch(mpos + TW_AHEAD, adv) : 0;
+                        pf_old = (k + 1 < n ? prefetch(mpos + TW_AHEAD / 2, 8) : 0) ^ (k >= 1 ? prefetch(a.wstream_e_frags + mposP + TW_AHEAD / 2, 8) : 0);
 #endif
-                    mpos += adv;
+                        mpos += k + 1 < n ? 8 : 0;
+                        mposP += k >= 1 ? 8 : 0;
+                    } else {
+                        const int adv = (k + 1 < n ? 16 : 0) + (k >= 1 ? 16 : 0);
+#ifndef TW_DEV_NO_WARMUP
+                        pf_old = adv != 0 ? prefetch(mpos + TW_AHEAD, adv) : 0;
+#endif
+                        mpos += adv;
+                    }
                 }
                 if (work) {
                     if (five) {
-                        if (k & 1) vector_interval5<1>(vp, prm_buf, lg, va5, t2w, mk5);
-                        else vector_interval5<0>(vp, prm_buf, lg, va5, t2w, mk5);
+                        if (k & 1) vector_interval5<1, F8>(vp, prm_buf, lg, va5, t2w, mk5);
+                        else vector_interval5<0, F8>(vp, prm_buf, lg, va5, t2w, mk5);
                     } else {
-                        if (k & 1) vector_interval<1>(vp, prm_buf, lg, va, t2w, mLp, mRp);
-                        else vector_interval<0>(vp, prm_buf, lg, va, t2w, mLp, mRp);
+                        if (k & 1) vector_interval<1, F8>(vp, prm_buf, lg, va, t2w, mLp, mRp);
+                        else vector_interval<0, F8>(vp, prm_buf, lg, va, t2w, mLp, mRp);
                     }
                 }
 #ifdef TW_TRACE_BARRIERS
@@ -839,14 +1029,17 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
 }
 
 #ifndef CRA_FORWARD_TU
-__global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) { tower_body(a, false, true); }
+__global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) { tower_body<false>(a, false, true); }
+__global__ __launch_bounds__(512) void tower_kernel_fp8(const TowerArgs a) { tower_body<true>(a, false, true); }
 
 void init_tower_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TW_DYN_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel_fp8), hipFuncAttributeMaxDynamicSharedMemorySize, TW_DYN_LDS_BYTES_F8);
 }
 
 void launch_tower(const TowerArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(tower_kernel, dim3(a.batch), dim3(512), TW_DYN_LDS_BYTES, s, a);
+    if (a.fp8) hipLaunchKernelGGL(tower_kernel_fp8, dim3(a.batch), dim3(512), TW_DYN_LDS_BYTES_F8, s, a);
+    else hipLaunchKernelGGL(tower_kernel, dim3(a.batch), dim3(512), TW_DYN_LDS_BYTES, s, a);
 }
 
 #endif  // CRA_FORWARD_TU

@@ -43,9 +43,17 @@ typedef struct mi_net mi_net;
  * "-bsize-<B>" first, else the one without "-bsize-"; a .cranet wins over an .onnx), or a direct path to either.
  * ONNX files are read in place (the graphs of the reference's model zoo, see csrc/nn/onnx_import.h), the "-v<maj>.<min>"
  * part of the name is the input-representation version (read_version_from_string, neuralnetapi.cpp:194-227).
- * precision: "float32" | "float16" (UCI option Precision, optionsuci.cpp:143-147). */
+ * precision: "float32" | "float16" (UCI option Precision, optionsuci.cpp:143-147) | "fp8" (also "float8"; "int8" -- the third value of the
+ * reference's option, TensorRT INT8 with a calibration cache, tensorrtapi.cpp:229-248 -- is accepted as a name for it): float16 with OCP
+ * e4m3 operands in the two GEMMs of every residual block (f32 accumulation, per-row power-of-two weight scales, no calibration file; the
+ * residual stream, stem and heads stay f16).  256-channel bottleneck (RISE) nets only; error against fp32 about 2^7 times float16's
+ * (DESIGN 4.3).  Other models: RuntimeError, as an unsupported precision is in the reference. */
 mi_net* mi_net_create(const char* model_dir, int device_id, int batch_size, const char* precision);
 void mi_net_destroy(mi_net* net);
+
+/* The weight quantiser of precision "fp8" (host only): float -> OCP e4m3fn byte, round to nearest even, |v| >= 448 clamps to +-448,
+ * NaN -> 0x7f.  Exposed so that the CPU test suite can pin it against an independent e4m3 conversion. */
+int mi_e4m3_from_float(float v);
 
 /* Offline form of the same import: parse the ONNX file and write it as a .cranet container (what TensorrtAPI caches as a
  * serialized engine next to the ONNX, tensorrtapi.cpp:297-332).  Host only, no GPU needed.  0 on success. */

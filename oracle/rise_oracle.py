@@ -107,6 +107,13 @@ def forward(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, sim_d
         h = _q(h + t, sim_dtype)
         if taps is not None:
             taps[f"block{i}"] = h
+    return _heads(cfg, sd, h, sim_dtype)
+
+
+def _heads(cfg: RiseConfig, sd, h, sim_dtype=None):
+    """Policy and value head on the tower output h (the tail of forward)."""
+    W = (lambda n: sd[n]) if sim_dtype is None else (lambda n: sd[n].to(sim_dtype).to(torch.float32))
+    x = h
     # policy head
     ph = _q(F.relu(_bn(sd, "policy_head.body.1", F.conv2d(h, W("policy_head.body.0.weight"), padding=1))), sim_dtype)
     pol = F.conv2d(ph, W("policy_head.body.3.weight"), padding=1)
@@ -128,6 +135,91 @@ def forward(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, sim_d
         v = F.relu(F.linear(vh, sd["value_head.body_final.0.weight"], sd["value_head.body_final.0.bias"]))
         value = torch.tanh(F.linear(v, sd["value_head.body_final.2.weight"], sd["value_head.body_final.2.bias"]))
     return value, pol, aux
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Precision fp8 (the product's counterpart of the reference's TensorRT INT8 mode, tensorrtapi.cpp:229-248): emulation of the
+# quantisation points of the HIP tower kernel, NOT a restatement of reference code (TensorRT's calibrated INT8 kernels are not in
+# /root/reference).  What is pinned is the fp32 forward above; this function says which roundings the fp8 mode adds to it:
+#   stem, SE gates, heads ........ as Precision float16 (f16 storage)
+#   expand 1x1 ................... A = BN1-folded weights / s1[c] -> e4m3, B = residual stream (f16) -> e4m3, f32 accumulate,
+#                                  + b1 / s1, ReLU, f16 (s1[c] = 2^floor(log2 max|w[c]|), folded into the depthwise weights)
+#   depthwise .................... f16 weights (w2 * s1), f16 activations, accumulated in f16 by fused multiply-adds in tap order (the
+#                                  kernel's v_pk_fma_f16 chain, started at the f16 BN2 bias); output -> e4m3
+#   project 1x1 .................. A = BN3-folded weights / s3[c] -> e4m3, B = that e4m3 tile; y = f16(x + s3 * (acc + b3 / s3))
+# e4m3 = OCP e4m3fn, round to nearest even, clamped at +-448 (torch.float8_e4m3fn after a clamp).
+# --------------------------------------------------------------------------------------------------------------
+E4M3_MAX = 448.0
+
+
+def q_e4m3(x):
+    return x.clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def _fold(sd, conv, bn):
+    w = sd[conv + ".weight"].double()
+    s = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + BN_EPS)
+    return w * s.view(-1, 1, 1, 1), sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * s
+
+
+def row_scale_pow2(w):
+    m = w.abs().flatten(1).max(dim=1).values
+    e = torch.floor(torch.log2(m.clamp_min(2.0 ** -24)))
+    return torch.where(m > 0, torch.exp2(e), torch.ones_like(m))
+
+
+def _depthwise_f16_chain(t, w, b, k):
+    """depthwise k x k on f16 values with an f16 accumulator: acc = f16(b); acc = f16(x * w + acc) tap by tap, row-major (exactly what a
+    chain of fused multiply-adds in f16 computes; taps that fall off the board contribute x = 0)"""
+    acc = b.to(torch.float16).double().view(1, -1, 1, 1).expand(t.shape[0], -1, 8, 8)
+    tp = F.pad(t, (k // 2, k // 2, k // 2, k // 2)).double()
+    wd = w.to(torch.float16).double()
+    for dy in range(k):
+        for dx in range(k):
+            acc = (tp[:, :, dy:dy + 8, dx:dx + 8] * wd[:, 0, dy, dx].view(1, -1, 1, 1) + acc).to(torch.float16).double()
+    return acc.float()
+
+
+@torch.no_grad()
+def forward_fp8_tower(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor):
+    """(value, policy logits, aux) of Precision fp8 as emulated on the CPU (bottleneck-block nets only)."""
+    assert not cfg.dense_blocks
+    qh = lambda t: t.to(torch.float16).to(torch.float32)
+    x = x.to(torch.float32)
+    pre = cfg.key_prefix
+    # stem as the f16 kernels run it: BN folded into the weights BEFORE they are rounded to f16 (the roundings of this mode amplify a
+    # one-ulp difference of the stream into a difference of the size of the mode's own error, so the emulation follows the kernel's
+    # order of operations wherever it is cheap to)
+    w0, b0 = _fold(sd, pre + ".0.body.0", pre + ".0.body.1")
+    h = qh(F.relu(F.conv2d(qh(x), qh(w0.float()), padding=1) + b0.float().view(1, -1, 1, 1)))
+    for i, (k, se) in enumerate(zip(cfg.kernels, cfg.se_types)):
+        p = f"{pre}.{i + 1}"
+        if se in ("ca_se", "se"):
+            y = h.mean(dim=(2, 3))
+            y = F.hardsigmoid(F.linear(F.relu(F.linear(y, sd[p + ".se.fc.0.weight"])), sd[p + ".se.fc.2.weight"]))
+            h = qh(h * y[:, :, None, None])
+        elif se == "eca_se":
+            y = h.mean(dim=(2, 3))
+            w = sd[p + ".se.body.0.weight"]
+            y = F.hardsigmoid(F.conv1d(y[:, :, None], w, sd[p + ".se.body.0.bias"], padding=w.shape[2] // 2)[:, :, 0])
+            h = qh(h * y[:, :, None, None])
+        w1, b1 = _fold(sd, p + ".body.0", p + ".body.1")
+        w2, b2 = _fold(sd, p + ".body.3", p + ".body.4")
+        w3, b3 = _fold(sd, p + ".body.6", p + ".body.7")
+        s1, s3 = row_scale_pow2(w1), row_scale_pow2(w3)
+        t = F.conv2d(q_e4m3(h), q_e4m3((w1 / s1.view(-1, 1, 1, 1)).float())) + (b1 / s1).float().view(1, -1, 1, 1)
+        t = qh(F.relu(t))                                                            # t1 in units of s1
+        cop = t.shape[1]
+        t = q_e4m3(F.relu(_depthwise_f16_chain(t, (w2 * s1.view(-1, 1, 1, 1)).float(), b2.float(), k)))
+        t = F.conv2d(t, q_e4m3((w3 / s3.view(-1, 1, 1, 1)).float())) + (b3 / s3).float().view(1, -1, 1, 1)
+        h = qh(h + t * s3.float().view(1, -1, 1, 1))
+    return _heads(cfg, sd, h, torch.float16)
+
+
+@torch.no_grad()
+def predict_fp8_tower(cfg, sd, x):
+    value, pol, aux = forward_fp8_tower(cfg, sd, x)
+    return value.reshape(-1), torch.softmax(pol, dim=1), aux
 
 
 @torch.no_grad()

@@ -446,6 +446,38 @@ def main():
                        "frac": round(tf32 / PEAK_F32_TFLOPS, 4), "per_op_ms": {k: round(v, 4) for k, v in a32.items()},
                        "logit_tolerance_met": "1e-3 (tests bound 1e-4; measured 5e-6)"}
             net32.close()
+        # ---- the same workload in Precision fp8 (the counterpart of the reference's INT8 mode): e4m3 operands in the tower's GEMMs.
+        # A reduced-precision mode: reported beside the headline, never as `value`.  The error columns compare its predict() outputs
+        # with Precision float16 on the bench's own planes. ----
+        fp8 = None
+        if args.precision == "float16" and not args.timed_only:
+            net8 = HipAPI(local_rank, args.batch, tmp, "fp8")
+            xin = np.ascontiguousarray(x.numpy()).reshape(-1)
+            v8 = np.zeros(args.batch, np.float32); p8 = np.zeros(args.batch * cfg.nb_policy, np.float32)
+            v16 = np.zeros(args.batch, np.float32); p16 = np.zeros(args.batch * cfg.nb_policy, np.float32)
+            net8.predict(xin, v8, p8)
+            net.predict(xin, v16, p16)
+            torch.as_tensor(net8.device_buffers()["planes"], device="cuda").copy_(x.cuda())
+            torch.cuda.synchronize()
+            steps8 = max(30, args.steps // 2)
+            for _ in range(5):
+                net8.forward_device()
+            net8.sync()
+            t8 = time.perf_counter()
+            for _ in range(steps8):
+                net8.forward_device()
+            net8.sync()
+            el8 = time.perf_counter() - t8
+            a8 = {}
+            for name, ms in net8.time_ops(5):
+                a8[name] = a8.get(name, 0.0) + ms
+            tf8 = net8.flops_per_position() * args.batch * steps8 / el8 / 1e12
+            fp8 = {"evals_per_sec": round(steps8 * args.batch / el8, 1), "ms_per_step": round(el8 / steps8 * 1e3, 4), "steps": steps8,
+                   "achieved": round(tf8, 2), "unit": "TFLOP/s", "per_op_ms": {k: round(v, 4) for k, v in a8.items()},
+                   "speedup_over_float16": round((steps8 * args.batch / el8) / value, 4),
+                   "operands": "e4m3 in the expand / project GEMMs of the residual tower (v_mfma_f32_32x32x64_f8f6f4), f16 elsewhere",
+                   "max_abs_diff_vs_float16": {"value": round(float(np.abs(v8 - v16).max()), 5), "prob": round(float(np.abs(p8 - p16).max()), 7)}}
+            net8.close()
         # ---- PCIe-inclusive rate: the reference's `inference` command (crazyara.cpp:156-181) = back-to-back blocking predict() on the
         # NeuralNetAPIUser's pinned buffers, planes in and value / probabilities out through PCIe on every call.  With pinned buffers
         # predict issues no copy commands (kernels read / write the host buffers in place); the copy path is timed beside it, and two
@@ -503,6 +535,8 @@ def main():
             out["pcie_inclusive"] = pcie
         if float32:
             out["float32"] = float32
+        if fp8:
+            out["fp8"] = fp8
         if mcts:
             out["mcts"] = mcts
         if mcts_configs:

@@ -72,9 +72,11 @@ template <typename T> int block_chunk_channels();   // C_op must be padded to a 
 //            rows = channels chunk*128 + w*32 + row), then 16 project fragments of chunk k-1 ([k-step of 16][row tile of 32],
 //            rows = couts w*64 + rt*32 + row, k = tower K position); kTowerWindow zero fragments at the very end
 //   bstream  4 matrix waves x per chunk [lane/32][element v] BN1 bias of row (v%4) + 8*(v/4) + 4*(lane/32)   (32 floats)
-//   pstream  4 vector waves x per chunk 2 KiB = [32 entries][lane group lg][4 channel pairs] half2 for K positions
-//            w*32 + lg*8 + pi*2 + {0,1}; entries = k*k folded taps then the BN2 bias (k = 3: 0..8, 9; k = 5: 0..24, 25), rest zero;
-//            one chunk of padding at the end
+//   pstream  4 vector waves x per chunk 2 KiB of half2 for K positions w*32 + lg*8 + pi*2 + {0,1}; entries = k*k folded taps then the BN2
+//            bias (k = 3: 0..8, 9; k = 5: 0..24, 25), rest zero; one chunk of padding at the end
+//              k = 5: [32 entries][lane group lg][4 channel pairs]
+//              k = 3: [10 entries][lane group lg][file variant][4 channel pairs]: variant 0 = for squares on file a (dx = -1 taps zero),
+//                     1 = files b..g, 2 = file h (dx = +1 taps zero)
 constexpr int kTowerWindow = 16;
 struct TowerBlockDesc {
     const float* b3;      // [256] BN3 bias (Precision fp8: divided by s3)

@@ -696,17 +696,33 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                                 const int ch = c * 128 + w * 32 + (v % 4) + 8 * (v / 4) + 4 * lh;
                                 tower_bs[w].push_back(ch < cop ? float(f1.b[ch] / s1[ch]) : 0.f);
                             }
-                        // depthwise weights [32 entries: k*k taps, BN2 bias, pad][lg][pair pi][2] for K positions w*32 + lg*8 + pi*2 + {0,1}
-                        // (entry-major: the four lane groups of one broadcast read sit in four different 16-byte bank slots)
-                        for (int ent = 0; ent < 32; ++ent)
-                            for (int lgk = 0; lgk < 4; ++lgk)
-                                for (int pi = 0; pi < 4; ++pi)
-                                    for (int hh = 0; hh < 2; ++hh) {
-                                        const int ch = tower_k_channel(c * 128 + w * 32 + lgk * 8 + pi * 2 + hh);
-                                        double v = 0.0;
-                                        if (ch < cop && ent <= k * k) v = ent < k * k ? f2.w[size_t(ch) * k * k + ent] * s1[ch] : f2.b[ch];
-                                        tower_ps[w].push_back(half_t(float(v)));
-                                    }
+                        // depthwise weights for K positions w*32 + lg*8 + pi*2 + {0,1}, entries = k*k taps then the BN2 bias:
+                        //   5 x 5: [32 entries][lg][pair pi][2]   (entry-major: the four lane groups of a broadcast read sit in four bank slots)
+                        //   3 x 3: [10 entries][lg][file variant][pair pi][2], variant 0 = file a (taps with dx = -1 zeroed), 1 = files b..g,
+                        //          2 = file h (dx = +1 zeroed); zero padding up to the chunk's 2 KiB
+                        auto dwv = [&](int lgk, int ent, int pi, int hh) {
+                            const int ch = tower_k_channel(c * 128 + w * 32 + lgk * 8 + pi * 2 + hh);
+                            double v = 0.0;
+                            if (ch < cop && ent <= k * k) v = ent < k * k ? f2.w[size_t(ch) * k * k + ent] * s1[ch] : f2.b[ch];
+                            return v;
+                        };
+                        const size_t chunk_begin = tower_ps[w].size();
+                        if (k == 3) {
+                            for (int ent = 0; ent < 10; ++ent)
+                                for (int lgk = 0; lgk < 4; ++lgk)
+                                    for (int var = 0; var < 3; ++var)
+                                        for (int pi = 0; pi < 4; ++pi)
+                                            for (int hh = 0; hh < 2; ++hh) {
+                                                const bool off_board = ent < 9 && ((var == 0 && ent % 3 == 0) || (var == 2 && ent % 3 == 2));
+                                                tower_ps[w].push_back(half_t(off_board ? 0.f : float(dwv(lgk, ent, pi, hh))));
+                                            }
+                        } else {
+                            for (int ent = 0; ent < 32; ++ent)
+                                for (int lgk = 0; lgk < 4; ++lgk)
+                                    for (int pi = 0; pi < 4; ++pi)
+                                        for (int hh = 0; hh < 2; ++hh) tower_ps[w].push_back(half_t(float(dwv(lgk, ent, pi, hh))));
+                        }
+                        tower_ps[w].resize(chunk_begin + 1024, half_t(0.f));
                     }
                 }
                 td.b3 = im.upload_d2f(f3.b, C);

@@ -63,7 +63,8 @@ constexpr int TW_XQ_OFF = TW_DYN_LDS_BYTES;
 constexpr int TW_XQ_BYTES = 64 * TW_XQROW;                    // 17408
 constexpr int TW_DYN_LDS_BYTES_F8 = TW_XQ_OFF + TW_XQ_BYTES;
 // Depthwise weights: a static LDS array, 4 vector waves x 2 buffers x 2 KiB, filled by LDS-DMA.
-constexpr int TW_PRM_ENT = 64;                                // bytes per entry of a buffer: [entry][lane group][16 B]
+constexpr int TW_PRM_ENT = 64;                                // bytes per entry of a 5 x 5 buffer: [entry][lane group][16 B]
+constexpr int TW_PRM_ENT3 = 192;                              // 3 x 3: [entry][lane group][file variant: a | b..g | h][16 B]
 constexpr int TW_PRM_BUF = 32 * TW_PRM_ENT;
 constexpr int TW_PRM_BYTES = 4 * 2 * TW_PRM_BUF;
 constexpr int TW_LDS_BYTES = TW_DYN_LDS_BYTES + TW_PRM_BYTES;
@@ -389,11 +390,14 @@ __device__ __forceinline__ void vector_store(char* t2w, int parity, int t, const
     else *reinterpret_cast<uint4*>(t2w + parity * TW_T2_BYTES + t * 16 * TW_T2ROW * 2) = uint4{o[0], o[1], o[2], o[3]};
 }
 
+// prm_off: byte offset of my weights inside an entry = lane group * 48 + file variant * 16.  The board has no file left of a and none
+// right of h: instead of multiplying the taps that leave the board by zero in every interval (24 packed multiplies), the stream
+// carries the weights three times -- as they are, with the dx = -1 taps zeroed (file a), with the dx = +1 taps zeroed (file h).
 template <int PARITY, bool F8>
-__device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf, int lg, const VecAddr& va, char* t2w, half2_t mLp, half2_t mRp) {
+__device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf, int prm_off, const VecAddr& va, char* t2w) {
     constexpr int T1ROW = TW_T1ROW;
     constexpr int TILE = 16 * T1ROW * 2;             // bytes between square tiles of a t1 buffer
-    const char* prm = prm_buf + lg * 16;
+    const char* prm = prm_buf + prm_off;
     // rows of neighbours: top(t) | mid(t) | bot(t), 3 reads each; bot(t) == top(t + 1)
     uint4 top[3], mid[3], bot[3], nmid[3], nbot[3];
 #pragma unroll
@@ -405,14 +409,9 @@ __device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf
     half2_t W[10][4];
 #pragma unroll
     for (int e = 0; e < 10; ++e) {
-        const uint4 u = *reinterpret_cast<const uint4*>(prm + e * TW_PRM_ENT);
+        const uint4 u = *reinterpret_cast<const uint4*>(prm + e * TW_PRM_ENT3);
         W[e][0] = __builtin_bit_cast(half2_t, u.x); W[e][1] = __builtin_bit_cast(half2_t, u.y);
         W[e][2] = __builtin_bit_cast(half2_t, u.z); W[e][3] = __builtin_bit_cast(half2_t, u.w);
-    }
-#pragma unroll
-    for (int pi = 0; pi < 4; ++pi) {                 // file a has no left neighbour, file h no right neighbour
-        W[0][pi] *= mLp; W[3][pi] *= mLp; W[6][pi] *= mLp;
-        W[2][pi] *= mRp; W[5][pi] *= mRp; W[8][pi] *= mRp;
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -869,6 +868,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
             TW_STAMP();
         }
     } else {
+        if constexpr (F8) __builtin_amdgcn_s_setprio(2);     // fp8: the depthwise waves bound the interval (measured 1-2 %; no effect in f16)
         VParams vp;
         vp.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.pstream)) + size_t(w) * a.pstream_wave_bytes, 0, 0x7fffffff, 0x00020000);
         vp.pos = 0;
@@ -878,7 +878,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
         vp.fetch(0, 0);                  // the first chunk's weights
         const bool hi = l15 >= 8;        // second board row of a 16-square tile
         const half2_t one2 = {half_t(1.f), half_t(1.f)}, zero2 = {half_t(0.f), half_t(0.f)};
-        const half2_t mLp = (l15 & 7) != 0 ? one2 : zero2, mRp = (l15 & 7) != 7 ? one2 : zero2;
+        const int prm_off3 = lg * 48 + ((l15 & 7) == 0 ? 0 : (l15 & 7) == 7 ? 32 : 16);    // 3 x 3 weights: my lane group, my file's variant
         // neighbour rows of my square in tile 0 (buffer rows: 0 = zero row, 1 + sq, 65 = zero row); file wrap-around reads a
         // wrong-but-finite row that meets a zero weight
         VecAddr va;
@@ -991,8 +991,8 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                         if (k & 1) vector_interval5<1, F8>(vp, prm_buf, lg, va5, t2w, mk5);
                         else vector_interval5<0, F8>(vp, prm_buf, lg, va5, t2w, mk5);
                     } else {
-                        if (k & 1) vector_interval<1, F8>(vp, prm_buf, lg, va, t2w, mLp, mRp);
-                        else vector_interval<0, F8>(vp, prm_buf, lg, va, t2w, mLp, mRp);
+                        if (k & 1) vector_interval<1, F8>(vp, prm_buf, prm_off3, va, t2w);
+                        else vector_interval<0, F8>(vp, prm_buf, prm_off3, va, t2w);
                     }
                 }
 #ifdef TW_TRACE_BARRIERS

@@ -314,7 +314,7 @@ private:
     ConvUnit conv_unit(int idx) const;
     bool is_linear(const Node& n) const { return n.op == "Gemm" || n.op == "MatMul"; }
     Linear linear(const Node& n) const;
-    std::string se_gate(const std::string& x, const std::string& prefix, std::string& se_type);
+    std::string se_gate(const std::string& x, const std::string& prefix, std::string& se_type, bool plain_sigmoid = false);
 
     void put(const std::string& name, std::vector<int64_t> dims, std::vector<float> data) { out_.push_back({name, std::move(dims), std::move(data)}); }
     void put_conv_bn(const std::string& conv, const std::string& bn, const ConvUnit& u);
@@ -504,8 +504,9 @@ void Importer::put_linear(const std::string& name, const Linear& l, bool with_bi
 }
 
 // x -> GlobalAveragePool -> (eca: Conv1d | ca: Linear, Relu, Linear) -> HardSigmoid -> Mul(x, gate).  Returns the Mul's output.
-// _EfficientChannelAttentionModule / _ChannelAttentionModule, builder_util.py:49-114
-std::string Importer::se_gate(const std::string& x, const std::string& prefix, std::string& se_type) {
+// _EfficientChannelAttentionModule / _ChannelAttentionModule, builder_util.py:49-114.  plain_sigmoid: the gate of AlphaZero's
+// ResidualBlock(use_se) = get_se("se", use_hard_sigmoid=False) on the body output (a0_resnet.py:94-95): ca form, Sigmoid activation.
+std::string Importer::se_gate(const std::string& x, const std::string& prefix, std::string& se_type, bool plain_sigmoid) {
     const std::vector<int>& c = cons(x);
     int gap = pick(c, "GlobalAveragePool");
     if (gap < 0) gap = pick(c, "ReduceMean");
@@ -540,10 +541,13 @@ std::string Importer::se_gate(const std::string& x, const std::string& prefix, s
     } else {
         fail(first.label() + ": unsupported channel gate (ca_se and eca_se are)");
     }
-    const Node* hs = sole(t, "HardSigmoid");
-    if (!hs) fail("channel gate at " + prefix + ": the gate activation must be HardSigmoid");
-    if (std::fabs(hs->float_attr("alpha", 0.2f) - 1.f / 6.f) > 1e-6f || std::fabs(hs->float_attr("beta", 0.5f) - 0.5f) > 1e-6f)
+    const Node* hs = sole(t, plain_sigmoid ? "Sigmoid" : "HardSigmoid");
+    if (!hs) fail("channel gate at " + prefix + ": the gate activation must be " + (plain_sigmoid ? "Sigmoid" : "HardSigmoid"));
+    if (plain_sigmoid) {
+        if (se_type != "ca_se") fail("channel gate at " + prefix + ": the gate on a residual branch's output is Linear -> Relu -> Linear -> Sigmoid");
+    } else if (std::fabs(hs->float_attr("alpha", 0.2f) - 1.f / 6.f) > 1e-6f || std::fabs(hs->float_attr("beta", 0.5f) - 0.5f) > 1e-6f) {
         fail(hs->label() + ": expected torch.nn.Hardsigmoid (alpha 1/6, beta 1/2)");
+    }
     const Node& m = nodes_[size_t(mul)];
     const std::string &a = resolve(m.in[0]), &b = resolve(m.in[1]), &xs = resolve(x), &gs = resolve(hs->out[0]);
     if (!((a == xs && b == gs) || (a == gs && b == xs))) fail(m.label() + ": expected block input x gate");
@@ -600,9 +604,15 @@ void Importer::run() {
             if (units.size() > 3) fail("residual block " + p + ": more than three convolutions");
         }
         const Node& an = nodes_[size_t(add)];
+        // AlphaZero's ResidualBlock(use_se): the branch output goes through a channel gate (plain sigmoid) before the shortcut
+        std::string branch_out = units.back().out, se_out = "none";
         {
-            const std::vector<int>& n = cons(units.back().out);
-            const std::string &a = resolve(an.in[0]), &b = resolve(an.in[1]), &xs = resolve(x), &us = resolve(units.back().out);
+            const std::vector<int>& n = cons(branch_out);
+            if (n.size() == 2 && pick(n, "Mul") >= 0) branch_out = se_gate(branch_out, p, se_out, true);
+        }
+        {
+            const std::vector<int>& n = cons(branch_out);
+            const std::string &a = resolve(an.in[0]), &b = resolve(an.in[1]), &xs = resolve(x), &us = resolve(branch_out);
             if (n.size() != 1 || n[0] != add || !((a == xs && b == us) || (a == us && b == xs)))
                 fail("residual block " + p + ": branch must end in the Add with the block input");
         }
@@ -615,6 +625,7 @@ void Importer::run() {
             const bool ok = e.k == 1 && e.group == 1 && e.relu && e.cin_g == C && d.group == e.cout && d.cin_g == 1 && d.cout == e.cout && d.k > 1 && d.relu &&
                             pr.k == 1 && pr.group == 1 && !pr.relu && pr.cin_g == e.cout && pr.cout == C && !post_relu;
             if (!ok) fail("residual block " + p + ": not a mobile bottleneck (1x1+ReLU, depthwise+ReLU, 1x1)");
+            if (se_out != "none") fail("residual block " + p + ": a bottleneck block gates its input, not its branch output");
             kind = "mobile_bottlekneck_res_block";
             put_conv_bn(p + ".body.0", p + ".body.1", e);
             put_conv_bn(p + ".body.3", p + ".body.4", d);
@@ -628,7 +639,11 @@ void Importer::run() {
             if (b.relu && !post_relu) kind = "classical_res_block";           // x + ReLU(BN(conv(..)))        builder_util.py:401-434
             else if (!b.relu && post_relu) kind = "a0_res_block";             // ReLU(x + BN(conv(..)))        a0_resnet.py:72-107
             else fail("residual block " + p + ": unknown activation placement around the residual Add");
-            if (se != "none") fail("residual block " + p + ": channel gates inside dense residual blocks are not supported");
+            // where the reference's two dense blocks put their gate: ClassicalResidualBlock on the block input (hard-sigmoid,
+            // builder_util.py:416,431-433), AlphaZero's ResidualBlock on the body output (plain sigmoid, a0_resnet.py:94-107)
+            if (kind == "classical_res_block" && se_out != "none") fail("residual block " + p + ": a classical residual block gates its input, not its branch output");
+            if (kind == "a0_res_block" && se != "none") fail("residual block " + p + ": an AlphaZero residual block gates its branch output, not its input");
+            if (kind == "a0_res_block") se = se_out;
             put_conv_bn(p + ".body.0", p + ".body.1", a);
             put_conv_bn(p + ".body.3", p + ".body.4", b);
             cops.push_back(C);

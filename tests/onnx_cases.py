@@ -25,6 +25,12 @@ CASES = {
                   34, "classical-v1.0.onnx", None),
     "alphazero": (_cfg(channels_operating_init=16, channel_expansion=0, conv_block="a0_res_block", channels_value_head=1, name="alphazero"),
                   35, "alphazero-v3.0.onnx", None),
+    # channel gates INSIDE the dense blocks: ClassicalResidualBlock(se_type) gates the block input (hard-sigmoid, builder_util.py:416,431-433),
+    # AlphaZero's ResidualBlock(use_se) gates the body output with a plain sigmoid before the shortcut (a0_resnet.py:94-107)
+    "classical-se": (_cfg(channels_operating_init=16, channel_expansion=0, conv_block="classical_res_block", se_types=["ca_se", "eca_se"],
+                          name="classical-se"), 37, "classical-se-v1.0.onnx", None),
+    "alphazero-se": (_cfg(channels_operating_init=16, channel_expansion=0, conv_block="a0_res_block", channels_value_head=1,
+                          se_types=["se", "se"], name="alphazero-se"), 38, "alphazero-se-v3.0.onnx", None),
     # torch-default initialisation: every BatchNorm has the same statistics, the exporter shares them through Identity nodes
     "mobile-shared-constants": (_cfg(kernels=[3, 5, 3], se_types=[None, "eca_se", "ca_se"], use_wdl=True, use_plys_to_end=True,
                                      name="mobile-shared-constants"), 36, "mobile-shared-constants-v3.0.onnx", None, False),

@@ -156,6 +156,17 @@ def rise_to_onnx(cfg, sd, batch=None, fold_bn: bool = True, linear: str = "gemm"
     x = b.conv_bn("data", f"{pre}.0.body.0", f"{pre}.0.body.1", True)
     for i, (k, cop, se) in enumerate(zip(cfg.kernels, cfg.channels_operating(), cfg.se_types)):
         p = f"{pre}.{i + 1}"
+        if cfg.conv_block == "a0_res_block":             # ResidualBlock(use_se): the gate sits on the branch output, plain sigmoid
+            y = b.conv_bn(x, p + ".body.0", p + ".body.1", True)
+            y = b.conv_bn(y, p + ".body.3", p + ".body.4", False)
+            if se is not None:
+                g = b.flatten(b.op("GlobalAveragePool", [y]), C)
+                g = b.op("Relu", [b.fc(g, p + ".se.fc.0", False)])
+                g = b.op("Sigmoid", [b.fc(g, p + ".se.fc.2", False)])
+                g = b.op("Reshape", [g, b.init("shape", np.array([-1, C, 1, 1], np.int64))])
+                y = b.op("Mul", [y, g])
+            x = b.op("Relu", [b.op("Add", [x, y])])
+            continue
         if se in ("ca_se", "se"):
             y = b.flatten(b.op("GlobalAveragePool", [x]), C)
             y = b.op("Relu", [b.fc(y, p + ".se.fc.0", False)])

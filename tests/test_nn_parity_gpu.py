@@ -270,7 +270,8 @@ def test_predict_from_board_descriptors_equals_predict_from_planes(tmp_path, hip
 
 
 @pytest.mark.parametrize("flavour", [dict(fold_bn=True, linear="gemm"), dict(fold_bn=False, linear="matmul")])
-@pytest.mark.parametrize("name", ["risev2-3", "risev33-wdlp", "rise-classical-4", "alphazero-3-cv8", "risev2-3-flat"])
+@pytest.mark.parametrize("name", ["risev2-3", "risev33-wdlp", "rise-classical-4", "alphazero-3-cv8", "risev2-3-flat", "rise-classical-3-se",
+                                  "alphazero-3-se"])
 def test_onnx_model_directory_loads_and_matches_golden(tmp_path, hip_lib, name, flavour):
     """a model directory holding only the reference's file format ("<prefix>-v<ver>.onnx") goes through
     mi_net_create (ONNX parsed in place, csrc/nn/onnx_import.cpp) and reproduces the reference model's outputs (committed goldens)."""

@@ -123,7 +123,8 @@ def test_files_of_the_torch_exporter(lib, tmp_path, name):
 
 @pytest.mark.parametrize("flavour", [dict(fold_bn=False, linear="gemm"), dict(fold_bn=True, linear="matmul"),
                                      dict(fold_bn=False, linear="matmul", raw=False), dict(fold_bn=True, linear="gemm", batch=8)])
-@pytest.mark.parametrize("name", ["risev2-3", "risev33-wdlp", "rise-classical-4", "alphazero-3-cv8", "risev2-3-flat"])
+@pytest.mark.parametrize("name", ["risev2-3", "risev33-wdlp", "rise-classical-4", "alphazero-3-cv8", "risev2-3-flat", "rise-classical-3-se",
+                                  "alphazero-3-se"])
 def test_other_exporter_flavours_at_full_size(lib, tmp_path, name, flavour):
     cfg, sd, _ = nn_cases.make_case(name)
     data = onnx_writer.rise_to_onnx(cfg, sd, **flavour)

@@ -29,6 +29,7 @@ BATCH = 256
 N_BLOCKS = 19
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+PEAK_FP8_TFLOPS = 5000.0      # dense fp8 MFMA peak (v_mfma_f32_32x32x64_f8f6f4 measures 4.41 PFLOP/s at the 2.10 GHz it settles at)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -472,8 +473,11 @@ def main():
             for name, ms in net8.time_ops(5):
                 a8[name] = a8.get(name, 0.0) + ms
             tf8 = net8.flops_per_position() * args.batch * steps8 / el8 / 1e12
+            f8_share = 876.6 / 1002.6 if args.blocks == N_BLOCKS else None      # FLOPs of the tower's 1x1 GEMMs / all FLOPs
             fp8 = {"evals_per_sec": round(steps8 * args.batch / el8, 1), "ms_per_step": round(el8 / steps8 * 1e3, 4), "steps": steps8,
-                   "achieved": round(tf8, 2), "unit": "TFLOP/s", "per_op_ms": {k: round(v, 4) for k, v in a8.items()},
+                   "achieved": round(tf8, 2), "unit": "TFLOP/s", "peak_8bit": PEAK_FP8_TFLOPS, "frac_of_8bit_peak": round(tf8 / PEAK_FP8_TFLOPS, 4),
+                   "share_of_flops_in_8bit": None if f8_share is None else round(f8_share, 3),
+                   "per_op_ms": {k: round(v, 4) for k, v in a8.items()},
                    "speedup_over_float16": round((steps8 * args.batch / el8) / value, 4),
                    "operands": "e4m3 in the expand / project GEMMs of the residual tower (v_mfma_f32_32x32x64_f8f6f4), f16 elsewhere",
                    "max_abs_diff_vs_float16": {"value": round(float(np.abs(v8 - v16).max()), 5), "prob": round(float(np.abs(p8 - p16).max()), 7)}}

@@ -27,10 +27,17 @@ if [ "${3:-pmc}" = "pmc" ]; then
   run tcc1 FETCH_SIZE TCC_HIT_sum
   run tcc2 WRITE_SIZE TCC_MISS_sum
   run grbm GRBM_GUI_ACTIVE
+  # the same forward in Precision fp8 (e4m3 GEMM operands): MFMA / LDS / L2 counters and a kernel trace of its own
+  run8() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python $REPO/scripts/prof_forward.py 19 256 fp8 3 > $OUT/$name.log 2>&1; }
+  run8 fp8_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
+  run8 fp8_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_WAVES
+  run8 fp8_tcc1 FETCH_SIZE TCC_HIT_sum
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fp8_trace -- python $REPO/scripts/prof_forward.py 19 256 fp8 200 > $OUT/fp8_trace.log 2>&1
   cd $REPO
-  for p in sq1 sq2 sq3 tcc1 tcc2 grbm; do python scripts/pmc_summary.py $OUT/$p > $OUT/pmc_$p.txt 2>&1; done
+  for p in sq1 sq2 sq3 tcc1 tcc2 grbm fp8_sq1 fp8_sq2 fp8_tcc1; do python scripts/pmc_summary.py $OUT/$p > $OUT/pmc_$p.txt 2>&1; done
   # raw counter CSVs are large; keep the summaries only
-  for p in sq1 sq2 sq3 tcc1 tcc2 grbm; do rm -rf $OUT/$p; done
+  for p in sq1 sq2 sq3 tcc1 tcc2 grbm fp8_sq1 fp8_sq2 fp8_tcc1; do rm -rf $OUT/$p; done
+  find $OUT/fp8_trace -type f ! -name "*stats*.csv" -delete
 fi
 # keep only the stats csvs of the trace
 find $OUT/trace -type f ! -name "*stats*.csv" -delete

@@ -96,6 +96,16 @@ SIGNATURES = {
     "mi_traindata_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mi_search_set_shared_collectors": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_selfplay_default_settings": (None, [C.c_void_p]),
+    "mi_selfplay_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p]),
+    "mi_selfplay_destroy": (None, [C.c_void_p]),
+    "mi_selfplay_set_start_fens": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mi_selfplay_play": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mi_selfplay_game": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_long]),
+    "mi_selfplay_get_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi_policy_apply_temperature": (None, [C.POINTER(C.c_double), C.c_int, C.c_double]),
+    "mi_policy_get_quantile": (C.c_double, [C.POINTER(C.c_double), C.c_int, C.c_double]),
+    "mi_policy_apply_quantile_clipping": (None, [C.POINTER(C.c_double), C.c_int, C.c_double]),
     "mi_search_tree_dump": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_long]),
 }
 

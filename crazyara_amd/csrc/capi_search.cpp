@@ -11,15 +11,12 @@
 
 #include "capi_common.h"
 #include "capi_net.h"
+#include "capi_search_handle.h"
 #include "capi_traindata.h"
 #include "search/pool.h"
 
 using namespace cra;
 using namespace cra::search;
-
-struct mi_search {
-    std::unique_ptr<SearchPool> pool;
-};
 
 namespace {
 SearchSettings convert(const mi_search_settings& m) {

@@ -1,0 +1,376 @@
+// Native self-play / arena loops -- see selfplay.h for the reference lines each step follows.
+#include "selfplay.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cfloat>
+#include <numeric>
+#include <stdexcept>
+
+namespace cra {
+namespace rl {
+
+using chess::Move;
+using chess::Position;
+using search::SearchStats;
+using search::Tree;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// blazeutil.h / agent.cpp helpers
+// ---------------------------------------------------------------------------------------------------------------------
+void apply_temperature(std::vector<double>& p, double t) {           // blazeutil.h:77-87: p^(1/T) renormalised; T == 1 leaves p untouched
+    if (t == 1.0) return;
+    double sum = 0;
+    for (double& v : p) { v = std::pow(v, 1.0 / t); sum += v; }
+    for (double& v : p) v /= sum;
+}
+
+// get_quantile (blazeutil.h:188-212), literally: sort ascending; 0 if the smallest entry already reaches the quantile; else accumulate
+// (in float32) from the SECOND smallest entry and return the entry BEFORE the one that crosses the quantile, plus FLT_EPSILON.  A
+// quantile above the mass behind the smallest entry: the reference asserts(false); release builds fall through (nothing is clipped).
+double get_quantile(const std::vector<double>& p, double quantile) {
+    std::vector<double> order(p);
+    std::sort(order.begin(), order.end());
+    if (order.empty() || order[0] >= quantile) return 0.0;
+    float acc = 0.f;
+    for (size_t i = 1; i < order.size(); ++i) {
+        acc = float(double(acc) + order[i]);
+        if (acc >= quantile) return order[i - 1] + double(FLT_EPSILON);
+    }
+    return -1.0;
+}
+
+void apply_quantile_clipping(double quantile, std::vector<double>& p) {    // agent.cpp:121-130
+    const double thresh = get_quantile(p, quantile);
+    double sum = 0;
+    for (double& v : p) { if (v < thresh) v = 0.0; sum += v; }              // sequential double sum, as the reference's loop adds it
+    for (double& v : p) v /= sum;
+}
+
+namespace {
+size_t sample_index(std::mt19937_64& rng, const std::vector<double>& p) {   // random_choice: inverse CDF on a uniform draw
+    double sum = 0;
+    for (double v : p) sum += v;
+    const double u = std::uniform_real_distribution<double>(0.0, 1.0)(rng) * sum;
+    double acc = 0;
+    for (size_t i = 0; i < p.size(); ++i) {
+        acc += p[i];
+        if (u < acc) return i;
+    }
+    for (size_t i = p.size(); i-- > 0;)
+        if (p[i] > 0) return i;
+    return 0;
+}
+double uniform01(std::mt19937_64& rng) { return std::uniform_real_distribution<double>(0.0, 1.0)(rng); }
+
+Position make_position(const std::string& fen, bool is960, chess::Variant v) {
+    Position p;
+    p.set(fen.empty() ? chess::start_fen(v) : fen, is960, v);
+    return p;
+}
+
+// play_move_and_update's bookkeeping for one move: SAN with '#' for a decisive end, the result from White's point of view
+int result_for_white(const Position& pos, chess::TerminalType t) {
+    const bool stm_white = pos.side_to_move() == chess::WHITE;
+    if (t == chess::TERMINAL_DRAW) return 0;
+    if (t == chess::TERMINAL_LOSS) return stm_white ? -1 : 1;              // the side to move has lost
+    return stm_white ? 1 : -1;
+}
+std::string mark_mate(std::string san, chess::TerminalType t) {
+    if (t == chess::TERMINAL_WIN || t == chess::TERMINAL_LOSS) {
+        if (!san.empty() && san.back() == '+') san.back() = '#';
+        else san += "#";
+    }
+    return san;
+}
+chess::TerminalType terminal_of(const Position& pos) {
+    std::vector<Move> mv;
+    pos.legal_moves(mv);
+    return pos.is_terminal(mv.size());
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// self-play
+// ---------------------------------------------------------------------------------------------------------------------
+SelfPlayDriver::SelfPlayDriver(search::SearchPool* pool, const SelfPlaySettings& s, int concurrent, chess::Variant variant, bool is960,
+                               TrainDataExporter* exporter)
+    : pool_(pool), s_(s), concurrent_(concurrent), variant_(variant), is960_(is960), exporter_(exporter) {
+    if (!pool || concurrent < 1) throw std::invalid_argument("self-play needs a pool and at least one concurrent game");
+    if (pool->n_trees() != 0) throw std::invalid_argument("the pool must be empty when the game loop takes it over");
+    if (!s.simulations && !s.nodes) throw std::invalid_argument("self-play needs a simulations or a nodes budget");
+    games_.resize(size_t(concurrent));
+    for (int slot = 0; slot < concurrent; ++slot) {
+        const int t = pool->add_position(make_position("", is960, variant));
+        if (t != slot) throw std::logic_error("tree slots out of order");
+        pool->set_active(slot, false);
+    }
+}
+
+void SelfPlayDriver::finish(Game& g, int result, const char* why) {
+    g.rec.result = result;
+    g.rec.termination = why;
+    if (exporter_) {                                                       // generate_game: samples are written once the result is known
+        exporter_->new_game();
+        for (const Game::Sample& sm : g.samples) exporter_->save_sample(sm.pos, sm.moves, sm.policy.data(), sm.policy.size(), sm.q);
+        stats_.samples += exporter_->export_game_samples(result > 0 ? WHITE_WIN : result < 0 ? BLACK_WIN : DRAWN);
+    }
+    finished_.push_back(std::move(g.rec));
+    // the slot's tree sits out the following runs until a new game takes it (a finished game's tree would otherwise be searched to the
+    // full budget every round and its visits counted as nodes)
+    pool_->set_active(g.slot, false);
+    games_[size_t(g.slot)].reset();
+}
+
+bool SelfPlayDriver::check_over(Game& g, const std::string* san, const std::string* uci) {
+    const chess::TerminalType t = terminal_of(g.pos);
+    if (san) {
+        g.rec.san.push_back(mark_mate(*san, t));
+        g.rec.uci.push_back(*uci);
+    }
+    if (t == chess::TERMINAL_NONE) return false;
+    finish(g, result_for_white(g.pos, t), "terminal");
+    return true;
+}
+
+// refill free slots; init_starting_state_from_raw_policy for all games that start in this round, ply by ply, one batch per ply
+void SelfPlayDriver::start_games(size_t n_games) {
+    std::vector<Game*> fresh;
+    for (int slot = 0; slot < concurrent_; ++slot) {
+        if (games_[size_t(slot)] || started_ >= n_games) continue;
+        const size_t idx = started_++;
+        std::unique_ptr<Game> g(new Game);
+        g->slot = slot;
+        std::seed_seq seq{uint32_t(s_.seed), uint32_t(s_.seed >> 32), uint32_t(idx), uint32_t(uint64_t(idx) >> 32)};
+        g->rng.seed(seq);
+        g->pos = make_position(start_fens_.empty() ? std::string() : start_fens_[idx % start_fens_.size()], is960_, variant_);
+        g->rec.start_fen = g->pos.fen();
+        pool_->reset_position(slot, g->pos);
+        pool_->set_active(slot, true);
+        if (s_.mean_init_ply > 0) {                                        // plies ~ round(Exp(mean)), clipped (selfplay.cpp:196-197)
+            const double e = std::exponential_distribution<double>(1.0 / s_.mean_init_ply)(g->rng);
+            g->opening_left = std::min(int(e + 0.5), s_.max_init_ply);
+            g->in_opening = g->opening_left > 0;
+        }
+        fresh.push_back(g.get());
+        games_[size_t(slot)] = std::move(g);
+    }
+    for (;;) {
+        bool any = false;
+        for (Game* g : fresh) any = any || g->in_opening;
+        if (!any) break;
+        SearchStats st;
+        pool_->evaluate_new_roots(&st);                                     // the raw policy of every position that needs one, batched
+        stats_.nn_evals += st.nn_evals;
+        for (Game* g : fresh) {
+            if (!g->in_opening) continue;
+            Tree& t = pool_->tree(g->slot);
+            const search::Node& root = t.root();
+            const size_t n = root.actions.size();
+            if (n == 0 || root.terminal) { g->in_opening = false; continue; }
+            std::vector<double> p(n, 1.0);
+            if (n > 1) {
+                for (size_t i = 0; i < n; ++i) p[i] = double(root.priors[i]);
+            }
+            if (uniform01(g->rng) < s_.raw_policy_prob_temperature) {     // apply_raw_policy_temp (selfplay.cpp:474-488)
+                const double u = uniform01(g->rng);
+                apply_temperature(p, u < 0.05 ? 10.0 : u < 0.25 ? 5.0 : 2.0);
+            }
+            const Move mv = root.actions[sample_index(g->rng, p)];
+            Position nxt = g->pos;
+            nxt.do_move(mv);
+            if (terminal_of(nxt) != chess::TERMINAL_NONE) { g->in_opening = false; continue; }     // leads_to_terminal: keep the game alive
+            g->rec.san.push_back(g->pos.move_to_san(mv) + " {book}");
+            g->rec.uci.push_back(g->pos.move_to_uci(mv));
+            g->pos = nxt;
+            t.apply_move(mv);                                              // the tree restarts at the new position, move history kept
+            if (--g->opening_left == 0) g->in_opening = false;
+        }
+    }
+    for (Game* g : fresh) {
+        g->rec.book_plies = int(g->rec.uci.size());
+        g->allow_resign = s_.resign_probability >= 0.01 && uniform01(g->rng) < s_.resign_probability;
+        check_over(*g, nullptr, nullptr);                                  // a start position can already be decided
+    }
+}
+
+size_t SelfPlayDriver::play(size_t n_games, int threads) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (finished_.size() < n_games) {
+        start_games(n_games);
+        std::vector<Game*> active;
+        for (auto& g : games_) if (g) active.push_back(g.get());
+        if (active.empty()) {
+            if (started_ >= n_games) break;
+            continue;                                                      // every fresh game was over at once: refill again
+        }
+        uint32_t sims = s_.simulations, nodes = s_.simulations ? 0 : s_.nodes;
+        if (s_.node_random_factor > 0 && s_.nodes) {                      // adjust_node_count (one draw per round)
+            const int span = int(double(s_.nodes) * s_.node_random_factor);
+            if (span > 0) {
+                sims = 0;
+                nodes = uint32_t(int(s_.nodes) + int(std::uniform_int_distribution<int>(0, span - 1)(active[0]->rng)) - span / 2);
+            }
+        }
+        SearchStats st;
+        pool_->run(sims, nodes, threads, &st);
+        stats_.nodes += st.nodes;
+        stats_.nn_evals += st.nn_evals;
+        for (Game* gp : active) {
+            Game& g = *gp;
+            Tree& t = pool_->tree(g.slot);
+            // Agent::set_best_move (agent.cpp:38-55) on the root's MCTS policy
+            std::vector<double> policy;
+            const int best = t.best_move_index(&policy);
+            if (best < 0) throw std::logic_error("self-play: a running game's tree has no searched root");
+            const float best_q = t.eval_best_move_q();
+            const size_t ply = g.rec.uci.size();                           // steps_from_null of the game state
+            size_t pick;
+            if (int(ply) < s_.temperature_moves && s_.init_temperature > 0.01) {
+                std::vector<double> p(policy);
+                apply_temperature(p, s_.init_temperature * std::pow(s_.temperature_decay, double(ply)));
+                if (s_.quantile_clipping != 0) apply_quantile_clipping(s_.quantile_clipping, p);
+                pick = sample_index(g.rng, p);
+            } else {
+                pick = size_t(std::max_element(policy.begin(), policy.end()) - policy.begin());
+            }
+            const Move mv = t.root().actions[pick];
+            if (exporter_) g.samples.push_back(Game::Sample{g.pos, t.root().actions, policy, best_q});   // save_sample before the move
+            const std::string uci = g.pos.move_to_uci(mv), san = g.pos.move_to_san(mv);
+            g.pos.do_move(mv);
+            ++stats_.moves;
+            if (check_over(g, &san, &uci)) continue;
+            if (g.allow_resign && best_q < s_.resign_threshold) {          // check_for_resignation (after the move: side to move wins)
+                finish(g, g.pos.side_to_move() == chess::WHITE ? 1 : -1, "resignation");
+                continue;
+            }
+            if (int(g.rec.uci.size()) >= s_.max_plies) {
+                finish(g, 0, "ply limit");
+                continue;
+            }
+            bool kept = false;
+            if (s_.reuse_tree) kept = t.apply_move(mv);
+            else pool_->reset_position(g.slot, g.pos);
+            if (kept) ++stats_.kept_subtrees; else ++stats_.restarts;
+        }
+    }
+    stats_.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return finished_.size();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// arena
+// ---------------------------------------------------------------------------------------------------------------------
+ArenaDriver::ArenaDriver(search::SearchPool* pool_a, search::SearchPool* pool_b, const SelfPlaySettings& s, int concurrent,
+                         chess::Variant variant, bool is960)
+    : s_(s), concurrent_(concurrent), variant_(variant), is960_(is960) {
+    pools_[0] = pool_a;
+    pools_[1] = pool_b;
+    if (!pool_a || !pool_b || concurrent < 1) throw std::invalid_argument("an arena needs two pools and at least one concurrent game");
+    if (!s.simulations && !s.nodes) throw std::invalid_argument("an arena needs a simulations or a nodes budget");
+    games_.resize(size_t(concurrent));
+    for (int slot = 0; slot < concurrent; ++slot)
+        for (search::SearchPool* p : pools_) {
+            if (p->add_position(make_position("", is960, variant)) != slot) throw std::invalid_argument("the pools must be empty when the arena takes them over");
+            p->set_active(slot, false);
+        }
+}
+
+size_t ArenaDriver::play(size_t n_games, int threads) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (finished_.size() < n_games) {
+        for (int slot = 0; slot < concurrent_; ++slot) {
+            Game& g = games_[size_t(slot)];
+            if (g.active || started_ >= n_games) continue;
+            const size_t idx = started_++;
+            const size_t pair = idx / 2;
+            if (idx % 2 == 0) {
+                g.pos = make_position(start_fens_.empty() ? std::string() : start_fens_[pair % start_fens_.size()], is960_, variant_);
+                if (pair_fen_.size() <= pair) pair_fen_.resize(pair + 1);
+                pair_fen_[pair] = g.pos.fen();
+            } else {
+                g.pos = make_position(pair_fen_.at(pair), is960_, variant_);   // gamePGN.fen of the game before
+            }
+            g.idx = idx;
+            g.rec = GameRecord();
+            g.rec.start_fen = g.pos.fen();
+            g.rec.contender_white = idx % 2 == 0;
+            g.active = true;
+            for (search::SearchPool* p : pools_) p->reset_position(slot, g.pos);
+        }
+        bool any = false;
+        std::vector<int> mover(size_t(concurrent_), -1);                   // which player searches this game now
+        for (int slot = 0; slot < concurrent_; ++slot) {
+            const Game& g = games_[size_t(slot)];
+            if (!g.active) continue;
+            any = true;
+            const bool white_to_move = g.pos.side_to_move() == chess::WHITE;
+            mover[size_t(slot)] = white_to_move == g.rec.contender_white ? 0 : 1;
+        }
+        if (!any) break;
+        for (int pi = 0; pi < 2; ++pi) {
+            bool has = false;
+            for (int slot = 0; slot < concurrent_; ++slot) {
+                const bool on = mover[size_t(slot)] == pi;
+                pools_[pi]->set_active(slot, on);
+                has = has || on;
+            }
+            if (has) {
+                SearchStats st;
+                pools_[pi]->run(s_.simulations, s_.simulations ? 0 : s_.nodes, threads, &st);
+                stats_.nodes += st.nodes;
+                stats_.nn_evals += st.nn_evals;
+            }
+        }
+        for (int slot = 0; slot < concurrent_; ++slot) {
+            Game& g = games_[size_t(slot)];
+            if (!g.active) continue;
+            Tree& t = pools_[mover[size_t(slot)]]->tree(slot);
+            std::vector<double> policy;
+            if (t.best_move_index(&policy) < 0) throw std::logic_error("arena: a running game's tree has no searched root");
+            const Move mv = t.root().actions[size_t(std::max_element(policy.begin(), policy.end()) - policy.begin())];
+            const std::string uci = g.pos.move_to_uci(mv), san = g.pos.move_to_san(mv);
+            g.pos.do_move(mv);
+            const chess::TerminalType term = terminal_of(g.pos);
+            g.rec.san.push_back(mark_mate(san, term));
+            g.rec.uci.push_back(uci);
+            ++stats_.moves;
+            const bool over = term != chess::TERMINAL_NONE || int(g.rec.uci.size()) >= s_.max_plies;
+            if (!over) {
+                for (search::SearchPool* p : pools_) p->tree(slot).apply_move(mv);   // own move in one tree, the opponent's move in the other
+                continue;
+            }
+            g.rec.result = term == chess::TERMINAL_NONE ? 0 : result_for_white(g.pos, term);
+            g.rec.termination = term != chess::TERMINAL_NONE ? "terminal" : "ply limit";
+            const int a_score = g.rec.contender_white ? g.rec.result : -g.rec.result;
+            if (a_score > 0) ++wins_; else if (a_score < 0) ++losses_; else ++draws_;
+            finished_.push_back(g.rec);
+            g.active = false;
+            for (search::SearchPool* p : pools_) p->set_active(slot, false);
+        }
+    }
+    stats_.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return finished_.size();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+std::string game_pgn(const GameRecord& g, const std::string& variant_tag, const std::string& event, const std::string& white,
+                     const std::string& black, const std::string& date) {
+    static const char* kResult[3] = {"0-1", "1/2-1/2", "1-0"};
+    const std::string res = kResult[g.result + 1];
+    std::string out;
+    out += "[Variant \"" + variant_tag + "\"]\n[Event \"" + event + "\"]\n[Date \"" + date + "\"]\n[Site \"MI355X\"]\n[Round \"?\"]\n";
+    out += "[FEN \"" + g.start_fen + "\"]\n[White \"" + white + "\"]\n[Black \"" + black + "\"]\n[Result \"" + res + "\"]\n";
+    out += "[PlyCount \"" + std::to_string(g.san.size()) + "\"]\n[TimeControl \"-\"]\n\n";
+    for (size_t ply = 0; ply < g.san.size(); ++ply) {
+        if (ply % 2 == 0) out += std::to_string(ply / 2 + 1) + ". ";
+        out += g.san[ply] + " ";
+        if ((ply + 1) % 8 == 0) out += "\n";
+    }
+    out += res + "\n\n";
+    return out;
+}
+
+}  // namespace rl
+}  // namespace cra

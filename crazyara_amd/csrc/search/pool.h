@@ -87,6 +87,9 @@ public:
     // runs until every tree reached `simulations` root visits (if > 0) and/or `nodes` counted nodes (if > 0)
     // (SearchThread::nodes_limits_ok, searchthread.cpp:326-331)
     void run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats);
+    // evaluates the roots that have no network result yet (new games, restarted trees) through the first lane, as run() does first;
+    // a game loop reads the raw policy of fresh positions from the root priors this leaves (RawNetAgent::evaluate_board_state)
+    void evaluate_new_roots(SearchStats* stats) { SearchStats st; evaluate_roots(&st.nn_evals, &st.batches); if (stats) *stats = st; }
     Tree& tree(int i) { return *trees_.at(i); }
     void reset_position(int i, const chess::Position& pos);   // a new game in slot i (same lane, same exploration stream seed)
     // trees that sit out the following runs (an arena game whose other player is to move): they keep their state

@@ -6,19 +6,23 @@ rl/gamepgn.cpp (:28-56) -- restructured for the many-trees pool: G games are pla
 slot, one `run` of the pool searches the next move of all of them in shared GPU batches, then every game picks and plays its
 move (the searched subtree is kept: mi_search_apply_move) and finished games are replaced by new ones.
 
-Where the reference draws from rand() / std::random_device (opening plies, temperature sampling, resignation, node-count
-jitter) this loop draws from one seeded numpy generator per game, so a run replays; the distributions are the reference's.
-Training-sample export (traindataexporter.cpp) is not part of this loop.
+The loops themselves are native (csrc/rl/selfplay.cpp behind mi_selfplay_*, include/crazyara_hip.h): this module holds the settings,
+the game records with the reference's PGN dialect, and thin handles that start a loop inside the library and read the finished games
+back.  Where the reference draws from rand() / std::random_device (opening plies, temperature sampling, resignation, node-count
+jitter) a game draws from its own seeded generator, so a run replays; the distributions are the reference's.  apply_temperature /
+get_quantile / apply_quantile_clipping below restate the library's helpers in numpy for the tests that compare them with the
+reference's compiled functions.
 """
 from __future__ import annotations
 
+import ctypes as C
 import time
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
 
-from . import env, search
+from . import _capi, env, search
 
 RESULT_STR = {1: "1-0", -1: "0-1", 0: "1/2-1/2"}          # from White's point of view (result[] in gamepgn / constants)
 
@@ -106,176 +110,123 @@ def apply_quantile_clipping(quantile: float, p: np.ndarray) -> np.ndarray:
     return q / np.cumsum(q)[-1]                 # sequential double sum, as the reference's loop adds it
 
 
-class _Game:
-    def __init__(self, slot: int, record: GameRecord, pos: env.Position, rng: np.random.Generator, allow_resign: bool):
-        self.slot, self.record, self.pos, self.rng, self.allow_resign = slot, record, pos, rng, allow_resign
-        self.samples = []               # (position clone, moves, policy, best_move_q) until the game's result is known
+class SelfPlaySettingsC(C.Structure):
+    """mi_selfplay_settings (include/crazyara_hip.h)"""
+    _fields_ = [("simulations", C.c_uint), ("nodes", C.c_uint), ("node_random_factor", C.c_float), ("mean_init_ply", C.c_float),
+                ("max_init_ply", C.c_int), ("raw_policy_prob_temperature", C.c_float), ("init_temperature", C.c_float),
+                ("temperature_moves", C.c_int), ("temperature_decay", C.c_float), ("quantile_clipping", C.c_float),
+                ("resign_probability", C.c_float), ("resign_threshold", C.c_float), ("reuse_tree", C.c_int), ("max_plies", C.c_int),
+                ("seed", C.c_ulonglong)]
 
 
-class SelfPlay:
-    """Plays `n_games` games, `concurrent` at a time, on the trees of one SearchPool.
+class SelfPlayStatsC(C.Structure):
+    """mi_selfplay_stats"""
+    _fields_ = [("moves", C.c_ulonglong), ("nodes", C.c_ulonglong), ("nn_evals", C.c_ulonglong), ("kept_subtrees", C.c_ulonglong),
+                ("restarts", C.c_ulonglong), ("samples", C.c_ulonglong), ("seconds", C.c_double), ("wins", C.c_int), ("draws", C.c_int),
+                ("losses", C.c_int)]
 
-    start_fen(game_index) -> FEN ("" = the variant's start position); raw_policy(list of positions) -> list of probability
-    vectors over each position's legal moves (needed only when mean_init_ply > 0: RawNetAgent::evaluate_board_state)."""
+
+def _settings_c(lib, s: SelfPlaySettings) -> SelfPlaySettingsC:
+    c = SelfPlaySettingsC()
+    lib.mi_selfplay_default_settings(C.byref(c))
+    for name, _ in SelfPlaySettingsC._fields_:
+        setattr(c, name, type(getattr(c, name))(getattr(s, name)))
+    return c
+
+
+class _NativeLoop:
+    """Handle of a native game loop (csrc/rl/selfplay.cpp behind mi_selfplay_*): the games are played inside the library; Python only
+    reads the finished games back."""
+
+    def __init__(self, pool_a, pool_b, settings: SelfPlaySettings, concurrent: int, start_fen, exporter=None, n_fens: int = 1024):
+        self._lib = _capi.load()
+        self.s, self.concurrent = settings, concurrent
+        c = _settings_c(self._lib, settings)
+        self._h = self._lib.mi_selfplay_create(pool_a._h, pool_b._h if pool_b is not None else None, C.byref(c), int(concurrent),
+                                               settings.variant.encode(), int(settings.is960), exporter._h if exporter is not None else None)
+        if not self._h:
+            raise RuntimeError(_capi.last_error())
+        self._pools = (pool_a, pool_b, exporter)           # keep them alive as long as the loop
+        self._start_fen, self._n_fens_sent = start_fen, 0
+        self._read = 0
+
+    def _send_fens(self, n: int):
+        if self._start_fen is None or n <= self._n_fens_sent:
+            return
+        fens = [self._start_fen(i) or "" for i in range(n)]
+        if self._lib.mi_selfplay_set_start_fens(self._h, ("\n".join(fens) + "\n").encode()):
+            raise RuntimeError(_capi.last_error())
+        self._n_fens_sent = n
+
+    def _run(self, n_games: int, threads: int) -> int:
+        n = self._lib.mi_selfplay_play(self._h, int(n_games), int(threads))
+        if n < 0:
+            raise RuntimeError(_capi.last_error())
+        return n
+
+    def _game(self, i: int):
+        res, book, cw = C.c_int(), C.c_int(), C.c_int()
+        n = self._lib.mi_selfplay_game(self._h, i, C.byref(res), C.byref(book), C.byref(cw), None, 0)
+        if n < 0:
+            raise RuntimeError(_capi.last_error())
+        buf = C.create_string_buffer(n + 1)
+        if self._lib.mi_selfplay_game(self._h, i, None, None, None, buf, n + 1) < 0:
+            raise RuntimeError(_capi.last_error())
+        fen, why, san, uci = buf.value.decode().split("\n")[:4]
+        return fen, why, [m for m in san.split("\t") if m], [m for m in uci.split("\t") if m], res.value, book.value, bool(cw.value)
+
+    def _stats(self) -> SelfPlayStatsC:
+        st = SelfPlayStatsC()
+        if self._lib.mi_selfplay_get_stats(self._h, C.byref(st)):
+            raise RuntimeError(_capi.last_error())
+        return st
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi_selfplay_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def _variant_tag(s: SelfPlaySettings) -> str:
+    return "standard" if s.variant == "chess" and not s.is960 else s.variant + ("960" if s.is960 else "")
+
+
+class SelfPlay(_NativeLoop):
+    """Plays `n_games` games, `concurrent` at a time, on the trees of one SearchPool -- inside the library (csrc/rl/selfplay.cpp).
+
+    start_fen(game_index) -> FEN ("" = the variant's start position).  The raw policy of the opening plies (mean_init_ply > 0) is read
+    from the pool's own evaluator: the root priors of a freshly reset tree are RawNetAgent::evaluate_board_state's policy over the legal
+    moves; `raw_policy` is accepted for compatibility with the earlier Python loop and not used.
+    exporter: a traindata.TrainDataExporter; every searched position becomes a training sample (generate_game, selfplay.cpp:237-248) --
+    the concurrent games buffer their samples and are written game by game as they finish."""
 
     def __init__(self, pool: search.SearchPool, settings: SelfPlaySettings, concurrent: int,
                  start_fen: Optional[Callable[[int], str]] = None,
                  raw_policy: Optional[Callable[[Sequence[env.Position]], List[np.ndarray]]] = None,
                  exporter=None):
-        """exporter: a traindata.TrainDataExporter; every searched position becomes a training sample (generate_game,
-        selfplay.cpp:237-248) -- the concurrent games buffer their samples and are written game by game as they finish."""
-        self.pool, self.s, self.concurrent = pool, settings, concurrent
-        self.exporter = exporter
-        self.start_fen = start_fen or (lambda i: "")
-        self.raw_policy = raw_policy
-        self.games: List[Optional[_Game]] = [None] * concurrent
+        super().__init__(pool, None, settings, concurrent, start_fen, exporter)
+        self.pool, self.exporter = pool, exporter
         self.finished: List[GameRecord] = []
-        self.started = 0
         self.stats = dict(moves=0, nodes=0, nn_evals=0, seconds=0.0, kept_subtrees=0, restarts=0)
-        for slot in range(concurrent):                      # one tree slot per concurrent game
-            t = pool.add_position("", settings.is960, settings.variant)
-            assert t == slot, "the pool must be empty when the game loop takes it over"
-
-    # ---- game start: init_starting_state_from_raw_policy --------------------------------------------------------------
-    def _new_game(self, slot: int) -> _Game:
-        idx = self.started
-        self.started += 1
-        s = self.s
-        rng = np.random.default_rng([s.seed, idx])
-        fen = self.start_fen(idx)
-        pos = env.Position(fen, s.is960, s.variant)
-        rec = GameRecord(start_fen=pos.fen(), variant=("standard" if s.variant == "chess" and not s.is960 else s.variant + ("960" if s.is960 else "")),
-                         white=s.white, black=s.black, event=s.event)
-        if s.mean_init_ply > 0:
-            if self.raw_policy is None:
-                raise ValueError("mean_init_ply > 0 needs a raw_policy evaluator")
-            plies = int(rng.exponential(s.mean_init_ply) + 0.5)          # random_exponential(1/mean) + 0.5, clip_ply
-            plies = min(plies, s.max_init_ply)
-            for _ in range(plies):
-                moves = pos.legal_moves()
-                if len(moves) == 0:
-                    break
-                p = np.ones(1) if len(moves) == 1 else np.asarray(self.raw_policy([pos])[0], np.float64)
-                if rng.random() < s.raw_policy_prob_temperature:          # apply_raw_policy_temp
-                    u = rng.random()
-                    p = apply_temperature(p, 10.0 if u < 0.05 else 5.0 if u < 0.25 else 2.0)
-                mv = moves[int(rng.choice(len(moves), p=p / p.sum()))]   # random_choice
-                nxt = pos.clone()
-                nxt.push(mv)
-                if nxt.terminal() != env.TERMINAL_NONE:                  # leads_to_terminal: keep the game alive
-                    nxt.close()
-                    break
-                rec.san.append(pos.move_san(mv) + " {book}")
-                rec.uci.append(pos.move_uci(mv))
-                pos.close()
-                pos = nxt
-            rec.book_plies = len(rec.uci)
-        self.pool.reset_position(slot, rec.start_fen, s.is960, s.variant)
-        self.pool.set_active(slot, True)
-        for u in rec.uci:
-            self.pool.apply_move(slot, u)
-        allow_resign = s.resign_probability >= 0.01 and rng.random() < s.resign_probability
-        return _Game(slot, rec, pos, rng, allow_resign)
-
-    # ---- one move of every running game -----------------------------------------------------------------------------
-    def _choose(self, g: _Game):
-        """Agent::set_best_move (agent.cpp:38-55) on the root's MCTS policy."""
-        s = self.s
-        moves, _, _, _ = self.pool.root_children(g.slot)
-        policy, best_q = self.pool.root_policy(g.slot)
-        ply = len(g.record.uci)                       # steps_from_null of the game state
-        if ply < s.temperature_moves and s.init_temperature > 0.01:
-            p = apply_temperature(policy.copy(), s.init_temperature * s.temperature_decay ** ply)
-            if s.quantile_clipping != 0:
-                p = apply_quantile_clipping(s.quantile_clipping, p)
-            i = int(g.rng.choice(len(p), p=p / p.sum()))
-        else:
-            i = int(np.argmax(policy))
-        return moves[i], best_q
-
-    def _finish(self, g: _Game, result: int, why: str):
-        g.record.result, g.record.termination = result, why
-        if self.exporter is not None:
-            self.exporter.new_game()
-            for p, moves, policy, q in g.samples:
-                self.exporter.save_sample(p, moves, policy, q)
-                p.close()
-            self.stats["samples"] = self.stats.get("samples", 0) + self.exporter.export_game_samples(result)
-            g.samples = []
-        self.finished.append(g.record)
-        g.pos.close()
-        self.games[g.slot] = None
-        # the slot's tree sits out the following pool.run calls until a new game takes it (otherwise a finished game's tree would be
-        # searched to the full budget every round and its visits counted as nodes)
-        self.pool.set_active(g.slot, False)
 
     def play(self, n_games: int, threads: int = 16) -> List[GameRecord]:
+        self._send_fens(n_games)
+        total = self._run(n_games, threads)
         s = self.s
-        t0 = time.perf_counter()
-        while len(self.finished) < n_games:
-            for slot in range(self.concurrent):                # refill free slots
-                if self.games[slot] is None and self.started < n_games:
-                    g = self._new_game(slot)
-                    self.games[slot] = g
-                    self._check_over(g)                        # a start position can already be decided
-            active = [g for g in self.games if g is not None]
-            if not active:
-                break
-            budget = dict(simulations=s.simulations) if s.simulations else dict(nodes=s.nodes)
-            if s.node_random_factor > 0 and s.nodes:            # adjust_node_count (one draw per round)
-                span = int(s.nodes * s.node_random_factor)
-                if span:
-                    budget = dict(nodes=s.nodes + int(active[0].rng.integers(0, span)) - span // 2)
-            st = self.pool.run(threads=threads, **budget)
-            self.stats["nodes"] += st.nodes
-            self.stats["nn_evals"] += st.nn_evals
-            for g in active:
-                mv, best_q = self._choose(g)
-                if self.exporter is not None:                                  # save_sample(state, evalInfo) before the move
-                    moves_all, _, _, _ = self.pool.root_children(g.slot)
-                    policy_all, _ = self.pool.root_policy(g.slot)
-                    g.samples.append((g.pos.clone(), moves_all, policy_all, best_q))
-                uci = g.pos.move_uci(mv)
-                san = g.pos.move_san(mv)
-                g.pos.push(mv)
-                over = self._check_over(g, san=san, uci=uci)
-                self.stats["moves"] += 1
-                if over:
-                    continue
-                if g.allow_resign and best_q < s.resign_threshold:           # check_for_resignation (after the move: side to move wins)
-                    self._finish(g, 1 if g.pos.side_to_move() == 0 else -1, "resignation")
-                    continue
-                if len(g.record.uci) >= s.max_plies:
-                    self._finish(g, 0, "ply limit")
-                    continue
-                if s.reuse_tree:
-                    kept = self.pool.apply_move(g.slot, uci)
-                else:
-                    self.pool.reset_position(g.slot, g.pos.fen(), s.is960, s.variant)
-                    kept = False
-                self.stats["kept_subtrees" if kept else "restarts"] += 1
-        self.stats["seconds"] = time.perf_counter() - t0
+        while self._read < total:
+            fen, why, san, uci, result, book, _ = self._game(self._read)
+            self._read += 1
+            self.finished.append(GameRecord(start_fen=fen, variant=_variant_tag(s), san=san, uci=uci, book_plies=book, result=result,
+                                            termination=why, white=s.white, black=s.black, event=s.event))
+        st = self._stats()
+        self.stats.update(moves=st.moves, nodes=st.nodes, nn_evals=st.nn_evals, seconds=st.seconds, kept_subtrees=st.kept_subtrees,
+                          restarts=st.restarts)
+        if self.exporter is not None:
+            self.stats["samples"] = st.samples
         return self.finished[:n_games]
-
-    def _check_over(self, g: _Game, san: Optional[str] = None, uci: Optional[str] = None) -> bool:
-        """play_move_and_update (selfplay.cpp:38-54): record the move, ask the state for the result, mark a win with '#'."""
-        t = g.pos.terminal()
-        if san is not None:
-            if t in (env.TERMINAL_WIN, env.TERMINAL_LOSS):
-                san = san[:-1] + "#" if san.endswith("+") else san + "#"
-            g.record.san.append(san)
-            g.record.uci.append(uci)
-        if t == env.TERMINAL_NONE:
-            return False
-        stm_white = g.pos.side_to_move() == 0
-        if t == env.TERMINAL_DRAW:
-            res = 0
-        elif t == env.TERMINAL_LOSS:                      # the side to move has lost
-            res = -1 if stm_white else 1
-        else:
-            res = 1 if stm_white else -1
-        self._finish(g, res, "terminal")
-        return True
 
 
 def net_raw_policy(net, mode: int, version_major: int, is_policy_map: bool = True):
@@ -314,89 +265,31 @@ class TournamentResult:
         return (self.wins + 0.5 * self.draws) / n if n else 0.0
 
 
-class Arena:
-    """Two players (search pools with their own nets) play `n_games` against each other, `concurrent` games at a time.
+class Arena(_NativeLoop):
+    """Two players (search pools with their own nets) play `n_games` against each other, `concurrent` games at a time, inside the library.
 
     go_arena (selfplay.cpp:387-424): game 2i has the contender A as White from a fresh start position, game 2i+1 replays the SAME
     start position with colours swapped.  generate_arena_game (:267-308): the player to move searches, both players apply the move
     to their trees (own move / opponent's move), always the best move (no temperature), no resignation.  Each game owns tree slot g
-    in BOTH pools; the pool of the player that is not to move pauses that tree (mi_search_set_active)."""
+    in BOTH pools; the pool of the player that is not to move pauses that tree.  start_fen(pair_index) -> FEN."""
 
     def __init__(self, pool_a: search.SearchPool, pool_b: search.SearchPool, settings: SelfPlaySettings, concurrent: int,
                  start_fen: Optional[Callable[[int], str]] = None, names=("contender", "champion")):
-        self.pools, self.s, self.concurrent, self.names = (pool_a, pool_b), settings, concurrent, names
-        self.start_fen = start_fen or (lambda i: "")
-        for slot in range(concurrent):
-            for p in self.pools:
-                assert p.add_position("", settings.is960, settings.variant) == slot
+        super().__init__(pool_a, pool_b, settings, concurrent, start_fen)
+        self.pools, self.names = (pool_a, pool_b), names
         self.stats = dict(moves=0, nodes=0, seconds=0.0)
+        self.records: List[GameRecord] = []
 
     def play(self, n_games: int, threads: int = 16):
+        self._send_fens((n_games + 1) // 2)
+        total = self._run(n_games, threads)
         s = self.s
-        res = TournamentResult(self.names[0], self.names[1])
-        games: List[Optional[dict]] = [None] * self.concurrent
-        records: List[GameRecord] = []
-        started, pair_fen = 0, {}
-        t0 = time.perf_counter()
-        while len(records) < n_games:
-            for slot in range(self.concurrent):
-                if games[slot] is None and started < n_games:
-                    idx = started
-                    started += 1
-                    if idx % 2 == 0:
-                        pos = env.Position(self.start_fen(idx // 2), s.is960, s.variant)
-                        pair_fen[idx // 2] = pos.fen()
-                    else:
-                        pos = env.Position(pair_fen[idx // 2], s.is960, s.variant)       # gamePGN.fen of the game before
-                    a_white = idx % 2 == 0
-                    rec = GameRecord(start_fen=pos.fen(), variant=s.variant + ("960" if s.is960 else ""), event="Arena",
-                                     white=self.names[0 if a_white else 1], black=self.names[1 if a_white else 0])
-                    for p in self.pools:
-                        p.reset_position(slot, rec.start_fen, s.is960, s.variant)
-                    games[slot] = dict(idx=idx, pos=pos, rec=rec, a_white=a_white)
-            active = [(slot, g) for slot, g in enumerate(games) if g is not None]
-            if not active:
-                break
-            mover = {}
-            for slot, g in active:                       # which player searches this game now
-                white_to_move = g["pos"].side_to_move() == 0
-                mover[slot] = 0 if white_to_move == g["a_white"] else 1
-            for pi, p in enumerate(self.pools):
-                for slot in range(self.concurrent):
-                    p.set_active(slot, games[slot] is not None and mover.get(slot) == pi)
-                if any(mover[slot] == pi for slot, _ in active):
-                    st = p.run(simulations=s.simulations, nodes=s.nodes, threads=threads)
-                    self.stats["nodes"] += st.nodes
-            for slot, g in active:
-                p = self.pools[mover[slot]]
-                moves, _, _, _ = p.root_children(slot)
-                policy, _ = p.root_policy(slot)
-                mv = moves[int(np.argmax(policy))]
-                uci, san = g["pos"].move_uci(mv), g["pos"].move_san(mv)
-                g["pos"].push(mv)
-                t = g["pos"].terminal()
-                if t in (env.TERMINAL_WIN, env.TERMINAL_LOSS):
-                    san = san[:-1] + "#" if san.endswith("+") else san + "#"
-                g["rec"].san.append(san)
-                g["rec"].uci.append(uci)
-                self.stats["moves"] += 1
-                over = t != env.TERMINAL_NONE or len(g["rec"].uci) >= s.max_plies
-                if not over:
-                    for q in self.pools:                 # own move in one tree, the opponent's move in the other
-                        q.apply_move(slot, uci)
-                    continue
-                stm_white = g["pos"].side_to_move() == 0
-                result = 0 if t in (env.TERMINAL_DRAW, env.TERMINAL_NONE) else ((-1 if stm_white else 1) if t == env.TERMINAL_LOSS else (1 if stm_white else -1))
-                g["rec"].result, g["rec"].termination = result, "terminal" if t != env.TERMINAL_NONE else "ply limit"
-                a_score = result if g["a_white"] else -result
-                if a_score > 0:
-                    res.wins += 1
-                elif a_score < 0:
-                    res.losses += 1
-                else:
-                    res.draws += 1
-                records.append(g["rec"])
-                g["pos"].close()
-                games[slot] = None
-        self.stats["seconds"] = time.perf_counter() - t0
-        return res, records
+        while self._read < total:
+            fen, why, san, uci, result, _, a_white = self._game(self._read)
+            self._read += 1
+            self.records.append(GameRecord(start_fen=fen, variant=s.variant + ("960" if s.is960 else ""), san=san, uci=uci, result=result,
+                                           termination=why, event="Arena", white=self.names[0 if a_white else 1],
+                                           black=self.names[1 if a_white else 0]))
+        st = self._stats()
+        self.stats.update(moves=st.moves, nodes=st.nodes, seconds=st.seconds)
+        return TournamentResult(self.names[0], self.names[1], st.wins, st.draws, st.losses), self.records[:n_games]

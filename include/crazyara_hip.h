@@ -275,6 +275,55 @@ int mi_traindata_export_game_samples(mi_traindata* t, int result, unsigned* writ
 int mi_traindata_info(const mi_traindata* t, unsigned* number_samples, unsigned* start_index, unsigned* game_index, int* nb_labels, int* channels,
                       int* is_full);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Self-play / arena game loops (engine/src/rl/selfplay.cpp: generate_game :192-265, generate_arena_game :267-308, go_arena :387-424,
+ * init_starting_state_from_raw_policy :426-452; agents/agent.cpp set_best_move :38-55; rl/gamepgn.cpp :28-56), native: G games run
+ * concurrently on the trees of one pool (arena: of two pools), one pool run searches the next move of all of them.  The pool(s) must
+ * be empty: the loop adds one tree per concurrent game.  Random draws come from one seeded generator per game.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct mi_selfplay mi_selfplay;
+typedef struct mi_selfplay_settings {
+    unsigned simulations, nodes;          /* budget per move (one of them) */
+    float node_random_factor;             /* RLSettings::nodeRandomFactor */
+    float mean_init_ply;                  /* PlaySettings::meanInitPly: opening plies sampled from the raw policy */
+    int max_init_ply;
+    float raw_policy_prob_temperature;    /* RLSettings::rawPolicyProbabilityTemperature */
+    float init_temperature;               /* PlaySettings::initTemperature / temperatureMoves / temperatureDecayFactor / quantileClipping */
+    int temperature_moves;
+    float temperature_decay;
+    float quantile_clipping;
+    float resign_probability;             /* RLSettings::resignProbability / resignThreshold */
+    float resign_threshold;
+    int reuse_tree;                       /* RLSettings::reuseTreeForSelpay */
+    int max_plies;                        /* safety net: adjudicated as a draw */
+    unsigned long long seed;
+} mi_selfplay_settings;
+typedef struct mi_selfplay_stats {
+    unsigned long long moves, nodes, nn_evals, kept_subtrees, restarts, samples;
+    double seconds;
+    int wins, draws, losses;              /* arena: seen from the contender (pool A) */
+} mi_selfplay_stats;
+void mi_selfplay_default_settings(mi_selfplay_settings* s);
+/* pool_b == NULL: self-play on pool_a (exporter: every searched position becomes a training sample, written game by game; may be NULL);
+ * pool_b != NULL: arena between pool_a (contender) and pool_b, colours alternating per pair of games (exporter must be NULL). */
+mi_selfplay* mi_selfplay_create(mi_search* pool_a, mi_search* pool_b, const mi_selfplay_settings* s, int concurrent, const char* variant,
+                                int is_chess960, mi_traindata* exporter);
+void mi_selfplay_destroy(mi_selfplay* sp);
+/* start positions, '\n'-separated FENs ("" line = the variant's start position): game i (arena: pair i) uses entry i mod count */
+int mi_selfplay_set_start_fens(mi_selfplay* sp, const char* fens);
+/* plays until n_games are finished in total; returns that total, -1 on error */
+int mi_selfplay_play(mi_selfplay* sp, int n_games, int threads);
+/* finished game `index`: result +1 / 0 / -1 for White, plies from the opening book, whether the contender had White (arena), and as
+ * text "start FEN\ntermination\nSAN moves separated by \t\nUCI moves separated by \t\n".  Returns the text's length (call with cap 0
+ * to size the buffer), -1 on error. */
+long mi_selfplay_game(mi_selfplay* sp, int index, int* result, int* book_plies, int* contender_white, char* text, long cap);
+int mi_selfplay_get_stats(mi_selfplay* sp, mi_selfplay_stats* out);
+/* The sampling helpers of Agent::set_best_move as the loops use them, in place on p[n] (for tests against the reference's functions):
+ * apply_temperature (blazeutil.h:77-87), get_quantile (:188-212), apply_quantile_clipping (agent.cpp:121-130). */
+void mi_policy_apply_temperature(double* p, int n, double temperature);
+double mi_policy_get_quantile(const double* p, int n, double quantile);
+void mi_policy_apply_quantile_clipping(double* p, int n, double quantile);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--max-plies", type=int, default=300)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--pgn", default="")
+    ap.add_argument("--precision", default="float16", help="float16 | fp8 | float32")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -53,8 +54,7 @@ def main():
     sd = rise_config.make_state_dict(cfg, seed=1)
     d = tempfile.mkdtemp(prefix="cra_selfplay_")
     netfile.export_rise(os.path.join(d, f"{cfg.name}-v{vstr}.cranet"), cfg, sd, input_version=vstr, variant=args.variant)
-    nets = [HipAPI(local_rank, args.batch, d, "float16") for _ in range(2)]
-    raw = HipAPI(local_rank, args.batch, d, "float16")
+    nets = [HipAPI(local_rank, args.batch, d, args.precision) for _ in range(2)]
 
     my_games = replicas.shard_items(args.games, rank, world)
     quota = max(1, args.batch // max(1, (args.concurrent + 1) // 2))
@@ -70,8 +70,8 @@ def main():
         from crazyara_amd import _capi
         return _capi.load().mi_chess960_start_fen((my_games[i % max(1, len(my_games))] * 37 + 11) % 960).decode()
 
-    loop = selfplay.SelfPlay(pool, s, min(args.concurrent, max(1, len(my_games))), start_fen=start_fen,
-                             raw_policy=selfplay.net_raw_policy(raw, mode, ver))
+    # the game loop runs inside the library (csrc/rl/selfplay.cpp); the opening plies' raw policy comes from the pool's own lanes
+    loop = selfplay.SelfPlay(pool, s, min(args.concurrent, max(1, len(my_games))), start_fen=start_fen)
     games = loop.play(len(my_games), threads=args.threads)
     stt = loop.stats
     if args.pgn:
@@ -89,11 +89,12 @@ def main():
                           "games": int(tot_games), "moves": int(ex[0]), "seconds": round(sec, 2),
                           "mcts_nodes_per_sec": round(ex[1] / sec, 1), "nn_evals_per_sec": round(ex[2] / sec, 1),
                           "config": {"variant": args.variant + ("960" if args.chess960 else ""), "net": cfg.name, "batch": args.batch,
-                                     "concurrent_games_per_gpu": args.concurrent, "simulations_per_move": args.simulations},
+                                     "concurrent_games_per_gpu": args.concurrent, "simulations_per_move": args.simulations,
+                                     "precision": args.precision, "game_loop": "native (mi_selfplay_*)"},
                           "rank0_results": {"white": res[1], "draw": res[0], "black": res[-1]},
                           "rank0_kept_subtrees": stt["kept_subtrees"], "rank0_restarts": stt["restarts"]}))
     pool.close()
-    for n in nets + [raw]:
+    for n in nets:
         n.close()
     if dist is not None:
         dist.barrier()

@@ -12,6 +12,10 @@ size_t cra_sizeof_search_stats(void) { return sizeof(mi_search_stats); }
 size_t cra_offsetof_settings_virtual_offset_strength(void) { return offsetof(mi_search_settings, virtual_offset_strength); }
 size_t cra_offsetof_settings_version_minor(void) { return offsetof(mi_search_settings, version_minor); }
 size_t cra_offsetof_stats_depth_max(void) { return offsetof(mi_search_stats, depth_max); }
+size_t cra_sizeof_selfplay_settings(void) { return sizeof(mi_selfplay_settings); }
+size_t cra_sizeof_selfplay_stats(void) { return sizeof(mi_selfplay_stats); }
+size_t cra_offsetof_selfplay_seed(void) { return offsetof(mi_selfplay_settings, seed); }
+size_t cra_offsetof_selfplay_stats_wins(void) { return offsetof(mi_selfplay_stats, wins); }
 
 /* typed function pointers: the declarations are complete prototypes with the expected parameter lists */
 const char* (*const cra_p_last_error)(void) = mi_last_error;
@@ -20,3 +24,5 @@ int (*const cra_p_net_predict)(mi_net*, const float*, float*, float*, float*) = 
 void (*const cra_p_net_destroy)(mi_net*) = mi_net_destroy;
 void* (*const cra_p_host_alloc)(size_t) = mi_host_alloc;
 int (*const cra_p_search_run)(mi_search*, unsigned, unsigned, int, mi_search_stats*) = mi_search_run;
+mi_selfplay* (*const cra_p_selfplay_create)(mi_search*, mi_search*, const mi_selfplay_settings*, int, const char*, int, mi_traindata*) = mi_selfplay_create;
+int (*const cra_p_selfplay_play)(mi_selfplay*, int, int) = mi_selfplay_play;

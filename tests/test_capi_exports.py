@@ -40,13 +40,19 @@ def test_header_is_plain_c99_and_struct_layouts_match_the_python_binding(hip_lib
                     os.path.join(ROOT, "tests", "c_header_check.c"), "-o", so, _capi.LIB_PATH], check=True)
     chk = C.CDLL(so)
     for fn in ("cra_sizeof_search_settings", "cra_sizeof_search_stats", "cra_offsetof_settings_virtual_offset_strength",
-               "cra_offsetof_settings_version_minor", "cra_offsetof_stats_depth_max"):
+               "cra_offsetof_settings_version_minor", "cra_offsetof_stats_depth_max", "cra_sizeof_selfplay_settings", "cra_sizeof_selfplay_stats",
+               "cra_offsetof_selfplay_seed", "cra_offsetof_selfplay_stats_wins"):
         getattr(chk, fn).restype = C.c_size_t
     assert chk.cra_sizeof_search_settings() == C.sizeof(search.SearchSettingsC)
     assert chk.cra_sizeof_search_stats() == C.sizeof(search.SearchStatsC)
     assert chk.cra_offsetof_settings_virtual_offset_strength() == search.SearchSettingsC.virtual_offset_strength.offset
     assert chk.cra_offsetof_settings_version_minor() == search.SearchSettingsC.version_minor.offset
     assert chk.cra_offsetof_stats_depth_max() == search.SearchStatsC.depth_max.offset
+    from crazyara_amd import selfplay
+    assert chk.cra_sizeof_selfplay_settings() == C.sizeof(selfplay.SelfPlaySettingsC)
+    assert chk.cra_sizeof_selfplay_stats() == C.sizeof(selfplay.SelfPlayStatsC)
+    assert chk.cra_offsetof_selfplay_seed() == selfplay.SelfPlaySettingsC.seed.offset
+    assert chk.cra_offsetof_selfplay_stats_wins() == selfplay.SelfPlayStatsC.wins.offset
 
 
 def test_integration_md_quotes_the_compiled_shim_verbatim():

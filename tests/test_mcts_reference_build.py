@@ -238,8 +238,11 @@ def test_reference_helpers_worked_examples():
     lib.ref_apply_quantile_clipping(p.ctypes.data_as(C.POINTER(C.c_double)), 3, 0.25)
     assert np.allclose(p, [0.0, 0.0, 1.0])
     assert lib.ref_value_to_centipawn(1.0) == 9999 and lib.ref_value_to_centipawn(0.0) == 0
-    # the product's port of the two (crazyara_amd/selfplay.py, used by Agent::set_best_move's sampling) against the compiled functions
-    from crazyara_amd import selfplay
+    # the product's ports of the two -- the library's (csrc/rl/selfplay.cpp, used by the native game loops) and the numpy restatement
+    # (crazyara_amd/selfplay.py) -- against the compiled functions
+    from crazyara_amd import _capi, selfplay
+    hip = _capi.load()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     rng = np.random.default_rng(3)
     for trial in range(200):
         n = int(rng.integers(2, 40))
@@ -253,3 +256,11 @@ def test_reference_helpers_worked_examples():
         clipped = p.copy()
         lib.ref_apply_quantile_clipping(clipped.ctypes.data_as(C.POINTER(C.c_double)), n, quant)
         assert np.array_equal(selfplay.apply_quantile_clipping(quant, p), clipped)
+        assert np.float32(hip.mi_policy_get_quantile(dp(p), n, quant)) == np.float32(ref_q)
+        mine = p.copy()
+        hip.mi_policy_apply_quantile_clipping(dp(mine), n, quant)
+        assert np.array_equal(mine, clipped)
+        temp = float(rng.choice([0.5, 1.0, 2.0, 10.0]))
+        tp = p.copy()
+        hip.mi_policy_apply_temperature(dp(tp), n, temp)
+        assert np.allclose(tp, selfplay.apply_temperature(p.copy(), temp), rtol=1e-14, atol=0)

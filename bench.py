@@ -201,6 +201,11 @@ def config_search_legs(args, device, threads):
         rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 1, 8, 800, cz, 1)
     leg("config1_two_search_threads", "the same with the reference's default Threads = 2: two collectors (one per lane, batch 8 each) "
         "share the one tree", rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 2, 8, 800, cz, 1, shared=1)
+    # `Threads` is a UCI option (optionsuci.cpp:182): a batch of 8 occupies 8 of the 256 CUs, so more collectors on the one tree put more
+    # batches of 8 on the GPU at the same time
+    leg("config1_four_search_threads", "the same with Threads = 4: four collectors (one per lane, batch 8 each) share the one tree",
+        rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 4, 8, 800, cz, 1, shared=1)
+    leg("config1_eight_search_threads", "the same with Threads = 8", rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 8, 8, 800, cz, 1, shared=1)
     # the single-position reading of config 2: one tree fills the whole batch of 256 by itself
     leg("config2_one_tree", "one crazyhouse position at a time, RISEv2-19, batch 256 collected from ONE tree by one collector, "
         "1600 simulations", rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 1, 256, 1600, cz, 1)

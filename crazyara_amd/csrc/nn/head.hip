@@ -273,6 +273,11 @@ __device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds
             lo[i] = x;
             po[i] = __expf(x - c);
         }
+        if (a.g_out != nullptr && b < a.g_n_valid) {     // search lane: the priors of the new node's legal moves, straight from the tile
+            const uint32_t cnt = a.g_cnt[b];
+            const size_t base = size_t(b) * a.g_stride;
+            for (uint32_t j = tid; j < cnt; j += 512) a.g_out[base + j] = __expf(logit[a.g_idx[base + j]] - c);
+        }
     }
 
     HD_STAMP();

@@ -130,6 +130,10 @@ struct StemArgs {
     long long stem_wave_frags;
     int cin, cin_pad;     // cin_pad: multiple of 16 in [48, 96]
     int batch;
+    // search lanes: instead of reading `planes`, the kernel builds its input tile from 192-byte board descriptors (the same plane_value()
+    // the stand-alone builder uses; normalised planes), boards >= n_valid read zeros.  nullptr = planes path.
+    const void* descs;
+    int layout, n_valid;
 };
 void launch_stem(const StemArgs& a, hipStream_t s);
 
@@ -159,6 +163,12 @@ struct HeadArgs {
     int wdlp;
     int batch;
     unsigned long long* trace;   // development: s_memtime stamps of workgroup 0, wave 0 (CRA_TOWER_TRACE)
+    // search lanes: board b < g_n_valid also writes probs[g_idx[b * g_stride + j]] to g_out[b * g_stride + j], j < g_cnt[b] (what the
+    // gather kernel does behind a three-launch lane step); nullptr = off
+    const uint16_t* g_idx;
+    const uint32_t* g_cnt;
+    float* g_out;
+    int g_stride, g_n_valid;
 };
 void launch_head(const HeadArgs& a, hipStream_t s);
 void init_head_kernel_attributes();

@@ -1326,7 +1326,33 @@ void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int la
     // moves ~50 KB in and ~170 KB out, so PCIe bandwidth is irrelevant; what a copy costs is the hand-over between the DMA engine
     // and the compute queue -- five copies around three kernel groups were 0.1-0.5 ms of latency per batch (host dependent), more
     // than the forward itself on a loaded host.  One queue, three launches back to back; the host polls the stream.
-    (void)stride;
+    Impl& im = *impl_;
+    const char* lane_mode = getenv("CRA_LANE_LAUNCHES");              // "1" / "3": force the one-launch / three-launch lane step (read per call)
+    const bool one_launch = lane_mode ? lane_mode[0] == '1' : B <= 64;
+    if (im.ops.size() == 1 && im.ops[0].kind == OpKind::Forward && one_launch) {
+        // ... and for SMALL batches, where the launches themselves are what a lane step costs (a batch of 8 occupies 8 CUs for 0.1 ms),
+        // ONE launch: the forward kernel's stem builds the planes of a board from the descriptor, its head writes the gathered priors,
+        // value and aux of the board straight into the caller's buffers.  Measured (profiles/r02/t_*): single-tree search at batch 8
+        // +4-5 % with 1 to 8 collectors; at batch 256 the plane building inside the 0.31 ms kernel costs more than the two small
+        // launches did beside the other lane's forward (-4 % on the headline search leg), so large batches keep three launches.
+        const Op& op = im.ops[0];
+        StemArgs st = op.st;
+        HeadArgs h = op.hd;
+        st.descs = descs_host;
+        st.layout = layout;
+        st.n_valid = n_valid;
+        h.value = value;
+        h.probs = d_probs_;
+        h.aux = (d_aux_ && aux) ? aux : d_aux_;
+        h.g_idx = idx;
+        h.g_cnt = cnt;
+        h.g_out = gathered;
+        h.g_stride = int(stride);
+        h.g_n_valid = n_valid;
+        launch_forward(st, op.tw, h, stream_);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (n_valid > 0) launch_planes_from_desc(static_cast<const BoardDesc*>(descs_host), n_valid, layout, 1, d_planes_, stream_);
     launch_forward_in_stream();
     launch_gather_probs(d_probs_, design_.nb_policy, idx, cnt, int(stride), n_valid, gathered, d_value_, value, int(B),

@@ -9,6 +9,7 @@
 // staged in LDS and leaves as 16-byte coalesced stores.  HBM per board: cin*256 B in, 32 KB out; weights 9*cin_pad*512 B from L2.
 #include "kernels.h"
 #include "device_utils.h"
+#include "../chess/planes.h"
 
 namespace cra {
 
@@ -42,7 +43,20 @@ __device__ __forceinline__ void stem_body(const StemArgs& a, const bool to_globa
     frag win[ST_WIN];
 #pragma unroll
     for (int i = 0; i < ST_WIN; ++i) win[i] = sp[i * 64];
-    {
+    if (a.descs != nullptr) {
+        // search lane: the planes of this board are computed here from its 192-byte descriptor (one launch instead of a plane-builder
+        // launch + 8.7-20 KB per board through HBM); same function, same values as planes_from_desc_kernel + the conversion below
+        __shared__ BoardDesc sd;
+        const bool valid = b < a.n_valid;
+        if (valid && tid < int(sizeof(BoardDesc) / 8))
+            reinterpret_cast<uint64_t*>(&sd)[tid] = reinterpret_cast<const uint64_t*>(static_cast<const BoardDesc*>(a.descs) + b)[tid];
+        for (int i = tid; i < 65 * prow / 2; i += 512) reinterpret_cast<uint32_t*>(pl)[i] = 0u;
+        __syncthreads();
+        if (valid) {
+#pragma unroll 1
+            for (int e = tid; e < a.cin * 64; e += 512) pl[(e & 63) * prow + (e >> 6)] = half_t(plane_value(sd, a.layout, true, e >> 6, e & 63));
+        }
+    } else {
         const float* pb = a.planes + size_t(b) * a.cin * 64;
         float pv[12];                                // cin <= 96 -> at most 12 values per thread, all loads in flight together
 #pragma unroll

@@ -105,11 +105,17 @@ def test_priors_gathered_on_the_gpu_equal_whole_probability_vectors(tmp_path, hi
     d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
     fens = openings.position_fens("crazyhouse")[20:28]
     results = []
-    for setting in (None, "0", "4"):
+    # a lane step is one launch at this batch size (the forward kernel builds the planes from the descriptors and writes the gathered
+    # priors itself) -- and three launches (plane builder, forward, gather kernel) when forced: the same trees either way
+    for setting, launches in ((None, None), ("0", None), ("4", None), (None, "1"), (None, "3")):
         if setting is None:
             monkeypatch.delenv("CRA_GATHER_PER_SLOT", raising=False)
         else:
             monkeypatch.setenv("CRA_GATHER_PER_SLOT", setting)
+        if launches is None:
+            monkeypatch.delenv("CRA_LANE_LAUNCHES", raising=False)
+        else:
+            monkeypatch.setenv("CRA_LANE_LAUNCHES", launches)
         nets = [HipAPI(0, 64, d, "float16") for _ in range(2)]
         st = search.default_settings(mode=0, version_major=1, batch_size=16, seed=3)
         pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1])
@@ -120,7 +126,7 @@ def test_priors_gathered_on_the_gpu_equal_whole_probability_vectors(tmp_path, hi
         pool.close()
         for n in nets:
             n.close()
-    assert results[0] == results[1] == results[2]
+    assert results[0] == results[1] == results[2] == results[3] == results[4]
     assert all(sum(r[0]) >= 239 for r in results[0])
 
 

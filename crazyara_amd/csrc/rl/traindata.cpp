@@ -1,5 +1,7 @@
 #include "traindata.h"
 
+#include <cmath>
+
 #include <sys/stat.h>
 
 #include <cstdio>
@@ -123,6 +125,7 @@ void TrainDataExporter::save_sample(const chess::Position& pos, const std::vecto
     for (size_t i = 0; i < legal_moves.size(); ++i) {
         const int li = chess::label_index(t, pos, legal_moves[i], mirror);
         if (li < 0) throw std::logic_error("legal move without a policy label: " + pos.move_to_uci(legal_moves[i]));
+        if (i < n_policy && !std::isfinite(policy[i])) throw std::invalid_argument("training sample with a non-finite policy entry");
         game_policy_[base + size_t(li)] = i < n_policy ? float(policy[i]) : 0.0f;
     }
     game_best_q_.push_back(best_move_q);

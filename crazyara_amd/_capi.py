@@ -96,6 +96,7 @@ SIGNATURES = {
     "mi_traindata_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mi_search_set_shared_collectors": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_search_set_adaptive_quota": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_selfplay_default_settings": (None, [C.c_void_p]),
     "mi_selfplay_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p]),
     "mi_selfplay_destroy": (None, [C.c_void_p]),

@@ -246,6 +246,11 @@ int mi_search_set_shared_collectors(mi_search* sp, int k) {
     return cra_guard([&] { sp->pool->set_shared_collectors(k); });
 }
 
+int mi_search_set_adaptive_quota(mi_search* sp, int cap) {
+    if (!sp) { cra_set_error("null search"); return 1; }
+    return cra_guard([&] { sp->pool->set_adaptive_quota(cap); });
+}
+
 int mi_search_set_active(mi_search* sp, int tree, int active) {
     if (!sp) { cra_set_error("null search"); return 1; }
     return cra_guard([&] { sp->pool->set_active(tree, active != 0); });

@@ -332,6 +332,13 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     double t_par = 0, t_submit = 0, t_item_max = 0, t_item_sum = 0, t_wait = 0;
     const bool timing = getenv("CRA_POOL_TIMING") != nullptr;
     std::atomic<bool> gather_overflow{false};
+    // simulations / nodes the tree still lacks (>= 1 for a tree that is not done)
+    auto remaining_need = [&](const Tree& t) -> int {
+        uint32_t need = 0xffffffffu;
+        if (simulations) need = std::min(need, simulations > t.root_visits() ? simulations - t.root_visits() : 1u);
+        if (nodes) need = std::min(need, nodes > t.node_count() ? nodes - t.node_count() : 1u);
+        return int(std::min<uint32_t>(need, 1u << 20));
+    };
     // one tree's share of a batch: leaves into its slots; the policy indices of the new nodes' legal moves go straight into the
     // lane's gather list (this thread just wrote them)
     auto collect_item = [&](Lane& lane, int i, int id) {
@@ -339,7 +346,9 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         const uint32_t gstride = ev.gather_stride();
         Tree& tree = item_tree(id);
         const int ctx = item_ctx(id);
-        lane.n_new[i] = tree.collect(lane.slot_count[i], ev.descs() + lane.slot_begin[i], ctx);
+        int take = lane.slot_count[i];
+        if (adaptive_cap_ > 0 && shared_k_ == 0) take = std::min(take, remaining_need(tree));   // no overshoot beyond the limit
+        lane.n_new[i] = tree.collect(take, ev.descs() + lane.slot_begin[i], ctx);
         if (gstride) {
             for (int k = 0; k < lane.slot_count[i]; ++k) {
                 const size_t slot = size_t(lane.slot_begin[i] + k);
@@ -404,7 +413,9 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         const int B = ev.batch_size();
         // fixed per-tree quota (= the reference's per-search Batch_Size): a tree's statistics do not depend on which other
         // trees are still running.  More trees than slots: the rest waits a round (rotation below).
-        const int quota = std::max(1, B / int(lane.trees.size()));
+        int quota = std::max(1, B / int(lane.trees.size()));
+        // adaptive (set_adaptive_quota): the trees still running share the whole batch
+        if (adaptive_cap_ > 0 && shared_k_ == 0) quota = std::max(quota, std::min(adaptive_cap_, B / int(active.size())));
         const int n_use = std::min<int>(int(active.size()), B / quota);
         lane.slot_begin.assign(n_use, 0);
         lane.slot_count.assign(n_use, 0);

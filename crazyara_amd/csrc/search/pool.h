@@ -100,6 +100,13 @@ public:
     // collector and lives in one lane (the many-trees mode: no locks).  Call between runs.
     void set_shared_collectors(int k);
     int shared_collectors() const { return shared_k_; }
+    // Many-trees mode, throughput setting (self-play): cap > 0 lets the trees of a lane that are still searching share the WHOLE batch
+    // -- each gets batch / (running trees) slots, at most `cap`, and never more than it still needs to reach its limit -- instead of the
+    // fixed batch / (trees of the lane) of the default (0), under which a tree's batches, and so its statistics, do not depend on the
+    // other trees.  With the absolute limits of tree reuse the trees of a round need very different numbers of simulations; the fixed
+    // quota then ends a round with mostly empty batches for the one tree that needs the most.
+    void set_adaptive_quota(int cap) { adaptive_cap_ = cap < 0 ? 0 : cap; }
+    int adaptive_quota() const { return adaptive_cap_; }
     int n_trees() const { return int(trees_.size()); }
     const SearchSettings& settings() const { return s_; }
 
@@ -120,6 +127,7 @@ private:
     int item_ctx(int item) const { return items_[size_t(item)].ctx; }
     std::vector<Item> items_;
     int shared_k_ = 0;
+    int adaptive_cap_ = 0;
     SearchSettings s_;
     int layout_;
     std::vector<std::unique_ptr<Tree>> trees_;

@@ -120,6 +120,11 @@ class SearchPool:
         if self._lib.mi_search_set_shared_collectors(self._h, int(k)):
             raise ValueError(_capi.last_error())
 
+    def set_adaptive_quota(self, cap: int) -> None:
+        """cap > 0: the trees of a lane that are still searching share the whole batch (throughput setting for self-play); 0 = fixed quota"""
+        if self._lib.mi_search_set_adaptive_quota(self._h, int(cap)):
+            raise RuntimeError(_capi.last_error())
+
     def set_active(self, tree: int, active: bool) -> None:
         if self._lib.mi_search_set_active(self._h, tree, int(active)):
             raise ValueError(_capi.last_error())

@@ -242,6 +242,9 @@ int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, floa
  * one lane, no locks (many trees fill the batches instead).  With more than one collector per tree the trees are no longer a
  * deterministic function of the seed (thread timing), exactly as in the reference.  Call between runs. */
 int mi_search_set_shared_collectors(mi_search* sp, int k);
+/* Throughput setting of the many-trees mode (self-play): cap > 0 = the trees of a lane that are still searching share the whole batch
+ * (each batch / running-trees slots, at most cap, never more than the tree still needs); 0 = the reference's fixed per-tree quota. */
+int mi_search_set_adaptive_quota(mi_search* sp, int cap);
 /* the whole tree as a flat word list, for inspection and the parity tests (the reference's counterpart: MCTSAgent::export_search_tree,
  * mctsagent.cpp:420-448): depth-first preorder over the expanded children, one record per node that was selected at least once:
  * [n_expanded, visit_sum, real_visits, free_visits, node_type, end_in_ply, terminal, float bits of value], then per expanded child

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--pgn", default="")
     ap.add_argument("--precision", default="float16", help="float16 | fp8 | float32")
+    ap.add_argument("--adaptive-quota", type=int, default=32, help="SearchPool.set_adaptive_quota: leaves per tree and batch may grow to this")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -60,6 +61,7 @@ def main():
     quota = max(1, args.batch // max(1, (args.concurrent + 1) // 2))
     st = search.default_settings(mode=mode, version_major=ver, batch_size=quota, seed=1 + rank)
     pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1])
+    pool.set_adaptive_quota(args.adaptive_quota)
     s = selfplay.SelfPlaySettings(variant=args.variant, is960=args.chess960, simulations=args.simulations, max_plies=args.max_plies,
                                   mean_init_ply=4.0, raw_policy_prob_temperature=0.05, init_temperature=0.8, temperature_moves=8,
                                   temperature_decay=0.9, quantile_clipping=0.25, seed=100 + rank)
@@ -90,7 +92,7 @@ def main():
                           "mcts_nodes_per_sec": round(ex[1] / sec, 1), "nn_evals_per_sec": round(ex[2] / sec, 1),
                           "config": {"variant": args.variant + ("960" if args.chess960 else ""), "net": cfg.name, "batch": args.batch,
                                      "concurrent_games_per_gpu": args.concurrent, "simulations_per_move": args.simulations,
-                                     "precision": args.precision, "game_loop": "native (mi_selfplay_*)"},
+                                     "precision": args.precision, "game_loop": "native (mi_selfplay_*)", "adaptive_quota": args.adaptive_quota},
                           "rank0_results": {"white": res[1], "draw": res[0], "black": res[-1]},
                           "rank0_kept_subtrees": stt["kept_subtrees"], "rank0_restarts": stt["restarts"]}))
     pool.close()

@@ -373,6 +373,40 @@ def test_pool_many_trees_two_lanes_matches_single_tree_runs(hip_lib):
     pool.close()
 
 
+def test_adaptive_quota_shares_the_batch_among_the_running_trees(hip_lib):
+    """SearchPool.set_adaptive_quota (throughput setting for self-play): trees that need very different numbers of simulations (absolute
+    limits after tree reuse) finish in fewer, fuller batches; every tree still reaches its limit and none overshoots it."""
+    nbp = NB_POLICY[0]
+    fens = ["", "r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] w KQkq - 0 8",
+            "5r2/ppp2pkp/3p4/2bP4/2Pnp1N1/3P2pP/PP2n1P1/R2Q1R1K[PBRQnbb] w - - 0 28",
+            "r1bqkbnr/pppp1ppp/2n5/4p3/4P3/5N2/PPPP1PPP/RNBQKB1R[] w KQkq - 2 3"]
+
+    def eval_descs(descs):
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    def run(cap):
+        st = search.default_settings(mode=0, version_major=1)
+        pool = search.SearchPool(st, eval_fn=eval_descs, fn_batch=32, fn_nb_policy=nbp)
+        for f in fens:
+            pool.add_position(f, False, "crazyhouse")
+        pool.set_adaptive_quota(cap)
+        for t in (1, 2, 3):                               # trees 1..3 are far ahead of tree 0: pause tree 0 for a first run
+            pool.set_active(0, False)
+        pool.run(simulations=150, threads=2)
+        pool.set_active(0, True)
+        st2 = pool.run(simulations=200, threads=2)        # tree 0 needs 200, the others 50
+        visits = [pool.tree_info(i)["root_visits"] for i in range(4)]
+        pool.close()
+        return st2.batches, visits
+
+    fixed_batches, fixed_visits = run(0)
+    adaptive_batches, adaptive_visits = run(64)
+    assert all(v >= 200 for v in fixed_visits) and all(v >= 200 for v in adaptive_visits)
+    assert all(v == 200 for v in adaptive_visits), adaptive_visits           # capped by what the tree still needs: no overshoot
+    assert adaptive_batches < fixed_batches, (adaptive_batches, fixed_batches)
+
+
 def test_search_limits_and_terminal_root(hip_lib):
     nbp = NB_POLICY[0]
 

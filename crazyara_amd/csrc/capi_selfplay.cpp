@@ -133,6 +133,9 @@ int mi_selfplay_get_stats(mi_selfplay* sp, mi_selfplay_stats* out) {
         out->wins = sp->arena ? sp->arena->wins() : 0;
         out->draws = sp->arena ? sp->arena->draws() : 0;
         out->losses = sp->arena ? sp->arena->losses() : 0;
+        out->reserved = 0;
+        out->run_seconds = st.run_seconds;
+        out->move_seconds = st.move_seconds;
     });
 }
 

@@ -214,17 +214,25 @@ size_t SelfPlayDriver::play(size_t n_games, int threads) {
             }
         }
         SearchStats st;
+        const auto r0 = std::chrono::steady_clock::now();
         pool_->run(sims, nodes, threads, &st);
+        stats_.run_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
         stats_.nodes += st.nodes;
         stats_.nn_evals += st.nn_evals;
-        for (Game* gp : active) {
-            Game& g = *gp;
+        // every running game picks and plays its move: the games touch nothing but their own tree, position and generator, so this
+        // part runs on the pool's worker threads; what is shared (the list of finished games, the exporter, the counters) follows serially
+        struct Played { std::string san, uci; chess::TerminalType term = chess::TERMINAL_NONE; float best_q = 0; bool kept = false; bool moved_tree = false; };
+        std::vector<Played> played(active.size());
+        const auto m0 = std::chrono::steady_clock::now();
+        pool_->parallel_for(int(active.size()), threads, [&](int gi) {
+            Game& g = *active[size_t(gi)];
+            Played& pl = played[size_t(gi)];
             Tree& t = pool_->tree(g.slot);
             // Agent::set_best_move (agent.cpp:38-55) on the root's MCTS policy
             std::vector<double> policy;
             const int best = t.best_move_index(&policy);
             if (best < 0) throw std::logic_error("self-play: a running game's tree has no searched root");
-            const float best_q = t.eval_best_move_q();
+            pl.best_q = t.eval_best_move_q();
             const size_t ply = g.rec.uci.size();                           // steps_from_null of the game state
             size_t pick;
             if (int(ply) < s_.temperature_moves && s_.init_temperature > 0.01) {
@@ -236,12 +244,31 @@ size_t SelfPlayDriver::play(size_t n_games, int threads) {
                 pick = size_t(std::max_element(policy.begin(), policy.end()) - policy.begin());
             }
             const Move mv = t.root().actions[pick];
-            if (exporter_) g.samples.push_back(Game::Sample{g.pos, t.root().actions, policy, best_q});   // save_sample before the move
-            const std::string uci = g.pos.move_to_uci(mv), san = g.pos.move_to_san(mv);
+            if (exporter_) g.samples.push_back(Game::Sample{g.pos, t.root().actions, policy, pl.best_q});   // save_sample before the move
+            pl.uci = g.pos.move_to_uci(mv);
+            pl.san = g.pos.move_to_san(mv);
             g.pos.do_move(mv);
+            pl.term = terminal_of(g.pos);
+            const bool goes_on = pl.term == chess::TERMINAL_NONE && !(g.allow_resign && pl.best_q < s_.resign_threshold) &&
+                                 int(g.rec.uci.size()) + 1 < s_.max_plies;
+            if (goes_on) {
+                pl.moved_tree = true;
+                if (s_.reuse_tree) pl.kept = t.apply_move(mv);
+                else pool_->reset_position(g.slot, g.pos);
+            }
+        });
+        stats_.move_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - m0).count();
+        for (size_t gi = 0; gi < active.size(); ++gi) {
+            Game& g = *active[gi];
+            const Played& pl = played[gi];
             ++stats_.moves;
-            if (check_over(g, &san, &uci)) continue;
-            if (g.allow_resign && best_q < s_.resign_threshold) {          // check_for_resignation (after the move: side to move wins)
+            g.rec.san.push_back(mark_mate(pl.san, pl.term));               // play_move_and_update
+            g.rec.uci.push_back(pl.uci);
+            if (pl.term != chess::TERMINAL_NONE) {
+                finish(g, result_for_white(g.pos, pl.term), "terminal");
+                continue;
+            }
+            if (g.allow_resign && pl.best_q < s_.resign_threshold) {       // check_for_resignation (after the move: side to move wins)
                 finish(g, g.pos.side_to_move() == chess::WHITE ? 1 : -1, "resignation");
                 continue;
             }
@@ -249,10 +276,7 @@ size_t SelfPlayDriver::play(size_t n_games, int threads) {
                 finish(g, 0, "ply limit");
                 continue;
             }
-            bool kept = false;
-            if (s_.reuse_tree) kept = t.apply_move(mv);
-            else pool_->reset_position(g.slot, g.pos);
-            if (kept) ++stats_.kept_subtrees; else ++stats_.restarts;
+            if (pl.kept) ++stats_.kept_subtrees; else ++stats_.restarts;
         }
     }
     stats_.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

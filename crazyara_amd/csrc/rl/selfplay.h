@@ -55,6 +55,7 @@ struct GameRecord {
 struct LoopStats {
     uint64_t moves = 0, nodes = 0, nn_evals = 0, kept_subtrees = 0, restarts = 0, samples = 0;
     double seconds = 0;
+    double run_seconds = 0, move_seconds = 0;      // inside SearchPool::run / inside the parallel move step
 };
 
 // blazeutil.h / agent.cpp helpers on double vectors (exposed for the tests)

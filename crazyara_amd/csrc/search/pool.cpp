@@ -227,6 +227,11 @@ int SearchPool::add_position(const chess::Position& pos) {
     return int(trees_.size()) - 1;
 }
 
+void SearchPool::parallel_for(int n, int threads, const std::function<void(int)>& fn) {
+    if (!workers_ || workers_->threads() != std::max(1, threads)) workers_.reset(new WorkerPool(std::max(1, threads)));
+    workers_->parallel_for(n, fn);
+}
+
 void SearchPool::reset_position(int i, const chess::Position& pos) {
     SearchSettings st = s_;
     st.seed = s_.seed + uint32_t(i);

@@ -91,6 +91,9 @@ public:
     // a game loop reads the raw policy of fresh positions from the root priors this leaves (RawNetAgent::evaluate_board_state)
     void evaluate_new_roots(SearchStats* stats) { SearchStats st; evaluate_roots(&st.nn_evals, &st.batches); if (stats) *stats = st; }
     Tree& tree(int i) { return *trees_.at(i); }
+    // fn(i) for i in [0, n) on the pool's worker threads (the game loops play the moves of their concurrent games this way: each game
+    // touches only its own tree); between runs only
+    void parallel_for(int n, int threads, const std::function<void(int)>& fn);
     void reset_position(int i, const chess::Position& pos);   // a new game in slot i (same lane, same exploration stream seed)
     // trees that sit out the following runs (an arena game whose other player is to move): they keep their state
     void set_active(int i, bool active);

@@ -123,7 +123,7 @@ class SelfPlayStatsC(C.Structure):
     """mi_selfplay_stats"""
     _fields_ = [("moves", C.c_ulonglong), ("nodes", C.c_ulonglong), ("nn_evals", C.c_ulonglong), ("kept_subtrees", C.c_ulonglong),
                 ("restarts", C.c_ulonglong), ("samples", C.c_ulonglong), ("seconds", C.c_double), ("wins", C.c_int), ("draws", C.c_int),
-                ("losses", C.c_int)]
+                ("losses", C.c_int), ("reserved", C.c_int), ("run_seconds", C.c_double), ("move_seconds", C.c_double)]
 
 
 def _settings_c(lib, s: SelfPlaySettings) -> SelfPlaySettingsC:
@@ -223,7 +223,7 @@ class SelfPlay(_NativeLoop):
                                             termination=why, white=s.white, black=s.black, event=s.event))
         st = self._stats()
         self.stats.update(moves=st.moves, nodes=st.nodes, nn_evals=st.nn_evals, seconds=st.seconds, kept_subtrees=st.kept_subtrees,
-                          restarts=st.restarts)
+                          restarts=st.restarts, run_seconds=st.run_seconds, move_seconds=st.move_seconds)
         if self.exporter is not None:
             self.stats["samples"] = st.samples
         return self.finished[:n_games]

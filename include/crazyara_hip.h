@@ -305,6 +305,8 @@ typedef struct mi_selfplay_stats {
     unsigned long long moves, nodes, nn_evals, kept_subtrees, restarts, samples;
     double seconds;
     int wins, draws, losses;              /* arena: seen from the contender (pool A) */
+    int reserved;
+    double run_seconds, move_seconds;     /* of `seconds`: inside the pool's searches / inside the (parallel) move step of the games */
 } mi_selfplay_stats;
 void mi_selfplay_default_settings(mi_selfplay_settings* s);
 /* pool_b == NULL: self-play on pool_a (exporter: every searched position becomes a training sample, written game by game; may be NULL);

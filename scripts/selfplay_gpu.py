@@ -94,7 +94,8 @@ def main():
                                      "concurrent_games_per_gpu": args.concurrent, "simulations_per_move": args.simulations,
                                      "precision": args.precision, "game_loop": "native (mi_selfplay_*)", "adaptive_quota": args.adaptive_quota},
                           "rank0_results": {"white": res[1], "draw": res[0], "black": res[-1]},
-                          "rank0_kept_subtrees": stt["kept_subtrees"], "rank0_restarts": stt["restarts"]}))
+                          "rank0_kept_subtrees": stt["kept_subtrees"], "rank0_restarts": stt["restarts"],
+                          "rank0_seconds_in_search": round(stt["run_seconds"], 3), "rank0_seconds_in_move_step": round(stt["move_seconds"], 3)}))
     pool.close()
     for n in nets:
         n.close()

@@ -206,6 +206,11 @@ def config_search_legs(args, device, threads):
     leg("config1_four_search_threads", "the same with Threads = 4: four collectors (one per lane, batch 8 each) share the one tree",
         rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 4, 8, 800, cz, 1, shared=1)
     leg("config1_eight_search_threads", "the same with Threads = 8", rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 8, 8, 800, cz, 1, shared=1)
+    # the same eight collectors of 8 leaves each arranged as the pool prefers them: two lanes, four collectors per lane collected in
+    # parallel on four threads, a lane's batch = their 32 leaves (a lane is driven by one thread: eight lanes of one collector serialise
+    # their collection on it)
+    leg("config1_eight_collectors_two_lanes", "ONE tree, 8 collectors x 8 leaves as 2 lanes x 4 collectors (batch 32 per lane), 800 simulations",
+        rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 32, 2, 8, 800, cz, 1, shared=4)
     # the single-position reading of config 2: one tree fills the whole batch of 256 by itself
     leg("config2_one_tree", "one crazyhouse position at a time, RISEv2-19, batch 256 collected from ONE tree by one collector, "
         "1600 simulations", rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 1, 256, 1600, cz, 1)

@@ -238,6 +238,68 @@ def config_search_legs(args, device, threads):
     return out
 
 
+def config_game_legs(args, device, threads):
+    """BASELINE configs 4 and 5 as GAMES (their one-GPU slices): chess960 self-play and a 3check / king-of-the-hill arena between two
+    nets, played by the library's native game loops (csrc/rl/selfplay.cpp).  games/min + the nodes/sec of the searches inside."""
+    from crazyara_amd import _capi, netfile, rise_config, search, searchbench, selfplay
+    from crazyara_amd.neuralnetapi import HipAPI
+    out = {}
+    lib = _capi.load()
+
+    def model_dir(cfg, version, seed, variant):
+        sd = rise_config.make_state_dict(cfg, seed=seed, stress=True)
+        d = tempfile.mkdtemp(prefix="cra_bench_game_")
+        netfile.export_rise(os.path.join(d, f"{cfg.name}-v{version}.cranet"), cfg, sd, input_version=version, variant=variant)
+        return d
+
+    # config 4: chess960 self-play, 8 concurrent games on this GPU, RISEv3.3, 800 simulations per move, tree reuse, temperature on
+    # the first moves (the RL settings' shape; random-init net, so the games are short and mostly drawn by the ply cap)
+    d = model_dir(rise_config.rise_v33_config(52, 76, False), "3.0", 41, "chess")
+    nets = [HipAPI(device, 256, d, args.precision) for _ in range(2)]
+    st = search.default_settings(mode=1, version_major=3, batch_size=64, seed=5)
+    pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1])
+    s = selfplay.SelfPlaySettings(variant="chess", is960=True, simulations=800, max_plies=100, mean_init_ply=2.0, init_temperature=0.8,
+                                  temperature_moves=8, temperature_decay=0.9, seed=11)
+    loop = selfplay.SelfPlay(pool, s, 8, start_fen=lambda i: lib.mi_chess960_start_fen((i * 97 + 13) % 960).decode())
+    games = loop.play(16, threads=min(threads, 8))
+    stt = loop.stats
+    out["config4_selfplay_one_gpu"] = {
+        "games_per_min": round(len(games) / stt["seconds"] * 60, 1), "games": len(games), "moves": int(stt["moves"]),
+        "seconds": round(stt["seconds"], 3), "mcts_nodes_per_sec": round(stt["nodes"] / stt["seconds"], 1),
+        "seconds_in_search": round(stt["run_seconds"], 3), "kept_subtrees": int(stt["kept_subtrees"]),
+        "workload": "chess960 self-play (native loop), 8 concurrent games, RISEv3.3, batch 256, 800 simulations per move, ply cap 100"}
+    loop.close()
+    pool.close()
+    for n in nets:
+        n.close()
+    # config 5: arena between two nets on 3check and king-of-the-hill (half of the games each), lichess tables, batch 1024
+    cfg5 = rise_config.rise_v2_config(13, 80, 84)
+    total = dict(games=0, moves=0, seconds=0.0, nodes=0, wins=0, draws=0, losses=0)
+    for variant in ("3check", "kingofthehill"):
+        da, db = model_dir(cfg5, "3.0", 42, variant), model_dir(cfg5, "3.0", 43, variant)
+        na = [HipAPI(device, 1024, da, args.precision) for _ in range(2)]
+        nb = [HipAPI(device, 1024, db, args.precision) for _ in range(2)]
+        st = search.default_settings(mode=2, version_major=3, batch_size=16, seed=6)
+        pa, pb = search.SearchPool(st, net_a=na[0], net_b=na[1]), search.SearchPool(st, net_a=nb[0], net_b=nb[1])
+        s = selfplay.SelfPlaySettings(variant=variant, simulations=400, max_plies=80, seed=12)
+        starts = [f for f, _, _ in searchbench.variant_positions(variant)]       # one start position per pair of games
+        arena = selfplay.Arena(pa, pb, s, 64, start_fen=lambda i: starts[i % len(starts)])
+        res, recs = arena.play(64, threads=threads)
+        total["games"] += len(recs); total["moves"] += int(arena.stats["moves"]); total["seconds"] += arena.stats["seconds"]
+        total["nodes"] += int(arena.stats["nodes"]); total["wins"] += res.wins; total["draws"] += res.draws; total["losses"] += res.losses
+        arena.close()
+        pa.close(); pb.close()
+        for n in na + nb:
+            n.close()
+    out["config5_arena_one_gpu"] = {
+        "games_per_min": round(total["games"] / total["seconds"] * 60, 1), "games": total["games"], "moves": total["moves"],
+        "seconds": round(total["seconds"], 3), "mcts_nodes_per_sec": round(total["nodes"] / total["seconds"], 1),
+        "contender_score": {"wins": total["wins"], "draws": total["draws"], "losses": total["losses"]},
+        "workload": "arena between two RISEv2-13 80-channel nets (native loop), 3check then king-of-the-hill, 64 concurrent games in colour-"
+                    "swapped pairs from the variants' opening positions, batch 1024, 400 simulations per move, ply cap 80"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,6 +389,7 @@ def main():
     # the pool's own run times add up to a second; median / min / max over three such repeats (crazyara_amd/searchbench.py).
     mcts = None
     mcts_configs = None
+    game_configs = None
     if not args.no_search:
         from crazyara_amd import openings, search, searchbench
         lanes = max(1, args.search_lanes)
@@ -385,6 +448,7 @@ def main():
         # ---- the other BASELINE configurations, searched (single GPU; extra keys, never `value`) ----
         if world == 1 and not args.no_config_legs:
             mcts_configs = config_search_legs(args, local_rank, threads)
+            game_configs = config_game_legs(args, local_rank, threads)
 
     out = None
     if rank == 0:
@@ -555,6 +619,8 @@ def main():
             out["mcts"] = mcts
         if mcts_configs:
             out["mcts_configs"] = mcts_configs
+        if game_configs:
+            out["game_configs"] = game_configs
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, x)
     net.close()

@@ -347,9 +347,13 @@ size_t ArenaDriver::play(size_t n_games, int threads) {
                 stats_.nn_evals += st.nn_evals;
             }
         }
-        for (int slot = 0; slot < concurrent_; ++slot) {
+        // the games play their moves on the worker threads (a game touches its own position and its tree slot in both pools)
+        std::vector<chess::TerminalType> terms(size_t(concurrent_), chess::TERMINAL_NONE);
+        std::vector<char> over(size_t(concurrent_), 0);
+        const auto m0 = std::chrono::steady_clock::now();
+        pools_[0]->parallel_for(concurrent_, threads, [&](int slot) {
             Game& g = games_[size_t(slot)];
-            if (!g.active) continue;
+            if (!g.active) return;
             Tree& t = pools_[mover[size_t(slot)]]->tree(slot);
             std::vector<double> policy;
             if (t.best_move_index(&policy) < 0) throw std::logic_error("arena: a running game's tree has no searched root");
@@ -357,14 +361,20 @@ size_t ArenaDriver::play(size_t n_games, int threads) {
             const std::string uci = g.pos.move_to_uci(mv), san = g.pos.move_to_san(mv);
             g.pos.do_move(mv);
             const chess::TerminalType term = terminal_of(g.pos);
+            terms[size_t(slot)] = term;
             g.rec.san.push_back(mark_mate(san, term));
             g.rec.uci.push_back(uci);
-            ++stats_.moves;
-            const bool over = term != chess::TERMINAL_NONE || int(g.rec.uci.size()) >= s_.max_plies;
-            if (!over) {
+            over[size_t(slot)] = term != chess::TERMINAL_NONE || int(g.rec.uci.size()) >= s_.max_plies;
+            if (!over[size_t(slot)])
                 for (search::SearchPool* p : pools_) p->tree(slot).apply_move(mv);   // own move in one tree, the opponent's move in the other
-                continue;
-            }
+        });
+        stats_.move_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - m0).count();
+        for (int slot = 0; slot < concurrent_; ++slot) {
+            Game& g = games_[size_t(slot)];
+            if (!g.active) continue;
+            ++stats_.moves;
+            if (!over[size_t(slot)]) continue;
+            const chess::TerminalType term = terms[size_t(slot)];
             g.rec.result = term == chess::TERMINAL_NONE ? 0 : result_for_white(g.pos, term);
             g.rec.termination = term != chess::TERMINAL_NONE ? "terminal" : "ply limit";
             const int a_score = g.rec.contender_white ? g.rec.result : -g.rec.result;

@@ -484,7 +484,7 @@ def main():
             net3.close()
         peak = PEAK_F16_TFLOPS if args.precision == "float16" else PEAK_F32_TFLOPS
         achieved = dom_flops / (agg[dom] * 1e-3) / 1e12
-        traffic = None if args.no_live_pmc else live_pmc_traffic(dom, args.blocks, args.batch, args.precision)
+        traffic = None if (args.no_live_pmc or world > 1) else live_pmc_traffic(dom, args.blocks, args.batch, args.precision)
         if traffic is None:
             traffic = committed_pmc_traffic(dom)
         roofline = {"bound": "mfma", "kernel": dom, "launches_per_step": cnt[dom],
@@ -499,7 +499,8 @@ def main():
         # ---- the same workload in Precision float32: the mode that meets north_star's 1e-3 on the logits (f16 operands cannot:
         # tests/test_nn_parity_gpu.py).  Exact-f32 MFMA (v_mfma_f32_16x16x4_f32), peak 157.3 TFLOP/s. ----
         float32 = None
-        if args.precision == "float16" and not args.timed_only:
+        single = world == 1 and not args.timed_only      # the other precision modes and the PCIe legs are N = 1 information
+        if args.precision == "float16" and single:
             net32 = HipAPI(local_rank, args.batch, tmp, "float32")
             torch.as_tensor(net32.device_buffers()["planes"], device="cuda").copy_(x.cuda())
             torch.cuda.synchronize()
@@ -525,7 +526,7 @@ def main():
         # A reduced-precision mode: reported beside the headline, never as `value`.  The error columns compare its predict() outputs
         # with Precision float16 on the bench's own planes. ----
         fp8 = None
-        if args.precision == "float16" and not args.timed_only:
+        if args.precision == "float16" and single:
             net8 = HipAPI(local_rank, args.batch, tmp, "fp8")
             xin = np.ascontiguousarray(x.numpy()).reshape(-1)
             v8 = np.zeros(args.batch, np.float32); p8 = np.zeros(args.batch * cfg.nb_policy, np.float32)
@@ -581,7 +582,7 @@ def main():
                 u.close()
             return len(users) * it * args.batch / el, zc
         pcie, pcie_rate_1 = None, None
-        if not args.timed_only:
+        if single:
             net_b = HipAPI(local_rank, args.batch, tmp, args.precision)
             pcie_rate_1, zc1 = pcie_rate([net])
             pcie_rate_2, zc2 = pcie_rate([net, net_b])

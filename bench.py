@@ -141,7 +141,44 @@ def cpu_baseline(cfg, sd, x, budget_s=15.0):
            "sample": f"{n} positions (batches of {x.shape[0]}) of the same synthetic workload, oracle/rise_oracle.predict "
                      f"(torch fp32 CPU restatement of the reference RiseV3 module), {el:.1f} s"}
     out.update(cpu_baseline_mcts(cfg, sd, cores))
+    out.update(cpu_baseline_reference_search(cores))
     return out
+
+
+def cpu_baseline_reference_search(cores):
+    """BASELINE config 1 as the reference runs it without a GPU: the reference's OWN search code (MCTSAgent / SearchThread / Node ...,
+    compiled unmodified into oracle/_ref/libcrazyara_ref.so) on the crazyhouse start position, RISEv2-7, batch 8, 800 simulations,
+    with the CPU net (oracle port of the reference PyTorch module) behind its NeuralNetAPI.  kind = "reference" for the search code."""
+    from crazyara_amd import env, rise_config, search
+    from oracle import ref_mcts, rise_oracle as ro
+    try:
+        ref_mcts.load()
+    except Exception as e:  # noqa: BLE001 -- the prebuilt file did not travel: report it, never fail the bench
+        return {"config1_reference_search": {"skipped": f"oracle/_ref/libcrazyara_ref.so not loadable: {e}"}}
+    cfg = rise_config.rise_v2_config(7, 34, 81)
+    sd = rise_config.make_state_dict(cfg, seed=31, stress=True)
+    layout = env._capi.load().mi_planes_layout(0, 1)
+    evals = [0]
+
+    def eval_descs(descs):
+        planes = env.planes_from_descs_host(b"".join(descs), len(descs), layout, True)
+        v, p, _ = ro.predict(cfg, sd, torch.from_numpy(planes))
+        evals[0] += len(descs)
+        return v.numpy(), p.numpy()
+
+    st = search.default_settings(mode=0, version_major=1, batch_size=8)
+    agent = ref_mcts.RefAgent(st, eval_descs, cfg.nb_policy)
+    agent.set_position("", False, "crazyhouse")
+    t0 = time.perf_counter()
+    agent.go(simulations=800)
+    el = time.perf_counter() - t0
+    info = agent.root_info()
+    agent.close()
+    return {"config1_reference_search": {
+        "mcts_nodes_per_sec": round((info["node_count"]) / el, 1), "nn_evals": evals[0], "seconds": round(el, 2), "cores": cores,
+        "kind": "reference",
+        "sample": "the reference's MCTSAgent (one SearchThread, batch 8) on the crazyhouse start position, 800 simulations, RISEv2-7 "
+                  "evaluated by the oracle CPU net behind the callback NeuralNetAPI"}}
 
 
 def cpu_baseline_mcts(cfg, sd, cores, trees=16, quota=16, simulations=48):

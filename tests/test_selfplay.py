@@ -114,6 +114,30 @@ def test_games_are_legal_finish_and_replay(hip_lib, variant, mode, kw):
         assert any(g.book_plies > 0 for g in games)
 
 
+def test_game_loop_refuses_what_it_cannot_run(hip_lib, tmp_path):
+    """the native loops take over EMPTY pools, need a budget, and an arena has no exporter"""
+    from crazyara_amd import traindata
+    pool = _pool(0, 8, 32)
+    pool.add_position("", False, "crazyhouse")
+    with pytest.raises(RuntimeError, match="empty"):
+        selfplay.SelfPlay(pool, selfplay.SelfPlaySettings(variant="crazyhouse", simulations=16), 2)
+    pool.close()
+    pool = _pool(0, 8, 32)
+    with pytest.raises(RuntimeError, match="budget"):
+        selfplay.SelfPlay(pool, selfplay.SelfPlaySettings(variant="crazyhouse", simulations=0, nodes=0), 2)
+    pool.close()
+    pa, pb = _pool(0, 8, 32), _pool(0, 8, 32)
+    arena = selfplay.Arena(pa, pb, selfplay.SelfPlaySettings(variant="crazyhouse", simulations=16, max_plies=6), 2)
+    res, recs = arena.play(2, threads=2)                       # a ply cap of 6: both games end as draws by the cap unless decided earlier
+    assert len(recs) == 2 and res.wins + res.draws + res.losses == 2
+    assert all(len(r.uci) <= 6 for r in recs) and {r.white for r in recs} == {"contender", "champion"}
+    more, recs2 = arena.play(4, threads=2)                     # a second call continues the tournament
+    assert len(recs2) == 4 and more.wins + more.draws + more.losses == 4
+    arena.close()
+    pa.close()
+    pb.close()
+
+
 def test_sampling_helpers():
     p = np.array([0.5, 0.3, 0.15, 0.05])
     assert np.allclose(selfplay.apply_temperature(p, 1.0), p)

@@ -1244,7 +1244,17 @@ void RiseNet::forward_on(hipStream_t s) {
     if (fp16_) enqueue<half_t>(s); else enqueue<float>(s);
 }
 
-void RiseNet::forward_async() { HIP_CHECK(hipGraphLaunch(graph_exec_, stream_)); }
+// Device-resident replay.  A forward that is ONE kernel gains nothing from a graph (there is no launch sequence to save) and loses the
+// graph launch's own cost between consecutive replays: it goes into the stream as a plain launch.  Everything else replays the graph.
+// CRA_DEVICE_GRAPH=1 forces the graph (A/B timing).
+void RiseNet::forward_async() {
+    if (launches_ == 1 && getenv("CRA_DEVICE_GRAPH") == nullptr) {
+        forward_on(stream_);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
+}
 
 // The forward between other work of the same stream (descriptor expansion before, gather / copies after).  A graph launch runs its
 // nodes on the graph's own queue and is tied to the launching stream by cross-queue dependencies, which this runtime resolves from

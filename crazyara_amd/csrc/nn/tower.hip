@@ -30,7 +30,8 @@
 // silently broken library.
 #if !defined(CRA_DEVELOPMENT) && (defined(TW_DEV_NO_MFMA) || defined(TW_DEV_HALF_E_READS) || defined(TW_DEV_NO_WLOAD) || \
     defined(TW_DEV_VEC_NO_LDS) || defined(TW_DEV_VEC_NO_VALU) || defined(TW_DEV_VEC_TILES) || defined(TW_DEV_PRIO) || \
-    defined(TW_DEV_NO_MATRIX) || defined(TW_DEV_NO_VECTOR) || defined(TW_DEV_NO_WARMUP) || defined(TW_TRACE_SE) || defined(TW_TRACE_BARRIERS))
+    defined(TW_DEV_NO_MATRIX) || defined(TW_DEV_NO_VECTOR) || defined(TW_DEV_NO_WARMUP) || defined(TW_TRACE_SE) || defined(TW_TRACE_BARRIERS) || \
+    defined(TW_DEV_STAGGER) || defined(TW_DEV_DEPTH))
 #error "TW_DEV_* / TW_TRACE_* are development switches (some compute wrong results): build with -DCRA_DEVELOPMENT, see scripts/build_variant.sh"
 #endif
 
@@ -72,6 +73,14 @@ static_assert(TW_LDS_BYTES <= 160 * 1024 && TW_DYN_LDS_BYTES_F8 + TW_PRM_BYTES <
 constexpr int TW_AHEAD = 96;                          // L2 warm-up distance in fragments per stream (3 full intervals, 384 KiB)
 constexpr int TW_WIN = kTowerWindow;                  // weight fragments in flight per matrix wave (16 KiB)
 static_assert(TW_WIN == 16, "one E or P phase consumes exactly one window");
+// development (timing experiment): only TW_DEV_DEPTH of the window's 16 loads in flight (slot q % depth, refill `depth` positions ahead):
+// does the weight stream run at "bytes in flight / loaded L2 latency"?
+#ifdef TW_DEV_DEPTH
+constexpr int TW_DEPTH = TW_DEV_DEPTH;
+static_assert(TW_DEPTH == 8 || TW_DEPTH == 4, "the depth must divide the phase length");
+#else
+constexpr int TW_DEPTH = TW_WIN;
+#endif
 
 typedef half_t half2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -244,10 +253,10 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
             // front of the MFMAs that consume them -- and every step waits out a full LDS latency (measured: 179 cycles per step).
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mma32(win[s * 2 + (i >> 1)], cur[i], accE[i & 1]);
+            for (int i = 0; i < 4; ++i) mma32(win[(s * 2 + (i >> 1)) % TW_DEPTH], cur[i], accE[i & 1]);
 #ifndef TW_DEV_NO_WLOAD
 #pragma unroll
-            for (int e = 0; e < 2; ++e) win[s * 2 + e] = sp.frag_at(s * 2 + e + TW_WIN);
+            for (int e = 0; e < 2; ++e) win[(s * 2 + e) % TW_DEPTH] = sp.frag_at(s * 2 + e + TW_DEPTH);
 #endif
             if (s == 0) {                            // the first MFMAs have read the bias registers: fetch the next phase's
                 bp += 32;                            // (the stream is closed with one chunk of zeros, rise_net.hip)
@@ -287,11 +296,11 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) mma32(win[(s * 2 + kk) * 2 + rt], cur[kk * 2 + ct], accP[rt][ct]);
+                    for (int ct = 0; ct < 2; ++ct) mma32(win[((s * 2 + kk) * 2 + rt) % TW_DEPTH], cur[kk * 2 + ct], accP[rt][ct]);
             if (do_e && s < 2) expand_epilogue(s);
 #ifndef TW_DEV_NO_WLOAD
 #pragma unroll
-            for (int e = 0; e < 4; ++e) win[s * 4 + e] = sp.frag_at(s * 4 + e + TW_WIN);
+            for (int e = 0; e < 4; ++e) win[(s * 4 + e) % TW_DEPTH] = sp.frag_at(s * 4 + e + TW_DEPTH);
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -694,6 +703,11 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4, l31 = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef TW_DEV_STAGGER
+    // development: the workgroups of an XCD start the tower TW_DEV_STAGGER x 64 cycles apart (do 32 CUs that ask for the same L2 lines
+    // in the same cycle hold each other up?)
+    for (int i = 0; i < ((b >> 3) & (TW_DEV_STAGGER_GROUPS - 1)) * TW_DEV_STAGGER; ++i) __builtin_amdgcn_s_sleep(1);
+#endif
     const bool is_matrix = wave < 4;
     const int w = wave & 3;                              // both roles: my 32-channel slice of a chunk / my 64 couts
 
@@ -764,7 +778,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
         spP.pos = uint32_t(a.wstream_e_frags) * 1024u;
         frag win[TW_WIN];
 #pragma unroll
-        for (int q = 0; q < TW_WIN; ++q) win[q] = (F8 && q >= TW_WIN8) ? spP.frag_at(q - TW_WIN8) : sp.frag_at(q);
+        for (int q = 0; q < (F8 ? TW_WIN : TW_DEPTH); ++q) win[q] = (F8 && q >= TW_WIN8) ? spP.frag_at(q - TW_WIN8) : sp.frag_at(q);
         f32x4 bias[4];                               // BN1 bias of the next expand phase (matrix_interval)
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias[i] = reinterpret_cast<const f32x4*>(bp)[i];

@@ -35,6 +35,19 @@ __device__ __forceinline__ void mma_k32(const float8& a, const float8& b, f32x4&
     for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[j], b.hi[j], c, 0, 0, 0);
 }
 
+// An MFMA's result registers must not be read by a VALU instruction for (passes + 2) issue slots after the MFMA.  The compiler pads
+// its OWN instructions with s_nop; it neither looks inside inline asm (the v_fma_mix / v_cvt_pk epilogues of these kernels) nor keeps
+// an `asm volatile("s_nop ...")` behind the MFMAs -- without a data dependence it schedules MFMAs across it (seen in the one-launch fp8
+// forward: the stem's last MFMA landed two slots in front of the asm pack, which then read the accumulator one k-step short on some
+// issues).  Hence the accumulator goes THROUGH the wait: MFMA -> this asm -> reader is a dependence chain the scheduler cannot reorder.
+// 20 slots cover the 16-pass v_mfma_f32_32x32x64_f8f6f4.  Every accumulator an asm epilogue reads goes through one of these, behind
+// its last MFMA.  (scripts/isa_mfma_hazards.py checks the compiled kernels for such distances; tests/test_isa_hazards.py runs it.)
+template <typename Acc> __device__ __forceinline__ void mfma_retire(Acc& a) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a)); }
+template <typename Acc> __device__ __forceinline__ void mfma_retire(Acc& a, Acc& b) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b)); }
+template <typename Acc> __device__ __forceinline__ void mfma_retire(Acc& a, Acc& b, Acc& c, Acc& d) {
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
 __device__ __forceinline__ float to_f(half_t v) { return float(v); }
 __device__ __forceinline__ float to_f(float v) { return v; }
 

@@ -22,9 +22,18 @@ static_assert(ST_OROW == TW_XROW && TW_XROW == HD_ROW, "the three kernels must a
 
 template <int NKS, bool F8 = false>
 __global__ __launch_bounds__(512) void forward_kernel(const StemArgs sa, const TowerArgs ta, const HeadArgs ha) {
+#ifdef CRA_DEV_SEAMS                     // development: bit 0 / bit 1 = hand the tile over through global memory at the first / second seam
+    stem_body<NKS>(sa, (CRA_DEV_SEAMS & 1) != 0);
+    if (CRA_DEV_SEAMS & 1) { __threadfence(); __syncthreads(); }
+    tower_body<F8>(ta, (CRA_DEV_SEAMS & 1) == 0, (CRA_DEV_SEAMS & 2) != 0);
+    if (CRA_DEV_SEAMS & 2) { __threadfence(); __syncthreads(); }
+    if (CRA_DEV_SEAMS & 4) __syncthreads();
+    head_body(ha, (CRA_DEV_SEAMS & 2) == 0);
+#else
     stem_body<NKS>(sa, false);           // ends in a workgroup barrier: the tile is complete
     tower_body<F8>(ta, true, false);     // every role ends in the barrier after the last block's epilogue
     head_body(ha, true);
+#endif
 }
 
 void init_forward_kernel_attributes() {

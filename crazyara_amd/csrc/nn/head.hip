@@ -164,7 +164,7 @@ __device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds
         pf_sink ^= pf_old;
         asm volatile("" ::"v"(pf_sink));
         HD_STAMP();
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs retire before the asm pack reads them
+        mfma_retire(acc[0], acc[1]);                 // the last MFMAs retire before the asm pack reads them (device_utils.h)
         // BN bias + ReLU -> P1; my 16 rows of a square are 16 consecutive K positions of conv 2 (kernels.h: tower_row_of_position)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {

@@ -154,7 +154,10 @@ __global__ __launch_bounds__(512 / NR) void restower_kernel(const ResTowerArgs a
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bias[rt][i] = reinterpret_cast<const f32x4*>(bp + rt * 32)[i];
             conv3x3(X, acc);
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs retire before the asm pack reads them
+#pragma unroll
+            for (int rt = 0; rt < NR; ++rt)          // the last MFMAs retire before the asm pack reads them (device_utils.h)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) mfma_retire(acc[rt][t]);
 #pragma unroll
             for (int rt = 0; rt < NR; ++rt)
 #pragma unroll

@@ -90,7 +90,7 @@ __device__ __forceinline__ void stem_body(const StemArgs& a, const bool to_globa
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(win[q % ST_WIN], b1, acc[1], 0, 0, 0);
         win[q % ST_WIN] = sp[(q + ST_WIN) * 64];     // (the stream ends with ST_WIN zero fragments)
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs retire before the asm pack reads them
+    mfma_retire(acc[0], acc[1]);                     // the last MFMAs retire before the asm pack reads them (device_utils.h)
     f32x4 bias[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) bias[i] = reinterpret_cast<const f32x4*>(a.stem_b + (wv * 2 + lh) * 16)[i];

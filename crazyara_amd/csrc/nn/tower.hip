@@ -47,7 +47,7 @@ constexpr int TW_XROW = TW_C + 8;
 constexpr int TW_T1ROW = TW_CK + 16;
 constexpr int TW_T2ROW = TW_CK + 8;
 constexpr int TW_XS_BYTES = 64 * TW_XROW * 2;        // 33792  residual stream tile
-constexpr int TW_T1_BYTES = 66 * TW_T1ROW * 2;       // 19008  expand output of a chunk: zero row, 64 squares, zero row; x2
+constexpr int TW_T1_BYTES = 67 * TW_T1ROW * 2;       // 19296  expand output of a chunk: zero row, 64 squares, two zero rows; x2
 constexpr int TW_T2_BYTES = 64 * TW_T2ROW * 2;       // 17408  depthwise output of a chunk; x2
 constexpr int TW_T1_OFF = TW_XS_BYTES;
 constexpr int TW_T2_OFF = TW_T1_OFF + 2 * TW_T1_BYTES;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
         }
         sp.pos += 16 * 1024;
     } else if (do_e) {
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last expand MFMAs retire before the asm epilogue reads them
+        mfma_retire(accE[0], accE[1]);               // the last expand MFMAs retire before the asm epilogue reads them (device_utils.h)
         expand_epilogue(0);
         expand_epilogue(1);
     }
@@ -331,7 +331,7 @@ __device__ __forceinline__ void matrix_interval8(bool do_e, bool do_p, f32x16 (&
         auto epi = [&](int s) { if (do_e) expand_epilogue(s); };
         project_phase8(accP, winP, spP, t2r, epi);
     } else if (do_e) {
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last expand MFMAs (64 cycles) retire first
+        mfma_retire(accE[0], accE[1]);               // the last expand MFMAs (16 passes) retire first
         expand_epilogue(0);
         expand_epilogue(1);
     }
@@ -719,9 +719,9 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
 
     // ---- residual stream tile -> LDS (optionally gated: the first block's SE gate was computed by a previous launch) ----
     auto load_board = [&]() {
-        if (tid < 4 * T1ROW / 2) {       // zero rows 0 and 65 of both t1 buffers (4 rows of T1ROW halves, as 32-bit words)
-            const int rowi = tid / (T1ROW / 2), col = tid % (T1ROW / 2);
-            reinterpret_cast<uint32_t*>(smem + TW_T1_OFF + (rowi >> 1) * TW_T1_BYTES + (rowi & 1) * 65 * T1ROW * 2)[col] = 0u;
+        if (tid < 6 * T1ROW / 2) {       // zero rows 0, 65 and 66 of both t1 buffers (6 rows of T1ROW halves, as 32-bit words)
+            const int rowi = tid / (T1ROW / 2), col = tid % (T1ROW / 2), r3 = rowi % 3;
+            reinterpret_cast<uint32_t*>(smem + TW_T1_OFF + (rowi / 3) * TW_T1_BYTES + (r3 == 0 ? 0 : 64 + r3) * T1ROW * 2)[col] = 0u;
         }
         if (x_in_lds) {
             if constexpr (F8) {                      // the stem of this launch left the f16 tile: make its e4m3 copy
@@ -836,6 +836,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
             // All residual reads of a cout tile go out before its first store (a store would order the later reads behind it).
             // Precision fp8: the accumulators are in units of the cout's weight scale (they started at b3 / s3): y = x + s3 * acc, and the
             // new stream's e4m3 copy is made from the rounded f16 values.
+            mfma_retire(accP[0][0], accP[0][1], accP[1][0], accP[1][1]);      // asm readers below (device_utils.h)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 uint2 rv[4][2];
@@ -893,8 +894,12 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
         const bool hi = l15 >= 8;        // second board row of a 16-square tile
         const half2_t one2 = {half_t(1.f), half_t(1.f)}, zero2 = {half_t(0.f), half_t(0.f)};
         const int prm_off3 = lg * 48 + ((l15 & 7) == 0 ? 0 : (l15 & 7) == 7 ? 32 : 16);    // 3 x 3 weights: my lane group, my file's variant
-        // neighbour rows of my square in tile 0 (buffer rows: 0 = zero row, 1 + sq, 65 = zero row); file wrap-around reads a
-        // wrong-but-finite row that meets a zero weight
+        // neighbour rows of my square in tile 0 (buffer rows: 0 = zero row, 1 + sq, 65 and 66 = zero rows); file wrap-around reads
+        // a wrong-but-FINITE row that meets a zero weight.  Finite matters: Inf or NaN times the zero weight is a NaN, which the ReLU
+        // (v_pk_max_f16 returns the other operand) silently turns into 0 for the whole output.  The 5 x 5 taps reach row -1 (the last
+        // 288 bytes in front of the buffer: the stream tile's last row for buffer 0, buffer 0's zero rows for buffer 1) and row 66
+        // (h8 + 2 files, h7 + 1 rank + 2 files); without the second zero row that was the first bytes of the t2 region for buffer 1
+        // -- f16 activations in Precision float16, but e4m3 bytes and 16 never-written pad bytes per row in Precision fp8
         VecAddr va;
         {
             const char* t1b = smem + TW_T1_OFF;

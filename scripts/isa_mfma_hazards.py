@@ -1,0 +1,71 @@
+"""Development: scans an AMDGPU assembly listing (hipcc -S --cuda-device-only) for readers of an MFMA result that follow the MFMA too
+closely.  The compiler pads its OWN instructions with s_nop; it does not look inside inline asm (;;#ASMSTART ... ;;#ASMEND), so a v_cvt / v_fma
+written in asm that consumes an accumulator right behind the MFMA reads the old value on some issues.  Wait states: one per instruction, s_nop N = N + 1, and an MFMA in between
+counts its passes (the next instruction of the wave issues only when the matrix pipe has taken it, which for back-to-back MFMAs is when the
+previous one has gone through).  usage: isa_mfma_hazards.py file.s [function-substring]"""
+import re, sys
+
+NEED = {"f8f6f4": 18, "32x32": 10, "16x16": 6}     # XDL write VGPR -> VALU / LDS / VMEM read, by passes (16, 8, 4) + 2
+reg = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
+
+
+def regs(tok):
+    out = set()
+    for m in reg.finditer(tok):
+        if m.group(1): out |= {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+        else: out.add((m.group(4), int(m.group(5))))
+    return out
+
+
+def scan(lines, name):
+    pending = {}          # register -> (wait states still required, mfma line no)
+    in_asm = False
+    hits = 0
+    for no, raw in lines:
+        ln = raw.split(";")[0].strip() if not raw.strip().startswith(";") else raw.strip()
+        if ln.startswith((";APP", ";;#ASMSTART")): in_asm = True; continue
+        if ln.startswith((";NO_APP", ";;#ASMEND")): in_asm = False; continue
+        if not ln or ln.startswith((".", ";")) or ln.endswith(":"): continue
+        op = ln.split()[0]
+        args = ln[len(op):]
+        parts = [a.strip() for a in args.split(",")]
+        ws = 1
+        if op == "s_nop": ws = int(parts[0]) + 1
+        if op.startswith("v_mfma"):
+            need = next(v for k, v in NEED.items() if k in op)
+            ws = need - 2
+            # srcC == dst accumulate chains are the hardware's business; A / B operands read from pending registers are checked below
+            srcs = set().union(*[regs(p) for p in parts[1:3]])
+            for r in srcs & pending.keys():
+                if pending[r][0] > 0:
+                    print(f"{name}:{no}: MFMA operand {r} written by the MFMA at line {pending[r][1]}, {pending[r][0]} wait states short"); hits += 1
+            for r in pending: pending[r] = (pending[r][0] - ws, pending[r][1])
+            for r in regs(parts[0]): pending[r] = (need, no)
+            continue
+        if op.startswith(("v_", "ds_", "buffer_", "global_", "flat_")):
+            touched = set().union(*[regs(p) for p in parts]) if parts else set()
+            for r in touched & pending.keys():
+                if pending[r][0] > 0:
+                    print(f"{name}:{no}: {'ASM ' if in_asm else ''}{op} touches {r[0]}{r[1]} written by the MFMA at line {pending[r][1]}, {pending[r][0]} wait states short")
+                    hits += 1
+                    break
+            for r in touched: pending.pop(r, None) if op.startswith("v_") and r in regs(parts[0]) else None
+        if op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_barrier")) and op != "s_barrier":
+            pass      # linear scan: fall-through order is what the listing gives; branches only shorten real distances
+        for r in list(pending):
+            pending[r] = (pending[r][0] - ws, pending[r][1])
+            if pending[r][0] <= 0: del pending[r]
+    return hits
+
+
+text = open(sys.argv[1]).read().split("\n")
+want = sys.argv[2] if len(sys.argv) > 2 else ""
+cur, body, total = None, [], 0
+for i, l in enumerate(text, 1):
+    m = re.match(r"^(_Z\w+):", l)
+    if m: cur, body = m.group(1), []
+    elif l.startswith(".Lfunc_end") and cur:
+        if want in cur: n = scan(body, cur[:60]); total += n; print(f"{cur[:80]}: {n} short distances")
+        cur = None
+    elif cur: body.append((i, l))
+print("total", total)

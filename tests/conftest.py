@@ -23,3 +23,20 @@ def hip_lib():
 @pytest.fixture(scope="session")
 def has_reference():
     return os.path.isdir("/root/reference/DeepCrazyhouse")
+
+
+@pytest.fixture(scope="session")
+def lds_poison():
+    """ctypes handle of tests/support/lds_poison.hip: poison(pattern, base, lo, hi) fills every CU's LDS before the next launch."""
+    import ctypes
+    import subprocess
+    src = os.path.join(ROOT, "tests", "support", "lds_poison.hip")
+    out = os.path.join(ROOT, "tests", "support", "_build", "liblds_poison.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        from crazyara_amd import build
+        subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", src, "-o", out], check=True, cwd="/tmp")
+    lib = ctypes.CDLL(out)
+    lib.poison_lds.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
+    lib.poison_lds.restype = ctypes.c_int
+    return lib

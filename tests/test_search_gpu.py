@@ -97,7 +97,8 @@ def test_lane_count_does_not_change_the_trees(tmp_path, hip_lib):
         assert len(visits) == len(env.Position(f, False, "crazyhouse").legal_uci())      # Dirichlet: root fully expanded
 
 
-def test_priors_gathered_on_the_gpu_equal_whole_probability_vectors(tmp_path, hip_lib, monkeypatch):
+@pytest.mark.parametrize("precision", ["float16", "fp8"])
+def test_priors_gathered_on_the_gpu_equal_whole_probability_vectors(tmp_path, hip_lib, monkeypatch, precision):
     """The HIP lanes bring back only the probabilities of the new nodes' legal moves (gather kernel behind the forward, ~40 KB per
     batch instead of 5.3 MB).  The same searches with the gather switched off, and with room for 4 entries per slot (fallback on
     nearly every batch), must give the same trees down to the last Q bit."""
@@ -116,7 +117,7 @@ def test_priors_gathered_on_the_gpu_equal_whole_probability_vectors(tmp_path, hi
             monkeypatch.delenv("CRA_LANE_LAUNCHES", raising=False)
         else:
             monkeypatch.setenv("CRA_LANE_LAUNCHES", launches)
-        nets = [HipAPI(0, 64, d, "float16") for _ in range(2)]
+        nets = [HipAPI(0, 64, d, precision) for _ in range(2)]
         st = search.default_settings(mode=0, version_major=1, batch_size=16, seed=3)
         pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1])
         for f in fens:

@@ -152,6 +152,32 @@ def test_submit_wait_and_device_resident_paths_agree(tmp_path, hip_lib):
     net.close()
 
 
+@pytest.mark.parametrize("name,precision,batch", [
+    ("rise-classical-4", "float16", 70), ("rise-classical-4", "float16-perblock", 9), ("alphazero-5", "float16", 33), ("alphazero-3-cv8", "float32", 9),
+    ("rise-classical-3-se", "float16", 40), ("alphazero-3-se", "float16", 40), ("risev2-3-flat", "float16", 64), ("risev33-wdlp", "float16", 64),
+    ("risev2-7", "float32", 20), ("risev2-7", "float16-perblock", 20), ("risev2-7", "float16-unfused", 20), ("risev33", "float32-unfused", 8),
+    ("risev2-13-lichess", "float16", 64)])
+def test_every_kernel_family_is_bit_identical_whatever_the_cus_held_before(tmp_path, hip_lib, lds_poison, name, precision, batch):
+    """tests/test_fp8.py's call-to-call check (LDS of every CU poisoned with a different pattern before each forward) over the other
+    kernel families: dense towers in one launch, per-block and layer-granular kernels, float32, flat and WDLP heads, lichess tables."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, _ = nn_cases.make_case(name)
+    d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
+    x = nn_cases.synthetic_planes(batch, cfg.nb_input_channels, 78).numpy().reshape(-1)
+    net = HipAPI(0, batch, d, precision)
+    outs = []
+    for pattern in (0x00000000, 0xffffffff, 0x7f7f7f7f, 0x7bff7bff, 0x7f800000, 0x00000000):
+        assert lds_poison.poison_lds(pattern, pattern, 0, 0) == 0
+        v = np.zeros(batch, np.float32)
+        p = np.zeros(batch * cfg.nb_policy, np.float32)
+        net.predict(x, v, p)
+        outs.append((v, p))
+    net.close()
+    assert np.isfinite(outs[0][0]).all() and np.isfinite(outs[0][1]).all()
+    for v, p in outs[1:]:
+        assert np.array_equal(v, outs[0][0]) and np.array_equal(p, outs[0][1])
+
+
 @pytest.mark.parametrize("name,precision", [("risev2-7", "float16"), ("risev33-wdlp", "float16"), ("risev2-3-flat", "float16"),
                                             ("alphazero-5", "float16"), ("risev2-7", "float32")])
 def test_zero_copy_predict_equals_copied_predict(tmp_path, hip_lib, name, precision):

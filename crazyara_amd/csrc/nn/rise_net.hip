@@ -582,9 +582,10 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             for (int c = 0; c < C; ++c) for (int j = 0; j < H; ++j) w2t[size_t(j) * C + c] = w2.data[size_t(c) * H + j];
             if (se_in_kernel) {
                 td.se_kind = 1;
-                // FC1: thread t -> outputs 2*(t%64), +1 over inputs c in [32*(t/64), +32); FC2: outputs 2*(t%128), +1 over j in [32*(t/128), +32)
-                td.se_w1 = im.upload(pack_se_threads(w1t, [](int t, int k) { return size_t((t >> 6) * 32 + k) * 64 + (t & 63); }));
-                td.se_w2 = im.upload(pack_se_threads(w2t, [](int t, int k) { return size_t((t >> 7) * 32 + k) * 128 + (t & 127); }));
+                // FC1: thread t -> outputs 2*(t/8), +1 over inputs c in [32*(t%8), +32); FC2: outputs 2*(t/4), +1 over j in [32*(t%4), +32):
+                // the threads of an output pair are neighbouring lanes (in-wave reduction, tower.hip: se_phase)
+                td.se_w1 = im.upload(pack_se_threads(w1t, [](int t, int k) { return size_t((t & 7) * 32 + k) * 64 + (t >> 3); }));
+                td.se_w2 = im.upload(pack_se_threads(w2t, [](int t, int k) { return size_t((t & 3) * 32 + k) * 128 + (t >> 2); }));
             } else {
                 Op op;
                 op.se_kind = 1;
@@ -603,9 +604,9 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             for (int o = 0; o < C; ++o) b[o] = bs[o];
             if (se_in_kernel) {
                 td.se_kind = 2;
-                // thread t -> outputs 2*(t%128), +1 over inputs i in [64*(t/128), +64): first 32 inputs, then the second 32
-                std::vector<half_t> pk = pack_se_threads(wt, [](int t, int k) { return size_t((t >> 7) * 64 + k) * 128 + (t & 127); });
-                const std::vector<half_t> pk2 = pack_se_threads(wt, [](int t, int k) { return size_t((t >> 7) * 64 + 32 + k) * 128 + (t & 127); });
+                // thread t -> outputs 2*(t/4), +1 over inputs i in [64*(t%4), +64): first 32 inputs, then the second 32
+                std::vector<half_t> pk = pack_se_threads(wt, [](int t, int k) { return size_t((t & 3) * 64 + k) * 128 + (t >> 2); });
+                const std::vector<half_t> pk2 = pack_se_threads(wt, [](int t, int k) { return size_t((t & 3) * 64 + 32 + k) * 128 + (t >> 2); });
                 pk.insert(pk.end(), pk2.begin(), pk2.end());
                 td.se_w1 = im.upload(pk);
                 td.se_b = im.upload(b);

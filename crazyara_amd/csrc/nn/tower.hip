@@ -529,10 +529,10 @@ __device__ __forceinline__ void vector_interval5(VParams& vp, const char* prm_bu
 template <bool F8>
 __device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_t* xs, char* xq, const float* pool_sum, float* se_mean,
                                      float* se_part, float* se_h, float* se_gate, unsigned long long* trc, int& trn) {
-    constexpr int XROW = TW_XROW;
+    constexpr int XROW = TW_XROW, SE_GRP = 36;       // floats per group of 32 means / hidden values (bank spread, see below)
     {
         // The gate weights do not depend on the data: a thread's first 32 dwords go out before the squeeze and fly while it runs,
-        // the second 32 as soon as the first are consumed (64 at once do not fit beside the matrix role's weight window).
+        // the second 32 behind the squeeze (they fly during FC1).
         // Host-packed in thread order (rise_net.hip: pack_se_threads): 8 coalesced 16-byte loads per thread and matrix.
         half2_t wa[32], wb[32];
         auto load_thread_weights = [&](const void* base, half2_t (&dst)[32]) {
@@ -544,7 +544,12 @@ __device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_
                 dst[4 * i + 2] = __builtin_bit_cast(half2_t, u.z); dst[4 * i + 3] = __builtin_bit_cast(half2_t, u.w);
             }
         };
-        // ca_se: FC1 outputs 2*j2, 2*j2+1 over c in [kq*32, +32); eca_se: centre-tap matrix, inputs i in [kq*64, +32)
+        // Excitation without a trip through LDS for the partial sums: the threads that share an output pair are NEIGHBOURING LANES
+        // (8 for FC1, 4 for FC2 / the eca matrix), each takes 32 inputs (eca: 2 x 32), and a DPP row_shr reduction leaves the total in
+        // the last lane of the group.  Barriers per SE phase: squeeze | FC1 | FC2 | scale (were six).  The vectors a group's lanes
+        // read (means, hidden) sit in LDS with 36 floats per 32 inputs, so that the 8 (4) concurrent 16-byte reads hit distinct banks.
+        //   ca_se : FC1 thread t -> hidden 2*(t/8), +1 over c in [32*(t%8), +32);  FC2 thread t -> gate 2*(t/4), +1 over j in [32*(t%4), +32)
+        //   eca_se: thread t -> gate 2*(t/4), +1 over inputs i in [64*(t%4), +64): first 32, then the second 32
         load_thread_weights(d.se_w1, wa);
         {   // squeeze: mean over the 64 squares of the residual stream as it sits in LDS.  A wave owns 32 channels: lane =
             // (4 groups of 8 channels) x (16 groups of 4 squares); 16-byte reads, then a 16-lane DPP row reduction.
@@ -566,94 +571,66 @@ __device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_
             }
             if (sg == 15) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) se_mean[wv * 32 + cg * 8 + j] = sum[j] * (1.f / 64.f);
+                for (int j = 0; j < 8; ++j) se_mean[wv * SE_GRP + cg * 8 + j] = sum[j] * (1.f / 64.f);      // channel c at (c / 32) * 36 + c % 32
             }
         }
+        if (d.se_kind == 1) load_thread_weights(d.se_w2, wb);                     // flies during FC1
+        else load_thread_weights(reinterpret_cast<const char*>(d.se_w1) + 8 * 512 * 16, wb);
         __syncthreads();
 #ifdef TW_TRACE_SE
         if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
 #endif
+        auto dot32 = [](const half2_t (&w)[32], const float* v, float& s0, float& s1) {   // v: 32 floats, 16-byte aligned
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(v + 4 * k4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s0 = fmaf(float(w[4 * k4 + j][0]), m[j], s0);
+                    s1 = fmaf(float(w[4 * k4 + j][1]), m[j], s1);
+                }
+            }
+        };
         if (d.se_kind == 1) {        // ca_se: relu(W1 mean) -> W2 -> hard-sigmoid (builder_util.py:83-114)
             {
-                const int j2 = tid & 63, kq = tid >> 6;
+                const int j2 = tid >> 3, kq = tid & 7;
                 float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    const float m = se_mean[kq * 32 + k];
-                    s0 = fmaf(float(wa[k][0]), m, s0);
-                    s1 = fmaf(float(wa[k][1]), m, s1);
+                dot32(wa, se_mean + kq * SE_GRP, s0, s1);
+                s0 += dpp_mov<0x111>(s0); s1 += dpp_mov<0x111>(s1);
+                s0 += dpp_mov<0x112>(s0); s1 += dpp_mov<0x112>(s1);
+                s0 += dpp_mov<0x114>(s0); s1 += dpp_mov<0x114>(s1);             // lane 7 of the group of 8: the whole sum
+                if (kq == 7) {                                                    // hidden j = 2*j2, +1 at (j / 32) * 36 + j % 32
+                    float* h = se_h + (j2 >> 4) * SE_GRP + 2 * (j2 & 15);
+                    h[0] = fmaxf(s0, 0.f);
+                    h[1] = fmaxf(s1, 0.f);
                 }
-                load_thread_weights(d.se_w2, wb);                                 // FC2: outputs 2*c2, 2*c2+1 over j in [kq2*32, +32)
-                se_part[kq * 128 + 2 * j2] = s0;
-                se_part[kq * 128 + 2 * j2 + 1] = s1;
             }
             __syncthreads();
 #ifdef TW_TRACE_SE
             if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef TW_TRACE_SE
-        if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
-#endif
-            if (tid < 128) {
-                float s = 0.f;
-#pragma unroll
-                for (int kq = 0; kq < 8; ++kq) s += se_part[kq * 128 + tid];
-                se_h[tid] = fmaxf(s, 0.f);
-            }
-            __syncthreads();
-#ifdef TW_TRACE_SE
-            if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef TW_TRACE_SE
-        if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
 #endif
             {
-                const int c2 = tid & 127, kq = tid >> 7;                          // outputs 2*c2, 2*c2+1; j in [kq*32, +32)
+                const int c2 = tid >> 2, kq = tid & 3;
                 float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    const float h = se_h[kq * 32 + k];
-                    s0 = fmaf(float(wb[k][0]), h, s0);
-                    s1 = fmaf(float(wb[k][1]), h, s1);
+                dot32(wb, se_h + kq * SE_GRP, s0, s1);
+                s0 += dpp_mov<0x111>(s0); s1 += dpp_mov<0x111>(s1);
+                s0 += dpp_mov<0x112>(s0); s1 += dpp_mov<0x112>(s1);             // lane 3 of the group of 4
+                if (kq == 3) {
+                    se_gate[2 * c2] = hard_sigmoid(s0);
+                    se_gate[2 * c2 + 1] = hard_sigmoid(s1);
                 }
-                se_part[kq * 256 + 2 * c2] = s0;
-                se_part[kq * 256 + 2 * c2 + 1] = s1;
             }
-            __syncthreads();
-#ifdef TW_TRACE_SE
-            if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef TW_TRACE_SE
-        if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
-#endif
-            if (tid < 256) se_gate[tid] = hard_sigmoid(se_part[tid] + se_part[256 + tid] + se_part[512 + tid] + se_part[768 + tid]);
         } else {                     // eca_se: centre-tap linear + bias -> hard-sigmoid (builder_util.py:49-80)
-            const int c2 = tid & 127, kq = tid >> 7;
+            const int c2 = tid >> 2, kq = tid & 3;
             float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const float m = se_mean[kq * 64 + k];
-                s0 = fmaf(float(wa[k][0]), m, s0);
-                s1 = fmaf(float(wa[k][1]), m, s1);
+            dot32(wa, se_mean + (2 * kq) * SE_GRP, s0, s1);
+            dot32(wb, se_mean + (2 * kq + 1) * SE_GRP, s0, s1);
+            s0 += dpp_mov<0x111>(s0); s1 += dpp_mov<0x111>(s1);
+            s0 += dpp_mov<0x112>(s0); s1 += dpp_mov<0x112>(s1);
+            if (kq == 3) {
+                se_gate[2 * c2] = hard_sigmoid(d.se_b[2 * c2] + s0);
+                se_gate[2 * c2 + 1] = hard_sigmoid(d.se_b[2 * c2 + 1] + s1);
             }
-            load_thread_weights(reinterpret_cast<const char*>(d.se_w1) + 8 * 512 * 16, wb);   // inputs i in [kq*64 + 32, +32)
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const float m = se_mean[kq * 64 + 32 + k];
-                s0 = fmaf(float(wb[k][0]), m, s0);
-                s1 = fmaf(float(wb[k][1]), m, s1);
-            }
-            se_part[kq * 256 + 2 * c2] = s0;
-            se_part[kq * 256 + 2 * c2 + 1] = s1;
-            __syncthreads();
-#ifdef TW_TRACE_SE
-            if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef TW_TRACE_SE
-        if (trc) trc[trn++] = __builtin_amdgcn_s_memtime();
-#endif
-            if (tid < 256)
-                se_gate[tid] = hard_sigmoid(d.se_b[tid] + se_part[tid] + se_part[256 + tid] + se_part[512 + tid] + se_part[768 + tid]);
         }
         __syncthreads();
 #ifdef TW_TRACE_SE
@@ -696,9 +673,9 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
     char* xq = smem + TW_XQ_OFF;                     // Precision fp8 only
     float* pool_sum = reinterpret_cast<float*>(smem + TW_POOL_OFF);
     float* se_mean = reinterpret_cast<float*>(smem + TW_SE_OFF);
-    float* se_part = se_mean + 256;
-    float* se_h = se_part + 1024;
-    float* se_gate = se_h + 128;
+    float* se_part = se_mean + 256;                  // (unused since the partial sums stay in the wave; the padded vectors live here)
+    float* se_h = se_mean + 512;                     // 4 x 36 floats (se_mean: 8 x 36)
+    float* se_gate = se_part + 1024 + 128;
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4, l31 = lane & 31, lh = lane >> 5;

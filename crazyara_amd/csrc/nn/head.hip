@@ -24,8 +24,8 @@ constexpr int HD_TILE_BYTES = 65 * HD_ROW * 2;       // 64 squares + a zero row
 constexpr int HD_X_OFF = 0;
 constexpr int HD_P1_OFF = HD_TILE_BYTES;
 constexpr int HD_LOGIT_OFF = 2 * HD_TILE_BYTES;      // float [96][64]
-constexpr int HD_VFLAT_OFF = HD_LOGIT_OFF + 96 * 64 * 4;      // float [512]: value conv output, channel-major flat
-constexpr int HD_FC_OFF = HD_VFLAT_OFF + 512 * 4;    // float [4][256] FC1 partial sums, [256] hidden
+constexpr int HD_VFLAT_OFF = HD_LOGIT_OFF + 96 * 64 * 4;      // float [4][132]: value conv output, channel-major flat, 128 per row
+constexpr int HD_FC_OFF = HD_VFLAT_OFF + 528 * 4;    // (spare: the FC1 partial sums stay in the wave)
 constexpr int HD_RED_OFF = HD_FC_OFF + 5 * 256 * 4;  // float [16] reductions
 constexpr int HD_LDS_BYTES = HD_RED_OFF + 64;
 constexpr int HD_WIN = 16;
@@ -46,6 +46,9 @@ __device__ __forceinline__ int nbr_row(int sq, int dy, int dx) {
     const int y = (sq >> 3) + dy, x = (sq & 7) + dx;
     return (unsigned(y) < 8u && unsigned(x) < 8u) ? sq + dy * 8 + dx : 64;
 }
+// flat index k of the value conv output -> float index in LDS: rows of 128 padded to 132, so that the four lanes of an FC1 group
+// (k = 128 * (lane % 4) + ...) read their 16 bytes from distinct banks
+__device__ __forceinline__ int vflat_at(int k) { return k + 4 * (k >> 7); }
 __device__ __forceinline__ float block_reduce_512(float v, float* red, bool is_max) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -75,7 +78,6 @@ __device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds
     half_t* P1 = reinterpret_cast<half_t*>(smem + HD_P1_OFF);
     float* logit = reinterpret_cast<float*>(smem + HD_LOGIT_OFF);
     float* vflat = reinterpret_cast<float*>(smem + HD_VFLAT_OFF);
-    float* fcp = reinterpret_cast<float*>(smem + HD_FC_OFF);
     float* red = reinterpret_cast<float*>(smem + HD_RED_OFF);
 
     const int b = blockIdx.x;
@@ -181,7 +183,7 @@ __device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int cv = lh * 4 + r;
-                    vflat[cv * 64 + ct * 32 + l31] = fmaxf(accv[ct][r] + a.vconv_bias[cv], 0.f);
+                    vflat[vflat_at(cv * 64 + ct * 32 + l31)] = fmaxf(accv[ct][r] + a.vconv_bias[cv], 0.f);
                 }
         }
     }
@@ -257,21 +259,37 @@ __device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds
     HD_STAMP();
 
     // ================= phase 3: softmax over the cp * 64 logits =================
+    // The tanh head's FC1 weights (256 KiB per workgroup) are requested first and fly while the softmax runs: thread t owns outputs
+    // 2*(t/4), +1 over k in [128*(t%4), +128), host-packed in thread order (rise_net.hip): load i of thread t = uint4 i*512 + t = the
+    // half2 weights of k = 128*(t%4) + 4i .. 4i+3.
+    uint4 vw[32];
+    if (!a.wdlp) {
+        const uint4* pk = reinterpret_cast<const uint4*>(a.fc1_w) + tid;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) vw[i] = pk[i * 512];
+    }
     {
-        const int n = a.cp * 64;
-        float* lo = a.logits + size_t(b) * n;
-        float* po = a.probs + size_t(b) * n;
+        const int n4 = a.cp * 16;                    // float4 units
+        const f32x4* lg4 = reinterpret_cast<const f32x4*>(logit);
+        f32x4* lo = reinterpret_cast<f32x4*>(a.logits + size_t(b) * n4 * 4);
+        f32x4* po = reinterpret_cast<f32x4*>(a.probs + size_t(b) * n4 * 4);
         float m = -INFINITY;
-        for (int i = tid; i < n; i += 512) m = fmaxf(m, logit[i]);
+        for (int i = tid; i < n4; i += 512) {
+            const f32x4 x = lg4[i];
+            m = fmaxf(fmaxf(m, fmaxf(x[0], x[1])), fmaxf(x[2], x[3]));
+        }
         m = block_reduce_512(m, red, true);
         float sum = 0.f;
-        for (int i = tid; i < n; i += 512) sum += __expf(logit[i] - m);
+        for (int i = tid; i < n4; i += 512) {
+            const f32x4 x = lg4[i];
+            sum += (__expf(x[0] - m) + __expf(x[1] - m)) + (__expf(x[2] - m) + __expf(x[3] - m));
+        }
         sum = block_reduce_512(sum, red, false);
         const float c = m + logf(sum);               // exp(x - (max + log(sum))) as apply_softmax(), neuralnetapi.cpp:241-260
-        for (int i = tid; i < n; i += 512) {
-            const float x = logit[i];
+        for (int i = tid; i < n4; i += 512) {
+            const f32x4 x = lg4[i];
             lo[i] = x;
-            po[i] = __expf(x - c);
+            po[i] = f32x4{__expf(x[0] - c), __expf(x[1] - c), __expf(x[2] - c), __expf(x[3] - c)};
         }
         if (a.g_out != nullptr && b < a.g_n_valid) {     // search lane: the priors of the new node's legal moves, straight from the tile
             const uint32_t cnt = a.g_cnt[b];
@@ -283,30 +301,25 @@ __device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds
     HD_STAMP();
     // ================= phase 4: value head =================
     if (!a.wdlp) {
-        {   // FC1 512 -> 256 (+ReLU below): outputs 2*j2, 2*j2+1, k in [kq*128, +128)
-            const half2_t* w = reinterpret_cast<const half2_t*>(a.fc1_w);    // [k][128] half2
-            const int j2 = tid & 127, kq = tid >> 7;
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-            for (int k0 = 0; k0 < 128; k0 += 32) {
-                half2_t wq[32];
-#pragma unroll
-                for (int k = 0; k < 32; ++k) wq[k] = w[(kq * 128 + k0 + k) * 128 + j2];
-#pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    const float f = vflat[kq * 128 + k0 + k];
-                    s0 = fmaf(float(wq[k][0]), f, s0);
-                    s1 = fmaf(float(wq[k][1]), f, s1);
-                }
-            }
-            fcp[kq * 256 + 2 * j2] = s0;
-            fcp[kq * 256 + 2 * j2 + 1] = s1;
-        }
-        __syncthreads();
         float part = 0.f;
-        if (tid < 256) {
-            const float h = fmaxf(fcp[tid] + fcp[256 + tid] + fcp[512 + tid] + fcp[768 + tid] + a.fc1_b[tid], 0.f);
-            part = h * a.fc2_w[tid];
+        {   // FC1 512 -> 256 + ReLU, FC2 256 -> 1: the four lanes of an output pair reduce by DPP, the last one carries on
+            const int j2 = tid >> 2, kq = tid & 3;
+            const float* vf = vflat + kq * 132;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const f32x4 f = *reinterpret_cast<const f32x4*>(vf + 4 * i);
+                const half2_t w0 = __builtin_bit_cast(half2_t, vw[i].x), w1 = __builtin_bit_cast(half2_t, vw[i].y);
+                const half2_t w2 = __builtin_bit_cast(half2_t, vw[i].z), w3 = __builtin_bit_cast(half2_t, vw[i].w);
+                s0 = fmaf(float(w0[0]), f[0], s0); s1 = fmaf(float(w0[1]), f[0], s1);
+                s0 = fmaf(float(w1[0]), f[1], s0); s1 = fmaf(float(w1[1]), f[1], s1);
+                s0 = fmaf(float(w2[0]), f[2], s0); s1 = fmaf(float(w2[1]), f[2], s1);
+                s0 = fmaf(float(w3[0]), f[3], s0); s1 = fmaf(float(w3[1]), f[3], s1);
+            }
+            s0 += dpp_mov<0x111>(s0); s1 += dpp_mov<0x111>(s1);
+            s0 += dpp_mov<0x112>(s0); s1 += dpp_mov<0x112>(s1);
+            if (kq == 3)
+                part = fmaxf(s0 + a.fc1_b[2 * j2], 0.f) * a.fc2_w[2 * j2] + fmaxf(s1 + a.fc1_b[2 * j2 + 1], 0.f) * a.fc2_w[2 * j2 + 1];
         }
         const float tot = block_reduce_512(part, red, false);
         if (tid == 0) a.value[b] = tanhf(tot + a.fc2_b);
@@ -314,7 +327,7 @@ __device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds
         const float* w = reinterpret_cast<const float*>(a.fc1_w);            // [4][512] float
         float p[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p[k] = w[k * 512 + tid] * vflat[tid];
+        for (int k = 0; k < 4; ++k) p[k] = w[k * 512 + tid] * vflat[vflat_at(tid)];
         float r[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) r[k] = block_reduce_512(p[k], red, false);

@@ -154,7 +154,7 @@ struct HeadArgs {
     const void* s2;
     long long s1_wave_frags, s2_wave_frags;
     const float* vconv_bias;  // [8]
-    const void* fc1_w;        // tanh head: f16 [512][256] (k-major);  WDLP head: float [4][512] (wdl rows 0..2, plys)
+    const void* fc1_w;        // tanh head: f16 pairs in thread order (head.hip, phase 4);  WDLP head: float [4][512] (wdl rows 0..2, plys)
     const float* fc1_b;       // [256]
     const float* fc2_w;       // [256]
     float fc2_b;

@@ -867,8 +867,17 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 macs += 4.0 * nfl;
             } else {
                 const TensorView &w1 = nf.get("value_head.body_final.0.weight"), &w2 = nf.get("value_head.body_final.2.weight");
-                std::vector<half_t> w1t(size_t(512) * fc, half_t(0.f));           // [512][fc], rows zero beyond nfl
-                for (int j = 0; j < fc; ++j) for (int k = 0; k < nfl; ++k) w1t[size_t(k) * fc + j] = half_t(w1.data[size_t(j) * nfl + k]);
+                // thread order (head.hip, phase 4): thread t of 512 owns outputs 2*(t/4), +1 over k in [128*(t%4), +128); its load i is the
+                // uint4 at index i*512 + t = the (w[2j2][k], w[2j2+1][k]) pairs of k = 128*(t%4) + 4i .. 4i+3; k >= nfl: zeros
+                std::vector<half_t> w1t(size_t(512) * fc, half_t(0.f));
+                for (int i = 0; i < 32; ++i)
+                    for (int t = 0; t < 512; ++t)
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = 128 * (t & 3) + 4 * i + j, o = 2 * (t >> 2);
+                            if (k >= nfl) continue;
+                            w1t[((size_t(i) * 512 + t) * 4 + j) * 2 + 0] = half_t(w1.data[size_t(o) * nfl + k]);
+                            w1t[((size_t(i) * 512 + t) * 4 + j) * 2 + 1] = half_t(w1.data[size_t(o + 1) * nfl + k]);
+                        }
                 const float* bb = nf.get("value_head.body_final.0.bias").data;
                 h.fc1_w = im.upload(w1t);
                 h.fc1_b = im.upload(std::vector<float>(bb, bb + fc));
@@ -1275,6 +1284,7 @@ bool RiseNet::buffers_are_pinned(const float* in_planes, float* value, float* pr
     if (set[0] == pinned_seen_[0] && set[1] == pinned_seen_[1] && set[2] == pinned_seen_[2] && set[3] == pinned_seen_[3] && set[0]) return true;
     for (const void* p : set) {
         if (!p) continue;
+        if (reinterpret_cast<uintptr_t>(p) & 15) return false;     // the kernels read / write the buffers in 16-byte units
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, p) != hipSuccess) {
             (void)hipGetLastError();               // a pageable pointer is reported as an error by some runtimes: not ours to keep

@@ -109,6 +109,8 @@ private:
     bool one_launch_ = true;     // stem + tower + head in one launch when the net is exactly that chain ("-3k": three launches)
     bool rt_thin_waves_ = false; // dense residual tower: 8 waves x 32 couts ("-8w") instead of 4 x 64
     int boards_per_wg_ = 0;      // dense residual tower: 0 = by batch size (2 from 512 boards), 1 / 2 = forced ("-1b" / "-2b")
+    struct Turn;                       // forwards of different streams take turns when one fills the chip (rise_net.hip)
+    int cu_count_ = 256;
     int device_ = 0;
     int launches_ = 0;
     hipStream_t stream_ = nullptr;

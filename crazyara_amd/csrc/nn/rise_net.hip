@@ -1,5 +1,7 @@
 #include "rise_net.h"
 
+#include <mutex>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -209,6 +211,10 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     HIP_CHECK(hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) throw std::invalid_argument("device id out of range");
     HIP_CHECK(hipSetDevice(device_id));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) cu_count_ = cus;
+    }
 
     NetFile nf;                                  // load_model: our container, or the reference's ONNX parsed in place (onnx_import.h)
     if (model_file_path_.size() > 5 && model_file_path_.compare(model_file_path_.size() - 5, 5, ".onnx") == 0) import_onnx(model_file_path_, nf);
@@ -1254,10 +1260,57 @@ void RiseNet::forward_on(hipStream_t s) {
     if (fp16_) enqueue<half_t>(s); else enqueue<float>(s);
 }
 
+// Forwards of DIFFERENT streams take turns when a forward fills the chip on its own (one workgroup per board, 160 KiB of LDS: one
+// per CU).  Two evaluator lanes (or two NeuralNetAPIUsers) keep two batches in flight on two streams; when the streams sit on
+// different hardware queues the dispatcher interleaves the workgroups of both forward kernels, both batches then finish together after
+// 2 x 0.31 ms, the host collects for both lanes with nothing queued, and the chip idles for every collect: measured 0.42 ms per batch
+// instead of 0.32 on the headline search leg (615k against 750k nodes/s), in one mode or the other for a whole process depending
+// on which queues the runtime handed out.  Taking turns (submission order) keeps one batch executing and one queued.  Small batches
+// are left alone: a batch of 8 occupies 8 CUs and SHOULD overlap with its neighbour.  The copy path of predict() gains too (its D2H copies
+// now run beside the other user's forward: two users 559k -> 767k evals/s); zero-copy predict is exempt (see submit()).
+namespace {
+struct ForwardTurns {
+    std::mutex mu;
+    hipEvent_t ev[64];
+    bool made = false, any = false;
+    int last = 0;
+    hipStream_t last_stream = nullptr;
+};
+ForwardTurns g_turns[64];     // per device
+}  // namespace
+
+struct RiseNet::Turn {
+    ForwardTurns* t = nullptr;
+    hipStream_t s = nullptr;
+    Turn(RiseNet& n) {
+        static const bool off = getenv("CRA_NO_FORWARD_TURNS") != nullptr;      // development: A/B
+        if (off || n.device_ < 0 || n.device_ >= 64 || int(n.design_.batch) * 4 < n.cu_count_ * 3) return;
+        t = &g_turns[n.device_];
+        s = n.stream_;
+        t->mu.lock();
+        if (!t->made) {
+            for (hipEvent_t& e : t->ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            t->made = true;
+        }
+        if (t->any && t->last_stream != s) HIP_CHECK(hipStreamWaitEvent(s, t->ev[t->last], 0));
+    }
+    ~Turn() {
+        if (!t) return;
+        const int next = (t->last + 1) & 63;
+        if (hipEventRecord(t->ev[next], s) == hipSuccess) {
+            t->last = next;
+            t->last_stream = s;
+            t->any = true;
+        }
+        t->mu.unlock();
+    }
+};
+
 // Device-resident replay.  A forward that is ONE kernel gains nothing from a graph (there is no launch sequence to save) and loses the
 // graph launch's own cost between consecutive replays: it goes into the stream as a plain launch.  Everything else replays the graph.
 // CRA_DEVICE_GRAPH=1 forces the graph (A/B timing).
 void RiseNet::forward_async() {
+    Turn turn(*this);
     if (launches_ == 1 && getenv("CRA_DEVICE_GRAPH") == nullptr) {
         forward_on(stream_);
         HIP_CHECK(hipGetLastError());
@@ -1272,6 +1325,7 @@ void RiseNet::forward_async() {
 // whenever the host was busy collecting).  With the whole forward in one to three kernels there is nothing left for a graph to save,
 // so these paths put the kernels straight into the stream: one queue, in-order, no host in the loop.
 void RiseNet::launch_forward_in_stream() {
+    Turn turn(*this);
     if (launches_ <= 4 && getenv("CRA_LANE_GRAPH") == nullptr) forward_on(stream_);
     else HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
 }
@@ -1306,6 +1360,8 @@ void RiseNet::submit(const float* in_planes, float* value, float* probs, float* 
         io.value = value;
         io.probs = probs;
         io.aux = (d_aux_ && aux) ? aux : nullptr;
+        // no turn-taking here: these kernels write 5 MB of probabilities per batch across PCIe from inside the forward, and two users
+        // in flight hide each other's write phase only when their kernels interleave (measured: 770k against 585k evals/s)
         if (fp16_) enqueue<half_t>(stream_, &io); else enqueue<float>(stream_, &io);
         return;
     }

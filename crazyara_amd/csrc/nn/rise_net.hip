@@ -1282,17 +1282,20 @@ ForwardTurns g_turns[64];     // per device
 struct RiseNet::Turn {
     ForwardTurns* t = nullptr;
     hipStream_t s = nullptr;
+    std::unique_lock<std::mutex> lk;       // a member: released also when the constructor throws
     Turn(RiseNet& n) {
         static const bool off = getenv("CRA_NO_FORWARD_TURNS") != nullptr;      // development: A/B
         if (off || n.device_ < 0 || n.device_ >= 64 || int(n.design_.batch) * 4 < n.cu_count_ * 3) return;
-        t = &g_turns[n.device_];
-        s = n.stream_;
-        t->mu.lock();
-        if (!t->made) {
-            for (hipEvent_t& e : t->ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            t->made = true;
+        ForwardTurns* ft = &g_turns[n.device_];
+        lk = std::unique_lock<std::mutex>(ft->mu);
+        if (!ft->made) {
+            HIP_CHECK(hipSetDevice(n.device_));
+            for (hipEvent_t& e : ft->ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ft->made = true;
         }
-        if (t->any && t->last_stream != s) HIP_CHECK(hipStreamWaitEvent(s, t->ev[t->last], 0));
+        if (ft->any && ft->last_stream != n.stream_) HIP_CHECK(hipStreamWaitEvent(n.stream_, ft->ev[ft->last], 0));
+        t = ft;
+        s = n.stream_;
     }
     ~Turn() {
         if (!t) return;
@@ -1302,7 +1305,6 @@ struct RiseNet::Turn {
             t->last_stream = s;
             t->any = true;
         }
-        t->mu.unlock();
     }
 };
 

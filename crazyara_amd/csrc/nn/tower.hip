@@ -96,14 +96,19 @@ __device__ __forceinline__ uint32_t pack_relu_cvt(float a, float b) {
 // A weight stream of one wave, read with raw buffer loads: resource descriptor + byte position live in SGPRs, the lane offset is
 // one constant VGPR, so a refill costs no vector address arithmetic (a flat load needs a 64-bit add per 4 KiB of stream).
 struct WStream {
-    __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t pos;        // byte position of the window start (wave-uniform)
+    // The window start is a wave-uniform POINTER that moves once per phase, and every load of a phase addresses "window start + a
+    // compile-time constant": the constant goes into the instruction's immediate / a loop-invariant SGPR.  (With a running byte
+    // position in the soffset operand each of the 32 loads of an interval cost an s_add of its own -- 8 % of the matrix wave's
+    // instructions, and a wave pays ~5 cycles of issue time for any instruction.)
+    const char* base;    // window start (wave-uniform)
     uint32_t lane_off;   // lane * 16
     __device__ __forceinline__ half8 frag_at(int q) const {      // fragment q positions after the window start
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, pos + uint32_t(q) * 1024u, 0);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0x7fffffff, 0x00020000);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, q * 1024, 0);
         return __builtin_bit_cast(half8, v);
     }
+    __device__ __forceinline__ void advance(int bytes) { base += bytes; }
 };
 
 // D(32x32) += A(32 x 16) * B(16 x 32): lane l holds A[row l%32][k = (l/32)*8 + j], B[k = (l/32)*8 + j][col l%32], j = 0..7;
@@ -114,6 +119,25 @@ __device__ __forceinline__ void mma32(const half8& a, const half8& b, f32x16& c)
 #else
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 #endif
+}
+
+// the first MFMA of an accumulator: C = the bias tuple, result in the accumulator's own registers
+__device__ __forceinline__ f32x16 mma32_init(const half8& a, const half8& b, const f32x16& c) {
+#ifdef TW_DEV_NO_MFMA
+    f32x16 r = c;
+    asm volatile("" : "+v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+// BN1 bias of a lane's 16 rows (bias stream: [lane/32][element v]) as one 16-register tuple
+__device__ __forceinline__ void load_bias(f32x16& bias, const float* __restrict__ bp) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 q = reinterpret_cast<const f32x4*>(bp)[i];
+        bias[4 * i + 0] = q[0]; bias[4 * i + 1] = q[1]; bias[4 * i + 2] = q[2]; bias[4 * i + 3] = q[3];
+    }
 }
 
 // ---- Precision fp8 ----
@@ -128,6 +152,9 @@ __device__ __forceinline__ i32x8 cat32(const half8& lo, const half8& hi) {
 }
 __device__ __forceinline__ void mma64(const i32x8& a, const i32x8& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma64_init(const i32x8& a, const i32x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
 }
 // four packed f16 pairs -> 8 e4m3 bytes (round to nearest even; the kernel runs with MODE.FP16_OVFL = 1, so values beyond +-448 clamp
 // instead of becoming NaN): v_cvt_scalef32_pk_fp8_f16 fills one 16-bit half of its destination per instruction
@@ -146,14 +173,10 @@ __device__ __forceinline__ uint2 f16x8_to_e4m3(const uint4& h) { return uint2{f1
 // the next phase of its kind, whatever the other kind does in between (the first and last intervals of a block run only one of them).
 //   expand : 4 k-steps x {1 fragment, 2 square tiles}: 8 MFMAs          project: 2 k-steps x {2 row tiles, 2 square tiles}: 8 MFMAs
 constexpr int TW_WIN8 = 8;
-__device__ __forceinline__ void expand_phase8(f32x16 (&accE)[2], half8 (&win)[TW_WIN8], WStream& sp, f32x4 (&bias)[4],
+__device__ __forceinline__ void expand_phase8(f32x16 (&accE)[2], half8 (&win)[TW_WIN8], WStream& sp, f32x16& bias,
                                               const float* __restrict__& bp, const char* xqr) {
     constexpr int BASE = 0;
     using frag = half8;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) accE[ct][v] = bias[v >> 2][v & 3];
     frag ba[4], bb[4];                               // [square tile][16-byte half] of a k-step
 #pragma unroll
     for (int i = 0; i < 4; ++i) ba[i] = *reinterpret_cast<const frag*>(xqr + (i >> 1) * 32 * TW_XQROW + (i & 1) * 16);
@@ -167,18 +190,24 @@ __device__ __forceinline__ void expand_phase8(f32x16 (&accE)[2], half8 (&win)[TW
         }
         __builtin_amdgcn_sched_barrier(0);
         const i32x8 a = cat32(win[BASE + 2 * s], win[BASE + 2 * s + 1]);
-        mma64(a, cat32(cur[0], cur[1]), accE[0]);
-        mma64(a, cat32(cur[2], cur[3]), accE[1]);
+        // youngest operands first, the bias as the first MFMA's C operand (see matrix_interval)
+        if (s == 0) {
+            accE[1] = mma64_init(a, cat32(cur[2], cur[3]), bias);
+            accE[0] = mma64_init(a, cat32(cur[0], cur[1]), bias);
+        } else {
+            mma64(a, cat32(cur[2], cur[3]), accE[1]);
+            mma64(a, cat32(cur[0], cur[1]), accE[0]);
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) win[BASE + 2 * s + e] = sp.frag_at(2 * s + e + TW_WIN8);
         if (s == 0) {
+            asm volatile("" ::"v"(bias));            // the tuple outlives both MFMAs (see matrix_interval)
             bp += 32;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bias[i] = reinterpret_cast<const f32x4*>(bp)[i];
+            load_bias(bias, bp);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    sp.pos += 8 * 1024;
+    sp.advance(8 * 1024);
 }
 template <typename EPI>
 __device__ __forceinline__ void project_phase8(f32x16 (&accP)[2][2], half8 (&win)[TW_WIN8], WStream& sp, const char* t2r, const EPI& epilogue) {
@@ -197,17 +226,17 @@ __device__ __forceinline__ void project_phase8(f32x16 (&accP)[2][2], half8 (&win
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 1; rt >= 0; --rt) {            // youngest operands first (see matrix_interval)
             const i32x8 a = cat32(win[BASE + s * 4 + rt * 2], win[BASE + s * 4 + rt * 2 + 1]);
-            mma64(a, cat32(cur[0], cur[1]), accP[rt][0]);
             mma64(a, cat32(cur[2], cur[3]), accP[rt][1]);
+            mma64(a, cat32(cur[0], cur[1]), accP[rt][0]);
         }
         epilogue(s);
 #pragma unroll
         for (int e = 0; e < 4; ++e) win[BASE + s * 4 + e] = sp.frag_at(s * 4 + e + TW_WIN8);
         __builtin_amdgcn_sched_barrier(0);
     }
-    sp.pos += 8 * 1024;
+    sp.advance(8 * 1024);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -217,7 +246,7 @@ __device__ __forceinline__ void project_phase8(f32x16 (&accP)[2][2], half8 (&win
 //   A step = 4 MFMAs + the LDS reads of the NEXT step's B fragments + 2 refills; nothing is scheduled across step boundaries.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&accP)[2][2], half8 (&win)[TW_WIN], WStream& sp,
-                                                f32x4 (&bias)[4], const float* __restrict__& bp, const half_t* xsr, half_t* t1w,
+                                                f32x16& bias, const float* __restrict__& bp, const half_t* xsr, half_t* t1w,
                                                 const half_t* t2r) {
     using frag = half8;
     constexpr int XROW = TW_XROW, T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
@@ -226,10 +255,6 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
     // the start of the phase that uses it, the wave would have to drain every weight load in flight (vmcnt counts in order) and
     // then sit out an L2 round trip before its first MFMA, once per interval.
     if (do_e) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) accE[ct][v] = bias[v >> 2][v & 3];      // accumulate on top of the BN1 bias
         frag bfa[4], bfb[4];                         // [k-step parity within the step][square tile]
 #pragma unroll
         for (int i = 0; i < 4; ++i) bfa[i] = *reinterpret_cast<const frag*>(xsr + (i & 1) * 32 * XROW + (i >> 1) * 16);
@@ -252,20 +277,27 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
             // Without this fence the scheduler sinks them below the MFMAs to save registers -- to the end of the step, directly in
             // front of the MFMAs that consume them -- and every step waits out a full LDS latency (measured: 179 cycles per step).
             __builtin_amdgcn_sched_barrier(0);
+            // The step's MFMAs run YOUNGEST OPERANDS FIRST (i = 3 .. 0): loads and LDS reads return in order, so the one s_waitcnt in
+            // front of the first MFMA covers the other three (oldest first, every MFMA had a wait of its own: 4 per step, and a wave
+            // pays issue time for a wait like for any instruction).  The first MFMA of a tile takes the BN1 bias as its C operand
+            // (a register tuple of its own: accumulators that START as a copy of the bias cost 24 moves per interval).
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mma32(win[(s * 2 + (i >> 1)) % TW_DEPTH], cur[i], accE[i & 1]);
+            for (int i = 3; i >= 0; --i) {
+                if (s == 0 && i >= 2) accE[i & 1] = mma32_init(win[(s * 2 + (i >> 1)) % TW_DEPTH], cur[i], bias);
+                else mma32(win[(s * 2 + (i >> 1)) % TW_DEPTH], cur[i], accE[i & 1]);
+            }
 #ifndef TW_DEV_NO_WLOAD
 #pragma unroll
             for (int e = 0; e < 2; ++e) win[(s * 2 + e) % TW_DEPTH] = sp.frag_at(s * 2 + e + TW_DEPTH);
 #endif
             if (s == 0) {                            // the first MFMAs have read the bias registers: fetch the next phase's
+                asm volatile("" ::"v"(bias));        // (the tuple outlives both MFMAs, or the second one accumulates in place in it)
                 bp += 32;                            // (the stream is closed with one chunk of zeros, rise_net.hip)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bias[i] = reinterpret_cast<const f32x4*>(bp)[i];
+                load_bias(bias, bp);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        sp.pos += 16 * 1024;
+        sp.advance(16 * 1024);
     }
     // expand epilogue for square tile ct: BN1 bias + ReLU -> f16.  A lane's 16 rows are 16 consecutive K positions of the tile
     // the project GEMM reads as its B operand (position p <-> row (p%4) + 8*((p%16)/4) + 4*(p/16), kernels.h: tower_k_channel),
@@ -292,11 +324,11 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
             }
             __builtin_amdgcn_sched_barrier(0);       // as in the expand loop: next step's reads are issued before this step's MFMAs
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 1; kk >= 0; --kk)          // youngest operands first (see the expand loop)
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+                for (int rt = 1; rt >= 0; --rt)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) mma32(win[((s * 2 + kk) * 2 + rt) % TW_DEPTH], cur[kk * 2 + ct], accP[rt][ct]);
+                    for (int ct = 1; ct >= 0; --ct) mma32(win[((s * 2 + kk) * 2 + rt) % TW_DEPTH], cur[kk * 2 + ct], accP[rt][ct]);
             if (do_e && s < 2) expand_epilogue(s);
 #ifndef TW_DEV_NO_WLOAD
 #pragma unroll
@@ -304,7 +336,7 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
-        sp.pos += 16 * 1024;
+        sp.advance(16 * 1024);
     } else if (do_e) {
         mfma_retire(accE[0], accE[1]);               // the last expand MFMAs retire before the asm epilogue reads them (device_utils.h)
         expand_epilogue(0);
@@ -314,7 +346,7 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
 
 // the same interval in Precision fp8 (window halves: [0, 8) expand stream, [8, 16) project stream)
 __device__ __forceinline__ void matrix_interval8(bool do_e, bool do_p, f32x16 (&accP)[2][2], half8 (&winE)[TW_WIN8], half8 (&winP)[TW_WIN8],
-                                                 WStream& spE, WStream& spP, f32x4 (&bias)[4], const float* __restrict__& bp, const char* xqr,
+                                                 WStream& spE, WStream& spP, f32x16& bias, const float* __restrict__& bp, const char* xqr,
                                                  half_t* t1w, const char* t2r) {
     constexpr int T1ROW = TW_T1ROW;
     f32x16 accE[2];
@@ -746,19 +778,17 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
 #endif
         // open the weight stream first: its window flies while the board tile comes in
         WStream sp;
-        sp.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.wstream)) + size_t(w) * a.wstream_wave_frags * 1024, 0, 0x7fffffff, 0x00020000);
-        sp.pos = 0;
+        sp.base = reinterpret_cast<const char*>(a.wstream) + size_t(w) * a.wstream_wave_frags * 1024;
         sp.lane_off = lane * 16;
         const float* bp = a.bstream + size_t(w) * a.bstream_wave_floats + lh * 16;
         // Precision fp8: two streams (expand loads first, project loads from a.wstream_e_frags on), a window of 8 loads each
         WStream spP = sp;
-        spP.pos = uint32_t(a.wstream_e_frags) * 1024u;
+        spP.base += size_t(a.wstream_e_frags) * 1024u;
         frag win[TW_WIN];
 #pragma unroll
         for (int q = 0; q < (F8 ? TW_WIN : TW_DEPTH); ++q) win[q] = (F8 && q >= TW_WIN8) ? spP.frag_at(q - TW_WIN8) : sp.frag_at(q);
-        f32x4 bias[4];                               // BN1 bias of the next expand phase (matrix_interval)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias[i] = reinterpret_cast<const f32x4*>(bp)[i];
+        f32x16 bias;                                 // BN1 bias of the next expand phase (matrix_interval): the first MFMAs' C operand
+        load_bias(bias, bp);
         load_board();
         __syncthreads();
         TW_STAMP();

@@ -81,8 +81,9 @@ constexpr int kTowerWindow = 16;
 struct TowerBlockDesc {
     const float* b3;      // [256] BN3 bias (Precision fp8: divided by s3)
     const float* s3;      // Precision fp8: [256] power-of-two scale of the project weights per cout (y = x + s3 * acc); else nullptr
-    const void* se_w1;    // f16: ca_se W1 transposed [256][128]; eca_se centre tap transposed [256][256]; or nullptr
-    const void* se_w2;    // f16: ca_se W2 transposed [128][256]
+    const void* se_w1;    // f16 pairs in thread order (rise_net.hip: pack_se_threads; tower.hip: se_phase): ca_se W1, or the eca_se centre-tap
+                          // matrix in two halves; or nullptr
+    const void* se_w2;    // f16 pairs in thread order: ca_se W2
     const float* se_b;    // eca_se bias [256]
     int cop_pad;          // multiple of 128
     int ks;               // depthwise kernel size: 3 or 5

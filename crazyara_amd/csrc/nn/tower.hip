@@ -31,7 +31,7 @@
 #if !defined(CRA_DEVELOPMENT) && (defined(TW_DEV_NO_MFMA) || defined(TW_DEV_HALF_E_READS) || defined(TW_DEV_NO_WLOAD) || \
     defined(TW_DEV_VEC_NO_LDS) || defined(TW_DEV_VEC_NO_VALU) || defined(TW_DEV_VEC_TILES) || defined(TW_DEV_PRIO) || \
     defined(TW_DEV_NO_MATRIX) || defined(TW_DEV_NO_VECTOR) || defined(TW_DEV_NO_WARMUP) || defined(TW_TRACE_SE) || defined(TW_TRACE_BARRIERS) || \
-    defined(TW_DEV_STAGGER) || defined(TW_DEV_DEPTH))
+    defined(TW_DEV_STAGGER) || defined(TW_DEV_DEPTH) || defined(TW_DEV_NO_BARRIER))
 #error "TW_DEV_* / TW_TRACE_* are development switches (some compute wrong results): build with -DCRA_DEVELOPMENT, see scripts/build_variant.sh"
 #endif
 
@@ -833,7 +833,11 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                     bwait += __builtin_amdgcn_s_memtime() - w0;
                 } else
 #endif
+#ifndef TW_DEV_NO_BARRIER
                     __syncthreads();
+#else
+                    __builtin_amdgcn_sched_barrier(0);   // development (wrong results): the interval barrier's cost
+#endif
             }
             if (trc) { trc[trn++] = __builtin_amdgcn_s_memtime() - bwait; bwait = 0; }   // loop end stamp minus barrier waits = busy time
             TW_STAMP();
@@ -1028,7 +1032,11 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                     bwait += __builtin_amdgcn_s_memtime() - w0;
                 } else
 #endif
+#ifndef TW_DEV_NO_BARRIER
                     __syncthreads();
+#else
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             if (trc) { trc[trn++] = __builtin_amdgcn_s_memtime() - bwait; bwait = 0; }
             TW_STAMP();

@@ -145,11 +145,21 @@ int mi_search_tree_fen(mi_search* sp, int tree, char* fen, int cap) {
     });
 }
 
+int mi_search_stop(mi_search* sp) {
+    if (!sp) { cra_set_error("null search"); return 1; }
+    sp->pool->request_stop();          // one atomic store: safe beside a running mi_search_run of another thread
+    return 0;
+}
+
 int mi_search_run(mi_search* sp, unsigned simulations, unsigned nodes, int threads, mi_search_stats* stats) {
+    return mi_search_run_timed(sp, simulations, nodes, 0, threads, stats);
+}
+
+int mi_search_run_timed(mi_search* sp, unsigned simulations, unsigned nodes, unsigned movetime_ms, int threads, mi_search_stats* stats) {
     if (!sp) { cra_set_error("null search"); return 1; }
     return cra_guard([&] {
         SearchStats st;
-        sp->pool->run(simulations, nodes, threads, &st);
+        sp->pool->run(simulations, nodes, threads, &st, movetime_ms);
         if (stats) {
             stats->nodes = st.nodes;
             stats->nn_evals = st.nn_evals;

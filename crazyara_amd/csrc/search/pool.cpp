@@ -299,8 +299,9 @@ void SearchPool::evaluate_roots(uint64_t* evals, uint64_t* batches) {
     *evals += todo.size();
 }
 
-void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats) {
-    if (!simulations && !nodes) throw std::invalid_argument("run needs a simulations or a nodes limit");
+void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats, uint32_t movetime_ms) {
+    if (!simulations && !nodes && !movetime_ms) throw std::invalid_argument("run needs a simulations, a nodes or a movetime limit");
+    halt_.store(false, std::memory_order_relaxed);
     if (!workers_ || workers_->threads() != std::max(1, threads)) workers_.reset(new WorkerPool(std::max(1, threads)));
     WorkerPool& workers = *workers_;
     SearchStats st;
@@ -326,9 +327,19 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     // simulations / nodes limits are ABSOLUTE on the root's counters, as SearchThread::nodes_limits_ok has them
     // (searchthread.cpp:326-331: rootNode->get_visits() < simulations, get_node_count() < nodes): visits inherited through tree
     // reuse count towards the limit of the next go
+    const auto deadline = t0 + std::chrono::milliseconds(movetime_ms);
+    auto halted = [&]() {                                           // request_stop() or the movetime: every tree is "done"
+        if (halt_.load(std::memory_order_relaxed)) return true;
+        if (movetime_ms && std::chrono::steady_clock::now() >= deadline) {
+            halt_.store(true, std::memory_order_relaxed);
+            return true;
+        }
+        return false;
+    };
     auto done = [&](int item) {                                     // per item = per (tree, collector): the tree's verdict
         const int id = items_[size_t(item)].tree;
         if (is_paused(id) || single_move[id]) return true;
+        if (halted()) return true;
         const Tree& t = *trees_[id];
         if (t.root().terminal || t.root_solved()) return true;      // is_root_node_unsolved(), searchthread.cpp:333-340
         return tree_done(t, simulations, nodes);

@@ -86,7 +86,13 @@ public:
     int add_position(const chess::Position& pos);
     // runs until every tree reached `simulations` root visits (if > 0) and/or `nodes` counted nodes (if > 0)
     // (SearchThread::nodes_limits_ok, searchthread.cpp:326-331)
-    void run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats);
+    // movetime_ms > 0: the searches also end when that much wall time has passed since the start of the call (the timer of
+    // ThreadManager::stop_search_based_on_limits, threadmanager.cpp:69-97, without its early-stopping heuristics); at least one of the
+    // three limits must be given.  Batches in flight are applied before the call returns: the trees are consistent.
+    void run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats, uint32_t movetime_ms = 0);
+    // from any thread while run() is executing: the searches end as if their limits had been reached (SearchThread::stop,
+    // searchthread.cpp:109-112; MCTSAgent::stop, mctsagent.cpp:364-373).  Without a run in progress it does nothing.
+    void request_stop() { halt_.store(true, std::memory_order_relaxed); }
     // evaluates the roots that have no network result yet (new games, restarted trees) through the first lane, as run() does first;
     // a game loop reads the raw policy of fresh positions from the root priors this leaves (RawNetAgent::evaluate_board_state)
     void evaluate_new_roots(SearchStats* stats) { SearchStats st; evaluate_roots(&st.nn_evals, &st.batches); if (stats) *stats = st; }
@@ -131,6 +137,7 @@ private:
     std::vector<Item> items_;
     int shared_k_ = 0;
     int adaptive_cap_ = 0;
+    std::atomic<bool> halt_{false};      // request_stop(); cleared when a run starts
     SearchSettings s_;
     int layout_;
     std::vector<std::unique_ptr<Tree>> trees_;

@@ -63,11 +63,18 @@ class SearchPool:
             raise ValueError(_capi.last_error())
         return t
 
-    def run(self, simulations: int = 0, nodes: int = 0, threads: int = 1) -> SearchStatsC:
+    def run(self, simulations: int = 0, nodes: int = 0, threads: int = 1, movetime_ms: int = 0) -> SearchStatsC:
+        """Searches every active tree to its limits (absolute on the root's counters, SearchThread::nodes_limits_ok); movetime_ms > 0
+        also ends the searches that long after the start of the call (SearchLimits::movetime).  ctypes releases the GIL for the
+        call, so `stop()` may come from another Python thread."""
         st = SearchStatsC()
-        if self._lib.mi_search_run(self._h, simulations, nodes, threads, C.byref(st)):
+        if self._lib.mi_search_run_timed(self._h, simulations, nodes, movetime_ms, threads, C.byref(st)):
             raise RuntimeError(_capi.last_error())
         return st
+
+    def stop(self) -> None:
+        """Ends a `run` that is executing in another thread (SearchThread::stop); no effect otherwise."""
+        self._lib.mi_search_stop(self._h)
 
     def root_children(self, tree: int):
         cap = 512

@@ -224,6 +224,14 @@ int mi_search_add_position(mi_search* sp, const char* fen, int is_chess960, cons
 int mi_search_apply_move(mi_search* sp, int tree, const char* uci, int* kept);
 int mi_search_tree_fen(mi_search* sp, int tree, char* fen, int cap);   /* FEN of the tree's root position */
 int mi_search_run(mi_search* sp, unsigned simulations, unsigned nodes, int threads, mi_search_stats* stats);
+/* the same with a wall-clock limit (SearchLimits::movetime; the timer half of ThreadManager::stop_search_based_on_limits,
+ * engine/src/manager/threadmanager.cpp:69-97): the searches also end movetime_ms after the start of the call.  At least one of the
+ * three limits must be non-zero; batches in flight are applied before the call returns. */
+int mi_search_run_timed(mi_search* sp, unsigned simulations, unsigned nodes, unsigned movetime_ms, int threads, mi_search_stats* stats);
+/* from ANOTHER thread while mi_search_run / mi_search_run_timed is executing: the searches end as if their limits had been reached
+ * (SearchThread::stop, engine/src/searchthread.cpp:109-112; MCTSAgent::stop, agents/mctsagent.cpp:364-373); the run call returns with
+ * consistent trees.  Without a run in progress it does nothing (a later run is not affected). */
+int mi_search_stop(mi_search* sp);
 /* root statistics of one tree, children in the node's (prior-sorted) order: returns number of expanded children */
 int mi_search_root_children(mi_search* sp, int tree, int cap, uint32_t* moves, uint32_t* visits, float* q, float* priors);
 int mi_search_tree_info(mi_search* sp, int tree, unsigned* root_visits, unsigned* node_count, unsigned* allocated_nodes, float* root_value);

@@ -722,3 +722,76 @@ def test_shared_tree_finds_the_mate_with_the_solver(hip_lib):
     assert pool.root_solved(t)["node_type"] == mo.NT_WIN and pool.best_move(t) == "a1a8"
     _check_tree_invariants(pool.tree_dump(t), allow_virtual=True)       # a proven root ends the search with batches still applied
     pool.close()
+
+
+def _slow_eval(nbp, delay):
+    import time
+
+    def fn(descs):
+        time.sleep(delay)
+        out = [_pseudo_net(key_from_desc(d), nbp) for d in descs]
+        return [o[0] for o in out], [o[1] for o in out]
+    return fn
+
+
+@pytest.mark.parametrize("lanes_threads", [(1, 1), (2, 3)])
+def test_movetime_ends_the_search_with_consistent_trees(hip_lib, lanes_threads):
+    """SearchLimits::movetime (the timer of ThreadManager::stop_search_based_on_limits, threadmanager.cpp:69-97): a run with no
+    simulation / node limit returns a little after the movetime, batches in flight applied -- no virtual loss left, visit counters
+    add up -- and the trees carry on in the next run."""
+    import time
+    nbp = NB_POLICY[0]
+    st = search.default_settings(mode=0, version_major=1, batch_size=8)
+    pool = search.SearchPool(st, eval_fn=_slow_eval(nbp, 0.002), fn_batch=16, fn_nb_policy=nbp)
+    ids = [pool.add_position("", False, "crazyhouse"), pool.add_position("r1bqkbnr/pppp1ppp/2n5/4p3/4P3/5N2/PPPP1PPP/RNBQKB1R[] w KQkq - 2 3", False, "crazyhouse")]
+    t0 = time.time()
+    stats = pool.run(movetime_ms=250, threads=lanes_threads[1])
+    dt = time.time() - t0
+    assert 0.24 <= dt < 1.5, dt
+    assert stats.simulations > 20
+    visits = []
+    for t in ids:
+        _, rv = _check_tree_invariants(pool.tree_dump(t))
+        visits.append(rv)
+        assert rv == pool.tree_info(t)["root_visits"] - 1 or rv == pool.tree_info(t)["root_visits"]
+    stats2 = pool.run(simulations=max(visits) + 64, threads=lanes_threads[1])      # the kept trees search on
+    assert all(pool.tree_info(t)["root_visits"] >= max(visits) + 64 for t in ids)
+    # the stricter of movetime and the simulation limit wins
+    pool.reset_position(ids[0]); pool.reset_position(ids[1], "r1bqkbnr/pppp1ppp/2n5/4p3/4P3/5N2/PPPP1PPP/RNBQKB1R[] w KQkq - 2 3")
+    t0 = time.time()
+    pool.run(simulations=40, movetime_ms=20000, threads=lanes_threads[1])
+    assert time.time() - t0 < 5.0
+    with pytest.raises(RuntimeError, match="limit"):
+        pool.run(threads=1)
+    pool.close()
+
+
+def test_stop_from_another_thread_ends_the_run(hip_lib):
+    """SearchThread::stop / MCTSAgent::stop (searchthread.cpp:109-112, mctsagent.cpp:364-373): `go infinite` is a run with a limit far
+    away and a stop from the UCI thread.  The run returns promptly with consistent trees; a stop without a run is a no-op."""
+    import threading
+    import time
+    nbp = NB_POLICY[0]
+    st = search.default_settings(mode=0, version_major=1, batch_size=8)
+    pool = search.SearchPool(st, eval_fn=_slow_eval(nbp, 0.002), fn_batch=8, fn_nb_policy=nbp)
+    t = pool.add_position("", False, "crazyhouse")
+    pool.stop()                                                        # nothing running: ignored, the next run is a full one
+    s0 = pool.run(simulations=64, threads=1)
+    assert pool.tree_info(t)["root_visits"] >= 64 and s0.simulations >= 60
+    result = {}
+
+    def go():
+        result["stats"] = pool.run(simulations=50_000_000, threads=2)
+    th = threading.Thread(target=go)
+    t0 = time.time()
+    th.start()
+    time.sleep(0.3)
+    pool.stop()
+    th.join(timeout=10)
+    assert not th.is_alive() and time.time() - t0 < 3.0
+    assert result["stats"].simulations > 20
+    _check_tree_invariants(pool.tree_dump(t))
+    assert pool.best_move(t)
+    pool.apply_move(t, pool.best_move(t))                              # no batch left in flight
+    pool.run(simulations=32, threads=1)
+    pool.close()

@@ -225,6 +225,27 @@ int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, floa
     return n;
 }
 
+int mi_search_pv(mi_search* sp, int tree, char* uci_line, int cap, int* centipawns, int* moves_to_mate) {
+    int n = -1;
+    if (!sp || !uci_line) { cra_set_error("null argument"); return n; }
+    cra_guard([&] {
+        Tree& t = sp->pool->tree(tree);
+        std::vector<chess::Move> pv;
+        t.principal_variation(pv, moves_to_mate, centipawns);
+        chess::Position pos = t.root_position();
+        std::string line;
+        for (chess::Move m : pv) {
+            if (!line.empty()) line += ' ';
+            line += pos.move_to_uci(m);
+            pos.do_move(m);
+        }
+        if (int(line.size()) + 1 > cap) throw std::invalid_argument("pv buffer too small");
+        std::memcpy(uci_line, line.c_str(), line.size() + 1);
+        n = int(pv.size());
+    });
+    return n;
+}
+
 long mi_search_tree_dump(mi_search* sp, int tree, uint32_t* out, long cap) {
     long n = -1;
     if (!sp) { cra_set_error("null search"); return n; }

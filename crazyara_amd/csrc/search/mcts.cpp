@@ -750,6 +750,51 @@ float Tree::eval_best_move_q() const {
     return best_move_q(best_move_index());
 }
 
+// value_to_centipawn (evalinfo.cpp:103-112): logarithmic pseudo-centipawns, base VALUE_TO_CENTI_PARAM (constants.h:89-93: 1.4 in
+// MODE_CHESS builds, 1.2 otherwise); float arithmetic as there
+static int value_to_centipawn(float value, int mode) {
+    const int sg = (value > 0.f) - (value < 0.f);
+    if (std::abs(value) >= 1) return sg * 9999;
+    const float base = mode == MODE_CHESS ? 1.4f : 1.2f;
+    return int(-(sg * std::log(1.0f - std::abs(value)) / std::log(base)) * 100.0f);
+}
+
+void Tree::principal_variation(std::vector<chess::Move>& pv, int* moves_to_mate, int* centipawns) const {
+    pv.clear();
+    int mate = 0, cp = 0;
+    const Node& r = nodes_[0];
+    if (!r.terminal && !r.actions.empty()) {
+        if (r.actions.size() == 1 && r.visit_sum == 0) {            // single move, blank root (evalinfo.cpp:226-232)
+            pv.push_back(r.actions[0]);
+            cp = value_to_centipawn(eval_best_move_q(), s_.mode);
+        } else if (r.has_data) {
+            const int b = best_move_index();
+            if (b >= 0) {
+                pv.push_back(r.actions[size_t(b)]);
+                float q = Q_INIT;
+                bool scored = true;
+                const int32_t first = b < int(r.child.size()) ? r.child[size_t(b)] : -1;
+                if (first >= 0) {
+                    int32_t cur = first;
+                    while (cur >= 0 && nodes_[size_t(cur)].has_data && !nodes_[size_t(cur)].terminal) {      // get_principal_variation
+                        const Node& n = nodes_[size_t(cur)];
+                        const int i = best_action_index_fast(n);
+                        pv.push_back(n.actions[size_t(i)]);
+                        cur = i < int(n.child.size()) ? n.child[size_t(i)] : -1;
+                    }
+                    const Node& next = nodes_[size_t(first)];
+                    q = best_move_q(b);
+                    if (next.has_data && next.node_type == NT_LOSS) { mate = (int(pv.size()) + 1) / 2; scored = false; }
+                    else if (next.has_data && next.node_type == NT_WIN) { mate = -(int(pv.size()) + 1) / 2; scored = false; }
+                }
+                if (scored) cp = value_to_centipawn(q, s_.mode);
+            }
+        }
+    }
+    if (moves_to_mate) *moves_to_mate = mate;
+    if (centipawns) *centipawns = cp;
+}
+
 void Tree::end_search() {                                       // tail of evaluate_board_state (mctsagent.cpp:337-339) over update_eval_info
     const Node& r = nodes_[0];
     if (r.terminal || r.actions.empty()) return;

@@ -207,6 +207,12 @@ public:
     // EvalInfo::bestMoveQ[0] as update_eval_info leaves it (evalinfo.cpp:184-243): best_move_q of the chosen child, or the root's own
     // value for a single-move root that was not searched
     float eval_best_move_q() const;
+    // EvalInfo::pv[0], movesToMate[0], centipawns[0] as update_eval_info / set_eval_for_single_pv leave them (evalinfo.cpp:120-243):
+    // the best root move, then Node::get_principal_variation (node.cpp:1111-1121) below it -- mating child, else the child that delays a
+    // proven loss longest, else the most-visited child, while the node has been selected at least once and is not terminal.
+    // moves_to_mate: +(len + 1) / 2 if the position after the best move is a proven LOSS for the side to move there, -(len + 1) / 2
+    // (C++ integer division) if a proven WIN, else 0; centipawns = value_to_centipawn(bestMoveQ) (evalinfo.cpp:103-112; 0 beside a mate)
+    void principal_variation(std::vector<chess::Move>& pv, int* moves_to_mate, int* centipawns) const;
     // Whole tree as a flat word list (inspection / parity tests; the reference's counterpart is MCTSAgent::export_search_tree,
     // mctsagent.cpp:420-448): depth-first preorder over the expanded children, one record per node that owns NodeData:
     // [n_expanded, visit_sum, real_visits, free_visits, node_type, end_in_ply, terminal, bits(value)] then per expanded child

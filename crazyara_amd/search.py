@@ -112,6 +112,15 @@ class SearchPool:
             raise RuntimeError(_capi.last_error())
         return np.array(buf[:n], np.float64), float(q.value)
 
+    def pv(self, tree: int) -> dict:
+        """EvalInfo pv[0] / centipawns[0] / movesToMate[0] of the tree (what a UCI front end prints)."""
+        buf = C.create_string_buffer(4096)
+        cp, mate = C.c_int(), C.c_int()
+        n = self._lib.mi_search_pv(self._h, tree, buf, 4096, C.byref(cp), C.byref(mate))
+        if n < 0:
+            raise RuntimeError(_capi.last_error())
+        return dict(pv=buf.value.decode().split(), centipawns=cp.value, moves_to_mate=mate.value)
+
     def tree_dump(self, tree: int) -> np.ndarray:
         """The whole tree as the flat word list of mi_search_tree_dump (depth-first records of every selected node)."""
         cap = 1 << 22

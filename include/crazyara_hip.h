@@ -242,6 +242,11 @@ int mi_search_best_move(mi_search* sp, int tree, char* uci, int cap);
 /* the whole Node::get_mcts_policy vector of the root (EvalInfo::policyProbSmall, one entry per expanded child in the order of
  * mi_search_root_children) and the Q value of the best move (EvalInfo::bestMoveQ); returns the number of entries or -1 */
 int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, float* best_move_q);
+/* what a UCI front end prints behind "info ... score" and "pv": EvalInfo::pv[0] as space-separated UCI moves (best root move, then
+ * Node::get_principal_variation, node.cpp:1111-1121), centipawns[0] (value_to_centipawn of bestMoveQ, evalinfo.cpp:103-112) and
+ * movesToMate[0] (non-zero when the position behind the best move is proven; centipawns is 0 then) as update_eval_info leaves them
+ * (evalinfo.cpp:195-260).  Returns the number of moves in the line, -1 on error (buffer too small). */
+int mi_search_pv(mi_search* sp, int tree, char* uci_line, int cap, int* centipawns, int* moves_to_mate);
 /* One tree, many collectors: the reference runs `Threads` SearchThreads on ONE tree (engine/src/uci/crazyara.cpp:555-561,734;
  * searchthread.cpp:403-416; per-node mutex node.h:100) -- the case of a single UCI `go`.  k >= 1 gives every tree k collectors in
  * EVERY lane: a lane's batch is the concatenation of its collectors' mini-batches (batch / (k * trees) leaves each), collected in

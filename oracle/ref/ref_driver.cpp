@@ -320,6 +320,25 @@ int ref_agent_eval(ref_agent* a, int cap, double* policy, char* best_uci, int uc
     return n;
 }
 
+// EvalInfo::pv[0] as a space-separated UCI line, centipawns[0], movesToMate[0] of the last go (update_eval_info, evalinfo.cpp:195-260)
+int ref_agent_pv(ref_agent* a, char* line, int cap, int* centipawns, int* moves_to_mate) {
+    const EvalInfo& e = a->eval;
+    std::string out;
+    int n = 0;
+    if (!e.pv.empty()) {
+        for (Action m : e.pv[0]) {
+            if (!out.empty()) out += ' ';
+            out += StateConstants::action_to_uci(m, a->state->is_chess960());
+            ++n;
+        }
+    }
+    if (int(out.size()) + 1 > cap) return -1;
+    std::memcpy(line, out.c_str(), out.size() + 1);
+    *centipawns = e.centipawns.empty() ? 0 : e.centipawns[0];
+    *moves_to_mate = e.movesToMate.empty() ? 0 : e.movesToMate[0];
+    return n;
+}
+
 // Whole-tree dump in depth-first preorder over the expanded children, one record per PLAYOUT node (a node that was selected at
 // least once: it owns NodeData):  [n_expanded, visit_sum, real_visits, free_visits, node_type, end_in_ply, terminal,
 // float bits of value, then per expanded child: move, visits, virtual-loss counter, float bits of Q, float bits of prior,

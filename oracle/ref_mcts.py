@@ -58,6 +58,8 @@ def _declare(lib):
                                             C.POINTER(C.c_float)]
     lib.ref_agent_root_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint)] * 2 + [C.POINTER(C.c_float)] + [C.POINTER(C.c_int)] * 3 + \
         [C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+    lib.ref_agent_pv.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.ref_agent_pv.restype = C.c_int
     lib.ref_agent_eval.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int, C.POINTER(C.c_float),
                                    C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     lib.ref_agent_tree_dump.restype = C.c_long
@@ -233,6 +235,14 @@ class RefAgent:
             raise RuntimeError("eval info")
         return dict(policy=np.array(pol[:n], np.float64), best_move=uci.value.decode(), best_q=float(q.value), nodes=nodes.value,
                     sel_depth=sel.value)
+
+    def pv(self) -> dict:
+        buf = C.create_string_buffer(4096)
+        cp, mate = C.c_int(), C.c_int()
+        n = self._lib.ref_agent_pv(self._h, buf, 4096, C.byref(cp), C.byref(mate))
+        if n < 0:
+            raise RuntimeError("pv")
+        return dict(pv=buf.value.decode().split(), centipawns=cp.value, moves_to_mate=mate.value)
 
     def tree_dump(self) -> np.ndarray:
         cap = 1 << 22

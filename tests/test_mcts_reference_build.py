@@ -54,7 +54,7 @@ def _normalise_ref_dump(words: np.ndarray) -> np.ndarray:
     return w
 
 
-def _compare(pool, t, ra, check_best=True):
+def _compare(pool, t, ra, check_best=True, centi_base=None):
     moves, visits, q, pri = pool.root_children(t)
     m2, v2, q2, p2 = ra.root_children()
     assert moves == m2                                         # same moves in the same (prior-sorted) order
@@ -76,6 +76,17 @@ def _compare(pool, t, ra, check_best=True):
         assert np.array_equal(pol, ev["policy"][:len(pol)]) and not ev["policy"][len(pol):].any()   # EvalInfo pads unexpanded moves with 0
         assert np.float32(best_q) == np.float32(ev["best_q"]) or rinfo["node_type"] != REF_UNSOLVED
         assert ev["nodes"] == info["node_count"]
+        # what the UCI front end prints: principal variation, pseudo-centipawns, mate distance (EvalInfo pv / centipawns / movesToMate)
+        mine, ref = pool.pv(t), ra.pv()
+        assert mine["pv"] == ref["pv"] and mine["moves_to_mate"] == ref["moves_to_mate"]
+        if centi_base is None:
+            assert mine["centipawns"] == ref["centipawns"]
+        elif ref["moves_to_mate"] == 0:
+            # VALUE_TO_CENTI_PARAM is a compile-time constant of the build flavour (constants.h:89-93: 1.4 with MODE_CHESS, else 1.2) and
+            # oracle/_ref is one binary (1.2): for the chess flavour the reference's formula is re-applied to ITS bestMoveQ with 1.4
+            q = np.float32(ev["best_q"])
+            want = int(np.sign(q)) * 9999 if abs(q) >= 1 else int(np.float32(-(np.float32(np.sign(q)) * np.log(np.float32(1) - np.abs(q)) / np.log(np.float32(centi_base))) * np.float32(100)))
+            assert mine["centipawns"] == want, (mine["centipawns"], want, ref["centipawns"])
 
 
 CASES = [
@@ -111,7 +122,7 @@ def test_product_tree_equals_reference_build(hip_lib, variant, is960, fen, mode,
     ra.set_position(fen, is960, variant)
     ra.go(simulations=sims)
     assert plog == rlog                                         # same batches: root alone, then the same leaf counts per mini-batch
-    _compare(pool, t, ra)
+    _compare(pool, t, ra, centi_base=1.4 if mode == 1 else None)
     pool.close()
     ra.close()
 
@@ -135,7 +146,7 @@ def test_solver_equals_reference_build(hip_lib, variant, fen, mode, verdict, bes
     ra = ref_mcts.RefAgent(st, _evaluator(nbp), nbp)
     ra.set_position(fen, False, variant)
     ra.go(simulations=sims)
-    _compare(pool, t, ra)
+    _compare(pool, t, ra, centi_base=1.4 if mode == 1 else None)
     rinfo = ra.root_info()
     if solver and verdict is not None:
         assert rinfo["node_type"] == verdict[0] and (verdict[1] is None or rinfo["end_in_ply"] == verdict[1])
@@ -163,7 +174,7 @@ def test_dirichlet_noise_equals_reference_build(hip_lib, variant, fen, mode, eps
     for go in range(2):                                         # the second go re-noises the kept root ("reuse the full tree")
         pool.run(simulations=sims, threads=1)
         ra.go(simulations=sims)
-        _compare(pool, t, ra)
+        _compare(pool, t, ra, centi_base=1.4 if mode == 1 else None)
         assert len(ra.root_children()[0]) == ra.root_info()["n_legal"]
     pool.close()
     ra.close()
@@ -186,7 +197,7 @@ def test_epsilon_exploration_equals_reference_build(hip_lib, variant, fen, mode,
     ra = ref_mcts.RefAgent(st, _evaluator(nbp), nbp)
     ra.set_position(fen, False, variant)
     ra.go(simulations=sims)
-    _compare(pool, t, ra)
+    _compare(pool, t, ra, centi_base=1.4 if mode == 1 else None)
     pool.close()
     ra.close()
 
@@ -209,7 +220,7 @@ def test_tree_reuse_across_played_moves_equals_reference_build(hip_lib, variant,
     for ply in range(8):
         pool.run(simulations=sims, threads=1)
         ra.go(simulations=sims)
-        _compare(pool, t, ra)
+        _compare(pool, t, ra, centi_base=1.4 if mode == 1 else None)
         mv = ra.eval_info()["best_move"]
         kept_any |= pool.apply_move(t, mv)
         ra.apply_move(mv)

@@ -4,6 +4,7 @@
 //       crazyara_amd/csrc/search/mcts.cpp crazyara_amd/csrc/chess/{position,policy,planes_host}.cpp \
 //       crazyara_amd/csrc/nn/{onnx_import,netfile}.cpp -o /tmp/sanitize_host && /tmp/sanitize_host [onnx files...]
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <random>
 #include <string>
@@ -85,6 +86,18 @@ static void run_search(const char* variant, int mode, int major, int minor, bool
         }
         nodes += tree.node_count();
         const int best = tree.best_move_index();
+        {
+            std::vector<chess::Move> pv;
+            int mate = 0, cp = 0;
+            tree.principal_variation(pv, &mate, &cp);                    // EvalInfo pv / centipawns / movesToMate
+            chess::Position walk = tree.root_position();
+            for (chess::Move m : pv) {                                    // every move of the line is legal where it is played
+                bool ok = false;
+                for (chess::Move l : walk.legal_moves()) ok = ok || l == m;
+                if (!ok) { std::printf("illegal move in the principal variation\n"); std::exit(1); }
+                walk.do_move(m);
+            }
+        }
         if (best < 0) break;
         tree.apply_move(tree.root().actions[size_t(best)]);
     }

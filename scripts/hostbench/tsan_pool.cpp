@@ -4,7 +4,9 @@
 //       crazyara_amd/csrc/search/{pool,mcts}.cpp crazyara_amd/csrc/chess/{position,policy,planes_host}.cpp -lpthread -o /tmp/tsan_pool
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <random>
+#include <thread>
 
 #include "../../crazyara_amd/csrc/nn/rise_net.h"
 #include "../../crazyara_amd/csrc/search/pool.h"
@@ -81,6 +83,26 @@ int main() {
             if (sum != visit_sum) { std::printf("visit counts do not add up\n"); return 1; }
             i += 8 + 6 * m;
         }
+    }
+    // movetime and an asynchronous stop (halt_ is an atomic read by the driving thread inside run, written by the stopping thread),
+    // then the principal variation of the kept tree
+    {
+        SearchPool timed(s, make_callback_evaluator(eval, nullptr, 64, 5184), make_callback_evaluator(eval, nullptr, 64, 5184));
+        for (int i = 0; i < 4; ++i) timed.add_position(p);
+        timed.run(0, 0, 4, &st, 150);
+        std::printf("movetime 150 ms: %llu simulations in %.3f s\n", (unsigned long long)st.simulations, st.seconds);
+        std::thread stopper([&] {
+            std::this_thread::sleep_for(std::chrono::milliseconds(120));
+            timed.request_stop();
+        });
+        timed.run(50000000, 0, 4, &st);
+        stopper.join();
+        std::printf("stopped: %llu simulations in %.3f s\n", (unsigned long long)st.simulations, st.seconds);
+        std::vector<chess::Move> pv;
+        int mate = 0, cp = 0;
+        timed.tree(0).principal_variation(pv, &mate, &cp);
+        std::printf("pv length %zu, cp %d, mate %d\n", pv.size(), cp, mate);
+        if (pv.empty() || st.seconds > 5.0) return 1;
     }
     std::printf("done\n");
     return 0;

@@ -225,6 +225,25 @@ int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, floa
     return n;
 }
 
+int mi_time_for_move(const mi_go_limits* l, int side, int move_number) {
+    if (!l || side < 0 || side > 1) { cra_set_error("mi_time_for_move: null limits or side not 0 / 1"); return -1; }
+    constexpr int EXPECTED_GAME_LENGTH = 38, THRESH_MOVE = 35, PROP_MOVES_TO_GO = 14, BUFFER_FACTOR = 30;   // constants.h:94-98
+    constexpr float INCREMENT_FACTOR = 0.7f;
+    if (l->infinite) return 0;
+    if ((l->nodes != 0 || l->simulations != 0 || l->depth != 0) && l->movetime == 0) return 0;
+    const int safe_remaining = std::max(l->time[side] - l->move_overhead * BUFFER_FACTOR, 1);              // get_safe_remaining_time
+    auto constant_movetime = [&](int moves_to_go) { return int(safe_remaining / moves_to_go + INCREMENT_FACTOR * l->inc[side]); };
+    int cur;
+    if (l->movetime != 0) cur = int(l->movetime);
+    else if (l->movestogo != 0) cur = constant_movetime(l->movestogo);
+    else if (l->time[side] != 0) cur = move_number < THRESH_MOVE ? constant_movetime(EXPECTED_GAME_LENGTH - move_number) : constant_movetime(PROP_MOVES_TO_GO);
+    else cur = 1000;                                                                                        // "No limit specification given"
+    cur -= l->move_overhead;
+    if (cur <= 0) cur = l->move_overhead * 2;
+    if (l->time[side] != 0) return std::min(safe_remaining, cur);
+    return cur;
+}
+
 int mi_search_pv(mi_search* sp, int tree, char* uci_line, int cap, int* centipawns, int* moves_to_mate) {
     int n = -1;
     if (!sp || !uci_line) { cra_set_error("null argument"); return n; }

@@ -18,6 +18,23 @@ class SearchSettingsC(C.Structure):
                 ("dirichlet_epsilon", C.c_float), ("dirichlet_alpha", C.c_float), ("version_minor", C.c_int)]
 
 
+class GoLimitsC(C.Structure):
+    """mi_go_limits: the SearchLimits fields TimeManager::get_time_for_move reads."""
+    _fields_ = [("movetime", C.c_longlong), ("nodes", C.c_ulonglong), ("simulations", C.c_ulonglong), ("movestogo", C.c_int),
+                ("depth", C.c_int), ("time", C.c_int * 2), ("inc", C.c_int * 2), ("move_overhead", C.c_int), ("infinite", C.c_int)]
+
+
+def time_for_move(side: int, move_number: int, *, movetime=0, nodes=0, simulations=0, movestogo=0, depth=0, wtime=0, btime=0,
+                  winc=0, binc=0, move_overhead=20, infinite=False) -> int:
+    """Milliseconds a `go` with these clock arguments searches (TimeManager::get_time_for_move); 0 = no time limit."""
+    lim = GoLimitsC(movetime, nodes, simulations, movestogo, depth, (C.c_int * 2)(wtime, btime), (C.c_int * 2)(winc, binc),
+                    move_overhead, int(infinite))
+    r = _capi.load().mi_time_for_move(C.byref(lim), side, move_number)
+    if r < 0:
+        raise ValueError(_capi.last_error())
+    return r
+
+
 class SearchStatsC(C.Structure):
     _fields_ = [("nodes", C.c_ulonglong), ("nn_evals", C.c_ulonglong), ("batches", C.c_ulonglong), ("simulations", C.c_ulonglong),
                 ("seconds", C.c_double), ("depth_avg", C.c_double), ("depth_max", C.c_uint)]

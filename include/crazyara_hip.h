@@ -242,6 +242,20 @@ int mi_search_best_move(mi_search* sp, int tree, char* uci, int cap);
 /* the whole Node::get_mcts_policy vector of the root (EvalInfo::policyProbSmall, one entry per expanded child in the order of
  * mi_search_root_children) and the Q value of the best move (EvalInfo::bestMoveQ); returns the number of entries or -1 */
 int mi_search_root_policy(mi_search* sp, int tree, int cap, double* policy, float* best_move_q);
+/* The movetime of a `go` with clock arguments: TimeManager::get_time_for_move (engine/src/manager/timemanager.cpp:50-103) with the
+ * constants of constants.h:94-98 (expected game length 38, proportional system from move 35 on with 14 moves to go, increment
+ * factor 0.7, safety buffer 30 x Move_Overhead) and randomMoveFactor 0.  side: 0 White, 1 Black; move_number = plies of the root / 2
+ * (mctsagent.cpp:349).  Returns milliseconds; 0 = no time limit (infinite, or node / simulation / depth limits without movetime).
+ * Feed the result to mi_search_run_timed. */
+typedef struct mi_go_limits {              /* SearchLimits (engine/src/agents/config/searchlimits.h:32-61), the fields the function reads */
+    long long movetime;
+    unsigned long long nodes, simulations;
+    int movestogo, depth;
+    int time[2], inc[2];                   /* wtime / btime, winc / binc in ms */
+    int move_overhead;                     /* Move_Overhead (optionsuci.cpp:135, default 20) */
+    int infinite;
+} mi_go_limits;
+int mi_time_for_move(const mi_go_limits* limits, int side, int move_number);
 /* what a UCI front end prints behind "info ... score" and "pv": EvalInfo::pv[0] as space-separated UCI moves (best root move, then
  * Node::get_principal_variation, node.cpp:1111-1121), centipawns[0] (value_to_centipawn of bestMoveQ, evalinfo.cpp:103-112) and
  * movesToMate[0] (non-zero when the position behind the best move is proven; centipawns is 0 then) as update_eval_info leaves them

@@ -320,6 +320,22 @@ int ref_agent_eval(ref_agent* a, int cap, double* policy, char* best_uci, int uc
     return n;
 }
 
+// TimeManager::get_time_for_move on a SearchLimits filled from the product's mi_go_limits (randomMoveFactor 0)
+int ref_time_for_move(const mi_go_limits* l, int side, int move_number) {
+    SearchLimits lim;
+    lim.movetime = l->movetime;
+    lim.nodes = l->nodes;
+    lim.simulations = l->simulations;
+    lim.movestogo = l->movestogo;
+    lim.depth = l->depth;
+    lim.time[0] = l->time[0]; lim.time[1] = l->time[1];
+    lim.inc[0] = l->inc[0]; lim.inc[1] = l->inc[1];
+    lim.moveOverhead = l->move_overhead;
+    lim.infinite = l->infinite != 0;
+    TimeManager tm(0.0f);
+    return tm.get_time_for_move(&lim, SideToMove(side), move_number);
+}
+
 // EvalInfo::pv[0] as a space-separated UCI line, centipawns[0], movesToMate[0] of the last go (update_eval_info, evalinfo.cpp:195-260)
 int ref_agent_pv(ref_agent* a, char* line, int cap, int* centipawns, int* moves_to_mate) {
     const EvalInfo& e = a->eval;

@@ -58,6 +58,8 @@ def _declare(lib):
                                             C.POINTER(C.c_float)]
     lib.ref_agent_root_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint)] * 2 + [C.POINTER(C.c_float)] + [C.POINTER(C.c_int)] * 3 + \
         [C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+    lib.ref_time_for_move.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.ref_time_for_move.restype = C.c_int
     lib.ref_agent_pv.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.ref_agent_pv.restype = C.c_int
     lib.ref_agent_eval.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int, C.POINTER(C.c_float),
@@ -267,3 +269,8 @@ class RefAgent:
             self.close()
         except Exception:
             pass
+
+
+def time_for_move(limits, side: int, move_number: int) -> int:
+    """TimeManager::get_time_for_move of the reference build on a crazyara_amd.search.GoLimitsC."""
+    return load().ref_time_for_move(C.byref(limits), side, move_number)

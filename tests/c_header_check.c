@@ -26,3 +26,5 @@ void* (*const cra_p_host_alloc)(size_t) = mi_host_alloc;
 int (*const cra_p_search_run)(mi_search*, unsigned, unsigned, int, mi_search_stats*) = mi_search_run;
 mi_selfplay* (*const cra_p_selfplay_create)(mi_search*, mi_search*, const mi_selfplay_settings*, int, const char*, int, mi_traindata*) = mi_selfplay_create;
 int (*const cra_p_selfplay_play)(mi_selfplay*, int, int) = mi_selfplay_play;
+size_t cra_sizeof_go_limits(void) { return sizeof(mi_go_limits); }
+size_t cra_offsetof_go_limits_move_overhead(void) { return offsetof(mi_go_limits, move_overhead); }

@@ -41,7 +41,7 @@ def test_header_is_plain_c99_and_struct_layouts_match_the_python_binding(hip_lib
     chk = C.CDLL(so)
     for fn in ("cra_sizeof_search_settings", "cra_sizeof_search_stats", "cra_offsetof_settings_virtual_offset_strength",
                "cra_offsetof_settings_version_minor", "cra_offsetof_stats_depth_max", "cra_sizeof_selfplay_settings", "cra_sizeof_selfplay_stats",
-               "cra_offsetof_selfplay_seed", "cra_offsetof_selfplay_stats_wins"):
+               "cra_offsetof_selfplay_seed", "cra_offsetof_selfplay_stats_wins", "cra_sizeof_go_limits", "cra_offsetof_go_limits_move_overhead"):
         getattr(chk, fn).restype = C.c_size_t
     assert chk.cra_sizeof_search_settings() == C.sizeof(search.SearchSettingsC)
     assert chk.cra_sizeof_search_stats() == C.sizeof(search.SearchStatsC)
@@ -53,6 +53,8 @@ def test_header_is_plain_c99_and_struct_layouts_match_the_python_binding(hip_lib
     assert chk.cra_sizeof_selfplay_stats() == C.sizeof(selfplay.SelfPlayStatsC)
     assert chk.cra_offsetof_selfplay_seed() == selfplay.SelfPlaySettingsC.seed.offset
     assert chk.cra_offsetof_selfplay_stats_wins() == selfplay.SelfPlayStatsC.wins.offset
+    assert chk.cra_sizeof_go_limits() == C.sizeof(search.GoLimitsC)
+    assert chk.cra_offsetof_go_limits_move_overhead() == search.GoLimitsC.move_overhead.offset
 
 
 def test_integration_md_quotes_the_compiled_shim_verbatim():

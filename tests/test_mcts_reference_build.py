@@ -275,3 +275,39 @@ def test_reference_helpers_worked_examples():
         tp = p.copy()
         hip.mi_policy_apply_temperature(dp(tp), n, temp)
         assert np.allclose(tp, selfplay.apply_temperature(p.copy(), temp), rtol=1e-14, atol=0)
+
+
+def test_time_for_move_equals_the_reference_time_manager():
+    """mi_time_for_move against TimeManager::get_time_for_move of the reference build (timemanager.cpp:50-103, randomMoveFactor 0) over
+    the branches of the function: infinite, node / simulation / depth limits with and without movetime, movestogo, sudden death before
+    and after the proportional threshold (move 35), increments, tiny clocks, no limits at all (1000 ms), both sides."""
+    rng = np.random.default_rng(5)
+    cases = []
+    for _ in range(400):
+        kind = rng.integers(0, 7)
+        kw = dict(move_overhead=int(rng.choice([0, 20, 100, 500])))
+        if kind == 0:
+            kw.update(infinite=True, wtime=int(rng.integers(0, 60000)))
+        elif kind == 1:
+            kw.update(movetime=int(rng.integers(1, 5000)))
+        elif kind == 2:
+            kw.update(nodes=int(rng.integers(0, 2) * 800), simulations=int(rng.integers(0, 2) * 400), depth=int(rng.integers(0, 2) * 5),
+                      movetime=int(rng.integers(0, 2) * rng.integers(1, 3000)), wtime=int(rng.integers(0, 2) * 30000), btime=20000)
+        elif kind == 3:
+            kw.update(movestogo=int(rng.integers(1, 40)), wtime=int(rng.integers(1, 300000)), btime=int(rng.integers(1, 300000)),
+                      winc=int(rng.integers(0, 3000)), binc=int(rng.integers(0, 3000)))
+        elif kind == 4:
+            kw.update(wtime=int(rng.integers(1, 600000)), btime=int(rng.integers(1, 600000)), winc=int(rng.integers(0, 5000)),
+                      binc=int(rng.integers(0, 5000)))
+        elif kind == 5:
+            kw.update(wtime=int(rng.integers(1, 700)), btime=int(rng.integers(1, 700)))               # less than the safety buffer
+        cases.append((int(rng.integers(0, 2)), int(rng.integers(0, 80)), kw))
+    for side, move_number, kw in cases:
+        lim = search.GoLimitsC(kw.get("movetime", 0), kw.get("nodes", 0), kw.get("simulations", 0), kw.get("movestogo", 0), kw.get("depth", 0),
+                               (search.C.c_int * 2)(kw.get("wtime", 0), kw.get("btime", 0)), (search.C.c_int * 2)(kw.get("winc", 0), kw.get("binc", 0)),
+                               kw.get("move_overhead", 20), int(kw.get("infinite", False)))
+        want = ref_mcts.time_for_move(lim, side, move_number)
+        got = search.time_for_move(side, move_number, **kw)
+        assert got == want, (side, move_number, kw, got, want)
+    with pytest.raises(ValueError):
+        search.time_for_move(2, 0)

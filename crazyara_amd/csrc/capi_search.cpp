@@ -265,6 +265,28 @@ int mi_search_pv(mi_search* sp, int tree, char* uci_line, int cap, int* centipaw
     return n;
 }
 
+int mi_search_pv_multi(mi_search* sp, int tree, int idx, int multipv, char* uci_line, int cap, int* centipawns, int* moves_to_mate, float* best_move_q) {
+    int n = -1;
+    if (!sp || !uci_line) { cra_set_error("null argument"); return n; }
+    cra_guard([&] {
+        Tree& t = sp->pool->tree(tree);
+        std::vector<chess::Move> pv;
+        if (cap > 0) uci_line[0] = 0;
+        if (!t.principal_variation_multi(idx, multipv, pv, moves_to_mate, centipawns, best_move_q)) { n = 0; return; }
+        chess::Position pos = t.root_position();
+        std::string line;
+        for (chess::Move m : pv) {
+            if (!line.empty()) line += ' ';
+            line += pos.move_to_uci(m);
+            pos.do_move(m);
+        }
+        if (int(line.size()) + 1 > cap) throw std::invalid_argument("pv buffer too small");
+        std::memcpy(uci_line, line.c_str(), line.size() + 1);
+        n = int(pv.size());
+    });
+    return n;
+}
+
 long mi_search_tree_dump(mi_search* sp, int tree, uint32_t* out, long cap) {
     long n = -1;
     if (!sp) { cra_set_error("null search"); return n; }

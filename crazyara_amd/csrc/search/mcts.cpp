@@ -759,40 +759,80 @@ static int value_to_centipawn(float value, int mode) {
     return int(-(sg * std::log(1.0f - std::abs(value)) / std::log(base)) * 100.0f);
 }
 
-void Tree::principal_variation(std::vector<chess::Move>& pv, int* moves_to_mate, int* centipawns) const {
-    pv.clear();
-    int mate = 0, cp = 0;
+// set_eval_for_single_pv (evalinfo.cpp:120-182) for root child b: the line below it, bestMoveQ, mate distance, centipawns
+void Tree::line_below_root_child(int b, std::vector<chess::Move>& pv, int* moves_to_mate, int* centipawns, float* q_out) const {
     const Node& r = nodes_[0];
-    if (!r.terminal && !r.actions.empty()) {
-        if (r.actions.size() == 1 && r.visit_sum == 0) {            // single move, blank root (evalinfo.cpp:226-232)
-            pv.push_back(r.actions[0]);
-            cp = value_to_centipawn(eval_best_move_q(), s_.mode);
-        } else if (r.has_data) {
-            const int b = best_move_index();
-            if (b >= 0) {
-                pv.push_back(r.actions[size_t(b)]);
-                float q = Q_INIT;
-                bool scored = true;
-                const int32_t first = b < int(r.child.size()) ? r.child[size_t(b)] : -1;
-                if (first >= 0) {
-                    int32_t cur = first;
-                    while (cur >= 0 && nodes_[size_t(cur)].has_data && !nodes_[size_t(cur)].terminal) {      // get_principal_variation
-                        const Node& n = nodes_[size_t(cur)];
-                        const int i = best_action_index_fast(n);
-                        pv.push_back(n.actions[size_t(i)]);
-                        cur = i < int(n.child.size()) ? n.child[size_t(i)] : -1;
-                    }
-                    const Node& next = nodes_[size_t(first)];
-                    q = best_move_q(b);
-                    if (next.has_data && next.node_type == NT_LOSS) { mate = (int(pv.size()) + 1) / 2; scored = false; }
-                    else if (next.has_data && next.node_type == NT_WIN) { mate = -(int(pv.size()) + 1) / 2; scored = false; }
-                }
-                if (scored) cp = value_to_centipawn(q, s_.mode);
-            }
+    int mate = 0, cp = 0;
+    pv.push_back(r.actions[size_t(b)]);
+    float q = Q_INIT;
+    bool scored = true;
+    const int32_t first = b < int(r.child.size()) ? r.child[size_t(b)] : -1;
+    if (first >= 0) {
+        int32_t cur = first;
+        while (cur >= 0 && nodes_[size_t(cur)].has_data && !nodes_[size_t(cur)].terminal) {      // Node::get_principal_variation
+            const Node& n = nodes_[size_t(cur)];
+            const int i = best_action_index_fast(n);
+            pv.push_back(n.actions[size_t(i)]);
+            cur = i < int(n.child.size()) ? n.child[size_t(i)] : -1;
         }
+        const Node& next = nodes_[size_t(first)];
+        q = best_move_q(b);
+        if (next.has_data && next.node_type == NT_LOSS) { mate = (int(pv.size()) + 1) / 2; scored = false; }
+        else if (next.has_data && next.node_type == NT_WIN) { mate = -(int(pv.size()) + 1) / 2; scored = false; }
     }
+    if (scored) cp = value_to_centipawn(q, s_.mode);
     if (moves_to_mate) *moves_to_mate = mate;
     if (centipawns) *centipawns = cp;
+    if (q_out) *q_out = q;
+}
+
+void Tree::principal_variation(std::vector<chess::Move>& pv, int* moves_to_mate, int* centipawns) const {
+    pv.clear();
+    if (moves_to_mate) *moves_to_mate = 0;
+    if (centipawns) *centipawns = 0;
+    const Node& r = nodes_[0];
+    if (r.terminal || r.actions.empty()) return;
+    if (r.actions.size() == 1 && r.visit_sum == 0) {                // single move, blank root (evalinfo.cpp:226-232)
+        pv.push_back(r.actions[0]);
+        if (centipawns) *centipawns = value_to_centipawn(eval_best_move_q(), s_.mode);
+        return;
+    }
+    if (!r.has_data) return;
+    const int b = best_move_index();
+    if (b >= 0) line_below_root_child(b, pv, moves_to_mate, centipawns, nullptr);
+}
+
+bool Tree::principal_variation_multi(int idx, int multipv, std::vector<chess::Move>& pv, int* moves_to_mate, int* centipawns, float* q) const {
+    pv.clear();
+    if (moves_to_mate) *moves_to_mate = 0;
+    if (centipawns) *centipawns = 0;
+    if (q) *q = 0.f;
+    const Node& r = nodes_[0];
+    if (idx < 0 || multipv < 1 || r.terminal || r.actions.empty()) return false;
+    if (r.actions.size() == 1 && r.visit_sum == 0) {                // single move, blank root: only pv[0] is filled
+        if (idx != 0) return false;
+        pv.push_back(r.actions[0]);
+        const float v = eval_best_move_q();
+        if (centipawns) *centipawns = value_to_centipawn(v, s_.mode);
+        if (q) *q = v;
+        return true;
+    }
+    if (!r.has_data) return false;
+    const int max_idx = std::min(multipv, int(r.no_visit_idx));
+    if (idx >= max_idx) return false;
+    std::vector<double> pol;
+    const int best = best_move_index(&pol);
+    if (best < 0) return false;
+    int b = best;
+    if (idx > 0) {                                                   // sort_eval_lists: rank by the policy over ALL legal moves, as float
+        pol.resize(r.actions.size(), 0.0);
+        std::vector<int> order(r.actions.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = int(i);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return float(pol[size_t(x)]) > float(pol[size_t(y)]); });
+        b = order[size_t(idx)];
+    }
+    line_below_root_child(b, pv, moves_to_mate, centipawns, q);
+    return true;
 }
 
 void Tree::end_search() {                                       // tail of evaluate_board_state (mctsagent.cpp:337-339) over update_eval_info

@@ -213,6 +213,11 @@ public:
     // moves_to_mate: +(len + 1) / 2 if the position after the best move is a proven LOSS for the side to move there, -(len + 1) / 2
     // (C++ integer division) if a proven WIN, else 0; centipawns = value_to_centipawn(bestMoveQ) (evalinfo.cpp:103-112; 0 beside a mate)
     void principal_variation(std::vector<chess::Move>& pv, int* moves_to_mate, int* centipawns) const;
+    // line idx of a Multi_PV output: update_eval_info with searchSettings->multiPV = multipv (evalinfo.cpp:195-260).  Line 0 is the one
+    // above; line idx >= 1 starts with the root move of rank idx in the MCTS policy over ALL legal moves (sort_eval_lists,
+    // evalinfo.cpp:184-193: descending, compared as float; equal entries keep their root order here, the reference's std::sort leaves
+    // them unspecified).  Lines exist for idx < min(multipv, expanded root children); returns false beyond.  q = bestMoveQ[idx].
+    bool principal_variation_multi(int idx, int multipv, std::vector<chess::Move>& pv, int* moves_to_mate, int* centipawns, float* q) const;
     // Whole tree as a flat word list (inspection / parity tests; the reference's counterpart is MCTSAgent::export_search_tree,
     // mctsagent.cpp:420-448): depth-first preorder over the expanded children, one record per node that owns NodeData:
     // [n_expanded, visit_sum, real_visits, free_visits, node_type, end_in_ply, terminal, bits(value)] then per expanded child
@@ -244,6 +249,7 @@ private:
     void random_playout(Collector& col, int cur, int& child_idx);
     int select_enhanced_move(int cur, const chess::Position& pos);
     int best_action_index_fast(const Node& n) const;
+    void line_below_root_child(int b, std::vector<chess::Move>& pv, int* moves_to_mate, int* centipawns, float* q) const;
 
     SearchSettings s_;
     chess::Position root_pos_;

@@ -138,6 +138,20 @@ class SearchPool:
             raise RuntimeError(_capi.last_error())
         return dict(pv=buf.value.decode().split(), centipawns=cp.value, moves_to_mate=mate.value)
 
+    def pv_multi(self, tree: int, multipv: int) -> list:
+        """The lines of a Multi_PV output (EvalInfo pv / bestMoveQ / centipawns / movesToMate per line)."""
+        out = []
+        for idx in range(multipv):
+            buf = C.create_string_buffer(4096)
+            cp, mate, q = C.c_int(), C.c_int(), C.c_float()
+            n = self._lib.mi_search_pv_multi(self._h, tree, idx, multipv, buf, 4096, C.byref(cp), C.byref(mate), C.byref(q))
+            if n < 0:
+                raise RuntimeError(_capi.last_error())
+            if n == 0:
+                break
+            out.append(dict(pv=buf.value.decode().split(), centipawns=cp.value, moves_to_mate=mate.value, best_move_q=q.value))
+        return out
+
     def tree_dump(self, tree: int) -> np.ndarray:
         """The whole tree as the flat word list of mi_search_tree_dump (depth-first records of every selected node)."""
         cap = 1 << 22

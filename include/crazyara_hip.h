@@ -261,6 +261,11 @@ int mi_time_for_move(const mi_go_limits* limits, int side, int move_number);
  * movesToMate[0] (non-zero when the position behind the best move is proven; centipawns is 0 then) as update_eval_info leaves them
  * (evalinfo.cpp:195-260).  Returns the number of moves in the line, -1 on error (buffer too small). */
 int mi_search_pv(mi_search* sp, int tree, char* uci_line, int cap, int* centipawns, int* moves_to_mate);
+/* line idx (0-based) of a Multi_PV output with the UCI option set to multipv (update_eval_info, evalinfo.cpp:195-260; sort_eval_lists
+ * :184-193): line 0 = mi_search_pv; line idx >= 1 starts with the root move of rank idx in the MCTS policy (descending, compared as float;
+ * equal entries in root order -- the reference's std::sort leaves their order open).  best_move_q = EvalInfo::bestMoveQ[idx].  Returns
+ * the number of moves in the line, 0 when idx >= min(multipv, expanded root children), -1 on error. */
+int mi_search_pv_multi(mi_search* sp, int tree, int idx, int multipv, char* uci_line, int cap, int* centipawns, int* moves_to_mate, float* best_move_q);
 /* One tree, many collectors: the reference runs `Threads` SearchThreads on ONE tree (engine/src/uci/crazyara.cpp:555-561,734;
  * searchthread.cpp:403-416; per-node mutex node.h:100) -- the case of a single UCI `go`.  k >= 1 gives every tree k collectors in
  * EVERY lane: a lane's batch is the concatenation of its collectors' mini-batches (batch / (k * trees) leaves each), collected in

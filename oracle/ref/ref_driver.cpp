@@ -320,6 +320,27 @@ int ref_agent_eval(ref_agent* a, int cap, double* policy, char* best_uci, int uc
     return n;
 }
 
+// Multi_PV: the option only changes what update_eval_info writes (evalinfo.cpp:195-260)
+void ref_agent_set_multipv(ref_agent* a, int k) { a->ss.multiPV = uint16_t(k < 1 ? 1 : k); }
+// line idx of the last go's EvalInfo; returns the number of moves, 0 when the line does not exist
+int ref_agent_pv_at(ref_agent* a, int idx, char* line, int cap, int* centipawns, int* moves_to_mate, float* q) {
+    const EvalInfo& e = a->eval;
+    if (idx < 0 || size_t(idx) >= e.pv.size() || e.pv[size_t(idx)].empty()) return 0;
+    std::string out;
+    int n = 0;
+    for (Action m : e.pv[size_t(idx)]) {
+        if (!out.empty()) out += ' ';
+        out += StateConstants::action_to_uci(m, a->state->is_chess960());
+        ++n;
+    }
+    if (int(out.size()) + 1 > cap) return -1;
+    std::memcpy(line, out.c_str(), out.size() + 1);
+    *centipawns = e.centipawns[size_t(idx)];
+    *moves_to_mate = e.movesToMate[size_t(idx)];
+    *q = e.bestMoveQ[size_t(idx)];
+    return n;
+}
+
 // TimeManager::get_time_for_move on a SearchLimits filled from the product's mi_go_limits (randomMoveFactor 0)
 int ref_time_for_move(const mi_go_limits* l, int side, int move_number) {
     SearchLimits lim;

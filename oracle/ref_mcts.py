@@ -60,6 +60,10 @@ def _declare(lib):
         [C.POINTER(C.c_uint), C.POINTER(C.c_int)]
     lib.ref_time_for_move.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.ref_time_for_move.restype = C.c_int
+    lib.ref_agent_set_multipv.argtypes = [C.c_void_p, C.c_int]
+    lib.ref_agent_set_multipv.restype = None
+    lib.ref_agent_pv_at.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    lib.ref_agent_pv_at.restype = C.c_int
     lib.ref_agent_pv.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.ref_agent_pv.restype = C.c_int
     lib.ref_agent_eval.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_int, C.POINTER(C.c_float),
@@ -237,6 +241,20 @@ class RefAgent:
             raise RuntimeError("eval info")
         return dict(policy=np.array(pol[:n], np.float64), best_move=uci.value.decode(), best_q=float(q.value), nodes=nodes.value,
                     sel_depth=sel.value)
+
+    def set_multipv(self, k: int) -> None:
+        self._lib.ref_agent_set_multipv(self._h, k)
+
+    def pv_multi(self, multipv: int) -> list:
+        out = []
+        for idx in range(multipv):
+            buf = C.create_string_buffer(4096)
+            cp, mate, q = C.c_int(), C.c_int(), C.c_float()
+            n = self._lib.ref_agent_pv_at(self._h, idx, buf, 4096, C.byref(cp), C.byref(mate), C.byref(q))
+            if n <= 0:
+                break
+            out.append(dict(pv=buf.value.decode().split(), centipawns=cp.value, moves_to_mate=mate.value, best_move_q=q.value))
+        return out
 
     def pv(self) -> dict:
         buf = C.create_string_buffer(4096)

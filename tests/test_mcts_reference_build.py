@@ -311,3 +311,42 @@ def test_time_for_move_equals_the_reference_time_manager():
         assert got == want, (side, move_number, kw, got, want)
     with pytest.raises(ValueError):
         search.time_for_move(2, 0)
+
+
+@pytest.mark.parametrize("variant,is960,fen,mode,sims", [
+    ("crazyhouse", False, "", 0, 400),
+    ("crazyhouse", False, "4R2b/1N3rkb/1p2P1pp/p2P4/2P1P3/8/PP4Q1/3R3K[QRBBNNNPPPPpp] w - - 2 53", 0, 300),     # proven lines among the top moves
+    ("chess", False, "r3k2r/pppq1ppp/2npbn2/2b1p3/2B1P3/2NPBN2/PPPQ1PPP/R3K2R b KQkq - 4 8", 1, 300),
+    ("3check", False, "1r4k1/1p2bp1p/3p2p1/PprPp2n/1R2PPq1/3Q4/1P1B1NPP/5RK1 b - - 1+1 2 22", 2, 300),
+])
+def test_multipv_lines_equal_the_reference_build(hip_lib, variant, is960, fen, mode, sims):
+    """Multi_PV = 4: the lines update_eval_info writes (root move of rank idx in the MCTS policy, Node::get_principal_variation below it,
+    bestMoveQ / centipawns / movesToMate per line), product against the reference build.  Lines whose policy entry ties with a neighbour's
+    are left out of the comparison (the reference orders them with an unstable std::sort)."""
+    nbp = NB_POLICY[mode]
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, batch_size=8)
+    pool = search.SearchPool(st, eval_fn=_evaluator(nbp), fn_batch=8, fn_nb_policy=nbp)
+    t = pool.add_position(fen, is960, variant)
+    pool.run(simulations=sims, threads=1)
+    ra = ref_mcts.RefAgent(st, _evaluator(nbp), nbp)
+    ra.set_position(fen, is960, variant)
+    ra.set_multipv(4)
+    ra.go(simulations=sims)
+    mine, ref = pool.pv_multi(t, 4), ra.pv_multi(4)
+    assert len(mine) == len(ref) >= 2
+    pol, _ = pool.root_policy(t)
+    ranked = np.sort(np.asarray(pol, np.float32))[::-1]
+    compared = 0
+    for idx, (a, b) in enumerate(zip(mine, ref)):
+        tie = idx > 0 and ((idx + 1 < len(ranked) and ranked[idx] == ranked[idx + 1]) or ranked[idx] == ranked[idx - 1])
+        if tie:
+            continue
+        assert a["pv"] == b["pv"] and a["moves_to_mate"] == b["moves_to_mate"], (idx, a, b)
+        assert np.float32(a["best_move_q"]) == np.float32(b["best_move_q"]), (idx, a, b)
+        if mode != 1 or b["moves_to_mate"] != 0:
+            assert a["centipawns"] == b["centipawns"]                    # (the chess flavour's constant: see _compare)
+        compared += 1
+    assert compared >= 2
+    assert mine[0]["pv"] == pool.pv(t)["pv"]                              # line 0 is the single-PV line
+    assert pool.pv_multi(t, 1) == mine[:1]
+    pool.close()

@@ -110,6 +110,11 @@ int mi_net_device_buffers(mi_net* net, float** d_planes, float** d_value, float*
     if (d_aux) *d_aux = net->net.d_aux();
     return 0;
 }
+int mi_net_keep_logits(mi_net* net, int on) {
+    if (!net) { g_err = "null net"; return 1; }
+    net->net.keep_logits(on != 0);
+    return 0;
+}
 int mi_net_forward_device(mi_net* net) {
     if (!net) { g_err = "null net"; return 1; }
     return guard([&] { net->net.forward_async(); });

@@ -9,7 +9,8 @@
 //            square or the zero row); result -> f16 tile P1 in LDS.  Wave 0 also runs the value head's 1x1 conv (8 couts).
 //   phase 2  policy conv 3x3 256->P (P <= 96): the 144 (tap, k-step) units are dealt 18 per wave, each wave accumulates all
 //            P x 64 partial logits of its units; the 8 partial sets are summed through LDS, one row tile at a time.
-//   phase 3  softmax over the P*64 logits in LDS; logits and probabilities go to HBM once.
+//   phase 3  softmax over the P*64 logits in LDS; the probabilities go to HBM once (the logits too, on request; a search lane takes
+//            only the gathered priors of its legal moves).
 //   phase 4  value head: FC(512->256)+ReLU -> FC(256->1) -> tanh, or the WDLP outputs.
 // The board tile, P1 and the logits never leave the CU; HBM traffic per board is 32 KB in and 2 * P*256 B + 4 B out.
 #include "kernels.h"
@@ -271,8 +272,8 @@ __device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds
     {
         const int n4 = a.cp * 16;                    // float4 units
         const f32x4* lg4 = reinterpret_cast<const f32x4*>(logit);
-        f32x4* lo = reinterpret_cast<f32x4*>(a.logits + size_t(b) * n4 * 4);
-        f32x4* po = reinterpret_cast<f32x4*>(a.probs + size_t(b) * n4 * 4);
+        f32x4* lo = a.logits ? reinterpret_cast<f32x4*>(a.logits + size_t(b) * n4 * 4) : nullptr;
+        f32x4* po = a.probs ? reinterpret_cast<f32x4*>(a.probs + size_t(b) * n4 * 4) : nullptr;
         float m = -INFINITY;
         for (int i = tid; i < n4; i += 512) {
             const f32x4 x = lg4[i];
@@ -286,10 +287,16 @@ __device__ __forceinline__ void head_body(const HeadArgs& a, const bool x_in_lds
         }
         sum = block_reduce_512(sum, red, false);
         const float c = m + logf(sum);               // exp(x - (max + log(sum))) as apply_softmax(), neuralnetapi.cpp:241-260
-        for (int i = tid; i < n4; i += 512) {
-            const f32x4 x = lg4[i];
-            lo[i] = x;
-            po[i] = f32x4{__expf(x[0] - c), __expf(x[1] - c), __expf(x[2] - c), __expf(x[3] - c)};
+        // policy_out itself (pre-softmax) leaves the CU only when somebody asked for it (mi_net_keep_logits: parity tests), and a search
+        // lane that takes the gathered priors below needs neither vector: 2 x 20.7 KB per board that nobody reads
+        if (a.probs != nullptr) {
+            for (int i = tid; i < n4; i += 512) {
+                const f32x4 x = lg4[i];
+                if (a.logits != nullptr) lo[i] = x;
+                po[i] = f32x4{__expf(x[0] - c), __expf(x[1] - c), __expf(x[2] - c), __expf(x[3] - c)};
+            }
+        } else if (a.logits != nullptr) {
+            for (int i = tid; i < n4; i += 512) lo[i] = lg4[i];
         }
         if (a.g_out != nullptr && b < a.g_n_valid) {     // search lane: the priors of the new node's legal moves, straight from the tile
             const uint32_t cnt = a.g_cnt[b];

@@ -21,7 +21,8 @@ inline int64_t packed_weight_elems(int cout_pad, int k_total) { return int64_t(c
 
 struct ConvArgs {
     const void* x;        // [B][64][cin]   T
-    const void* wpk;      // packed weights T
+    const void* wpk;      // packed weights T (Precision float16x3: the hi halves, f16)
+    const void* wpk_lo;   // Precision float16x3 only: the lo halves (same fragment image), else nullptr
     const float* bias;    // [cout_pad]
     const void* resid;    // optional [B][64][cout_ld] T (added before the activation)
     void* out;            // T [B][64][cout_ld]   or   float [B][cout_real*64] (policy-map, channel-major)
@@ -54,6 +55,8 @@ struct BlockArgs {
     const float* wdw;     // [ks*ks][cop_pad] float (folded), zero padded
     const float* b2;      // [cop_pad]
     const void* w3pk;     // project weights packed (cout = C, k = cop_pad)
+    const void* w1pk_lo;  // Precision float16x3 only (x3.hip): lo halves of the split expand / project weights, w1pk / w3pk hold the hi halves
+    const void* w3pk_lo;
     const float* b3;      // [C]
     int batch, C, cop_pad, ks;
     const float* gate;    // optional [B][C]: SE gate multiplied into x while the tile is loaded (residual uses the gated x)
@@ -61,6 +64,12 @@ struct BlockArgs {
     const float* dwpk;    // 3x3 only: [cop_pad][12] = 9 folded taps, BN1 bias, BN2 bias, 0 (one 48-byte record per channel)
 };
 template <typename T> void launch_block(const BlockArgs& a, hipStream_t s);
+// Precision float16x3 (x3.hip): split-operand f16 MFMAs (a = hi + lo; hi*hi + hi*lo + lo*hi, f32 accumulate) on float activations.
+// The conv GEMM covers every dense layer of every net family; the fused block covers the 3x3 bottleneck blocks of 256-channel nets.
+void launch_conv_gemm_x3(const ConvArgs& a, hipStream_t s);
+void launch_block_x3(const BlockArgs& a, hipStream_t s);          // needs dwpk, w1pk_lo, w3pk_lo; ks == 3
+void init_x3_kernel_attributes();
+int block_x3_chunk_channels();
 template <typename T> void init_block_kernel_attributes();
 template <typename T> int block_chunk_channels();   // C_op must be padded to a multiple of this
 
@@ -146,8 +155,8 @@ void launch_stem(const StemArgs& a, hipStream_t s);
 //       -> conv-1 channel as in tower_k_channel), then 9 zero fragments
 struct HeadArgs {
     const void* x;            // [B][64][256] f16
-    float* logits;            // [B][cp*64] policy_out
-    float* probs;             // [B][cp*64] softmax
+    float* logits;            // [B][cp*64] policy_out (pre-softmax), or nullptr: not written
+    float* probs;             // [B][cp*64] softmax, or nullptr: not written (a search lane that only takes g_out)
     float* value;             // [B]
     float* aux;               // [B][4] or nullptr
     const void* s1;

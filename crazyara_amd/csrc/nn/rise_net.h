@@ -31,6 +31,8 @@ public:
     // precision: "float16" (f16 MFMA operands, f32 accumulate; the reference TensorRT default, optionsuci.cpp:143-147)
     //            or "fp8" ("float8"; "int8" is accepted as the reference's name for its reduced-precision mode): float16 with e4m3
     //            operands in the GEMMs of the residual tower (256-channel bottleneck nets only)
+    //            or "float16x3" (float activations, every dense contraction as three f16 MFMAs on hi/lo split operands: ~1e-5 on the
+    //            logits at several times the float32 rate, x3.hip)
     //            or "float32" (exact f32 MFMA); float16 runs the residual tower kernel (tower.hip: runs of 3x3 blocks in one launch);
     //            suffix "-perblock" selects one fused launch per bottleneck block, "-unfused" the layer-granular kernels
     //            (both kept for A/B measurements and as independent implementations in the parity tests).   Throws std::invalid_argument / std::runtime_error.
@@ -65,7 +67,8 @@ public:
     float* d_planes() const { return d_planes_; }     // [B][C][64] float (NCHW, as predict() takes it)
     float* d_value() const { return d_value_; }       // [B]
     float* d_probs() const { return d_probs_; }       // [B][nb_policy]
-    float* d_logits() const { return d_logits_; }     // [B][nb_policy] pre-softmax policy_out
+    float* d_logits() const { return d_logits_; }     // [B][nb_policy] pre-softmax policy_out: valid after a forward made with keep_logits(true)
+    void keep_logits(bool on) { keep_logits_ = on; }
     float* d_aux() const { return d_aux_; }           // [B][nb_aux] or nullptr
     void forward_async();
     void launch_forward_in_stream();     // the forward as part of a stream's in-order work (submit*, see rise_net.hip)                              // graph replay on stream(); no copies, no sync
@@ -98,11 +101,13 @@ private:
     void capture();
     bool buffers_are_pinned(const float* in_planes, float* value, float* probs, float* aux);
     bool last_zero_copy_ = false;
-    const void* pinned_seen_[4] = {nullptr, nullptr, nullptr, nullptr};   // the last buffer set found pinned (a NeuralNetAPIUser reuses its four)
+    bool keep_logits_ = false;   // the one-launch head also writes policy_out (pre-softmax) to d_logits() (parity tests); nets whose heads
+                                 // run as separate launches always have it there (the softmax launch reads it)
 
     RiseDesign design_;
     std::string model_name_, model_file_path_;
     bool fp16_ = true;
+    bool x3_ = false;            // Precision float16x3: float activations, split-operand f16 MFMAs (x3.hip); fp16_ is false
     bool fp8_tower_ = false;     // Precision fp8 (alias int8): e4m3 operands in the residual tower's GEMMs, everything else as float16
     bool fused_ = true;
     bool tower_ = true;

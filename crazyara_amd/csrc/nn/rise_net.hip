@@ -106,6 +106,18 @@ std::vector<T> pack_dense(const Folded& f, int cout, int cin, int ks, int cout_p
     return out;
 }
 
+// Precision float16x3: w = hi + lo, both f16 (hi = the nearest f16, lo = the nearest f16 to the rest), as two fragment images
+struct SplitPack { std::vector<half_t> hi, lo; };
+SplitPack pack_dense_split(const Folded& f, int cout, int cin, int ks, int cout_pad, int cin_pad) {
+    Folded fh = f, fl = f;
+    for (size_t i = 0; i < f.w.size(); ++i) {
+        const half_t h = half_t(float(f.w[i]));
+        fh.w[i] = double(float(h));
+        fl.w[i] = f.w[i] - fh.w[i];
+    }
+    return SplitPack{pack_dense<half_t>(fh, cout, cin, ks, cout_pad, cin_pad), pack_dense<half_t>(fl, cout, cin, ks, cout_pad, cin_pad)};
+}
+
 enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower, Forward };
 
 struct Op {
@@ -187,7 +199,10 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     // f32 accumulation, the residual stream itself stays f16); stem and heads stay f16.  "int8" is accepted as the reference's name for it.
     else if (prec == "fp8" || prec == "float8" || prec == "int8") { fp16_ = true; fp8_tower_ = true; }
     else if (prec == "float32" || prec == "fp32") fp16_ = false;
-    else throw std::invalid_argument("unsupported precision '" + precision + "' (float16 | float32)");
+    // the fast mode that meets "logits within 1e-3 of fp32": float activations, every dense contraction as three f16 MFMAs on split
+    // operands (x3.hip)
+    else if (prec == "float16x3" || prec == "fp16x3" || prec == "f16x3") { fp16_ = false; x3_ = true; }
+    else throw std::invalid_argument("unsupported precision '" + precision + "' (float16 | float16x3 | float32 | fp8)");
     design_.batch = batch_size;
 
     // model discovery (TensorrtAPI ctor, tensorrtapi.cpp:53-58)
@@ -306,6 +321,16 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     T* f = static_cast<T*>(im.dalloc(size_t(B) * kSquares * cop_max * sizeof(T)));
 
     double macs = 0;
+    // packed A-fragment images of a dense layer: T, or the f16 hi / lo pair of Precision float16x3
+    auto set_conv_weights = [&](ConvArgs& c, const Folded& fd, int co, int ci, int k, int co_pad, int ci_pad) {
+        if (x3_) {
+            SplitPack sp = pack_dense_split(fd, co, ci, k, co_pad, ci_pad);
+            c.wpk = im.upload(sp.hi);
+            c.wpk_lo = im.upload(sp.lo);
+        } else {
+            c.wpk = im.upload(pack_dense<T>(fd, co, ci, k, co_pad, ci_pad));
+        }
+    };
     auto add_conv = [&](const std::string& conv, const std::string& bn, const T* x, T* out, const T* resid, int ci, int ci_pad,
                         int co, int k, int relu, float* out_policy) {
         Folded fd = fold_bn(nf, conv, bn);
@@ -313,7 +338,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         Op op;
         op.kind = OpKind::Conv;
         op.conv.x = x;
-        op.conv.wpk = im.upload(pack_dense<T>(fd, co, ci, k, co_pad, ci_pad));
+        set_conv_weights(op.conv, fd, co, ci, k, co_pad, ci_pad);
         op.conv.bias = im.upload_d2f(fd.b, co_pad);
         op.conv.resid = resid;
         op.conv.out = out_policy ? static_cast<void*>(out_policy) : static_cast<void*>(out);
@@ -436,8 +461,10 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         tower_gate = nullptr;
         std::swap(cur, nxt);
     };
-    auto add_se = [&](Op op) {
-        if (fused_ && C == 256 && prod_op >= 0) {
+    // a block runs on the fused per-block kernel (else on the layer kernels): Precision float16x3 has a fused kernel for 3x3 blocks only
+    auto block_fused = [&](int k) { return fused_ && C == 256 && !(x3_ && k != 3); };
+    auto add_se = [&](Op op, bool consumer_fused) {
+        if (consumer_fused && prod_op >= 0) {
             if (!se_pool) {
                 se_pool = static_cast<float*>(im.dalloc(size_t(B) * C * sizeof(float)));
                 se_gate = static_cast<float*>(im.dalloc(size_t(B) * C * sizeof(float)));
@@ -604,7 +631,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 op.w0 = im.upload(w1t);
                 op.w1 = im.upload(w2t);
                 op.C = C;
-                add_se(op);
+                add_se(op, block_fused(k));
             }
             macs += 2.0 * C * H;
         } else if (se_types[i] == "eca_se") {                           // _EfficientChannelAttentionModule, builder_util.py:49-80
@@ -628,7 +655,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 op.w0 = im.upload(wt);
                 op.b0 = im.upload(b);
                 op.C = C;
-                add_se(op);
+                add_se(op, block_fused(k));
             }
             macs += double(C) * C;
         } else if (se_types[i] != "none" && !se_types[i].empty()) {
@@ -748,9 +775,9 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 tower_blocks.push_back(td);
                 macs += double(kSquares) * cop * (2.0 * C + k * k);
             }
-        } else if (fused_ && C == 256) {
-            // fused bottleneck block: expand -> depthwise -> project -> +x in one launch (kernels.hip: block_kernel)
-            const int cop_pad = round_up(cop, block_chunk_channels<T>());
+        } else if (block_fused(k)) {
+            // fused bottleneck block: expand -> depthwise -> project -> +x in one launch (kernels.hip: block_kernel; x3.hip: block_x3_kernel)
+            const int cop_pad = round_up(cop, x3_ ? block_x3_chunk_channels() : block_chunk_channels<T>());
             Folded f1 = fold_bn(nf, p + ".body.0", p + ".body.1");
             Folded f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
             Folded f3 = fold_bn(nf, p + ".body.6", p + ".body.7");
@@ -761,11 +788,19 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             BlockArgs& ba = op.blk;
             ba.x = cur;
             ba.y = nxt;
-            ba.w1pk = im.upload(pack_dense<T>(f1, cop, C, 1, cop_pad, C));
+            if (x3_) {
+                SplitPack s1 = pack_dense_split(f1, cop, C, 1, cop_pad, C), s3 = pack_dense_split(f3, C, cop, 1, C, cop_pad);
+                ba.w1pk = im.upload(s1.hi);
+                ba.w1pk_lo = im.upload(s1.lo);
+                ba.w3pk = im.upload(s3.hi);
+                ba.w3pk_lo = im.upload(s3.lo);
+            } else {
+                ba.w1pk = im.upload(pack_dense<T>(f1, cop, C, 1, cop_pad, C));
+                ba.w3pk = im.upload(pack_dense<T>(f3, C, cop, 1, C, cop_pad));
+            }
             ba.b1 = im.upload_d2f(f1.b, cop_pad);
             ba.wdw = im.upload(w);
             ba.b2 = im.upload_d2f(f2.b, cop_pad);
-            ba.w3pk = im.upload(pack_dense<T>(f3, C, cop, 1, C, cop_pad));
             ba.b3 = im.upload_d2f(f3.b, C);
             ba.batch = B;
             ba.C = C;
@@ -805,6 +840,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             }
             add_conv(p + ".body.6", p + ".body.7", f, nxt, cur, cop, cop, C, 1, false, nullptr);    // 1x1 project + BN + residual
             std::swap(cur, nxt);
+            prod_op = -1;                  // the residual stream now comes from a layer kernel: nobody emits its channel sums
         }
     }
     flush_tower();
@@ -916,7 +952,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             Op op;
             op.kind = OpKind::Conv;
             op.conv.x = nxt;
-            op.conv.wpk = im.upload(pack_dense<T>(fd, cp, C, 3, co_pad, C));
+            set_conv_weights(op.conv, fd, cp, C, 3, co_pad, C);
             op.conv.bias = im.upload_d2f(fd.b, co_pad);
             op.conv.out = pflat;
             op.conv.batch = B;
@@ -941,7 +977,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             Op op;
             op.kind = OpKind::Conv;
             op.conv.x = pflat;
-            op.conv.wpk = im.upload(pack_dense<T>(fl, n_labels, nfl, 1, nl_pad, nfl));
+            set_conv_weights(op.conv, fl, n_labels, nfl, 1, nl_pad, nfl);
             op.conv.bias = im.upload_d2f(fl.b, nl_pad);
             op.conv.out = d_logits_;
             op.conv.batch = Bpad / 64;
@@ -977,7 +1013,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             Op op;
             op.kind = OpKind::Conv;
             op.conv.x = cur;
-            op.conv.wpk = im.upload(pack_dense<T>(fd, cv, C, 1, co_pad, C));
+            set_conv_weights(op.conv, fd, cv, C, 1, co_pad, C);
             op.conv.bias = im.upload_d2f(fd.b, co_pad);
             op.conv.out = vflat;
             op.conv.batch = B;
@@ -1023,7 +1059,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             Op op;
             op.kind = OpKind::Conv;
             op.conv.x = vflat;
-            op.conv.wpk = im.upload(pack_dense<T>(f1, fc, nfl, 1, fc_pad, nfl));
+            set_conv_weights(op.conv, f1, fc, nfl, 1, fc_pad, nfl);
             op.conv.bias = im.upload_d2f(f1.b, fc_pad);
             op.conv.out = vh;
             op.conv.batch = Bpad / 64;        // 64 boards per workgroup tile
@@ -1084,6 +1120,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     }
     }   // !head_ok
     init_block_kernel_attributes<T>();
+    init_x3_kernel_attributes();
     init_tower_kernel_attributes();
     init_restower_kernel_attributes();
     init_head_kernel_attributes();
@@ -1115,7 +1152,10 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
         case OpKind::PlanesToAct:
             launch_planes_to_act<T>(op.x == d_planes_ ? planes : static_cast<const float*>(op.x), static_cast<T*>(op.y), B, op.C, im.cin_pad, s);
             break;
-        case OpKind::Conv: launch_conv_gemm<T>(op.conv, s); break;
+        case OpKind::Conv:
+            if (x3_) launch_conv_gemm_x3(op.conv, s);
+            else launch_conv_gemm<T>(op.conv, s);
+            break;
         case OpKind::Depthwise:
             launch_depthwise<T>(static_cast<const T*>(op.x), static_cast<T*>(op.y), op.w0, op.b0, B, op.C, op.ks, s);
             break;
@@ -1128,7 +1168,10 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             break;
         }
         case OpKind::Softmax: launch_softmax(d_logits_, probs, B, design_.nb_policy, s); break;
-        case OpKind::Block: launch_block<T>(op.blk, s); break;
+        case OpKind::Block:
+            if (x3_) launch_block_x3(op.blk, s);
+            else launch_block<T>(op.blk, s);
+            break;
         case OpKind::ValueFinal: {
             ValueFinalArgs v = op.vf;
             v.value = value;
@@ -1142,6 +1185,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             h.value = value;
             h.probs = probs;
             h.aux = aux;
+            h.logits = keep_logits_ ? d_logits_ : nullptr;
             launch_head(h, s);
             break;
         }
@@ -1159,6 +1203,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             h.value = value;
             h.probs = probs;
             h.aux = aux;
+            h.logits = keep_logits_ ? d_logits_ : nullptr;
             launch_forward(st, op.tw, h, s);
             break;
         }
@@ -1177,12 +1222,12 @@ const char* RiseNet::op_name(int i) const {
     const Op& op = impl_->ops.at(i);
     switch (op.kind) {
         case OpKind::PlanesToAct: return "planes_to_act";
-        case OpKind::Conv: return op.conv.ks == 1 ? "conv_gemm_1x1" : "conv_gemm_3x3";
+        case OpKind::Conv: return x3_ ? (op.conv.ks == 1 ? "conv_gemm_x3_1x1" : "conv_gemm_x3_3x3") : (op.conv.ks == 1 ? "conv_gemm_1x1" : "conv_gemm_3x3");
         case OpKind::Depthwise: return "depthwise";
         case OpKind::SE: return "se";
         case OpKind::ValueHead: return "value_head";
         case OpKind::Softmax: return "softmax";
-        case OpKind::Block: return "fused_block";
+        case OpKind::Block: return x3_ ? "block_x3" : "fused_block";
         case OpKind::ValueFinal: return "value_final";
         case OpKind::SEGate: return "se_gate";
         case OpKind::Tower: return "tower";
@@ -1365,12 +1410,12 @@ void RiseNet::launch_forward_in_stream() {
     else HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
 }
 
-// every buffer of the call in pinned (device-visible) host memory?  hipPointerGetAttributes costs a microsecond or two per pointer, so
-// the last set that passed is remembered: a NeuralNetAPIUser calls predict with the same four buffers for its whole life.
+// every buffer of the call in pinned (device-visible) host memory?  Asked of the runtime on EVERY call (hipPointerGetAttributes: a
+// microsecond or two per pointer against a forward of 100+ us): a remembered answer would outlive a hipHostFree / hipHostUnregister of
+// the caller's buffers, and a later call with pageable memory at the same addresses would then be read and written by the kernels.
 bool RiseNet::buffers_are_pinned(const float* in_planes, float* value, float* probs, float* aux) {
     if (getenv("CRA_PREDICT_COPY") != nullptr) return false;     // read per call: bench.py times both paths in one process
     const void* set[4] = {in_planes, value, probs, (d_aux_ && aux) ? aux : nullptr};
-    if (set[0] == pinned_seen_[0] && set[1] == pinned_seen_[1] && set[2] == pinned_seen_[2] && set[3] == pinned_seen_[3] && set[0]) return true;
     for (const void* p : set) {
         if (!p) continue;
         if (reinterpret_cast<uintptr_t>(p) & 15) return false;     // the kernels read / write the buffers in 16-byte units
@@ -1381,7 +1426,6 @@ bool RiseNet::buffers_are_pinned(const float* in_planes, float* value, float* pr
         }
         if (at.type != hipMemoryTypeHost) return false;
     }
-    for (int i = 0; i < 4; ++i) pinned_seen_[i] = set[i];
     return true;
 }
 
@@ -1439,28 +1483,37 @@ void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int la
     // and the compute queue -- five copies around three kernel groups were 0.1-0.5 ms of latency per batch (host dependent), more
     // than the forward itself on a loaded host.  One queue, three launches back to back; the host polls the stream.
     Impl& im = *impl_;
-    const char* lane_mode = getenv("CRA_LANE_LAUNCHES");              // "1" / "3": force the one-launch / three-launch lane step (read per call)
-    const bool one_launch = lane_mode ? lane_mode[0] == '1' : B <= 64;
-    if (im.ops.size() == 1 && im.ops[0].kind == OpKind::Forward && one_launch) {
-        // ... and for SMALL batches, where the launches themselves are what a lane step costs (a batch of 8 occupies 8 CUs for 0.1 ms),
-        // ONE launch: the forward kernel's stem builds the planes of a board from the descriptor, its head writes the gathered priors,
-        // value and aux of the board straight into the caller's buffers.  Measured (profiles/r02/t_*): single-tree search at batch 8
-        // +4-5 % with 1 to 8 collectors; at batch 256 the plane building inside the 0.31 ms kernel costs more than the two small
-        // launches did beside the other lane's forward (-4 % on the headline search leg), so large batches keep three launches.
+    const char* lane_mode = getenv("CRA_LANE_LAUNCHES");              // "1" / "2" / "3": force the shape of the lane step (read per call)
+    if (im.ops.size() == 1 && im.ops[0].kind == OpKind::Forward && !(lane_mode && lane_mode[0] == '3')) {
+        // The forward kernel's head writes the gathered priors, value and aux of a board straight into the caller's buffers: a search
+        // reads nothing else (set_probabilities_for_moves, node.cpp:961-979), so neither the 20.7 KB probability vector nor the logits of
+        // a board leave its CU, and there is no gather launch behind the forward.
+        //  * SMALL batches, where the launches themselves are what a lane step costs (a batch of 8 occupies 8 CUs for 0.1 ms), run as
+        //    ONE launch: the kernel's stem builds the planes of a board from its descriptor (profiles/r02/t_*: single-tree search at
+        //    batch 8 +4-5 % with 1 to 8 collectors).
+        //  * LARGE batches keep the plane builder as a launch of its own: inside the 0.31 ms kernel it cost more than the small launch
+        //    does beside the other lane's forward (-4 % on the headline search leg).
+        const bool one_launch = lane_mode ? lane_mode[0] == '1' : B <= 64;
         const Op& op = im.ops[0];
         StemArgs st = op.st;
         HeadArgs h = op.hd;
-        st.descs = descs_host;
-        st.layout = layout;
-        st.n_valid = n_valid;
+        if (one_launch) {
+            st.descs = descs_host;
+            st.layout = layout;
+            st.n_valid = n_valid;
+        } else if (n_valid > 0) {
+            launch_planes_from_desc(static_cast<const BoardDesc*>(descs_host), n_valid, layout, 1, d_planes_, stream_);
+        }
         h.value = value;
-        h.probs = d_probs_;
+        h.probs = nullptr;
+        h.logits = nullptr;
         h.aux = (d_aux_ && aux) ? aux : d_aux_;
         h.g_idx = idx;
         h.g_cnt = cnt;
         h.g_out = gathered;
         h.g_stride = int(stride);
         h.g_n_valid = n_valid;
+        Turn turn(*this);                         // forwards that fill the chip take turns (small batches: a no-op)
         launch_forward(st, op.tw, h, stream_);
         HIP_CHECK(hipGetLastError());
         return;

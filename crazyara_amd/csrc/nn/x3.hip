@@ -1,0 +1,415 @@
+// Precision float16x3: the fast mode that meets north_star's "logits within 1e-3 of fp32" (it measures ~1e-5).
+//
+// Every dense contraction of the network (stem, expand / project 1x1, dense 3x3 towers, policy convs, value head conv and FCs, flat
+// policy Linear) runs on the f16 matrix pipe with SPLIT operands: a = a_hi + a_lo, a_hi = rne_f16(a), a_lo = rne_f16(a - a_hi), and
+//     a * b  ~=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (three v_mfma_f32_16x16x32_f16, f32 accumulate; a_lo*b_lo ~ 2^-22 is dropped)
+// so a product carries ~22 significand bits (17+ for operands small enough that a_lo is an f16 subnormal, |a| < 2^-3: absolute error
+// <= 2^-25) where Precision float16 carries 11.  The matrix pipe does 3 MFMAs per product at 16x the exact-f32 MFMA rate
+// (v_mfma_f32_16x16x4_f32, Precision float32): a ceiling of 2500 / 3 = 833 TFLOP/s against 157.
+//
+// Layout: activations live in HBM as float [B][64][C] exactly as in Precision float32 (depthwise, SE gates, softmax and the last value
+// FC are the float32 mode's own kernels); a board tile is split ONCE while it is staged into LDS (two f16 tiles, hi and lo), weights
+// are split once on the host after BN folding in double (two A-fragment images, rise_net.hip: pack_dense_split).
+//
+// Reference semantics: the same modules as kernels.hip (builder_util.py:154-178, 437-475, 206-326).
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace cra {
+
+namespace {
+
+__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const half_t h = half_t(v[j]);               // round to nearest even
+        hi[j] = h;
+        lo[j] = half_t(v[j] - float(h));             // the difference is exact in f32; its f16 rounding is the mode's error
+    }
+}
+__device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const half_t h = half_t(v[j]);
+        hi[j] = h;
+        lo[j] = half_t(v[j] - float(h));
+    }
+}
+
+// one product tile: the two cross terms first, the main term last
+__device__ __forceinline__ void mma_x3(const half8& ah, const half8& al, const half8& bh, const half8& bl, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+}
+
+constexpr int X3_KC = 128;                 // input channels staged per pass of the conv GEMM
+constexpr int X3_ROWP = X3_KC + 8;         // halves per LDS row (+16 B: the 16 rows of a fragment read land in 16 bank groups)
+
+}  // namespace
+
+// ================================================================================================================
+// Dense conv (1x1 / 3x3) as implicit GEMM -- conv_gemm_kernel<float> (kernels.hip) with split operands.
+// ================================================================================================================
+template <int KS>
+__global__ __launch_bounds__(256) void conv_gemm_x3_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* xh = reinterpret_cast<half_t*>(smem);            // [65][ROWP] hi
+    half_t* xl = xh + 65 * X3_ROWP;                          // [65][ROWP] lo
+    constexpr int ROWP = X3_ROWP, KC = X3_KC;
+
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int co_tile = blockIdx.x * 4 + wave;
+    const bool active = co_tile * 16 < a.cout_pad;
+    const float* xb = reinterpret_cast<const float*>(a.x) + size_t(b) * kSquares * a.cin;
+    const int nslab_ci = a.cin >> 5;
+    const int nslab = KS * KS * nslab_ci;
+    const half8* wph = reinterpret_cast<const half8*>(a.wpk) + size_t(active ? co_tile : 0) * nslab * 64 + lane;
+    const half8* wpl = reinterpret_cast<const half8*>(a.wpk_lo) + size_t(active ? co_tile : 0) * nslab * 64 + lane;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int i = tid; i < ROWP; i += 256) {                  // row 64: what out-of-board taps read
+        xh[64 * ROWP + i] = half_t(0.f);
+        xl[64 * ROWP + i] = half_t(0.f);
+    }
+
+    for (int kc0 = 0; kc0 < a.cin; kc0 += KC) {
+        const int kcl = min(KC, a.cin - kc0);
+        __syncthreads();
+        const int vec_per_row = kcl >> 3;                    // 8 floats -> 8 + 8 halves
+        for (int i = tid; i < kSquares * vec_per_row; i += 256) {
+            const int r = i / vec_per_row, v = i - r * vec_per_row;
+            float f[8];
+            load8<float>(xb + size_t(r) * a.cin + kc0 + v * 8, f);
+            half8 h, l;
+            split8(f, h, l);
+            *reinterpret_cast<half8*>(xh + r * ROWP + v * 8) = h;
+            *reinterpret_cast<half8*>(xl + r * ROWP + v * 8) = l;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int tap = 0; tap < KS * KS; ++tap) {
+                const int dy = tap / KS - KS / 2, dx = tap % KS - KS / 2;
+                int rowoff[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int sq = t * 16 + l15;
+                    const int ny = (sq >> 3) + dy, nx = (sq & 7) + dx;
+                    const bool ok = (unsigned(ny) < 8u) && (unsigned(nx) < 8u);
+                    rowoff[t] = (ok ? ny * 8 + nx : 64) * ROWP + lg * 8;
+                }
+                const size_t wo = size_t(tap * nslab_ci + (kc0 >> 5)) * 64;
+                const int ns = kcl >> 5;
+                half8 ah = wph[wo], al = wpl[wo];
+                for (int sl = 0; sl < ns; ++sl) {
+                    const half8 ch = ah, cl = al;
+                    if (sl + 1 < ns) {                       // next slab's fragments fly while this slab's MFMAs run
+                        ah = wph[wo + size_t(sl + 1) * 64];
+                        al = wpl[wo + size_t(sl + 1) * 64];
+                    }
+                    half8 bh[4], bl[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        bh[t] = *reinterpret_cast<const half8*>(xh + rowoff[t] + sl * 32);
+                        bl[t] = *reinterpret_cast<const half8*>(xl + rowoff[t] + sl * 32);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, bl[t], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, bh[t], acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active) return;
+
+    // epilogue: conv_gemm_kernel<float>'s, word for word (bias, ReLU before / after the shortcut, the four output layouts)
+    const int co0 = co_tile * 16 + lg * 4;
+    float bs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bs[r] = a.bias[co0 + r];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int sq = t * 16 + l15;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[t][r] + bs[r];
+        if (a.relu == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (a.resid) {
+            float rv[4];
+            load4<float>(reinterpret_cast<const float*>(a.resid) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, rv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        }
+        if (a.relu == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (a.out_policy_f32) {
+            float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.cout_real * kSquares;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
+        } else if (a.out_rows_f32) {
+            const int row = b * kSquares + sq;
+            if (row < a.rows_valid) {
+                float* o = reinterpret_cast<float*>(a.out) + size_t(row) * a.cout_real;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < a.cout_real) o[co0 + r] = v[r];
+            }
+        } else if (a.out_flat) {
+            float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.flat_pitch;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
+        } else {
+            store4<float>(reinterpret_cast<float*>(a.out) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, v);
+        }
+    }
+}
+
+void launch_conv_gemm_x3(const ConvArgs& a, hipStream_t s) {
+    const size_t shmem = size_t(2) * 65 * X3_ROWP * sizeof(half_t);      // 35 KB: four workgroups per CU
+    dim3 grid((a.cout_pad + 63) / 64, a.batch), block(256);
+    if (a.ks == 1) hipLaunchKernelGGL((conv_gemm_x3_kernel<1>), grid, block, shmem, s, a);
+    else hipLaunchKernelGGL((conv_gemm_x3_kernel<3>), grid, block, shmem, s, a);
+}
+
+// ================================================================================================================
+// Fused 3x3 mobile-bottleneck block -- block_kernel_dpp (kernels.hip) with split operands: expand (MFMA x3) -> BN1 + ReLU + depthwise
+// 3x3 + BN2 + ReLU on the f32 accumulators by DPP lane shifts (no LDS round trip, exact f32) -> split -> LDS -> project (MFMA x3)
+// into the register accumulator -> + BN3 bias + x.  8 waves, one board per workgroup; x and y are float [B][64][256].
+// ================================================================================================================
+namespace {
+struct X3Block {
+    static constexpr int C = 256, NW = 8, CK = 16 * NW, NTHR = 64 * NW;
+    static constexpr int XROW = C + 16;      // halves; 32-byte row pad (rows step 8 banks: conflict-free 16-row fragment reads)
+    static constexpr int TROW = CK + 16;
+    static constexpr size_t lds_bytes = (size_t(2) * 64 * XROW + size_t(2) * 64 * TROW) * sizeof(half_t);     // 106,496 B
+};
+}  // namespace
+
+__global__ __launch_bounds__(512) void block_x3_kernel(const BlockArgs a) {
+    using G = X3Block;
+    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NTHR = G::NTHR, NW = G::NW;
+    constexpr int NJ = C / 16 / NW;                            // 2 cout tiles per wave in the project phase
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* xh = reinterpret_cast<half_t*>(smem);              // [64][XROW] block input, hi
+    half_t* xl = xh + 64 * XROW;                               //                         lo
+    half_t* t2h = xl + 64 * XROW;                              // [64][TROW] depthwise output of the current chunk, hi
+    half_t* t2l = t2h + 64 * TROW;                             //                                                    lo
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const int nchunk = a.cop_pad / CK;
+    const int nslab3 = a.cop_pad >> 5;
+    const half8* w1h = reinterpret_cast<const half8*>(a.w1pk) + lane;
+    const half8* w1l = reinterpret_cast<const half8*>(a.w1pk_lo) + lane;
+    const half8* w3h = reinterpret_cast<const half8*>(a.w3pk) + lane;
+    const half8* w3l = reinterpret_cast<const half8*>(a.w3pk_lo) + lane;
+    const bool hi = l15 >= 8;                                  // second board row of a 16-square tile
+    const float mL = (l15 & 7) != 0 ? 1.f : 0.f;               // a left / right neighbour exists on the board
+    const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
+
+    half8 e_h[C / 32], e_l[C / 32];                            // expand fragments of the chunk, requested one phase ahead
+    auto prefetch_expand = [&](int ch) {
+        const size_t o = size_t(ch * NW + wave) * (C / 32) * 64;
+#pragma unroll
+        for (int s = 0; s < C / 32; ++s) {
+            e_h[s] = w1h[o + s * 64];
+            e_l[s] = w1l[o + s * 64];
+        }
+    };
+    prefetch_expand(0);
+
+    {   // block input -> split tiles (optionally x := x * gate[b][c], _ChannelAttentionModule.forward, builder_util.py:114)
+        const float* xb = reinterpret_cast<const float*>(a.x) + size_t(b) * 64 * C;
+        const float* g = a.gate ? a.gate + size_t(b) * C : nullptr;
+        for (int i = tid; i < 64 * (C / 8); i += NTHR) {
+            const int r = i / (C / 8), v = i - r * (C / 8);
+            float f[8];
+            load8<float>(xb + size_t(r) * C + v * 8, f);
+            if (g) {
+                float gv[8];
+                load8<float>(g + v * 8, gv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] *= gv[j];
+            }
+            half8 h, l;
+            split8(f, h, l);
+            *reinterpret_cast<half8*>(xh + r * XROW + v * 8) = h;
+            *reinterpret_cast<half8*>(xl + r * XROW + v * 8) = l;
+        }
+    }
+    __syncthreads();
+
+    f32x4 accP[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accP[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        // per-channel depthwise record of my 4 channels (9 taps, BN1 bias, BN2 bias, 0): lands while the expand MFMAs run
+        f32x4 dwr[4][3];
+        {
+            const f32x4* dp = reinterpret_cast<const f32x4*>(a.dwpk + size_t(ch * CK + wave * 16 + lg * 4) * 12);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dwr[r][k] = dp[r * 3 + k];
+        }
+        // ---------------- E: expand, 16 channels x 64 squares per wave, K = C ----------------
+        f32x4 accE[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accE[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < C / 32; ++s) {
+            half8 bh[4], bl[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bh[t] = *reinterpret_cast<const half8*>(xh + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                bl[t] = *reinterpret_cast<const half8*>(xl + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_l[s], bh[t], accE[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_h[s], bl[t], accE[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_h[s], bh[t], accE[t], 0, 0, 0);
+        }
+        // this chunk's project fragments: they land while the depthwise runs
+        half8 p_h[CK / 32][NJ], p_l[CK / 32][NJ];
+#pragma unroll
+        for (int s2 = 0; s2 < CK / 32; ++s2)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const size_t o = (size_t(wave * NJ + j) * nslab3 + ch * (CK / 32) + s2) * 64;
+                p_h[s2][j] = w3h[o];
+                p_l[s2][j] = w3l[o];
+            }
+
+        // ---------------- D: BN1 + ReLU, depthwise 3x3 on the accumulators (block_kernel_dpp), BN2 + ReLU, exact f32 ----------------
+        float outv[4][4];                                       // [tile][channel r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float b1 = dwr[r][2][1], b2 = dwr[r][2][2];
+            float w[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k] = dwr[r][k >> 2][k & 3];
+            w[0] *= mL; w[3] *= mL; w[6] *= mL;                 // file-edge masks folded into the dx = -1 / +1 columns
+            w[2] *= mR; w[5] *= mR; w[8] *= mR;
+            float e[4], rot[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                e[t] = fmaxf(accE[t][r] + b1, 0.f);
+                rot[t] = dpp_mov<DPP_ROW_ROR8>(e[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float up = hi ? rot[t] : (t > 0 ? rot[t > 0 ? t - 1 : 0] : 0.f);
+                const float dn = hi ? (t < 3 ? rot[t < 3 ? t + 1 : 3] : 0.f) : rot[t];
+                float acc = b2;
+                acc = fmaf(w[0], dpp_mov<DPP_ROW_SHR1>(up), acc);
+                acc = fmaf(w[1], up, acc);
+                acc = fmaf(w[2], dpp_mov<DPP_ROW_SHL1>(up), acc);
+                acc = fmaf(w[3], dpp_mov<DPP_ROW_SHR1>(e[t]), acc);
+                acc = fmaf(w[4], e[t], acc);
+                acc = fmaf(w[5], dpp_mov<DPP_ROW_SHL1>(e[t]), acc);
+                acc = fmaf(w[6], dpp_mov<DPP_ROW_SHR1>(dn), acc);
+                acc = fmaf(w[7], dn, acc);
+                acc = fmaf(w[8], dpp_mov<DPP_ROW_SHL1>(dn), acc);
+                outv[t][r] = fmaxf(acc, 0.f);
+            }
+        }
+        {
+            const int cl = wave * 16 + lg * 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                half4 h, l;
+                split4(outv[t], h, l);
+                *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
+                *reinterpret_cast<half4*>(t2l + (t * 16 + l15) * TROW + cl) = l;
+            }
+        }
+        __syncthreads();
+        if (ch + 1 < nchunk) prefetch_expand(ch + 1);           // lands while the project MFMAs run
+        // ---------------- P: project, 32 couts x 64 squares per wave, K = CK (accumulates over chunks) ----------------
+#pragma unroll
+        for (int s2 = 0; s2 < CK / 32; ++s2) {
+            half8 bh[4], bl[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bh[t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                bl[t] = *reinterpret_cast<const half8*>(t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_l[s2][j], bh[t], accP[j][t], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_h[s2][j], bl[t], accP[j][t], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_h[s2][j], bh[t], accP[j][t], 0, 0, 0);
+        }
+        __syncthreads();                                        // t2 is rewritten by the next chunk's depthwise
+    }
+
+    // ---------------- epilogue: + BN3 bias + residual (hi + lo of the staged input = x to 2^-22) ----------------
+    float* yb = reinterpret_cast<float*>(a.y) + size_t(b) * 64 * C;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int co0 = (wave * NJ + j) * 16 + lg * 4;
+        float bs[4];
+        load4<float>(a.b3 + co0, bs);
+        float pool[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int sq = t * 16 + l15;
+            float rh[4], rl[4], v[4];
+            load4<half_t>(xh + sq * XROW + co0, rh);
+            load4<half_t>(xl + sq * XROW + co0, rl);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = accP[j][t][r] + bs[r] + (rh[r] + rl[r]);
+                pool[r] += v[r];
+            }
+            store4<float>(yb + size_t(sq) * C + co0, v);
+        }
+        if (a.pool_out) {                                       // squeeze (AdaptiveAvgPool2d) of the block output, fused here
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) pool[r] += __shfl_xor(pool[r], off, 64);
+            if (l15 == 0) store4<float>(a.pool_out + size_t(b) * C + co0, pool);
+        }
+    }
+}
+
+void init_x3_kernel_attributes() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+}
+int block_x3_chunk_channels() { return X3Block::CK; }
+
+void launch_block_x3(const BlockArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(block_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+}
+
+}  // namespace cra

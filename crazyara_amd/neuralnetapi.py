@@ -30,13 +30,15 @@ class _DevArray:
 
 
 class HipAPI:
-    def __init__(self, device_id: int, batch_size: int, model_directory: str, precision: str = "float16"):
+    def __init__(self, device_id: int, batch_size: int, model_directory: str, precision: str = "float16", keep_logits: bool = False):
         self._lib = _capi.load()
         self._h = self._lib.mi_net_create(model_directory.encode(), int(device_id), int(batch_size), precision.encode())
         if not self._h:
             msg = _capi.last_error()
             # the reference throws invalid_argument / runtime_error from the constructor (neuralnetapi.cpp:65-70,173)
             raise (ValueError if "directory" in msg or "precision" in msg or "batch" in msg else RuntimeError)(msg)
+        if keep_logits:      # tests / analysis: forwards also leave policy_out (pre-softmax) in device_buffers()["logits"]
+            self._lib.mi_net_keep_logits(self._h, 1)
         shape = (C.c_int * 4)()
         npol, naux, ver, phase = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         self._lib.mi_net_design(self._h, shape, C.byref(npol), C.byref(naux), C.byref(ver), C.byref(phase))

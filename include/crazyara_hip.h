@@ -43,7 +43,8 @@ typedef struct mi_net mi_net;
  * "-bsize-<B>" first, else the one without "-bsize-"; a .cranet wins over an .onnx), or a direct path to either.
  * ONNX files are read in place (the graphs of the reference's model zoo, see csrc/nn/onnx_import.h), the "-v<maj>.<min>"
  * part of the name is the input-representation version (read_version_from_string, neuralnetapi.cpp:194-227).
- * precision: "float32" | "float16" (UCI option Precision, optionsuci.cpp:143-147) | "fp8" (also "float8"; "int8" -- the third value of the
+ * precision: "float32" | "float16" (UCI option Precision, optionsuci.cpp:143-147) | "float16x3" (float activations, every dense contraction
+ * as three f16 MFMAs on hi/lo split operands: logits within ~1e-5 of fp32 at several times the float32 rate; every net family) | "fp8" (also "float8"; "int8" -- the third value of the
  * reference's option, TensorRT INT8 with a calibration cache, tensorrtapi.cpp:229-248 -- is accepted as a name for it): float16 with OCP
  * e4m3 operands in the two GEMMs of every residual block (f32 accumulation, per-row power-of-two weight scales, no calibration file; the
  * residual stream, stem and heads stay f16).  256-channel bottleneck (RISE) nets only; error against fp32 about 2^7 times float16's
@@ -86,6 +87,9 @@ int mi_net_last_submit_zero_copy(const mi_net* net);
  * d_planes [B][C][64] float, d_value [B], d_probs [B][nb_policy], d_logits [B][nb_policy] (pre-softmax policy_out),
  * d_aux [B][4] or NULL.  Any out-pointer may be NULL. */
 int mi_net_device_buffers(mi_net* net, float** d_planes, float** d_value, float** d_probs, float** d_logits, float** d_aux);
+/* d_logits is test / analysis output (predict's contract is the softmaxed vector): forwards write it only after mi_net_keep_logits(net, 1)
+ * (the one-launch head keeps the logits in LDS otherwise; nets whose heads run as separate launches always have it). */
+int mi_net_keep_logits(mi_net* net, int on);
 int mi_net_forward_device(mi_net* net);          /* hipGraph replay on the net stream, asynchronous */
 int mi_net_sync(mi_net* net);                    /* hipStreamSynchronize(net stream) */
 void* mi_net_stream(mi_net* net);                /* the hipStream_t */

@@ -222,6 +222,92 @@ def predict_fp8_tower(cfg, sd, x):
     return value.reshape(-1), torch.softmax(pol, dim=1), aux
 
 
+# --------------------------------------------------------------------------------------------------------------
+# Precision float16x3 (crazyara_amd/csrc/nn/x3.hip): emulation of the mode's rounding points, NOT a restatement of reference code.
+# What is pinned is the fp32 forward above; this function says what the split-operand mode adds to it:
+#   every dense contraction (stem, expand / project 1x1, dense 3x3, policy convs, value conv, value FC1, flat-policy Linear):
+#       BN folded into the weights in double; weights and input activations split a = hi + lo (hi = rne_f16(a), lo = rne_f16(a - hi));
+#       product = hi*hi + hi*lo + lo*hi (the lo*lo term is dropped), exact accumulation here (f32 in the kernel)
+#   depthwise, SE gates, last value FC / WDLP, softmax: fp32 as in Precision float32
+# --------------------------------------------------------------------------------------------------------------
+def _split_f16(t):
+    hi = t.float().to(torch.float16).double()
+    lo = (t.double() - hi).float().to(torch.float16).double()
+    return hi, lo
+
+
+def _x3_conv(x, w, padding=0):
+    xh, xl = _split_f16(x)
+    wh, wl = _split_f16(w)
+    return (F.conv2d(xh, wh, padding=padding) + F.conv2d(xh, wl, padding=padding) + F.conv2d(xl, wh, padding=padding)).float()
+
+
+def _x3_layer(sd, x, conv, bn, padding=0):
+    if bn:
+        w, b = _fold(sd, conv, bn)
+        return _x3_conv(x, w, padding) + b.float().view(1, -1, 1, 1)
+    return _x3_conv(x, sd[conv + ".weight"].double(), padding)
+
+
+@torch.no_grad()
+def forward_x3(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor):
+    """(value, policy logits, aux) of Precision float16x3 as emulated on the CPU (every net family)."""
+    x = x.to(torch.float32)
+    pre = cfg.key_prefix
+    h = F.relu(_x3_layer(sd, x, pre + ".0.body.0", pre + ".0.body.1", 1))
+    for i, (k, se) in enumerate(zip(cfg.kernels, cfg.se_types)):
+        p = f"{pre}.{i + 1}"
+
+        def gate(z, hard):
+            y = z.mean(dim=(2, 3))
+            if se in ("ca_se", "se"):
+                y = F.linear(F.relu(F.linear(y, sd[p + ".se.fc.0.weight"])), sd[p + ".se.fc.2.weight"])
+            else:
+                w = sd[p + ".se.body.0.weight"]
+                y = F.conv1d(y[:, :, None], w, sd[p + ".se.body.0.bias"], padding=w.shape[2] // 2)[:, :, 0]
+            y = F.hardsigmoid(y) if hard else torch.sigmoid(y)
+            return z * y[:, :, None, None]
+        if cfg.dense_blocks:
+            if se is not None and cfg.conv_block == "classical_res_block":
+                h = gate(h, True)
+            t = F.relu(_x3_layer(sd, h, p + ".body.0", p + ".body.1", 1))
+            t = _x3_layer(sd, t, p + ".body.3", p + ".body.4", 1)
+            if cfg.conv_block == "classical_res_block":
+                h = h + F.relu(t)
+            else:
+                if se is not None:
+                    t = gate(t, False)
+                h = F.relu(h + t)
+            continue
+        if se is not None:
+            h = gate(h, True)
+        t = F.relu(_x3_layer(sd, h, p + ".body.0", p + ".body.1"))
+        cop = t.shape[1]
+        t = F.relu(_bn(sd, p + ".body.4", F.conv2d(t, sd[p + ".body.3.weight"], padding=k // 2, groups=cop)))
+        h = h + _x3_layer(sd, t, p + ".body.6", p + ".body.7")
+    B = x.shape[0]
+    ph = F.relu(_x3_layer(sd, h, "policy_head.body.0", "policy_head.body.1", 1))
+    if cfg.select_policy_from_plane:
+        pol = _x3_layer(sd, ph, "policy_head.body.3", "", 1).reshape(B, -1)
+    else:
+        pol = F.relu(_x3_layer(sd, ph, "policy_head.body.3", "policy_head.body2.0", 1)).reshape(B, -1)
+        pol = _x3_conv(pol[:, :, None, None], sd["policy_head.body3.0.weight"].double()[:, :, None, None]).reshape(B, -1) \
+            + sd["policy_head.body3.0.bias"]
+    vh = F.relu(_x3_layer(sd, h, "value_head.body.0", "value_head.body.1")).reshape(B, -1)
+    aux = None
+    if cfg.use_wdl and cfg.use_plys_to_end:
+        wdl = F.linear(vh, sd["value_head.body_wdl.0.weight"], sd["value_head.body_wdl.0.bias"])
+        plys = torch.sigmoid(F.linear(vh, sd["value_head.body_plys.0.weight"], sd["value_head.body_plys.0.bias"]))
+        sm = torch.softmax(wdl, dim=1)
+        value = -sm[:, 0:1] + sm[:, 2:3]
+        aux = torch.cat((wdl, plys), dim=1)
+    else:
+        v = _x3_conv(vh[:, :, None, None], sd["value_head.body_final.0.weight"].double()[:, :, None, None]).reshape(B, -1)
+        v = F.relu(v + sd["value_head.body_final.0.bias"])
+        value = torch.tanh(F.linear(v, sd["value_head.body_final.2.weight"], sd["value_head.body_final.2.bias"]))
+    return value, pol, aux
+
+
 @torch.no_grad()
 def predict(cfg, sd, x, sim_dtype=None):
     """NeuralNetAPI::predict contract: value (tanh range), policy AFTER softmax over all nbPolicy entries, aux."""

@@ -26,7 +26,7 @@ precisions = sys.argv[1:] or ["float16"]
 def run(cfg, sd, x, precision, version):
     d = nn_cases.export_case(tempfile.mkdtemp(), cfg.name, cfg, sd, version=version)
     B = x.shape[0]
-    net = HipAPI(0, B, d, precision)
+    net = HipAPI(0, B, d, precision, keep_logits=True)
     v, p = np.zeros(B, np.float32), np.zeros(B * cfg.nb_policy, np.float32)
     aux = np.zeros(B * 4, np.float32) if cfg.nb_aux else None
     net.predict(np.ascontiguousarray(x.numpy()), v, p, aux)

@@ -3,6 +3,9 @@
 Tolerances (BASELINE.json north_star: "value/policy logits within 1e-3 fp32"):
   Precision float32 (exact-f32 MFMA): |logit| err < 1e-4, |value| err < 1e-4, |prob| err < 1e-6 (measured on an MI355X:
       5.0e-6 / 4.9e-7 / 1.2e-8, profiles/r02/a_error_scan.txt) -- THE mode that satisfies north_star's 1e-3 on the logits.
+  Precision float16x3 (split-operand f16 MFMAs, x3.hip): the same bounds as float32 -- the mode's own emulation
+      (oracle/rise_oracle.forward_x3) differs from fp32 by 1e-6 ... 6e-6 on the logits of these cases, i.e. by f32 round-off.  THE FAST
+      mode that satisfies north_star's 1e-3 on the logits; the headline of bench.py.
   Precision float16 (f16 MFMA operands, f32 accumulate -- the reference TensorRT default): predict() outputs
       |value| err < 1e-3 (measured <= 6.9e-4), |prob| err < 1e-5 (measured <= 3.1e-6).  The LOGITS do not meet 1e-3 with f16
       operands: rounding the weights alone to f16 moves them by 1.6e-3 (scripts/error_budget.py, profiles/r02/a_error_budget.txt),
@@ -33,6 +36,8 @@ def logit_tol(tol, ref_logits):
 
 # float16 runs the residual-tower kernel (runs of 3x3 blocks in one launch); "-perblock" = one fused launch per bottleneck
 # block, "-unfused" = layer-granular kernels (conv GEMM / depthwise / project as separate launches): three implementations
+TOL["float16x3"] = TOL["float32"]
+TOL["float16x3-unfused"] = TOL["float32"]   # every block on the layer kernels (conv GEMM x3 / float depthwise), as the 5x5 blocks always are
 TOL["float32-unfused"] = TOL["float32"]
 TOL["float16-unfused"] = TOL["float16"]
 TOL["float16-perblock"] = TOL["float16"]
@@ -45,7 +50,7 @@ def _run(tmp_path, hip_lib, name, precision):
     cfg, sd, x = nn_cases.make_case(name)
     d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
     B = x.shape[0]
-    net = HipAPI(0, B, d, precision)
+    net = HipAPI(0, B, d, precision, keep_logits=True)
     assert net.get_batch_size() == B and net.get_nb_policy_values() == cfg.nb_policy
     assert net.get_nb_input_values_total() == cfg.nb_input_channels * 64
     assert net.get_nb_auxiliary_outputs() == cfg.nb_aux
@@ -59,7 +64,8 @@ def _run(tmp_path, hip_lib, name, precision):
     return cfg, sd, x, value, probs.reshape(B, -1), aux, logits
 
 
-@pytest.mark.parametrize("precision", ["float32", "float16", "float16-3k", "float16-perblock", "float32-unfused", "float16-unfused"])
+@pytest.mark.parametrize("precision", ["float32", "float16", "float16x3", "float16-3k", "float16-perblock", "float32-unfused", "float16-unfused",
+                                       "float16x3-unfused"])
 @pytest.mark.parametrize("name", list(nn_cases.CASES))
 def test_predict_matches_oracle_and_golden(tmp_path, hip_lib, name, precision):
     cfg, sd, x, value, probs, aux, logits = _run(tmp_path, hip_lib, name, precision)
@@ -88,25 +94,26 @@ def test_dense_tower_kernel_shapes(tmp_path, hip_lib, name, variant):
     assert np.abs(logits - g["logits"]).max() < logit_tol(tol, g["logits"])
 
 
+@pytest.mark.parametrize("precision", ["float16", "float16x3"])
 @pytest.mark.parametrize("case", ["risev2-7", "alphazero-3-cv8"])
 @pytest.mark.parametrize("batch", [1, 3, 300])
-def test_tower_and_head_kernels_any_batch_size(tmp_path, hip_lib, batch, case):
+def test_tower_and_head_kernels_any_batch_size(tmp_path, hip_lib, batch, case, precision):
     """One workgroup per board: batch sizes below / not a multiple of / above the 256 CUs must all be exact per row
     (bottleneck tower and dense residual tower)."""
     from crazyara_amd.neuralnetapi import HipAPI
     cfg, sd, _ = nn_cases.make_case(case)
     x = nn_cases.synthetic_planes(batch, cfg.nb_input_channels, 4242)
     d = nn_cases.export_case(tmp_path, case, cfg, sd)
-    net = HipAPI(0, batch, d, "float16")
+    net = HipAPI(0, batch, d, precision)
     v, p = np.zeros(batch, np.float32), np.zeros(batch * cfg.nb_policy, np.float32)
     net.predict(np.ascontiguousarray(x.numpy()), v, p)
     net.close()
     o_value, o_logits, _ = ro.forward(cfg, sd, x)
     # dense 3x3 towers contract K = 2304 f16 products per output (9x the 1x1 tower): the oracle's own f16 emulation
     # (sim_dtype=float16) puts the worst of these 300 boards at 0.98e-3 for the value (risev2-7: 0.35e-3) -> 2e-3 here
-    value_tol = 2e-3 if cfg.dense_blocks else TOL["float16"]["value"]
+    value_tol = 2e-3 if cfg.dense_blocks and precision == "float16" else TOL[precision]["value"]
     assert np.abs(v - o_value.numpy().reshape(-1)).max() < value_tol
-    assert np.abs(p.reshape(batch, -1) - torch.softmax(o_logits, 1).numpy()).max() < TOL["float16"]["prob"]
+    assert np.abs(p.reshape(batch, -1) - torch.softmax(o_logits, 1).numpy()).max() < TOL[precision]["prob"]
 
 
 def test_partial_batch_and_stale_slots(tmp_path, hip_lib):
@@ -156,7 +163,8 @@ def test_submit_wait_and_device_resident_paths_agree(tmp_path, hip_lib):
     ("rise-classical-4", "float16", 70), ("rise-classical-4", "float16-perblock", 9), ("alphazero-5", "float16", 33), ("alphazero-3-cv8", "float32", 9),
     ("rise-classical-3-se", "float16", 40), ("alphazero-3-se", "float16", 40), ("risev2-3-flat", "float16", 64), ("risev33-wdlp", "float16", 64),
     ("risev2-7", "float32", 20), ("risev2-7", "float16-perblock", 20), ("risev2-7", "float16-unfused", 20), ("risev33", "float32-unfused", 8),
-    ("risev2-13-lichess", "float16", 64)])
+    ("risev2-13-lichess", "float16", 64), ("risev2-7", "float16x3", 20), ("risev33-wdlp", "float16x3", 9), ("alphazero-3-se", "float16x3", 9),
+    ("risev2-3-flat", "float16x3", 9)])
 def test_every_kernel_family_is_bit_identical_whatever_the_cus_held_before(tmp_path, hip_lib, lds_poison, name, precision, batch):
     """tests/test_fp8.py's call-to-call check (LDS of every CU poisoned with a different pattern before each forward) over the other
     kernel families: dense towers in one launch, per-block and layer-granular kernels, float32, flat and WDLP heads, lichess tables."""
@@ -179,7 +187,7 @@ def test_every_kernel_family_is_bit_identical_whatever_the_cus_held_before(tmp_p
 
 
 @pytest.mark.parametrize("name,precision", [("risev2-7", "float16"), ("risev33-wdlp", "float16"), ("risev2-3-flat", "float16"),
-                                            ("alphazero-5", "float16"), ("risev2-7", "float32")])
+                                            ("alphazero-5", "float16"), ("risev2-7", "float32"), ("risev2-7", "float16x3")])
 def test_zero_copy_predict_equals_copied_predict(tmp_path, hip_lib, name, precision):
     """predict() with the caller's buffers in pinned memory (NeuralNetAPIUser, neuralnetapiuser.cpp:50-60) issues no copy commands: the
     kernels read the planes and write value / probabilities / aux in place.  Same bits as the copy path (pageable numpy buffers),
@@ -312,8 +320,8 @@ def test_onnx_model_directory_loads_and_matches_golden(tmp_path, hip_lib, name, 
     B = x.shape[0]
     tol = TOL["float16"]
     g = np.load(os.path.join(nn_cases.GOLDEN_DIR, f"nn_{name}.npz"))
-    for precision in ("float32", "float16"):
-        net = HipAPI(0, B, d, precision)
+    for precision in ("float32", "float16", "float16x3"):
+        net = HipAPI(0, B, d, precision, keep_logits=True)
         assert net.get_model_name() == fname and net.get_version() == make_version(3, 0)
         assert net.get_nb_policy_values() == cfg.nb_policy and net.get_nb_auxiliary_outputs() == cfg.nb_aux
         assert abs(net.flops_per_position() - ro.flops_per_position(cfg)) < 1.0
@@ -340,8 +348,11 @@ def test_onnx_model_directory_loads_and_matches_golden(tmp_path, hip_lib, name, 
             assert np.array_equal(v2, value) and np.array_equal(p2, probs)
 
 
-def test_headline_configuration_at_full_size(tmp_path, hip_lib):
-    """BASELINE.json config 2 as bench.py runs it: RISEv2-19, batch 256, Precision float16.  Beyond the per-row parity above:
+@pytest.mark.parametrize("precision", ["float16x3", "float16"])
+def test_headline_configuration_at_full_size(tmp_path, hip_lib, precision):
+    """BASELINE.json config 2 as bench.py runs it: RISEv2-19, batch 256, Precision float16x3 (the headline: the fast mode that meets
+    north_star's 1e-3 on the logits -- held to 1e-4 here) and Precision float16 (the reference's TensorRT default; its logits miss 1e-3,
+    bound as measured).  Beyond the per-row parity above:
     rows 0-3 are the committed reference golden's inputs (they must come out as in the 4-board fixture), every row matches the oracle,
     and the size-independent properties hold: probabilities sum to one, values inside the tanh range, a permuted batch gives the
     permuted outputs bit for bit (one workgroup per board, no cross-row arithmetic)."""
@@ -351,17 +362,17 @@ def test_headline_configuration_at_full_size(tmp_path, hip_lib):
     x = nn_cases.synthetic_planes(B, cfg.nb_input_channels, 777).numpy()
     x[:4] = xg.numpy()
     d = nn_cases.export_case(tmp_path, "risev2-19", cfg, sd)
-    net = HipAPI(0, B, d, "float16")
+    net = HipAPI(0, B, d, precision, keep_logits=True)
     v, p = np.zeros(B, np.float32), np.zeros(B * cfg.nb_policy, np.float32)
     net.predict(np.ascontiguousarray(x), v, p)
     logits = torch.as_tensor(net.device_buffers()["logits"], device="cuda").cpu().numpy().copy()
     p = p.reshape(B, -1)
     g = np.load(os.path.join(nn_cases.GOLDEN_DIR, "nn_risev2-19.npz"))
-    tol = TOL["float16"]
+    tol = TOL[precision]
     assert np.abs(v[:4] - g["value"].reshape(-1)).max() < tol["value"]
     assert np.abs(logits[:4] - g["logits"]).max() < logit_tol(tol, g["logits"])
     o_value, o_logits, _ = ro.forward(cfg, sd, torch.from_numpy(x))
-    assert np.abs(logits - o_logits.numpy()).max() < logit_tol(tol, o_logits.numpy())     # measured 3.31e-3 (bound 4.2e-3)
+    assert np.abs(logits - o_logits.numpy()).max() < logit_tol(tol, o_logits.numpy())     # float16: measured 3.31e-3 (bound 4.2e-3)
     assert np.abs(v - o_value.numpy().reshape(-1)).max() < tol["value"]
     assert np.abs(p - torch.softmax(o_logits, 1).numpy()).max() < tol["prob"]
     assert np.allclose(p.sum(axis=1), 1.0, atol=1e-4) and (p >= 0).all() and np.abs(v).max() <= 1.0
@@ -375,7 +386,7 @@ def test_headline_configuration_at_full_size(tmp_path, hip_lib):
     net.close()
 
 
-@pytest.mark.parametrize("precision", ["float32", "float16"])
+@pytest.mark.parametrize("precision", ["float32", "float16", "float16x3"])
 @pytest.mark.parametrize("channels,family", [(128, "mobile"), (192, "mobile"), (512, "mobile"), (128, "a0"), (320, "classical")])
 def test_other_trunk_widths_run_on_the_layer_kernels(tmp_path, hip_lib, channels, family, precision):
     """`channels` is a constructor argument of RiseV3 / AlphaZeroResnet: the fused tower / head kernels are specialised for 256,
@@ -397,7 +408,7 @@ def test_other_trunk_widths_run_on_the_layer_kernels(tmp_path, hip_lib, channels
     sd = ro.make_state_dict(cfg, seed=90 + channels)
     x = nn_cases.synthetic_planes(5, 34, 17)
     d = nn_cases.export_case(tmp_path, cfg.name, cfg, sd)
-    net = HipAPI(0, 5, d, precision)
+    net = HipAPI(0, 5, d, precision, keep_logits=True)
     v, p = np.zeros(5, np.float32), np.zeros(5 * cfg.nb_policy, np.float32)
     net.predict(np.ascontiguousarray(x.numpy()), v, p)
     logits = torch.as_tensor(net.device_buffers()["logits"], device="cuda").cpu().numpy()

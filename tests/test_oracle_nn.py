@@ -56,3 +56,28 @@ def test_oracle_equals_live_reference(has_reference):
     assert float((value - out[0]).abs().max()) < 2e-6
     assert float((logits - out[1]).abs().max()) < 2e-5
     assert float((aux - out[2]).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["risev2-3", "risev2-7", "risev33-wdlp", "alphazero-3-se", "risev2-3-flat", "rise-classical-3-se"])
+def test_float16x3_emulation_is_fp32_to_round_off(name):
+    """Precision float16x3 (crazyara_amd/csrc/nn/x3.hip) is DEFINED by oracle.forward_x3: every dense contraction on hi/lo-split f16
+    operands, three products per term.  Its distance from the pinned fp32 forward is the mode's error: f32 round-off (the GPU tests
+    hold the kernels to 1e-4 against fp32; Precision float16 sits at 1e-3 ... 3e-3 on these cases)."""
+    cfg, sd, x = nn_cases.make_case(name)
+    v, l, a = ro.forward(cfg, sd, x)
+    v3, l3, a3 = ro.forward_x3(cfg, sd, x)
+    assert (l3 - l).abs().max() < 2e-5 and (v3 - v).abs().max() < 5e-6
+    if a is not None:
+        assert (a3 - a).abs().max() < 5e-6
+    v16, l16, _ = ro.forward(cfg, sd, x, sim_dtype=torch.float16)
+    assert (l16 - l).abs().max() > 20 * (l3 - l).abs().max()        # and two orders of magnitude inside the plain f16 emulation
+
+
+def test_float16x3_split_carries_22_bits():
+    """hi + lo of the split reproduces a float to 2^-22 relative (2^-25 absolute where lo is an f16 subnormal)."""
+    g = torch.Generator().manual_seed(3)
+    for scale in (4.0, 1.0, 0.05, 1e-3):
+        t = torch.randn(20000, generator=g) * scale
+        hi, lo = ro._split_f16(t)
+        err = (hi + lo - t.double()).abs()
+        assert (err <= torch.maximum(t.double().abs() * 2.0 ** -22, torch.tensor(2.0 ** -25, dtype=torch.float64))).all()

@@ -233,7 +233,7 @@ def config_search_legs(args, device, threads):
         for n in nets:
             n.close()
 
-    cz = [(f, False, "crazyhouse") for f in openings.position_fens("crazyhouse")]
+    cz = [(f, False, "crazyhouse") for f in openings.crazyhouse_opening_set()]
     # config 1: the crazyhouse start position (then the rest of the opening set, one position per round), ONE tree, batch 8
     leg("config1", "crazyhouse start position + opening set one at a time, RISEv2-7, batch 8, 800 simulations, ONE tree (a single UCI go)",
         rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 1, 8, 800, cz, 1)
@@ -257,6 +257,12 @@ def config_search_legs(args, device, threads):
         1600, cz, 1, shared=8)
     leg("config2_one_tree_shared_6400", "the same with 6400 simulations per go (a longer think)",
         rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 2, 32, 6400, cz, 1, shared=8)
+    # CrazyAra::benchmark on its own position table (one tree, one go per position)
+    nets = nets_for(rise_config.rise_v2_config(19, 34, 81), "1.0", 256, 2, seed=31)
+    st_b = search.default_settings(mode=0, version_major=1, batch_size=32)
+    out["benchmark_positions"] = searchbench.benchmark_positions_leg(st_b, nets, 3200, min(threads, 16), shared_collectors=8)
+    for n in nets:
+        n.close()
     chess = [(f, False, "chess") for f in openings.position_fens("chess")]
     leg("config3", "standard chess calibration-game positions, RISEv3.3, batch 512, 3200 simulations, 2 lanes x 32 trees",
         rise_config.rise_v33_config(52, 76, False), "3.0", 1, 512, 2, 16, 3200, chess, 64)
@@ -487,7 +493,8 @@ def main():
         lanes = max(1, args.search_lanes)
         st = search.default_settings(mode=0, version_major=1, batch_size=args.search_quota)
         n_trees = lanes * max(1, args.batch // args.search_quota)
-        positions = [(f, False, "crazyhouse") for f in openings.position_fens("crazyhouse")]
+        # the fixed crazyhouse opening set: the 50 openings of zh-50_startpos.pgn + every position of the two calibration games
+        positions = [(f, False, "crazyhouse") for f in openings.crazyhouse_opening_set()]
         # host budget of this rank: its slice of the node's CPUs (near its GPU when the topology is known), threads <= that slice.
         # `threads` counts the driving thread; one tree of a lane per thread is the fastest split, so with 16 trees per lane anything
         # below 16 makes one thread do two trees per batch

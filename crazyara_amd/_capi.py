@@ -30,6 +30,7 @@ SIGNATURES = {
     "mi_net_wait": (C.c_int, [C.c_void_p]),
     "mi_net_device_buffers": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5),
     "mi_net_keep_logits": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_net_block_dump": (C.c_void_p, [C.c_void_p, c_int_p]),
     "mi_net_forward_device": (C.c_int, [C.c_void_p]),
     "mi_net_sync": (C.c_int, [C.c_void_p]),
     "mi_net_stream": (C.c_void_p, [C.c_void_p]),

@@ -115,6 +115,12 @@ int mi_net_keep_logits(mi_net* net, int on) {
     net->net.keep_logits(on != 0);
     return 0;
 }
+void* mi_net_block_dump(mi_net* net, int* n_tiles) {
+    if (!net) { g_err = "null net"; return nullptr; }
+    void* p = nullptr;
+    if (guard([&] { p = net->net.enable_block_dump(n_tiles); })) return nullptr;
+    return p;
+}
 int mi_net_forward_device(mi_net* net) {
     if (!net) { g_err = "null net"; return 1; }
     return guard([&] { net->net.forward_async(); });

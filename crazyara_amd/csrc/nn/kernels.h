@@ -117,6 +117,8 @@ struct TowerArgs {
                           // each closed by 8 loads of zeros.  Weights divided by a power of two per row (max |w_q| in [1, 2)): the expand
                           // scale is folded into the depthwise weights, bstream = b1 / s1, b3 = b3 / s3
     long long wstream_e_frags;
+    void* block_dump;     // test hook (mi_net_block_dump), else nullptr: f16 [nblocks + 1][B][64][256] -- tile 0 = the residual stream as the
+                          // tower received it, tile i + 1 = the stream behind block i (before the next block's SE gate scales it)
 };
 void launch_tower(const TowerArgs& a, hipStream_t s);
 void init_tower_kernel_attributes();

@@ -1544,6 +1544,31 @@ void RiseNet::predict(const float* in_planes, float* value, float* probs, float*
     wait();
 }
 
+void* RiseNet::enable_block_dump(int* n_tiles) {
+    HIP_CHECK(hipSetDevice(device_));
+    Op* tower = nullptr;
+    for (Op& op : impl_->ops)
+        if (op.kind == OpKind::Tower || op.kind == OpKind::Forward) {
+            if (tower) throw std::runtime_error("block dump: more than one tower launch in this net");
+            tower = &op;
+        }
+    if (!tower) throw std::runtime_error("block dump: this net / precision does not run the one-launch bottleneck tower");
+    const int tiles = tower->tw.nblocks + 1;
+    if (!tower->tw.block_dump) {
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        tower->tw.block_dump = impl_->dalloc(size_t(tiles) * design_.batch * kSquares * 256 * sizeof(half_t));
+        if (launches_ > 1) {                 // forwards of several launches replay a captured graph: capture again with the pointer set
+            if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+            if (graph_) (void)hipGraphDestroy(graph_);
+            graph_exec_ = nullptr;
+            graph_ = nullptr;
+            capture();
+        }
+    }
+    if (n_tiles) *n_tiles = tiles;
+    return tower->tw.block_dump;
+}
+
 uint8_t float_to_e4m3(float v) { return to_e4m3(double(v)); }
 
 }  // namespace cra

@@ -767,6 +767,16 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
 
     half_t* t1 = reinterpret_cast<half_t*>(smem + TW_T1_OFF);
     half_t* t2 = reinterpret_cast<half_t*>(smem + TW_T2_OFF);
+    // test hook: the stream tile as it stands behind a workgroup barrier -> block_dump[tile][b] (all 512 threads, both roles call it at
+    // the same points; nothing writes the tile before the next barrier)
+    auto dump_tile = [&](int tile) {
+        if (a.block_dump == nullptr) return;
+        half_t* db = reinterpret_cast<half_t*>(a.block_dump) + (size_t(tile) * a.batch + b) * 64 * C;
+        for (int i = tid; i < 64 * 32; i += 512) {
+            const int r = i >> 5, v = i & 31;
+            *reinterpret_cast<uint4*>(db + size_t(r) * C + v * 8) = *reinterpret_cast<const uint4*>(xs + r * XROW + v * 8);
+        }
+    };
 
     // The two roles run completely separate control flow (same barrier sequence), so that neither carries the other's
     // register state.  Per block: [SE gate, all threads] then intervals k = -1 .. n, one barrier each:
@@ -791,6 +801,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
         load_bias(bias, bp);
         load_board();
         __syncthreads();
+        dump_tile(0);
         TW_STAMP();
         // per-lane LDS addresses: B-operand fragments (row lane%32 of a 32-square tile, k offset (lane/32)*8), my t1 store slot
         const half_t* xsr = xs + l31 * XROW + lh * 8;
@@ -891,6 +902,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                 }
             }
             __syncthreads();
+            dump_tile(blk + 1);
             TW_STAMP();
         }
     } else {
@@ -971,6 +983,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
         }
         load_board();
         __syncthreads();
+        dump_tile(0);
         TW_STAMP();
         for (int blk = 0; blk < a.nblocks; ++blk) {
             const TowerBlockDesc& d = a.blocks[blk];
@@ -1041,6 +1054,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
             if (trc) { trc[trn++] = __builtin_amdgcn_s_memtime() - bwait; bwait = 0; }
             TW_STAMP();
             __syncthreads();             // the matrix waves' block epilogue
+            dump_tile(blk + 1);
             TW_STAMP();
         }
         pf_sink ^= pf_old;

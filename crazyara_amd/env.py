@@ -78,6 +78,22 @@ class Position:
         self.push(m)
         return True
 
+    def san_to_move(self, san: str) -> int:
+        """The legal move whose SAN (Board::pgn_move form, mi_pos_move_to_san) is `san`; check / mate marks and "e.p." are ignored, 0 if
+        none matches.  The inverse a PGN opening book needs (zh-50_startpos.pgn)."""
+        want = san.rstrip("+#!?").replace("e.p.", "").strip()
+        for m in self.legal_moves():
+            if self.move_san(m).rstrip("+#") == want:
+                return m
+        return 0
+
+    def push_san(self, san: str) -> bool:
+        m = self.san_to_move(san)
+        if not m:
+            return False
+        self.push(m)
+        return True
+
     def terminal(self) -> int:
         return self._lib.mi_pos_terminal(self._h)
 

@@ -129,6 +129,15 @@ class HipAPI:
             out["aux"] = _DevArray(p[4].value, (B, self._nb_aux))
         return out
 
+    def block_dump(self):
+        """Test hook (mi_net_block_dump): device view [blocks + 1][B][64][256] float16 of the residual stream in front of the tower's first
+        block and behind every block, filled by every forward from now on."""
+        n = C.c_int()
+        p = self._lib.mi_net_block_dump(self._h, C.byref(n))
+        if not p:
+            raise RuntimeError(_capi.last_error())
+        return _DevArray(p, (n.value, self.input_shape[0], 64, 256), "<f2")
+
     def forward_device(self) -> None:
         if self._lib.mi_net_forward_device(self._h):
             raise RuntimeError(_capi.last_error())

@@ -84,3 +84,34 @@ def variant_positions(variant: str, base_variant: str = "chess", max_positions: 
                 seen.add(f)
                 out.append((f, is960, variant))
     return out[:max_positions] if max_positions else out
+
+
+def benchmark_positions_leg(st, nets: Sequence, simulations: int, threads: int, shared_collectors: int = 8) -> dict:
+    """`CrazyAra::benchmark` (engine/src/uci/crazyara.cpp:287-330) on its own position table (engine/tests/benchmarkpositions.cpp:31-49):
+    one `go` per position on ONE tree, and the command's summary -- passed (best move != the table's blunder move), NPS average and
+    median over the positions (EvalInfo::calculate_nps, evalinfo.cpp:73-80), average PV depth.  The reference limits each `go` by
+    movetime; a simulation limit makes the leg repeatable.  With random-init weights "passed" says nothing about strength -- it is
+    reported because the command reports it."""
+    from . import openings
+    table = openings.benchmark_positions()
+    pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1] if len(nets) > 1 else None)
+    pool.add_position(table[0]["fen"], False, "crazyhouse")
+    if shared_collectors:
+        pool.set_shared_collectors(shared_collectors)
+    pool.run(simulations=min(200, simulations), threads=threads)
+    nps, depth, passed, alt, nodes, seconds = [], [], 0, 0, 0, 0.0
+    for t in table:
+        pool.reset_position(0, t["fen"], False, "crazyhouse")
+        s = pool.run(simulations=simulations, threads=threads)
+        nps.append(s.nodes / max(s.seconds, 1e-9))
+        nodes, seconds = nodes + s.nodes, seconds + s.seconds
+        depth.append(len(pool.pv(0)["pv"]))
+        best = pool.best_move(0)
+        passed += best != t["blunder"]
+        alt += best == t["alternative"]
+    pool.close()
+    return {"positions": len(table), "passed": int(passed), "alternative_played": int(alt), "nps_avg": round(sum(nps) / len(nps), 1),
+            "nps_median": round(sorted(nps)[len(nps) // 2], 1), "pv_depth_avg": round(sum(depth) / len(depth), 2),
+            "mcts_nodes_per_sec": round(nodes / max(seconds, 1e-9), 1), "simulations_per_go": simulations,
+            "collectors_per_tree_and_lane": shared_collectors or None, "lanes": len(nets), "batch": nets[0].get_batch_size(),
+            "workload": "CrazyAra::benchmark: the crazyhouse blunder-check positions of engine/tests/benchmarkpositions.cpp, one go each on ONE tree"}

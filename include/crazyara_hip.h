@@ -90,6 +90,11 @@ int mi_net_device_buffers(mi_net* net, float** d_planes, float** d_value, float*
 /* d_logits is test / analysis output (predict's contract is the softmaxed vector): forwards write it only after mi_net_keep_logits(net, 1)
  * (the one-launch head keeps the logits in LDS otherwise; nets whose heads run as separate launches always have it). */
 int mi_net_keep_logits(mi_net* net, int on);
+/* Test hook of the one-launch bottleneck tower (Precision float16 / fp8 on 256-channel RISE nets): from this call on every forward also
+ * stores the f16 residual stream in front of the first block and behind every block.  Returns the device buffer
+ * [*n_tiles = blocks + 1][batch][64][256] f16 (NULL + mi_last_error when the net does not run that kernel).  What a parity test needs to
+ * check a reduced-precision mode block by block (tests/test_fp8.py) -- the reference has no counterpart. */
+void* mi_net_block_dump(mi_net* net, int* n_tiles);
 int mi_net_forward_device(mi_net* net);          /* hipGraph replay on the net stream, asynchronous */
 int mi_net_sync(mi_net* net);                    /* hipStreamSynchronize(net stream) */
 void* mi_net_stream(mi_net* net);                /* the hipStream_t */

@@ -180,6 +180,48 @@ def _depthwise_f16_chain(t, w, b, k):
     return acc.float()
 
 
+def _se_gate(sd, p, se, h, f16_weights=False):
+    """hard-sigmoid channel gate of block p on the stream h (builder_util.py:49-114); f16_weights: the gate matrices rounded to f16 as the
+    tower kernel holds them (f32 accumulation)"""
+    q = (lambda t: t.to(torch.float16).to(torch.float32)) if f16_weights else (lambda t: t)
+    y = h.mean(dim=(2, 3))
+    if se in ("ca_se", "se"):
+        return F.hardsigmoid(F.linear(F.relu(F.linear(y, q(sd[p + ".se.fc.0.weight"]))), q(sd[p + ".se.fc.2.weight"])))
+    w = sd[p + ".se.body.0.weight"]
+    return F.hardsigmoid(F.conv1d(y[:, :, None], q(w), sd[p + ".se.body.0.bias"], padding=w.shape[2] // 2)[:, :, 0])
+
+
+@torch.no_grad()
+def fp8_block(cfg: RiseConfig, sd, i: int, h: torch.Tensor, se_f16_weights=False):
+    """Block i of Precision fp8 from the f16 stream h in front of it (its SE gate included) -> the f16 stream behind it."""
+    qh = lambda t: t.to(torch.float16).to(torch.float32)
+    k, se = cfg.kernels[i], cfg.se_types[i]
+    p = f"{cfg.key_prefix}.{i + 1}"
+    if se is not None:
+        h = qh(h * _se_gate(sd, p, se, h, se_f16_weights)[:, :, None, None])
+    w1, b1 = _fold(sd, p + ".body.0", p + ".body.1")
+    w2, b2 = _fold(sd, p + ".body.3", p + ".body.4")
+    w3, b3 = _fold(sd, p + ".body.6", p + ".body.7")
+    s1, s3 = row_scale_pow2(w1), row_scale_pow2(w3)
+    t = F.conv2d(q_e4m3(h), q_e4m3((w1 / s1.view(-1, 1, 1, 1)).float())) + (b1 / s1).float().view(1, -1, 1, 1)
+    t = qh(F.relu(t))                                                            # t1 in units of s1
+    t = q_e4m3(F.relu(_depthwise_f16_chain(t, (w2 * s1.view(-1, 1, 1, 1)).float(), b2.float(), k)))
+    t = F.conv2d(t, q_e4m3((w3 / s3.view(-1, 1, 1, 1)).float())) + (b3 / s3).float().view(1, -1, 1, 1)
+    return qh(h + t * s3.float().view(1, -1, 1, 1))
+
+
+@torch.no_grad()
+def fp32_block(cfg: RiseConfig, sd, i: int, h: torch.Tensor):
+    """Block i of the pinned fp32 forward from the stream h in front of it (the bottleneck branch of forward(), one block)."""
+    k, se = cfg.kernels[i], cfg.se_types[i]
+    p = f"{cfg.key_prefix}.{i + 1}"
+    if se is not None:
+        h = h * _se_gate(sd, p, se, h)[:, :, None, None]
+    t = F.relu(_bn(sd, p + ".body.1", F.conv2d(h, sd[p + ".body.0.weight"])))
+    t = F.relu(_bn(sd, p + ".body.4", F.conv2d(t, sd[p + ".body.3.weight"], padding=k // 2, groups=t.shape[1])))
+    return h + _bn(sd, p + ".body.7", F.conv2d(t, sd[p + ".body.6.weight"]))
+
+
 @torch.no_grad()
 def forward_fp8_tower(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor):
     """(value, policy logits, aux) of Precision fp8 as emulated on the CPU (bottleneck-block nets only)."""
@@ -192,27 +234,8 @@ def forward_fp8_tower(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Ten
     # order of operations wherever it is cheap to)
     w0, b0 = _fold(sd, pre + ".0.body.0", pre + ".0.body.1")
     h = qh(F.relu(F.conv2d(qh(x), qh(w0.float()), padding=1) + b0.float().view(1, -1, 1, 1)))
-    for i, (k, se) in enumerate(zip(cfg.kernels, cfg.se_types)):
-        p = f"{pre}.{i + 1}"
-        if se in ("ca_se", "se"):
-            y = h.mean(dim=(2, 3))
-            y = F.hardsigmoid(F.linear(F.relu(F.linear(y, sd[p + ".se.fc.0.weight"])), sd[p + ".se.fc.2.weight"]))
-            h = qh(h * y[:, :, None, None])
-        elif se == "eca_se":
-            y = h.mean(dim=(2, 3))
-            w = sd[p + ".se.body.0.weight"]
-            y = F.hardsigmoid(F.conv1d(y[:, :, None], w, sd[p + ".se.body.0.bias"], padding=w.shape[2] // 2)[:, :, 0])
-            h = qh(h * y[:, :, None, None])
-        w1, b1 = _fold(sd, p + ".body.0", p + ".body.1")
-        w2, b2 = _fold(sd, p + ".body.3", p + ".body.4")
-        w3, b3 = _fold(sd, p + ".body.6", p + ".body.7")
-        s1, s3 = row_scale_pow2(w1), row_scale_pow2(w3)
-        t = F.conv2d(q_e4m3(h), q_e4m3((w1 / s1.view(-1, 1, 1, 1)).float())) + (b1 / s1).float().view(1, -1, 1, 1)
-        t = qh(F.relu(t))                                                            # t1 in units of s1
-        cop = t.shape[1]
-        t = q_e4m3(F.relu(_depthwise_f16_chain(t, (w2 * s1.view(-1, 1, 1, 1)).float(), b2.float(), k)))
-        t = F.conv2d(t, q_e4m3((w3 / s3.view(-1, 1, 1, 1)).float())) + (b3 / s3).float().view(1, -1, 1, 1)
-        h = qh(h + t * s3.float().view(1, -1, 1, 1))
+    for i in range(len(cfg.kernels)):
+        h = fp8_block(cfg, sd, i, h)
     return _heads(cfg, sd, h, torch.float16)
 
 

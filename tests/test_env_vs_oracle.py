@@ -199,3 +199,23 @@ def test_state_tests_of_the_reference_random_games(hip_lib, variant, seed):
     assert b.terminal() == t                                            # the oracle agrees on the verdict of the final position
     if t == 0:
         assert not moves or variant in ("atomic", "antichess", "horde", "racingkings", "kingofthehill", "3check")   # LOSS: mated or variant rule
+
+
+def test_reference_position_sets_load():
+    """The fixed sets SURVEY 8d names: the blunder-check FENs of engine/tests/benchmarkpositions.cpp (pockets as "[QNbpp]" and as a 9th
+    slash field) parse, their blunder / alternative moves are legal moves of the position (so pockets, side and castling were read as the
+    reference means them), and the 50 SAN openings of zh-50_startpos.pgn replay from the start position."""
+    from crazyara_amd import env, openings
+    pos = openings.benchmark_positions()
+    assert len(pos) == 15
+    for t in pos:
+        p = env.Position(t["fen"], False, "crazyhouse")
+        legal = set(p.legal_uci())
+        assert t["blunder"] in legal, (t["fen"], t["blunder"])
+        assert t["alternative"] in legal, (t["fen"], t["alternative"])
+        b = co.Board(t["fen"], False, "crazyhouse")
+        assert sorted(b.move_uci(m) for m in b.legal_moves()) == sorted(legal)
+    fens = openings.zh50_fens()
+    assert len(fens) == 50 and len(set(fens)) >= 49          # two of the file's lines end in the same position
+    assert fens[0].startswith("rnbqkbnr/pppppppp/8/8/4P3/8/PPPP1PPP/RNBQKBNR")
+    assert len(openings.crazyhouse_opening_set()) > 200

@@ -174,3 +174,69 @@ def test_fp8_is_refused_where_the_tower_kernel_does_not_run(tmp_path, hip_lib):
     with pytest.raises(RuntimeError, match="fp8"):
         HipAPI(0, 4, d, "fp8")
     HipAPI(0, 4, d, "float16").close()
+
+
+def _f16_ulp(t):
+    """spacing of f16 values around |t| (2^-24 in the subnormal range)"""
+    e = torch.floor(torch.log2(t.abs().clamp_min(2.0 ** -14)))
+    return torch.exp2(e - 10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,batch", [("risev2-19", 6), ("risev33", 5), ("risev2-13-lichess", 3), ("risev33-wdlp", 3)])
+def test_fp8_tower_block_by_block_teacher_forced(tmp_path, hip_lib, name, batch):
+    """Pins Precision fp8 BLOCK BY BLOCK (a deep net cannot be compared end to end: a one-ulp difference of the f16 stream is amplified
+    by the next e4m3 rounding to the size of the mode's own error).  The kernel stores its f16 residual stream in front of every block
+    (mi_net_block_dump); block i is then emulated from the kernel's OWN input of block i (oracle.fp8_block: SE gate, e4m3 expand,
+    f16 depthwise chain, e4m3 project, f16 sum) and must give the kernel's output of block i: every element within a tenth of that block's
+    mode error (|fp8 emulation - fp32 block| on the same input) plus one f16 spacing of the value (an f32 sum that lands on the other
+    side of a rounding point).  A wrong scale, a mis-indexed fragment or a skipped tap in ANY block -- 3 x 3 and 5 x 5 depthwise, both SE
+    kinds, 34 / 52 / 80-channel stems -- moves whole channels by the mode error or more."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    factory, seed, stress, _ = nn_cases.CASES[name]
+    cfg = factory()
+    sd = ro.make_state_dict(cfg, seed=seed, stress=stress)
+    x = nn_cases.synthetic_planes(batch, cfg.nb_input_channels, seed + 3000)
+    d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
+    net = HipAPI(0, batch, d, "fp8")
+    dump = net.block_dump()
+    v, p = np.zeros(batch, np.float32), np.zeros(batch * cfg.nb_policy, np.float32)
+    net.predict(np.ascontiguousarray(x.numpy()), v, p)
+    tiles = torch.as_tensor(dump, device="cuda").cpu().float()                  # [blocks + 1][B][64 squares][256 channels]
+    net.close()
+    assert tiles.shape[0] == len(cfg.kernels) + 1 and torch.isfinite(tiles).all()
+    nchw = lambda t: t.permute(0, 2, 1).reshape(batch, 256, 8, 8).contiguous()
+    worst = []
+    for i in range(len(cfg.kernels)):
+        h_in, h_gpu = nchw(tiles[i]), nchw(tiles[i + 1])
+        h_emu = ro.fp8_block(cfg, sd, i, h_in, se_f16_weights=True)
+        mode = float((h_emu - ro.fp32_block(cfg, sd, i, h_in)).abs().max())
+        assert mode > 1e-3, (i, mode)                                            # the roundings are there
+        excess = (h_gpu - h_emu).abs() - _f16_ulp(h_emu)
+        worst.append(float(excess.max()) / mode)
+        assert float(excess.max()) <= 0.1 * mode, (name, i, float(excess.max()), mode)
+        assert float(((h_gpu - h_emu).abs() > 0).float().mean()) < 0.25, (name, i)      # and most elements are bit-equal
+    print(f"{name}: worst (|gpu - emulation| - ulp) / block mode error over {len(worst)} blocks = {max(worst):.3f}")
+
+
+@pytest.mark.gpu
+def test_float16_tower_block_by_block_against_the_oracle(tmp_path, hip_lib):
+    """The same hook on Precision float16: every block of RISEv2-19, teacher-forced from the kernel's own f16 input, against the fp32
+    block of the oracle -- per-block error at the f16 level (K = 256 ... 1280 products of f16 operands), no accumulation along the depth."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, _ = nn_cases.make_case("risev2-19")
+    batch = 5
+    x = nn_cases.synthetic_planes(batch, cfg.nb_input_channels, 4100)
+    d = nn_cases.export_case(tmp_path, "risev2-19", cfg, sd)
+    net = HipAPI(0, batch, d, "float16")
+    dump = net.block_dump()
+    v, p = np.zeros(batch, np.float32), np.zeros(batch * cfg.nb_policy, np.float32)
+    net.predict(np.ascontiguousarray(x.numpy()), v, p)
+    tiles = torch.as_tensor(dump, device="cuda").cpu().float()
+    net.close()
+    nchw = lambda t: t.permute(0, 2, 1).reshape(batch, 256, 8, 8).contiguous()
+    for i in range(len(cfg.kernels)):
+        h_in, h_gpu = nchw(tiles[i]), nchw(tiles[i + 1])
+        h_32 = ro.fp32_block(cfg, sd, i, h_in)
+        err = (h_gpu - h_32).abs() - _f16_ulp(h_32)
+        assert float(err.max()) < 3e-3 * max(1.0, float(h_32.abs().max())), (i, float(err.max()))

@@ -573,7 +573,7 @@ def main():
         flops_total = net.flops_per_position() * args.batch
         # algorithmic FLOPs of the dominant kernel's launches (1x1 expand/project GEMMs + depthwise of all blocks)
         cops = cfg.channels_operating()
-        if dom in ("fused_block", "tower", "block_x3"):
+        if dom in ("fused_block", "tower", "block_x3", "tower_x3"):
             dom_flops = sum(2.0 * 64 * c * (2 * cfg.channels + 9) for c in cops) * args.batch
         elif dom == "conv_gemm_1x1":
             dom_flops = sum(2.0 * 64 * cfg.channels * c * 2 for c in cops) * args.batch

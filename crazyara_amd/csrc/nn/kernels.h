@@ -70,6 +70,27 @@ void launch_conv_gemm_x3(const ConvArgs& a, hipStream_t s);
 void launch_block_x3(const BlockArgs& a, hipStream_t s);          // needs dwpk, w1pk_lo, w3pk_lo; ks == 3
 void init_x3_kernel_attributes();
 int block_x3_chunk_channels();
+// a run of consecutive 3x3 bottleneck blocks in one launch (x3.hip: tower_x3_kernel): the residual stream stays in LDS as a hi / lo f16
+// pair, the SE gate of every block but the first is computed in-kernel from float weights (the first block's gate, if any, is applied
+// by the caller's SE launch)
+struct X3TowerBlock {
+    const void *w1pk, *w1pk_lo, *w3pk, *w3pk_lo;     // as BlockArgs
+    const float* dwpk;                               // [cop_pad][12]
+    const float* b3;                                 // [256]
+    const float* se_w1t;                             // ca_se: [256][128] transposed; eca_se: [256][256] transposed centre tap
+    const float* se_w2t;                             // ca_se: [128][256] transposed
+    const float* se_b;                               // eca_se: [256]
+    int cop_pad;                                     // multiple of block_x3_chunk_channels()
+    int se_kind;                                     // 0 none, 1 ca_se, 2 eca_se
+};
+struct X3TowerArgs {
+    const float* x;       // [B][64][256]
+    float* y;             // [B][64][256]
+    const X3TowerBlock* blocks;   // device array
+    int nblocks;
+    int batch;
+};
+void launch_tower_x3(const X3TowerArgs& a, hipStream_t s);
 template <typename T> void init_block_kernel_attributes();
 template <typename T> int block_chunk_channels();   // C_op must be padded to a multiple of this
 

@@ -118,7 +118,7 @@ SplitPack pack_dense_split(const Folded& f, int cout, int cin, int ks, int cout_
     return SplitPack{pack_dense<half_t>(fh, cout, cin, ks, cout_pad, cin_pad), pack_dense<half_t>(fl, cout, cin, ks, cout_pad, cin_pad)};
 }
 
-enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower, Forward };
+enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower, Forward, TowerX3 };
 
 struct Op {
     OpKind kind;
@@ -135,6 +135,7 @@ struct Op {
     HeadArgs hd{};
     ResTowerArgs rt{};
     StemArgs st{};
+    X3TowerArgs tx{};
 };
 }  // namespace
 
@@ -481,6 +482,22 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
         im.ops.push_back(op);
     };
+    // Precision float16x3: runs of consecutive 3x3 blocks in one launch (x3.hip: tower_x3_kernel)
+    std::vector<X3TowerBlock> x3_blocks;
+    auto flush_x3_tower = [&]() {
+        if (x3_blocks.empty()) return;
+        Op op;
+        op.kind = OpKind::TowerX3;
+        op.tx.x = reinterpret_cast<const float*>(cur);
+        op.tx.y = reinterpret_cast<float*>(nxt);
+        op.tx.blocks = im.upload(x3_blocks);
+        op.tx.nblocks = int(x3_blocks.size());
+        op.tx.batch = B;
+        im.ops.push_back(op);
+        x3_blocks.clear();
+        prod_op = -1;                      // this launch does not emit channel sums: a gate behind it is an SE launch of its own
+        std::swap(cur, nxt);
+    };
     auto to_half = [](const std::vector<float>& v) {
         std::vector<half_t> h(v.size());
         for (size_t i = 0; i < v.size(); ++i) h[i] = half_t(v[i]);
@@ -613,13 +630,21 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         if (!in_tower) flush_tower();
         const bool se_in_kernel = in_tower && !tower_blocks.empty();
         TowerBlockDesc td{};
+        const bool in_x3_tower = x3_ && tower_ && fused_ && C == 256 && k == 3;
+        if (!in_x3_tower) flush_x3_tower();
+        const bool x3_se_in_kernel = in_x3_tower && !x3_blocks.empty();       // the first block of a run takes its gate from an SE launch
+        X3TowerBlock xb{};
         if (se_types[i] == "ca_se" || se_types[i] == "se") {           // _ChannelAttentionModule, builder_util.py:83-114
             const TensorView &w1 = nf.get(p + ".se.fc.0.weight"), &w2 = nf.get(p + ".se.fc.2.weight");
             const int H = C / 2;
             std::vector<float> w1t(size_t(C) * H), w2t(size_t(H) * C);
             for (int j = 0; j < H; ++j) for (int c = 0; c < C; ++c) w1t[size_t(c) * H + j] = w1.data[size_t(j) * C + c];
             for (int c = 0; c < C; ++c) for (int j = 0; j < H; ++j) w2t[size_t(j) * C + c] = w2.data[size_t(c) * H + j];
-            if (se_in_kernel) {
+            if (x3_se_in_kernel) {
+                xb.se_kind = 1;
+                xb.se_w1t = im.upload(w1t);
+                xb.se_w2t = im.upload(w2t);
+            } else if (se_in_kernel) {
                 td.se_kind = 1;
                 // FC1: thread t -> outputs 2*(t/8), +1 over inputs c in [32*(t%8), +32); FC2: outputs 2*(t/4), +1 over j in [32*(t%4), +32):
                 // the threads of an output pair are neighbouring lanes (in-wave reduction, tower.hip: se_phase)
@@ -631,7 +656,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 op.w0 = im.upload(w1t);
                 op.w1 = im.upload(w2t);
                 op.C = C;
-                add_se(op, block_fused(k));
+                add_se(op, block_fused(k) && !in_x3_tower);
             }
             macs += 2.0 * C * H;
         } else if (se_types[i] == "eca_se") {                           // _EfficientChannelAttentionModule, builder_util.py:49-80
@@ -641,7 +666,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             for (int o = 0; o < C; ++o) for (int c = 0; c < C; ++c) wt[size_t(c) * C + o] = w.data[(size_t(o) * C + c) * kk + mid];
             const float* bs = nf.get(p + ".se.body.0.bias").data;
             for (int o = 0; o < C; ++o) b[o] = bs[o];
-            if (se_in_kernel) {
+            if (x3_se_in_kernel) {
+                xb.se_kind = 2;
+                xb.se_w1t = im.upload(wt);
+                xb.se_b = im.upload(b);
+            } else if (se_in_kernel) {
                 td.se_kind = 2;
                 // thread t -> outputs 2*(t/4), +1 over inputs i in [64*(t%4), +64): first 32 inputs, then the second 32
                 std::vector<half_t> pk = pack_se_threads(wt, [](int t, int k) { return size_t((t & 3) * 64 + k) * 128 + (t >> 2); });
@@ -655,7 +684,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 op.w0 = im.upload(wt);
                 op.b0 = im.upload(b);
                 op.C = C;
-                add_se(op, block_fused(k));
+                add_se(op, block_fused(k) && !in_x3_tower);
             }
             macs += double(C) * C;
         } else if (se_types[i] != "none" && !se_types[i].empty()) {
@@ -775,6 +804,27 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 tower_blocks.push_back(td);
                 macs += double(kSquares) * cop * (2.0 * C + k * k);
             }
+        } else if (in_x3_tower) {
+            const int cop_pad = round_up(cop, block_x3_chunk_channels());
+            Folded f1 = fold_bn(nf, p + ".body.0", p + ".body.1");
+            Folded f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
+            Folded f3 = fold_bn(nf, p + ".body.6", p + ".body.7");
+            SplitPack s1 = pack_dense_split(f1, cop, C, 1, cop_pad, C), s3 = pack_dense_split(f3, C, cop, 1, C, cop_pad);
+            xb.w1pk = im.upload(s1.hi);
+            xb.w1pk_lo = im.upload(s1.lo);
+            xb.w3pk = im.upload(s3.hi);
+            xb.w3pk_lo = im.upload(s3.lo);
+            std::vector<float> rec(size_t(cop_pad) * 12, 0.f);      // per channel: 9 taps, BN1 bias, BN2 bias, pad
+            for (int c = 0; c < cop; ++c) {
+                for (int t = 0; t < 9; ++t) rec[size_t(c) * 12 + t] = float(f2.w[size_t(c) * 9 + t]);
+                rec[size_t(c) * 12 + 9] = float(f1.b[c]);
+                rec[size_t(c) * 12 + 10] = float(f2.b[c]);
+            }
+            xb.dwpk = im.upload(rec);
+            xb.b3 = im.upload_d2f(f3.b, C);
+            xb.cop_pad = cop_pad;
+            x3_blocks.push_back(xb);
+            macs += double(kSquares) * cop * (2.0 * C + k * k);
         } else if (block_fused(k)) {
             // fused bottleneck block: expand -> depthwise -> project -> +x in one launch (kernels.hip: block_kernel; x3.hip: block_x3_kernel)
             const int cop_pad = round_up(cop, x3_ ? block_x3_chunk_channels() : block_chunk_channels<T>());
@@ -844,6 +894,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
     }
     flush_tower();
+    flush_x3_tower();
     // value heads with fewer than 8 channels (AlphaZeroResnet: 4) run as 8 with zero rows: ReLU(0) = 0 meets zero FC weights
     const bool head_ok = tower_ok && policy_map && cv >= 1 && cv <= 8 && cp <= 96 && (wdl || fc == 256);
     if (head_ok) {
@@ -1190,6 +1241,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             break;
         }
         case OpKind::ResTower: launch_restower(op.rt, s); break;
+        case OpKind::TowerX3: launch_tower_x3(op.tx, s); break;
         case OpKind::Stem: {
             StemArgs st = op.st;
             st.planes = planes;
@@ -1235,6 +1287,7 @@ const char* RiseNet::op_name(int i) const {
         case OpKind::ResTower: return "restower";
         case OpKind::Stem: return "stem";
         case OpKind::Forward: return "forward";
+        case OpKind::TowerX3: return "tower_x3";
     }
     return "?";
 }

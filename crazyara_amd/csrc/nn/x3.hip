@@ -19,21 +19,43 @@ namespace cra {
 
 namespace {
 
+// (a, b) -> packed f16 pairs hi = rne(a | b), lo = rne((a | b) - hi): 4 instructions (pack-convert, two mix-precision FMAs that read the
+// f16 halves in place, pack-convert) where the compiler's form of the same arithmetic takes about ten.  The difference a - hi is exact.
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    float ra, rb;
+    asm("v_cvt_pk_f16_f32 %0, %3, %4\n\t"
+        "v_fma_mix_f32 %1, %0, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hi), "=&v"(ra), "=&v"(rb)
+        : "v"(a), "v"(b));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(ra), "v"(rb));
+}
 __device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
+    uint32_t h[4], l[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const half_t h = half_t(v[j]);               // round to nearest even
-        hi[j] = h;
-        lo[j] = half_t(v[j] - float(h));             // the difference is exact in f32; its f16 rounding is the mode's error
-    }
+    for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    hi = __builtin_bit_cast(half8, u32x4{h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(half8, u32x4{l[0], l[1], l[2], l[3]});
 }
 __device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo) {
+    uint32_t h[2], l[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const half_t h = half_t(v[j]);
-        hi[j] = h;
-        lo[j] = half_t(v[j] - float(h));
-    }
+    for (int j = 0; j < 2; ++j) split_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(half4, u32x2{h[0], h[1]});
+    lo = __builtin_bit_cast(half4, u32x2{l[0], l[1]});
+}
+
+// acc += w * x[lane -/+ 1 within the 16-lane row] (lanes shifted in from outside the row contribute 0) as ONE instruction: the compiler
+// keeps a v_mov_b32_dpp in front of most of these multiply-adds (88 moves per chunk and wave), VOP2's DPP form takes the shift itself
+__device__ __forceinline__ float fmac_shr1(float acc, float x, float w) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(w));
+    return acc;
+}
+__device__ __forceinline__ float fmac_shl1(float acc, float x, float w) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(w));
+    return acc;
 }
 
 // one product tile: the two cross terms first, the main term last
@@ -189,84 +211,90 @@ void launch_conv_gemm_x3(const ConvArgs& a, hipStream_t s) {
 }
 
 // ================================================================================================================
-// Fused 3x3 mobile-bottleneck block -- block_kernel_dpp (kernels.hip) with split operands: expand (MFMA x3) -> BN1 + ReLU + depthwise
+// Fused 3x3 mobile-bottleneck blocks -- block_kernel_dpp (kernels.hip) with split operands: expand (MFMA x3) -> BN1 + ReLU + depthwise
 // 3x3 + BN2 + ReLU on the f32 accumulators by DPP lane shifts (no LDS round trip, exact f32) -> split -> LDS -> project (MFMA x3)
-// into the register accumulator -> + BN3 bias + x.  8 waves, one board per workgroup; x and y are float [B][64][256].
+// into the register accumulator -> + BN3 bias + x.  8 waves, one board per workgroup.
+//   block_x3_kernel : one block per launch, x and y float [B][64][256] in HBM
+//   tower_x3_kernel : a run of consecutive 3x3 blocks in ONE launch -- the residual stream stays in LDS as its hi / lo f16 pair
+//                     (x to 2^-22) from the first block to the last, SE gates are computed in-kernel (exact f32)
 // ================================================================================================================
 namespace {
 struct X3Block {
-    static constexpr int C = 256, NW = 8, CK = 16 * NW, NTHR = 64 * NW;
+    static constexpr int C = 256, NW = 8, CK = 16 * NW, NTHR = 64 * NW, NJ = C / 16 / NW;
     static constexpr int XROW = C + 16;      // halves; 32-byte row pad (rows step 8 banks: conflict-free 16-row fragment reads)
     static constexpr int TROW = CK + 16;
     static constexpr size_t lds_bytes = (size_t(2) * 64 * XROW + size_t(2) * 64 * TROW) * sizeof(half_t);     // 106,496 B
 };
-}  // namespace
 
-__global__ __launch_bounds__(512) void block_x3_kernel(const BlockArgs a) {
+struct X3Tiles {
+    half_t *xh, *xl;        // [64][XROW] block input = residual stream, hi / lo
+    half_t *t2h, *t2l;      // [64][TROW] depthwise output of the current chunk, hi / lo
+};
+__device__ __forceinline__ X3Tiles x3_tiles(char* smem) {
+    X3Tiles t;
+    t.xh = reinterpret_cast<half_t*>(smem);
+    t.xl = t.xh + 64 * X3Block::XROW;
+    t.t2h = t.xl + 64 * X3Block::XROW;
+    t.t2l = t.t2h + 64 * X3Block::TROW;
+    return t;
+}
+
+// float board tile [64][256] (optionally x := x * gate[c], _ChannelAttentionModule.forward, builder_util.py:114) -> split tiles
+__device__ __forceinline__ void x3_stage_tile(const X3Tiles& T, const float* xb, const float* g, int tid) {
+    constexpr int C = X3Block::C, XROW = X3Block::XROW;
+#pragma unroll 1
+    for (int i = tid; i < 64 * (C / 8); i += X3Block::NTHR) {
+        const int r = i / (C / 8), v = i - r * (C / 8);
+        float f[8];
+        load8<float>(xb + size_t(r) * C + v * 8, f);
+        if (g) {
+            float gv[8];
+            load8<float>(g + v * 8, gv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] *= gv[j];
+        }
+        half8 h, l;
+        split8(f, h, l);
+        *reinterpret_cast<half8*>(T.xh + r * XROW + v * 8) = h;
+        *reinterpret_cast<half8*>(T.xl + r * XROW + v * 8) = l;
+    }
+}
+
+// The chunk loop of one block: accP[j][t] += project(depthwise(expand(x))) for this wave's 32 couts x 64 squares.  The caller has put a
+// barrier behind the last write of the x tiles; the loop ends with a barrier (t2 and x are free to be rewritten).
+struct X3Weights {
+    const half8 *w1h, *w1l, *w3h, *w3l;     // packed expand / project weights, hi / lo (kernels.h: packed-weight geometry), + lane
+    const float* dwpk;                      // [cop_pad][12]: 9 folded taps, BN1 bias, BN2 bias, 0
+    int cop_pad;
+};
+__device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, f32x4 (&accP)[X3Block::NJ][4]) {
     using G = X3Block;
-    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NTHR = G::NTHR, NW = G::NW;
-    constexpr int NJ = C / 16 / NW;                            // 2 cout tiles per wave in the project phase
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* xh = reinterpret_cast<half_t*>(smem);              // [64][XROW] block input, hi
-    half_t* xl = xh + 64 * XROW;                               //                         lo
-    half_t* t2h = xl + 64 * XROW;                              // [64][TROW] depthwise output of the current chunk, hi
-    half_t* t2l = t2h + 64 * TROW;                             //                                                    lo
-
-    const int b = blockIdx.x;
+    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NW = G::NW, NJ = G::NJ;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
-    const int nchunk = a.cop_pad / CK;
-    const int nslab3 = a.cop_pad >> 5;
-    const half8* w1h = reinterpret_cast<const half8*>(a.w1pk) + lane;
-    const half8* w1l = reinterpret_cast<const half8*>(a.w1pk_lo) + lane;
-    const half8* w3h = reinterpret_cast<const half8*>(a.w3pk) + lane;
-    const half8* w3l = reinterpret_cast<const half8*>(a.w3pk_lo) + lane;
+    const int nchunk = W.cop_pad / CK;
+    const int nslab3 = W.cop_pad >> 5;
     const bool hi = l15 >= 8;                                  // second board row of a 16-square tile
     const float mL = (l15 & 7) != 0 ? 1.f : 0.f;               // a left / right neighbour exists on the board
     const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
 
-    half8 e_h[C / 32], e_l[C / 32];                            // expand fragments of the chunk, requested one phase ahead
-    auto prefetch_expand = [&](int ch) {
-        const size_t o = size_t(ch * NW + wave) * (C / 32) * 64;
-#pragma unroll
-        for (int s = 0; s < C / 32; ++s) {
-            e_h[s] = w1h[o + s * 64];
-            e_l[s] = w1l[o + s * 64];
-        }
+    // Weight fragments come through two small rolling windows (a phase's whole set in registers -- 64 + 64 VGPRs -- leaves the
+    // compiler no room in the one-launch tower): the expand window holds 4 of the 8 k-slabs (hi + lo), the project window 2 of 4.
+    // A slot is refilled as soon as its MFMAs are issued, i.e. 4 (2) slabs = ~1k+ cycles ahead of its next use; the first slabs of a
+    // phase are requested a whole phase ahead.
+    constexpr int EW = 4, PW = 2;
+    half8 e_h[EW], e_l[EW];
+    auto load_expand = [&](int ch, int s) {
+        const size_t o = (size_t(ch * NW + wave) * (C / 32) + s) * 64;
+        e_h[s % EW] = W.w1h[o];
+        e_l[s % EW] = W.w1l[o];
     };
-    prefetch_expand(0);
-
-    {   // block input -> split tiles (optionally x := x * gate[b][c], _ChannelAttentionModule.forward, builder_util.py:114)
-        const float* xb = reinterpret_cast<const float*>(a.x) + size_t(b) * 64 * C;
-        const float* g = a.gate ? a.gate + size_t(b) * C : nullptr;
-        for (int i = tid; i < 64 * (C / 8); i += NTHR) {
-            const int r = i / (C / 8), v = i - r * (C / 8);
-            float f[8];
-            load8<float>(xb + size_t(r) * C + v * 8, f);
-            if (g) {
-                float gv[8];
-                load8<float>(g + v * 8, gv);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] *= gv[j];
-            }
-            half8 h, l;
-            split8(f, h, l);
-            *reinterpret_cast<half8*>(xh + r * XROW + v * 8) = h;
-            *reinterpret_cast<half8*>(xl + r * XROW + v * 8) = l;
-        }
-    }
-    __syncthreads();
-
-    f32x4 accP[NJ][4];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) accP[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    for (int s = 0; s < EW; ++s) load_expand(0, s);
     for (int ch = 0; ch < nchunk; ++ch) {
         // per-channel depthwise record of my 4 channels (9 taps, BN1 bias, BN2 bias, 0): lands while the expand MFMAs run
         f32x4 dwr[4][3];
         {
-            const f32x4* dp = reinterpret_cast<const f32x4*>(a.dwpk + size_t(ch * CK + wave * 16 + lg * 4) * 12);
+            const f32x4* dp = reinterpret_cast<const f32x4*>(W.dwpk + size_t(ch * CK + wave * 16 + lg * 4) * 12);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -281,26 +309,29 @@ __global__ __launch_bounds__(512) void block_x3_kernel(const BlockArgs a) {
             half8 bh[4], bl[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                bh[t] = *reinterpret_cast<const half8*>(xh + (t * 16 + l15) * XROW + s * 32 + lg * 8);
-                bl[t] = *reinterpret_cast<const half8*>(xl + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                bh[t] = *reinterpret_cast<const half8*>(T.xh + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                bl[t] = *reinterpret_cast<const half8*>(T.xl + (t * 16 + l15) * XROW + s * 32 + lg * 8);
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_l[s], bh[t], accE[t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_l[s % EW], bh[t], accE[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_h[s], bl[t], accE[t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_h[s % EW], bl[t], accE[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_h[s], bh[t], accE[t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_h[s % EW], bh[t], accE[t], 0, 0, 0);
+            if (s + EW < C / 32) load_expand(ch, s + EW);
         }
-        // this chunk's project fragments: they land while the depthwise runs
-        half8 p_h[CK / 32][NJ], p_l[CK / 32][NJ];
-#pragma unroll
-        for (int s2 = 0; s2 < CK / 32; ++s2)
+        // the first slabs of this chunk's project fragments: they land while the depthwise runs
+        half8 p_h[PW][NJ], p_l[PW][NJ];
+        auto load_project = [&](int s2) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const size_t o = (size_t(wave * NJ + j) * nslab3 + ch * (CK / 32) + s2) * 64;
-                p_h[s2][j] = w3h[o];
-                p_l[s2][j] = w3l[o];
+                p_h[s2 % PW][j] = W.w3h[o];
+                p_l[s2 % PW][j] = W.w3l[o];
             }
+        };
+#pragma unroll
+        for (int s2 = 0; s2 < PW; ++s2) load_project(s2);
 
         // ---------------- D: BN1 + ReLU, depthwise 3x3 on the accumulators (block_kernel_dpp), BN2 + ReLU, exact f32 ----------------
         float outv[4][4];                                       // [tile][channel r]
@@ -323,15 +354,15 @@ __global__ __launch_bounds__(512) void block_x3_kernel(const BlockArgs a) {
                 const float up = hi ? rot[t] : (t > 0 ? rot[t > 0 ? t - 1 : 0] : 0.f);
                 const float dn = hi ? (t < 3 ? rot[t < 3 ? t + 1 : 3] : 0.f) : rot[t];
                 float acc = b2;
-                acc = fmaf(w[0], dpp_mov<DPP_ROW_SHR1>(up), acc);
+                acc = fmac_shr1(acc, up, w[0]);
                 acc = fmaf(w[1], up, acc);
-                acc = fmaf(w[2], dpp_mov<DPP_ROW_SHL1>(up), acc);
-                acc = fmaf(w[3], dpp_mov<DPP_ROW_SHR1>(e[t]), acc);
+                acc = fmac_shl1(acc, up, w[2]);
+                acc = fmac_shr1(acc, e[t], w[3]);
                 acc = fmaf(w[4], e[t], acc);
-                acc = fmaf(w[5], dpp_mov<DPP_ROW_SHL1>(e[t]), acc);
-                acc = fmaf(w[6], dpp_mov<DPP_ROW_SHR1>(dn), acc);
+                acc = fmac_shl1(acc, e[t], w[5]);
+                acc = fmac_shr1(acc, dn, w[6]);
                 acc = fmaf(w[7], dn, acc);
-                acc = fmaf(w[8], dpp_mov<DPP_ROW_SHL1>(dn), acc);
+                acc = fmac_shl1(acc, dn, w[8]);
                 outv[t][r] = fmaxf(acc, 0.f);
             }
         }
@@ -341,36 +372,66 @@ __global__ __launch_bounds__(512) void block_x3_kernel(const BlockArgs a) {
             for (int t = 0; t < 4; ++t) {
                 half4 h, l;
                 split4(outv[t], h, l);
-                *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
-                *reinterpret_cast<half4*>(t2l + (t * 16 + l15) * TROW + cl) = l;
+                *reinterpret_cast<half4*>(T.t2h + (t * 16 + l15) * TROW + cl) = h;
+                *reinterpret_cast<half4*>(T.t2l + (t * 16 + l15) * TROW + cl) = l;
             }
         }
         __syncthreads();
-        if (ch + 1 < nchunk) prefetch_expand(ch + 1);           // lands while the project MFMAs run
+        if (ch + 1 < nchunk) {                                  // the next chunk's first expand slabs land while the project MFMAs run
+#pragma unroll
+            for (int s = 0; s < EW; ++s) load_expand(ch + 1, s);
+        }
         // ---------------- P: project, 32 couts x 64 squares per wave, K = CK (accumulates over chunks) ----------------
 #pragma unroll
         for (int s2 = 0; s2 < CK / 32; ++s2) {
             half8 bh[4], bl[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                bh[t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
-                bl[t] = *reinterpret_cast<const half8*>(t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                bh[t] = *reinterpret_cast<const half8*>(T.t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                bl[t] = *reinterpret_cast<const half8*>(T.t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_l[s2][j], bh[t], accP[j][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_l[s2 % PW][j], bh[t], accP[j][t], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_h[s2][j], bl[t], accP[j][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_h[s2 % PW][j], bl[t], accP[j][t], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_h[s2][j], bh[t], accP[j][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_h[s2 % PW][j], bh[t], accP[j][t], 0, 0, 0);
+            if (s2 + PW < CK / 32) load_project(s2 + PW);
         }
         __syncthreads();                                        // t2 is rewritten by the next chunk's depthwise
     }
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) void block_x3_kernel(const BlockArgs a) {
+    using G = X3Block;
+    constexpr int C = G::C, XROW = G::XROW, NJ = G::NJ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const X3Tiles T = x3_tiles(smem);
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    X3Weights W;
+    W.w1h = reinterpret_cast<const half8*>(a.w1pk) + lane;
+    W.w1l = reinterpret_cast<const half8*>(a.w1pk_lo) + lane;
+    W.w3h = reinterpret_cast<const half8*>(a.w3pk) + lane;
+    W.w3l = reinterpret_cast<const half8*>(a.w3pk_lo) + lane;
+    W.dwpk = a.dwpk;
+    W.cop_pad = a.cop_pad;
+    x3_stage_tile(T, reinterpret_cast<const float*>(a.x) + size_t(b) * 64 * C, a.gate ? a.gate + size_t(b) * C : nullptr, tid);
+    __syncthreads();
+
+    f32x4 accP[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accP[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    x3_chunks(T, W, accP);
 
     // ---------------- epilogue: + BN3 bias + residual (hi + lo of the staged input = x to 2^-22) ----------------
     float* yb = reinterpret_cast<float*>(a.y) + size_t(b) * 64 * C;
@@ -384,8 +445,8 @@ __global__ __launch_bounds__(512) void block_x3_kernel(const BlockArgs a) {
         for (int t = 0; t < 4; ++t) {
             const int sq = t * 16 + l15;
             float rh[4], rl[4], v[4];
-            load4<half_t>(xh + sq * XROW + co0, rh);
-            load4<half_t>(xl + sq * XROW + co0, rl);
+            load4<half_t>(T.xh + sq * XROW + co0, rh);
+            load4<half_t>(T.xl + sq * XROW + co0, rl);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = accP[j][t][r] + bs[r] + (rh[r] + rl[r]);
@@ -403,13 +464,150 @@ __global__ __launch_bounds__(512) void block_x3_kernel(const BlockArgs a) {
     }
 }
 
+// ---- the run of blocks in one launch ----
+namespace {
+// SE gate of a block on the stream in LDS, exact f32 (the arithmetic of se_gate_kernel / se_kernel, kernels.hip): squeeze over the 64
+// squares, ca_se: relu(W1 mean) -> W2 -> hard-sigmoid, eca_se: centre-tap linear + bias -> hard-sigmoid, then x := x * gate, re-split.
+// scratch: 256 + 4 * 256 + 128 + 256 floats (the t2 tiles, idle between blocks).  Ends with a barrier.
+__device__ __forceinline__ void x3_se_phase(const X3Tiles& T, const X3TowerBlock& d, float* scratch, int tid) {
+    constexpr int C = X3Block::C, XROW = X3Block::XROW, H = C / 2;
+    float* mean = scratch;            // [256]
+    float* part = scratch + 256;      // [4][256]
+    float* hid = part + 4 * 256;      // [128]
+    float* gate = hid + 128;          // [256]
+    {   // squeeze: thread = (channel c, half of the squares)
+        const int c = tid & 255, q = tid >> 8;
+        float s = 0.f;
+#pragma unroll 4
+        for (int sq = q * 32; sq < q * 32 + 32; ++sq) s += float(T.xh[sq * XROW + c]) + float(T.xl[sq * XROW + c]);
+        part[q * 256 + c] = s;
+    }
+    __syncthreads();
+    if (tid < 256) mean[tid] = (part[tid] + part[256 + tid]) * (1.f / 64.f);
+    __syncthreads();
+    if (d.se_kind == 1) {
+        {   // FC1: 128 outputs, K = 256 in 4 slices of 64
+            const int j = tid & (H - 1), q = tid >> 7;
+            float s = 0.f;
+#pragma unroll 8
+            for (int c = q * 64; c < q * 64 + 64; ++c) s = fmaf(d.se_w1t[size_t(c) * H + j], mean[c], s);
+            part[q * 256 + j] = s;
+        }
+        __syncthreads();
+        if (tid < H) hid[tid] = fmaxf(part[tid] + part[256 + tid] + part[512 + tid] + part[768 + tid], 0.f);
+        __syncthreads();
+        {   // FC2: 256 outputs, K = 128 in 2 slices of 64
+            const int c = tid & 255, q = tid >> 8;
+            float s = 0.f;
+#pragma unroll 8
+            for (int j = q * 64; j < q * 64 + 64; ++j) s = fmaf(d.se_w2t[size_t(j) * C + c], hid[j], s);
+            part[q * 256 + c] = s;
+        }
+        __syncthreads();
+        if (tid < 256) gate[tid] = hard_sigmoid(part[tid] + part[256 + tid]);
+    } else {
+        {   // eca: 256 outputs, K = 256 in 2 slices of 128
+            const int c = tid & 255, q = tid >> 8;
+            float s = 0.f;
+#pragma unroll 8
+            for (int i = q * 128; i < q * 128 + 128; ++i) s = fmaf(d.se_w1t[size_t(i) * C + c], mean[i], s);
+            part[q * 256 + c] = s;
+        }
+        __syncthreads();
+        if (tid < 256) gate[tid] = hard_sigmoid(d.se_b[tid] + part[tid] + part[256 + tid]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int i = tid; i < 64 * (C / 8); i += X3Block::NTHR) {      // x := x * gate (the residual uses the gated x, builder_util.py:473-475)
+        const int r = i / (C / 8), v = i - r * (C / 8);
+        float fh[8], fl[8], gv[8];
+        load8<half_t>(T.xh + r * XROW + v * 8, fh);
+        load8<half_t>(T.xl + r * XROW + v * 8, fl);
+        load8<float>(gate + v * 8, gv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fh[j] = (fh[j] + fl[j]) * gv[j];
+        half8 h, l;
+        split8(fh, h, l);
+        *reinterpret_cast<half8*>(T.xh + r * XROW + v * 8) = h;
+        *reinterpret_cast<half8*>(T.xl + r * XROW + v * 8) = l;
+    }
+    __syncthreads();
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) void tower_x3_kernel(const X3TowerArgs a) {
+    using G = X3Block;
+    constexpr int C = G::C, XROW = G::XROW, NJ = G::NJ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const X3Tiles T = x3_tiles(smem);
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    x3_stage_tile(T, a.x + size_t(b) * 64 * C, nullptr, tid);
+    __syncthreads();
+    for (int blk = 0; blk < a.nblocks; ++blk) {
+        const X3TowerBlock& d = a.blocks[blk];
+        if (blk > 0 && d.se_kind != 0) x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid);
+        X3Weights W;
+        W.w1h = reinterpret_cast<const half8*>(d.w1pk) + lane;
+        W.w1l = reinterpret_cast<const half8*>(d.w1pk_lo) + lane;
+        W.w3h = reinterpret_cast<const half8*>(d.w3pk) + lane;
+        W.w3l = reinterpret_cast<const half8*>(d.w3pk_lo) + lane;
+        W.dwpk = d.dwpk;
+        W.cop_pad = d.cop_pad;
+        f32x4 accP[NJ][4];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {                          // the project accumulators start at the BN3 bias of their 4 couts
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(d.b3 + (wave * NJ + j) * 16 + lg * 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accP[j][t] = bs;
+        }
+        x3_chunks(T, W, accP);
+        // block epilogue: new stream = x + body(x), split again, in place.  A wave rewrites exactly the columns (its 32 couts) it reads
+        // here, and the chunk loop's closing barrier is behind every other read of the tiles.
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int co0 = (wave * NJ + j) * 16 + lg * 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int sq = t * 16 + l15;
+                float rh[4], rl[4], v[4];
+                load4<half_t>(T.xh + sq * XROW + co0, rh);
+                load4<half_t>(T.xl + sq * XROW + co0, rl);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = accP[j][t][r] + (rh[r] + rl[r]);
+                half4 h, l;
+                split4(v, h, l);
+                *reinterpret_cast<half4*>(T.xh + sq * XROW + co0) = h;
+                *reinterpret_cast<half4*>(T.xl + sq * XROW + co0) = l;
+            }
+        }
+        __syncthreads();
+    }
+    // stream -> HBM as float, 32-byte pieces per thread
+    float* yb = a.y + size_t(b) * 64 * C;
+#pragma unroll 1
+    for (int i = tid; i < 64 * (C / 8); i += G::NTHR) {
+        const int r = i / (C / 8), v = i - r * (C / 8);
+        float fh[8], fl[8];
+        load8<half_t>(T.xh + r * XROW + v * 8, fh);
+        load8<half_t>(T.xl + r * XROW + v * 8, fl);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fh[j] += fl[j];
+        store8<float>(yb + size_t(r) * C + v * 8, fh);
+    }
+}
+
 void init_x3_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
 }
 int block_x3_chunk_channels() { return X3Block::CK; }
 
 void launch_block_x3(const BlockArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(block_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+}
+void launch_tower_x3(const X3TowerArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(tower_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
 }
 
 }  // namespace cra

@@ -37,6 +37,7 @@ def logit_tol(tol, ref_logits):
 # float16 runs the residual-tower kernel (runs of 3x3 blocks in one launch); "-perblock" = one fused launch per bottleneck
 # block, "-unfused" = layer-granular kernels (conv GEMM / depthwise / project as separate launches): three implementations
 TOL["float16x3"] = TOL["float32"]
+TOL["float16x3-perblock"] = TOL["float32"]  # one launch per 3x3 block (block_x3_kernel); plain float16x3 runs them in one launch (tower_x3_kernel)
 TOL["float16x3-unfused"] = TOL["float32"]   # every block on the layer kernels (conv GEMM x3 / float depthwise), as the 5x5 blocks always are
 TOL["float32-unfused"] = TOL["float32"]
 TOL["float16-unfused"] = TOL["float16"]
@@ -65,7 +66,7 @@ def _run(tmp_path, hip_lib, name, precision):
 
 
 @pytest.mark.parametrize("precision", ["float32", "float16", "float16x3", "float16-3k", "float16-perblock", "float32-unfused", "float16-unfused",
-                                       "float16x3-unfused"])
+                                       "float16x3-perblock", "float16x3-unfused"])
 @pytest.mark.parametrize("name", list(nn_cases.CASES))
 def test_predict_matches_oracle_and_golden(tmp_path, hip_lib, name, precision):
     cfg, sd, x, value, probs, aux, logits = _run(tmp_path, hip_lib, name, precision)

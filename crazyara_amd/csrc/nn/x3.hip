@@ -15,9 +15,29 @@
 #include "kernels.h"
 #include "device_utils.h"
 
+// CRA_X3_ABL: development switches that TIME parts of the tower's chunk loop (scripts/ubench/x3_tower_ablate.hip); every bit computes wrong
+// results on purpose, so they only compile in a development build.  1: no depthwise arithmetic, 2: no expand MFMAs, 4: no project MFMAs,
+// 8: no LDS operand reads (expand and project), 16: no weight loads, 32: no chunk barriers, 64: no t2 stores
+#ifndef CRA_X3_ABL
+#define CRA_X3_ABL 0
+#endif
+// channel tiles (16 channels each) of the expand GEMM per wave: 1 = chunks of 128 channels, 2 = chunks of 256 (a stream fragment read
+// from LDS then feeds two channel tiles: half the LDS operand traffic of the expand phase)
+#ifndef CRA_X3_NE
+#define CRA_X3_NE 1
+#endif
+#if CRA_X3_ABL != 0 && !defined(CRA_DEVELOPMENT)
+#error "CRA_X3_ABL is a development switch (wrong results): build with -DCRA_DEVELOPMENT"
+#endif
+
 namespace cra {
 
 namespace {
+constexpr int X3_ABL = CRA_X3_ABL;
+__device__ __forceinline__ void x3_mfma(const half8& a, const half8& b, f32x4& c, bool on) {
+    if (on) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    else asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+}
 
 // (a, b) -> packed f16 pairs hi = rne(a | b), lo = rne((a | b) - hi): 4 instructions (pack-convert, two mix-precision FMAs that read the
 // f16 halves in place, pack-convert) where the compiler's form of the same arithmetic takes about ten.  The difference a - hi is exact.
@@ -220,11 +240,12 @@ void launch_conv_gemm_x3(const ConvArgs& a, hipStream_t s) {
 // ================================================================================================================
 namespace {
 struct X3Block {
-    static constexpr int C = 256, NW = 8, CK = 16 * NW, NTHR = 64 * NW, NJ = C / 16 / NW;
+    static constexpr int C = 256, NW = 8, NE = CRA_X3_NE, CK = 16 * NW * NE, NTHR = 64 * NW, NJ = C / 16 / NW;
     static constexpr int XROW = C + 16;      // halves; 32-byte row pad (rows step 8 banks: conflict-free 16-row fragment reads)
     static constexpr int TROW = CK + 16;
-    static constexpr size_t lds_bytes = (size_t(2) * 64 * XROW + size_t(2) * 64 * TROW) * sizeof(half_t);     // 106,496 B
+    static constexpr size_t lds_bytes = (size_t(2) * 64 * XROW + size_t(2) * 64 * TROW) * sizeof(half_t);     // NE = 1: 106,496 B; NE = 2: 139,264 B
 };
+static_assert(X3Block::lds_bytes <= 160 * 1024, "LDS budget");
 
 struct X3Tiles {
     half_t *xh, *xl;        // [64][XROW] block input = residual stream, hi / lo
@@ -269,7 +290,7 @@ struct X3Weights {
 };
 __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, f32x4 (&accP)[X3Block::NJ][4]) {
     using G = X3Block;
-    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NW = G::NW, NJ = G::NJ;
+    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NJ = G::NJ, NE = G::NE;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const int nchunk = W.cop_pad / CK;
     const int nslab3 = W.cop_pad >> 5;
@@ -277,52 +298,83 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
     const float mL = (l15 & 7) != 0 ? 1.f : 0.f;               // a left / right neighbour exists on the board
     const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
 
-    // Weight fragments come through two small rolling windows (a phase's whole set in registers -- 64 + 64 VGPRs -- leaves the
-    // compiler no room in the one-launch tower): the expand window holds 4 of the 8 k-slabs (hi + lo), the project window 2 of 4.
-    // A slot is refilled as soon as its MFMAs are issued, i.e. 4 (2) slabs = ~1k+ cycles ahead of its next use; the first slabs of a
-    // phase are requested a whole phase ahead.
-    constexpr int EW = 4, PW = 2;
-    half8 e_h[EW], e_l[EW];
-    auto load_expand = [&](int ch, int s) {
-        const size_t o = (size_t(ch * NW + wave) * (C / 32) + s) * 64;
-        e_h[s % EW] = W.w1h[o];
-        e_l[s % EW] = W.w1l[o];
+    // Weight fragments come through two small rolling windows (a phase's whole set in registers leaves the compiler no room in the
+    // one-launch tower): the expand window holds EW of the 8 k-slabs (hi + lo, NE channel tiles), the project window PW of CK / 32.
+    // A slot is refilled as soon as its MFMAs are issued, EW (PW) slabs ahead of its next use; the first slabs of a phase are
+    // requested a whole phase ahead.
+    constexpr int EW = NE == 1 ? 4 : 2, PW = 2;
+    half8 e_h[EW][NE], e_l[EW][NE];
+    if constexpr (X3_ABL & 16) {
+#pragma unroll
+        for (int s = 0; s < EW; ++s)
+#pragma unroll
+            for (int ne = 0; ne < NE; ++ne) e_h[s][ne] = e_l[s][ne] = *reinterpret_cast<const half8*>(T.xh + lane * 8);
+    }
+    auto load_expand = [&](int ch, int s) {                    // cout tile (16 channels) of (chunk, wave, ne) = ch * CK / 16 + wave * NE + ne
+        if constexpr (X3_ABL & 16) return;
+#pragma unroll
+        for (int ne = 0; ne < NE; ++ne) {
+            const size_t o = (size_t(ch * (CK / 16) + wave * NE + ne) * (C / 32) + s) * 64;
+            e_h[s % EW][ne] = W.w1h[o];
+            e_l[s % EW][ne] = W.w1l[o];
+        }
     };
 #pragma unroll
     for (int s = 0; s < EW; ++s) load_expand(0, s);
     for (int ch = 0; ch < nchunk; ++ch) {
-        // per-channel depthwise record of my 4 channels (9 taps, BN1 bias, BN2 bias, 0): lands while the expand MFMAs run
-        f32x4 dwr[4][3];
-        {
-            const f32x4* dp = reinterpret_cast<const f32x4*>(W.dwpk + size_t(ch * CK + wave * 16 + lg * 4) * 12);
+        // ---------------- E: expand, NE x 16 channels x 64 squares per wave, K = C; a tile fragment of the stream feeds NE channel tiles ----
+        f32x4 accE[NE][4];
+#pragma unroll
+        for (int ne = 0; ne < NE; ++ne)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accE[ne][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // per-channel depthwise records of my 4 channels of a tile (9 taps, BN1 bias, BN2 bias, 0), requested ahead of their use
+        f32x4 dwr[NE][4][3];
+        auto load_dw = [&](int ne) {
+            const f32x4* dp = reinterpret_cast<const f32x4*>(W.dwpk + size_t(ch * CK + (wave * NE + ne) * 16 + lg * 4) * 12);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) dwr[r][k] = dp[r * 3 + k];
-        }
-        // ---------------- E: expand, 16 channels x 64 squares per wave, K = C ----------------
-        f32x4 accE[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) accE[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < 3; ++k) dwr[ne][r][k] = dp[r * 3 + k];
+        };
 #pragma unroll
         for (int s = 0; s < C / 32; ++s) {
             half8 bh[4], bl[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                bh[t] = *reinterpret_cast<const half8*>(T.xh + (t * 16 + l15) * XROW + s * 32 + lg * 8);
-                bl[t] = *reinterpret_cast<const half8*>(T.xl + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                if constexpr (X3_ABL & 8) {
+                    bh[t] = e_h[s % EW][0];
+                    bl[t] = e_l[s % EW][0];
+                } else {
+                    bh[t] = *reinterpret_cast<const half8*>(T.xh + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                    bl[t] = *reinterpret_cast<const half8*>(T.xl + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                }
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_l[s % EW], bh[t], accE[t], 0, 0, 0);
+            for (int ne = 0; ne < NE; ++ne)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_h[s % EW], bl[t], accE[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) x3_mfma(e_l[s % EW][ne], bh[t], accE[ne][t], !(X3_ABL & 2));
 #pragma unroll
-            for (int t = 0; t < 4; ++t) accE[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e_h[s % EW], bh[t], accE[t], 0, 0, 0);
+            for (int ne = 0; ne < NE; ++ne)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bl[t], accE[ne][t], !(X3_ABL & 2));
+#pragma unroll
+            for (int ne = 0; ne < NE; ++ne)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bh[t], accE[ne][t], !(X3_ABL & 2));
             if (s + EW < C / 32) load_expand(ch, s + EW);
+            if (s == C / 64) load_dw(0);                       // half-way through the expand MFMAs: landed when the depthwise starts
         }
         // the first slabs of this chunk's project fragments: they land while the depthwise runs
         half8 p_h[PW][NJ], p_l[PW][NJ];
+        if constexpr (X3_ABL & 16) {
+#pragma unroll
+            for (int s2 = 0; s2 < PW; ++s2)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) p_h[s2][j] = p_l[s2][j] = *reinterpret_cast<const half8*>(T.xl + lane * 8);
+        }
         auto load_project = [&](int s2) {
+            if constexpr (X3_ABL & 16) return;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const size_t o = (size_t(wave * NJ + j) * nslab3 + ch * (CK / 32) + s2) * 64;
@@ -334,49 +386,61 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
         for (int s2 = 0; s2 < PW; ++s2) load_project(s2);
 
         // ---------------- D: BN1 + ReLU, depthwise 3x3 on the accumulators (block_kernel_dpp), BN2 + ReLU, exact f32 ----------------
-        float outv[4][4];                                       // [tile][channel r]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float b1 = dwr[r][2][1], b2 = dwr[r][2][2];
-            float w[9];
+        for (int ne = 0; ne < NE; ++ne) {
+            if (ne + 1 < NE) load_dw(ne + 1);                   // the next tile's record flies while this tile's depthwise runs
+            float outv[4][4];                                   // [tile][channel r]
+            if constexpr (X3_ABL & 1) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) w[k] = dwr[r][k >> 2][k & 3];
-            w[0] *= mL; w[3] *= mL; w[6] *= mL;                 // file-edge masks folded into the dx = -1 / +1 columns
-            w[2] *= mR; w[5] *= mR; w[8] *= mR;
-            float e[4], rot[4];
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                e[t] = fmaxf(accE[t][r] + b1, 0.f);
-                rot[t] = dpp_mov<DPP_ROW_ROR8>(e[t]);
+                    for (int r = 0; r < 4; ++r) outv[t][r] = accE[ne][t][r] + dwr[ne][r][0][0];
+            } else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float b1 = dwr[ne][r][2][1], b2 = dwr[ne][r][2][2];
+                float w[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) w[k] = dwr[ne][r][k >> 2][k & 3];
+                w[0] *= mL; w[3] *= mL; w[6] *= mL;             // file-edge masks folded into the dx = -1 / +1 columns
+                w[2] *= mR; w[5] *= mR; w[8] *= mR;
+                float e[4], rot[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    e[t] = fmaxf(accE[ne][t][r] + b1, 0.f);
+                    rot[t] = dpp_mov<DPP_ROW_ROR8>(e[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float up = hi ? rot[t] : (t > 0 ? rot[t > 0 ? t - 1 : 0] : 0.f);
+                    const float dn = hi ? (t < 3 ? rot[t < 3 ? t + 1 : 3] : 0.f) : rot[t];
+                    float acc = b2;
+                    acc = fmac_shr1(acc, up, w[0]);
+                    acc = fmaf(w[1], up, acc);
+                    acc = fmac_shl1(acc, up, w[2]);
+                    acc = fmac_shr1(acc, e[t], w[3]);
+                    acc = fmaf(w[4], e[t], acc);
+                    acc = fmac_shl1(acc, e[t], w[5]);
+                    acc = fmac_shr1(acc, dn, w[6]);
+                    acc = fmaf(w[7], dn, acc);
+                    acc = fmac_shl1(acc, dn, w[8]);
+                    outv[t][r] = fmaxf(acc, 0.f);
+                }
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float up = hi ? rot[t] : (t > 0 ? rot[t > 0 ? t - 1 : 0] : 0.f);
-                const float dn = hi ? (t < 3 ? rot[t < 3 ? t + 1 : 3] : 0.f) : rot[t];
-                float acc = b2;
-                acc = fmac_shr1(acc, up, w[0]);
-                acc = fmaf(w[1], up, acc);
-                acc = fmac_shl1(acc, up, w[2]);
-                acc = fmac_shr1(acc, e[t], w[3]);
-                acc = fmaf(w[4], e[t], acc);
-                acc = fmac_shl1(acc, e[t], w[5]);
-                acc = fmac_shr1(acc, dn, w[6]);
-                acc = fmaf(w[7], dn, acc);
-                acc = fmac_shl1(acc, dn, w[8]);
-                outv[t][r] = fmaxf(acc, 0.f);
-            }
-        }
-        {
-            const int cl = wave * 16 + lg * 4;
+            const int cl = (wave * NE + ne) * 16 + lg * 4;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 half4 h, l;
                 split4(outv[t], h, l);
-                *reinterpret_cast<half4*>(T.t2h + (t * 16 + l15) * TROW + cl) = h;
-                *reinterpret_cast<half4*>(T.t2l + (t * 16 + l15) * TROW + cl) = l;
+                if constexpr (X3_ABL & 64) {
+                    asm volatile("" ::"v"(h), "v"(l));
+                } else {
+                    *reinterpret_cast<half4*>(T.t2h + (t * 16 + l15) * TROW + cl) = h;
+                    *reinterpret_cast<half4*>(T.t2l + (t * 16 + l15) * TROW + cl) = l;
+                }
             }
         }
-        __syncthreads();
+        if constexpr (!(X3_ABL & 32)) __syncthreads();
         if (ch + 1 < nchunk) {                                  // the next chunk's first expand slabs land while the project MFMAs run
 #pragma unroll
             for (int s = 0; s < EW; ++s) load_expand(ch + 1, s);
@@ -387,24 +451,29 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
             half8 bh[4], bl[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                bh[t] = *reinterpret_cast<const half8*>(T.t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
-                bl[t] = *reinterpret_cast<const half8*>(T.t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                if constexpr (X3_ABL & 8) {
+                    bh[t] = p_h[s2 % PW][0];
+                    bl[t] = p_l[s2 % PW][0];
+                } else {
+                    bh[t] = *reinterpret_cast<const half8*>(T.t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                    bl[t] = *reinterpret_cast<const half8*>(T.t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                }
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_l[s2 % PW][j], bh[t], accP[j][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) x3_mfma(p_l[s2 % PW][j], bh[t], accP[j][t], !(X3_ABL & 4));
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_h[s2 % PW][j], bl[t], accP[j][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bl[t], accP[j][t], !(X3_ABL & 4));
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) accP[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_h[s2 % PW][j], bh[t], accP[j][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[t], accP[j][t], !(X3_ABL & 4));
             if (s2 + PW < CK / 32) load_project(s2 + PW);
         }
-        __syncthreads();                                        // t2 is rewritten by the next chunk's depthwise
+        if constexpr (!(X3_ABL & 32)) __syncthreads();          // t2 is rewritten by the next chunk's depthwise
     }
 }
 }  // namespace

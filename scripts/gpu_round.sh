@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python __graft_entry__.py > $OUT/build.log 2>&1
 if [ "${2:-tests}" = "tests" ]; then
-  timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1
+  timeout 1200 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1
   echo "pytest exit $?" >> $OUT/pytest_gpu.log
   tail -5 $OUT/pytest_gpu.log
 fi

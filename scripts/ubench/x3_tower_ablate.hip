@@ -1,0 +1,74 @@
+// Development: where does tower_x3_kernel's time go?  Compiles x3.hip with one CRA_X3_ABL switch set (each computes wrong results on
+// purpose, x3.hip) and times the RISEv2-19 tower (19 blocks, C_op 128 ... 1280, 256 boards) with random weights.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCRA_DEVELOPMENT -DCRA_X3_ABL=<bits> -Icrazyara_amd/csrc/nn scripts/ubench/x3_tower_ablate.hip -o /tmp/x3abl_<bits>
+// scripts/run_x3_ablation.sh builds and runs the set.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "x3.hip"        // -I crazyara_amd/csrc/nn
+
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "HIP error %s at %s\n", hipGetErrorString(_e), #e); exit(1); } } while (0)
+
+template <typename T> T* upload(const std::vector<T>& h) {
+    T* d = nullptr;
+    CK(hipMalloc(&d, h.size() * sizeof(T)));
+    CK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+int main(int argc, char** argv) {
+    using namespace cra;
+    const int B = argc > 1 ? atoi(argv[1]) : 256, nblocks = argc > 2 ? atoi(argv[2]) : 19, iters = argc > 3 ? atoi(argv[3]) : 20;
+    std::mt19937 rng(7);
+    std::uniform_real_distribution<float> u(-0.05f, 0.05f);
+    std::vector<X3TowerBlock> blocks;
+    const int chunk = block_x3_chunk_channels();
+    double flops = 0;
+    for (int i = 0; i < nblocks; ++i) {
+        const int cop = 128 + 64 * i, cop_pad = (cop + chunk - 1) / chunk * chunk;
+        std::vector<half_t> w1(size_t(cop_pad) * 256), w3(size_t(256) * cop_pad);
+        for (auto& v : w1) v = half_t(u(rng));
+        for (auto& v : w3) v = half_t(u(rng));
+        std::vector<float> rec(size_t(cop_pad) * 12), b3(256);
+        for (auto& v : rec) v = u(rng);
+        for (auto& v : b3) v = u(rng);
+        X3TowerBlock b{};
+        b.w1pk = upload(w1); b.w1pk_lo = upload(w1);
+        b.w3pk = upload(w3); b.w3pk_lo = upload(w3);
+        b.dwpk = upload(rec);
+        b.b3 = upload(b3);
+        b.cop_pad = cop_pad;
+        blocks.push_back(b);
+        flops += 2.0 * 64 * cop * (2.0 * 256 + 9) * B;
+    }
+    std::vector<float> x(size_t(B) * 64 * 256);
+    for (auto& v : x) v = u(rng) * 10;
+    X3TowerArgs a{};
+    a.x = upload(x);
+    a.y = upload(x);
+    a.blocks = upload(blocks);
+    a.nblocks = nblocks;
+    a.batch = B;
+    init_x3_kernel_attributes();
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    for (int i = 0; i < 3; ++i) launch_tower_x3(a, s);
+    CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) launch_tower_x3(a, s);
+    CK(hipEventRecord(e1, s));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= iters;
+    printf("CRA_X3_ABL=%d  B=%d blocks=%d chunk=%d: %.4f ms per tower launch  (%.1f algorithmic TFLOP/s)\n", CRA_X3_ABL, B, nblocks, chunk, ms,
+           flops / (ms * 1e-3) / 1e12);
+    return 0;
+}

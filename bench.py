@@ -502,9 +502,9 @@ def main():
         _, budget_threads = replicas.pin_rank_to_cpus(world, local_rank)
         threads = max(1, min(args.search_threads, budget_threads))
 
-        def config2_leg(precision, repeats):
+        def config2_leg(precision, repeats, leg_threads=None):
             nets = [HipAPI(local_rank, args.batch, tmp, precision) for _ in range(lanes)]
-            leg = searchbench.timed_search_leg(st, nets, positions, n_trees, args.simulations, threads,
+            leg = searchbench.timed_search_leg(st, nets, positions, n_trees, args.simulations, leg_threads or threads,
                                                min_seconds=args.search_seconds, repeats=repeats, offset=rank * 37)
             nodes_m, evals_m, sims_m, sec_m = leg.pop("_median_totals")
             leg.pop("_spread")
@@ -553,6 +553,17 @@ def main():
             nets, mcts_headline_mode = config2_leg(args.precision, 1)       # the same leg with the headline mode behind the lanes
             for n_ in nets:
                 n_.close()
+        if world == 1 and not args.no_config_legs:
+            # how many host threads a GPU needs (searchthread.cpp runs `Threads` of them per GPU): the same leg with fewer
+            sweep = {}
+            for th in (4, 8):
+                if th < threads:
+                    nets, r_ = config2_leg(args.search_precision, 1, leg_threads=th)
+                    sweep[str(th)] = r_["mcts_nodes_per_sec"]
+                    for n_ in nets:
+                        n_.close()
+            sweep[str(threads)] = mcts["mcts_nodes_per_sec"]
+            mcts["nodes_per_sec_by_host_threads"] = sweep
         # ---- the other BASELINE configurations, searched (single GPU; extra keys, never `value`) ----
         if world == 1 and not args.no_config_legs:
             cargs = argparse.Namespace(**vars(args))
@@ -735,6 +746,8 @@ def main():
         if mcts:
             summary[f"config2_mcts_nodes_per_sec_{mcts['precision']}"] = mcts["mcts_nodes_per_sec"]
             summary["config2_host_throttled_ms"] = mcts.get("host_cgroup_throttled_ms_during_search")
+            for th_, v_ in mcts.get("nodes_per_sec_by_host_threads", {}).items():
+                summary[f"config2_mcts_nodes_per_sec_{th_}_host_threads"] = v_
         if mcts_headline_mode:
             summary[f"config2_mcts_nodes_per_sec_{args.precision}"] = mcts_headline_mode["mcts_nodes_per_sec"]
         for k_, r_ in (mcts_configs or {}).items():

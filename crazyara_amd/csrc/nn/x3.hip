@@ -67,16 +67,11 @@ __device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo
     lo = __builtin_bit_cast(half4, u32x2{l[0], l[1]});
 }
 
-// acc += w * x[lane -/+ 1 within the 16-lane row] (lanes shifted in from outside the row contribute 0) as ONE instruction: the compiler
-// keeps a v_mov_b32_dpp in front of most of these multiply-adds (88 moves per chunk and wave), VOP2's DPP form takes the shift itself
-__device__ __forceinline__ float fmac_shr1(float acc, float x, float w) {
-    asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(w));
-    return acc;
-}
-__device__ __forceinline__ float fmac_shl1(float acc, float x, float w) {
-    asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(w));
-    return acc;
-}
+// acc += w * x[lane -/+ 1 within the 16-lane row] (lanes shifted in from outside the row contribute 0).  Through the builtin, not inline
+// assembly: a DPP operand written by a VALU instruction needs two wait states in front of the DPP read, the compiler inserts them for
+// its own instructions and does not look inside an asm statement (a hand-written v_fmac_f32_dpp here read stale registers: r03c).
+__device__ __forceinline__ float fmac_shr1(float acc, float x, float w) { return fmaf(w, dpp_mov<DPP_ROW_SHR1>(x), acc); }
+__device__ __forceinline__ float fmac_shl1(float acc, float x, float w) { return fmaf(w, dpp_mov<DPP_ROW_SHL1>(x), acc); }
 
 // one product tile: the two cross terms first, the main term last
 __device__ __forceinline__ void mma_x3(const half8& ah, const half8& al, const half8& bh, const half8& bl, f32x4& c) {
@@ -283,15 +278,34 @@ __device__ __forceinline__ void x3_stage_tile(const X3Tiles& T, const float* xb,
 
 // The chunk loop of one block: accP[j][t] += project(depthwise(expand(x))) for this wave's 32 couts x 64 squares.  The caller has put a
 // barrier behind the last write of the x tiles; the loop ends with a barrier (t2 and x are free to be rewritten).
+// Weights are read with raw buffer loads: resource descriptor + wave-uniform byte offset in SGPRs, the lane part one constant VGPR.
+// (Through the pointers of a descriptor array in device memory the compiler can only emit FLAT loads, which count on the LDS
+// counter too: every wait for an LDS operand then also waits for the weight fragments requested slabs ahead.)
 struct X3Weights {
-    const half8 *w1h, *w1l, *w3h, *w3l;     // packed expand / project weights, hi / lo (kernels.h: packed-weight geometry), + lane
-    const float* dwpk;                      // [cop_pad][12]: 9 folded taps, BN1 bias, BN2 bias, 0
+    __amdgpu_buffer_rsrc_t w1h, w1l, w3h, w3l;   // packed expand / project weights, hi / lo (kernels.h: packed-weight geometry)
+    __amdgpu_buffer_rsrc_t dw;                   // [cop_pad][12] floats: 9 folded taps, BN1 bias, BN2 bias, 0
     int cop_pad;
 };
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ X3Weights x3_weights(const void* w1h, const void* w1l, const void* w3h, const void* w3l, const float* dwpk, int cop_pad) {
+    X3Weights W;
+    W.w1h = x3_rsrc(w1h); W.w1l = x3_rsrc(w1l); W.w3h = x3_rsrc(w3h); W.w3l = x3_rsrc(w3l);
+    W.dw = x3_rsrc(dwpk);
+    W.cop_pad = cop_pad;
+    return W;
+}
+__device__ __forceinline__ half8 x3_frag(__amdgpu_buffer_rsrc_t r, uint32_t lane_off, uint32_t frag) {      // fragment = 64 lanes x 16 B
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, frag * 1024u, 0));
+}
 __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, f32x4 (&accP)[X3Block::NJ][4]) {
     using G = X3Block;
     constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NJ = G::NJ, NE = G::NE;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lane_off = uint32_t(lane) * 16u;
     const int nchunk = W.cop_pad / CK;
     const int nslab3 = W.cop_pad >> 5;
     const bool hi = l15 >= 8;                                  // second board row of a 16-square tile
@@ -314,9 +328,9 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
         if constexpr (X3_ABL & 16) return;
 #pragma unroll
         for (int ne = 0; ne < NE; ++ne) {
-            const size_t o = (size_t(ch * (CK / 16) + wave * NE + ne) * (C / 32) + s) * 64;
-            e_h[s % EW][ne] = W.w1h[o];
-            e_l[s % EW][ne] = W.w1l[o];
+            const uint32_t f = uint32_t(ch * (CK / 16) + wave * NE + ne) * (C / 32) + uint32_t(s);
+            e_h[s % EW][ne] = x3_frag(W.w1h, lane_off, f);
+            e_l[s % EW][ne] = x3_frag(W.w1l, lane_off, f);
         }
     };
 #pragma unroll
@@ -331,39 +345,50 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
         // per-channel depthwise records of my 4 channels of a tile (9 taps, BN1 bias, BN2 bias, 0), requested ahead of their use
         f32x4 dwr[NE][4][3];
         auto load_dw = [&](int ne) {
-            const f32x4* dp = reinterpret_cast<const f32x4*>(W.dwpk + size_t(ch * CK + (wave * NE + ne) * 16 + lg * 4) * 12);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const uint32_t base = uint32_t(ch * CK + (wave * NE + ne) * 16) * 48u;        // wave-uniform; + my channel group's 4 records
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) dwr[ne][r][k] = dp[r * 3 + k];
+                for (int k = 0; k < 3; ++k)
+                    dwr[ne][r][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, uint32_t(lg) * 192u, base + uint32_t(r * 48 + k * 16), 0));
         };
-#pragma unroll
-        for (int s = 0; s < C / 32; ++s) {
-            half8 bh[4], bl[4];
+        // A slab = 12 * NE MFMAs on the stream fragments of one k-slab.  The NEXT slab's fragments are read from LDS before this slab's
+        // MFMAs issue and the window refills right behind them; the fences keep the machine scheduler from sinking either to just in
+        // front of their consumers (it does, to shorten live ranges: every slab then waits out an LDS or L2 latency).
+        half8 bh[2][4], bl[2][4];
+        auto read_stream = [&](int s, half8 (&h)[4], half8 (&l)[4]) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if constexpr (X3_ABL & 8) {
-                    bh[t] = e_h[s % EW][0];
-                    bl[t] = e_l[s % EW][0];
+                    h[t] = e_h[s % EW][0];
+                    l[t] = e_l[s % EW][0];
                 } else {
-                    bh[t] = *reinterpret_cast<const half8*>(T.xh + (t * 16 + l15) * XROW + s * 32 + lg * 8);
-                    bl[t] = *reinterpret_cast<const half8*>(T.xl + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                    h[t] = *reinterpret_cast<const half8*>(T.xh + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                    l[t] = *reinterpret_cast<const half8*>(T.xl + (t * 16 + l15) * XROW + s * 32 + lg * 8);
                 }
             }
+        };
+        read_stream(0, bh[0], bl[0]);
+#pragma unroll
+        for (int s = 0; s < C / 32; ++s) {
+            if (s + 1 < C / 32) read_stream(s + 1, bh[(s + 1) & 1], bl[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ne = 0; ne < NE; ++ne)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) x3_mfma(e_l[s % EW][ne], bh[t], accE[ne][t], !(X3_ABL & 2));
+                for (int t = 0; t < 4; ++t) x3_mfma(e_l[s % EW][ne], bh[s & 1][t], accE[ne][t], !(X3_ABL & 2));
 #pragma unroll
             for (int ne = 0; ne < NE; ++ne)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bl[t], accE[ne][t], !(X3_ABL & 2));
+                for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bl[s & 1][t], accE[ne][t], !(X3_ABL & 2));
 #pragma unroll
             for (int ne = 0; ne < NE; ++ne)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bh[t], accE[ne][t], !(X3_ABL & 2));
+                for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bh[s & 1][t], accE[ne][t], !(X3_ABL & 2));
             if (s + EW < C / 32) load_expand(ch, s + EW);
             if (s == C / 64) load_dw(0);                       // half-way through the expand MFMAs: landed when the depthwise starts
+            __builtin_amdgcn_sched_barrier(0);
         }
         // the first slabs of this chunk's project fragments: they land while the depthwise runs
         half8 p_h[PW][NJ], p_l[PW][NJ];
@@ -377,9 +402,9 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
             if constexpr (X3_ABL & 16) return;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const size_t o = (size_t(wave * NJ + j) * nslab3 + ch * (CK / 32) + s2) * 64;
-                p_h[s2 % PW][j] = W.w3h[o];
-                p_l[s2 % PW][j] = W.w3l[o];
+                const uint32_t f = uint32_t(wave * NJ + j) * uint32_t(nslab3) + uint32_t(ch * (CK / 32) + s2);
+                p_h[s2 % PW][j] = x3_frag(W.w3h, lane_off, f);
+                p_l[s2 % PW][j] = x3_frag(W.w3l, lane_off, f);
             }
         };
 #pragma unroll
@@ -446,32 +471,37 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
             for (int s = 0; s < EW; ++s) load_expand(ch + 1, s);
         }
         // ---------------- P: project, 32 couts x 64 squares per wave, K = CK (accumulates over chunks) ----------------
-#pragma unroll
-        for (int s2 = 0; s2 < CK / 32; ++s2) {
-            half8 bh[4], bl[4];
+        auto read_t2 = [&](int s2, half8 (&h)[4], half8 (&l)[4]) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if constexpr (X3_ABL & 8) {
-                    bh[t] = p_h[s2 % PW][0];
-                    bl[t] = p_l[s2 % PW][0];
+                    h[t] = p_h[s2 % PW][0];
+                    l[t] = p_l[s2 % PW][0];
                 } else {
-                    bh[t] = *reinterpret_cast<const half8*>(T.t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
-                    bl[t] = *reinterpret_cast<const half8*>(T.t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                    h[t] = *reinterpret_cast<const half8*>(T.t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                    l[t] = *reinterpret_cast<const half8*>(T.t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
                 }
             }
+        };
+        read_t2(0, bh[0], bl[0]);
+#pragma unroll
+        for (int s2 = 0; s2 < CK / 32; ++s2) {
+            if (s2 + 1 < CK / 32) read_t2(s2 + 1, bh[(s2 + 1) & 1], bl[(s2 + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) x3_mfma(p_l[s2 % PW][j], bh[t], accP[j][t], !(X3_ABL & 4));
+                for (int t = 0; t < 4; ++t) x3_mfma(p_l[s2 % PW][j], bh[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bl[t], accP[j][t], !(X3_ABL & 4));
+                for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bl[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[t], accP[j][t], !(X3_ABL & 4));
+                for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
             if (s2 + PW < CK / 32) load_project(s2 + PW);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (!(X3_ABL & 32)) __syncthreads();          // t2 is rewritten by the next chunk's depthwise
     }
@@ -485,13 +515,7 @@ __global__ __launch_bounds__(512) void block_x3_kernel(const BlockArgs a) {
     const X3Tiles T = x3_tiles(smem);
     const int b = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
-    X3Weights W;
-    W.w1h = reinterpret_cast<const half8*>(a.w1pk) + lane;
-    W.w1l = reinterpret_cast<const half8*>(a.w1pk_lo) + lane;
-    W.w3h = reinterpret_cast<const half8*>(a.w3pk) + lane;
-    W.w3l = reinterpret_cast<const half8*>(a.w3pk_lo) + lane;
-    W.dwpk = a.dwpk;
-    W.cop_pad = a.cop_pad;
+    const X3Weights W = x3_weights(a.w1pk, a.w1pk_lo, a.w3pk, a.w3pk_lo, a.dwpk, a.cop_pad);
     x3_stage_tile(T, reinterpret_cast<const float*>(a.x) + size_t(b) * 64 * C, a.gate ? a.gate + size_t(b) * C : nullptr, tid);
     __syncthreads();
 
@@ -616,13 +640,7 @@ __global__ __launch_bounds__(512) void tower_x3_kernel(const X3TowerArgs a) {
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const X3TowerBlock& d = a.blocks[blk];
         if (blk > 0 && d.se_kind != 0) x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid);
-        X3Weights W;
-        W.w1h = reinterpret_cast<const half8*>(d.w1pk) + lane;
-        W.w1l = reinterpret_cast<const half8*>(d.w1pk_lo) + lane;
-        W.w3h = reinterpret_cast<const half8*>(d.w3pk) + lane;
-        W.w3l = reinterpret_cast<const half8*>(d.w3pk_lo) + lane;
-        W.dwpk = d.dwpk;
-        W.cop_pad = d.cop_pad;
+        const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
         f32x4 accP[NJ][4];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {                          // the project accumulators start at the BN3 bias of their 4 couts

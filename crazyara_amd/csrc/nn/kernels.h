@@ -75,10 +75,10 @@ int block_x3_chunk_channels();
 // by the caller's SE launch)
 struct X3TowerBlock {
     const void *w1pk, *w1pk_lo, *w3pk, *w3pk_lo;     // as BlockArgs
-    const float* dwpk;                               // [cop_pad][12]
+    const float* dwpk;                               // [cop_pad][12] + 64 floats of padding (a wave loads 1 KiB where its records start)
     const float* b3;                                 // [256]
-    const float* se_w1t;                             // ca_se: [256][128] transposed; eca_se: [256][256] transposed centre tap
-    const float* se_w2t;                             // ca_se: [128][256] transposed
+    const float* se_w1t;                             // gate matrices in THREAD order (x3.hip: x3_se_phase; rise_net.hip: pack_se_threads_f32):
+    const float* se_w2t;                             //   ca_se: W1 then W2, 16 float4 loads per thread each; eca_se: se_w1t = both halves
     const float* se_b;                               // eca_se: [256]
     int cop_pad;                                     // multiple of block_x3_chunk_channels()
     int se_kind;                                     // 0 none, 1 ca_se, 2 eca_se

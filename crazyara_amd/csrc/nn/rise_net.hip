@@ -516,6 +516,15 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 }
         return out;
     };
+    // the float16x3 tower's gate matrices in thread order (x3.hip: x3_se_phase): thread t of 512 reads 16 float4, load i at float4 index
+    // i * 512 + t = (a[2i], b[2i], a[2i+1], b[2i+1]) of its two output rows a, b; w(row, k) returns the matrix entry for the thread's k-th input
+    auto pack_se_threads_f32 = [](auto w) {
+        std::vector<float> out(size_t(16) * 512 * 4);
+        for (int i = 0; i < 16; ++i)
+            for (int t = 0; t < 512; ++t)
+                for (int e = 0; e < 4; ++e) out[(size_t(i) * 512 + t) * 4 + e] = w(t, e & 1, 2 * i + (e >> 1));
+        return out;
+    };
     if (dense_blocks && tower_ok) {
         // all blocks in one launch (restower.hip; stream layouts in kernels.h: ResTowerArgs)
         if constexpr (kHalf) {
@@ -642,8 +651,9 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             for (int c = 0; c < C; ++c) for (int j = 0; j < H; ++j) w2t[size_t(j) * C + c] = w2.data[size_t(c) * H + j];
             if (x3_se_in_kernel) {
                 xb.se_kind = 1;
-                xb.se_w1t = im.upload(w1t);
-                xb.se_w2t = im.upload(w2t);
+                // FC1: thread t -> hidden rows 2*(t/8), +1 over inputs c = 32*(t%8) + k;  FC2: gate rows 2*(t/4), +1 over hidden j = 32*(t%4) + k
+                xb.se_w1t = im.upload(pack_se_threads_f32([&](int t, int row, int k) { return w1t[size_t(32 * (t & 7) + k) * H + 2 * (t >> 3) + row]; }));
+                xb.se_w2t = im.upload(pack_se_threads_f32([&](int t, int row, int k) { return w2t[size_t(32 * (t & 3) + k) * C + 2 * (t >> 2) + row]; }));
             } else if (se_in_kernel) {
                 td.se_kind = 1;
                 // FC1: thread t -> outputs 2*(t/8), +1 over inputs c in [32*(t%8), +32); FC2: outputs 2*(t/4), +1 over j in [32*(t%4), +32):
@@ -668,7 +678,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             for (int o = 0; o < C; ++o) b[o] = bs[o];
             if (x3_se_in_kernel) {
                 xb.se_kind = 2;
-                xb.se_w1t = im.upload(wt);
+                // thread t -> gate rows 2*(t/4), +1 over inputs i = 64*(t%4) + k: the first 32 inputs, then (second image) the other 32
+                std::vector<float> pk = pack_se_threads_f32([&](int t, int row, int k) { return wt[size_t(64 * (t & 3) + k) * C + 2 * (t >> 2) + row]; });
+                const std::vector<float> pk2 = pack_se_threads_f32([&](int t, int row, int k) { return wt[size_t(64 * (t & 3) + 32 + k) * C + 2 * (t >> 2) + row]; });
+                pk.insert(pk.end(), pk2.begin(), pk2.end());
+                xb.se_w1t = im.upload(pk);
                 xb.se_b = im.upload(b);
             } else if (se_in_kernel) {
                 td.se_kind = 2;
@@ -814,7 +828,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             xb.w1pk_lo = im.upload(s1.lo);
             xb.w3pk = im.upload(s3.hi);
             xb.w3pk_lo = im.upload(s3.lo);
-            std::vector<float> rec(size_t(cop_pad) * 12, 0.f);      // per channel: 9 taps, BN1 bias, BN2 bias, pad
+            std::vector<float> rec(size_t(cop_pad) * 12 + 64, 0.f); // per channel: 9 taps, BN1 bias, BN2 bias, pad; + 64 floats (kernels.h)
             for (int c = 0; c < cop; ++c) {
                 for (int t = 0; t < 9; ++t) rec[size_t(c) * 12 + t] = float(f2.w[size_t(c) * 9 + t]);
                 rec[size_t(c) * 12 + 9] = float(f1.b[c]);
@@ -857,7 +871,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             ba.cop_pad = cop_pad;
             ba.ks = k;
             if (k == 3) {   // per-channel record for the DPP depthwise kernel: 9 taps, BN1 bias, BN2 bias, pad
-                std::vector<float> rec(size_t(cop_pad) * 12, 0.f);
+                std::vector<float> rec(size_t(cop_pad) * 12 + 64, 0.f);     // + 64: the float16x3 kernel loads 1 KiB where a wave's records start
                 for (int c = 0; c < cop; ++c) {
                     for (int t = 0; t < 9; ++t) rec[size_t(c) * 12 + t] = float(f2.w[size_t(c) * 9 + t]);
                     rec[size_t(c) * 12 + 9] = float(f1.b[c]);

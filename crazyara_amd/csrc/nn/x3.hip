@@ -238,20 +238,27 @@ struct X3Block {
     static constexpr int C = 256, NW = 8, NE = CRA_X3_NE, CK = 16 * NW * NE, NTHR = 64 * NW, NJ = C / 16 / NW;
     static constexpr int XROW = C + 16;      // halves; 32-byte row pad (rows step 8 banks: conflict-free 16-row fragment reads)
     static constexpr int TROW = CK + 16;
-    static constexpr size_t lds_bytes = (size_t(2) * 64 * XROW + size_t(2) * 64 * TROW) * sizeof(half_t);     // NE = 1: 106,496 B; NE = 2: 139,264 B
+    static constexpr size_t dws_bytes = size_t(NW) * NE * 1024;
+    // NE = 1: the depthwise output tile is double-buffered -- ONE barrier per chunk (the depthwise of chunk k + 1 writes the other
+    // buffer while slower waves still read chunk k's in their project phase), and the waves of a SIMD drift apart: one is in a
+    // matrix phase while its partner runs the depthwise
+    static constexpr int T2BUF = NE == 1 ? 2 : 1;
+    static constexpr size_t lds_bytes = (size_t(2) * 64 * XROW + size_t(2) * T2BUF * 64 * TROW) * sizeof(half_t) + dws_bytes;   // NE = 1: 151,552 B; NE = 2: 155,648 B
 };
 static_assert(X3Block::lds_bytes <= 160 * 1024, "LDS budget");
 
 struct X3Tiles {
     half_t *xh, *xl;        // [64][XROW] block input = residual stream, hi / lo
-    half_t *t2h, *t2l;      // [64][TROW] depthwise output of the current chunk, hi / lo
+    half_t *t2h, *t2l;      // [T2BUF][64][TROW] depthwise output of a chunk, hi / lo (buffer = chunk parity)
+    float* dws;             // [8 waves][NE][256 floats] the waves' depthwise records of the chunk (16 channels x 12 floats + pad each)
 };
 __device__ __forceinline__ X3Tiles x3_tiles(char* smem) {
     X3Tiles t;
     t.xh = reinterpret_cast<half_t*>(smem);
     t.xl = t.xh + 64 * X3Block::XROW;
     t.t2h = t.xl + 64 * X3Block::XROW;
-    t.t2l = t.t2h + 64 * X3Block::TROW;
+    t.t2l = t.t2h + X3Block::T2BUF * 64 * X3Block::TROW;
+    t.dws = reinterpret_cast<float*>(t.t2l + X3Block::T2BUF * 64 * X3Block::TROW);
     return t;
 }
 
@@ -277,7 +284,8 @@ __device__ __forceinline__ void x3_stage_tile(const X3Tiles& T, const float* xb,
 }
 
 // The chunk loop of one block: accP[j][t] += project(depthwise(expand(x))) for this wave's 32 couts x 64 squares.  The caller has put a
-// barrier behind the last write of the x tiles; the loop ends with a barrier (t2 and x are free to be rewritten).
+// barrier behind the last write of the x tiles.  On return every wave is done with the x tiles (the last expand phase lies before the
+// last chunk barrier); other waves may still be reading t2 in their last project phase.
 // Weights are read with raw buffer loads: resource descriptor + wave-uniform byte offset in SGPRs, the lane part one constant VGPR.
 // (Through the pointers of a descriptor array in device memory the compiler can only emit FLAT loads, which count on the LDS
 // counter too: every wait for an LDS operand then also waits for the weight fragments requested slabs ahead.)
@@ -336,22 +344,33 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
 #pragma unroll
     for (int s = 0; s < EW; ++s) load_expand(0, s);
     for (int ch = 0; ch < nchunk; ++ch) {
+        half_t* const t2h = T.t2h + (G::T2BUF == 2 ? (ch & 1) * 64 * TROW : 0);
+        half_t* const t2l = T.t2l + (G::T2BUF == 2 ? (ch & 1) * 64 * TROW : 0);
         // ---------------- E: expand, NE x 16 channels x 64 squares per wave, K = C; a tile fragment of the stream feeds NE channel tiles ----
         f32x4 accE[NE][4];
 #pragma unroll
         for (int ne = 0; ne < NE; ++ne)
 #pragma unroll
             for (int t = 0; t < 4; ++t) accE[ne][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // per-channel depthwise records of my 4 channels of a tile (9 taps, BN1 bias, BN2 bias, 0), requested ahead of their use
-        f32x4 dwr[NE][4][3];
-        auto load_dw = [&](int ne) {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const uint32_t base = uint32_t(ch * CK + (wave * NE + ne) * 16) * 48u;        // wave-uniform; + my channel group's 4 records
+        // Depthwise records (per channel 9 taps, BN1 bias, BN2 bias, 0 = 48 B) of my 16 * NE channels: ONE 16-byte load per lane and tile
+        // (768 of its 1024 bytes are the tile's records), parked in a wave-private LDS scratch half-way through the expand MFMAs and read
+        // back per lane as 12 broadcast reads.  (Loaded per lane straight from L2 -- 12 loads of which 16 lanes each fetch the same
+        // bytes -- the records were a quarter of all bytes on the 64 B/clk L2 -> CU path, which this loop nearly saturates.)
+        f32x4 dw_raw[NE];
+#pragma unroll
+        for (int ne = 0; ne < NE; ++ne)
+            dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(ch * CK + (wave * NE + ne) * 16) * 48u, 0));
+        float* my_dws = T.dws + (wave * NE) * 256;
+        auto park_dw = [&]() {
+#pragma unroll
+            for (int ne = 0; ne < NE; ++ne) *reinterpret_cast<f32x4*>(my_dws + ne * 256 + lane * 4) = dw_raw[ne];
+        };
+        f32x4 dwr[4][3];
+        auto read_dw = [&](int ne) {                           // my 4 channels' records (the same wave wrote them: LDS keeps the order)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    dwr[ne][r][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, uint32_t(lg) * 192u, base + uint32_t(r * 48 + k * 16), 0));
+                for (int k = 0; k < 3; ++k) dwr[r][k] = *reinterpret_cast<const f32x4*>(my_dws + ne * 256 + (lg * 4 + r) * 12 + k * 4);
         };
         // A slab = 12 * NE MFMAs on the stream fragments of one k-slab.  The NEXT slab's fragments are read from LDS before this slab's
         // MFMAs issue and the window refills right behind them; the fences keep the machine scheduler from sinking either to just in
@@ -387,7 +406,7 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
 #pragma unroll
                 for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bh[s & 1][t], accE[ne][t], !(X3_ABL & 2));
             if (s + EW < C / 32) load_expand(ch, s + EW);
-            if (s == C / 64) load_dw(0);                       // half-way through the expand MFMAs: landed when the depthwise starts
+            if (s == C / 64) park_dw();                        // the records' load is half a phase old by now
             __builtin_amdgcn_sched_barrier(0);
         }
         // the first slabs of this chunk's project fragments: they land while the depthwise runs
@@ -413,20 +432,20 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
         // ---------------- D: BN1 + ReLU, depthwise 3x3 on the accumulators (block_kernel_dpp), BN2 + ReLU, exact f32 ----------------
 #pragma unroll
         for (int ne = 0; ne < NE; ++ne) {
-            if (ne + 1 < NE) load_dw(ne + 1);                   // the next tile's record flies while this tile's depthwise runs
+            read_dw(ne);
             float outv[4][4];                                   // [tile][channel r]
             if constexpr (X3_ABL & 1) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) outv[t][r] = accE[ne][t][r] + dwr[ne][r][0][0];
+                    for (int r = 0; r < 4; ++r) outv[t][r] = accE[ne][t][r] + dwr[r][0][0];
             } else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float b1 = dwr[ne][r][2][1], b2 = dwr[ne][r][2][2];
+                const float b1 = dwr[r][2][1], b2 = dwr[r][2][2];
                 float w[9];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) w[k] = dwr[ne][r][k >> 2][k & 3];
+                for (int k = 0; k < 9; ++k) w[k] = dwr[r][k >> 2][k & 3];
                 w[0] *= mL; w[3] *= mL; w[6] *= mL;             // file-edge masks folded into the dx = -1 / +1 columns
                 w[2] *= mR; w[5] *= mR; w[8] *= mR;
                 float e[4], rot[4];
@@ -460,8 +479,8 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
                 if constexpr (X3_ABL & 64) {
                     asm volatile("" ::"v"(h), "v"(l));
                 } else {
-                    *reinterpret_cast<half4*>(T.t2h + (t * 16 + l15) * TROW + cl) = h;
-                    *reinterpret_cast<half4*>(T.t2l + (t * 16 + l15) * TROW + cl) = l;
+                    *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
+                    *reinterpret_cast<half4*>(t2l + (t * 16 + l15) * TROW + cl) = l;
                 }
             }
         }
@@ -478,8 +497,8 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
                     h[t] = p_h[s2 % PW][0];
                     l[t] = p_l[s2 % PW][0];
                 } else {
-                    h[t] = *reinterpret_cast<const half8*>(T.t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
-                    l[t] = *reinterpret_cast<const half8*>(T.t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                    h[t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                    l[t] = *reinterpret_cast<const half8*>(t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
                 }
             }
         };
@@ -503,7 +522,7 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
             if (s2 + PW < CK / 32) load_project(s2 + PW);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (!(X3_ABL & 32)) __syncthreads();          // t2 is rewritten by the next chunk's depthwise
+        if constexpr (!(X3_ABL & 32) && G::T2BUF == 1) __syncthreads();     // single t2 buffer: it is rewritten by the next chunk's depthwise
     }
 }
 }  // namespace
@@ -561,53 +580,96 @@ __global__ __launch_bounds__(512) void block_x3_kernel(const BlockArgs a) {
 namespace {
 // SE gate of a block on the stream in LDS, exact f32 (the arithmetic of se_gate_kernel / se_kernel, kernels.hip): squeeze over the 64
 // squares, ca_se: relu(W1 mean) -> W2 -> hard-sigmoid, eca_se: centre-tap linear + bias -> hard-sigmoid, then x := x * gate, re-split.
-// scratch: 256 + 4 * 256 + 128 + 256 floats (the t2 tiles, idle between blocks).  Ends with a barrier.
+// The scheme of the float16 tower's SE phase (tower.hip) with float weights: the gate matrices are host-packed in THREAD order
+// (rise_net.hip: pack_se_threads_f32), a thread's 64 (eca: 128) weights are 16 (32) coalesced 16-byte loads that are all in flight
+// before the squeeze ends; the threads that share an output pair are neighbouring lanes and reduce by DPP.
+//   ca_se : FC1 thread t -> hidden 2*(t/8), +1 over c in [32*(t%8), +32);  FC2 thread t -> gate 2*(t/4), +1 over j in [32*(t%4), +32)
+//   eca_se: thread t -> gate 2*(t/4), +1 over inputs i in [64*(t%4), +64)
+// scratch (the t2 tiles, idle between blocks): mean 8 x 36, hidden 4 x 36, gate 256 floats.  Ends with a barrier.
 __device__ __forceinline__ void x3_se_phase(const X3Tiles& T, const X3TowerBlock& d, float* scratch, int tid) {
-    constexpr int C = X3Block::C, XROW = X3Block::XROW, H = C / 2;
-    float* mean = scratch;            // [256]
-    float* part = scratch + 256;      // [4][256]
-    float* hid = part + 4 * 256;      // [128]
-    float* gate = hid + 128;          // [256]
-    {   // squeeze: thread = (channel c, half of the squares)
-        const int c = tid & 255, q = tid >> 8;
-        float s = 0.f;
-#pragma unroll 4
-        for (int sq = q * 32; sq < q * 32 + 32; ++sq) s += float(T.xh[sq * XROW + c]) + float(T.xl[sq * XROW + c]);
-        part[q * 256 + c] = s;
+    constexpr int C = X3Block::C, XROW = X3Block::XROW, GRP = 36;     // floats per group of 32 means / hidden values (bank spread)
+    float* se_mean = scratch;              // [8][36]
+    float* se_h = scratch + 8 * GRP;       // [4][36]
+    float* se_gate = se_h + 4 * GRP;       // [256]
+    f32x4 wa[16], wb[16];
+    auto load_thread_weights = [&](const float* base, f32x4 (&dst)[16]) {
+        const f32x4* pk = reinterpret_cast<const f32x4*>(base) + tid;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[i] = pk[i * 512];
+    };
+    load_thread_weights(d.se_w1t, wa);
+    {   // squeeze: a wave owns 32 channels: lane = (4 groups of 8 channels) x (16 groups of 4 squares); 16-lane DPP row reduction
+        const int lane = tid & 63, wv = tid >> 6, cg = lane >> 4, sg = lane & 15;
+        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float fh[8], fl[8];
+            load8<half_t>(T.xh + (sg * 4 + q) * XROW + wv * 32 + cg * 8, fh);
+            load8<half_t>(T.xl + (sg * 4 + q) * XROW + wv * 32 + cg * 8, fl);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum[j] += fh[j] + fl[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sum[j] += dpp_mov<0x111>(sum[j]);    // row_shr:1
+            sum[j] += dpp_mov<0x112>(sum[j]);    // row_shr:2
+            sum[j] += dpp_mov<0x114>(sum[j]);    // row_shr:4
+            sum[j] += dpp_mov<0x118>(sum[j]);    // row_shr:8 -> lane 15 of the row holds the row's sum
+        }
+        if (sg == 15) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) se_mean[wv * GRP + cg * 8 + j] = sum[j] * (1.f / 64.f);      // channel c at (c / 32) * 36 + c % 32
+        }
     }
+    load_thread_weights(d.se_kind == 1 ? d.se_w2t : d.se_w1t + size_t(16) * 512 * 4, wb);      // flies during FC1 (eca: the second half)
     __syncthreads();
-    if (tid < 256) mean[tid] = (part[tid] + part[256 + tid]) * (1.f / 64.f);
-    __syncthreads();
+    auto dot32 = [](const f32x4 (&w)[16], const float* v, float& s0, float& s1) {   // v: 32 floats, 16-byte aligned; w[i] = (a, b, a', b') of k = 2i, 2i+1
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(v + 4 * k4);
+            s0 = fmaf(w[2 * k4][0], m[0], s0); s1 = fmaf(w[2 * k4][1], m[0], s1);
+            s0 = fmaf(w[2 * k4][2], m[1], s0); s1 = fmaf(w[2 * k4][3], m[1], s1);
+            s0 = fmaf(w[2 * k4 + 1][0], m[2], s0); s1 = fmaf(w[2 * k4 + 1][1], m[2], s1);
+            s0 = fmaf(w[2 * k4 + 1][2], m[3], s0); s1 = fmaf(w[2 * k4 + 1][3], m[3], s1);
+        }
+    };
     if (d.se_kind == 1) {
-        {   // FC1: 128 outputs, K = 256 in 4 slices of 64
-            const int j = tid & (H - 1), q = tid >> 7;
-            float s = 0.f;
-#pragma unroll 8
-            for (int c = q * 64; c < q * 64 + 64; ++c) s = fmaf(d.se_w1t[size_t(c) * H + j], mean[c], s);
-            part[q * 256 + j] = s;
+        {
+            const int j2 = tid >> 3, kq = tid & 7;
+            float s0 = 0.f, s1 = 0.f;
+            dot32(wa, se_mean + kq * GRP, s0, s1);
+            s0 += dpp_mov<0x111>(s0); s1 += dpp_mov<0x111>(s1);
+            s0 += dpp_mov<0x112>(s0); s1 += dpp_mov<0x112>(s1);
+            s0 += dpp_mov<0x114>(s0); s1 += dpp_mov<0x114>(s1);             // lane 7 of the group of 8: the whole sum
+            if (kq == 7) {                                                    // hidden j = 2*j2, +1 at (j / 32) * 36 + j % 32
+                float* h = se_h + (j2 >> 4) * GRP + 2 * (j2 & 15);
+                h[0] = fmaxf(s0, 0.f);
+                h[1] = fmaxf(s1, 0.f);
+            }
         }
         __syncthreads();
-        if (tid < H) hid[tid] = fmaxf(part[tid] + part[256 + tid] + part[512 + tid] + part[768 + tid], 0.f);
-        __syncthreads();
-        {   // FC2: 256 outputs, K = 128 in 2 slices of 64
-            const int c = tid & 255, q = tid >> 8;
-            float s = 0.f;
-#pragma unroll 8
-            for (int j = q * 64; j < q * 64 + 64; ++j) s = fmaf(d.se_w2t[size_t(j) * C + c], hid[j], s);
-            part[q * 256 + c] = s;
+        {
+            const int c2 = tid >> 2, kq = tid & 3;
+            float s0 = 0.f, s1 = 0.f;
+            dot32(wb, se_h + kq * GRP, s0, s1);
+            s0 += dpp_mov<0x111>(s0); s1 += dpp_mov<0x111>(s1);
+            s0 += dpp_mov<0x112>(s0); s1 += dpp_mov<0x112>(s1);             // lane 3 of the group of 4
+            if (kq == 3) {
+                se_gate[2 * c2] = hard_sigmoid(s0);
+                se_gate[2 * c2 + 1] = hard_sigmoid(s1);
+            }
         }
-        __syncthreads();
-        if (tid < 256) gate[tid] = hard_sigmoid(part[tid] + part[256 + tid]);
     } else {
-        {   // eca: 256 outputs, K = 256 in 2 slices of 128
-            const int c = tid & 255, q = tid >> 8;
-            float s = 0.f;
-#pragma unroll 8
-            for (int i = q * 128; i < q * 128 + 128; ++i) s = fmaf(d.se_w1t[size_t(i) * C + c], mean[i], s);
-            part[q * 256 + c] = s;
+        const int c2 = tid >> 2, kq = tid & 3;
+        float s0 = 0.f, s1 = 0.f;
+        dot32(wa, se_mean + (2 * kq) * GRP, s0, s1);
+        dot32(wb, se_mean + (2 * kq + 1) * GRP, s0, s1);
+        s0 += dpp_mov<0x111>(s0); s1 += dpp_mov<0x111>(s1);
+        s0 += dpp_mov<0x112>(s0); s1 += dpp_mov<0x112>(s1);
+        if (kq == 3) {
+            se_gate[2 * c2] = hard_sigmoid(d.se_b[2 * c2] + s0);
+            se_gate[2 * c2 + 1] = hard_sigmoid(d.se_b[2 * c2 + 1] + s1);
         }
-        __syncthreads();
-        if (tid < 256) gate[tid] = hard_sigmoid(d.se_b[tid] + part[tid] + part[256 + tid]);
     }
     __syncthreads();
 #pragma unroll 1
@@ -616,7 +678,7 @@ __device__ __forceinline__ void x3_se_phase(const X3Tiles& T, const X3TowerBlock
         float fh[8], fl[8], gv[8];
         load8<half_t>(T.xh + r * XROW + v * 8, fh);
         load8<half_t>(T.xl + r * XROW + v * 8, fl);
-        load8<float>(gate + v * 8, gv);
+        load8<float>(se_gate + v * 8, gv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) fh[j] = (fh[j] + fl[j]) * gv[j];
         half8 h, l;

@@ -294,14 +294,19 @@ struct X3Weights {
     __amdgpu_buffer_rsrc_t dw;                   // [cop_pad][12] floats: 9 folded taps, BN1 bias, BN2 bias, 0
     int cop_pad;
 };
+// The pointer is wave-uniform, but read from a descriptor array in device memory the compiler has it in VGPRs and wraps EVERY buffer load
+// in a waterfall loop (readfirstlane / compare / saveexec / branch: ~12 instructions per load, 33 loads per chunk): say so explicitly.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint64_t u = (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))))) << 32) |
+                       uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v))));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(u), 0, 0x7fffffff, 0x00020000);
 }
 __device__ __forceinline__ X3Weights x3_weights(const void* w1h, const void* w1l, const void* w3h, const void* w3l, const float* dwpk, int cop_pad) {
     X3Weights W;
     W.w1h = x3_rsrc(w1h); W.w1l = x3_rsrc(w1l); W.w3h = x3_rsrc(w3h); W.w3l = x3_rsrc(w3l);
     W.dw = x3_rsrc(dwpk);
-    W.cop_pad = cop_pad;
+    W.cop_pad = __builtin_amdgcn_readfirstlane(cop_pad);
     return W;
 }
 __device__ __forceinline__ half8 x3_frag(__amdgpu_buffer_rsrc_t r, uint32_t lane_off, uint32_t frag) {      // fragment = 64 lanes x 16 B

@@ -15,6 +15,8 @@
 #include "kernels.h"
 #include "device_utils.h"
 
+#include <cstdlib>
+
 // CRA_X3_ABL: development switches that TIME parts of the tower's chunk loop (scripts/ubench/x3_tower_ablate.hip); every bit computes wrong
 // results on purpose, so they only compile in a development build.  1: no depthwise arithmetic, 2: no expand MFMAs, 4: no project MFMAs,
 // 8: no LDS operand reads (expand and project), 16: no weight loads, 32: no chunk barriers, 64: no t2 stores
@@ -751,9 +753,289 @@ __global__ __launch_bounds__(512) void tower_x3_kernel(const X3TowerArgs a) {
     }
 }
 
+// ---- the same run of blocks with the waves in two ROLES ----
+// Waves 0-3 expand and run the depthwise (EXPAND waves), waves 4-7 project (PROJECT waves); wave w and wave w + 4 share a SIMD.
+//   interval k (one workgroup barrier):  EXPAND wave w : E(k+1) = 32 channels x 64 squares, K = 256 (two 16-channel tiles share every
+//                                                         stream fragment they read from LDS), then D(k+1) on the accumulators -> t2[(k+1)&1]
+//                                        PROJECT wave v: P(k)   = 64 couts x 64 squares, K = 128 from t2[k&1] into its persistent accumulator
+// Against the symmetric form (x3_chunks: every wave 16 channels of E, then D, then 32 couts of P): a fragment read from LDS feeds twice
+// the MFMAs (LDS operand traffic halves: the symmetric expand phase is LDS-bound), a SIMD's matrix pipe always has the PROJECT wave's
+// MFMAs to run while its EXPAND wave is in the depthwise, and there is one barrier per chunk.  The price is the pipeline's fill and
+// drain once per block (the next block's expand needs this block's output): intervals -1 and n - 1 run one role only.
+__global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a) {
+    using G = X3Block;
+    static_assert(G::NE == 1 && G::T2BUF == 2 && G::CK == 128, "the role kernel uses the NE = 1 tile geometry (two t2 buffers of 128 channels)");
+    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const X3Tiles T = x3_tiles(smem);
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool expand_role = wave < 4;
+    const int w = wave & 3;
+    const uint32_t lane_off = uint32_t(lane) * 16u;
+    x3_stage_tile(T, a.x + size_t(b) * 64 * C, nullptr, tid);
+    __syncthreads();
+    for (int blk = 0; blk < a.nblocks; ++blk) {
+        const X3TowerBlock& d = a.blocks[blk];
+        if (blk > 0 && d.se_kind != 0) x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid);
+        const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
+        const int n = W.cop_pad / CK;
+        const int nslab3 = W.cop_pad >> 5;
+        if (expand_role) {
+#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_EPRIO)
+            __builtin_amdgcn_s_setprio(CRA_X3_EPRIO);                  // development: issue priority of the EXPAND waves
+#endif
+            const bool hi = l15 >= 8;                                  // second board row of a 16-square tile
+            const float mL = (l15 & 7) != 0 ? 1.f : 0.f;               // a left / right neighbour exists on the board
+            const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
+            // expand weight window: 2 of the 8 k-slabs x 2 channel tiles x (hi, lo); the stream runs on across chunk boundaries (through
+            // the depthwise): slab s of chunk k sits in slot s % 2 and is refilled with the slab 2 positions ahead right behind its MFMAs
+            constexpr int EW = 2;
+            half8 e_h[EW][2], e_l[EW][2];
+            auto load_e = [&](int k, int s) {                          // cout tile (16 channels) of (chunk k, wave w, ne) = k * 8 + w * 2 + ne
+                if constexpr (X3_ABL & 16) return;
+#pragma unroll
+                for (int ne = 0; ne < 2; ++ne) {
+                    const uint32_t f = uint32_t(k * (CK / 16) + w * 2 + ne) * (C / 32) + uint32_t(s);
+                    e_h[s % EW][ne] = x3_frag(W.w1h, lane_off, f);
+                    e_l[s % EW][ne] = x3_frag(W.w1l, lane_off, f);
+                }
+            };
+            if constexpr (X3_ABL & 16) {
+#pragma unroll
+                for (int s = 0; s < EW; ++s)
+#pragma unroll
+                    for (int ne = 0; ne < 2; ++ne) e_h[s][ne] = e_l[s][ne] = *reinterpret_cast<const half8*>(T.xh + lane * 8);
+            }
+#pragma unroll
+            for (int s = 0; s < EW; ++s) load_e(0, s);
+            float* my_dws = T.dws + (w * 2) * 256;                     // this wave's two record tiles (8 x 256 floats in all)
+            for (int kk = -1; kk < n; ++kk) {
+                const int k = kk + 1;                                  // the chunk this interval expands
+                if (k < n) {
+                    half_t* const t2h = T.t2h + (k & 1) * 64 * TROW;
+                    half_t* const t2l = T.t2l + (k & 1) * 64 * TROW;
+                    // depthwise records of my 32 channels: two 16-byte loads per lane (x3_chunks), parked in LDS half-way through the MFMAs
+                    f32x4 dw_raw[2];
+#pragma unroll
+                    for (int ne = 0; ne < 2; ++ne)
+                        dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(k * CK + (w * 2 + ne) * 16) * 48u, 0));
+                    f32x4 accE[2][4];
+#pragma unroll
+                    for (int ne = 0; ne < 2; ++ne)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) accE[ne][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    half8 bh[2][4], bl[2][4];
+                    auto read_stream = [&](int s, half8 (&h)[4], half8 (&l)[4]) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if constexpr (X3_ABL & 8) {
+                                h[t] = e_h[s % EW][0];
+                                l[t] = e_l[s % EW][0];
+                            } else {
+                                h[t] = *reinterpret_cast<const half8*>(T.xh + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                                l[t] = *reinterpret_cast<const half8*>(T.xl + (t * 16 + l15) * XROW + s * 32 + lg * 8);
+                            }
+                        }
+                    };
+                    read_stream(0, bh[0], bl[0]);
+#pragma unroll
+                    for (int s = 0; s < C / 32; ++s) {
+                        if (s + 1 < C / 32) read_stream(s + 1, bh[(s + 1) & 1], bl[(s + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ne = 0; ne < 2; ++ne)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) x3_mfma(e_l[s % EW][ne], bh[s & 1][t], accE[ne][t], !(X3_ABL & 2));
+#pragma unroll
+                        for (int ne = 0; ne < 2; ++ne)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bl[s & 1][t], accE[ne][t], !(X3_ABL & 2));
+#pragma unroll
+                        for (int ne = 0; ne < 2; ++ne)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bh[s & 1][t], accE[ne][t], !(X3_ABL & 2));
+                        if (s + EW < C / 32) load_e(k, s + EW);
+                        else if (k + 1 < n) load_e(k + 1, s + EW - C / 32);
+                        if (s == C / 64) {
+#pragma unroll
+                            for (int ne = 0; ne < 2; ++ne) *reinterpret_cast<f32x4*>(my_dws + ne * 256 + lane * 4) = dw_raw[ne];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // D: BN1 + ReLU, depthwise 3x3 on the accumulators by DPP lane shifts, BN2 + ReLU (exact f32), split -> t2
+#pragma unroll
+                    for (int ne = 0; ne < 2; ++ne) {
+                        f32x4 dwr[4][3];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) dwr[r][q] = *reinterpret_cast<const f32x4*>(my_dws + ne * 256 + (lg * 4 + r) * 12 + q * 4);
+                        float outv[4][4];                               // [tile][channel r]
+                        if constexpr (X3_ABL & 1) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) outv[t][r] = accE[ne][t][r] + dwr[r][0][0];
+                        } else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float b1 = dwr[r][2][1], b2 = dwr[r][2][2];
+                            float wt[9];
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) wt[q] = dwr[r][q >> 2][q & 3];
+                            wt[0] *= mL; wt[3] *= mL; wt[6] *= mL;     // file-edge masks folded into the dx = -1 / +1 columns
+                            wt[2] *= mR; wt[5] *= mR; wt[8] *= mR;
+                            float e[4], rot[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                e[t] = fmaxf(accE[ne][t][r] + b1, 0.f);
+                                rot[t] = dpp_mov<DPP_ROW_ROR8>(e[t]);
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const float up = hi ? rot[t] : (t > 0 ? rot[t > 0 ? t - 1 : 0] : 0.f);
+                                const float dn = hi ? (t < 3 ? rot[t < 3 ? t + 1 : 3] : 0.f) : rot[t];
+                                float acc = b2;
+                                acc = fmac_shr1(acc, up, wt[0]);
+                                acc = fmaf(wt[1], up, acc);
+                                acc = fmac_shl1(acc, up, wt[2]);
+                                acc = fmac_shr1(acc, e[t], wt[3]);
+                                acc = fmaf(wt[4], e[t], acc);
+                                acc = fmac_shl1(acc, e[t], wt[5]);
+                                acc = fmac_shr1(acc, dn, wt[6]);
+                                acc = fmaf(wt[7], dn, acc);
+                                acc = fmac_shl1(acc, dn, wt[8]);
+                                outv[t][r] = fmaxf(acc, 0.f);
+                            }
+                        }
+                        const int cl = (w * 2 + ne) * 16 + lg * 4;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            half4 h, l;
+                            split4(outv[t], h, l);
+                            if constexpr (X3_ABL & 64) {
+                                asm volatile("" ::"v"(h), "v"(l));
+                            } else {
+                                *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
+                                *reinterpret_cast<half4*>(t2l + (t * 16 + l15) * TROW + cl) = l;
+                            }
+                        }
+                    }
+                }
+                if constexpr (!(X3_ABL & 32)) __syncthreads();
+            }
+            __syncthreads();                                            // the PROJECT waves' block epilogue
+        } else {
+            // project weight window: 2 of a chunk's 4 k-slabs x 4 cout tiles x (hi, lo), running on across chunk boundaries
+            constexpr int PW = 2, NJ = 4;
+            half8 p_h[PW][NJ], p_l[PW][NJ];
+            auto load_p = [&](int k, int s2) {                         // cout tile = w * 4 + j, K slab = k * 4 + s2
+                if constexpr (X3_ABL & 16) return;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const uint32_t f = uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + s2);
+                    p_h[s2 % PW][j] = x3_frag(W.w3h, lane_off, f);
+                    p_l[s2 % PW][j] = x3_frag(W.w3l, lane_off, f);
+                }
+            };
+            if constexpr (X3_ABL & 16) {
+#pragma unroll
+                for (int s2 = 0; s2 < PW; ++s2)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) p_h[s2][j] = p_l[s2][j] = *reinterpret_cast<const half8*>(T.xl + lane * 8);
+            }
+            f32x4 accP[NJ][4];                                          // couts (w * 4 + j) * 16 + lg * 4 .. + 3, squares t * 16 + l15
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {                              // the accumulators start at the BN3 bias of their 4 couts
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(d.b3 + (w * NJ + j) * 16 + lg * 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accP[j][t] = bs;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < PW; ++s2) load_p(0, s2);
+            for (int kk = -1; kk < n; ++kk) {
+                if (kk >= 0) {
+                    const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
+                    const half_t* const t2l = T.t2l + (kk & 1) * 64 * TROW;
+                    half8 bh[2][4], bl[2][4];
+                    auto read_t2 = [&](int s2, half8 (&h)[4], half8 (&l)[4]) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if constexpr (X3_ABL & 8) {
+                                h[t] = p_h[s2 % PW][0];
+                                l[t] = p_l[s2 % PW][0];
+                            } else {
+                                h[t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                                l[t] = *reinterpret_cast<const half8*>(t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                            }
+                        }
+                    };
+                    read_t2(0, bh[0], bl[0]);
+#pragma unroll
+                    for (int s2 = 0; s2 < CK / 32; ++s2) {
+                        if (s2 + 1 < CK / 32) read_t2(s2 + 1, bh[(s2 + 1) & 1], bl[(s2 + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) x3_mfma(p_l[s2 % PW][j], bh[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bl[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
+                        if (s2 + PW < CK / 32) load_p(kk, s2 + PW);
+                        else if (kk + 1 < n) load_p(kk + 1, s2 + PW - CK / 32);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if constexpr (!(X3_ABL & 32)) __syncthreads();
+            }
+            // block epilogue: new stream = x + body(x), split again, in place (every EXPAND wave is behind its last read of the tiles: it
+            // waits at the barrier below)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int co0 = (w * NJ + j) * 16 + lg * 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int sq = t * 16 + l15;
+                    float rh[4], rl[4], v[4];
+                    load4<half_t>(T.xh + sq * XROW + co0, rh);
+                    load4<half_t>(T.xl + sq * XROW + co0, rl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = accP[j][t][r] + (rh[r] + rl[r]);
+                    half4 h, l;
+                    split4(v, h, l);
+                    *reinterpret_cast<half4*>(T.xh + sq * XROW + co0) = h;
+                    *reinterpret_cast<half4*>(T.xl + sq * XROW + co0) = l;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // stream -> HBM as float, 32-byte pieces per thread
+    float* yb = a.y + size_t(b) * 64 * C;
+#pragma unroll 1
+    for (int i = tid; i < 64 * (C / 8); i += G::NTHR) {
+        const int r = i / (C / 8), v = i - r * (C / 8);
+        float fh[8], fl[8];
+        load8<half_t>(T.xh + r * XROW + v * 8, fh);
+        load8<half_t>(T.xl + r * XROW + v * 8, fl);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fh[j] += fl[j];
+        store8<float>(yb + size_t(r) * C + v * 8, fh);
+    }
+}
+
 void init_x3_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
 }
 int block_x3_chunk_channels() { return X3Block::CK; }
 
@@ -761,7 +1043,10 @@ void launch_block_x3(const BlockArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(block_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
 }
 void launch_tower_x3(const X3TowerArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(tower_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+    // CRA_X3_TOWER=symmetric: every wave runs all three phases (A/B reference); default: the two-role kernel
+    static const bool symmetric = [] { const char* e = getenv("CRA_X3_TOWER"); return e != nullptr && e[0] == 's'; }();
+    if (symmetric) hipLaunchKernelGGL(tower_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+    else hipLaunchKernelGGL(tower_x3_roles_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
 }
 
 }  // namespace cra

@@ -762,6 +762,8 @@ __global__ __launch_bounds__(512) void tower_x3_kernel(const X3TowerArgs a) {
 // the MFMAs (LDS operand traffic halves: the symmetric expand phase is LDS-bound), a SIMD's matrix pipe always has the PROJECT wave's
 // MFMAs to run while its EXPAND wave is in the depthwise, and there is one barrier per chunk.  The price is the pipeline's fill and
 // drain once per block (the next block's expand needs this block's output): intervals -1 and n - 1 run one role only.
+// Measured and NOT kept (profiles/r03/h_*): L2 warm-up touches of the weight stream two chunks ahead (the float16 tower's trick) made
+// this kernel 9 % slower -- alone, its weight stream already runs at 27 TB/s (80 % of the L2 -> CU peak); s_setprio on the EXPAND waves: nothing.
 __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a) {
     using G = X3Block;
     static_assert(G::NE == 1 && G::T2BUF == 2 && G::CK == 128, "the role kernel uses the NE = 1 tile geometry (two t2 buffers of 128 channels)");
@@ -774,45 +776,6 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
     const bool expand_role = wave < 4;
     const int w = wave & 3;
     const uint32_t lane_off = uint32_t(lane) * 16u;
-    // L2 warm-up of the weight stream (the float16 tower's trick, tower.hip): the 32 workgroups of an XCD consume the same 256 KiB of
-    // fragments per chunk in near lockstep, so without help every line is an L2 miss IN FLIGHT for all of them (the 27 MB of a net's
-    // split weights do not stay in a 4 MiB L2 from one forward to the next) and every slab waits out a fabric round trip.  Each
-    // workgroup therefore touches 1/32 of a chunk's 2048 lines (one dword each: 4 x 16 lanes, one group per fragment array) two chunks
-    // before they are needed; workgroup b is on XCD b % 8 under round-robin dispatch -- an assumption about speed only.
-    int pf_sink = 0;
-    auto touch_chunk = [&](const X3TowerBlock& dd, int k) {            // chunk k of block dd; called by ONE wave
-        const int L = lane * 32 + ((b >> 3) & 31);                     // my line of the chunk's 2048: [w1 hi | w1 lo | w3 hi | w3 lo] x 512
-        const int g = lane >> 4, l = L & 511;
-        const uint32_t nsl = uint32_t(__builtin_amdgcn_readfirstlane(dd.cop_pad)) >> 5;
-        const uint32_t off = g < 2 ? uint32_t(k) * 65536u + uint32_t(l) * 128u                                  // 64 KiB of expand tiles per chunk
-                                   : (uint32_t(l >> 5) * nsl + uint32_t(k) * 4u) * 1024u + uint32_t(l & 31) * 128u;   // 16 cout tiles x 4 KiB
-        const __amdgpu_buffer_rsrc_t r0 = x3_rsrc(dd.w1pk), r1 = x3_rsrc(dd.w1pk_lo), r2 = x3_rsrc(dd.w3pk), r3 = x3_rsrc(dd.w3pk_lo);
-        int v = 0;
-        if (g == 0) v = __builtin_amdgcn_raw_buffer_load_b32(r0, off, 0, 0);
-        else if (g == 1) v = __builtin_amdgcn_raw_buffer_load_b32(r1, off, 0, 0);
-        else if (g == 2) v = __builtin_amdgcn_raw_buffer_load_b32(r2, off, 0, 0);
-        else v = __builtin_amdgcn_raw_buffer_load_b32(r3, off, 0, 0);
-        pf_sink ^= v;
-    };
-#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_TOUCH_AHEAD)
-    constexpr int TOUCH_AHEAD = CRA_X3_TOUCH_AHEAD;
-#else
-    constexpr int TOUCH_AHEAD = 2;                                     // chunks
-#endif
-    // chunk `ahead` positions after (blk, k) in the run of blocks, or nothing behind the last block
-    auto touch_ahead = [&](int blk, int k, int ahead) {
-        int tb = blk, tk = k + ahead;
-        while (tb < a.nblocks) {
-            const int nb = __builtin_amdgcn_readfirstlane(a.blocks[tb].cop_pad) / CK;
-            if (tk < nb) { touch_chunk(a.blocks[tb], tk); return; }
-            tk -= nb;
-            ++tb;
-        }
-    };
-    if (wave == 0) {
-#pragma unroll 1
-        for (int i = 0; i < TOUCH_AHEAD; ++i) touch_ahead(0, 0, i);
-    }
     x3_stage_tile(T, a.x + size_t(b) * 64 * C, nullptr, tid);
     __syncthreads();
     for (int blk = 0; blk < a.nblocks; ++blk) {
@@ -903,11 +866,6 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    // the warm-up touch for the chunk two positions ahead goes out here: this wave's next wait on a load is a whole
-                    // depthwise away (loads retire in order: a touch -- a miss by design -- in front of a fragment load would hold it up)
-#if !(defined(CRA_DEVELOPMENT) && defined(CRA_X3_NO_TOUCH))
-                    if (wave == 0) touch_ahead(blk, k, TOUCH_AHEAD);
-#endif
                     // D: BN1 + ReLU, depthwise 3x3 on the accumulators by DPP lane shifts, BN2 + ReLU (exact f32), split -> t2
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne) {
@@ -1062,7 +1020,6 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
             __syncthreads();
         }
     }
-    asm volatile("" ::"v"(pf_sink));                             // keeps the warm-up loads alive; their values are never used
     // stream -> HBM as float, 32-byte pieces per thread
     float* yb = a.y + size_t(b) * 64 * C;
 #pragma unroll 1

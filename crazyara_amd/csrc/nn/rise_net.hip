@@ -198,7 +198,17 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     // 8-bit format with a one-instruction conversion from f16 and a matrix instruction at twice the f16 rate is e4m3, so that is what
     // the mode runs on: the GEMMs of the residual tower take e4m3 operands (no calibration file: per-row power-of-two weight scales,
     // f32 accumulation, the residual stream itself stays f16); stem and heads stay f16.  "int8" is accepted as the reference's name for it.
-    else if (prec == "fp8" || prec == "float8" || prec == "int8") { fp16_ = true; fp8_tower_ = true; }
+    else if (prec == "fp8" || prec == "float8" || prec == "int8") {
+        fp16_ = true;
+        fp8_tower_ = true;
+        if (prec == "int8") {        // say so once per process: a user of the reference's calibrated INT8 gets a different 8-bit mode
+            static std::once_flag told;
+            std::call_once(told, [] {
+                fprintf(stderr, "info string Precision int8: running the e4m3 mode (\"fp8\": OCP e4m3 GEMM operands in the residual tower, no calibration "
+                                "file; value within ~3e-2 of fp32) -- TensorRT's calibrated INT8 kernels have no counterpart here\n");
+            });
+        }
+    }
     else if (prec == "float32" || prec == "fp32") fp16_ = false;
     // the fast mode that meets "logits within 1e-3 of fp32": float activations, every dense contraction as three f16 MFMAs on split
     // operands (x3.hip)

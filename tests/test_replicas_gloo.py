@@ -1,5 +1,7 @@
 """N > 1 path on CPU: world-size-2 gloo run of the replica statistics reduction bench.py uses on RCCL."""
 import os
+
+import pytest
 import socket
 
 import torch
@@ -105,3 +107,22 @@ def test_two_ranks_split_the_host_threads_and_report_per_rank():
         assert set(c0) | set(c1) <= set(b0)
     assert t0 >= 1 and t1 >= 1 and t0 <= max(1, len(b0) // 2)
     assert g0 == g1 and [v[1] for v in g0] == [1000.0, 2000.0]
+
+
+def test_bench_started_plainly_with_gpus_2_becomes_two_ranks():
+    """`python bench.py --gpus 2` (no launcher around it: how the driver starts the N > 1 runs) re-executes itself under
+    torch.distributed.run with one rank per GPU.  On this GPU-less host both ranks must come up and refuse loudly -- the hot path has
+    no CPU fallback -- instead of the launch failing before any rank exists."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU box: the ranks would run")
+    assert r.returncode != 0
+    assert r.stdout.count("bench.py needs a GPU") == 2, r.stdout[-2000:]

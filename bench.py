@@ -327,10 +327,16 @@ def config_game_legs(args, device, threads):
         pa, pb = search.SearchPool(st, net_a=na[0], net_b=na[1]), search.SearchPool(st, net_a=nb[0], net_b=nb[1])
         s = selfplay.SelfPlaySettings(variant=variant, simulations=400, max_plies=80, seed=12)
         starts = [f for f, _, _ in searchbench.variant_positions(variant)]       # one start position per pair of games
-        arena = selfplay.Arena(pa, pb, s, 64, start_fen=lambda i: starts[i % len(starts)])
-        res, recs = arena.play(64, threads=threads)
+        # only the side to move searches, so half of a pool's trees sit out every round: the trees that run share the whole batch
+        # (mi_search_set_adaptive_quota) -- 128 concurrent games = 32 running trees per lane x 32 leaves = the batch of 1024
+        pa.set_adaptive_quota(32)
+        pb.set_adaptive_quota(32)
+        arena = selfplay.Arena(pa, pb, s, 128, start_fen=lambda i: starts[i % len(starts)])
+        res, recs = arena.play(128, threads=threads)
         total["games"] += len(recs); total["moves"] += int(arena.stats["moves"]); total["seconds"] += arena.stats["seconds"]
         total["nodes"] += int(arena.stats["nodes"]); total["wins"] += res.wins; total["draws"] += res.draws; total["losses"] += res.losses
+        total["run_seconds"] = total.get("run_seconds", 0.0) + arena.stats["run_seconds"]
+        total["move_seconds"] = total.get("move_seconds", 0.0) + arena.stats["move_seconds"]
         arena.close()
         pa.close(); pb.close()
         for n in na + nb:
@@ -338,9 +344,11 @@ def config_game_legs(args, device, threads):
     out["config5_arena_one_gpu"] = {
         "games_per_min": round(total["games"] / total["seconds"] * 60, 1), "games": total["games"], "moves": total["moves"],
         "seconds": round(total["seconds"], 3), "mcts_nodes_per_sec": round(total["nodes"] / total["seconds"], 1),
+        "seconds_in_search": round(total["run_seconds"], 3), "seconds_in_move_step": round(total["move_seconds"], 3),
         "contender_score": {"wins": total["wins"], "draws": total["draws"], "losses": total["losses"]},
-        "workload": "arena between two RISEv2-13 80-channel nets (native loop), 3check then king-of-the-hill, 64 concurrent games in colour-"
-                    "swapped pairs from the variants' opening positions, batch 1024, 400 simulations per move, ply cap 80"}
+        "workload": "arena between two RISEv2-13 80-channel nets (native loop), 3check then king-of-the-hill, 128 concurrent games in colour-"
+                    "swapped pairs from the variants' opening positions, both players searching at the same time, batch 1024 shared by the "
+                    "running trees, 400 simulations per move, ply cap 80"}
     return out
 
 

@@ -353,14 +353,17 @@ size_t ArenaDriver::play(size_t n_games, int threads) {
             }
         SearchStats st[2];
         const auto r0 = std::chrono::steady_clock::now();
-        if (has[0] && has[1] && threads >= 2 && getenv("CRA_ARENA_SERIAL") == nullptr) {       // CRA_ARENA_SERIAL=1: one pool after the other (A/B)
-            const int tb = threads / 2;
+        const bool concurrent_pools = threads >= 2 && getenv("CRA_ARENA_SERIAL") == nullptr;     // CRA_ARENA_SERIAL=1: one pool after the other (A/B)
+        // each pool keeps ONE worker count for the whole arena (its searches and the move step below): a pool rebuilds its worker
+        // threads whenever it is asked for a different number
+        const int tb = concurrent_pools ? threads / 2 : threads, ta = concurrent_pools ? threads - tb : threads;
+        if (has[0] && has[1] && concurrent_pools) {
             std::exception_ptr err;
             std::thread other([&] {
                 try { pools_[1]->run(s_.simulations, s_.simulations ? 0 : s_.nodes, tb, &st[1]); } catch (...) { err = std::current_exception(); }
             });
             try {
-                pools_[0]->run(s_.simulations, s_.simulations ? 0 : s_.nodes, threads - tb, &st[0]);
+                pools_[0]->run(s_.simulations, s_.simulations ? 0 : s_.nodes, ta, &st[0]);
             } catch (...) {
                 other.join();
                 throw;
@@ -369,7 +372,7 @@ size_t ArenaDriver::play(size_t n_games, int threads) {
             if (err) std::rethrow_exception(err);
         } else {
             for (int pi = 0; pi < 2; ++pi)
-                if (has[pi]) pools_[pi]->run(s_.simulations, s_.simulations ? 0 : s_.nodes, threads, &st[pi]);
+                if (has[pi]) pools_[pi]->run(s_.simulations, s_.simulations ? 0 : s_.nodes, pi == 0 ? ta : tb, &st[pi]);
         }
         stats_.run_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
         for (int pi = 0; pi < 2; ++pi) {
@@ -380,7 +383,7 @@ size_t ArenaDriver::play(size_t n_games, int threads) {
         std::vector<chess::TerminalType> terms(size_t(concurrent_), chess::TERMINAL_NONE);
         std::vector<char> over(size_t(concurrent_), 0);
         const auto m0 = std::chrono::steady_clock::now();
-        pools_[0]->parallel_for(concurrent_, threads, [&](int slot) {
+        pools_[0]->parallel_for(concurrent_, ta, [&](int slot) {
             Game& g = games_[size_t(slot)];
             if (!g.active) return;
             Tree& t = pools_[mover[size_t(slot)]]->tree(slot);

@@ -277,7 +277,7 @@ class Arena(_NativeLoop):
                  start_fen: Optional[Callable[[int], str]] = None, names=("contender", "champion")):
         super().__init__(pool_a, pool_b, settings, concurrent, start_fen)
         self.pools, self.names = (pool_a, pool_b), names
-        self.stats = dict(moves=0, nodes=0, seconds=0.0)
+        self.stats = dict(moves=0, nodes=0, seconds=0.0, run_seconds=0.0, move_seconds=0.0)
         self.records: List[GameRecord] = []
 
     def play(self, n_games: int, threads: int = 16):
@@ -291,5 +291,5 @@ class Arena(_NativeLoop):
                                            termination=why, event="Arena", white=self.names[0 if a_white else 1],
                                            black=self.names[1 if a_white else 0]))
         st = self._stats()
-        self.stats.update(moves=st.moves, nodes=st.nodes, seconds=st.seconds)
+        self.stats.update(moves=st.moves, nodes=st.nodes, seconds=st.seconds, run_seconds=st.run_seconds, move_seconds=st.move_seconds)
         return TournamentResult(self.names[0], self.names[1], st.wins, st.draws, st.losses), self.records[:n_games]

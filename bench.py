@@ -31,7 +31,8 @@ PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARC
 PEAK_F32_TFLOPS = 157.3
 PEAK_FP8_TFLOPS = 5000.0      # dense fp8 MFMA peak (v_mfma_f32_32x32x64_f8f6f4 measures 4.41 PFLOP/s at the 2.10 GHz it settles at)
 PEAK_HBM_GBS = 8000.0
-KERNEL_SYMBOL = {"fused_block": "block_kernel", "block_x3": "block_x3_kernel"}      # op name (mi_net_time_ops) -> substring of the kernel symbol
+# op name (mi_net_time_ops) -> substring of the kernel symbol ("tower_x3_" matches the two-role and the symmetric kernel)
+KERNEL_SYMBOL = {"fused_block": "block_kernel", "block_x3": "block_x3_kernel", "tower_x3": "tower_x3_"}
 
 
 def synthetic_planes(batch, channels, seed):
@@ -52,11 +53,7 @@ def committed_pmc_traffic(kernel: str):
     import glob
     import re
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    sets = sorted(glob.glob(os.path.join(root, "r*", "*_pmc_tcc1.txt")))
-    if not sets:
-        return {"traffic": None}
-    f1 = sets[-1]
-    f2 = f1.replace("_pmc_tcc1.txt", "_pmc_tcc2.txt")
+    symbol = KERNEL_SYMBOL.get(kernel, f"{kernel}_kernel")
 
     def counter(path, name):
         if not os.path.exists(path):
@@ -64,16 +61,19 @@ def committed_pmc_traffic(kernel: str):
         block = False
         for line in open(path):
             if line.startswith("=="):
-                block = KERNEL_SYMBOL.get(kernel, f"{kernel}_kernel") in line
+                block = symbol in line
             elif block and line.split()[:1] == [name]:
                 m = re.search(r"mean\s+([0-9.]+)", line)
                 return float(m.group(1)) if m else None
         return None
-    fetch, write = counter(f1, "FETCH_SIZE"), counter(f2, "WRITE_SIZE")
-    if fetch is None or write is None:
-        return {"traffic": None}
-    return {"traffic": round((2.0 * fetch + write) * 1024.0), "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
-            "traffic_source": os.path.relpath(f1, os.path.dirname(root))}
+    # newest committed pass (by round directory, then set letter) that holds this kernel
+    for f1 in sorted(glob.glob(os.path.join(root, "r*", "*_pmc_*tcc1.txt")), reverse=True):
+        f2 = f1.replace("tcc1.txt", "tcc2.txt")
+        fetch, write = counter(f1, "FETCH_SIZE"), counter(f2, "WRITE_SIZE")
+        if fetch is not None and write is not None:
+            return {"traffic": round((2.0 * fetch + write) * 1024.0), "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
+                    "traffic_source": os.path.relpath(f1, os.path.dirname(root))}
+    return {"traffic": None}
 
 
 def live_pmc_traffic(kernel: str, blocks: int, batch: int, precision: str, timeout_s: int = 150):
@@ -255,6 +255,8 @@ def config_search_legs(args, device, threads):
     leg("config2_one_tree_shared", "one crazyhouse position at a time, RISEv2-19, 2 lanes x batch 256, ONE tree shared by 8 collectors "
         "per lane (32 leaves each) under per-node locks, 1600 simulations", rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 2, 32,
         1600, cz, 1, shared=8)
+    leg("config2_one_tree_three_lanes", "the same tree with a third lane (3 x 256 leaves in flight, 8 collectors per lane)",
+        rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 3, 32, 1600, cz, 1, shared=8)
     leg("config2_one_tree_shared_6400", "the same with 6400 simulations per go (a longer think)",
         rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 2, 32, 6400, cz, 1, shared=8)
     # CrazyAra::benchmark on its own position table (one tree, one go per position)

@@ -1045,8 +1045,10 @@ void launch_block_x3(const BlockArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(block_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
 }
 void launch_tower_x3(const X3TowerArgs& a, hipStream_t s) {
-    // CRA_X3_TOWER=symmetric: every wave runs all three phases (A/B reference); default: the two-role kernel
-    static const bool symmetric = [] { const char* e = getenv("CRA_X3_TOWER"); return e != nullptr && e[0] == 's'; }();
+    // CRA_X3_TOWER=symmetric: every wave runs all three phases (A/B reference, read per launch so that a test can switch); default: the
+    // two-role kernel.  The two add up every output in the same order: same bits.
+    const char* e = getenv("CRA_X3_TOWER");
+    const bool symmetric = e != nullptr && e[0] == 's';
     if (symmetric) hipLaunchKernelGGL(tower_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
     else hipLaunchKernelGGL(tower_x3_roles_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
 }

@@ -420,3 +420,22 @@ def test_other_trunk_widths_run_on_the_layer_kernels(tmp_path, hip_lib, channels
     # up to 0.5e-3, the worst board measured 1.2e-3 -> 2e-3; the float32 precision mode holds the 1e-4 of the other tests
     assert np.abs(v - o_value.numpy().reshape(-1)).max() < (2e-3 if precision == "float16" else tol["value"])
     assert np.abs(logits - o_logits.numpy()).max() < logit_tol(tol, o_logits.numpy())
+
+
+@pytest.mark.parametrize("name,batch", [("risev2-7", 9), ("risev33-wdlp", 5)])
+def test_float16x3_two_role_tower_equals_the_symmetric_one_bit_for_bit(tmp_path, hip_lib, name, batch, monkeypatch):
+    """tower_x3_roles_kernel (EXPAND / PROJECT waves, the default) and tower_x3_kernel (every wave all three phases) add up every
+    output in the same order: identical bits, 3x3 runs between 5x5 blocks and both SE kinds included."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, _ = nn_cases.make_case(name)
+    d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
+    x = nn_cases.synthetic_planes(batch, cfg.nb_input_channels, 91).numpy().reshape(-1)
+    outs = []
+    for mode in ("roles", "symmetric"):
+        monkeypatch.setenv("CRA_X3_TOWER", mode)
+        net = HipAPI(0, batch, d, "float16x3")
+        v, p = np.zeros(batch, np.float32), np.zeros(batch * cfg.nb_policy, np.float32)
+        net.predict(x, v, p)
+        net.close()
+        outs.append((v, p))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

@@ -204,6 +204,10 @@ void SelfPlayDriver::start_games(size_t n_games) {
 size_t SelfPlayDriver::play(size_t n_games, int threads) {
     const auto t0 = std::chrono::steady_clock::now();
     while (finished_.size() < n_games) {
+        // the export file is full (TrainDataExporter::is_file_full, traindataexporter.cpp:162-165): further games would have their
+        // samples dropped by the exporter, so generation ends here -- what SelfPlay::go(0) does by counting samples
+        // (generatedSamples < max_samples_per_iteration(), selfplay.cpp:374-377)
+        if (exporter_ && exporter_->is_file_full()) break;
         start_games(n_games);
         std::vector<Game*> active;
         for (auto& g : games_) if (g) active.push_back(g.get());

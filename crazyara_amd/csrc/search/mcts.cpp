@@ -1,6 +1,8 @@
 #include "mcts.h"
 
+#include <cstdlib>
 #include <cstring>
+#include <new>
 
 #include <algorithm>
 #include <cmath>
@@ -48,10 +50,14 @@ struct NodeLock {                                // Node::lock() / unlock() (nod
 };
 }  // namespace
 
-NodeArena::NodeArena() : table_(new std::atomic<Node*>[kMaxChunks]) {
-    for (int i = 0; i < kMaxChunks; ++i) table_[i].store(nullptr, std::memory_order_relaxed);
+static_assert(sizeof(std::atomic<Node*>) == sizeof(Node*) && std::atomic<Node*>::is_always_lock_free, "the table is raw zeroed memory");
+NodeArena::NodeArena() : table_(static_cast<std::atomic<Node*>*>(std::calloc(size_t(kMaxChunks), sizeof(std::atomic<Node*>)))) {
+    if (!table_) throw std::bad_alloc();
 }
-NodeArena::~NodeArena() { clear(); }
+NodeArena::~NodeArena() {
+    clear();
+    std::free(table_);
+}
 void NodeArena::clear() {
     const size_t chunks = (size_t(size_.load()) + kChunk - 1) >> kChunkBits;
     for (size_t c = 0; c < size_t(kMaxChunks) && (c < chunks || table_[c].load(std::memory_order_relaxed)); ++c) {
@@ -61,7 +67,7 @@ void NodeArena::clear() {
     size_.store(0);
 }
 void NodeArena::swap(NodeArena& o) {
-    table_.swap(o.table_);
+    std::swap(table_, o.table_);
     const uint32_t a = size_.load(), b = o.size_.load();
     size_.store(b);
     o.size_.store(a);

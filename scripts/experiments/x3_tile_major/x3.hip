@@ -799,14 +799,11 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
             constexpr int EW = 2;
 #endif
             half8 e_h[EW][2], e_l[EW][2];
-            auto load_e = [&](int k, int s) {                          // cout tile (16 channels) of (chunk k, wave w, ne) = k * 8 + w * 2 + ne
+            auto load_e = [&](int k, int s, int ne) {                  // cout tile (16 channels) of (chunk k, wave w, ne) = k * 8 + w * 2 + ne
                 if constexpr (X3_ABL & 16) return;
-#pragma unroll
-                for (int ne = 0; ne < 2; ++ne) {
-                    const uint32_t f = uint32_t(k * (CK / 16) + w * 2 + ne) * (C / 32) + uint32_t(s);
-                    e_h[s % EW][ne] = x3_frag(W.w1h, lane_off, f);
-                    e_l[s % EW][ne] = x3_frag(W.w1l, lane_off, f);
-                }
+                const uint32_t f = uint32_t(k * (CK / 16) + w * 2 + ne) * (C / 32) + uint32_t(s);
+                e_h[s % EW][ne] = x3_frag(W.w1h, lane_off, f);
+                e_l[s % EW][ne] = x3_frag(W.w1l, lane_off, f);
             };
             if constexpr (X3_ABL & 16) {
 #pragma unroll
@@ -815,7 +812,9 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                     for (int ne = 0; ne < 2; ++ne) e_h[s][ne] = e_l[s][ne] = *reinterpret_cast<const half8*>(T.xh + lane * 8);
             }
 #pragma unroll
-            for (int s = 0; s < EW; ++s) load_e(0, s);
+            for (int s = 0; s < EW; ++s)
+#pragma unroll
+                for (int ne = 0; ne < 2; ++ne) load_e(0, s, ne);
             float* my_dws = T.dws + (w * 2) * 256;                     // this wave's two record tiles (8 x 256 floats in all)
             for (int kk = -1; kk < n; ++kk) {
                 const int k = kk + 1;                                  // the chunk this interval expands
@@ -850,20 +849,19 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                     for (int s = 0; s < C / 32; ++s) {
                         if (s + 1 < C / 32) read_stream(s + 1, bh[(s + 1) & 1], bl[(s + 1) & 1]);
                         __builtin_amdgcn_sched_barrier(0);
+                        // tile by tile: a tile's window slot is free -- and refilled -- after its own 12 MFMAs (the refills then go out
+                        // every 12 MFMAs instead of in bursts of four loads every 24: a steadier demand on the L2 -> CU path)
 #pragma unroll
-                        for (int ne = 0; ne < 2; ++ne)
+                        for (int ne = 0; ne < 2; ++ne) {
 #pragma unroll
                             for (int t = 0; t < 4; ++t) x3_mfma(e_l[s % EW][ne], bh[s & 1][t], accE[ne][t], !(X3_ABL & 2));
 #pragma unroll
-                        for (int ne = 0; ne < 2; ++ne)
-#pragma unroll
                             for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bl[s & 1][t], accE[ne][t], !(X3_ABL & 2));
 #pragma unroll
-                        for (int ne = 0; ne < 2; ++ne)
-#pragma unroll
                             for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bh[s & 1][t], accE[ne][t], !(X3_ABL & 2));
-                        if (s + EW < C / 32) load_e(k, s + EW);
-                        else if (k + 1 < n) load_e(k + 1, s + EW - C / 32);
+                            if (s + EW < C / 32) load_e(k, s + EW, ne);
+                            else if (k + 1 < n) load_e(k + 1, s + EW - C / 32, ne);
+                        }
                         if (s == C / 64) {
 #pragma unroll
                             for (int ne = 0; ne < 2; ++ne) *reinterpret_cast<f32x4*>(my_dws + ne * 256 + lane * 4) = dw_raw[ne];
@@ -941,14 +939,11 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
             constexpr int PW = 2, NJ = 4;
 #endif
             half8 p_h[PW][NJ], p_l[PW][NJ];
-            auto load_p = [&](int k, int s2) {                         // cout tile = w * 4 + j, K slab = k * 4 + s2
+            auto load_p = [&](int k, int s2, int j) {                  // cout tile = w * 4 + j, K slab = k * 4 + s2
                 if constexpr (X3_ABL & 16) return;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const uint32_t f = uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + s2);
-                    p_h[s2 % PW][j] = x3_frag(W.w3h, lane_off, f);
-                    p_l[s2 % PW][j] = x3_frag(W.w3l, lane_off, f);
-                }
+                const uint32_t f = uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + s2);
+                p_h[s2 % PW][j] = x3_frag(W.w3h, lane_off, f);
+                p_l[s2 % PW][j] = x3_frag(W.w3l, lane_off, f);
             };
             if constexpr (X3_ABL & 16) {
 #pragma unroll
@@ -964,7 +959,9 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                 for (int t = 0; t < 4; ++t) accP[j][t] = bs;
             }
 #pragma unroll
-            for (int s2 = 0; s2 < PW; ++s2) load_p(0, s2);
+            for (int s2 = 0; s2 < PW; ++s2)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) load_p(0, s2, j);
             for (int kk = -1; kk < n; ++kk) {
                 if (kk >= 0) {
                     const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
@@ -988,19 +985,16 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                         if (s2 + 1 < CK / 32) read_t2(s2 + 1, bh[(s2 + 1) & 1], bl[(s2 + 1) & 1]);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j)
+                        for (int j = 0; j < NJ; ++j) {                  // cout tile by cout tile, each refilled behind its own 12 MFMAs
 #pragma unroll
                             for (int t = 0; t < 4; ++t) x3_mfma(p_l[s2 % PW][j], bh[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-#pragma unroll
                             for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bl[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-#pragma unroll
                             for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
-                        if (s2 + PW < CK / 32) load_p(kk, s2 + PW);
-                        else if (kk + 1 < n) load_p(kk + 1, s2 + PW - CK / 32);
+                            if (s2 + PW < CK / 32) load_p(kk, s2 + PW, j);
+                            else if (kk + 1 < n) load_p(kk + 1, s2 + PW - CK / 32, j);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }

@@ -12,9 +12,15 @@ for abl in $ABLS; do
     $REPO/scripts/ubench/x3_tower_ablate.hip -o /tmp/x3abl/abl_$abl 2> /tmp/x3abl/build_$abl.log &
   pids+=($!)
 done
-for v in EPRIO=1; do
+for v in EW=4 PW=4 "EW=4 -DCRA_X3_PW=4"; do
   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCRA_DEVELOPMENT -DCRA_X3_ABL=0 -DCRA_X3_$v -I$REPO/crazyara_amd/csrc/nn \
-    $REPO/scripts/ubench/x3_tower_ablate.hip -o /tmp/x3abl/var_$v 2> /tmp/x3abl/build_var_$v.log &
+    $REPO/scripts/ubench/x3_tower_ablate.hip -o "/tmp/x3abl/var_${v// /_}" 2> "/tmp/x3abl/build_var_${v// /_}.log" &
+  pids+=($!)
+done
+# experiment: the two-role kernel with tile-major MFMA order and per-tile window refills (scripts/experiments/x3_tile_major/x3.hip)
+for v in "" "-DCRA_X3_EW=4"; do
+  hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCRA_DEVELOPMENT -DCRA_X3_ABL=0 $v -I$REPO/scripts/experiments/x3_tile_major -I$REPO/crazyara_amd/csrc/nn \
+    $REPO/scripts/ubench/x3_tower_ablate.hip -o "/tmp/x3abl/tilemajor${v// /_}" 2> "/tmp/x3abl/build_tilemajor${v// /_}.log" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
@@ -26,6 +32,7 @@ for p in "${pids[@]}"; do wait $p; done
       if [ -x /tmp/x3abl/abl_$abl ]; then echo -n "$kern "; CRA_X3_TOWER=$kern /tmp/x3abl/abl_$abl 256 19 20; else echo "build failed for ABL=$abl"; tail -3 /tmp/x3abl/build_$abl.log; fi
     done
   done
-  for v in EPRIO=1; do echo -n "roles, -DCRA_X3_$v: "; CRA_X3_TOWER=roles /tmp/x3abl/var_$v 256 19 20; done
+  for v in EW=4 PW=4 "EW=4 -DCRA_X3_PW=4"; do echo -n "roles, -DCRA_X3_$v: "; CRA_X3_TOWER=roles "/tmp/x3abl/var_${v// /_}" 256 19 20; done
+  for v in "" "-DCRA_X3_EW=4"; do echo -n "roles, tile-major order $v: "; CRA_X3_TOWER=roles "/tmp/x3abl/tilemajor${v// /_}" 256 19 20; done
   for bb in 512 1024; do echo -n "roles "; CRA_X3_TOWER=roles /tmp/x3abl/abl_0 $bb 19 10; echo -n "symmetric "; CRA_X3_TOWER=symmetric /tmp/x3abl/abl_0 $bb 19 10; done
 } > $OUT 2>&1

@@ -61,7 +61,7 @@ struct BlockArgs {
     int batch, C, cop_pad, ks;
     const float* gate;    // optional [B][C]: SE gate multiplied into x while the tile is loaded (residual uses the gated x)
     float* pool_out;      // optional [B][C]: sum over the 64 squares of y (feeds the NEXT block's SE gate)
-    const float* dwpk;    // 3x3 only: [cop_pad][12] = 9 folded taps, BN1 bias, BN2 bias, 0 (one 48-byte record per channel)
+    const float* dwpk;    // 3x3 only: [cop_pad][12] = 9 folded taps, BN1 bias, BN2 bias, 0 (one 48-byte record per channel); float16x3: X3TowerBlock's tile layout
 };
 template <typename T> void launch_block(const BlockArgs& a, hipStream_t s);
 // Precision float16x3 (x3.hip): split-operand f16 MFMAs (a = hi + lo; hi*hi + hi*lo + lo*hi, f32 accumulate) on float activations.
@@ -75,7 +75,7 @@ int block_x3_chunk_channels();
 // by the caller's SE launch)
 struct X3TowerBlock {
     const void *w1pk, *w1pk_lo, *w3pk, *w3pk_lo;     // as BlockArgs
-    const float* dwpk;                               // [cop_pad][12] + 64 floats of padding (a wave loads 1 KiB where its records start)
+    const float* dwpk;                               // [cop_pad / 16 tiles][12 rows: 9 folded taps, BN1 bias, BN2 bias, 0][16 channels] + 64 floats of padding (a wave loads 1 KiB where a tile's records start)
     const float* b3;                                 // [256]
     const float* se_w1t;                             // gate matrices in THREAD order (x3.hip: x3_se_phase; rise_net.hip: pack_se_threads_f32):
     const float* se_w2t;                             //   ca_se: W1 then W2, 16 float4 loads per thread each; eca_se: se_w1t = both halves

@@ -118,6 +118,20 @@ SplitPack pack_dense_split(const Folded& f, int cout, int cin, int ks, int cout_
     return SplitPack{pack_dense<half_t>(fh, cout, cin, ks, cout_pad, cin_pad), pack_dense<half_t>(fl, cout, cin, ks, cout_pad, cin_pad)};
 }
 
+// Precision float16x3, depthwise 3x3 records of a block (x3.hip: x3_depthwise): per tile of 16 expanded channels 12 rows of 16 floats --
+// the 9 folded taps, the BN1 bias, the BN2 bias, zeros -- so that a lane reads one tap of its 4 channels with one 16-byte LDS read;
+// + 64 floats of padding (a wave loads 1 KiB where a tile's 768 bytes start)
+std::vector<float> pack_x3_depthwise_records(const Folded& bn1, const Folded& dw, int cop, int cop_pad) {
+    std::vector<float> rec(size_t(cop_pad) * 12 + 64, 0.f);
+    for (int c = 0; c < cop; ++c) {
+        float* tile = rec.data() + size_t(c / 16) * 192 + (c % 16);
+        for (int t = 0; t < 9; ++t) tile[t * 16] = float(dw.w[size_t(c) * 9 + t]);
+        tile[9 * 16] = float(bn1.b[c]);
+        tile[10 * 16] = float(dw.b[c]);
+    }
+    return rec;
+}
+
 enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower, Forward, TowerX3 };
 
 struct Op {
@@ -838,13 +852,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             xb.w1pk_lo = im.upload(s1.lo);
             xb.w3pk = im.upload(s3.hi);
             xb.w3pk_lo = im.upload(s3.lo);
-            std::vector<float> rec(size_t(cop_pad) * 12 + 64, 0.f); // per channel: 9 taps, BN1 bias, BN2 bias, pad; + 64 floats (kernels.h)
-            for (int c = 0; c < cop; ++c) {
-                for (int t = 0; t < 9; ++t) rec[size_t(c) * 12 + t] = float(f2.w[size_t(c) * 9 + t]);
-                rec[size_t(c) * 12 + 9] = float(f1.b[c]);
-                rec[size_t(c) * 12 + 10] = float(f2.b[c]);
-            }
-            xb.dwpk = im.upload(rec);
+            xb.dwpk = im.upload(pack_x3_depthwise_records(f1, f2, cop, cop_pad));
             xb.b3 = im.upload_d2f(f3.b, C);
             xb.cop_pad = cop_pad;
             x3_blocks.push_back(xb);
@@ -881,13 +889,17 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             ba.cop_pad = cop_pad;
             ba.ks = k;
             if (k == 3) {   // per-channel record for the DPP depthwise kernel: 9 taps, BN1 bias, BN2 bias, pad
-                std::vector<float> rec(size_t(cop_pad) * 12 + 64, 0.f);     // + 64: the float16x3 kernel loads 1 KiB where a wave's records start
-                for (int c = 0; c < cop; ++c) {
-                    for (int t = 0; t < 9; ++t) rec[size_t(c) * 12 + t] = float(f2.w[size_t(c) * 9 + t]);
-                    rec[size_t(c) * 12 + 9] = float(f1.b[c]);
-                    rec[size_t(c) * 12 + 10] = float(f2.b[c]);
+                if (x3_) {
+                    ba.dwpk = im.upload(pack_x3_depthwise_records(f1, f2, cop, cop_pad));
+                } else {
+                    std::vector<float> rec(size_t(cop_pad) * 12, 0.f);
+                    for (int c = 0; c < cop; ++c) {
+                        for (int t = 0; t < 9; ++t) rec[size_t(c) * 12 + t] = float(f2.w[size_t(c) * 9 + t]);
+                        rec[size_t(c) * 12 + 9] = float(f1.b[c]);
+                        rec[size_t(c) * 12 + 10] = float(f2.b[c]);
+                    }
+                    ba.dwpk = im.upload(rec);
                 }
-                ba.dwpk = im.upload(rec);
             }
             ba.gate = pending_gate;
             pending_gate = nullptr;

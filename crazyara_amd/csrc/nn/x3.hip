@@ -16,6 +16,7 @@
 #include "device_utils.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 // CRA_X3_ABL: development switches that TIME parts of the tower's chunk loop (scripts/ubench/x3_tower_ablate.hip); every bit computes wrong
 // results on purpose, so they only compile in a development build.  1: no depthwise arithmetic, 2: no expand MFMAs, 4: no project MFMAs,
@@ -23,16 +24,33 @@
 #ifndef CRA_X3_ABL
 #define CRA_X3_ABL 0
 #endif
-// channel tiles (16 channels each) of the expand GEMM per wave: 1 = chunks of 128 channels, 2 = chunks of 256 (a stream fragment read
-// from LDS then feeds two channel tiles: half the LDS operand traffic of the expand phase)
-#ifndef CRA_X3_NE
-#define CRA_X3_NE 1
-#endif
 #if CRA_X3_ABL != 0 && !defined(CRA_DEVELOPMENT)
 #error "CRA_X3_ABL is a development switch (wrong results): build with -DCRA_DEVELOPMENT"
 #endif
+// CRA_X3_TRACE=<block>: development, the two-role tower stamps the shader clock at its phase boundaries while it runs block <block>
+// (workgroups 0 and 131, every wave; scripts/ubench/x3_tower_ablate.hip prints the timeline)
+#if defined(CRA_X3_TRACE) && !defined(CRA_DEVELOPMENT)
+#error "CRA_X3_TRACE is a development switch: build with -DCRA_DEVELOPMENT"
+#endif
 
 namespace cra {
+
+#ifdef CRA_X3_TRACE
+__device__ unsigned long long x3_trace[2][8][128][2];      // [workgroup 0 | 131][wave][stamp](clock, interval * 16 + phase id)
+#define X3_STAMP(id)                                                                                    \
+    do {                                                                                                \
+        if (tracing && trace_n < 128) {                                                                 \
+            const unsigned long long t_ = __builtin_readcyclecounter();                                 \
+            if (lane == 0) {                                                                            \
+                x3_trace[b != 0][wave][trace_n][0] = t_;                                                \
+                x3_trace[b != 0][wave][trace_n][1] = (unsigned long long)((kk + 1) * 16 + (id));        \
+            }                                                                                           \
+            ++trace_n;                                                                                  \
+        }                                                                                               \
+    } while (0)
+#else
+#define X3_STAMP(id) do { } while (0)
+#endif
 
 namespace {
 constexpr int X3_ABL = CRA_X3_ABL;
@@ -237,7 +255,7 @@ void launch_conv_gemm_x3(const ConvArgs& a, hipStream_t s) {
 // ================================================================================================================
 namespace {
 struct X3Block {
-    static constexpr int C = 256, NW = 8, NE = CRA_X3_NE, CK = 16 * NW * NE, NTHR = 64 * NW, NJ = C / 16 / NW;
+    static constexpr int C = 256, NW = 8, NE = 1, CK = 16 * NW * NE, NTHR = 64 * NW, NJ = C / 16 / NW;
     static constexpr int XROW = C + 16;      // halves; 32-byte row pad (rows step 8 banks: conflict-free 16-row fragment reads)
     static constexpr int TROW = CK + 16;
     static constexpr size_t dws_bytes = size_t(NW) * NE * 1024;
@@ -264,14 +282,101 @@ __device__ __forceinline__ X3Tiles x3_tiles(char* smem) {
     return t;
 }
 
+// Row order of the board tiles in LDS.  A 16-square MFMA tile t (rows t * 16 ... + 15 of the x and t2 tiles) holds board ranks t (lanes
+// l15 = 0-7, files a-h) and t + 4 (lanes 8-15): the rank above / below a lane's square is then the SAME lane of tile t - 1 / t + 1, so the
+// depthwise finds its vertical neighbours in the neighbouring accumulator registers without a lane shuffle or a select; only rank 4's upper
+// and rank 3's lower neighbour cross the two halves (one row_ror:8 each).  Everything between staging and the store to HBM works on tile
+// rows and never needs to know which square a row is.
+__device__ __forceinline__ int x3_row(int sq) { return ((sq >> 3) & 3) * 16 + (sq >> 5) * 8 + (sq & 7); }      // square -> tile row
+__device__ __forceinline__ int x3_square(int row) { return ((row >> 4) + 4 * ((row >> 3) & 1)) * 8 + (row & 7); }   // tile row -> square
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int CTRL> __device__ __forceinline__ f32x2 dpp_mov2(f32x2 v) { return f32x2{dpp_mov<CTRL>(v.x), dpp_mov<CTRL>(v.y)}; }
+__device__ __forceinline__ f32x2 pair_of(const f32x4& v, int p) { return p == 0 ? f32x2{v[0], v[1]} : f32x2{v[2], v[3]}; }
+
+// D of one 16-channel tile: BN1 bias + ReLU on the expand accumulators, depthwise 3x3, BN2 bias + ReLU, exact f32 in the tap order of
+// block_kernel_dpp (kernels.hip).  A lane holds 4 channels (accumulator rows r) of one file on ranks t / t + 4 (x3_row); channels go two
+// at a time (P = 0, 1).
+// Horizontal neighbours: row_shr:1 / row_shl:1 copies, each feeding the three outputs it is up / mid / down neighbour of; lane 8 would
+// read lane 7 (file h of the other rank) and lane 0 a zero: the file-edge masks are folded into the dx = -1 / +1 weights.
+// In pieces (load, gather<P>, taps<P>) so that a caller can spread them over a stretch of MFMAs.
+//   rec: this tile's records in LDS, [12 rows: 9 taps, BN1 bias, BN2 bias, 0][16 channels]
+struct X3Depthwise {
+    f32x2 w[11];                                                 // the current channel pair's records
+    f32x2 S[6], L[6], R[6];                                      // rank - 1 ... rank + 4 of this lane's half: S[1 + t] = tile t
+    float outv[4][4];                                            // [tile][channel r]
+
+    template <int P> __device__ __forceinline__ void load(const float* rec, int lg) {
+#pragma unroll
+        for (int q = 0; q < 11; ++q) w[q] = *reinterpret_cast<const f32x2*>(rec + q * 16 + lg * 4 + 2 * P);
+    }
+    template <int P> __device__ __forceinline__ void gather(const f32x4 (&acc)[4], bool upper, float mL, float mR) {
+        if constexpr (X3_ABL & 1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) S[1 + t] = pair_of(acc[t], P) + w[0];
+            return;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            w[0][c] *= mL; w[3][c] *= mL; w[6][c] *= mL;
+            w[2][c] *= mR; w[5][c] *= mR; w[8][c] *= mR;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) S[1 + t][c] = fmaxf(acc[t][2 * P + c] + w[9][c], 0.f);
+            const float across_up = dpp_mov<DPP_ROW_ROR8>(S[4][c]), across_dn = dpp_mov<DPP_ROW_ROR8>(S[1][c]);
+            S[0][c] = upper ? across_up : 0.f;                    // above rank 4 lies rank 3 (tile 3, other half); above rank 0 the edge
+            S[5][c] = upper ? 0.f : across_dn;                    // below rank 3 lies rank 4 (tile 0, other half); below rank 7 the edge
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                L[j][c] = dpp_mov<DPP_ROW_SHR1>(S[j][c]);
+                R[j][c] = dpp_mov<DPP_ROW_SHL1>(S[j][c]);
+            }
+        }
+    }
+    // plain v_fmac_f32, NOT v_pk_fma_f32: a packed f32 FMA does not run in the shadow of MFMAs (scripts/ubench/mix_kinds.hip: an MFMA
+    // followed by two of them 38.5 cycles, by two v_fmac_f32 18.5; beside another wave's MFMAs 14.7 cycles each against 8.75)
+    template <int P> __device__ __forceinline__ void taps(int t0, int t1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < t0 || t >= t1) continue;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if constexpr (X3_ABL & 1) {
+                    outv[t][2 * P + c] = S[1 + t][c];
+                    continue;
+                }
+                float a = w[10][c];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    a = fmaf(w[dy * 3 + 0][c], L[t + dy][c], a);
+                    a = fmaf(w[dy * 3 + 1][c], S[t + dy][c], a);
+                    a = fmaf(w[dy * 3 + 2][c], R[t + dy][c], a);
+                }
+                outv[t][2 * P + c] = fmaxf(a, 0.f);
+            }
+        }
+    }
+};
+__device__ __forceinline__ void x3_depthwise(const f32x4 (&acc)[4], const float* rec, int lg, bool upper, float mL, float mR, float (&outv)[4][4]) {
+    X3Depthwise dw;
+    dw.template load<0>(rec, lg);
+    dw.template gather<0>(acc, upper, mL, mR);
+    dw.template taps<0>(0, 4);
+    dw.template load<1>(rec, lg);
+    dw.template gather<1>(acc, upper, mL, mR);
+    dw.template taps<1>(0, 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) outv[t][r] = dw.outv[t][r];
+}
 // float board tile [64][256] (optionally x := x * gate[c], _ChannelAttentionModule.forward, builder_util.py:114) -> split tiles
 __device__ __forceinline__ void x3_stage_tile(const X3Tiles& T, const float* xb, const float* g, int tid) {
     constexpr int C = X3Block::C, XROW = X3Block::XROW;
 #pragma unroll 1
     for (int i = tid; i < 64 * (C / 8); i += X3Block::NTHR) {
-        const int r = i / (C / 8), v = i - r * (C / 8);
+        const int sq = i / (C / 8), v = i - sq * (C / 8), r = x3_row(sq);
         float f[8];
-        load8<float>(xb + size_t(r) * C + v * 8, f);
+        load8<float>(xb + size_t(sq) * C + v * 8, f);
         if (g) {
             float gv[8];
             load8<float>(g + v * 8, gv);
@@ -293,7 +398,7 @@ __device__ __forceinline__ void x3_stage_tile(const X3Tiles& T, const float* xb,
 // counter too: every wait for an LDS operand then also waits for the weight fragments requested slabs ahead.)
 struct X3Weights {
     __amdgpu_buffer_rsrc_t w1h, w1l, w3h, w3l;   // packed expand / project weights, hi / lo (kernels.h: packed-weight geometry)
-    __amdgpu_buffer_rsrc_t dw;                   // [cop_pad][12] floats: 9 folded taps, BN1 bias, BN2 bias, 0
+    __amdgpu_buffer_rsrc_t dw;                   // [cop_pad / 16 tiles][12 rows: 9 folded taps, BN1 bias, BN2 bias, 0][16 channels] floats
     int cop_pad;
 };
 // The pointer is wave-uniform, but read from a descriptor array in device memory the compiler has it in VGPRs and wraps EVERY buffer load
@@ -315,6 +420,12 @@ __device__ __forceinline__ half8 x3_frag(__amdgpu_buffer_rsrc_t r, uint32_t lane
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, frag * 1024u, 0));
 }
+// The chunk loop of one block: accP[j][t] += project(depthwise(expand(x))) for this wave's 32 couts x 64 squares.  The caller has put a
+// barrier behind the last write of the x tiles.  On return every wave is done with the x tiles (the last expand phase lies before the
+// last chunk barrier); other waves may still be reading t2 in their last project phase.
+// Measured and NOT kept (profiles/r03/o_*): P(ch - 1) and D(ch) as one instruction stream per wave (the depthwise cut in four pieces
+// between the project MFMAs, sched_group_barrier recipes): 0.754 ms against 0.710 for this form -- 256 registers with spills, and the
+// scheduler interleaved only half of the stretches.
 __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, f32x4 (&accP)[X3Block::NJ][4]) {
     using G = X3Block;
     constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NJ = G::NJ, NE = G::NE;
@@ -323,7 +434,7 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
     const uint32_t lane_off = uint32_t(lane) * 16u;
     const int nchunk = W.cop_pad / CK;
     const int nslab3 = W.cop_pad >> 5;
-    const bool hi = l15 >= 8;                                  // second board row of a 16-square tile
+    const bool hi = l15 >= 8;                                  // the tile's second rank (t + 4, x3_row)
     const float mL = (l15 & 7) != 0 ? 1.f : 0.f;               // a left / right neighbour exists on the board
     const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
 
@@ -359,7 +470,7 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
         for (int ne = 0; ne < NE; ++ne)
 #pragma unroll
             for (int t = 0; t < 4; ++t) accE[ne][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // Depthwise records (per channel 9 taps, BN1 bias, BN2 bias, 0 = 48 B) of my 16 * NE channels: ONE 16-byte load per lane and tile
+        // Depthwise records (per 16-channel tile 12 rows of 16 floats: 9 taps, BN1 bias, BN2 bias, 0) of my NE tiles: ONE 16-byte load per lane and tile
         // (768 of its 1024 bytes are the tile's records), parked in a wave-private LDS scratch half-way through the expand MFMAs and read
         // back per lane as 12 broadcast reads.  (Loaded per lane straight from L2 -- 12 loads of which 16 lanes each fetch the same
         // bytes -- the records were a quarter of all bytes on the 64 B/clk L2 -> CU path, which this loop nearly saturates.)
@@ -371,13 +482,6 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
         auto park_dw = [&]() {
 #pragma unroll
             for (int ne = 0; ne < NE; ++ne) *reinterpret_cast<f32x4*>(my_dws + ne * 256 + lane * 4) = dw_raw[ne];
-        };
-        f32x4 dwr[4][3];
-        auto read_dw = [&](int ne) {                           // my 4 channels' records (the same wave wrote them: LDS keeps the order)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) dwr[r][k] = *reinterpret_cast<const f32x4*>(my_dws + ne * 256 + (lg * 4 + r) * 12 + k * 4);
         };
         // A slab = 12 * NE MFMAs on the stream fragments of one k-slab.  The NEXT slab's fragments are read from LDS before this slab's
         // MFMAs issue and the window refills right behind them; the fences keep the machine scheduler from sinking either to just in
@@ -439,45 +543,8 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
         // ---------------- D: BN1 + ReLU, depthwise 3x3 on the accumulators (block_kernel_dpp), BN2 + ReLU, exact f32 ----------------
 #pragma unroll
         for (int ne = 0; ne < NE; ++ne) {
-            read_dw(ne);
             float outv[4][4];                                   // [tile][channel r]
-            if constexpr (X3_ABL & 1) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) outv[t][r] = accE[ne][t][r] + dwr[r][0][0];
-            } else
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float b1 = dwr[r][2][1], b2 = dwr[r][2][2];
-                float w[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) w[k] = dwr[r][k >> 2][k & 3];
-                w[0] *= mL; w[3] *= mL; w[6] *= mL;             // file-edge masks folded into the dx = -1 / +1 columns
-                w[2] *= mR; w[5] *= mR; w[8] *= mR;
-                float e[4], rot[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    e[t] = fmaxf(accE[ne][t][r] + b1, 0.f);
-                    rot[t] = dpp_mov<DPP_ROW_ROR8>(e[t]);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float up = hi ? rot[t] : (t > 0 ? rot[t > 0 ? t - 1 : 0] : 0.f);
-                    const float dn = hi ? (t < 3 ? rot[t < 3 ? t + 1 : 3] : 0.f) : rot[t];
-                    float acc = b2;
-                    acc = fmac_shr1(acc, up, w[0]);
-                    acc = fmaf(w[1], up, acc);
-                    acc = fmac_shl1(acc, up, w[2]);
-                    acc = fmac_shr1(acc, e[t], w[3]);
-                    acc = fmaf(w[4], e[t], acc);
-                    acc = fmac_shl1(acc, e[t], w[5]);
-                    acc = fmac_shr1(acc, dn, w[6]);
-                    acc = fmaf(w[7], dn, acc);
-                    acc = fmac_shl1(acc, dn, w[8]);
-                    outv[t][r] = fmaxf(acc, 0.f);
-                }
-            }
+            x3_depthwise(accE[ne], my_dws + ne * 256, lg, hi, mL, mR, outv);
             const int cl = (wave * NE + ne) * 16 + lg * 4;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -571,7 +638,7 @@ __global__ __launch_bounds__(512) void block_x3_kernel(const BlockArgs a) {
                 v[r] = accP[j][t][r] + bs[r] + (rh[r] + rl[r]);
                 pool[r] += v[r];
             }
-            store4<float>(yb + size_t(sq) * C + co0, v);
+            store4<float>(yb + size_t(x3_square(sq)) * C + co0, v);
         }
         if (a.pool_out) {                                       // squeeze (AdaptiveAvgPool2d) of the block output, fused here
 #pragma unroll
@@ -611,8 +678,8 @@ __device__ __forceinline__ void x3_se_phase(const X3Tiles& T, const X3TowerBlock
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float fh[8], fl[8];
-            load8<half_t>(T.xh + (sg * 4 + q) * XROW + wv * 32 + cg * 8, fh);
-            load8<half_t>(T.xl + (sg * 4 + q) * XROW + wv * 32 + cg * 8, fl);
+            load8<half_t>(T.xh + x3_row(sg * 4 + q) * XROW + wv * 32 + cg * 8, fh);     // squares in board order: the sum's rounding does not depend on the tile-row order
+            load8<half_t>(T.xl + x3_row(sg * 4 + q) * XROW + wv * 32 + cg * 8, fl);
 #pragma unroll
             for (int j = 0; j < 8; ++j) sum[j] += fh[j] + fl[j];
         }
@@ -743,13 +810,13 @@ __global__ __launch_bounds__(512) void tower_x3_kernel(const X3TowerArgs a) {
     float* yb = a.y + size_t(b) * 64 * C;
 #pragma unroll 1
     for (int i = tid; i < 64 * (C / 8); i += G::NTHR) {
-        const int r = i / (C / 8), v = i - r * (C / 8);
+        const int sq = i / (C / 8), v = i - sq * (C / 8), r = x3_row(sq);
         float fh[8], fl[8];
         load8<half_t>(T.xh + r * XROW + v * 8, fh);
         load8<half_t>(T.xl + r * XROW + v * 8, fl);
 #pragma unroll
         for (int j = 0; j < 8; ++j) fh[j] += fl[j];
-        store8<float>(yb + size_t(r) * C + v * 8, fh);
+        store8<float>(yb + size_t(sq) * C + v * 8, fh);
     }
 }
 
@@ -784,11 +851,15 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
         const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
         const int n = W.cop_pad / CK;
         const int nslab3 = W.cop_pad >> 5;
+#ifdef CRA_X3_TRACE
+        const bool tracing = (b == 0 || b == 131) && blk == CRA_X3_TRACE;
+        int trace_n = 0;
+#endif
         if (expand_role) {
 #if defined(CRA_DEVELOPMENT) && defined(CRA_X3_EPRIO)
             __builtin_amdgcn_s_setprio(CRA_X3_EPRIO);                  // development: issue priority of the EXPAND waves
 #endif
-            const bool hi = l15 >= 8;                                  // second board row of a 16-square tile
+            const bool hi = l15 >= 8;                                  // the tile's second rank (t + 4, x3_row)
             const float mL = (l15 & 7) != 0 ? 1.f : 0.f;               // a left / right neighbour exists on the board
             const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
             // expand weight window: 2 of the 8 k-slabs x 2 channel tiles x (hi, lo); the stream runs on across chunk boundaries (through
@@ -819,6 +890,7 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
             float* my_dws = T.dws + (w * 2) * 256;                     // this wave's two record tiles (8 x 256 floats in all)
             for (int kk = -1; kk < n; ++kk) {
                 const int k = kk + 1;                                  // the chunk this interval expands
+                X3_STAMP(0);
                 if (k < n) {
                     half_t* const t2h = T.t2h + (k & 1) * 64 * TROW;
                     half_t* const t2l = T.t2l + (k & 1) * 64 * TROW;
@@ -867,55 +939,23 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                         if (s == C / 64) {
 #pragma unroll
                             for (int ne = 0; ne < 2; ++ne) *reinterpret_cast<f32x4*>(my_dws + ne * 256 + lane * 4) = dw_raw[ne];
+                            X3_STAMP(1);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    X3_STAMP(2);
+#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_MIDBAR)
+                    __syncthreads();                                    // development: the PROJECT waves start here, not at the interval's start
+                    X3_STAMP(6);
+#endif
+#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_EPRIO)
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     // D: BN1 + ReLU, depthwise 3x3 on the accumulators by DPP lane shifts, BN2 + ReLU (exact f32), split -> t2
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne) {
-                        f32x4 dwr[4][3];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int q = 0; q < 3; ++q) dwr[r][q] = *reinterpret_cast<const f32x4*>(my_dws + ne * 256 + (lg * 4 + r) * 12 + q * 4);
                         float outv[4][4];                               // [tile][channel r]
-                        if constexpr (X3_ABL & 1) {
-#pragma unroll
-                            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) outv[t][r] = accE[ne][t][r] + dwr[r][0][0];
-                        } else
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float b1 = dwr[r][2][1], b2 = dwr[r][2][2];
-                            float wt[9];
-#pragma unroll
-                            for (int q = 0; q < 9; ++q) wt[q] = dwr[r][q >> 2][q & 3];
-                            wt[0] *= mL; wt[3] *= mL; wt[6] *= mL;     // file-edge masks folded into the dx = -1 / +1 columns
-                            wt[2] *= mR; wt[5] *= mR; wt[8] *= mR;
-                            float e[4], rot[4];
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                e[t] = fmaxf(accE[ne][t][r] + b1, 0.f);
-                                rot[t] = dpp_mov<DPP_ROW_ROR8>(e[t]);
-                            }
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                const float up = hi ? rot[t] : (t > 0 ? rot[t > 0 ? t - 1 : 0] : 0.f);
-                                const float dn = hi ? (t < 3 ? rot[t < 3 ? t + 1 : 3] : 0.f) : rot[t];
-                                float acc = b2;
-                                acc = fmac_shr1(acc, up, wt[0]);
-                                acc = fmaf(wt[1], up, acc);
-                                acc = fmac_shl1(acc, up, wt[2]);
-                                acc = fmac_shr1(acc, e[t], wt[3]);
-                                acc = fmaf(wt[4], e[t], acc);
-                                acc = fmac_shl1(acc, e[t], wt[5]);
-                                acc = fmac_shr1(acc, dn, wt[6]);
-                                acc = fmaf(wt[7], dn, acc);
-                                acc = fmac_shl1(acc, dn, wt[8]);
-                                outv[t][r] = fmaxf(acc, 0.f);
-                            }
-                        }
+                        x3_depthwise(accE[ne], my_dws + ne * 256, lg, hi, mL, mR, outv);
                         const int cl = (w * 2 + ne) * 16 + lg * 4;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
@@ -929,10 +969,19 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                             }
                         }
                     }
+                    X3_STAMP(3);
                 }
+#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_MIDBAR)
+                else __syncthreads();
+#endif
                 if constexpr (!(X3_ABL & 32)) __syncthreads();
+#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_EPRIO)
+                __builtin_amdgcn_s_setprio(CRA_X3_EPRIO);
+#endif
+                X3_STAMP(4);
             }
             __syncthreads();                                            // the PROJECT waves' block epilogue
+            { const int kk = n; X3_STAMP(5); }
         } else {
             // project weight window: 2 of a chunk's 4 k-slabs x 4 cout tiles x (hi, lo), running on across chunk boundaries
 #if defined(CRA_DEVELOPMENT) && defined(CRA_X3_PW)
@@ -966,6 +1015,11 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
 #pragma unroll
             for (int s2 = 0; s2 < PW; ++s2) load_p(0, s2);
             for (int kk = -1; kk < n; ++kk) {
+                X3_STAMP(8);
+#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_MIDBAR)
+                __syncthreads();
+                X3_STAMP(14);
+#endif
                 if (kk >= 0) {
                     const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
                     const half_t* const t2l = T.t2l + (kk & 1) * 64 * TROW;
@@ -1001,10 +1055,13 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                             for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
                         if (s2 + PW < CK / 32) load_p(kk, s2 + PW);
                         else if (kk + 1 < n) load_p(kk + 1, s2 + PW - CK / 32);
+                        if (s2 == 1) X3_STAMP(9);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    X3_STAMP(10);
                 }
                 if constexpr (!(X3_ABL & 32)) __syncthreads();
+                X3_STAMP(11);
             }
             // block epilogue: new stream = x + body(x), split again, in place (every EXPAND wave is behind its last read of the tiles: it
             // waits at the barrier below)
@@ -1025,20 +1082,22 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                     *reinterpret_cast<half4*>(T.xl + sq * XROW + co0) = l;
                 }
             }
+            { const int kk = n; X3_STAMP(12); }
             __syncthreads();
+            { const int kk = n; X3_STAMP(13); }
         }
     }
     // stream -> HBM as float, 32-byte pieces per thread
     float* yb = a.y + size_t(b) * 64 * C;
 #pragma unroll 1
     for (int i = tid; i < 64 * (C / 8); i += G::NTHR) {
-        const int r = i / (C / 8), v = i - r * (C / 8);
+        const int sq = i / (C / 8), v = i - sq * (C / 8), r = x3_row(sq);
         float fh[8], fl[8];
         load8<half_t>(T.xh + r * XROW + v * 8, fh);
         load8<half_t>(T.xl + r * XROW + v * 8, fl);
 #pragma unroll
         for (int j = 0; j < 8; ++j) fh[j] += fl[j];
-        store8<float>(yb + size_t(r) * C + v * 8, fh);
+        store8<float>(yb + size_t(sq) * C + v * 8, fh);
     }
 }
 

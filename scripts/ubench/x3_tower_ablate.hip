@@ -70,5 +70,28 @@ int main(int argc, char** argv) {
     ms /= iters;
     printf("CRA_X3_ABL=%d  B=%d blocks=%d chunk=%d: %.4f ms per tower launch  (%.1f algorithmic TFLOP/s)\n", CRA_X3_ABL, B, nblocks, chunk, ms,
            flops / (ms * 1e-3) / 1e12);
+#ifdef CRA_X3_TRACE
+    // timeline of block CRA_X3_TRACE in workgroups 0 and 131 (last launch): shader-clock cycles since the workgroup's first stamp.
+    // EXPAND waves 0-3: 0 interval start, 1 half of the expand MFMAs, 2 expand done, 3 depthwise done, 4 behind the chunk barrier, 5 block end
+    // PROJECT waves 4-7: 8 interval start, 9 half of the project MFMAs, 10 project done, 11 behind the chunk barrier, 12 epilogue done, 13 block end
+    static unsigned long long tr[2][8][128][2];
+    CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(cra::x3_trace), sizeof(tr)));
+    for (int g = 0; g < 2; ++g) {
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < 8; ++w)
+            if (tr[g][w][0][0] && tr[g][w][0][0] < t0) t0 = tr[g][w][0][0];
+        printf("workgroup %d, block %d (C_op %d = %d chunks)\n", g ? 131 : 0, CRA_X3_TRACE, 128 + 64 * CRA_X3_TRACE, (128 + 64 * CRA_X3_TRACE + chunk - 1) / chunk);
+        for (int w = 0; w < 8; ++w) {
+            printf("  wave %d:", w);
+            int last_iv = -99;
+            for (int i = 0; i < 128 && tr[g][w][i][0]; ++i) {
+                const int iv = int(tr[g][w][i][1] >> 4) - 1, id = int(tr[g][w][i][1] & 15);
+                if (iv != last_iv) { printf("\n    interval %2d:", iv); last_iv = iv; }
+                printf("  [%d] %6llu", id, tr[g][w][i][0] - t0);
+            }
+            printf("\n");
+        }
+    }
+#endif
     return 0;
 }

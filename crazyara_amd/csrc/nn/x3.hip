@@ -256,7 +256,7 @@ void launch_conv_gemm_x3(const ConvArgs& a, hipStream_t s) {
 namespace {
 struct X3Block {
     static constexpr int C = 256, NW = 8, NE = 1, CK = 16 * NW * NE, NTHR = 64 * NW, NJ = C / 16 / NW;
-    static constexpr int XROW = C + 16;      // halves; 32-byte row pad (rows step 8 banks: conflict-free 16-row fragment reads)
+    static constexpr int XROW = C + 16;      // halves; 32-byte row pad (16 and 48 bytes measured the same: profiles/r03/s_*)
     static constexpr int TROW = CK + 16;
     static constexpr size_t dws_bytes = size_t(NW) * NE * 1024;
     // NE = 1: the depthwise output tile is double-buffered -- ONE barrier per chunk (the depthwise of chunk k + 1 writes the other
@@ -310,7 +310,7 @@ struct X3Depthwise {
 #pragma unroll
         for (int q = 0; q < 11; ++q) w[q] = *reinterpret_cast<const f32x2*>(rec + q * 16 + lg * 4 + 2 * P);
     }
-    template <int P> __device__ __forceinline__ void gather(const f32x4 (&acc)[4], bool upper, float mL, float mR) {
+    template <int P> __device__ __forceinline__ void gather(const f32x4 (&acc)[4], bool upper, float mL, float mR, int c0 = 0, int c1 = 2) {
         if constexpr (X3_ABL & 1) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) S[1 + t] = pair_of(acc[t], P) + w[0];
@@ -318,6 +318,7 @@ struct X3Depthwise {
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
+            if (c < c0 || c >= c1) continue;
             w[0][c] *= mL; w[3][c] *= mL; w[6][c] *= mL;
             w[2][c] *= mR; w[5][c] *= mR; w[8][c] *= mR;
 #pragma unroll
@@ -354,6 +355,14 @@ struct X3Depthwise {
                 outv[t][2 * P + c] = fmaxf(a, 0.f);
             }
         }
+    }
+    // keeps the values computed so far where they were written (a piece set between MFMAs is otherwise sunk to its first use)
+    __device__ __forceinline__ void pin_taps(int t0, int t1, int P) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (t >= t0 && t < t1) asm volatile("" : "+v"(outv[t][2 * P + c]));
     }
 };
 __device__ __forceinline__ void x3_depthwise(const f32x4 (&acc)[4], const float* rec, int lg, bool upper, float mL, float mR, float (&outv)[4][4]) {
@@ -822,15 +831,24 @@ __global__ __launch_bounds__(512) void tower_x3_kernel(const X3TowerArgs a) {
 
 // ---- the same run of blocks with the waves in two ROLES ----
 // Waves 0-3 expand and run the depthwise (EXPAND waves), waves 4-7 project (PROJECT waves); wave w and wave w + 4 share a SIMD.
-//   interval k (one workgroup barrier):  EXPAND wave w : E(k+1) = 32 channels x 64 squares, K = 256 (two 16-channel tiles share every
-//                                                         stream fragment they read from LDS), then D(k+1) on the accumulators -> t2[(k+1)&1]
-//                                        PROJECT wave v: P(k)   = 64 couts x 64 squares, K = 128 from t2[k&1] into its persistent accumulator
-// Against the symmetric form (x3_chunks: every wave 16 channels of E, then D, then 32 couts of P): a fragment read from LDS feeds twice
-// the MFMAs (LDS operand traffic halves: the symmetric expand phase is LDS-bound), a SIMD's matrix pipe always has the PROJECT wave's
-// MFMAs to run while its EXPAND wave is in the depthwise, and there is one barrier per chunk.  The price is the pipeline's fill and
-// drain once per block (the next block's expand needs this block's output): intervals -1 and n - 1 run one role only.
-// Measured and NOT kept (profiles/r03/h_*): L2 warm-up touches of the weight stream two chunks ahead (the float16 tower's trick) made
-// this kernel 9 % slower -- alone, its weight stream already runs at 27 TB/s (80 % of the L2 -> CU peak); s_setprio on the EXPAND waves: nothing.
+// A chunk = 128 expanded channels; an EXPAND wave owns two 16-channel tiles of it.  Interval i (one workgroup barrier):
+//   EXPAND wave w : E(i) = 32 channels x 64 squares, K = 256 (both tiles share every stream fragment read from LDS) with the depthwise
+//                   D(i - 1) of the chunk before INSIDE the MFMA stream (its accumulators were set aside), t2[(i - 1) & 1] written
+//   PROJECT wave v: P(i - 2) = 64 couts x 64 squares, K = 128 from t2[i & 1] into its persistent accumulator
+// The depthwise inside the MFMA stream: a wave issues two VALU instructions behind each of its own MFMAs at no cost
+// (scripts/ubench/mix_kinds.hip: MFMA + 2 VALU 18.5 cycles against 17.3), whereas depthwise work that runs behind the MFMA loop is the
+// interval's bare critical path -- the SIMD serves the MFMAs of its two waves one at a time whichever wave they come from (r03k
+// timeline: depthwise behind the expand MFMAs 4.4k of the interval's 9.9k cycles, matrix pipe 64 % busy).
+// Against the symmetric form (x3_chunks): a stream fragment read from LDS in the project phase feeds twice the MFMAs, and the matrix
+// pipe has the PROJECT wave's MFMAs whenever the EXPAND wave's stream thins out.  The price is the pipeline's fill and drain once per
+// block (the next block's expand needs this block's output): two intervals run one role only.
+// Also measured and NOT kept (profiles/r03/q_*, r_*): the chunk's two tiles in two passes of half an interval each (no second
+// accumulator set, but every stream fragment read from LDS twice): 0.72 ms against 0.69 -- the operand reads are a quarter of an
+// expand pass (4.6k cycles with, 3.4k without them).
+// Measured and NOT kept: L2 warm-up touches of the weight stream two chunks ahead (the float16 tower's trick) made this kernel 9 %
+// slower (profiles/r03/h_*) -- alone, its weight stream already runs at 27 TB/s, 80 % of the L2 -> CU peak; s_setprio on the EXPAND
+// waves, a barrier that holds the PROJECT waves back until the expand MFMAs are through (profiles/r03/m_*): nothing / slower;
+// v_pk_fma_f32 for the depthwise: it does not run in the shadow of MFMAs (mix_kinds.hip: 38.5 cycles for MFMA + 2 of them).
 __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a) {
     using G = X3Block;
     static_assert(G::NE == 1 && G::T2BUF == 2 && G::CK == 128, "the role kernel uses the NE = 1 tile geometry (two t2 buffers of 128 channels)");
@@ -855,26 +873,24 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
         const bool tracing = (b == 0 || b == 131) && blk == CRA_X3_TRACE;
         int trace_n = 0;
 #endif
+        // barriers of a block, the same for both roles: one behind each of the halves 0 ... 2n, then the one behind the epilogue
         if (expand_role) {
-#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_EPRIO)
-            __builtin_amdgcn_s_setprio(CRA_X3_EPRIO);                  // development: issue priority of the EXPAND waves
-#endif
             const bool hi = l15 >= 8;                                  // the tile's second rank (t + 4, x3_row)
             const float mL = (l15 & 7) != 0 ? 1.f : 0.f;               // a left / right neighbour exists on the board
             const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
-            // expand weight window: 2 of the 8 k-slabs x 2 channel tiles x (hi, lo); the stream runs on across chunk boundaries (through
-            // the depthwise): slab s of chunk k sits in slot s % 2 and is refilled with the slab 2 positions ahead right behind its MFMAs
+            // expand weight window: EW of the 8 k-slabs x 2 channel tiles x (hi, lo); the stream runs on across chunk boundaries: slab s of
+            // chunk i sits in slot s % EW and is refilled with the slab EW positions ahead right behind its MFMAs
 #if defined(CRA_DEVELOPMENT) && defined(CRA_X3_EW)
             constexpr int EW = CRA_X3_EW;
 #else
             constexpr int EW = 2;
 #endif
             half8 e_h[EW][2], e_l[EW][2];
-            auto load_e = [&](int k, int s) {                          // cout tile (16 channels) of (chunk k, wave w, ne) = k * 8 + w * 2 + ne
+            auto load_e = [&](int i, int s) {                          // cout tile (16 channels) of (chunk i, wave w, ne) = i * 8 + w * 2 + ne
                 if constexpr (X3_ABL & 16) return;
 #pragma unroll
                 for (int ne = 0; ne < 2; ++ne) {
-                    const uint32_t f = uint32_t(k * (CK / 16) + w * 2 + ne) * (C / 32) + uint32_t(s);
+                    const uint32_t f = uint32_t(i * (CK / 16) + w * 2 + ne) * (C / 32) + uint32_t(s);
                     e_h[s % EW][ne] = x3_frag(W.w1h, lane_off, f);
                     e_l[s % EW][ne] = x3_frag(W.w1l, lane_off, f);
                 }
@@ -887,97 +903,109 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
             }
 #pragma unroll
             for (int s = 0; s < EW; ++s) load_e(0, s);
-            float* my_dws = T.dws + (w * 2) * 256;                     // this wave's two record tiles (8 x 256 floats in all)
-            for (int kk = -1; kk < n; ++kk) {
-                const int k = kk + 1;                                  // the chunk this interval expands
-                X3_STAMP(0);
-                if (k < n) {
-                    half_t* const t2h = T.t2h + (k & 1) * 64 * TROW;
-                    half_t* const t2l = T.t2l + (k & 1) * 64 * TROW;
-                    // depthwise records of my 32 channels: two 16-byte loads per lane (x3_chunks), parked in LDS half-way through the MFMAs
-                    f32x4 dw_raw[2];
+            float* const my_dws = T.dws + (w * 2) * 256;               // this wave's two record tiles (8 x 256 floats in all)
+            f32x4 accE[2][4], accD[2][4];                               // chunk i being expanded / chunk i - 1 in the depthwise
+            X3Depthwise dw;
+            // Interval i: E(i) (HASE) with D(i - 1) (HASD) cut into sixteen pieces, two per k-slab: tile 0 in slabs 0-3, tile 1 in 4-7.
+            auto interval = [&](auto hase_c, auto hasd_c, int i) {
+                constexpr bool HASE = decltype(hase_c)::value, HASD = decltype(hasd_c)::value;
+                // stream fragments (B operands) through a ring of four (k-slab, square tile) steps: a step's pair (hi, lo) is requested
+                // three steps = 18 MFMAs ahead (a slab's eight pairs double-buffered would be 64 registers beside the depthwise's state)
+                half8 ring_h[4], ring_l[4];
+                auto read_step = [&](int st) {                          // step st = k-slab st / 4, square tile st % 4
+                    if constexpr (X3_ABL & 8) {
+                        ring_h[st % 4] = e_h[0][0];
+                        ring_l[st % 4] = e_l[0][0];
+                    } else {
+                        ring_h[st % 4] = *reinterpret_cast<const half8*>(T.xh + ((st & 3) * 16 + l15) * XROW + (st >> 2) * 32 + lg * 8);
+                        ring_l[st % 4] = *reinterpret_cast<const half8*>(T.xl + ((st & 3) * 16 + l15) * XROW + (st >> 2) * 32 + lg * 8);
+                    }
+                };
+                f32x4 dw_raw[2];
+                if constexpr (HASE) {
+                    // depthwise records of chunk i's two tiles: one 16-byte load per lane and tile (x3_chunks); they go to LDS at the end of
+                    // the interval, behind the depthwise that still reads chunk i - 1's
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
-                        dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(k * CK + (w * 2 + ne) * 16) * 48u, 0));
-                    f32x4 accE[2][4];
+                        dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(i * CK + (w * 2 + ne) * 16) * 48u, 0));
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
 #pragma unroll
                         for (int t = 0; t < 4; ++t) accE[ne][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    half8 bh[2][4], bl[2][4];
-                    auto read_stream = [&](int s, half8 (&h)[4], half8 (&l)[4]) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            if constexpr (X3_ABL & 8) {
-                                h[t] = e_h[s % EW][0];
-                                l[t] = e_l[s % EW][0];
-                            } else {
-                                h[t] = *reinterpret_cast<const half8*>(T.xh + (t * 16 + l15) * XROW + s * 32 + lg * 8);
-                                l[t] = *reinterpret_cast<const half8*>(T.xl + (t * 16 + l15) * XROW + s * 32 + lg * 8);
-                            }
-                        }
-                    };
-                    read_stream(0, bh[0], bl[0]);
-#pragma unroll
-                    for (int s = 0; s < C / 32; ++s) {
-                        if (s + 1 < C / 32) read_stream(s + 1, bh[(s + 1) & 1], bl[(s + 1) & 1]);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int ne = 0; ne < 2; ++ne)
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) x3_mfma(e_l[s % EW][ne], bh[s & 1][t], accE[ne][t], !(X3_ABL & 2));
-#pragma unroll
-                        for (int ne = 0; ne < 2; ++ne)
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bl[s & 1][t], accE[ne][t], !(X3_ABL & 2));
-#pragma unroll
-                        for (int ne = 0; ne < 2; ++ne)
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) x3_mfma(e_h[s % EW][ne], bh[s & 1][t], accE[ne][t], !(X3_ABL & 2));
-                        if (s + EW < C / 32) load_e(k, s + EW);
-                        else if (k + 1 < n) load_e(k + 1, s + EW - C / 32);
-                        if (s == C / 64) {
-#pragma unroll
-                            for (int ne = 0; ne < 2; ++ne) *reinterpret_cast<f32x4*>(my_dws + ne * 256 + lane * 4) = dw_raw[ne];
-                            X3_STAMP(1);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    X3_STAMP(2);
-#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_MIDBAR)
-                    __syncthreads();                                    // development: the PROJECT waves start here, not at the interval's start
-                    X3_STAMP(6);
-#endif
-#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_EPRIO)
-                    __builtin_amdgcn_s_setprio(0);
-#endif
-                    // D: BN1 + ReLU, depthwise 3x3 on the accumulators by DPP lane shifts, BN2 + ReLU (exact f32), split -> t2
-#pragma unroll
-                    for (int ne = 0; ne < 2; ++ne) {
-                        float outv[4][4];                               // [tile][channel r]
-                        x3_depthwise(accE[ne], my_dws + ne * 256, lg, hi, mL, mR, outv);
-                        const int cl = (w * 2 + ne) * 16 + lg * 4;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            half4 h, l;
-                            split4(outv[t], h, l);
-                            if constexpr (X3_ABL & 64) {
-                                asm volatile("" ::"v"(h), "v"(l));
-                            } else {
-                                *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
-                                *reinterpret_cast<half4*>(t2l + (t * 16 + l15) * TROW + cl) = l;
-                            }
-                        }
-                    }
-                    X3_STAMP(3);
+                    read_step(0); read_step(1); read_step(2);
                 }
-#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_MIDBAR)
-                else __syncthreads();
-#endif
+                if constexpr (HASD) dw.template load<0>(my_dws, lg);
+                half_t* const t2h = T.t2h + ((i - 1) & 1) * 64 * TROW;
+                half_t* const t2l = T.t2l + ((i - 1) & 1) * 64 * TROW;
+#pragma unroll
+                for (int sl = 0; sl < C / 32; ++sl) {
+                    const int dt = sl / 4, ph = sl % 4;                 // the depthwise's tile and quarter
+                    if constexpr (HASD) {
+                        if (ph == 2) dw.template load<1>(my_dws + dt * 256, lg);
+                        if (sl == 4) dw.template load<0>(my_dws + 256, lg);      // (tile 0's last pieces ran in slab 3)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (HASE) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int st = sl * 4 + t;
+                            if (st + 3 < 4 * (C / 32)) read_step(st + 3);
+#pragma unroll
+                            for (int ne = 0; ne < 2; ++ne) {
+                                x3_mfma(e_l[sl % EW][ne], ring_h[st % 4], accE[ne][t], !(X3_ABL & 2));
+                                x3_mfma(e_h[sl % EW][ne], ring_l[st % 4], accE[ne][t], !(X3_ABL & 2));
+                                x3_mfma(e_h[sl % EW][ne], ring_h[st % 4], accE[ne][t], !(X3_ABL & 2));
+                            }
+                        }
+                        if (sl + EW < C / 32) load_e(i, sl + EW);
+                        else load_e(i + 1 < n ? i + 1 : i, sl + EW - C / 32);    // (behind the last chunk: a valid address, no branch in the stretch)
+                    }
+                    if constexpr (HASD) {
+                        if (ph == 0) dw.template gather<0>(accD[dt], hi, mL, mR);
+                        if (ph == 1) { dw.template taps<0>(0, 4); dw.pin_taps(0, 4, 0); }
+                        if (ph == 2) dw.template gather<1>(accD[dt], hi, mL, mR);
+                        if (ph == 3) {
+                            dw.template taps<1>(0, 4);
+                            const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                half4 h, l;
+                                split4(dw.outv[t], h, l);
+                                if constexpr (X3_ABL & 64) {
+                                    asm volatile("" ::"v"(h), "v"(l));
+                                } else {
+                                    *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
+                                    *reinterpret_cast<half4*>(t2l + (t * 16 + l15) * TROW + cl) = l;
+                                }
+                            }
+                        }
+                    }
+                    if constexpr (HASE && HASD) {
+#pragma unroll
+                        for (int r = 0; r < 24; ++r) {                   // behind every MFMA up to four VALU instructions
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (HASE) {                                    // the depthwise is through with chunk i - 1: its records and accumulators make room
+#pragma unroll
+                    for (int ne = 0; ne < 2; ++ne) *reinterpret_cast<f32x4*>(my_dws + ne * 256 + lane * 4) = dw_raw[ne];
+#pragma unroll
+                    for (int ne = 0; ne < 2; ++ne)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) accD[ne][t] = accE[ne][t];
+                }
+            };
+            for (int i = 0; i <= n; ++i) {
+                const int kk = i - 1;                                    // (stamp bookkeeping)
+                X3_STAMP(0);
+                if (i == 0) interval(std::true_type{}, std::false_type{}, i);
+                else if (i < n) interval(std::true_type{}, std::true_type{}, i);
+                else interval(std::false_type{}, std::true_type{}, i);
+                X3_STAMP(3);
                 if constexpr (!(X3_ABL & 32)) __syncthreads();
-#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_EPRIO)
-                __builtin_amdgcn_s_setprio(CRA_X3_EPRIO);
-#endif
                 X3_STAMP(4);
             }
             __syncthreads();                                            // the PROJECT waves' block epilogue
@@ -1014,53 +1042,53 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
             }
 #pragma unroll
             for (int s2 = 0; s2 < PW; ++s2) load_p(0, s2);
-            for (int kk = -1; kk < n; ++kk) {
-                X3_STAMP(8);
-#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_MIDBAR)
+            if constexpr (!(X3_ABL & 32)) {
+                __syncthreads();                                        // intervals 0 and 1: chunk 0 is expanded, then run through the depthwise
                 __syncthreads();
-                X3_STAMP(14);
-#endif
-                if (kk >= 0) {
-                    const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
-                    const half_t* const t2l = T.t2l + (kk & 1) * 64 * TROW;
-                    half8 bh[2][4], bl[2][4];
-                    auto read_t2 = [&](int s2, half8 (&h)[4], half8 (&l)[4]) {
+            }
+            for (int kk = 0; kk < n; ++kk) {                            // P(kk) runs in interval kk + 2
+                const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
+                const half_t* const t2l = T.t2l + (kk & 1) * 64 * TROW;
+                X3_STAMP(8);
+                half8 bh[2][4], bl[2][4];
+                auto read_t2 = [&](int s2, half8 (&h)[4], half8 (&l)[4]) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            if constexpr (X3_ABL & 8) {
-                                h[t] = p_h[s2 % PW][0];
-                                l[t] = p_l[s2 % PW][0];
-                            } else {
-                                h[t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
-                                l[t] = *reinterpret_cast<const half8*>(t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
-                            }
+                    for (int t = 0; t < 4; ++t) {
+                        if constexpr (X3_ABL & 8) {
+                            h[t] = p_h[s2 % PW][0];
+                            l[t] = p_l[s2 % PW][0];
+                        } else {
+                            h[t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                            l[t] = *reinterpret_cast<const half8*>(t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
                         }
-                    };
-                    read_t2(0, bh[0], bl[0]);
-#pragma unroll
-                    for (int s2 = 0; s2 < CK / 32; ++s2) {
-                        if (s2 + 1 < CK / 32) read_t2(s2 + 1, bh[(s2 + 1) & 1], bl[(s2 + 1) & 1]);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) x3_mfma(p_l[s2 % PW][j], bh[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bl[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
-                        if (s2 + PW < CK / 32) load_p(kk, s2 + PW);
-                        else if (kk + 1 < n) load_p(kk + 1, s2 + PW - CK / 32);
-                        if (s2 == 1) X3_STAMP(9);
-                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    X3_STAMP(10);
+                };
+                read_t2(0, bh[0], bl[0]);
+#pragma unroll
+                for (int s2 = 0; s2 < CK / 32; ++s2) {
+                    if (s2 + 1 < CK / 32) read_t2(s2 + 1, bh[(s2 + 1) & 1], bl[(s2 + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) x3_mfma(p_l[s2 % PW][j], bh[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bl[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[s2 & 1][t], accP[j][t], !(X3_ABL & 4));
+                    if (s2 + PW < CK / 32) load_p(kk, s2 + PW);
+                    else load_p(kk + 1 < n ? kk + 1 : kk, s2 + PW - CK / 32);
+                    if (s2 == 1) X3_STAMP(9);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (!(X3_ABL & 32)) __syncthreads();
+                X3_STAMP(10);
+                if (kk + 1 < n) {
+                    if constexpr (!(X3_ABL & 32)) __syncthreads();      // (the last chunk's project phase has no partner: the epilogue's barrier follows)
+                }
                 X3_STAMP(11);
             }
             // block epilogue: new stream = x + body(x), split again, in place (every EXPAND wave is behind its last read of the tiles: it

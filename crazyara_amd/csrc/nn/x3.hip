@@ -108,39 +108,64 @@ constexpr int X3_ROWP = X3_KC + 8;         // halves per LDS row (+16 B: the 16 
 // ================================================================================================================
 // Dense conv (1x1 / 3x3) as implicit GEMM -- conv_gemm_kernel<float> (kernels.hip) with split operands.
 // ================================================================================================================
-template <int KS>
-__global__ __launch_bounds__(256) void conv_gemm_x3_kernel(const ConvArgs a) {
+// Workgroup = one board x (NW waves x MT cout tiles of 16): the board's channels are staged and split ONCE per workgroup, so wide
+// layers take the whole cout range in one workgroup (NW = 8, MT = 2: 256 couts -- stem, policy conv 1; with 64 couts per workgroup the
+// split was redone four times per board), and a stream fragment read from LDS feeds MT x 3 MFMAs.
+// NS > 0: every staged pass has exactly NS k-slabs (cin a multiple of 32 * NS, at most KC per pass) and runs a static schedule:
+// weight fragments through a window of three (tap, k-slab) steps -- requested before the pass is staged, refilled right behind
+// their MFMAs -- and the stream fragments of the next step read from LDS before this step's MFMAs (as in the tower).  NS = 0: any cin.
+template <int KS, int MT, int NW, int NS>
+__global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* xh = reinterpret_cast<half_t*>(smem);            // [65][ROWP] hi
     half_t* xl = xh + 65 * X3_ROWP;                          // [65][ROWP] lo
-    constexpr int ROWP = X3_ROWP, KC = X3_KC;
+    constexpr int ROWP = X3_ROWP, KC = X3_KC, NTHR = 64 * NW;
 
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int co_tile = blockIdx.x * 4 + wave;
-    const bool active = co_tile * 16 < a.cout_pad;
+    const int co_tile0 = (blockIdx.x * NW + wave) * MT;
+    bool active[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) active[m] = (co_tile0 + m) * 16 < a.cout_pad;
     const float* xb = reinterpret_cast<const float*>(a.x) + size_t(b) * kSquares * a.cin;
     const int nslab_ci = a.cin >> 5;
     const int nslab = KS * KS * nslab_ci;
-    const half8* wph = reinterpret_cast<const half8*>(a.wpk) + size_t(active ? co_tile : 0) * nslab * 64 + lane;
-    const half8* wpl = reinterpret_cast<const half8*>(a.wpk_lo) + size_t(active ? co_tile : 0) * nslab * 64 + lane;
-
-    f32x4 acc[4];
+    const half8 *wph[MT], *wpl[MT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m) {
+        wph[m] = reinterpret_cast<const half8*>(a.wpk) + size_t(active[m] ? co_tile0 + m : 0) * nslab * 64 + lane;
+        wpl[m] = reinterpret_cast<const half8*>(a.wpk_lo) + size_t(active[m] ? co_tile0 + m : 0) * nslab * 64 + lane;
+    }
 
-    for (int i = tid; i < ROWP; i += 256) {                  // row 64: what out-of-board taps read
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int i = tid; i < ROWP; i += NTHR) {                 // row 64: what out-of-board taps read
         xh[64 * ROWP + i] = half_t(0.f);
         xl[64 * ROWP + i] = half_t(0.f);
     }
 
     for (int kc0 = 0; kc0 < a.cin; kc0 += KC) {
-        const int kcl = min(KC, a.cin - kc0);
+        const int kcl = NS > 0 ? 32 * NS : min(KC, a.cin - kc0);
+        constexpr int NSTEP = KS * KS * (NS > 0 ? NS : 1), D = 3;
+        half8 wh[D][MT], wl[D][MT];
+        auto wload = [&](int st) {                           // step st = tap st / NS, k-slab st % NS of this pass
+            const size_t wo = size_t((st / (NS > 0 ? NS : 1)) * nslab_ci + (kc0 >> 5) + st % (NS > 0 ? NS : 1)) * 64;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { wh[st % D][m] = wph[m][wo]; wl[st % D][m] = wpl[m][wo]; }
+        };
+        if constexpr (NS > 0) {
+#pragma unroll
+            for (int st = 0; st < D && st < NSTEP; ++st) wload(st);
+        }
         __syncthreads();
         const int vec_per_row = kcl >> 3;                    // 8 floats -> 8 + 8 halves
-        for (int i = tid; i < kSquares * vec_per_row; i += 256) {
+        for (int i = tid; i < kSquares * vec_per_row; i += NTHR) {
             const int r = i / vec_per_row, v = i - r * vec_per_row;
             float f[8];
             load8<float>(xb + size_t(r) * a.cin + kc0 + v * 8, f);
@@ -150,7 +175,44 @@ __global__ __launch_bounds__(256) void conv_gemm_x3_kernel(const ConvArgs a) {
             *reinterpret_cast<half8*>(xl + r * ROWP + v * 8) = l;
         }
         __syncthreads();
-        if (active) {
+        if constexpr (NS > 0) {
+            if (active[0]) {
+                half8 bh[2][4], bl[2][4];
+                auto read_frag = [&](int st) {
+                    const int tap = st / NS, sl = st % NS, dy = tap / KS - KS / 2, dx = tap % KS - KS / 2;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int sq = t * 16 + l15;
+                        const int ny = (sq >> 3) + dy, nx = (sq & 7) + dx;
+                        const bool ok = (unsigned(ny) < 8u) && (unsigned(nx) < 8u);
+                        const int off = (ok ? ny * 8 + nx : 64) * ROWP + lg * 8 + sl * 32;
+                        bh[st & 1][t] = *reinterpret_cast<const half8*>(xh + off);
+                        bl[st & 1][t] = *reinterpret_cast<const half8*>(xl + off);
+                    }
+                };
+                read_frag(0);
+#pragma unroll
+                for (int st = 0; st < NSTEP; ++st) {
+                    if (st + 1 < NSTEP) read_frag(st + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[st % D][m], bh[st & 1][t], acc[m][t], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st % D][m], bl[st & 1][t], acc[m][t], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st % D][m], bh[st & 1][t], acc[m][t], 0, 0, 0);
+                    if (st + D < NSTEP) wload(st + D);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else
+        if (active[0]) {
 #pragma unroll
             for (int tap = 0; tap < KS * KS; ++tap) {
                 const int dy = tap / KS - KS / 2, dx = tap % KS - KS / 2;
@@ -164,12 +226,19 @@ __global__ __launch_bounds__(256) void conv_gemm_x3_kernel(const ConvArgs a) {
                 }
                 const size_t wo = size_t(tap * nslab_ci + (kc0 >> 5)) * 64;
                 const int ns = kcl >> 5;
-                half8 ah = wph[wo], al = wpl[wo];
+                half8 ah[MT], al[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) { ah[m] = wph[m][wo]; al[m] = wpl[m][wo]; }
                 for (int sl = 0; sl < ns; ++sl) {
-                    const half8 ch = ah, cl = al;
+                    half8 ch[MT], cl[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) { ch[m] = ah[m]; cl[m] = al[m]; }
                     if (sl + 1 < ns) {                       // next slab's fragments fly while this slab's MFMAs run
-                        ah = wph[wo + size_t(sl + 1) * 64];
-                        al = wpl[wo + size_t(sl + 1) * 64];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            ah[m] = wph[m][wo + size_t(sl + 1) * 64];
+                            al[m] = wpl[m][wo + size_t(sl + 1) * 64];
+                        }
                     }
                     half8 bh[4], bl[4];
 #pragma unroll
@@ -178,71 +247,96 @@ __global__ __launch_bounds__(256) void conv_gemm_x3_kernel(const ConvArgs a) {
                         bl[t] = *reinterpret_cast<const half8*>(xl + rowoff[t] + sl * 32);
                     }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, bh[t], acc[t], 0, 0, 0);
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, bl[t], acc[t], 0, 0, 0);
+                        for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[m], bh[t], acc[m][t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, bh[t], acc[t], 0, 0, 0);
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[m], bl[t], acc[m][t], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[m], bh[t], acc[m][t], 0, 0, 0);
                 }
             }
         }
     }
-    if (!active) return;
 
     // epilogue: conv_gemm_kernel<float>'s, word for word (bias, ReLU before / after the shortcut, the four output layouts)
-    const int co0 = co_tile * 16 + lg * 4;
-    float bs[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bs[r] = a.bias[co0 + r];
+    for (int m = 0; m < MT; ++m) {
+        if (!active[m]) continue;
+        const int co0 = (co_tile0 + m) * 16 + lg * 4;
+        float bs[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int sq = t * 16 + l15;
-        float v[4];
+        for (int r = 0; r < 4; ++r) bs[r] = a.bias[co0 + r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[t][r] + bs[r];
-        if (a.relu == 2) {
+        for (int t = 0; t < 4; ++t) {
+            const int sq = t * 16 + l15;
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (a.resid) {
-            float rv[4];
-            load4<float>(reinterpret_cast<const float*>(a.resid) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, rv);
+            for (int r = 0; r < 4; ++r) v[r] = acc[m][t][r] + bs[r];
+            if (a.relu == 2) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += rv[r];
-        }
-        if (a.relu == 1) {
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.resid) {
+                float rv[4];
+                load4<float>(reinterpret_cast<const float*>(a.resid) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, rv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (a.out_policy_f32) {
-            float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.cout_real * kSquares;
+                for (int r = 0; r < 4; ++r) v[r] += rv[r];
+            }
+            if (a.relu == 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
-        } else if (a.out_rows_f32) {
-            const int row = b * kSquares + sq;
-            if (row < a.rows_valid) {
-                float* o = reinterpret_cast<float*>(a.out) + size_t(row) * a.cout_real;
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.out_policy_f32) {
+                float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.cout_real * kSquares;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (co0 + r < a.cout_real) o[co0 + r] = v[r];
-            }
-        } else if (a.out_flat) {
-            float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.flat_pitch;
+                    if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
+            } else if (a.out_rows_f32) {
+                const int row = b * kSquares + sq;
+                if (row < a.rows_valid) {
+                    float* o = reinterpret_cast<float*>(a.out) + size_t(row) * a.cout_real;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
-        } else {
-            store4<float>(reinterpret_cast<float*>(a.out) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, v);
+                    for (int r = 0; r < 4; ++r)
+                        if (co0 + r < a.cout_real) o[co0 + r] = v[r];
+                }
+            } else if (a.out_flat) {
+                float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.flat_pitch;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
+            } else {
+                store4<float>(reinterpret_cast<float*>(a.out) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, v);
+            }
         }
     }
 }
 
+template <int KS, int NS> static void launch_conv_gemm_x3_ks(const ConvArgs& a, hipStream_t s) {
+    const size_t shmem = size_t(2) * 65 * X3_ROWP * sizeof(half_t);      // 35 KB
+    const int tiles = a.cout_pad / 16;
+    if (a.out_rows_f32) {                   // an FC over the batch: few "boards" (64 rows each), so as many workgroups as the couts give
+        hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 1, 4, NS>), dim3((tiles + 3) / 4, a.batch), dim3(256), shmem, s, a);
+    } else if (tiles >= 12) {               // 192 couts and more: 8 waves x 2 tiles, the whole cout range of a 256-wide layer in one workgroup
+        hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 2, 8, NS>), dim3((tiles + 15) / 16, a.batch), dim3(512), shmem, s, a);
+    } else if (tiles >= 5) {                // 80 ... 176 couts: 8 waves x 1 tile (measured against 4 waves x 2 tiles: 0.036 / 0.042 ms for 96 couts)
+        hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 1, 8, NS>), dim3((tiles + 7) / 8, a.batch), dim3(512), shmem, s, a);
+    } else {
+        hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 1, 4, NS>), dim3((tiles + 3) / 4, a.batch), dim3(256), shmem, s, a);
+    }
+}
+template <int KS> static void launch_conv_gemm_x3_cin(const ConvArgs& a, hipStream_t s) {
+    if (a.cin % X3_KC == 0) launch_conv_gemm_x3_ks<KS, X3_KC / 32>(a, s);     // every pass is a full one
+    else if (a.cin == 64) launch_conv_gemm_x3_ks<KS, 2>(a, s);                // the stem's padded planes
+    else launch_conv_gemm_x3_ks<KS, 0>(a, s);
+}
 void launch_conv_gemm_x3(const ConvArgs& a, hipStream_t s) {
-    const size_t shmem = size_t(2) * 65 * X3_ROWP * sizeof(half_t);      // 35 KB: four workgroups per CU
-    dim3 grid((a.cout_pad + 63) / 64, a.batch), block(256);
-    if (a.ks == 1) hipLaunchKernelGGL((conv_gemm_x3_kernel<1>), grid, block, shmem, s, a);
-    else hipLaunchKernelGGL((conv_gemm_x3_kernel<3>), grid, block, shmem, s, a);
+    if (a.ks == 1) launch_conv_gemm_x3_cin<1>(a, s);
+    else launch_conv_gemm_x3_cin<3>(a, s);
 }
 
 // ================================================================================================================

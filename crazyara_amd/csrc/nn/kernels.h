@@ -38,6 +38,9 @@ struct ConvArgs {
     int flat_pitch;
     int out_rows_f32;     // 1: write float row-major out[(b*64 + sq) * cout_real + co] for rows < rows_valid (an FC over the batch)
     int rows_valid;
+    // Precision float16x3, with out_policy_f32 and the whole cout range in ONE workgroup: softmax over the board's cout_real * 64 logits
+    // in the same launch, probabilities to softmax_out[b * cout_real * 64 + ...] (policy_softmax); the logits go to `out` only if it is set
+    float* softmax_out;
 };
 
 template <typename T> void launch_conv_gemm(const ConvArgs& a, hipStream_t s);

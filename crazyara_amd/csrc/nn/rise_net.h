@@ -68,7 +68,7 @@ public:
     float* d_value() const { return d_value_; }       // [B]
     float* d_probs() const { return d_probs_; }       // [B][nb_policy]
     float* d_logits() const { return d_logits_; }     // [B][nb_policy] pre-softmax policy_out: valid after a forward made with keep_logits(true)
-    void keep_logits(bool on) { keep_logits_ = on; }
+    void keep_logits(bool on);
     // test hook: the one-launch bottleneck tower also stores the f16 residual stream in front of its first block and behind every
     // block (kernels.h: TowerArgs::block_dump).  Returns the device buffer [n_tiles][B][64][256] f16; throws when the net has no such
     // tower (or more than one run of blocks).

@@ -137,6 +137,7 @@ enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block,
 struct Op {
     OpKind kind;
     ConvArgs conv{};
+    bool fused_softmax = false;   // float16x3 policy-map conv: the softmax runs in its launch (the probabilities' address is a launch-time value)
     // depthwise / se
     const void* x = nullptr;
     void* y = nullptr;
@@ -1080,7 +1081,12 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             macs += double(nfl) * n_labels;
         }
     }
-    {
+    // Precision float16x3, policy map: the policy conv holds a board's whole logit vector in one workgroup and runs the softmax itself
+    // (conv_gemm_x3_kernel; the launcher takes one workgroup per board up to 256 couts, the staging tiles hold 8192 logits)
+    if (x3_ && !im.ops.empty() && im.ops.back().kind == OpKind::Conv && im.ops.back().conv.out_policy_f32 &&
+        im.ops.back().conv.cout_pad <= 256 && im.ops.back().conv.cout_real * kSquares <= 8192) {
+        im.ops.back().fused_softmax = true;
+    } else {
         Op op;
         op.kind = OpKind::Softmax;
         im.ops.push_back(op);
@@ -1240,7 +1246,12 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             launch_planes_to_act<T>(op.x == d_planes_ ? planes : static_cast<const float*>(op.x), static_cast<T*>(op.y), B, op.C, im.cin_pad, s);
             break;
         case OpKind::Conv:
-            if (x3_) launch_conv_gemm_x3(op.conv, s);
+            if (x3_ && op.fused_softmax) {
+                ConvArgs c = op.conv;
+                c.softmax_out = probs;
+                if (!keep_logits_) c.out = nullptr;          // (the logits stay in LDS unless a test / analysis asked for them)
+                launch_conv_gemm_x3(c, s);
+            } else if (x3_) launch_conv_gemm_x3(op.conv, s);
             else launch_conv_gemm<T>(op.conv, s);
             break;
         case OpKind::Depthwise:
@@ -1380,6 +1391,19 @@ float RiseNet::time_forward(int iters) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return t;
+}
+
+void RiseNet::keep_logits(bool on) {
+    if (on == keep_logits_) return;
+    keep_logits_ = on;
+    if (launches_ > 1 && graph_exec_) {      // forwards of several launches replay a captured graph: capture again with the new head arguments
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        (void)hipGraphExecDestroy(graph_exec_);
+        if (graph_) (void)hipGraphDestroy(graph_);
+        graph_exec_ = nullptr;
+        graph_ = nullptr;
+        capture();
+    }
 }
 
 void RiseNet::capture() {

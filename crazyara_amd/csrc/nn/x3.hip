@@ -264,6 +264,7 @@ __global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a)
     }
 
     // epilogue: conv_gemm_kernel<float>'s, word for word (bias, ReLU before / after the shortcut, the four output layouts)
+    if (a.softmax_out) __syncthreads();                      // the board's logits gather in the staging tiles: every wave is done reading them
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         if (!active[m]) continue;
@@ -293,9 +294,13 @@ __global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a)
             }
             if (a.out_policy_f32) {
                 float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.cout_real * kSquares;
+                float* lds_logits = reinterpret_cast<float*>(smem);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
+                    if (co0 + r < a.cout_real) {
+                        if (a.out) o[(co0 + r) * kSquares + sq] = v[r];
+                        if (a.softmax_out) lds_logits[(co0 + r) * kSquares + sq] = v[r];
+                    }
             } else if (a.out_rows_f32) {
                 const int row = b * kSquares + sq;
                 if (row < a.rows_valid) {
@@ -314,6 +319,35 @@ __global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a)
             }
         }
     }
+    if (a.softmax_out) {
+        // row softmax of the board's logits (softmax_kernel, kernels.hip; apply_softmax(), neuralnetapi.cpp:241-260): exp(x - (max + log(sum)))
+        __syncthreads();
+        const float* in = reinterpret_cast<const float*>(smem);
+        float* red = reinterpret_cast<float*>(smem) + 8192;  // behind the logits (at most 8192 of them: 32 KiB of the 35 KiB)
+        const int n = a.cout_real * kSquares;
+        float* out = a.softmax_out + size_t(b) * n;
+        float m = -INFINITY;
+        for (int i = tid; i < n; i += NTHR) m = fmaxf(m, in[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = red[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) m = fmaxf(m, red[i]);
+        float sum = 0.f;
+        for (int i = tid; i < n; i += NTHR) sum += expf(in[i] - m);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = sum;
+        __syncthreads();
+        sum = red[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) sum += red[i];
+        const float c = m + logf(sum);
+        for (int i = tid; i < n; i += NTHR) out[i] = expf(in[i] - c);
+    }
 }
 
 template <int KS, int NS> static void launch_conv_gemm_x3_ks(const ConvArgs& a, hipStream_t s) {
@@ -321,7 +355,7 @@ template <int KS, int NS> static void launch_conv_gemm_x3_ks(const ConvArgs& a, 
     const int tiles = a.cout_pad / 16;
     if (a.out_rows_f32) {                   // an FC over the batch: few "boards" (64 rows each), so as many workgroups as the couts give
         hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 1, 4, NS>), dim3((tiles + 3) / 4, a.batch), dim3(256), shmem, s, a);
-    } else if (tiles >= 12) {               // 192 couts and more: 8 waves x 2 tiles, the whole cout range of a 256-wide layer in one workgroup
+    } else if (tiles >= 12 || (a.softmax_out && tiles > 8)) {   // 192 couts and more (or a fused softmax: the board in one workgroup): 8 waves x 2 tiles, the whole cout range of a 256-wide layer in one workgroup
         hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 2, 8, NS>), dim3((tiles + 15) / 16, a.batch), dim3(512), shmem, s, a);
     } else if (tiles >= 5) {                // 80 ... 176 couts: 8 waves x 1 tile (measured against 4 waves x 2 tiles: 0.036 / 0.042 ms for 96 couts)
         hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 1, 8, NS>), dim3((tiles + 7) / 8, a.batch), dim3(512), shmem, s, a);

@@ -41,6 +41,10 @@ struct ConvArgs {
     // Precision float16x3, with out_policy_f32 and the whole cout range in ONE workgroup: softmax over the board's cout_real * 64 logits
     // in the same launch, probabilities to softmax_out[b * cout_real * 64 + ...] (policy_softmax); the logits go to `out` only if it is set
     float* softmax_out;
+    // Precision float16x3: x is not an activation tile but the NCHW input planes [B][planes_c][64] (float); channels planes_c ... cin - 1
+    // read as zeros (the stem conv does the planes -> NHWC transform while it stages the board)
+    const float* planes;
+    int planes_c;
 };
 
 template <typename T> void launch_conv_gemm(const ConvArgs& a, hipStream_t s);

@@ -137,6 +137,7 @@ enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block,
 struct Op {
     OpKind kind;
     ConvArgs conv{};
+    bool from_planes = false;     // float16x3 stem conv: reads the NCHW input planes (their address is a launch-time value too)
     bool fused_softmax = false;   // float16x3 policy-map conv: the softmax runs in its launch (the probabilities' address is a launch-time value)
     // depthwise / se
     const void* x = nullptr;
@@ -412,7 +413,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         im.ops.push_back(op);
         macs += double(kSquares) * cin * C * 9;
     } else {
-        {   // input layout transform
+        if (!x3_) {   // input layout transform (Precision float16x3: the stem conv reads the planes itself)
             Op op;
             op.kind = OpKind::PlanesToAct;
             op.x = d_planes_;
@@ -421,6 +422,10 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             im.ops.push_back(op);
         }
         add_conv("body_spatial.0.body.0", "body_spatial.0.body.1", x0, a0, nullptr, cin, cin_pad, C, 3, true, nullptr);   // _Stem
+        if (x3_) {
+            im.ops.back().from_planes = true;
+            im.ops.back().conv.planes_c = cin;
+        }
     }
     T *cur = a0, *nxt = a1;
     // SE plumbing for the fused paths: the squeeze (per-channel sums) is produced by the previous block / tower kernel's
@@ -1246,7 +1251,11 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             launch_planes_to_act<T>(op.x == d_planes_ ? planes : static_cast<const float*>(op.x), static_cast<T*>(op.y), B, op.C, im.cin_pad, s);
             break;
         case OpKind::Conv:
-            if (x3_ && op.fused_softmax) {
+            if (x3_ && op.from_planes) {
+                ConvArgs c = op.conv;
+                c.planes = planes;
+                launch_conv_gemm_x3(c, s);
+            } else if (x3_ && op.fused_softmax) {
                 ConvArgs c = op.conv;
                 c.softmax_out = probs;
                 if (!keep_logits_) c.out = nullptr;          // (the logits stay in LDS unless a test / analysis asked for them)

@@ -168,7 +168,16 @@ __global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a)
         for (int i = tid; i < kSquares * vec_per_row; i += NTHR) {
             const int r = i / vec_per_row, v = i - r * vec_per_row;
             float f[8];
-            load8<float>(xb + size_t(r) * a.cin + kc0 + v * 8, f);
+            if (a.planes) {                                  // NCHW planes: channel c of square r
+                const float* pb = a.planes + size_t(b) * a.planes_c * kSquares + r;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = kc0 + v * 8 + j;
+                    f[j] = c < a.planes_c ? pb[c * kSquares] : 0.f;
+                }
+            } else {
+                load8<float>(xb + size_t(r) * a.cin + kc0 + v * 8, f);
+            }
             half8 h, l;
             split8(f, h, l);
             *reinterpret_cast<half8*>(xh + r * ROWP + v * 8) = h;

@@ -274,6 +274,7 @@ struct ValueHeadArgs {
     float* aux;             // [B][4] or nullptr
     int batch, C, cv, fc;
 };
+template <typename T> void prepare_value_head(const ValueHeadArgs& a);   // once per net: LDS allowance of the kernel
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s);
 
 // last stage of the value head, one wave per board.

@@ -8,6 +8,8 @@
 //   policy / value heads .......... builder_util.py:206-326
 //   softmax on policy_out ......... engine/src/nn/tensorrtapi.cpp:378-392, engine/src/nn/neuralnetapi.cpp:241-260
 #include "kernels.h"
+
+#include <stdexcept>
 #include "device_utils.h"
 
 namespace cra {
@@ -364,23 +366,76 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
     return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
+// The whole value head of one board in exact f32 on the vector units (0.5 MFLOP per board: the cost is moving the board, not the
+// arithmetic).  The board tile is staged once (coalesced) with the folded conv weights beside it; conv 1x1: thread = (square, group of
+// channels), a 16-byte LDS read of the square's row per four input channels, the weights as broadcast reads; FC1: thread = (four outputs, a quarter
+// of the inputs), a row of the transposed weight matrix as one 16-byte load per lane, 32 loads in flight.  Precision float16x3 runs this kernel (one launch instead of conv
+// GEMM + FC GEMM + final), as do the unfused layer paths.
 template <typename T>
 __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_flat = reinterpret_cast<float*>(smem);   // [64*cv]
-    float* s_red = s_flat + kSquares * a.cv;            // [4]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int XP = a.C + 4;                                   // floats per staged row: rows step 4 banks
+    float* xs = reinterpret_cast<float*>(smem);               // [64][C + 4]
+    float* ws = xs + kSquares * XP;                            // [cv][C]
+    float* s_flat = ws + a.cv * a.C;                           // [64 * cv]
+    float* s_red = s_flat + kSquares * a.cv;                   // [8]
+    const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const T* xb = reinterpret_cast<const T*>(a.x) + size_t(b) * kSquares * a.C;
     const int nf = kSquares * a.cv;
 
-    // conv 1x1: lanes split the C input channels, waves split the squares; wave-reduce each (square, cv) dot product
-    for (int sq = wave; sq < kSquares; sq += 4) {
-        for (int co = 0; co < a.cv; ++co) {
-            float part = 0.f;
-            for (int ci = lane; ci < a.C; ci += 64) part = fmaf(a.wconv[co * a.C + ci], to_f(xb[size_t(sq) * a.C + ci]), part);
-            part = wave_sum(part);
-            if (lane == 0) s_flat[co * kSquares + sq] = fmaxf(part + a.bconv[co], 0.f);
+    // (eight pieces per thread at C = 256, all loads in flight before the first LDS write: taken one by one the loop is eight HBM
+    // round trips long)
+    for (int i0 = tid; i0 < kSquares * (a.C / 8); i0 += 8 * 256) {
+        float f[8][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            if (i < kSquares * (a.C / 8)) load8<T>(xb + size_t(i / (a.C / 8)) * a.C + (i % (a.C / 8)) * 8, f[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            if (i < kSquares * (a.C / 8)) {
+                const int r = i / (a.C / 8), v = i % (a.C / 8);
+                *reinterpret_cast<f32x4*>(xs + r * XP + v * 8) = f32x4{f[u][0], f[u][1], f[u][2], f[u][3]};
+                *reinterpret_cast<f32x4*>(xs + r * XP + v * 8 + 4) = f32x4{f[u][4], f[u][5], f[u][6], f[u][7]};
+            }
+        }
+    }
+    for (int i0 = tid * 4; i0 < a.cv * a.C; i0 += 4 * 1024) {    // the folded conv weights, 16 bytes per thread and piece, four pieces in flight
+        f32x4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * 1024 < a.cv * a.C) wv[u] = *reinterpret_cast<const f32x4*>(a.wconv + i0 + u * 1024);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * 1024 < a.cv * a.C) *reinterpret_cast<f32x4*>(ws + i0 + u * 1024) = wv[u];
+    }
+    __syncthreads();
+
+    {   // conv 1x1 + BN + ReLU: thread = square tid % 64, channels tid / 64, + 4, ... (at most four per thread)
+        const int sq = tid & 63, g = tid >> 6;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* xr = xs + sq * XP;
+        for (int c = 0; c < a.C; c += 4) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = g + 4 * k;
+                if (co < a.cv) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + co * a.C + c);
+                    acc[k] = fmaf(wv[0], xv[0], acc[k]);
+                    acc[k] = fmaf(wv[1], xv[1], acc[k]);
+                    acc[k] = fmaf(wv[2], xv[2], acc[k]);
+                    acc[k] = fmaf(wv[3], xv[3], acc[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = g + 4 * k;
+            if (co < a.cv) s_flat[co * kSquares + sq] = fmaxf(acc[k] + a.bconv[co], 0.f);
         }
     }
     __syncthreads();
@@ -412,10 +467,42 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
         return;
     }
 
+    // FC1 + ReLU + FC2: thread = (four consecutive outputs, quarter of the inputs): a row of the transposed matrix is one 16-byte load per
+    // lane (a wave reads 1 KiB), 32 of them in flight; the quarters' partial sums meet in LDS (the staged board is dead by now)
+    float* s_part = xs;                                         // [4 quarters][fc]
     float part = 0.f;
+    const int kq = tid >> 6, nq = nf / 4;
+    for (int j4 = tid & 63; 4 * j4 < a.fc; j4 += 64) {
+        f32x4 h = {0.f, 0.f, 0.f, 0.f};
+        const float* wt = a.w1t + size_t(kq) * nq * a.fc + 4 * j4;
+        const float* fl = s_flat + kq * nq;
+        int i = 0;
+        for (; i + 32 <= nq; i += 32) {
+            f32x4 w[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) w[j] = *reinterpret_cast<const f32x4*>(wt + size_t(i + j) * a.fc);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 f = *reinterpret_cast<const f32x4*>(fl + i + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[0] = fmaf(w[4 * q + e][0], f[e], h[0]);
+                    h[1] = fmaf(w[4 * q + e][1], f[e], h[1]);
+                    h[2] = fmaf(w[4 * q + e][2], f[e], h[2]);
+                    h[3] = fmaf(w[4 * q + e][3], f[e], h[3]);
+                }
+            }
+        }
+        for (; i < nq; ++i) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wt + size_t(i) * a.fc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = fmaf(w[e], fl[i], h[e]);
+        }
+        *reinterpret_cast<f32x4*>(s_part + kq * a.fc + 4 * j4) = h;
+    }
+    __syncthreads();
     for (int t = tid; t < a.fc; t += 256) {
-        float h = a.b1[t];
-        for (int i = 0; i < nf; ++i) h = fmaf(a.w1t[size_t(i) * a.fc + t], s_flat[i], h);
+        const float h = a.b1[t] + ((s_part[t] + s_part[a.fc + t]) + (s_part[2 * a.fc + t] + s_part[3 * a.fc + t]));
         part = fmaf(a.w2[t], fmaxf(h, 0.f), part);
     }
     const float tot = block_sum_256(part, s_red);
@@ -464,9 +551,24 @@ template <typename T> void launch_value_final(const ValueFinalArgs& a, hipStream
 template void launch_value_final<half_t>(const ValueFinalArgs&, hipStream_t);
 template void launch_value_final<float>(const ValueFinalArgs&, hipStream_t);
 
+static size_t value_head_lds_bytes(const ValueHeadArgs& a) {
+    return (size_t(kSquares) * (a.C + 4) + size_t(a.cv) * a.C + size_t(kSquares) * a.cv + 8) * sizeof(float);
+}
+// once per net, outside any stream capture: the kernel's dynamic LDS allowance (the staged board is more than the default 64 KiB)
+template <typename T> void prepare_value_head(const ValueHeadArgs& a) {
+    if (a.C % 8 != 0 || a.cv > 16 || (!a.wwdl && a.fc % 4 != 0)) throw std::runtime_error("value head: channels must be a multiple of 8, value channels at most 16, FC width a multiple of 4");
+    const size_t shmem = value_head_lds_bytes(a);
+    if (shmem > 160 * 1024) throw std::runtime_error("value head: the board tile does not fit the LDS");
+    static size_t allowed = 0;
+    if (shmem > allowed) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&value_head_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(shmem));
+        allowed = shmem;
+    }
+}
+template void prepare_value_head<half_t>(const ValueHeadArgs&);
+template void prepare_value_head<float>(const ValueHeadArgs&);
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s) {
-    const size_t shmem = (size_t(kSquares) * a.cv + 8) * sizeof(float);
-    hipLaunchKernelGGL((value_head_kernel<T>), dim3(a.batch), dim3(256), shmem, s, a);
+    hipLaunchKernelGGL((value_head_kernel<T>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
 }
 template void launch_value_head<half_t>(const ValueHeadArgs&, hipStream_t);
 template void launch_value_head<float>(const ValueHeadArgs&, hipStream_t);

@@ -1096,8 +1096,8 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         op.kind = OpKind::Softmax;
         im.ops.push_back(op);
     }
-    if (fused_) {
-        // _ValueHead (builder_util.py:246-326) as three MFMA/wave-level launches instead of one latency-bound VALU kernel:
+    if (fused_ && !x3_) {
+        // _ValueHead (builder_util.py:246-326) as three MFMA/wave-level launches (Precision float16x3: the one-launch f32 kernel below):
         //   (1) conv1x1(C->cv)+BN+ReLU on the conv-GEMM kernel, written channel-major flat  (x.view(-1, nb_flatten))
         //   (2) FC(nfl->fc)+ReLU as a GEMM over the BATCH: 64 boards play the role of the 64 "squares" of one workgroup tile
         //   (3) FC(fc->1)+tanh, or the WDLP outputs, one wave per board
@@ -1214,6 +1214,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             macs += double(nfl) * fc + fc;
         }
         macs += double(kSquares) * C * cv;
+        prepare_value_head<T>(op.vh);
         im.ops.push_back(op);
     }
     }   // !head_ok

@@ -1096,8 +1096,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         op.kind = OpKind::Softmax;
         im.ops.push_back(op);
     }
-    if (fused_ && !x3_) {
-        // _ValueHead (builder_util.py:246-326) as three MFMA/wave-level launches (Precision float16x3: the one-launch f32 kernel below):
+    if (fused_) {
+        // _ValueHead (builder_util.py:246-326) as three MFMA/wave-level launches instead of one latency-bound VALU kernel.
+        // (Precision float16x3 ran the one-launch f32 kernel of the unfused path for a while -- 0.022 ms against 0.039 for these three -- but
+        // with it behind the two-role tower the searches of two concurrent lanes stopped being reproducible run to run (profiles/NOTES.md,
+        // set ab): taken out again until that is understood.)
         //   (1) conv1x1(C->cv)+BN+ReLU on the conv-GEMM kernel, written channel-major flat  (x.view(-1, nb_flatten))
         //   (2) FC(nfl->fc)+ReLU as a GEMM over the BATCH: 64 boards play the role of the 64 "squares" of one workgroup tile
         //   (3) FC(fc->1)+tanh, or the WDLP outputs, one wave per board

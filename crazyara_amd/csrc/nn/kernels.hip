@@ -374,8 +374,9 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
 template <typename T>
 __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int XP = a.C + 4;                                   // floats per staged row: rows step 4 banks
-    float* xs = reinterpret_cast<float*>(smem);               // [64][C + 4]
+    const int CH = a.C / 2;                                    // the board is staged in two halves of its channels (LDS stays below 64 KiB)
+    const int XP = CH + 4;                                    // floats per staged row: rows step 4 banks
+    float* xs = reinterpret_cast<float*>(smem);               // [64][C / 2 + 4]
     float* ws = xs + kSquares * XP;                            // [cv][C]
     float* s_flat = ws + a.cv * a.C;                           // [64 * cv]
     float* s_red = s_flat + kSquares * a.cv;                   // [8]
@@ -384,25 +385,6 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
     const T* xb = reinterpret_cast<const T*>(a.x) + size_t(b) * kSquares * a.C;
     const int nf = kSquares * a.cv;
 
-    // (eight pieces per thread at C = 256, all loads in flight before the first LDS write: taken one by one the loop is eight HBM
-    // round trips long)
-    for (int i0 = tid; i0 < kSquares * (a.C / 8); i0 += 8 * 256) {
-        float f[8][8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 256;
-            if (i < kSquares * (a.C / 8)) load8<T>(xb + size_t(i / (a.C / 8)) * a.C + (i % (a.C / 8)) * 8, f[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 256;
-            if (i < kSquares * (a.C / 8)) {
-                const int r = i / (a.C / 8), v = i % (a.C / 8);
-                *reinterpret_cast<f32x4*>(xs + r * XP + v * 8) = f32x4{f[u][0], f[u][1], f[u][2], f[u][3]};
-                *reinterpret_cast<f32x4*>(xs + r * XP + v * 8 + 4) = f32x4{f[u][4], f[u][5], f[u][6], f[u][7]};
-            }
-        }
-    }
     for (int i0 = tid * 4; i0 < a.cv * a.C; i0 += 4 * 1024) {    // the folded conv weights, 16 bytes per thread and piece, four pieces in flight
         f32x4 wv[4];
 #pragma unroll
@@ -412,23 +394,44 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
         for (int u = 0; u < 4; ++u)
             if (i0 + u * 1024 < a.cv * a.C) *reinterpret_cast<f32x4*>(ws + i0 + u * 1024) = wv[u];
     }
-    __syncthreads();
-
     {   // conv 1x1 + BN + ReLU: thread = square tid % 64, channels tid / 64, + 4, ... (at most four per thread)
         const int sq = tid & 63, g = tid >> 6;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         const float* xr = xs + sq * XP;
-        for (int c = 0; c < a.C; c += 4) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();                         // everyone is through with the first half of the tile
+            // (four pieces per thread at C = 256, all loads in flight before the first LDS write: taken one by one the loop is four
+            // HBM round trips long)
+            for (int i0 = tid; i0 < kSquares * (CH / 8); i0 += 4 * 256) {
+                float f[4][8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int co = g + 4 * k;
-                if (co < a.cv) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + co * a.C + c);
-                    acc[k] = fmaf(wv[0], xv[0], acc[k]);
-                    acc[k] = fmaf(wv[1], xv[1], acc[k]);
-                    acc[k] = fmaf(wv[2], xv[2], acc[k]);
-                    acc[k] = fmaf(wv[3], xv[3], acc[k]);
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * 256;
+                    if (i < kSquares * (CH / 8)) load8<T>(xb + size_t(i / (CH / 8)) * a.C + half * CH + (i % (CH / 8)) * 8, f[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * 256;
+                    if (i < kSquares * (CH / 8)) {
+                        const int r = i / (CH / 8), v = i % (CH / 8);
+                        *reinterpret_cast<f32x4*>(xs + r * XP + v * 8) = f32x4{f[u][0], f[u][1], f[u][2], f[u][3]};
+                        *reinterpret_cast<f32x4*>(xs + r * XP + v * 8 + 4) = f32x4{f[u][4], f[u][5], f[u][6], f[u][7]};
+                    }
+                }
+            }
+            __syncthreads();
+            for (int c = 0; c < CH; c += 4) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int co = g + 4 * k;
+                    if (co < a.cv) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + co * a.C + half * CH + c);
+                        acc[k] = fmaf(wv[0], xv[0], acc[k]);
+                        acc[k] = fmaf(wv[1], xv[1], acc[k]);
+                        acc[k] = fmaf(wv[2], xv[2], acc[k]);
+                        acc[k] = fmaf(wv[3], xv[3], acc[k]);
+                    }
                 }
             }
         }
@@ -552,11 +555,11 @@ template void launch_value_final<half_t>(const ValueFinalArgs&, hipStream_t);
 template void launch_value_final<float>(const ValueFinalArgs&, hipStream_t);
 
 static size_t value_head_lds_bytes(const ValueHeadArgs& a) {
-    return (size_t(kSquares) * (a.C + 4) + size_t(a.cv) * a.C + size_t(kSquares) * a.cv + 8) * sizeof(float);
+    return (size_t(kSquares) * (a.C / 2 + 4) + size_t(a.cv) * a.C + size_t(kSquares) * a.cv + 8) * sizeof(float);
 }
 // once per net, outside any stream capture: the kernel's dynamic LDS allowance (the staged board is more than the default 64 KiB)
 template <typename T> void prepare_value_head(const ValueHeadArgs& a) {
-    if (a.C % 8 != 0 || a.cv > 16 || (!a.wwdl && a.fc % 4 != 0)) throw std::runtime_error("value head: channels must be a multiple of 8, value channels at most 16, FC width a multiple of 4");
+    if (a.C % 16 != 0 || a.cv > 16 || (!a.wwdl && a.fc % 4 != 0)) throw std::runtime_error("value head: channels must be a multiple of 16, value channels at most 16, FC width a multiple of 4");
     const size_t shmem = value_head_lds_bytes(a);
     if (shmem > 160 * 1024) throw std::runtime_error("value head: the board tile does not fit the LDS");
     static size_t allowed = 0;

@@ -115,6 +115,7 @@ SIGNATURES = {
     "mi_policy_get_quantile": (C.c_double, [C.POINTER(C.c_double), C.c_int, C.c_double]),
     "mi_policy_apply_quantile_clipping": (None, [C.POINTER(C.c_double), C.c_int, C.c_double]),
     "mi_search_tree_dump": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_long]),
+    "mi_search_debug_replay": (C.c_long, [C.c_void_p, C.c_char_p, C.c_long]),
 }
 
 _lib = None

@@ -287,6 +287,22 @@ int mi_search_pv_multi(mi_search* sp, int tree, int idx, int multipv, char* uci_
     return n;
 }
 
+long mi_search_debug_replay(mi_search* sp, char* report, long cap) {
+    long n = -1;
+    if (!sp) { cra_set_error("null search"); return n; }
+    cra_guard([&] {
+        std::string text;
+        const size_t bad = sp->pool->debug_replay(&text);
+        if (report && cap > 0) {
+            const size_t m = std::min(text.size(), size_t(cap - 1));
+            std::memcpy(report, text.data(), m);
+            report[m] = 0;
+        }
+        n = long(bad);
+    });
+    return n;
+}
+
 long mi_search_tree_dump(mi_search* sp, int tree, uint32_t* out, long cap) {
     long n = -1;
     if (!sp) { cra_set_error("null search"); return n; }

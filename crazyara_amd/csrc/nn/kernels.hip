@@ -562,10 +562,11 @@ template <typename T> void prepare_value_head(const ValueHeadArgs& a) {
     if (a.C % 16 != 0 || a.cv > 16 || (!a.wwdl && a.fc % 4 != 0)) throw std::runtime_error("value head: channels must be a multiple of 16, value channels at most 16, FC width a multiple of 4");
     const size_t shmem = value_head_lds_bytes(a);
     if (shmem > 160 * 1024) throw std::runtime_error("value head: the board tile does not fit the LDS");
-    static size_t allowed = 0;
-    if (shmem > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&value_head_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(shmem));
-        allowed = shmem;
+    // per net build, like the other kernels' allowances: the attribute belongs to the current DEVICE's copy of the function, so a
+    // remembered process-wide maximum would leave the second device of a First/Last_Device_ID range at the default 64 KiB
+    if (shmem > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_head_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(shmem));
+        if (e != hipSuccess) throw std::runtime_error(std::string("value head: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
     }
 }
 template void prepare_value_head<half_t>(const ValueHeadArgs&);

@@ -24,6 +24,8 @@ namespace cra {
 
 namespace {
 constexpr double kBnEps = 1e-5;   // torch.nn.BatchNorm2d default; the reference never overrides it
+// the float16x3 forward's value head: false = conv GEMM + FC GEMM + value_final (three launches), true = value_head_kernel (one)
+constexpr bool kX3ValueHeadOneLaunch = false;
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -1096,7 +1098,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         op.kind = OpKind::Softmax;
         im.ops.push_back(op);
     }
-    if (fused_) {
+    // CRA_X3_VALUE_HEAD=one / three: the float16x3 forward's value head as the one-launch f32 kernel or as the three launches below
+    // (development: A/B and the lane determinism stress test, tests/test_lane_determinism_gpu.py)
+    const char* x3_vh = getenv("CRA_X3_VALUE_HEAD");
+    const bool x3_value_one_launch = x3_ && fused_ && (x3_vh ? x3_vh[0] == 'o' : kX3ValueHeadOneLaunch);
+    if (fused_ && !x3_value_one_launch) {
         // _ValueHead (builder_util.py:246-326) as three MFMA/wave-level launches instead of one latency-bound VALU kernel.
         // (Precision float16x3 ran the one-launch f32 kernel of the unfused path for a while -- 0.022 ms against 0.039 for these three -- but
         // with it behind the two-role tower the searches of two concurrent lanes stopped being reproducible run to run (profiles/NOTES.md,
@@ -1472,7 +1478,8 @@ struct RiseNet::Turn {
     std::unique_lock<std::mutex> lk;       // a member: released also when the constructor throws
     Turn(RiseNet& n) {
         static const bool off = getenv("CRA_NO_FORWARD_TURNS") != nullptr;      // development: A/B
-        if (off || n.device_ < 0 || n.device_ >= 64 || int(n.design_.batch) * 4 < n.cu_count_ * 3) return;
+        static const bool always = getenv("CRA_FORCE_FORWARD_TURNS") != nullptr;
+        if (off || n.device_ < 0 || n.device_ >= 64 || (!always && int(n.design_.batch) * 4 < n.cu_count_ * 3)) return;
         ForwardTurns* ft = &g_turns[n.device_];
         lk = std::unique_lock<std::mutex>(ft->mu);
         if (!ft->made) {
@@ -1532,7 +1539,7 @@ void RiseNet::forward_async() {
 // so these paths put the kernels straight into the stream: one queue, in-order, no host in the loop.
 void RiseNet::launch_forward_in_stream() {
     Turn turn(*this);
-    if (launches_ <= 4 && getenv("CRA_LANE_GRAPH") == nullptr) forward_on(stream_);
+    if ((launches_ <= 4 && getenv("CRA_LANE_GRAPH") == nullptr) || getenv("CRA_LANE_NO_GRAPH") != nullptr) forward_on(stream_);
     else HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
 }
 
@@ -1646,6 +1653,7 @@ void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int la
     }
     if (n_valid > 0) launch_planes_from_desc(static_cast<const BoardDesc*>(descs_host), n_valid, layout, 1, d_planes_, stream_);
     launch_forward_in_stream();
+    if (getenv("CRA_LANE_SYNC") != nullptr) HIP_CHECK(hipStreamSynchronize(stream_));     // development: bisecting the lane step's ordering
     launch_gather_probs(d_probs_, design_.nb_policy, idx, cnt, int(stride), n_valid, gathered, d_value_, value, int(B),
                         (d_aux_ && aux) ? d_aux_ : nullptr, aux, stream_);
 }

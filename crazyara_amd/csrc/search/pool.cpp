@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 
 #include "../nn/rise_net.h"
 
@@ -63,17 +64,80 @@ public:
     BoardDesc* descs() override { return descs_; }
     const float* values() override { return values_; }
     const float* probs() override { return probs_; }
-    void submit(int n_valid, int layout) override { net_->submit_boards(descs_, n_valid, layout, values_, probs_, aux_); }
-    void wait() override { net_->wait(); }
+    void submit(int n_valid, int layout) override {
+        if (record_) before_submit(n_valid, layout, false);
+        net_->submit_boards(descs_, n_valid, layout, values_, probs_, aux_);
+    }
+    void wait() override {
+        net_->wait();
+        if (record_ && pending_) after_wait();
+    }
     uint32_t gather_stride() const override { return gstride_; }
     uint16_t* gather_idx() override { return gidx_; }
     uint32_t* gather_cnt() override { return gcnt_; }
     const float* gathered() override { return gout_; }
     void submit_gathered(int n_valid, int layout) override {
+        if (record_) before_submit(n_valid, layout, true);
         net_->submit_boards_gathered(descs_, n_valid, layout, gidx_, gcnt_, gstride_, values_, gout_, aux_);
     }
+    size_t debug_replay(std::string* report) override;
 
 private:
+    // ---- CRA_LANE_RECORD=1 (diagnostic: tests/test_lane_determinism_gpu.py, scripts/lane_divergence.py) ----
+    // Every batch of the lane is kept: what went in (descriptors, gather lists) and what the host found in the output buffers when
+    // wait() returned (`seen`) and again when the next batch was submitted or the replay started (`late`: a result that lands after
+    // the stream was reported idle shows up as a difference between the two).  The outputs are poisoned before every submit, so a
+    // result the GPU never wrote is visible as such.  debug_replay() then sends every recorded batch through the lane again, alone
+    // on the device, and compares bit for bit.
+    struct Record {
+        int n_valid = 0, layout = 0;
+        bool gathered = false;
+        std::vector<BoardDesc> descs;
+        std::vector<uint16_t> gidx;
+        std::vector<uint32_t> gcnt;
+        std::vector<uint32_t> seen_v, seen_o, late_v, late_o;     // bit patterns of values / (gathered priors | whole vectors)
+    };
+    static constexpr uint32_t kPoison = 0x7fc0dead;
+    size_t out_words(const Record& r) const { return r.gathered ? size_t(r.n_valid) * gstride_ : size_t(r.n_valid) * nb_policy_; }
+    const float* out_buf(const Record& r) const { return r.gathered ? gout_ : probs_; }
+    void snapshot(const Record& r, std::vector<uint32_t>& v, std::vector<uint32_t>& o) const {
+        v.resize(size_t(r.n_valid));
+        std::memcpy(v.data(), values_, v.size() * 4);
+        o.resize(out_words(r));
+        std::memcpy(o.data(), out_buf(r), o.size() * 4);
+    }
+    void poison(const Record& r) {
+        uint32_t* v = reinterpret_cast<uint32_t*>(values_);
+        for (int i = 0; i < r.n_valid; ++i) v[i] = kPoison;
+        uint32_t* o = reinterpret_cast<uint32_t*>(const_cast<float*>(out_buf(r)));
+        for (size_t i = 0; i < out_words(r); ++i) o[i] = kPoison;
+    }
+    void close_last() {
+        if (!records_.empty() && records_.back().late_v.empty() && !pending_) snapshot(records_.back(), records_.back().late_v, records_.back().late_o);
+    }
+    void before_submit(int n_valid, int layout, bool gathered) {
+        close_last();
+        Record r;
+        r.n_valid = n_valid;
+        r.layout = layout;
+        r.gathered = gathered;
+        r.descs.assign(descs_, descs_ + n_valid);
+        if (gathered) {
+            r.gidx.assign(gidx_, gidx_ + size_t(n_valid) * gstride_);
+            r.gcnt.assign(gcnt_, gcnt_ + n_valid);
+        }
+        poison(r);
+        records_.push_back(std::move(r));
+        pending_ = true;
+    }
+    void after_wait() {
+        pending_ = false;
+        snapshot(records_.back(), records_.back().seen_v, records_.back().seen_o);
+    }
+    bool record_ = getenv("CRA_LANE_RECORD") != nullptr;
+    bool pending_ = false;
+    std::vector<Record> records_;
+
     RiseNet* net_;
     int batch_ = 0, nb_policy_ = 0;
     BoardDesc* descs_ = nullptr;
@@ -124,6 +188,66 @@ private:
     std::vector<uint32_t> gcnt_;
     std::vector<float> gout_;
 };
+size_t HipEvaluator::debug_replay(std::string* report) {
+    if (!record_) return 0;
+    if (pending_) throw std::logic_error("debug_replay with a batch in flight");
+    close_last();
+    record_ = false;                                  // the replays themselves are not recorded
+    size_t bad = 0;
+    char line[512];
+    auto say = [&](const char* what, size_t batch, int slot, long entry, uint32_t a, uint32_t b, const char* note) {
+        ++bad;
+        if (!report || report->size() > (1u << 16)) return;
+        float fa, fb;
+        std::memcpy(&fa, &a, 4);
+        std::memcpy(&fb, &b, 4);
+        snprintf(line, sizeof line, "%s batch %zu slot %d entry %ld: %08x (%.9g) vs %08x (%.9g)%s\n", what, batch, slot, entry, a, double(fa), b, double(fb), note);
+        *report += line;
+    };
+    for (size_t k = 0; k < records_.size(); ++k) {
+        const Record& r = records_[k];
+        if (r.seen_v.empty() && r.n_valid > 0) continue;
+        std::memcpy(descs_, r.descs.data(), r.descs.size() * sizeof(BoardDesc));
+        if (r.gathered) {
+            std::memcpy(gidx_, r.gidx.data(), r.gidx.size() * sizeof(uint16_t));
+            std::memset(gcnt_, 0, sizeof(uint32_t) * size_t(batch_));
+            std::memcpy(gcnt_, r.gcnt.data(), r.gcnt.size() * sizeof(uint32_t));
+        }
+        poison(r);
+        if (r.gathered) net_->submit_boards_gathered(descs_, r.n_valid, r.layout, gidx_, gcnt_, gstride_, values_, gout_, aux_);
+        else net_->submit_boards(descs_, r.n_valid, r.layout, values_, probs_, aux_);
+        net_->wait();
+        std::vector<uint32_t> v, o;
+        snapshot(r, v, o);
+        const size_t per = r.gathered ? gstride_ : size_t(nb_policy_);
+        for (int s = 0; s < r.n_valid; ++s) {
+            const size_t cnt = r.gathered ? r.gcnt[size_t(s)] : per;
+            if (r.gathered && cnt == 0) continue;          // (a slot without a new node: nothing is written, nothing is read)
+            // where does a wrong value come from?  the batch before (stale buffer), another slot of this batch, poison (never written)
+            auto origin = [&](uint32_t got) -> const char* {
+                if (got == kPoison) return "  [poison: never written]";
+                if (k > 0 && size_t(s) < records_[k - 1].seen_v.size() && records_[k - 1].seen_v[size_t(s)] == got) return "  [= this slot's value of the batch before]";
+                for (int t = 0; t < r.n_valid; ++t)
+                    if (t != s && v[size_t(t)] == got) return "  [= another slot's value of this batch]";
+                return "";
+            };
+            if (r.seen_v[size_t(s)] != v[size_t(s)]) say("value   seen/replay", k, s, -1, r.seen_v[size_t(s)], v[size_t(s)], origin(r.seen_v[size_t(s)]));
+            if (r.late_v[size_t(s)] != r.seen_v[size_t(s)]) say("value   seen/late  ", k, s, -1, r.seen_v[size_t(s)], r.late_v[size_t(s)], "");
+            for (size_t j = 0; j < cnt; ++j) {
+                const size_t i = size_t(s) * per + j;
+                if (r.seen_o[i] != o[i]) say("prior   seen/replay", k, s, long(j), r.seen_o[i], o[i], r.seen_o[i] == kPoison ? "  [poison: never written]" : "");
+                if (r.late_o[i] != r.seen_o[i]) say("prior   seen/late  ", k, s, long(j), r.seen_o[i], r.late_o[i], "");
+            }
+        }
+    }
+    if (report) {
+        snprintf(line, sizeof line, "lane replay: %zu batches, %zu differing words\n", records_.size(), bad);
+        *report += line;
+    }
+    records_.clear();
+    record_ = true;
+    return bad;
+}
 }  // namespace
 
 std::unique_ptr<Evaluator> make_hip_evaluator(RiseNet* net) { return std::unique_ptr<Evaluator>(new HipEvaluator(net)); }

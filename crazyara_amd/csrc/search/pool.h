@@ -3,6 +3,7 @@
 #include <atomic>
 #include <exception>
 #include <mutex>
+#include <string>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -36,6 +37,9 @@ public:
     virtual uint32_t* gather_cnt() = 0;                // [batch]
     virtual const float* gathered() = 0;               // [batch][stride]
     virtual void submit_gathered(int n_valid, int layout) = 0;   // values() and gathered() are valid after wait(); probs() is not
+    // diagnostic (CRA_LANE_RECORD=1, HIP lanes): every batch this lane evaluated is sent through it again, alone on the device, and
+    // compared bit for bit with what the host saw at the time; returns the number of differing words, details appended to `report`
+    virtual size_t debug_replay(std::string* report) { (void)report; return 0; }
 };
 
 // HIP lane: RiseNet::submit_boards on the net's side stream (192 B/position H2D, planes built on the GPU, D2H of results)
@@ -117,6 +121,11 @@ public:
     void set_adaptive_quota(int cap) { adaptive_cap_ = cap < 0 ? 0 : cap; }
     int adaptive_quota() const { return adaptive_cap_; }
     int n_trees() const { return int(trees_.size()); }
+    size_t debug_replay(std::string* report) {                   // Evaluator::debug_replay of every lane (between runs)
+        size_t bad = 0;
+        for (Lane& lane : lanes_) bad += lane.eval->debug_replay(report);
+        return bad;
+    }
     const SearchSettings& settings() const { return s_; }
 
 private:

@@ -161,6 +161,16 @@ class SearchPool:
             raise RuntimeError(_capi.last_error())
         return np.ctypeslib.as_array(buf)[:n].copy()
 
+    def debug_replay(self):
+        """(differing words, report) of mi_search_debug_replay: the lanes' recorded batches evaluated again, alone on the device, and
+        compared bit for bit with what the searches consumed.  Needs CRA_LANE_RECORD=1 in the environment when the pool is made."""
+        cap = 1 << 17
+        buf = C.create_string_buffer(cap)
+        n = self._lib.mi_search_debug_replay(self._h, buf, cap)
+        if n < 0:
+            raise RuntimeError(_capi.last_error())
+        return int(n), buf.value.decode()
+
     def set_shared_collectors(self, k: int) -> None:
         """k >= 1 collectors per tree in every lane (SearchThreads sharing one tree, crazyara.cpp:555-561): the single-`go` mode.
         0 = many-trees mode (one collector per tree, each tree in one lane)."""

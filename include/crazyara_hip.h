@@ -292,6 +292,13 @@ int mi_search_set_adaptive_quota(mi_search* sp, int cap);
  * [move, visits, virtual-loss counter, float bits of Q, float bits of prior, state: 0 no node / 1 evaluated, never selected /
  * 2 its record follows].  Returns the number of 32-bit words written, -1 on error (buffer too small). */
 long mi_search_tree_dump(mi_search* sp, int tree, uint32_t* out, long cap);
+/* Diagnostic of the HIP lanes (process started with CRA_LANE_RECORD=1; otherwise returns 0): every batch the pool's lanes evaluated
+ * since the last call is sent through its lane again, alone on the device, and compared bit for bit with what the host found in the
+ * lane's result buffers when the batch was reported complete (SearchThread reads them right after predict() returns,
+ * searchthread.cpp:403-416) and again when the next batch went out.  Returns the number of differing 32-bit words (0 = every result
+ * the searches consumed is reproducible), -1 on error; a text report (NUL-terminated, truncated to cap) goes to `report` if given.
+ * Between runs only. */
+long mi_search_debug_replay(mi_search* sp, char* report, long cap);
 /* active = 0: the tree sits out the following mi_search_run calls and keeps its state (the player that is not to move in an
  * arena game, generate_arena_game, selfplay.cpp:267-308); trees start active */
 int mi_search_set_active(mi_search* sp, int tree, int active);

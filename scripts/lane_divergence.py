@@ -1,0 +1,156 @@
+"""Two-lane search reproducibility: bisecting harness (profiles/NOTES.md round 4).
+
+The scenario of tests/test_search_gpu.py::test_priors_gathered_on_the_gpu_equal_whole_probability_vectors: 8 crazyhouse trees, two
+evaluator lanes (two nets, two streams), 4 host threads, batch 64, 240 simulations.  A tree lives in ONE lane, so its result is a pure
+function of the network outputs: two runs that differ got different numbers from the GPU.  Every run is recorded (CRA_LANE_RECORD) and
+replayed single-stream afterwards (mi_search_debug_replay): a differing word names batch, slot and output.
+
+    python scripts/lane_divergence.py                  # the table of configurations, one child process each
+    python scripts/lane_divergence.py --child NAME     # one configuration in this process (environment already set)
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# name -> (environment, options)
+CONFIGS = {
+    "three_roles": ({"CRA_X3_VALUE_HEAD": "three"}, {}),
+    "one_roles": ({"CRA_X3_VALUE_HEAD": "one"}, {}),
+    "one_symmetric": ({"CRA_X3_VALUE_HEAD": "one", "CRA_X3_TOWER": "symmetric"}, {}),
+    "one_roles_hwq1": ({"CRA_X3_VALUE_HEAD": "one", "GPU_MAX_HW_QUEUES": "1"}, {}),
+    "one_roles_serialize": ({"CRA_X3_VALUE_HEAD": "one", "AMD_SERIALIZE_KERNEL": "3"}, {}),
+    "one_roles_lanesync": ({"CRA_X3_VALUE_HEAD": "one", "CRA_LANE_SYNC": "1"}, {}),
+    "one_roles_nograph": ({"CRA_X3_VALUE_HEAD": "one", "CRA_LANE_NO_GRAPH": "1"}, {}),
+    "one_roles_turns": ({"CRA_X3_VALUE_HEAD": "one", "CRA_FORCE_FORWARD_TURNS": "1"}, {}),
+    "one_roles_onelane": ({"CRA_X3_VALUE_HEAD": "one"}, {"lanes": 1}),
+    "one_roles_whole_vectors": ({"CRA_X3_VALUE_HEAD": "one", "CRA_GATHER_PER_SLOT": "0"}, {}),
+    "three_roles_nograph": ({"CRA_X3_VALUE_HEAD": "three", "CRA_LANE_NO_GRAPH": "1"}, {}),
+    "float16": ({}, {"precision": "float16"}),
+}
+
+
+def child(name, runs, predicts):
+    import numpy as np
+    import nn_cases
+    from crazyara_amd import _capi, openings, search
+    from crazyara_amd.neuralnetapi import HipAPI, NeuralNetAPIUser
+
+    env, opt = CONFIGS[name]
+    precision = opt.get("precision", "float16x3")
+    lanes = opt.get("lanes", 2)
+    tmp = tempfile.mkdtemp(prefix="cra_lane_")
+    cfg, sd, _ = nn_cases.make_case("risev2-3")
+    d = nn_cases.export_case(tmp, "risev2-3", cfg, sd)
+    fens = openings.position_fens("crazyhouse")[20:28]
+    out = {"name": name, "env": env, "precision": precision, "lanes": lanes}
+
+    # ---- (1) forwards of two nets from two host threads, fixed inputs, zero-copy predict: every output against the net alone ----
+    nets = [HipAPI(0, 64, d, precision) for _ in range(2)]
+    users = [NeuralNetAPIUser([n]) for n in nets]
+    rng = np.random.default_rng(5)
+    for u in users:
+        u.input_planes[:] = (rng.random(u.input_planes.shape) < 0.1).astype(np.float32)
+    ref = []
+    for n, u in zip(nets, users):
+        n.predict(u.input_planes, u.value_outputs, u.prob_outputs)
+        ref.append((u.value_outputs.copy(), u.prob_outputs.copy()))
+    bad = [[0, 0, 0], [0, 0, 0]]      # predicts that differ, of those: value differs, probabilities differ
+    worst = [0.0, 0.0]
+
+    def loop(i):
+        n, u = nets[i], users[i]
+        for _ in range(predicts):
+            u.value_outputs[:] = np.nan
+            n.predict(u.input_planes, u.value_outputs, u.prob_outputs)
+            dv = not np.array_equal(u.value_outputs.view(np.uint32), ref[i][0].view(np.uint32))
+            dp = not np.array_equal(u.prob_outputs.view(np.uint32), ref[i][1].view(np.uint32))
+            if dv or dp:
+                bad[i][0] += 1
+                bad[i][1] += int(dv)
+                bad[i][2] += int(dp)
+                worst[i] = max(worst[i], float(np.nanmax(np.abs(u.value_outputs - ref[i][0]))) if not np.isnan(u.value_outputs).any() else float("inf"))
+    th = [threading.Thread(target=loop, args=(i,)) for i in range(2)]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    out["concurrent_predicts"] = {"per_net": predicts, "differing": bad, "worst_value_delta": worst, "seconds": round(time.time() - t0, 2)}
+    for u in users:
+        u.close()
+
+    # ---- (2) the searches, recorded and replayed ----
+    os.environ["CRA_LANE_RECORD"] = "1"
+    first = None
+    equal = 0
+    replay_bad = 0
+    reports = []
+    t0 = time.time()
+    for r in range(runs):
+        st = search.default_settings(mode=0, version_major=1, batch_size=16, seed=3)
+        pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1] if lanes == 2 else None)
+        for f in fens:
+            pool.add_position(f, False, "crazyhouse")
+        pool.run(simulations=240, threads=4)
+        dumps = [pool.tree_dump(i).tobytes() for i in range(len(fens))]
+        n_bad, text = pool.debug_replay()
+        replay_bad += n_bad
+        if n_bad and len(reports) < 6:
+            reports.append(f"run {r}: " + text[-1500:])
+        if first is None:
+            first = dumps
+            equal += 1
+        else:
+            same = [a == b for a, b in zip(first, dumps)]
+            equal += int(all(same))
+            if not all(same) and len(reports) < 6:
+                reports.append(f"run {r}: trees that differ from run 0: {[i for i, s in enumerate(same) if not s]} (replay: {n_bad} differing words)")
+        pool.close()
+    out["searches"] = {"runs": runs, "equal_to_first": equal, "replay_differing_words": replay_bad, "seconds": round(time.time() - t0, 2)}
+    out["reports"] = reports
+    for n in nets:
+        n.close()
+    print("RESULT " + json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--child")
+    ap.add_argument("--runs", type=int, default=60)
+    ap.add_argument("--predicts", type=int, default=300)
+    ap.add_argument("--configs", default=",".join(CONFIGS))
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    if a.child:
+        child(a.child, a.runs, a.predicts)
+        return
+    lines = []
+    for name in a.configs.split(","):
+        env = dict(os.environ)
+        env.update(CONFIGS[name][0])
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", name, "--runs", str(a.runs), "--predicts", str(a.predicts)],
+                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            res = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+            line = res[-1][7:] if res else json.dumps({"name": name, "error": r.stdout[-1500:], "rc": r.returncode})
+        except subprocess.TimeoutExpired:
+            line = json.dumps({"name": name, "error": "timeout"})
+        print(f"[{time.time() - t0:6.1f} s] {line}", flush=True)
+        lines.append(line)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -125,4 +125,7 @@ def test_bench_started_plainly_with_gpus_2_becomes_two_ranks():
     if torch.cuda.is_available():
         pytest.skip("a GPU box: the ranks would run")
     assert r.returncode != 0
-    assert r.stdout.count("bench.py needs a GPU") == 2, r.stdout[-2000:]
+    # the launcher ends the other rank (SIGTERM) as soon as the first one has failed: one refusal is certain, the second rank's may be
+    # cut off -- but the launcher's report names both ranks
+    assert 1 <= r.stdout.count("bench.py needs a GPU") <= 2, r.stdout[-2000:]
+    assert "local_rank: 0" in r.stdout and "local_rank: 1" in r.stdout, r.stdout[-2000:]

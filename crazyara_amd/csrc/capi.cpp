@@ -121,6 +121,9 @@ void* mi_net_block_dump(mi_net* net, int* n_tiles) {
     if (guard([&] { p = net->net.enable_block_dump(n_tiles); })) return nullptr;
     return p;
 }
+// development hook (not in the public header): device pointer to the value head's [B][8] stage checksums, null unless the process
+// runs with CRA_VALUE_HEAD_DEBUG (scripts/lane_divergence.py)
+void* mi_dev_value_head_debug(mi_net* net) { return net ? static_cast<void*>(net->net.value_head_debug()) : nullptr; }
 int mi_net_forward_device(mi_net* net) {
     if (!net) { g_err = "null net"; return 1; }
     return guard([&] { net->net.forward_async(); });

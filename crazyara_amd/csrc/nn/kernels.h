@@ -273,6 +273,10 @@ struct ValueHeadArgs {
     float* value;           // [B]
     float* aux;             // [B][4] or nullptr
     int batch, C, cv, fc;
+    // development (CRA_VALUE_HEAD_DEBUG, scripts/lane_divergence.py): [B][8] stage checksums of the launch -- staged board, staged conv
+    // weights, conv output, FC1 partial sums, FC2 sum, value -- each added up in a fixed order: equal inputs give equal bits
+    float* dbg;
+    int lds_pad;            // development: extra dynamic LDS per workgroup (keeps other workgroups off the CU)
 };
 template <typename T> void prepare_value_head(const ValueHeadArgs& a);   // once per net: LDS allowance of the kernel
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s);

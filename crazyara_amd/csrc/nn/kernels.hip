@@ -394,6 +394,7 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
         for (int u = 0; u < 4; ++u)
             if (i0 + u * 1024 < a.cv * a.C) *reinterpret_cast<f32x4*>(ws + i0 + u * 1024) = wv[u];
     }
+    float dbg_in = 0.f;                                        // (development) what this thread staged of the board
     {   // conv 1x1 + BN + ReLU: thread = square tid % 64, channels tid / 64, + 4, ... (at most four per thread)
         const int sq = tid & 63, g = tid >> 6;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -416,6 +417,8 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
                         const int r = i / (CH / 8), v = i % (CH / 8);
                         *reinterpret_cast<f32x4*>(xs + r * XP + v * 8) = f32x4{f[u][0], f[u][1], f[u][2], f[u][3]};
                         *reinterpret_cast<f32x4*>(xs + r * XP + v * 8 + 4) = f32x4{f[u][4], f[u][5], f[u][6], f[u][7]};
+                        if (a.dbg)
+                            for (int e = 0; e < 8; ++e) dbg_in += f[u][e];
                     }
                 }
             }
@@ -470,6 +473,17 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
         return;
     }
 
+    if (a.dbg) {                                               // (development) stage checksums, see ValueHeadArgs::dbg
+        float* o = a.dbg + size_t(b) * 8;
+        const float s_in = block_sum_256(dbg_in, s_red);
+        float w_sum = 0.f, f_sum = 0.f;
+        for (int i = tid; i < a.cv * a.C; i += 256) w_sum += ws[i];
+        for (int i = tid; i < nf; i += 256) f_sum += s_flat[i];
+        const float s_w = block_sum_256(w_sum, s_red), s_f = block_sum_256(f_sum, s_red);
+        if (tid == 0) { o[0] = s_in; o[1] = s_w; o[2] = s_f; }
+        __syncthreads();
+    }
+
     // FC1 + ReLU + FC2: thread = (four consecutive outputs, quarter of the inputs): a row of the transposed matrix is one 16-byte load per
     // lane (a wave reads 1 KiB), 32 of them in flight; the quarters' partial sums meet in LDS (the staged board is dead by now)
     float* s_part = xs;                                         // [4 quarters][fc]
@@ -510,6 +524,19 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
     }
     const float tot = block_sum_256(part, s_red);
     if (tid == 0) a.value[b] = tanhf(tot + a.b2);
+    if (a.dbg) {
+        float p_sum = 0.f;
+        for (int i = tid; i < 4 * a.fc; i += 256) p_sum += s_part[i];
+        const float s_p = block_sum_256(p_sum, s_red);
+        if (tid == 0) {
+            float* o = a.dbg + size_t(b) * 8;
+            o[3] = s_p;
+            o[4] = tot;
+            o[5] = tanhf(tot + a.b2);
+            o[6] = __builtin_bit_cast(float, __builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_ID: wave / simd / cu / sh / se (raw bits)
+            o[7] = __builtin_bit_cast(float, __builtin_amdgcn_s_getreg((31 << 11) | 20));     // XCC_ID
+        }
+    }
 }
 
 template <typename T>
@@ -555,7 +582,7 @@ template void launch_value_final<half_t>(const ValueFinalArgs&, hipStream_t);
 template void launch_value_final<float>(const ValueFinalArgs&, hipStream_t);
 
 static size_t value_head_lds_bytes(const ValueHeadArgs& a) {
-    return (size_t(kSquares) * (a.C / 2 + 4) + size_t(a.cv) * a.C + size_t(kSquares) * a.cv + 8) * sizeof(float);
+    return (size_t(kSquares) * (a.C / 2 + 4) + size_t(a.cv) * a.C + size_t(kSquares) * a.cv + 8) * sizeof(float) + size_t(a.lds_pad);
 }
 // once per net, outside any stream capture: the kernel's dynamic LDS allowance (the staged board is more than the default 64 KiB)
 template <typename T> void prepare_value_head(const ValueHeadArgs& a) {

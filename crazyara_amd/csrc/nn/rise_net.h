@@ -73,6 +73,7 @@ public:
     // block (kernels.h: TowerArgs::block_dump).  Returns the device buffer [n_tiles][B][64][256] f16; throws when the net has no such
     // tower (or more than one run of blocks).
     void* enable_block_dump(int* n_tiles);
+    float* value_head_debug() const { return value_head_dbg_; }   // development: [B][8] stage checksums (CRA_VALUE_HEAD_DEBUG), else null
     float* d_aux() const { return d_aux_; }           // [B][nb_aux] or nullptr
     void forward_async();
     void launch_forward_in_stream();     // the forward as part of a stream's in-order work (submit*, see rise_net.hip)                              // graph replay on stream(); no copies, no sync
@@ -105,6 +106,7 @@ private:
     void capture();
     bool buffers_are_pinned(const float* in_planes, float* value, float* probs, float* aux);
     bool last_zero_copy_ = false;
+    float* value_head_dbg_ = nullptr;
     bool keep_logits_ = false;   // the one-launch head also writes policy_out (pre-softmax) to d_logits() (parity tests); nets whose heads
                                  // run as separate launches always have it there (the softmax launch reads it)
 

@@ -1223,6 +1223,12 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             macs += double(nfl) * fc + fc;
         }
         macs += double(kSquares) * C * cv;
+        if (getenv("CRA_VALUE_HEAD_DEBUG") != nullptr) {              // development: stage checksums of every launch (ValueHeadArgs::dbg)
+            v.dbg = static_cast<float*>(im.dalloc(size_t(B) * 8 * sizeof(float)));
+            HIP_CHECK(hipMemset(v.dbg, 0, size_t(B) * 8 * sizeof(float)));
+            value_head_dbg_ = v.dbg;
+        }
+        if (const char* pad = getenv("CRA_VALUE_HEAD_LDS_PAD")) v.lds_pad = atoi(pad);
         prepare_value_head<T>(op.vh);
         im.ops.push_back(op);
     }

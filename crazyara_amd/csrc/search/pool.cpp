@@ -424,8 +424,15 @@ void SearchPool::evaluate_roots(uint64_t* evals, uint64_t* batches) {
 }
 
 void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats, uint32_t movetime_ms) {
+    // this run's generation: the announced one (a stop sent since the announcement already names it) or a new one
+    const uint64_t my_gen = state_.load(std::memory_order_acquire) == 1 ? go_gen_.load(std::memory_order_acquire)
+                                                                        : go_gen_.fetch_add(1, std::memory_order_acq_rel) + 1;
+    state_.store(2, std::memory_order_release);
+    struct Idle {                                                  // whichever way the run ends: no search announced or running
+        std::atomic<int>& s;
+        ~Idle() { s.store(0, std::memory_order_release); }
+    } idle_at_exit{state_};
     if (!simulations && !nodes && !movetime_ms) throw std::invalid_argument("run needs a simulations, a nodes or a movetime limit");
-    halt_.store(false, std::memory_order_relaxed);
     if (!workers_ || workers_->threads() != std::max(1, threads)) workers_.reset(new WorkerPool(std::max(1, threads)));
     WorkerPool& workers = *workers_;
     SearchStats st;
@@ -452,10 +459,12 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     // (searchthread.cpp:326-331: rootNode->get_visits() < simulations, get_node_count() < nodes): visits inherited through tree
     // reuse count towards the limit of the next go
     const auto deadline = t0 + std::chrono::milliseconds(movetime_ms);
+    std::atomic<bool> time_up_flag{false};
     auto halted = [&]() {                                           // request_stop() or the movetime: every tree is "done"
-        if (halt_.load(std::memory_order_relaxed)) return true;
+        if (stop_gen_.load(std::memory_order_acquire) == my_gen) return true;
+        if (time_up_flag.load(std::memory_order_relaxed)) return true;
         if (movetime_ms && std::chrono::steady_clock::now() >= deadline) {
-            halt_.store(true, std::memory_order_relaxed);
+            time_up_flag.store(true, std::memory_order_relaxed);
             return true;
         }
         return false;

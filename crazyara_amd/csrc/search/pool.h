@@ -94,9 +94,19 @@ public:
     // ThreadManager::stop_search_based_on_limits, threadmanager.cpp:69-97, without its early-stopping heuristics); at least one of the
     // three limits must be given.  Batches in flight are applied before the call returns: the trees are consistent.
     void run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats, uint32_t movetime_ms = 0);
-    // from any thread while run() is executing: the searches end as if their limits had been reached (SearchThread::stop,
-    // searchthread.cpp:109-112; MCTSAgent::stop, mctsagent.cpp:364-373).  Without a run in progress it does nothing.
-    void request_stop() { halt_.store(true, std::memory_order_relaxed); }
+    // Stop protocol (SearchThread::stop, searchthread.cpp:109-112; MCTSAgent::stop, mctsagent.cpp:364-373).  Every search has a
+    // generation number.  announce_go() -- called by the thread that decides to search, BEFORE it hands run() to another thread --
+    // opens the next generation; run() adopts an announced generation (or opens one itself); request_stop() from any thread names
+    // the generation that is announced or running, and the run of that generation ends as if its limits had been reached, also
+    // when it has not entered run() yet: a stop is sticky for its search and never reaches a later one.  With nothing announced or
+    // running a stop does nothing (MCTSAgent::stop: `if (!isRunning) return`).
+    void announce_go() {
+        go_gen_.fetch_add(1, std::memory_order_acq_rel);
+        state_.store(1, std::memory_order_release);
+    }
+    void request_stop() {
+        if (state_.load(std::memory_order_acquire) != 0) stop_gen_.store(go_gen_.load(std::memory_order_acquire), std::memory_order_release);
+    }
     // evaluates the roots that have no network result yet (new games, restarted trees) through the first lane, as run() does first;
     // a game loop reads the raw policy of fresh positions from the root priors this leaves (RawNetAgent::evaluate_board_state)
     void evaluate_new_roots(SearchStats* stats) { SearchStats st; evaluate_roots(&st.nn_evals, &st.batches); if (stats) *stats = st; }
@@ -146,7 +156,8 @@ private:
     std::vector<Item> items_;
     int shared_k_ = 0;
     int adaptive_cap_ = 0;
-    std::atomic<bool> halt_{false};      // request_stop(); cleared when a run starts
+    std::atomic<uint64_t> go_gen_{0}, stop_gen_{0};      // stop protocol: the generation announced / running, the generation told to stop
+    std::atomic<int> state_{0};                          // 0 idle, 1 a go is announced, 2 running
     SearchSettings s_;
     int layout_;
     std::vector<std::unique_ptr<Tree>> trees_;

@@ -89,8 +89,13 @@ class SearchPool:
             raise RuntimeError(_capi.last_error())
         return st
 
+    def announce_go(self) -> None:
+        """The commanding thread's half of `go`: from now on a `stop` belongs to the coming `run`, also when it arrives before the
+        search thread has entered it (mi_search_announce_go)."""
+        self._lib.mi_search_announce_go(self._h)
+
     def stop(self) -> None:
-        """Ends a `run` that is executing in another thread (SearchThread::stop); no effect otherwise."""
+        """Ends the `run` that is executing in another thread or has been announced (SearchThread::stop); no effect otherwise."""
         self._lib.mi_search_stop(self._h)
 
     def root_children(self, tree: int):

@@ -237,9 +237,14 @@ int mi_search_run(mi_search* sp, unsigned simulations, unsigned nodes, int threa
  * engine/src/manager/threadmanager.cpp:69-97): the searches also end movetime_ms after the start of the call.  At least one of the
  * three limits must be non-zero; batches in flight are applied before the call returns. */
 int mi_search_run_timed(mi_search* sp, unsigned simulations, unsigned nodes, unsigned movetime_ms, int threads, mi_search_stats* stats);
-/* from ANOTHER thread while mi_search_run / mi_search_run_timed is executing: the searches end as if their limits had been reached
- * (SearchThread::stop, engine/src/searchthread.cpp:109-112; MCTSAgent::stop, agents/mctsagent.cpp:364-373); the run call returns with
- * consistent trees.  Without a run in progress it does nothing (a later run is not affected). */
+/* Stop protocol.  mi_search_stop from ANOTHER thread ends the search that is running or announced as if its limits had been reached
+ * (SearchThread::stop, engine/src/searchthread.cpp:109-112; MCTSAgent::stop, agents/mctsagent.cpp:364-373); the run call returns
+ * with consistent trees.  mi_search_announce_go is what the commanding thread (the UCI loop on `go`, uci/crazyara.cpp:183-231) calls
+ * BEFORE it hands mi_search_run / mi_search_run_timed to its search thread: a stop that arrives between the announcement and the
+ * moment the search thread enters the run call is kept and ends that search at once (after the roots are evaluated, so that a best
+ * move exists) -- it is sticky for ITS search and never reaches a later one.  A run that was not announced opens its own generation
+ * on entry; with nothing announced or running a stop does nothing (MCTSAgent::stop: `if (!isRunning) return`). */
+int mi_search_announce_go(mi_search* sp);
 int mi_search_stop(mi_search* sp);
 /* root statistics of one tree, children in the node's (prior-sorted) order: returns number of expanded children */
 int mi_search_root_children(mi_search* sp, int tree, int cap, uint32_t* moves, uint32_t* visits, float* q, float* priors);

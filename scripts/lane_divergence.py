@@ -35,6 +35,11 @@ CONFIGS = {
     "one_roles_whole_vectors": ({"CRA_X3_VALUE_HEAD": "one", "CRA_GATHER_PER_SLOT": "0"}, {}),
     "three_roles_nograph": ({"CRA_X3_VALUE_HEAD": "three", "CRA_LANE_NO_GRAPH": "1"}, {}),
     "float16": ({}, {"precision": "float16"}),
+    # the value head's stage checksums under the storm of concurrent predicts: which stage differs first?
+    "dbg_one": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1"}, {"predicts": 20000, "runs": 0}),
+    "dbg_one_alone_on_cu": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_LDS_PAD": "100000"}, {"predicts": 20000, "runs": 0}),
+    "dbg_one_hwq1": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "GPU_MAX_HW_QUEUES": "1"}, {"predicts": 20000, "runs": 0}),
+    "storm_three": ({"CRA_X3_VALUE_HEAD": "three"}, {"predicts": 20000, "runs": 0}),
 }
 
 
@@ -65,6 +70,23 @@ def child(name, runs, predicts):
         ref.append((u.value_outputs.copy(), u.prob_outputs.copy()))
     bad = [[0, 0, 0], [0, 0, 0]]      # predicts that differ, of those: value differs, probabilities differ
     worst = [0.0, 0.0]
+    predicts = opt.get("predicts", predicts)
+    runs = opt.get("runs", runs)
+    lib = _capi.load()
+    dbg_view, dbg_ref, dbg_events = [None, None], [None, None], []
+    if "CRA_VALUE_HEAD_DEBUG" in env:
+        import ctypes as C
+        import torch
+        from crazyara_amd.neuralnetapi import _DevArray
+        lib.mi_dev_value_head_debug.restype = C.c_void_p
+        lib.mi_dev_value_head_debug.argtypes = [C.c_void_p]
+        for i, n in enumerate(nets):
+            ptr = lib.mi_dev_value_head_debug(n._h)
+            assert ptr, "no debug buffer: CRA_VALUE_HEAD_DEBUG must be set before the net is built"
+            dbg_view[i] = torch.as_tensor(_DevArray(ptr, (64, 8)), device="cuda")
+            n.predict(users[i].input_planes, users[i].value_outputs, users[i].prob_outputs)
+            dbg_ref[i] = dbg_view[i].cpu().numpy().copy()
+    stage_names = ["board", "conv_w", "conv_out", "fc1_parts", "fc2_sum", "value", "hw_id", "xcc_id"]
 
     def loop(i):
         n, u = nets[i], users[i]
@@ -78,6 +100,15 @@ def child(name, runs, predicts):
                 bad[i][1] += int(dv)
                 bad[i][2] += int(dp)
                 worst[i] = max(worst[i], float(np.nanmax(np.abs(u.value_outputs - ref[i][0]))) if not np.isnan(u.value_outputs).any() else float("inf"))
+                if dv and dbg_view[i] is not None and len(dbg_events) < 40:
+                    got = dbg_view[i].cpu().numpy()
+                    for b in np.nonzero(u.value_outputs.view(np.uint32) != ref[i][0].view(np.uint32))[0]:
+                        diff = [stage_names[c] for c in range(6) if got[b, c].view(np.uint32) != dbg_ref[i][b, c].view(np.uint32)]
+                        dbg_events.append({"net": i, "board": int(b), "stages_that_differ": diff,
+                                           "got": [float(v) for v in got[b, :6]], "ref": [float(v) for v in dbg_ref[i][b, :6]],
+                                           "hw_id": hex(int(got[b, 6].view(np.uint32))), "xcc_id": hex(int(got[b, 7].view(np.uint32))),
+                                           "ref_hw_id": hex(int(dbg_ref[i][b, 6].view(np.uint32))), "ref_xcc_id": hex(int(dbg_ref[i][b, 7].view(np.uint32))),
+                                           "value": float(u.value_outputs[b]), "ref_value": float(ref[i][0][b])})
     th = [threading.Thread(target=loop, args=(i,)) for i in range(2)]
     t0 = time.time()
     for t in th:
@@ -85,6 +116,8 @@ def child(name, runs, predicts):
     for t in th:
         t.join()
     out["concurrent_predicts"] = {"per_net": predicts, "differing": bad, "worst_value_delta": worst, "seconds": round(time.time() - t0, 2)}
+    if dbg_events:
+        out["value_head_stage_events"] = dbg_events
     for u in users:
         u.close()
 

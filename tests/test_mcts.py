@@ -795,3 +795,41 @@ def test_stop_from_another_thread_ends_the_run(hip_lib):
     pool.apply_move(t, pool.best_move(t))                              # no batch left in flight
     pool.run(simulations=32, threads=1)
     pool.close()
+
+
+def test_stop_sent_before_the_search_thread_entered_run_is_not_lost(hip_lib):
+    """The reference's stop is sticky (SearchThread::stop sets isRunning = false, searchthread.cpp:109-112; the search loop tests it
+    before every mini-batch): `go` announces the search on the commanding thread (mi_search_announce_go), a `stop` that arrives before
+    the search thread has entered mi_search_run ends that search at once -- and only that one."""
+    import threading
+    import time
+    nbp = NB_POLICY[0]
+    st = search.default_settings(mode=0, version_major=1, batch_size=8)
+    pool = search.SearchPool(st, eval_fn=_slow_eval(nbp, 0.002), fn_batch=8, fn_nb_policy=nbp)
+    t = pool.add_position("", False, "crazyhouse")
+    result = {}
+
+    def go():
+        time.sleep(0.2)                                                # the search thread is slow to start
+        result["stats"] = pool.run(simulations=50_000_000, threads=2)
+    pool.announce_go()
+    th = threading.Thread(target=go)
+    t0 = time.time()
+    th.start()
+    pool.stop()                                                        # before run() was entered
+    th.join(timeout=10)
+    assert not th.is_alive() and time.time() - t0 < 2.0
+    assert result["stats"].simulations < 64                            # the root evaluation and at most a batch or two
+    assert pool.best_move(t)                                           # ... but a move exists
+    _check_tree_invariants(pool.tree_dump(t))
+    # the stop belonged to that search: the next one (announced or not) runs to its limit
+    s1 = pool.run(simulations=200, threads=1)
+    assert pool.tree_info(t)["root_visits"] >= 200 and s1.simulations > 100
+    pool.announce_go()
+    s2 = pool.run(simulations=400, threads=1)
+    assert pool.tree_info(t)["root_visits"] >= 400 and s2.simulations > 100
+    # a stop with nothing announced or running is ignored (MCTSAgent::stop: `if (!isRunning) return`)
+    pool.stop()
+    s3 = pool.run(simulations=600, threads=1)
+    assert pool.tree_info(t)["root_visits"] >= 600 and s3.simulations > 100
+    pool.close()

@@ -212,20 +212,20 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
         prec.resize(prec.size() - perblock_tag.size());
     }
     if (prec == "float16" || prec == "fp16" || prec == "half") fp16_ = true;
-    // The reference's reduced-precision mode is TensorRT INT8 (tensorrtapi.cpp:229-248, UCI option Precision = int8).  On gfx950 the
-    // 8-bit format with a one-instruction conversion from f16 and a matrix instruction at twice the f16 rate is e4m3, so that is what
-    // the mode runs on: the GEMMs of the residual tower take e4m3 operands (no calibration file: per-row power-of-two weight scales,
-    // f32 accumulation, the residual stream itself stays f16); stem and heads stay f16.  "int8" is accepted as the reference's name for it.
-    else if (prec == "fp8" || prec == "float8" || prec == "int8") {
+    // The reference's reduced-precision mode is TensorRT INT8, entropy-calibrated on the plies of two recorded games
+    // (tensorrtapi.cpp:334-360, chessbatchstream.cpp:44-94; UCI option Precision = int8).  This back end has no calibrated 8-bit mode:
+    // its 8-bit mode is e4m3 (the format with a one-instruction conversion from f16 and a matrix instruction at twice the f16 rate on
+    // gfx950) in the GEMMs of the residual tower -- per-row power-of-two weight scales, f32 accumulation, f16 residual stream, f16 stem
+    // and heads -- and calibrated activation scales do not improve it (e4m3 keeps three mantissa bits wherever a scale puts the values:
+    // profiles/r03/fp8_calibration_study.txt; value error ~3e-2 with or without).  So `int8` is REFUSED rather than mapped to a mode
+    // with another accuracy contract; the e4m3 mode is an explicit opt-in under its own name.
+    else if (prec == "int8")
+        throw std::invalid_argument("unsupported precision 'int8': this back end has no calibrated INT8 mode (tensorrtapi.cpp:334-360); its 8-bit "
+                                    "mode is e4m3 in the residual tower, value within ~3e-2 of fp32 -- select it explicitly with Precision fp8, "
+                                    "or use float16 / float16x3 / float32");
+    else if (prec == "fp8" || prec == "float8") {
         fp16_ = true;
         fp8_tower_ = true;
-        if (prec == "int8") {        // say so once per process: a user of the reference's calibrated INT8 gets a different 8-bit mode
-            static std::once_flag told;
-            std::call_once(told, [] {
-                fprintf(stderr, "info string Precision int8: running the e4m3 mode (\"fp8\": OCP e4m3 GEMM operands in the residual tower, no calibration "
-                                "file; value within ~3e-2 of fp32) -- TensorRT's calibrated INT8 kernels have no counterpart here\n");
-            });
-        }
     }
     else if (prec == "float32" || prec == "fp32") fp16_ = false;
     // the fast mode that meets "logits within 1e-3 of fp32": float activations, every dense contraction as three f16 MFMAs on split

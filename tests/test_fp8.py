@@ -86,7 +86,7 @@ def _predict(tmp_path, cfg, sd, x, precision, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp8", "fp8-3k", "int8"])
+@pytest.mark.parametrize("precision", ["fp8", "fp8-3k"])
 @pytest.mark.parametrize("identity", [True, False])
 def test_one_block_net_matches_the_emulation(tmp_path, hip_lib, precision, identity):
     cfg = ro.rise_v2_config(1, 34, 81)
@@ -251,3 +251,17 @@ def test_float16_tower_block_by_block_against_the_oracle(tmp_path, hip_lib):
         h_32 = ro.fp32_block(cfg, sd, i, h_in)
         err = (h_gpu - h_32).abs() - _f16_ulp(h_32)
         assert float(err.max()) < 3e-3 * max(1.0, float(h_32.abs().max())), (i, float(err.max()))
+
+
+def test_int8_is_refused_by_name(tmp_path, hip_lib):
+    """The reference's Precision int8 is TensorRT's entropy-calibrated INT8 (tensorrtapi.cpp:334-360, chessbatchstream.cpp:44-94).  This
+    back end has no calibrated 8-bit mode (calibration of its e4m3 mode was measured without gain, profiles/r03/fp8_calibration_study.txt),
+    so the name is refused -- loudly, naming the explicit opt-in -- instead of selecting a mode with another accuracy contract.  (The
+    precision is checked before the device is touched: the refusal is the same with and without a GPU.)"""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg = ro.rise_v2_config(1, 34, 81)
+    sd = ro.make_state_dict(cfg, seed=31, stress=True)
+    d = nn_cases.export_case(tmp_path, "int8-refused", cfg, sd)
+    with pytest.raises(ValueError) as e:
+        HipAPI(0, 4, d, "int8")
+    assert "int8" in str(e.value) and "fp8" in str(e.value) and "calibrated" in str(e.value)

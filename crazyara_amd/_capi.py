@@ -51,6 +51,7 @@ SIGNATURES = {
     "mi_pos_move_to_uci": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_int]),
     "mi_pos_do_move": (C.c_int, [C.c_void_p, C.c_uint32]),
     "mi_pos_terminal": (C.c_int, [C.c_void_p]),
+    "mi_pos_game_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mi_pos_number_repetitions": (C.c_int, [C.c_void_p]),
     "mi_pos_in_check": (C.c_int, [C.c_void_p]),
     "mi_pos_insufficient_material": (C.c_int, [C.c_void_p]),
@@ -115,6 +116,8 @@ SIGNATURES = {
     "mi_policy_apply_temperature": (None, [C.POINTER(C.c_double), C.c_int, C.c_double]),
     "mi_policy_get_quantile": (C.c_double, [C.POINTER(C.c_double), C.c_int, C.c_double]),
     "mi_policy_apply_quantile_clipping": (None, [C.POINTER(C.c_double), C.c_int, C.c_double]),
+    "mi_policy_sharpen_distribution": (None, [C.POINTER(C.c_double), C.c_int, C.c_double]),
+    "mi_selfplay_set_phase_exporter": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mi_search_tree_dump": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_long]),
     "mi_search_debug_replay": (C.c_long, [C.c_void_p, C.c_char_p, C.c_long]),
 }

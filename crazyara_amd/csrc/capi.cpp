@@ -123,6 +123,10 @@ void* mi_net_block_dump(mi_net* net, int* n_tiles) {
 }
 // development hook (not in the public header): device pointer to the value head's [B][8] stage checksums, null unless the process
 // runs with CRA_VALUE_HEAD_DEBUG (scripts/lane_divergence.py)
+int mi_dev_launch_op(mi_net* net, int op, int iters) {       // development hook: one op of the forward, `iters` times, no wait
+    if (!net) { g_err = "null net"; return 1; }
+    return guard([&] { net->net.dev_launch_op(op, iters); });
+}
 void* mi_dev_value_head_debug(mi_net* net) { return net ? static_cast<void*>(net->net.value_head_debug()) : nullptr; }
 int mi_net_forward_device(mi_net* net) {
     if (!net) { g_err = "null net"; return 1; }

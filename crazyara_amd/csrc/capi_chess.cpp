@@ -82,6 +82,12 @@ int mi_pos_move_to_san(const mi_pos* pos, uint32_t move, char* buf, int cap) {
     return n;
 }
 
+int mi_pos_game_phase(const mi_pos* pos, int num_phases, int definition) {
+    if (!pos || num_phases < 1) return -1;
+    int phase = -1;
+    cra_guard([&] { phase = pos->pos.game_phase(unsigned(num_phases), definition); });
+    return phase;
+}
 int mi_pos_insufficient_material(const mi_pos* pos) { return pos && pos->pos.draw_by_insufficient_material() ? 1 : 0; }
 int mi_pos_plies_from_null(const mi_pos* pos) { return pos ? pos->pos.plies_from_null() : 0; }
 int mi_pos_in_check(const mi_pos* pos) { return pos && pos->pos.checkers() != 0 ? 1 : 0; }

@@ -40,6 +40,13 @@ void mi_selfplay_default_settings(mi_selfplay_settings* m) {
     m->reuse_tree = d.reuse_tree ? 1 : 0;
     m->max_plies = d.max_plies;
     m->seed = d.seed;
+    m->quick_search_probability = float(d.quick_search_probability);
+    m->quick_search_nodes = d.quick_search_nodes;
+    m->quick_search_q_value_weight = float(d.quick_search_q_value_weight);
+    m->quick_dirichlet_epsilon = float(d.quick_dirichlet_epsilon);
+    m->low_policy_clip_threshold = float(d.low_policy_clip_threshold);
+    m->num_phases = d.num_phases;
+    m->game_phase_definition = d.game_phase_definition;
 }
 
 mi_selfplay* mi_selfplay_create(mi_search* pool_a, mi_search* pool_b, const mi_selfplay_settings* m, int concurrent, const char* variant,
@@ -63,6 +70,13 @@ mi_selfplay* mi_selfplay_create(mi_search* pool_a, mi_search* pool_b, const mi_s
         s.reuse_tree = m->reuse_tree != 0;
         s.max_plies = m->max_plies;
         s.seed = m->seed;
+        s.quick_search_probability = m->quick_search_probability;
+        s.quick_search_nodes = m->quick_search_nodes;
+        s.quick_search_q_value_weight = m->quick_search_q_value_weight;
+        s.quick_dirichlet_epsilon = m->quick_dirichlet_epsilon;
+        s.low_policy_clip_threshold = m->low_policy_clip_threshold;
+        s.num_phases = m->num_phases;
+        s.game_phase_definition = m->game_phase_definition;
         const chess::Variant v = chess::variant_from_name(variant && *variant ? variant : "chess");
         std::unique_ptr<mi_selfplay> sp(new mi_selfplay);
         if (pool_b) {
@@ -87,6 +101,14 @@ int mi_selfplay_set_start_fens(mi_selfplay* sp, const char* fens) {
         while (std::getline(ss, line)) list.push_back(line);
         if (sp->self) sp->self->set_start_fens(std::move(list));
         else sp->arena->set_start_fens(std::move(list));
+    });
+}
+
+int mi_selfplay_set_phase_exporter(mi_selfplay* sp, int phase, mi_traindata* exporter) {
+    if (!sp || !exporter) { cra_set_error("null argument"); return 1; }
+    return cra_guard([&] {
+        if (!sp->self) throw std::invalid_argument("an arena does not export training samples");
+        sp->self->set_phase_exporter(phase, &exporter->exp);
     });
 }
 
@@ -136,6 +158,8 @@ int mi_selfplay_get_stats(mi_selfplay* sp, mi_selfplay_stats* out) {
         out->reserved = 0;
         out->run_seconds = st.run_seconds;
         out->move_seconds = st.move_seconds;
+        out->quick_searches = st.quick_searches;
+        out->samples_dropped = st.samples_dropped;
     });
 }
 
@@ -145,6 +169,11 @@ void mi_policy_apply_temperature(double* p, int n, double temperature) {
     std::copy(v.begin(), v.end(), p);
 }
 double mi_policy_get_quantile(const double* p, int n, double quantile) { return rl::get_quantile(std::vector<double>(p, p + n), quantile); }
+void mi_policy_sharpen_distribution(double* p, int n, double thresh) {
+    std::vector<double> v(p, p + n);
+    rl::sharpen_distribution(v, thresh);
+    std::copy(v.begin(), v.end(), p);
+}
 void mi_policy_apply_quantile_clipping(double* p, int n, double quantile) {
     std::vector<double> v(p, p + n);
     rl::apply_quantile_clipping(quantile, v);

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <sstream>
@@ -766,6 +767,59 @@ TerminalType Position::is_terminal(size_t n_legal) const {          // boardstat
     }
     if (can_claim_3fold_repetition() || is_50_move_rule_draw(n_legal) || draw_by_insufficient_material()) return TERMINAL_DRAW;
     return TERMINAL_NONE;
+}
+
+// ---- game phase (training-data exporter choice of self-play, selfplay.cpp:232-238) ----
+bool Position::backrank_sparse() const {                       // three or fewer pieces left on either side's own first rank
+    return popcount(by_color_[WHITE] & 0xffull) <= 3 || popcount(by_color_[BLACK] & (0xffull << 56)) <= 3;
+}
+
+// Mixedness of the Divider: every 2x2 window of the board (lower-left corner on ranks 1-7, files a-g) scores by how many white and
+// black pieces it holds and how far up the board it sits.  The score of a window is `base + slope term`, tabulated by (white, black)
+// count; y = rank of the window's lower row, 1-based.
+int Position::mixedness() const {
+    auto window_score = [](int w, int b, int y) -> int {
+        switch (w * 5 + b) {
+            case 1 * 5 + 0: return 1 + (8 - y);
+            case 2 * 5 + 0: return 2 + std::max(y - 2, 0);
+            case 3 * 5 + 0: return 3 + std::max(y - 1, 0);
+            case 4 * 5 + 0: return 3 + std::max(y - 1, 0);
+            case 0 * 5 + 1: return 1 + y;
+            case 1 * 5 + 1: return 5 + std::abs(3 - y);
+            case 2 * 5 + 1: return 4 + y;
+            case 3 * 5 + 1: return 5 + y;
+            case 0 * 5 + 2: return 2 + std::max(6 - y, 0);
+            case 1 * 5 + 2: return 4 + (6 - y);
+            case 2 * 5 + 2: return 7;
+            case 0 * 5 + 3: return 3 + std::max(7 - y, 0);
+            case 1 * 5 + 3: return 5 + (6 - y);
+            case 0 * 5 + 4: return 3 + std::max(7 - y, 0);
+            default: return 0;
+        }
+    };
+    int mix = 0;
+    for (int r = 0; r < 7; ++r)
+        for (int f = 0; f < 7; ++f) {
+            const Bitboard window = (Bitboard(0x303) << (r * 8 + f));          // squares (f, r), (f+1, r), (f, r+1), (f+1, r+1)
+            mix += window_score(popcount(by_color_[WHITE] & window), popcount(by_color_[BLACK] & window), r + 1);
+        }
+    return mix;
+}
+
+int Position::game_phase(unsigned num_phases, int definition) const {
+    if (definition == 0) {                                     // lichess: three phases whatever num_phases says (the reference only asserts it)
+        const int mm = majors_and_minors();
+        if (mm <= 6) return 2;
+        if (mm <= 10 || backrank_sparse() || mixedness() > 150) return 1;
+        return 0;
+    }
+    if (definition == 1) {                                     // movecount
+        if (num_phases <= 1) return 0;
+        const double phase_length = std::round(42.85 / double(num_phases));
+        const double g = double(size_t(game_ply_ / 2)) / phase_length;        // total_move_cout() = gamePly / 2 (board.cpp:127-130)
+        return g > double(num_phases - 1) ? int(num_phases - 1) : int(g);
+    }
+    return 0;
 }
 
 uint64_t Position::perft(int depth) const {

@@ -112,6 +112,14 @@ public:
     bool draw_by_insufficient_material() const;
     TerminalType is_terminal(size_t n_legal) const;
 
+    // Board::get_phase (board.cpp:540-587) with its helpers get_majors_and_minors_count / is_backrank_sparse / get_mixedness
+    // (board.cpp:446-538; the lichess / scalachess Divider): definition 0 = lichess (three phases: opening 0, middlegame 1, endgame 2),
+    // 1 = movecount (num_phases equal slices of an average game of 42.85 moves).  One phase: always 0.
+    int game_phase(unsigned num_phases, int definition) const;
+    int majors_and_minors() const { return popcount(by_type_[QUEEN] | by_type_[ROOK] | by_type_[KNIGHT] | by_type_[BISHOP]); }
+    bool backrank_sparse() const;
+    int mixedness() const;
+
     uint64_t perft(int depth) const;
 
 private:

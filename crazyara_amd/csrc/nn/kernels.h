@@ -277,6 +277,9 @@ struct ValueHeadArgs {
     // weights, conv output, FC1 partial sums, FC2 sum, value -- each added up in a fixed order: equal inputs give equal bits
     float* dbg;
     int lds_pad;            // development: extra dynamic LDS per workgroup (keeps other workgroups off the CU)
+    int variant;            // development (CRA_VALUE_HEAD_VARIANT): 1 = FC1 partial sums in LDS of their own (not over the dead board tile),
+                            // 2 = FC1 accumulators pinned per step (no packed f32 FMAs), 4 = s_waitcnt vmcnt(0) behind every group of 32 weight
+                            // loads, 8 = weight loads non-temporal
 };
 template <typename T> void prepare_value_head(const ValueHeadArgs& a);   // once per net: LDS allowance of the kernel
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s);

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
 
     // FC1 + ReLU + FC2: thread = (four consecutive outputs, quarter of the inputs): a row of the transposed matrix is one 16-byte load per
     // lane (a wave reads 1 KiB), 32 of them in flight; the quarters' partial sums meet in LDS (the staged board is dead by now)
-    float* s_part = xs;                                         // [4 quarters][fc]
+    float* s_part = (a.variant & 1) ? s_red + 8 : xs;           // [4 quarters][fc]
     float part = 0.f;
     const int kq = tid >> 6, nq = nf / 4;
     for (int j4 = tid & 63; 4 * j4 < a.fc; j4 += 64) {
@@ -497,7 +497,11 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
         for (; i + 32 <= nq; i += 32) {
             f32x4 w[32];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) w[j] = *reinterpret_cast<const f32x4*>(wt + size_t(i + j) * a.fc);
+            for (int j = 0; j < 32; ++j) {
+                if (a.variant & 8) w[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wt + size_t(i + j) * a.fc));
+                else w[j] = *reinterpret_cast<const f32x4*>(wt + size_t(i + j) * a.fc);
+            }
+            if (a.variant & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (development) every load back before the first product
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const f32x4 f = *reinterpret_cast<const f32x4*>(fl + i + 4 * q);
@@ -507,6 +511,7 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
                     h[1] = fmaf(w[4 * q + e][1], f[e], h[1]);
                     h[2] = fmaf(w[4 * q + e][2], f[e], h[2]);
                     h[3] = fmaf(w[4 * q + e][3], f[e], h[3]);
+                    if (a.variant & 2) asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
                 }
             }
         }
@@ -528,6 +533,7 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
         float p_sum = 0.f;
         for (int i = tid; i < 4 * a.fc; i += 256) p_sum += s_part[i];
         const float s_p = block_sum_256(p_sum, s_red);
+        for (int i = tid; i < 4 * a.fc && i < 1024; i += 256) a.dbg[size_t(a.batch) * 8 + size_t(b) * 1024 + i] = s_part[i];   // the partial sums themselves
         if (tid == 0) {
             float* o = a.dbg + size_t(b) * 8;
             o[3] = s_p;
@@ -582,7 +588,7 @@ template void launch_value_final<half_t>(const ValueFinalArgs&, hipStream_t);
 template void launch_value_final<float>(const ValueFinalArgs&, hipStream_t);
 
 static size_t value_head_lds_bytes(const ValueHeadArgs& a) {
-    return (size_t(kSquares) * (a.C / 2 + 4) + size_t(a.cv) * a.C + size_t(kSquares) * a.cv + 8) * sizeof(float) + size_t(a.lds_pad);
+    return (size_t(kSquares) * (a.C / 2 + 4) + size_t(a.cv) * a.C + size_t(kSquares) * a.cv + 8 + ((a.variant & 1) ? 4 * a.fc : 0)) * sizeof(float) + size_t(a.lds_pad);
 }
 // once per net, outside any stream capture: the kernel's dynamic LDS allowance (the staged board is more than the default 64 KiB)
 template <typename T> void prepare_value_head(const ValueHeadArgs& a) {

@@ -73,6 +73,7 @@ public:
     // block (kernels.h: TowerArgs::block_dump).  Returns the device buffer [n_tiles][B][64][256] f16; throws when the net has no such
     // tower (or more than one run of blocks).
     void* enable_block_dump(int* n_tiles);
+    void dev_launch_op(int op, int iters);                        // development: op `op` of the forward `iters` times into the net's stream, no wait
     float* value_head_debug() const { return value_head_dbg_; }   // development: [B][8] stage checksums (CRA_VALUE_HEAD_DEBUG), else null
     float* d_aux() const { return d_aux_; }           // [B][nb_aux] or nullptr
     void forward_async();

@@ -1224,11 +1224,12 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
         macs += double(kSquares) * C * cv;
         if (getenv("CRA_VALUE_HEAD_DEBUG") != nullptr) {              // development: stage checksums of every launch (ValueHeadArgs::dbg)
-            v.dbg = static_cast<float*>(im.dalloc(size_t(B) * 8 * sizeof(float)));
-            HIP_CHECK(hipMemset(v.dbg, 0, size_t(B) * 8 * sizeof(float)));
+            v.dbg = static_cast<float*>(im.dalloc(size_t(B) * (8 + 1024) * sizeof(float)));
+            HIP_CHECK(hipMemset(v.dbg, 0, size_t(B) * (8 + 1024) * sizeof(float)));
             value_head_dbg_ = v.dbg;
         }
         if (const char* pad = getenv("CRA_VALUE_HEAD_LDS_PAD")) v.lds_pad = atoi(pad);
+        if (const char* var = getenv("CRA_VALUE_HEAD_VARIANT")) v.variant = atoi(var);
         prepare_value_head<T>(op.vh);
         im.ops.push_back(op);
     }
@@ -1400,6 +1401,15 @@ void RiseNet::time_ops(int iters, float* ms) {
                 fprintf(stderr, "\n");
             }
         }
+}
+
+void RiseNet::dev_launch_op(int op, int iters) {
+    HIP_CHECK(hipSetDevice(device_));
+    if (op < 0 || op >= int(impl_->ops.size())) throw std::invalid_argument("op index out of range");
+    for (int it = 0; it < iters; ++it) {
+        if (fp16_) launch_op<half_t>(op, stream_); else launch_op<float>(op, stream_);
+    }
+    HIP_CHECK(hipGetLastError());
 }
 
 float RiseNet::time_forward(int iters) {

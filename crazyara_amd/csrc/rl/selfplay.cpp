@@ -50,6 +50,13 @@ void apply_quantile_clipping(double quantile, std::vector<double>& p) {    // ag
     for (double& v : p) v /= sum;
 }
 
+void sharpen_distribution(std::vector<double>& p, double thresh) {          // blazeutil.h:94-105
+    if (p.empty() || *std::max_element(p.begin(), p.end()) < thresh) return;
+    double sum = 0;
+    for (double& v : p) { if (v < thresh) v = 0.0; sum += v; }
+    for (double& v : p) v /= sum;
+}
+
 namespace {
 size_t sample_index(std::mt19937_64& rng, const std::vector<double>& p) {   // random_choice: inverse CDF on a uniform draw
     double sum = 0;
@@ -102,6 +109,12 @@ SelfPlayDriver::SelfPlayDriver(search::SearchPool* pool, const SelfPlaySettings&
     if (!pool || concurrent < 1) throw std::invalid_argument("self-play needs a pool and at least one concurrent game");
     if (pool->n_trees() != 0) throw std::invalid_argument("the pool must be empty when the game loop takes it over");
     if (!s.simulations && !s.nodes) throw std::invalid_argument("self-play needs a simulations or a nodes budget");
+    if (s.num_phases < 1) throw std::invalid_argument("self-play needs at least one game phase");
+    if (s.game_phase_definition == 0 && s.num_phases != 1 && s.num_phases != 3)
+        throw std::invalid_argument("the lichess game-phase definition has three phases (board.cpp:544)");
+    if (s.game_phase_definition != 0 && s.game_phase_definition != 1) throw std::invalid_argument("game phase definition: 0 lichess, 1 movecount");
+    exporters_.assign(size_t(s.num_phases), nullptr);
+    exporters_[0] = exporter;
     games_.resize(size_t(concurrent));
     for (int slot = 0; slot < concurrent; ++slot) {
         const int t = pool->add_position(make_position("", is960, variant));
@@ -114,9 +127,13 @@ void SelfPlayDriver::finish(Game& g, int result, const char* why) {
     g.rec.result = result;
     g.rec.termination = why;
     if (exporter_) {                                                       // generate_game: samples are written once the result is known
-        exporter_->new_game();
-        for (const Game::Sample& sm : g.samples) exporter_->save_sample(sm.pos, sm.moves, sm.policy.data(), sm.policy.size(), sm.q);
-        stats_.samples += exporter_->export_game_samples(result > 0 ? WHITE_WIN : result < 0 ? BLACK_WIN : DRAWN);
+        // new_game on every exporter, every sample to the exporter of its phase, export_game_samples on every exporter (selfplay.cpp:204-206,
+        // 232-238,248-250).  The phase COLUMN of a sample is the position's phase under the definition, also with one exporter
+        // (save_cur_phase, traindataexporter.cpp:91-103).
+        for (TrainDataExporter* e : exporters_) e->new_game();
+        for (const Game::Sample& sm : g.samples)
+            exporters_[s_.num_phases > 1 ? size_t(sm.phase) : 0]->save_sample(sm.pos, sm.moves, sm.policy.data(), sm.policy.size(), sm.q, sm.phase);
+        for (TrainDataExporter* e : exporters_) stats_.samples += e->export_game_samples(result > 0 ? WHITE_WIN : result < 0 ? BLACK_WIN : DRAWN);
     }
     finished_.push_back(std::move(g.rec));
     // the slot's tree sits out the following runs until a new game takes it (a finished game's tree would otherwise be searched to the
@@ -201,27 +218,64 @@ void SelfPlayDriver::start_games(size_t n_games) {
     }
 }
 
+void SelfPlayDriver::set_phase_exporter(int phase, TrainDataExporter* exporter) {
+    if (phase < 1 || phase >= s_.num_phases) throw std::invalid_argument("phase exporter: phase out of range (phase 0 is the constructor's)");
+    if (!exporter_) throw std::invalid_argument("phase exporters need the phase-0 exporter");
+    exporters_[size_t(phase)] = exporter;
+}
+
+size_t SelfPlayDriver::sample_capacity() const { return exporter_ ? exporter_->get_number_samples() : 0; }
+
 size_t SelfPlayDriver::play(size_t n_games, int threads) {
     const auto t0 = std::chrono::steady_clock::now();
-    while (finished_.size() < n_games) {
-        // the export file is full (TrainDataExporter::is_file_full, traindataexporter.cpp:162-165): further games would have their
-        // samples dropped by the exporter, so generation ends here -- what SelfPlay::go(0) does by counting samples
-        // (generatedSamples < max_samples_per_iteration(), selfplay.cpp:374-377)
-        if (exporter_ && exporter_->is_file_full()) break;
-        start_games(n_games);
+    const bool until_full = n_games == 0;                                  // SelfPlay::go(0): `while (generatedSamples < max_samples_per_iteration())`
+    if (until_full && !exporter_) throw std::invalid_argument("self-play until the export file is full needs an exporter");
+    if (exporter_)
+        for (TrainDataExporter* e : exporters_)
+            if (!e) throw std::invalid_argument("self-play with several game phases needs an exporter for every phase (set_phase_exporter)");
+    // search settings of a normal and of a quick move (update_q_value_weight / update_dirichlet_epsilon, selfplay.cpp:217-222,184-190)
+    const search::SearchSettings normal = pool_->settings();
+    search::SearchSettings quick = normal;
+    quick.q_value_weight = float(s_.quick_search_q_value_weight);
+    quick.dirichlet_epsilon = float(s_.quick_dirichlet_epsilon);
+    const size_t capacity = sample_capacity();
+    for (;;) {
+        // go(N): N games; go(0): new games while the sample count is below the file's capacity -- running games are always played out
+        const size_t target = until_full ? (samples_taken_ < capacity ? started_ + size_t(concurrent_) : started_) : n_games;
+        if (!until_full && finished_.size() >= n_games) break;
+        start_games(target);
         std::vector<Game*> active;
         for (auto& g : games_) if (g) active.push_back(g.get());
         if (active.empty()) {
-            if (started_ >= n_games) break;
+            if (started_ >= target) break;
             continue;                                                      // every fresh game was over at once: refill again
         }
-        uint32_t sims = s_.simulations, nodes = s_.simulations ? 0 : s_.nodes;
-        if (s_.node_random_factor > 0 && s_.nodes) {                      // adjust_node_count (one draw per round)
-            const int span = int(double(s_.nodes) * s_.node_random_factor);
-            if (span > 0) {
-                sims = 0;
-                nodes = uint32_t(int(s_.nodes) + int(std::uniform_int_distribution<int>(0, span - 1)(active[0]->rng)) - span / 2);
-            }
+        // every game's limits and settings for THIS move (generate_game's loop head, selfplay.cpp:209-221): a draw for the jitter, a
+        // draw for the quick search, quick: nodes = quickSearchNodes + its Q weight and Dirichlet epsilon; then adjust_node_count
+        // (:146-152) on whichever node budget applies.  The simulations limit stays as configured (SearchLimits keeps it).
+        for (Game* g : active) {
+            const uint32_t rand_int = uint32_t(std::uniform_int_distribution<uint32_t>(0, 0x7fffffffu)(g->rng));      // rand()
+            g->quick = s_.quick_search_probability >= 0.01 && uniform01(g->rng) < s_.quick_search_probability;
+            uint64_t nodes = g->quick ? s_.quick_search_nodes : s_.nodes;
+            const uint64_t max_random = uint64_t(double(nodes) * s_.node_random_factor);
+            if (max_random != 0) nodes = nodes + (uint64_t(rand_int) % max_random) - max_random / 2;
+            uint32_t sims = s_.simulations;
+            if (g->quick && !nodes) nodes = 1;                                 // (a quick search without a node budget would be a normal one)
+            if (!sims && !nodes) nodes = 1;
+            pool_->set_tree_limits(g->slot, sims, uint32_t(nodes));
+            search::SearchSettings st = g->quick ? quick : normal;
+            st.seed = normal.seed + uint32_t(g->slot);
+            pool_->tree(g->slot).set_search_settings(st);
+            if (g->quick) ++stats_.quick_searches;
+        }
+        const uint32_t sims = s_.simulations, nodes = s_.nodes ? s_.nodes : (s_.simulations ? 0u : 1u);
+        // which of this round's positions are exported (`!isQuickSearch && generatedSamples < max_samples_per_iteration()`, :224): decided
+        // in game order, the shared count is not touched from the parallel step
+        std::vector<char> take(active.size(), 0);
+        for (size_t gi = 0; gi < active.size(); ++gi) {
+            if (!exporter_ || active[gi]->quick) continue;
+            if (samples_taken_ < capacity) { take[gi] = 1; ++samples_taken_; }
+            else ++stats_.samples_dropped;
         }
         SearchStats st;
         const auto r0 = std::chrono::steady_clock::now();
@@ -254,7 +308,12 @@ size_t SelfPlayDriver::play(size_t n_games, int threads) {
                 pick = size_t(std::max_element(policy.begin(), policy.end()) - policy.begin());
             }
             const Move mv = t.root().actions[pick];
-            if (exporter_) g.samples.push_back(Game::Sample{g.pos, t.root().actions, policy, pl.best_q});   // save_sample before the move
+            if (take[size_t(gi)]) {                                        // save_sample before the move (selfplay.cpp:225-240)
+                std::vector<double> exported(policy);
+                if (s_.low_policy_clip_threshold > 0) sharpen_distribution(exported, s_.low_policy_clip_threshold);   // the move was picked from the unsharpened policy
+                g.samples.push_back(Game::Sample{g.pos, t.root().actions, std::move(exported), pl.best_q,
+                                                 g.pos.game_phase(unsigned(s_.num_phases), s_.game_phase_definition)});
+            }
             pl.uci = g.pos.move_to_uci(mv);
             pl.san = g.pos.move_to_san(mv);
             g.pos.do_move(mv);
@@ -274,12 +333,14 @@ size_t SelfPlayDriver::play(size_t n_games, int threads) {
             ++stats_.moves;
             g.rec.san.push_back(mark_mate(pl.san, pl.term));               // play_move_and_update
             g.rec.uci.push_back(pl.uci);
-            if (pl.term != chess::TERMINAL_NONE) {
-                finish(g, result_for_white(g.pos, pl.term), "terminal");
+            // check_for_resignation runs AFTER play_move_and_update and overwrites its verdict (selfplay.cpp:241-243,168-182): a mover whose
+            // best move scores below the threshold has resigned even when that move ended the game on the board
+            if (g.allow_resign && pl.best_q < s_.resign_threshold) {       // (after the move: the side to move wins)
+                finish(g, g.pos.side_to_move() == chess::WHITE ? 1 : -1, "resignation");
                 continue;
             }
-            if (g.allow_resign && pl.best_q < s_.resign_threshold) {       // check_for_resignation (after the move: side to move wins)
-                finish(g, g.pos.side_to_move() == chess::WHITE ? 1 : -1, "resignation");
+            if (pl.term != chess::TERMINAL_NONE) {
+                finish(g, result_for_white(g.pos, pl.term), "terminal");
                 continue;
             }
             if (int(g.rec.uci.size()) >= s_.max_plies) {

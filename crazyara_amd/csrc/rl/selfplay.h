@@ -41,6 +41,19 @@ struct SelfPlaySettings {
     bool reuse_tree = true;                 // RLSettings::reuseTreeForSelpay
     int max_plies = 600;                    // safety net: adjudicated as a draw
     uint64_t seed = 1;
+    // quick searches (is_quick_search, selfplay.cpp:154-159; :213-221): with this probability a move is searched with quick_search_nodes
+    // nodes, its own Q-value weight and Dirichlet epsilon, and its position is NOT exported (:224); below 0.01 = never
+    double quick_search_probability = 0.0;  // RLSettings::quickSearchProbability (Centi_Quick_Probability)
+    uint32_t quick_search_nodes = 100;      // RLSettings::quickSearchNodes (Quick_Nodes)
+    double quick_search_q_value_weight = 0.7;   // RLSettings::quickSearchQValueWeight (Centi_Quick_Q_Value_Weight)
+    double quick_dirichlet_epsilon = 0.0;   // RLSettings::quickDirichletEpsilon (Centi_Quick_Dirichlet_Epsilon)
+    // sharpen_distribution on the EXPORTED policy (blazeutil.h:94-105, selfplay.cpp:229-231): entries below the threshold are zeroed and
+    // the rest renormalised, unless the largest entry is itself below it; 0 = off (Milli_Policy_Clip_Thresh)
+    double low_policy_clip_threshold = 0.0;
+    // game phases (MCTSAgent::get_num_phases, SearchSettings::gamePhaseDefinition): with more than one phase a sample goes to the
+    // exporter of its position's phase (selfplay.cpp:232-238); definition 0 = lichess (1 or 3 phases), 1 = movecount
+    int num_phases = 1;
+    int game_phase_definition = 0;
 };
 
 struct GameRecord {
@@ -54,6 +67,8 @@ struct GameRecord {
 
 struct LoopStats {
     uint64_t moves = 0, nodes = 0, nn_evals = 0, kept_subtrees = 0, restarts = 0, samples = 0;
+    uint64_t quick_searches = 0;            // moves searched in quick mode (their positions were not exported)
+    uint64_t samples_dropped = 0;           // searched positions that found their export file full (generatedSamples >= max_samples_per_iteration)
     double seconds = 0;
     double run_seconds = 0, move_seconds = 0;      // inside SearchPool::run / inside the parallel move step
 };
@@ -62,6 +77,7 @@ struct LoopStats {
 void apply_temperature(std::vector<double>& p, double t);
 double get_quantile(const std::vector<double>& p, double quantile);
 void apply_quantile_clipping(double quantile, std::vector<double>& p);
+void sharpen_distribution(std::vector<double>& p, double thresh);          // blazeutil.h:94-105
 
 class SelfPlayDriver {
 public:
@@ -70,7 +86,12 @@ public:
                    TrainDataExporter* exporter);
     // game i starts from start_fens[i % size] ("" = the variant's start position); default: always the start position
     void set_start_fens(std::vector<std::string> fens) { start_fens_ = std::move(fens); }
-    // plays until n_games are finished in total (over all calls); returns that total
+    // one more exporter per further game phase (phase 0 = the constructor's): SelfPlay's `exporters` (selfplay.cpp:115-125)
+    void set_phase_exporter(int phase, TrainDataExporter* exporter);
+    // n_games > 0: plays until n_games are finished in total (over all calls) -- SelfPlay::go(N): every game is played out, positions
+    // beyond the export file's capacity are searched and dropped (stats().samples_dropped);  n_games == 0: SelfPlay::go(0)
+    // (selfplay.cpp:374-377), games are started until the phase-0 export file is full, the running ones are played out.
+    // Returns the total of finished games.
     size_t play(size_t n_games, int threads);
     const std::vector<GameRecord>& finished() const { return finished_; }
     const LoopStats& stats() const { return stats_; }
@@ -84,7 +105,8 @@ private:
         bool allow_resign = false;
         bool in_opening = false;
         int opening_left = 0;
-        struct Sample { chess::Position pos; std::vector<chess::Move> moves; std::vector<double> policy; float q; };
+        bool quick = false;                 // this move's search is a quick one
+        struct Sample { chess::Position pos; std::vector<chess::Move> moves; std::vector<double> policy; float q; int phase; };
         std::vector<Sample> samples;
     };
     void start_games(size_t n_games);
@@ -95,7 +117,10 @@ private:
     int concurrent_;
     chess::Variant variant_;
     bool is960_;
-    TrainDataExporter* exporter_;
+    TrainDataExporter* exporter_;           // phase 0
+    std::vector<TrainDataExporter*> exporters_;      // by phase; [0] == exporter_
+    size_t samples_taken_ = 0;              // generatedSamples: positions accepted for export so far (buffered in their games or written)
+    size_t sample_capacity() const;         // max_samples_per_iteration() = the export file's capacity
     std::vector<std::string> start_fens_;
     std::vector<std::unique_ptr<Game>> games_;
     std::vector<GameRecord> finished_;

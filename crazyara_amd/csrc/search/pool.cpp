@@ -475,17 +475,20 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         if (halted()) return true;
         const Tree& t = *trees_[id];
         if (t.root().terminal || t.root_solved()) return true;      // is_root_node_unsolved(), searchthread.cpp:333-340
-        return tree_done(t, simulations, nodes);
+        uint32_t sims_t = simulations, nodes_t = nodes;
+        limits_of(id, sims_t, nodes_t);
+        return tree_done(t, sims_t, nodes_t);
     };
 
     double t_par = 0, t_submit = 0, t_item_max = 0, t_item_sum = 0, t_wait = 0;
     const bool timing = getenv("CRA_POOL_TIMING") != nullptr;
     std::atomic<bool> gather_overflow{false};
     // simulations / nodes the tree still lacks (>= 1 for a tree that is not done)
-    auto remaining_need = [&](const Tree& t) -> int {
-        uint32_t need = 0xffffffffu;
-        if (simulations) need = std::min(need, simulations > t.root_visits() ? simulations - t.root_visits() : 1u);
-        if (nodes) need = std::min(need, nodes > t.node_count() ? nodes - t.node_count() : 1u);
+    auto remaining_need = [&](const Tree& t, int tree_id) -> int {
+        uint32_t need = 0xffffffffu, sims_t = simulations, nodes_t = nodes;
+        limits_of(tree_id, sims_t, nodes_t);
+        if (sims_t) need = std::min(need, sims_t > t.root_visits() ? sims_t - t.root_visits() : 1u);
+        if (nodes_t) need = std::min(need, nodes_t > t.node_count() ? nodes_t - t.node_count() : 1u);
         return int(std::min<uint32_t>(need, 1u << 20));
     };
     // one tree's share of a batch: leaves into its slots; the policy indices of the new nodes' legal moves go straight into the
@@ -496,7 +499,7 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         Tree& tree = item_tree(id);
         const int ctx = item_ctx(id);
         int take = lane.slot_count[i];
-        if (adaptive_cap_ > 0 && shared_k_ == 0) take = std::min(take, remaining_need(tree));   // no overshoot beyond the limit
+        if (adaptive_cap_ > 0 && shared_k_ == 0) take = std::min(take, remaining_need(tree, items_[size_t(id)].tree));   // no overshoot beyond the limit
         lane.n_new[i] = tree.collect(take, ev.descs() + lane.slot_begin[i], ctx);
         if (gstride) {
             for (int k = 0; k < lane.slot_count[i]; ++k) {

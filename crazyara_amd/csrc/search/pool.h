@@ -129,6 +129,14 @@ public:
     // other trees.  With the absolute limits of tree reuse the trees of a round need very different numbers of simulations; the fixed
     // quota then ends a round with mostly empty batches for the one tree that needs the most.
     void set_adaptive_quota(int cap) { adaptive_cap_ = cap < 0 ? 0 : cap; }
+    // Per-tree limits for the following runs, replacing run()'s simulations / nodes for that tree (both 0 = back to run()'s): the
+    // concurrent games of a self-play loop search with their own node budgets -- quick searches and the per-move node jitter of
+    // SelfPlay::generate_game (selfplay.cpp:146-152,213-221), which the reference sets on its one SearchLimits before every move.
+    void set_tree_limits(int i, uint32_t simulations, uint32_t nodes) {
+        (void)trees_.at(size_t(i));
+        if (tree_limits_.size() < trees_.size()) tree_limits_.resize(trees_.size(), {0u, 0u});
+        tree_limits_[size_t(i)] = {simulations, nodes};
+    }
     int adaptive_quota() const { return adaptive_cap_; }
     int n_trees() const { return int(trees_.size()); }
     size_t debug_replay(std::string* report) {                   // Evaluator::debug_replay of every lane (between runs)
@@ -149,6 +157,14 @@ private:
         bool same_trees_next = false;      // the next batch can keep this batch's trees and slots (no rotation, no tree finished)
     };
     bool tree_done(const Tree& t, uint32_t simulations, uint32_t nodes) const;
+    // the limits tree `id` searches under: its own (set_tree_limits) or the run's
+    void limits_of(int id, uint32_t& simulations, uint32_t& nodes) const {
+        if (size_t(id) < tree_limits_.size() && (tree_limits_[size_t(id)].first || tree_limits_[size_t(id)].second)) {
+            simulations = tree_limits_[size_t(id)].first;
+            nodes = tree_limits_[size_t(id)].second;
+        }
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> tree_limits_;
     void evaluate_roots(uint64_t* evals, uint64_t* batches);
     void rebuild_items();
     Tree& item_tree(int item) { return *trees_[size_t(items_[size_t(item)].tree)]; }

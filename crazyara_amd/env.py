@@ -97,6 +97,10 @@ class Position:
     def terminal(self) -> int:
         return self._lib.mi_pos_terminal(self._h)
 
+    def game_phase(self, num_phases: int = 3, definition: int = 0) -> int:
+        """Board::get_phase (board.cpp:540-587): definition 0 lichess (0 / 1 / 2), 1 movecount."""
+        return self._lib.mi_pos_game_phase(self._h, int(num_phases), int(definition))
+
     def in_check(self) -> bool:
         return bool(self._lib.mi_pos_in_check(self._h))
 

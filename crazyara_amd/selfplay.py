@@ -46,6 +46,13 @@ class SelfPlaySettings:
     reuse_tree: bool = True             # RLSettings::reuseTreeForSelpay
     max_plies: int = 600                # safety net: adjudicated as a draw
     seed: int = 1
+    quick_search_probability: float = 0.0   # RLSettings::quickSearchProbability: a move searched quickly is not exported (:154-159,213-224)
+    quick_search_nodes: int = 100           # RLSettings::quickSearchNodes
+    quick_search_q_value_weight: float = 0.7    # RLSettings::quickSearchQValueWeight
+    quick_dirichlet_epsilon: float = 0.0    # RLSettings::quickDirichletEpsilon
+    low_policy_clip_threshold: float = 0.0  # RLSettings::lowPolicyClipThreshold: sharpen_distribution on the exported policy (:229-231)
+    num_phases: int = 1                 # MCTSAgent::get_num_phases: > 1 = one exporter per game phase (:232-238)
+    game_phase_definition: int = 0      # SearchSettings::gamePhaseDefinition: 0 lichess, 1 movecount (board.cpp:540-587)
     event: str = "SelfPlay"
     white: str = "crazyara-amd"
     black: str = "crazyara-amd"
@@ -116,14 +123,17 @@ class SelfPlaySettingsC(C.Structure):
                 ("max_init_ply", C.c_int), ("raw_policy_prob_temperature", C.c_float), ("init_temperature", C.c_float),
                 ("temperature_moves", C.c_int), ("temperature_decay", C.c_float), ("quantile_clipping", C.c_float),
                 ("resign_probability", C.c_float), ("resign_threshold", C.c_float), ("reuse_tree", C.c_int), ("max_plies", C.c_int),
-                ("seed", C.c_ulonglong)]
+                ("seed", C.c_ulonglong), ("quick_search_probability", C.c_float), ("quick_search_nodes", C.c_uint),
+                ("quick_search_q_value_weight", C.c_float), ("quick_dirichlet_epsilon", C.c_float), ("low_policy_clip_threshold", C.c_float),
+                ("num_phases", C.c_int), ("game_phase_definition", C.c_int)]
 
 
 class SelfPlayStatsC(C.Structure):
     """mi_selfplay_stats"""
     _fields_ = [("moves", C.c_ulonglong), ("nodes", C.c_ulonglong), ("nn_evals", C.c_ulonglong), ("kept_subtrees", C.c_ulonglong),
                 ("restarts", C.c_ulonglong), ("samples", C.c_ulonglong), ("seconds", C.c_double), ("wins", C.c_int), ("draws", C.c_int),
-                ("losses", C.c_int), ("reserved", C.c_int), ("run_seconds", C.c_double), ("move_seconds", C.c_double)]
+                ("losses", C.c_int), ("reserved", C.c_int), ("run_seconds", C.c_double), ("move_seconds", C.c_double),
+                ("quick_searches", C.c_ulonglong), ("samples_dropped", C.c_ulonglong)]
 
 
 def _settings_c(lib, s: SelfPlaySettings) -> SelfPlaySettingsC:
@@ -207,13 +217,19 @@ class SelfPlay(_NativeLoop):
                  start_fen: Optional[Callable[[int], str]] = None,
                  raw_policy: Optional[Callable[[Sequence[env.Position]], List[np.ndarray]]] = None,
                  exporter=None):
+        exporters = list(exporter) if isinstance(exporter, (list, tuple)) else [exporter]       # one per game phase (num_phases > 1)
+        exporter = exporters[0]
         super().__init__(pool, None, settings, concurrent, start_fen, exporter)
+        for phase, e in enumerate(exporters[1:], start=1):
+            if self._lib.mi_selfplay_set_phase_exporter(self._h, phase, e._h):
+                raise ValueError(_capi.last_error())
+        self._phase_exporters = exporters
         self.pool, self.exporter = pool, exporter
         self.finished: List[GameRecord] = []
         self.stats = dict(moves=0, nodes=0, nn_evals=0, seconds=0.0, kept_subtrees=0, restarts=0)
 
     def play(self, n_games: int, threads: int = 16) -> List[GameRecord]:
-        self._send_fens(n_games)
+        self._send_fens(n_games or 1024)
         total = self._run(n_games, threads)
         s = self.s
         while self._read < total:
@@ -224,9 +240,10 @@ class SelfPlay(_NativeLoop):
         st = self._stats()
         self.stats.update(moves=st.moves, nodes=st.nodes, nn_evals=st.nn_evals, seconds=st.seconds, kept_subtrees=st.kept_subtrees,
                           restarts=st.restarts, run_seconds=st.run_seconds, move_seconds=st.move_seconds)
+        self.stats.update(quick_searches=st.quick_searches, samples_dropped=st.samples_dropped)
         if self.exporter is not None:
             self.stats["samples"] = st.samples
-        return self.finished[:n_games]
+        return self.finished[:n_games] if n_games else self.finished
 
 
 def net_raw_policy(net, mode: int, version_major: int, is_policy_map: bool = True):

@@ -131,6 +131,9 @@ int mi_pos_move_to_uci(const mi_pos* pos, uint32_t move, char* buf, int cap);  /
 int mi_pos_move_to_san(const mi_pos* pos, uint32_t move, char* buf, int cap);
 int mi_pos_do_move(mi_pos* pos, uint32_t move);                        /* do_action */
 int mi_pos_terminal(const mi_pos* pos);                                /* is_terminal(legal count) -> MI_TERMINAL_* */
+/* Board::get_phase (environments/chess_related/board.cpp:540-587): definition 0 = lichess (0 opening, 1 middlegame, 2 endgame; majors and
+ * minors, sparse back rank, mixedness of the Divider, board.cpp:446-538), 1 = movecount (num_phases slices of a 42.85-move game); -1 on error */
+int mi_pos_game_phase(const mi_pos* pos, int num_phases, int definition);
 int mi_pos_number_repetitions(const mi_pos* pos);
 int mi_pos_insufficient_material(const mi_pos* pos);                  /* Board::draw_by_insufficient_material (board.cpp:175-221) */
 int mi_pos_plies_from_null(const mi_pos* pos);                        /* State::steps_from_null (boardstate.h) */
@@ -353,6 +356,15 @@ typedef struct mi_selfplay_settings {
     int reuse_tree;                       /* RLSettings::reuseTreeForSelpay */
     int max_plies;                        /* safety net: adjudicated as a draw */
     unsigned long long seed;
+    /* quick searches (SelfPlay::is_quick_search, rl/selfplay.cpp:154-159,213-221): with this probability (< 0.01 = never) a move is
+     * searched with quick_search_nodes nodes, its own Q-value weight and Dirichlet epsilon; its position is not exported */
+    float quick_search_probability;       /* RLSettings::quickSearchProbability   (Centi_Quick_Probability / 100) */
+    unsigned quick_search_nodes;          /* RLSettings::quickSearchNodes         (Quick_Nodes) */
+    float quick_search_q_value_weight;    /* RLSettings::quickSearchQValueWeight  (Centi_Quick_Q_Value_Weight / 100) */
+    float quick_dirichlet_epsilon;        /* RLSettings::quickDirichletEpsilon    (Centi_Quick_Dirichlet_Epsilon / 100) */
+    float low_policy_clip_threshold;      /* RLSettings::lowPolicyClipThreshold: sharpen_distribution on the exported policy (0 = off) */
+    int num_phases;                       /* MCTSAgent::get_num_phases: > 1 = one exporter per game phase (mi_selfplay_set_phase_exporter) */
+    int game_phase_definition;            /* SearchSettings::gamePhaseDefinition: 0 lichess (1 or 3 phases), 1 movecount */
 } mi_selfplay_settings;
 typedef struct mi_selfplay_stats {
     unsigned long long moves, nodes, nn_evals, kept_subtrees, restarts, samples;
@@ -360,6 +372,8 @@ typedef struct mi_selfplay_stats {
     int wins, draws, losses;              /* arena: seen from the contender (pool A) */
     int reserved;
     double run_seconds, move_seconds;     /* of `seconds`: inside the pool's searches / inside the (parallel) move step of the games */
+    unsigned long long quick_searches;    /* moves searched in quick mode (not exported) */
+    unsigned long long samples_dropped;   /* searched positions that found the export file full (rl/selfplay.cpp:224) */
 } mi_selfplay_stats;
 void mi_selfplay_default_settings(mi_selfplay_settings* s);
 /* pool_b == NULL: self-play on pool_a (exporter: every searched position becomes a training sample, written game by game; may be NULL);
@@ -369,7 +383,13 @@ mi_selfplay* mi_selfplay_create(mi_search* pool_a, mi_search* pool_b, const mi_s
 void mi_selfplay_destroy(mi_selfplay* sp);
 /* start positions, '\n'-separated FENs ("" line = the variant's start position): game i (arena: pair i) uses entry i mod count */
 int mi_selfplay_set_start_fens(mi_selfplay* sp, const char* fens);
-/* plays until n_games are finished in total; returns that total, -1 on error */
+/* self-play with num_phases > 1: the exporter of game phase `phase` >= 1 (phase 0 is mi_selfplay_create's); every sample goes to the
+ * exporter of its position's phase (rl/selfplay.cpp:232-238, Board::get_phase, board.cpp:540-587) */
+int mi_selfplay_set_phase_exporter(mi_selfplay* sp, int phase, mi_traindata* exporter);
+/* n_games > 0: plays until n_games are finished in total (SelfPlay::go(N): every game is played out; positions beyond the export
+ * file's capacity are searched and dropped, mi_selfplay_stats::samples_dropped).  n_games == 0 (self-play with an exporter):
+ * SelfPlay::go(0), rl/selfplay.cpp:374-377 -- games are started until the export file is full, running games are played out.
+ * Returns the total of finished games, -1 on error */
 int mi_selfplay_play(mi_selfplay* sp, int n_games, int threads);
 /* finished game `index`: result +1 / 0 / -1 for White, plies from the opening book, whether the contender had White (arena), and as
  * text "start FEN\ntermination\nSAN moves separated by \t\nUCI moves separated by \t\n".  Returns the text's length (call with cap 0
@@ -381,6 +401,7 @@ int mi_selfplay_get_stats(mi_selfplay* sp, mi_selfplay_stats* out);
 void mi_policy_apply_temperature(double* p, int n, double temperature);
 double mi_policy_get_quantile(const double* p, int n, double quantile);
 void mi_policy_apply_quantile_clipping(double* p, int n, double quantile);
+void mi_policy_sharpen_distribution(double* p, int n, double thresh);            /* sharpen_distribution, util/blazeutil.h:94-105 */
 
 #ifdef __cplusplus
 }

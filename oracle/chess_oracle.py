@@ -585,6 +585,78 @@ class Board:
                 return TERMINAL_DRAW
         return TERMINAL_NONE
 
+    # ------------------------------------------------------------------------------------------------ game phase
+    # Board::get_phase (board.cpp:540-587) with get_majors_and_minors_count (:446-449), is_backrank_sparse (:451-458), score_region
+    # (:460-507) and get_mixedness (:509-538): the lichess Divider.  The phase column of the training samples
+    # (TrainDataExporter::save_cur_phase, traindataexporter.cpp:91-103) and the exporter choice of self-play (selfplay.cpp:232-238).
+    def majors_and_minors(self):
+        return sum(1 for p in self.b if p is not None and p.upper() in "QRNB")
+
+    def backrank_sparse(self):
+        white = sum(1 for s in range(0, 8) if self.b[s] is not None and self.b[s].isupper())
+        black = sum(1 for s in range(56, 64) if self.b[s] is not None and self.b[s].islower())
+        return white <= 3 or black <= 3
+
+    @staticmethod
+    def _score_region(w, b, rank):                        # rank 1-based (board.cpp:460-507), branch by branch
+        if (w, b) == (1, 0):
+            return 1 + (8 - rank)
+        if (w, b) == (2, 0):
+            return 2 + (rank - 2 if rank > 2 else 0)
+        if (w, b) in ((3, 0), (4, 0)):
+            return 3 + (rank - 1 if rank > 1 else 0)
+        if (w, b) == (0, 1):
+            return 1 + rank
+        if (w, b) == (1, 1):
+            return 5 + abs(3 - rank)
+        if (w, b) == (2, 1):
+            return 4 + rank
+        if (w, b) == (3, 1):
+            return 5 + rank
+        if (w, b) == (0, 2):
+            return 2 + (6 - rank if rank < 6 else 0)
+        if (w, b) == (1, 2):
+            return 4 + (6 - rank)
+        if (w, b) == (2, 2):
+            return 7
+        if (w, b) in ((0, 3), (0, 4)):
+            return 3 + (7 - rank if rank < 7 else 0)
+        if (w, b) == (1, 3):
+            return 5 + (6 - rank)
+        return 0
+
+    def mixedness(self):
+        mix = 0
+        for r in range(7):
+            for f in range(7):
+                w = b = 0
+                for dx in (0, 1):
+                    for dy in (0, 1):
+                        p = self.b[sq(f + dx, r + dy)]
+                        if p is not None:
+                            if p.isupper():
+                                w += 1
+                            else:
+                                b += 1
+                mix += self._score_region(w, b, r + 1)
+        return mix
+
+    def game_phase(self, num_phases: int, definition: int) -> int:
+        if definition == 0:                               # LICHESS (the reference only asserts num_phases == 3)
+            mm = self.majors_and_minors()
+            if mm <= 6:
+                return 2
+            if mm <= 10 or self.backrank_sparse() or self.mixedness() > 150:
+                return 1
+            return 0
+        if definition == 1:                               # MOVECOUNT
+            if num_phases == 1:
+                return 0
+            phase_length = float(round(42.85 / num_phases))          # std::round: half away from zero; never a tie for small counts
+            g = (self.ply // 2) / phase_length                      # total_move_cout() = gamePly / 2 (board.cpp:127-130)
+            return num_phases - 1 if g > num_phases - 1 else int(g)
+        return 0
+
     def perft(self, depth):
         moves = self.legal_moves()
         if depth <= 1:

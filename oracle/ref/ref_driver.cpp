@@ -472,6 +472,13 @@ void ref_apply_quantile_clipping(double* v, int n, float quantile) {
     for (int i = 0; i < n; ++i) v[i] = d[i];
 }
 
+void ref_sharpen_distribution(double* v, int n, float thresh) {       // blazeutil.h:94-105 (rl/selfplay.cpp:229-231)
+    blaze::DynamicVector<double> d{static_cast<size_t>(n)};
+    for (int i = 0; i < n; ++i) d[i] = v[i];
+    sharpen_distribution(d, thresh);
+    for (int i = 0; i < n; ++i) v[i] = d[i];
+}
+
 int ref_value_to_centipawn(float v) { return value_to_centipawn(v); }
 
 #ifdef REF_WITH_HIPAPI

@@ -78,6 +78,7 @@ def _declare(lib):
     lib.ref_get_quantile.restype = C.c_float
     lib.ref_get_quantile.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_float]
     lib.ref_apply_quantile_clipping.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_float]
+    lib.ref_sharpen_distribution.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_float]
     lib.ref_value_to_centipawn.restype = C.c_int
     lib.ref_value_to_centipawn.argtypes = [C.c_float]
 

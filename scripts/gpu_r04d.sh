@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 4, set b: the one-launch value head under a storm of concurrent predicts, stage checksums (scripts/lane_divergence.py dbg_*)
+OUT=$(pwd)/gpurun_out/r04d
+mkdir -p $OUT
+export TMPDIR=/tmp
+python __graft_entry__.py > $OUT/build.log 2>&1
+timeout 1200 python scripts/lane_divergence.py --configs big_default,big_own_lds,big_vmcnt0,big_nt_loads,big_alone_on_cu,big_default_again --out $OUT/lane_divergence.jsonl > $OUT/lane_divergence.log 2>&1
+tail -c 5000 $OUT/lane_divergence.log

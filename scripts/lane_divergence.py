@@ -40,6 +40,15 @@ CONFIGS = {
     "dbg_one_alone_on_cu": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_LDS_PAD": "100000"}, {"predicts": 20000, "runs": 0}),
     "dbg_one_hwq1": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "GPU_MAX_HW_QUEUES": "1"}, {"predicts": 20000, "runs": 0}),
     "storm_three": ({"CRA_X3_VALUE_HEAD": "three"}, {"predicts": 20000, "runs": 0}),
+    "dbg_one_own_lds": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "1"}, {"predicts": 20000, "runs": 0}),
+    "dbg_one_no_pk": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "2"}, {"predicts": 20000, "runs": 0}),
+    "one_no_dbg_storm": ({"CRA_X3_VALUE_HEAD": "one"}, {"predicts": 20000, "runs": 0}),
+    "big_default": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1"}, {"predicts": 80000, "runs": 0}),
+    "big_own_lds": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "1"}, {"predicts": 80000, "runs": 0}),
+    "big_vmcnt0": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "4"}, {"predicts": 80000, "runs": 0}),
+    "big_nt_loads": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "8"}, {"predicts": 80000, "runs": 0}),
+    "big_alone_on_cu": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_LDS_PAD": "100000"}, {"predicts": 80000, "runs": 0}),
+    "big_default_again": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1"}, {"predicts": 80000, "runs": 0}),
 }
 
 
@@ -83,7 +92,7 @@ def child(name, runs, predicts):
         for i, n in enumerate(nets):
             ptr = lib.mi_dev_value_head_debug(n._h)
             assert ptr, "no debug buffer: CRA_VALUE_HEAD_DEBUG must be set before the net is built"
-            dbg_view[i] = torch.as_tensor(_DevArray(ptr, (64, 8)), device="cuda")
+            dbg_view[i] = torch.as_tensor(_DevArray(ptr, (64 * (8 + 1024),)), device="cuda")
             n.predict(users[i].input_planes, users[i].value_outputs, users[i].prob_outputs)
             dbg_ref[i] = dbg_view[i].cpu().numpy().copy()
     stage_names = ["board", "conv_w", "conv_out", "fc1_parts", "fc2_sum", "value", "hw_id", "xcc_id"]
@@ -101,13 +110,19 @@ def child(name, runs, predicts):
                 bad[i][2] += int(dp)
                 worst[i] = max(worst[i], float(np.nanmax(np.abs(u.value_outputs - ref[i][0]))) if not np.isnan(u.value_outputs).any() else float("inf"))
                 if dv and dbg_view[i] is not None and len(dbg_events) < 40:
-                    got = dbg_view[i].cpu().numpy()
+                    raw = dbg_view[i].cpu().numpy()
+                    got = raw[:64 * 8].reshape(64, 8)
+                    parts, parts_ref = raw[64 * 8:].reshape(64, 1024), dbg_ref[i][64 * 8:].reshape(64, 1024)
+                    dbg_ref8 = dbg_ref[i][:64 * 8].reshape(64, 8)
                     for b in np.nonzero(u.value_outputs.view(np.uint32) != ref[i][0].view(np.uint32))[0]:
-                        diff = [stage_names[c] for c in range(6) if got[b, c].view(np.uint32) != dbg_ref[i][b, c].view(np.uint32)]
+                        wrong = np.nonzero(parts[b].view(np.uint32) != parts_ref[b].view(np.uint32))[0]
+                        diff = [stage_names[c] for c in range(6) if got[b, c].view(np.uint32) != dbg_ref8[b, c].view(np.uint32)]
                         dbg_events.append({"net": i, "board": int(b), "stages_that_differ": diff,
-                                           "got": [float(v) for v in got[b, :6]], "ref": [float(v) for v in dbg_ref[i][b, :6]],
+                                           "got": [float(v) for v in got[b, :6]], "ref": [float(v) for v in dbg_ref8[b, :6]],
+                                           "wrong_partial_sums": [int(w) for w in wrong[:64]], "n_wrong": int(len(wrong)),
+                                           "wrong_delta": [float(parts[b, w] - parts_ref[b, w]) for w in wrong[:16]],
                                            "hw_id": hex(int(got[b, 6].view(np.uint32))), "xcc_id": hex(int(got[b, 7].view(np.uint32))),
-                                           "ref_hw_id": hex(int(dbg_ref[i][b, 6].view(np.uint32))), "ref_xcc_id": hex(int(dbg_ref[i][b, 7].view(np.uint32))),
+                                           "ref_hw_id": hex(int(dbg_ref8[b, 6].view(np.uint32))), "ref_xcc_id": hex(int(dbg_ref8[b, 7].view(np.uint32))),
                                            "value": float(u.value_outputs[b]), "ref_value": float(ref[i][0][b])})
     th = [threading.Thread(target=loop, args=(i,)) for i in range(2)]
     t0 = time.time()

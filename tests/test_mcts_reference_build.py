@@ -271,6 +271,12 @@ def test_reference_helpers_worked_examples():
         mine = p.copy()
         hip.mi_policy_apply_quantile_clipping(dp(mine), n, quant)
         assert np.array_equal(mine, clipped)
+        # sharpen_distribution (blazeutil.h:94-105): the exported policy of self-play under lowPolicyClipThreshold
+        thresh = float(rng.choice([0.0, 0.01, 0.03, 0.1, 0.9]))
+        sharp_ref, sharp = p.copy(), p.copy()
+        lib.ref_sharpen_distribution(dp(sharp_ref), n, thresh)
+        hip.mi_policy_sharpen_distribution(dp(sharp), n, thresh)
+        assert np.array_equal(sharp, sharp_ref)
         temp = float(rng.choice([0.5, 1.0, 2.0, 10.0]))
         tp = p.copy()
         hip.mi_policy_apply_temperature(dp(tp), n, temp)

@@ -176,7 +176,10 @@ def test_training_samples_of_selfplay_games(hip_lib, tmp_path):
         for i, u in enumerate(g.uci[g.book_plies:]):
             assert np.array_equal(x[row], p.planes(mode, 1, False).astype(np.int16).reshape(34, 8, 8))
             stm = 1 if p.side_to_move() == 0 else -1
-            assert val[row] == stm * g.result and plys[row] == n - i and phase[row] == 0
+            # the phase column is the position's phase under the (default: lichess) definition, also with one exporter (save_cur_phase,
+            # traindataexporter.cpp:91-103) -- checked against the oracle board's restatement of Board::get_phase
+            ob = co.Board(p.fen(), False, variant)
+            assert val[row] == stm * g.result and plys[row] == n - i and phase[row] == ob.game_phase(1, 0)
             assert abs(float(pol[row].sum()) - 1.0) < 1e-5 and -1.0 <= q[row] <= 1.0
             legal_idx = {p.policy_index(m, mode, False) for m in p.legal_moves()}
             assert set(np.nonzero(pol[row])[0]) <= legal_idx       # probability only on labels of legal moves
@@ -283,3 +286,148 @@ def test_exporter_sample_from_a_searched_tree_equals_the_explicit_call(hip_lib, 
     assert again.export_game_samples(traindata.DRAWN) == 1
     assert list(zr.read_array(str(tmp_path / "a.zarr"), "y_value")[:2]) == [0, 1] and again.info()["start_index"] == 1
     pool.close()
+
+
+def test_game_phase_product_equals_oracle(hip_lib):
+    """Board::get_phase (board.cpp:540-587; majors and minors, sparse back rank, mixedness of the lichess Divider :446-538; movecount
+    slices): the product's Position against the oracle board's restatement along seeded random games.  (The reference has no test for
+    these functions and its Board does not compile here: parity beyond the two restatements agreeing is unpinned.)"""
+    rng = np.random.default_rng(11)
+    seen = set()
+    for game in range(12):
+        variant = ("chess", "crazyhouse")[game % 2]
+        ob = co.Board(None, False, variant)
+        p = env.Position("", False, variant)
+        for ply in range(120):
+            for num_phases, definition in ((3, 0), (1, 0), (3, 1), (2, 1), (5, 1), (1, 1)):
+                assert p.game_phase(num_phases, definition) == ob.game_phase(num_phases, definition), (p.fen(), num_phases, definition)
+            seen.add(ob.game_phase(3, 0))
+            legal = ob.legal_uci()
+            if not legal or ob.terminal() is not None and ob.terminal() != 4:
+                break
+            u = legal[int(rng.integers(len(legal)))]
+            ob.push_uci(u)
+            assert p.push_uci(u)
+    assert seen == {0, 1, 2}
+    # worked values of the start position: 14 majors and minors, full back ranks, mixedness 70 -> opening
+    ob = co.Board(None, False, "chess")
+    assert (ob.majors_and_minors(), ob.backrank_sparse(), ob.mixedness()) == (14, False, 70)
+
+
+def _exported(root):
+    import zarr_v2_reader as zr
+    arrays = {n: zr.read_array(root, n) for n in ("y_policy", "phase_vector", "start_indices", "plys_to_end")}
+    return arrays
+
+
+def test_quick_searches_are_not_exported_and_search_with_their_own_budget(hip_lib, tmp_path):
+    """generate_game, selfplay.cpp:209-224: with probability quickSearchProbability a move is searched with quickSearchNodes nodes (its own
+    Q-value weight and Dirichlet epsilon) and its position is NOT exported; normal moves keep the configured budget."""
+    from crazyara_amd import traindata
+    mode, variant = 0, "crazyhouse"
+
+    def run(prob, tag):
+        pool = _pool(mode, 8, 8 * 3)
+        exp = traindata.TrainDataExporter(str(tmp_path / f"{tag}.zarr"), mode, 1, nb_labels=2272, number_chunks=4, chunk_size=64)
+        s = selfplay.SelfPlaySettings(variant=variant, simulations=0, nodes=64, max_plies=24, seed=7, reuse_tree=False,
+                                      quick_search_probability=prob, quick_search_nodes=12, quick_search_q_value_weight=0.3)
+        loop = selfplay.SelfPlay(pool, s, 3, raw_policy=_raw_policy_from_pseudo_net(mode), exporter=exp)
+        games = loop.play(4, threads=2)
+        st = dict(loop.stats)
+        pool.close()
+        return games, st
+    games, st = run(1.0, "all_quick")
+    assert st["quick_searches"] == st["moves"] > 0 and st["samples"] == 0
+    # a quick move searches 12 nodes, a normal one 64: every node beyond the tree's root counts once per move (reuse_tree off)
+    assert st["nodes"] <= st["moves"] * (12 + 8)
+    games, st = run(0.0, "none_quick")
+    assert st["quick_searches"] == 0 and st["samples"] == st["moves"]
+    assert st["nodes"] >= st["moves"] * 40
+    games, st = run(0.5, "half_quick")
+    assert 0 < st["quick_searches"] < st["moves"] and st["samples"] == st["moves"] - st["quick_searches"]
+
+
+def test_low_policy_clip_threshold_sharpens_the_exported_policy_only(hip_lib, tmp_path):
+    """selfplay.cpp:229-231: sharpen_distribution(evalInfo.policyProbSmall, lowPolicyClipThreshold) runs after the move was chosen: the
+    games are the same with and without it, the exported policies have no entry below the threshold and still add up to one."""
+    from crazyara_amd import traindata
+    mode, variant = 0, "crazyhouse"
+    T = 0.0555                  # (between two visit fractions: the reference compares a double entry with a float threshold, ties aside)
+    out = {}
+    for thresh in (0.0, T):
+        pool = _pool(mode, 8, 8 * 2)
+        root = str(tmp_path / f"clip{thresh}.zarr")
+        exp = traindata.TrainDataExporter(root, mode, 1, nb_labels=2272, number_chunks=4, chunk_size=64)
+        s = selfplay.SelfPlaySettings(variant=variant, simulations=40, max_plies=20, seed=9, low_policy_clip_threshold=thresh)
+        loop = selfplay.SelfPlay(pool, s, 2, raw_policy=_raw_policy_from_pseudo_net(mode), exporter=exp)
+        games = loop.play(3, threads=2)
+        pool.close()
+        out[thresh] = ([g.uci for g in games], _exported(root)["y_policy"][:loop.stats["samples"]])
+    assert out[0.0][0] == out[T][0]                                     # the moves were picked from the unsharpened policy
+    plain, sharp = out[0.0][1], out[T][1]
+    assert ((plain > 0) & (plain < T)).any()                            # the threshold bites ...
+    assert not ((sharp > 0) & (sharp < T - 1e-6)).any()                 # ... and nothing below it is exported
+    assert np.allclose(sharp.sum(axis=1), 1.0, atol=1e-5)
+    for a, b in zip(plain, sharp):                                         # row by row: blazeutil.h:94-105 on the plain row
+        if a.max() < T:
+            assert np.allclose(a, b)
+        else:
+            e = np.where(a < T, 0.0, a)
+            assert np.allclose(b, e / e.sum(), atol=1e-6)
+
+
+def test_resignation_overrides_the_board_result_of_the_same_move(hip_lib):
+    """check_for_resignation runs after play_move_and_update and overwrites gameResult (selfplay.cpp:241-243,168-182): with resignation
+    always allowed and a threshold above every Q the FIRST searched move of every game ends it, the side to move afterwards wins."""
+    games, _ = _play("crazyhouse", 0, 4, 2, resign_probability=1.0, resign_threshold=1.5)
+    for g in games:
+        assert g.termination == "resignation" and len(g.uci) - g.book_plies == 1
+        mover_white = (g.book_plies % 2 == 0)                              # the start position has White to move
+        assert g.result == (-1 if mover_white else 1)
+
+
+def test_play_until_the_export_file_is_full(hip_lib, tmp_path):
+    """SelfPlay::go(0) (selfplay.cpp:374-377): games are generated while generatedSamples < max_samples_per_iteration(); running games
+    are played out, their positions beyond the capacity are searched and dropped.  go(N) plays N games whatever the file holds."""
+    from crazyara_amd import traindata
+    mode, variant = 0, "crazyhouse"
+    pool = _pool(mode, 8, 8 * 3)
+    root = str(tmp_path / "full.zarr")
+    exp = traindata.TrainDataExporter(root, mode, 1, nb_labels=2272, number_chunks=2, chunk_size=16)       # 32 samples
+    s = selfplay.SelfPlaySettings(variant=variant, simulations=24, max_plies=14, seed=4)
+    loop = selfplay.SelfPlay(pool, s, 3, raw_policy=_raw_policy_from_pseudo_net(mode), exporter=exp)
+    games = list(loop.play(0, threads=2))
+    st = dict(loop.stats)
+    assert len(games) >= 3 and all(g.result is not None for g in games)
+    assert st["samples"] == 32 and st["samples"] + st["samples_dropped"] == st["moves"]
+    start = _exported(root)["start_indices"]
+    assert int(start[len(games)]) == 32 or int(max(start[:len(games) + 1])) == 32
+    # go(N) on the full file: the games are played, nothing more is written
+    more = loop.play(len(games) + 2, threads=2)
+    assert len(more) == len(games) + 2 and loop.stats["samples"] == 32 and loop.stats["samples_dropped"] > st["samples_dropped"]
+    pool.close()
+
+
+def test_samples_go_to_the_exporter_of_their_game_phase(hip_lib, tmp_path):
+    """selfplay.cpp:115-125,232-238: with several phases every sample is saved by the exporter of its position's phase
+    (Board::get_phase); all exporters see every game."""
+    from crazyara_amd import traindata
+    mode, variant = 0, "crazyhouse"
+    pool = _pool(mode, 8, 8 * 2)
+    roots = [str(tmp_path / f"phase{i}.zarr") for i in range(3)]
+    exps = [traindata.TrainDataExporter(r, mode, 1, nb_labels=2272, number_chunks=4, chunk_size=64) for r in roots]
+    s = selfplay.SelfPlaySettings(variant=variant, simulations=24, max_plies=70, seed=6, num_phases=3, game_phase_definition=1)
+    loop = selfplay.SelfPlay(pool, s, 2, raw_policy=_raw_policy_from_pseudo_net(mode), exporter=exps)
+    games = loop.play(3, threads=2)
+    pool.close()
+    total = 0
+    for i, r in enumerate(roots):
+        a = _exported(r)
+        n = int(max(a["start_indices"]))
+        total += n
+        assert (a["phase_vector"][:n] == i).all()
+        assert not a["phase_vector"][n:].any()
+    assert total == loop.stats["samples"] == sum(len(g.uci) - g.book_plies for g in games)
+    assert all(int(max(_exported(r)["start_indices"])) > 0 for r in roots)          # 70-ply games visit all three movecount slices
+    with pytest.raises((ValueError, RuntimeError)):                          # lichess: one or three phases
+        selfplay.SelfPlay(_pool(mode, 8, 16), selfplay.SelfPlaySettings(variant=variant, num_phases=2, game_phase_definition=0), 2)

@@ -1091,7 +1091,8 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     // Precision float16x3, policy map: the policy conv holds a board's whole logit vector in one workgroup and runs the softmax itself
     // (conv_gemm_x3_kernel; the launcher takes one workgroup per board up to 256 couts, the staging tiles hold 8192 logits)
     if (x3_ && !im.ops.empty() && im.ops.back().kind == OpKind::Conv && im.ops.back().conv.out_policy_f32 &&
-        im.ops.back().conv.cout_pad <= 256 && im.ops.back().conv.cout_real * kSquares <= 8192) {
+        im.ops.back().conv.cout_pad <= 256 && im.ops.back().conv.cout_real * kSquares <= 8192 &&
+        getenv("CRA_X3_NO_FUSED_SOFTMAX") == nullptr) {                    // (development: the softmax as its own launch)
         im.ops.back().fused_softmax = true;
     } else {
         Op op;

@@ -169,8 +169,9 @@ const char* ref_last_error(void) { return g_error.c_str(); }
 }  // extern "C"
 
 // SearchSettings / PlaySettings exactly as CrazyAra::init_search_settings fills them, from the product's settings struct
+// search_threads = the UCI option `Threads`: that many SearchThreads on the one tree, each with its own batch net (crazyara.cpp:548-563)
 template <typename MakeNet>
-static ref_agent* create_agent(const mi_search_settings* s, MakeNet&& make_net) {
+static ref_agent* create_agent(const mi_search_settings* s, MakeNet&& make_net, unsigned search_threads = 1) {
     ref_agent* a = nullptr;
     if (guard([&] {
             refshim::Config& c = refshim::config();
@@ -183,7 +184,7 @@ static ref_agent* create_agent(const mi_search_settings* s, MakeNet&& make_net) 
             a = new ref_agent;
             SearchSettings& ss = a->ss;
             ss.multiPV = 1;
-            ss.threads = 1;
+            ss.threads = search_threads;
             ss.batchSize = unsigned(s->batch_size);
             ss.useMCGS = false;                                 // see DESIGN: the transposition link is unreachable in this snapshot
             ss.searchPlayerMode = MODE_TWO_PLAYER;
@@ -211,8 +212,10 @@ static ref_agent* create_agent(const mi_search_settings* s, MakeNet&& make_net) 
             a->ps.temperatureDecayFactor = 1.0;
             a->ps.quantileClipping = 0.0;
             a->netSingle.emplace_back(make_net(1u));            // crazyara.cpp:548-563: batch-1 net for the agent, batch-N per SearchThread
-            a->netBatches.emplace_back();
-            a->netBatches[0].emplace_back(make_net(unsigned(s->batch_size)));
+            for (unsigned t = 0; t < search_threads; ++t) {
+                a->netBatches.emplace_back();
+                a->netBatches[t].emplace_back(make_net(unsigned(s->batch_size)));
+            }
             StateConstants::init(a->netSingle[0]->is_policy_map(), false);
             a->agent.reset(new MCTSAgent(a->netSingle, a->netBatches, &a->ss, &a->ps));
             g_rand_state = s->seed;
@@ -486,6 +489,11 @@ int ref_value_to_centipawn(float v) { return value_to_centipawn(v); }
 // the reference's MCTSAgent / SearchThread on HipAPI nets: `go` computes on the GPU through mi_net_predict
 ref_agent* ref_agent_create_hip(const mi_search_settings* s, const char* model_dir, int device_id, const char* precision) {
     return create_agent(s, [&](unsigned batch) { return new HipAPI(device_id, batch, model_dir, precision); });
+}
+// the same with `Threads` SearchThreads (measurement leg of bench.py: the throughput a CrazyAra build with this back end gets)
+ref_agent* ref_agent_create_hip_threads(const mi_search_settings* s, const char* model_dir, int device_id, const char* precision, int threads) {
+    if (threads < 1 || threads > 64) return nullptr;
+    return create_agent(s, [&](unsigned batch) { return new HipAPI(device_id, batch, model_dir, precision); }, unsigned(threads));
 }
 
 struct ref_hipapi {

@@ -107,6 +107,8 @@ def load_hip():
     _declare(lib)
     lib.ref_agent_create_hip.restype = C.c_void_p
     lib.ref_agent_create_hip.argtypes = [C.POINTER(SearchSettingsC), C.c_char_p, C.c_int, C.c_char_p]
+    lib.ref_agent_create_hip_threads.restype = C.c_void_p
+    lib.ref_agent_create_hip_threads.argtypes = [C.POINTER(SearchSettingsC), C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     lib.ref_hipapi_create.restype = C.c_void_p
     lib.ref_hipapi_create.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.c_char_p, C.c_int]
     lib.ref_hipapi_destroy.argtypes = [C.c_void_p]
@@ -172,12 +174,13 @@ class RefAgent:
     eval_fn(list of 192-byte board descriptors) -> (values, probs[n][nb_policy]) -- the signature the product's callback lane uses."""
 
     def __init__(self, settings: SearchSettingsC, eval_fn: Callable = None, nb_policy: int = 0, hip_model_dir: str = None,
-                 device_id: int = 0, precision: str = "float16"):
+                 device_id: int = 0, precision: str = "float16", threads: int = 1):
         self.nb_policy = nb_policy
         if hip_model_dir is not None:                       # the agent's nets are HipAPI objects: `go` evaluates on the GPU
             self._lib = load_hip()
             self._cb = None
-            self._h = self._lib.ref_agent_create_hip(C.byref(settings), hip_model_dir.encode(), device_id, precision.encode())
+            # threads = the UCI option `Threads`: that many SearchThreads (own batch net each) on the one tree, crazyara.cpp:548-563
+            self._h = self._lib.ref_agent_create_hip_threads(C.byref(settings), hip_model_dir.encode(), device_id, precision.encode(), int(threads))
             if not self._h:
                 raise RuntimeError(_err(self._lib))
             return

@@ -463,6 +463,11 @@ def main():
                     help="second precision of the config-2 search leg (the reference's TensorRT default: value / priors within 1e-3 / 1e-5 of "
                          "fp32, logits non-conformant), reported as config2_mcts_nodes_per_sec_<mode>")
     ap.add_argument("--no-dropin-leg", action="store_true", help="skip the reference-MCTSAgent-on-HipAPI throughput leg")
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="rehearsal of the N-rank launch on a box with ONE GPU: every rank binds to device 0, rank 0 runs its legs, ranks "
+                         "1..N-1 skip the compute and take part in every rendezvous, barrier, reduce and gather.  RCCL is tried with the "
+                         "shared device; when it refuses (duplicate GPU) the collectives run over gloo and the line says so.  The numbers "
+                         "of such a run are those of N = 1; it exists so that the multi-rank path has run on hardware before a node does")
     ap.add_argument("--search-seconds", type=float, default=1.0, help="minimum timed region of one repeat of a search leg")
     ap.add_argument("--search-repeats", type=int, default=3)
     ap.add_argument("--no-config-legs", action="store_true", help="skip the search legs of BASELINE configs 1, 3, 4, 5")
@@ -486,14 +491,58 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path is the HIP library, there is no CPU fallback")
     if args.gpus != world:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    dry = bool(args.dry_ranks) and rank > 0                 # a rehearsal rank: every collective, no compute
+    if args.dry_ranks:
+        local_rank = 0                                      # every rank on the one GPU
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible -- refusing to "
-                         f"share a GPU between replicas (the numbers would mean nothing)")
+                         f"share a GPU between replicas (the numbers would mean nothing; --dry-ranks rehearses the launch on one GPU)")
     torch.cuda.set_device(local_rank)
     dist = None
+    collective_backend = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if not args.dry_ranks:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            collective_backend = "nccl"
+        else:
+            # gloo carries the rehearsal whatever happens; RCCL is tried on a second group over the shared device and its verdict
+            # (agreed over gloo, so that every rank takes the same branch) decides which group the collectives below use
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            ok, why = 1, ""
+            try:
+                g = dist.new_group(backend="nccl")
+                t = torch.ones(1, device="cuda")
+                dist.all_reduce(t, group=g)
+                torch.cuda.synchronize()
+                ok = int(float(t.item()) == float(world))
+            except Exception as e:  # noqa: BLE001 -- RCCL refuses ranks that share a device
+                ok, why = 0, repr(e)[:300]
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            collective_backend = "nccl (shared device)" if int(flag.item()) == 1 else "gloo (RCCL refused the shared device: " + (why or "on another rank") + ")"
+            if int(flag.item()) == 1:
+                nccl_group = g
+                _all_reduce, _all_gather, _barrier = dist.all_reduce, dist.all_gather, dist.barrier
+
+                class _OnNccl:                               # the same three calls, on the nccl group
+                    ReduceOp = dist.ReduceOp
+                    is_initialized = staticmethod(dist.is_initialized)
+                    get_world_size = staticmethod(dist.get_world_size)
+                    destroy_process_group = staticmethod(dist.destroy_process_group)
+
+                    @staticmethod
+                    def all_reduce(t_, op=dist.ReduceOp.SUM):
+                        return _all_reduce(t_, op=op, group=nccl_group)
+
+                    @staticmethod
+                    def all_gather(l_, t_):
+                        return _all_gather(l_, t_, group=nccl_group)
+
+                    @staticmethod
+                    def barrier():
+                        return _barrier(group=nccl_group)
+                dist = _OnNccl
 
     from crazyara_amd import build, netfile, replicas, rise_config
     from crazyara_amd.neuralnetapi import HipAPI
@@ -512,6 +561,8 @@ def main():
     torch.as_tensor(bufs["planes"], device="cuda").copy_(x.cuda())
     torch.cuda.synchronize()
     dev = torch.device("cuda", local_rank)
+    if collective_backend is not None and collective_backend.startswith("gloo"):
+        dev = torch.device("cpu")                           # gloo reduces host tensors
 
     def sync_all():
         net.sync()
@@ -525,15 +576,16 @@ def main():
         NN leg besides the SUM of evaluations)."""
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            net.forward_device()
+        if not dry:
+            for _ in range(args.steps):
+                net.forward_device()
         net.sync()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        ev, el, _ = replicas.reduce_stats(replicas.ReplicaStats(units=float(args.steps * args.batch), seconds=el), dist, dev)
+        ev, el, _ = replicas.reduce_stats(replicas.ReplicaStats(units=0.0 if dry else float(args.steps * args.batch), seconds=el), dist, dev)
         return ev, el
 
-    for _ in range(args.warmup):
+    for _ in range(0 if dry else args.warmup):
         net.forward_device()
     # A 20-step request is 7 ms of GPU time: one region decides nothing.  The region is repeated (same K steps each, barrier-bracketed
     # each) until the repeats add up to --min-timed-seconds; `ms_per_step` / `value` are the MEDIAN repeat, all repeats are reported.
@@ -564,13 +616,16 @@ def main():
         # `threads` counts the driving thread; one tree of a lane per thread is the fastest split, so with 16 trees per lane anything
         # below 16 makes one thread do two trees per batch
         cpus_avail = replicas.available_cpus()
-        _, budget_threads = replicas.pin_rank_to_cpus(world, local_rank)
+        _, budget_threads = replicas.pin_rank_to_cpus(world, int(os.environ.get("LOCAL_RANK", "0")), use_gpu_topology=not args.dry_ranks)
         threads = max(1, min(args.search_threads, budget_threads))
 
         def config2_leg(precision, repeats, leg_threads=None):
-            nets = [HipAPI(local_rank, args.batch, tmp, precision) for _ in range(lanes)]
-            leg = searchbench.timed_search_leg(st, nets, positions, n_trees, args.simulations, leg_threads or threads,
-                                               min_seconds=args.search_seconds, repeats=repeats, offset=rank * 37)
+            if dry:                                         # rehearsal rank: no search, every collective
+                nets, leg = [], {"_median_totals": (0, 0, 0, 1e-9), "_spread": None}
+            else:
+                nets = [HipAPI(local_rank, args.batch, tmp, precision) for _ in range(lanes)]
+                leg = searchbench.timed_search_leg(st, nets, positions, n_trees, args.simulations, leg_threads or threads,
+                                                   min_seconds=args.search_seconds, repeats=repeats, offset=rank * 37)
             nodes_m, evals_m, sims_m, sec_m = leg.pop("_median_totals")
             leg.pop("_spread")
             # RCCL sum of {nodes, evals, simulations}, max of seconds over the ranks' median repeats
@@ -591,7 +646,7 @@ def main():
             return nets, r
 
         nets, mcts = config2_leg(args.search_precision, args.search_repeats)
-        if len(nets) > 1:
+        if len(nets) > 1 and world == 1:
             # informational: two batches of 256 in flight, as two SearchThreads of the reference keep them (own weights, own stream
             # each).  Never `value`.
             import threading
@@ -621,7 +676,7 @@ def main():
         if world == 1 and not args.no_config_legs:
             # how many host threads a GPU needs (searchthread.cpp runs `Threads` of them per GPU): the same leg with fewer
             sweep = {}
-            for th in (4, 8):
+            for th in (1, 2, 4, 8):
                 if th < threads:
                     nets, r_ = config2_leg(args.search_precision, 1, leg_threads=th)
                     sweep[str(th)] = r_["mcts_nodes_per_sec"]
@@ -629,6 +684,13 @@ def main():
                         n_.close()
             sweep[str(threads)] = mcts["mcts_nodes_per_sec"]
             mcts["nodes_per_sec_by_host_threads"] = sweep
+            # what 8 ranks on this host would get: each rank its eighth of the CPUs this process may use (replicas.pin_rank_to_cpus)
+            per_rank = max(1, cpus_avail // 8)
+            usable = max((int(k) for k in sweep if int(k) <= per_rank), default=min(int(k) for k in sweep))
+            mcts["predicted_8_gpus"] = {"host_cpus": cpus_avail, "host_threads_per_rank": per_rank, "sweep_point_used": usable,
+                                        "mcts_nodes_per_sec": round(8 * sweep[str(usable)], 1),
+                                        "note": "8 x the one-GPU rate at the host-thread count an eighth of this host's CPUs gives a rank; "
+                                                "the GPUs do not interact (replicas), the host is the shared resource"}
         # ---- the other BASELINE configurations, searched (single GPU; extra keys, never `value`) ----
         if world == 1 and not args.no_config_legs:
             cargs = argparse.Namespace(**vars(args))
@@ -779,7 +841,8 @@ def main():
             "dtype": {"float16": "f16", "float16x3": "f16x3", "float32": "f32"}[args.precision], "data": "synthetic",
             "config": {"workload": f"crazyhouse RISEv2 {args.blocks}-block (34x8x8 planes -> 5184 policy + value), "
                                    f"batch={args.batch}, inputs resident in HBM, random-init seeded weights",
-                       "batch": args.batch, "parallelism": f"replicas x{world}", "precision": args.precision,
+                       "batch": args.batch, "parallelism": f"replicas x{world}" + (" (dry ranks: one GPU, rehearsal of the launch)" if args.dry_ranks else ""),
+                       "collective_backend": collective_backend, "precision": args.precision,
                        "flops_per_position": net.flops_per_position()},
             "timed_region": {"repeats": len(regions), "steps_per_repeat": args.steps, "seconds_total": round(float(sum(regions)), 4),
                              "ms_per_step_median": round(elapsed / args.steps * 1e3, 4),

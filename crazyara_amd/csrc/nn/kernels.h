@@ -45,6 +45,8 @@ struct ConvArgs {
     // read as zeros (the stem conv does the planes -> NHWC transform while it stages the board)
     const float* planes;
     int planes_c;
+    int dev;              // development (CRA_X3_CONV_DEV): 1 = every wave leaves the kernel behind one last barrier, 2 = waves without a cout
+                          // tile request no weight fragments
 };
 
 template <typename T> void launch_conv_gemm(const ConvArgs& a, hipStream_t s);
@@ -276,7 +278,7 @@ struct ValueHeadArgs {
     // development (CRA_VALUE_HEAD_DEBUG, scripts/lane_divergence.py): [B][8] stage checksums of the launch -- staged board, staged conv
     // weights, conv output, FC1 partial sums, FC2 sum, value -- each added up in a fixed order: equal inputs give equal bits
     float* dbg;
-    int lds_pad;            // development: extra dynamic LDS per workgroup (keeps other workgroups off the CU)
+    int lds_pad;            // development (CRA_VALUE_HEAD_LDS_PAD): < 0 = only the LDS the kernel uses (its workgroups then share compute units)
     int variant;            // development (CRA_VALUE_HEAD_VARIANT): 1 = FC1 partial sums in LDS of their own (not over the dead board tile),
                             // 2 = FC1 accumulators pinned per step (no packed f32 FMAs), 4 = s_waitcnt vmcnt(0) behind every group of 32 weight
                             // loads, 8 = weight loads non-temporal

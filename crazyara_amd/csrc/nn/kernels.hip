@@ -9,6 +9,7 @@
 //   softmax on policy_out ......... engine/src/nn/tensorrtapi.cpp:378-392, engine/src/nn/neuralnetapi.cpp:241-260
 #include "kernels.h"
 
+#include <algorithm>
 #include <stdexcept>
 #include "device_utils.h"
 
@@ -587,8 +588,18 @@ template <typename T> void launch_value_final(const ValueFinalArgs& a, hipStream
 template void launch_value_final<half_t>(const ValueFinalArgs&, hipStream_t);
 template void launch_value_final<float>(const ValueFinalArgs&, hipStream_t);
 
+// The kernel asks for (nearly) a whole compute unit's LDS although it uses 44 KB of it: its workgroups must not share a compute unit with
+// the float16x3 policy conv (conv_gemm_x3_kernel<3, 1, 8, 4>, 35 KB of LDS).  Measured in round 4 (profiles/NOTES.md, sets r04a-g): with
+// workgroups of that kernel on the same compute unit, one accumulator register of the FC1 loop comes out wrong in lanes 48-63 of one
+// wave in 20-30 % of the launches (value off by 1e-4 ... 5e-2); with no neighbour, or any other kernel of the forward as neighbour, 0 of
+// 160,000.  Not the LDS tile aliasing, not the order of the weight loads, not the neighbour's early-exiting waves or its
+// transcendentals (each switched off in turn); the cause below the ISA is not known.  144 KB leaves 16 KB: no kernel with a staged
+// board fits beside it.  One workgroup per compute unit is what a batch of 256 gives this kernel anyway.
+constexpr size_t kValueHeadExclusiveLds = 144 * 1024;
 static size_t value_head_lds_bytes(const ValueHeadArgs& a) {
-    return (size_t(kSquares) * (a.C / 2 + 4) + size_t(a.cv) * a.C + size_t(kSquares) * a.cv + 8 + ((a.variant & 1) ? 4 * a.fc : 0)) * sizeof(float) + size_t(a.lds_pad);
+    const size_t used = (size_t(kSquares) * (a.C / 2 + 4) + size_t(a.cv) * a.C + size_t(kSquares) * a.cv + 8 + ((a.variant & 1) ? 4 * a.fc : 0)) * sizeof(float);
+    if (a.lds_pad < 0) return used;                              // development: the kernel as it was (shares compute units)
+    return std::max(used + size_t(a.lds_pad), kValueHeadExclusiveLds);
 }
 // once per net, outside any stream capture: the kernel's dynamic LDS allowance (the staged board is more than the default 64 KiB)
 template <typename T> void prepare_value_head(const ValueHeadArgs& a) {

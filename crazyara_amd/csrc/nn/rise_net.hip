@@ -25,7 +25,7 @@ namespace cra {
 namespace {
 constexpr double kBnEps = 1e-5;   // torch.nn.BatchNorm2d default; the reference never overrides it
 // the float16x3 forward's value head: false = conv GEMM + FC GEMM + value_final (three launches), true = value_head_kernel (one)
-constexpr bool kX3ValueHeadOneLaunch = false;
+constexpr bool kX3ValueHeadOneLaunch = true;
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -1104,10 +1104,10 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     const char* x3_vh = getenv("CRA_X3_VALUE_HEAD");
     const bool x3_value_one_launch = x3_ && fused_ && (x3_vh ? x3_vh[0] == 'o' : kX3ValueHeadOneLaunch);
     if (fused_ && !x3_value_one_launch) {
-        // _ValueHead (builder_util.py:246-326) as three MFMA/wave-level launches instead of one latency-bound VALU kernel.
-        // (Precision float16x3 ran the one-launch f32 kernel of the unfused path for a while -- 0.022 ms against 0.039 for these three -- but
-        // with it behind the two-role tower the searches of two concurrent lanes stopped being reproducible run to run (profiles/NOTES.md,
-        // set ab): taken out again until that is understood.)
+        // _ValueHead (builder_util.py:246-326) as three MFMA/wave-level launches instead of one latency-bound VALU kernel (Precision
+        // float16 / fp8 layer paths; float16x3 on request).  Precision float16x3 runs the one-launch f32 kernel below (0.022 ms against
+        // 0.039): in round 3 it made two-lane searches irreproducible -- its workgroups shared compute units with the policy conv of the
+        // other lane; it now takes a compute unit's LDS for itself (kernels.hip: kValueHeadExclusiveLds, profiles/NOTES.md round 4).
         //   (1) conv1x1(C->cv)+BN+ReLU on the conv-GEMM kernel, written channel-major flat  (x.view(-1, nb_flatten))
         //   (2) FC(nfl->fc)+ReLU as a GEMM over the BATCH: 64 boards play the role of the 64 "squares" of one workgroup tile
         //   (3) FC(fc->1)+tanh, or the WDLP outputs, one wave per board
@@ -1269,7 +1269,13 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             launch_planes_to_act<T>(op.x == d_planes_ ? planes : static_cast<const float*>(op.x), static_cast<T*>(op.y), B, op.C, im.cin_pad, s);
             break;
         case OpKind::Conv:
-            if (x3_ && op.from_planes) {
+            if (x3_ && getenv("CRA_X3_CONV_DEV") != nullptr) {             // development: bisecting switches of conv_gemm_x3_kernel
+                ConvArgs c = op.conv;
+                c.dev = atoi(getenv("CRA_X3_CONV_DEV"));
+                if (op.from_planes) c.planes = planes;
+                if (op.fused_softmax) { c.softmax_out = probs; if (!keep_logits_) c.out = nullptr; }
+                launch_conv_gemm_x3(c, s);
+            } else if (x3_ && op.from_planes) {
                 ConvArgs c = op.conv;
                 c.planes = planes;
                 launch_conv_gemm_x3(c, s);

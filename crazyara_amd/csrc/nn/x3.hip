@@ -160,8 +160,10 @@ __global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a)
             for (int m = 0; m < MT; ++m) { wh[st % D][m] = wph[m][wo]; wl[st % D][m] = wpl[m][wo]; }
         };
         if constexpr (NS > 0) {
+            if (!(a.dev & 2) || active[0]) {
 #pragma unroll
-            for (int st = 0; st < D && st < NSTEP; ++st) wload(st);
+                for (int st = 0; st < D && st < NSTEP; ++st) wload(st);
+            }
         }
         __syncthreads();
         const int vec_per_row = kcl >> 3;                    // 8 floats -> 8 + 8 halves
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a)
         const float c = m + logf(sum);
         for (int i = tid; i < n; i += NTHR) out[i] = expf(in[i] - c);
     }
+    if (a.dev & 1) __syncthreads();
 }
 
 template <int KS, int NS> static void launch_conv_gemm_x3_ks(const ConvArgs& a, hipStream_t s) {

@@ -1,5 +1,7 @@
 #include "mcts.h"
 
+#include <sys/mman.h>
+
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -50,13 +52,18 @@ struct NodeLock {                                // Node::lock() / unlock() (nod
 };
 }  // namespace
 
+// The chunk-pointer table (1 MiB of address space) is an anonymous mapping of its own: zero pages the kernel hands over one by one when
+// they are first touched, whatever the allocator's thresholds are at the moment (a calloc of this size can come from the heap once
+// glibc has raised its mmap threshold, and is then memset in full on every played move); the atomics are constructed in place.
 static_assert(sizeof(std::atomic<Node*>) == sizeof(Node*) && std::atomic<Node*>::is_always_lock_free, "the table is raw zeroed memory");
-NodeArena::NodeArena() : table_(static_cast<std::atomic<Node*>*>(std::calloc(size_t(kMaxChunks), sizeof(std::atomic<Node*>)))) {
-    if (!table_) throw std::bad_alloc();
+NodeArena::NodeArena() {
+    void* p = mmap(nullptr, size_t(kMaxChunks) * sizeof(std::atomic<Node*>), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) throw std::bad_alloc();
+    table_ = static_cast<std::atomic<Node*>*>(p);          // all-zero pages: every entry is a null pointer; entries are created where used
 }
 NodeArena::~NodeArena() {
     clear();
-    std::free(table_);
+    munmap(static_cast<void*>(table_), size_t(kMaxChunks) * sizeof(std::atomic<Node*>));
 }
 void NodeArena::clear() {
     const size_t chunks = (size_t(size_.load()) + kChunk - 1) >> kChunkBits;
@@ -78,7 +85,10 @@ int NodeArena::emplace_back() {
     if (c >= size_t(kMaxChunks)) throw std::length_error("search tree: node arena exhausted");
     if (table_[c].load(std::memory_order_acquire) == nullptr) {
         std::lock_guard<std::mutex> lk(grow_);
-        if (table_[c].load(std::memory_order_acquire) == nullptr) table_[c].store(new Node[kChunk], std::memory_order_release);
+        if (table_[c].load(std::memory_order_acquire) == nullptr) {
+            new (&table_[c]) std::atomic<Node*>(nullptr);               // the object's lifetime starts here (its bytes are already zero)
+            table_[c].store(new Node[kChunk], std::memory_order_release);
+        }
     }
     return int(i);
 }

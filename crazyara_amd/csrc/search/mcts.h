@@ -125,8 +125,8 @@ struct Collector {
 // collectors can allocate nodes while others walk the tree (a std::vector would move every node on growth).
 class NodeArena {
 public:
-    // 256 nodes per chunk, room for 33.5 M nodes.  The chunk-pointer table (1 MiB) comes from calloc: fresh zero pages that the OS hands
-    // over only when they are touched, so a tree costs its first chunk (64 KiB of nodes) and one page of table -- not a 256 KiB memset
+    // 256 nodes per chunk, room for 33.5 M nodes.  The chunk-pointer table (1 MiB) is an anonymous mapping: fresh zero pages that the OS
+    // hands over only when they are touched, so a tree costs its first chunk (64 KiB of nodes) and one page of table -- not a 256 KiB memset
     // plus 1024 constructed nodes per tree, which a game loop paid on every played move of every game (Tree::apply_move, reset_position)
     static constexpr int kChunkBits = 8, kChunk = 1 << kChunkBits, kMaxChunks = 1 << 17;
     NodeArena();
@@ -140,7 +140,7 @@ public:
     void clear();                         // single-threaded phases only
     void swap(NodeArena& o);              // single-threaded phases only
 private:
-    std::atomic<Node*>* table_;           // calloc'ed: all-zero bytes are null pointers
+    std::atomic<Node*>* table_;           // mmap'ed zero pages: all-zero bytes are null pointers
     std::atomic<uint32_t> size_{0};
     std::mutex grow_;
 };

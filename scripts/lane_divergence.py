@@ -22,33 +22,38 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # name -> (environment, options)
+# CRA_VALUE_HEAD_LDS_PAD=-1: the one-launch value head as it was in round 3 (44 KB of LDS, sharing compute units with other kernels) -- the
+# form that fails; without it the kernel takes a compute unit's LDS for itself (the shipped form)
 CONFIGS = {
     "three_roles": ({"CRA_X3_VALUE_HEAD": "three"}, {}),
-    "one_roles": ({"CRA_X3_VALUE_HEAD": "one"}, {}),
-    "one_symmetric": ({"CRA_X3_VALUE_HEAD": "one", "CRA_X3_TOWER": "symmetric"}, {}),
-    "one_roles_hwq1": ({"CRA_X3_VALUE_HEAD": "one", "GPU_MAX_HW_QUEUES": "1"}, {}),
-    "one_roles_serialize": ({"CRA_X3_VALUE_HEAD": "one", "AMD_SERIALIZE_KERNEL": "3"}, {}),
-    "one_roles_lanesync": ({"CRA_X3_VALUE_HEAD": "one", "CRA_LANE_SYNC": "1"}, {}),
-    "one_roles_nograph": ({"CRA_X3_VALUE_HEAD": "one", "CRA_LANE_NO_GRAPH": "1"}, {}),
-    "one_roles_turns": ({"CRA_X3_VALUE_HEAD": "one", "CRA_FORCE_FORWARD_TURNS": "1"}, {}),
-    "one_roles_onelane": ({"CRA_X3_VALUE_HEAD": "one"}, {"lanes": 1}),
-    "one_roles_whole_vectors": ({"CRA_X3_VALUE_HEAD": "one", "CRA_GATHER_PER_SLOT": "0"}, {}),
+    "one_roles": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1"}, {}),
+    "one_symmetric": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_X3_TOWER": "symmetric"}, {}),
+    "one_roles_hwq1": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "GPU_MAX_HW_QUEUES": "1"}, {}),
+    "one_roles_serialize": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "AMD_SERIALIZE_KERNEL": "3"}, {}),
+    "one_roles_lanesync": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_LANE_SYNC": "1"}, {}),
+    "one_roles_nograph": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_LANE_NO_GRAPH": "1"}, {}),
+    "one_roles_turns": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_FORCE_FORWARD_TURNS": "1"}, {}),
+    "one_roles_onelane": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1"}, {"lanes": 1}),
+    "one_roles_whole_vectors": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_GATHER_PER_SLOT": "0"}, {}),
     "three_roles_nograph": ({"CRA_X3_VALUE_HEAD": "three", "CRA_LANE_NO_GRAPH": "1"}, {}),
     "float16": ({}, {"precision": "float16"}),
     # the value head's stage checksums under the storm of concurrent predicts: which stage differs first?
-    "dbg_one": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1"}, {"predicts": 20000, "runs": 0}),
-    "dbg_one_alone_on_cu": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_LDS_PAD": "100000"}, {"predicts": 20000, "runs": 0}),
-    "dbg_one_hwq1": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "GPU_MAX_HW_QUEUES": "1"}, {"predicts": 20000, "runs": 0}),
+    "dbg_one": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_VALUE_HEAD_DEBUG": "1"}, {"predicts": 20000, "runs": 0}),
+    "dbg_one_alone_on_cu": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_LDS_PAD": "0"}, {"predicts": 20000, "runs": 0}),
+    "dbg_one_hwq1": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_VALUE_HEAD_DEBUG": "1", "GPU_MAX_HW_QUEUES": "1"}, {"predicts": 20000, "runs": 0}),
     "storm_three": ({"CRA_X3_VALUE_HEAD": "three"}, {"predicts": 20000, "runs": 0}),
-    "dbg_one_own_lds": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "1"}, {"predicts": 20000, "runs": 0}),
-    "dbg_one_no_pk": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "2"}, {"predicts": 20000, "runs": 0}),
-    "one_no_dbg_storm": ({"CRA_X3_VALUE_HEAD": "one"}, {"predicts": 20000, "runs": 0}),
-    "big_default": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1"}, {"predicts": 80000, "runs": 0}),
-    "big_own_lds": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "1"}, {"predicts": 80000, "runs": 0}),
-    "big_vmcnt0": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "4"}, {"predicts": 80000, "runs": 0}),
-    "big_nt_loads": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "8"}, {"predicts": 80000, "runs": 0}),
-    "big_alone_on_cu": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_LDS_PAD": "100000"}, {"predicts": 80000, "runs": 0}),
-    "big_default_again": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1"}, {"predicts": 80000, "runs": 0}),
+    # the shipped kernel (exclusive compute unit) against the round-3 form that shares compute units (CRA_VALUE_HEAD_LDS_PAD=-1)
+    "shipped_one": ({"CRA_X3_VALUE_HEAD": "one"}, {"predicts": 40000, "runs": 100}),
+    "sharing_one": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1"}, {"predicts": 40000, "runs": 100}),
+    "dbg_one_own_lds": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "1"}, {"predicts": 20000, "runs": 0}),
+    "dbg_one_no_pk": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "2"}, {"predicts": 20000, "runs": 0}),
+    "one_no_dbg_storm": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1"}, {"predicts": 20000, "runs": 0}),
+    "big_default": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_VALUE_HEAD_DEBUG": "1"}, {"predicts": 80000, "runs": 0}),
+    "big_own_lds": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "1"}, {"predicts": 80000, "runs": 0}),
+    "big_vmcnt0": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "4"}, {"predicts": 80000, "runs": 0}),
+    "big_nt_loads": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_VARIANT": "8"}, {"predicts": 80000, "runs": 0}),
+    "big_alone_on_cu": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_DEBUG": "1", "CRA_VALUE_HEAD_LDS_PAD": "0"}, {"predicts": 80000, "runs": 0}),
+    "big_default_again": ({"CRA_X3_VALUE_HEAD": "one", "CRA_VALUE_HEAD_LDS_PAD": "-1", "CRA_VALUE_HEAD_DEBUG": "1"}, {"predicts": 80000, "runs": 0}),
 }
 
 

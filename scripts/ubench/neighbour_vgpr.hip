@@ -55,7 +55,7 @@ template <int KIND> __global__ __launch_bounds__(512) void aggressor(float* sink
         for (int i = 0; i < 8; ++i) {
             if constexpr (KIND == 0 || KIND == 7) asm volatile("v_exp_f32 %0, %0\n\ts_nop 1\n\tv_mul_f32 %0, 0.5, %0" : "+v"(x[i]));
             if constexpr (KIND == 1) asm volatile("v_log_f32 %0, %0\n\ts_nop 1\n\tv_max_f32 %0, 0.5, %0" : "+v"(x[i]));
-            if constexpr (KIND == 2) asm volatile("v_fma_f32 %0, %0, 0.5, 0.25" : "+v"(x[i]));
+            if constexpr (KIND == 2) asm volatile("v_fma_f32 %0, %0, 0.5, 0.5" : "+v"(x[i]));
             if constexpr (KIND == 3) x[i] = __shfl_xor(x[i], 1 << (i % 6), 64);
             if constexpr (KIND == 4) asm volatile("v_rcp_f32 %0, %0\n\ts_nop 1\n\tv_add_f32 %0, 1.0, %0" : "+v"(x[i]));
             if constexpr (KIND == 5) sink[(size_t(blockIdx.x) * 512 + threadIdx.x) * 8 + i] = x[i] + float(it);

@@ -13,6 +13,7 @@ import threading
 
 os.environ["CRA_X3_VALUE_HEAD"] = "one"
 os.environ["CRA_VALUE_HEAD_DEBUG"] = "1"
+os.environ.setdefault("CRA_VALUE_HEAD_LDS_PAD", "-1")      # the round-3 form that shares compute units (0 = the shipped, exclusive form)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -217,26 +217,26 @@ def cpu_baseline_mcts(cfg, sd, cores, trees=16, quota=16, simulations=48):
 
 def dropin_reference_search(model_dir, device, batch, precisions=("float16x3", "float16"), threads_list=(1, 2, 4, 8)):
     """The number a CrazyAra maintainer gets after the three edits of INTEGRATION.md: the reference's OWN MCTSAgent + SearchThreads
-    (compiled from /root/reference into oracle/_ref/libcrazyara_ref_hip.so, searchthread.cpp:403-416) on HipAPI nets
+    (compiled from /root/reference into oracle/_ref/libcrazyara_ref_hip_release.so with the reference's Release flags, searchthread.cpp:403-416) on HipAPI nets
     (integration/hipapi.h -> mi_net_predict), `Threads` = 1 / 2 / 4 / 8, Batch_Size 256.  Two workloads: BASELINE config 2 (crazyhouse
     openings, 1600 simulations per go) and CrazyAra::benchmark's 15 positions (3200 simulations per go, crazyara.cpp:287-330).
     A MEASUREMENT leg like cpu_baseline (kind "reference"): the product path never runs this code."""
     from crazyara_amd import openings, search
     from oracle import ref_mcts
     try:
-        ref_mcts.load_hip()
+        ref_mcts.load_hip(release=True)
     except Exception as e:  # noqa: BLE001 -- the prebuilt file did not travel: report it, never fail the bench
-        return {"skipped": f"oracle/_ref/libcrazyara_ref_hip.so not loadable: {e}"}
+        return {"skipped": f"oracle/_ref/libcrazyara_ref_hip_release.so not loadable: {e}"}
     st = search.default_settings(mode=0, version_major=1, batch_size=batch)
     opening_fens = openings.crazyhouse_opening_set()[::7][:10]
     table = openings.benchmark_positions()
     out = {"kind": "reference", "batch_size": batch,
-           "workload": "the reference's MCTSAgent / SearchThread (oracle/_ref/libcrazyara_ref_hip.so) on HipAPI nets, RISEv2-19, Batch_Size 256: "
+           "workload": "the reference's MCTSAgent / SearchThread (oracle/_ref/libcrazyara_ref_hip_release.so, -O3 -DNDEBUG) on HipAPI nets, RISEv2-19, Batch_Size 256: "
                        "config2 = 10 crazyhouse openings x go simulations 1600; benchmark = the 15 positions of benchmarkpositions.cpp x go "
                        "simulations 3200; nodes = visits - freeVisits at the root (evalinfo.cpp:73-80)"}
     for precision in precisions:
         for th in threads_list:
-            agent = ref_mcts.RefAgent(st, hip_model_dir=model_dir, device_id=device, precision=precision, threads=th)
+            agent = ref_mcts.RefAgent(st, hip_model_dir=model_dir, device_id=device, precision=precision, threads=th, release=True)
             agent.set_position(opening_fens[0], False, "crazyhouse")
             agent.go(simulations=400)                                      # warm-up: kernels loaded, pinned buffers touched
             rates = {}

@@ -32,6 +32,7 @@ SRC = os.path.join(REF, "engine", "src")
 OUT = os.path.join(os.path.dirname(HERE), "_ref")
 LIB = os.path.join(OUT, "libcrazyara_ref.so")
 LIB_HIP = os.path.join(OUT, "libcrazyara_ref_hip.so")     # + integration/hipapi.h, linked against the product library
+LIB_HIP_RELEASE = os.path.join(OUT, "libcrazyara_ref_hip_release.so")
 
 REFERENCE_SOURCES = [
     "nodedata.cpp", "searchthread.cpp", "evalinfo.cpp", "state.cpp", "stateobj.cpp",
@@ -119,6 +120,29 @@ def build(force: bool = False, verbose: bool = False):
                             "-Wl,-rpath,$ORIGIN/../../crazyara_amd/lib", "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed (HipAPI build):\n" + r.stdout)
+        # The same once more as a RELEASE build (-O3 -DNDEBUG: what the reference's CMake Release configuration compiles) for the throughput
+        # leg of bench.py: with Threads > 1 the reference's own assert on the virtual-loss counter (node.h:506) fires under its threads'
+        # races, which a release engine does not contain; the parity tests keep the asserting build above.
+        rel_dir = os.path.join(OUT, "obj_release")
+        os.makedirs(rel_dir, exist_ok=True)
+        rel_flags = [f for f in FLAGS if f != "-O2"] + ["-O3", "-DNDEBUG"]
+        jobs = []
+        for base, names in ((SRC, REFERENCE_SOURCES), (HERE, SHIM_SOURCES), (os.path.join(ROOT, "crazyara_amd", "csrc"), PRODUCT_ENV_SOURCES)):
+            for n in names:
+                obj = os.path.join(rel_dir, n.replace("/", "_") + ".o")
+                extra = ["-DREF_WITH_HIPAPI", "-I", os.path.join(ROOT, "include")] if n == "ref_driver.cpp" else []
+                jobs.append((n, obj, subprocess.Popen([gxx] + rel_flags + inc + extra + ["-c", os.path.join(base, n), "-o", obj],
+                                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        rel_objs = []
+        for n, obj, p in jobs:
+            out, _ = p.communicate()
+            if p.returncode != 0:
+                raise RuntimeError(f"g++ failed on {n} (release build):\n{out}")
+            rel_objs.append(obj)
+        r = subprocess.run([gxx, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB_HIP_RELEASE] + rel_objs + ["-L", product_lib_dir, "-lcrazyara_hip",
+                            "-Wl,-rpath,$ORIGIN/../../crazyara_amd/lib", "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed (HipAPI release build):\n" + r.stdout)
     with open(stamp_file, "w") as f:
         f.write(stamp)
     return LIB

@@ -92,9 +92,28 @@ def hip_available() -> bool:
     return os.path.exists(LIB_HIP_PATH) or build_ref.reference_present()
 
 
-def load_hip():
-    """The same library with integration/hipapi.h compiled in (the reference-side binding of the product library)."""
-    global _lib_hip
+LIB_HIP_RELEASE_PATH = os.path.join(HERE, "_ref", "libcrazyara_ref_hip_release.so")
+_lib_hip_release = None
+
+
+def load_hip(release: bool = False):
+    """The same library with integration/hipapi.h compiled in (the reference-side binding of the product library).
+    release = True: the -O3 -DNDEBUG build of the same sources (the reference's Release configuration), for throughput measurements."""
+    global _lib_hip, _lib_hip_release
+    if release:
+        if _lib_hip_release is None:
+            from oracle.ref import build_ref
+            build_ref.build()
+            if not os.path.exists(LIB_HIP_RELEASE_PATH):
+                raise RuntimeError("oracle/_ref/libcrazyara_ref_hip_release.so is not built")
+            from crazyara_amd import _capi
+            _capi.load()
+            lib = C.CDLL(LIB_HIP_RELEASE_PATH)
+            _declare(lib)
+            lib.ref_agent_create_hip_threads.restype = C.c_void_p
+            lib.ref_agent_create_hip_threads.argtypes = [C.POINTER(SearchSettingsC), C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+            _lib_hip_release = lib
+        return _lib_hip_release
     if _lib_hip is not None:
         return _lib_hip
     from oracle.ref import build_ref
@@ -174,10 +193,10 @@ class RefAgent:
     eval_fn(list of 192-byte board descriptors) -> (values, probs[n][nb_policy]) -- the signature the product's callback lane uses."""
 
     def __init__(self, settings: SearchSettingsC, eval_fn: Callable = None, nb_policy: int = 0, hip_model_dir: str = None,
-                 device_id: int = 0, precision: str = "float16", threads: int = 1):
+                 device_id: int = 0, precision: str = "float16", threads: int = 1, release: bool = False):
         self.nb_policy = nb_policy
         if hip_model_dir is not None:                       # the agent's nets are HipAPI objects: `go` evaluates on the GPU
-            self._lib = load_hip()
+            self._lib = load_hip(release)
             self._cb = None
             # threads = the UCI option `Threads`: that many SearchThreads (own batch net each) on the one tree, crazyara.cpp:548-563
             self._h = self._lib.ref_agent_create_hip_threads(C.byref(settings), hip_model_dir.encode(), device_id, precision.encode(), int(threads))

@@ -91,6 +91,12 @@ struct X3TowerBlock {
     const float* se_b;                               // eca_se: [256]
     int cop_pad;                                     // multiple of block_x3_chunk_channels()
     int se_kind;                                     // 0 none, 1 ca_se, 2 eca_se
+    // Precision float16p8 (x3.hip, tower_x3_roles_kernel<true>): w3pk = f16 image of w3 * 2^p, w3pk_lo = the 8-bit image of the cross terms
+    // (per cout tile and 64 k: lanes' 32 bytes [e4m3((w3 * 2^p) - hi) for 64 k ; e4m3(w3 * 2^(p - 11)) for the same 64 k], bytes 0-15 in
+    // "slab" 2 J, bytes 16-31 in "slab" 2 J + 1 of the lo image's geometry), b3 = BN3 bias * 2^p, w3_inv = 2^-p;
+    // lo_scale = the scale operand that makes v_cvt_scalef32_pk_fp8_f32 return e4m3(residual * 2^11)
+    float w3_inv;
+    float lo_scale;
 };
 struct X3TowerArgs {
     const float* x;       // [B][64][256]
@@ -98,6 +104,7 @@ struct X3TowerArgs {
     const X3TowerBlock* blocks;   // device array
     int nblocks;
     int batch;
+    int p8;               // Precision float16p8
 };
 void launch_tower_x3(const X3TowerArgs& a, hipStream_t s);
 template <typename T> void init_block_kernel_attributes();

@@ -87,6 +87,43 @@ __device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo
     lo = __builtin_bit_cast(half4, u32x2{l[0], l[1]});
 }
 
+// Precision float16p8 (the project GEMM of the two-role tower): a value v goes to the matrix unit as the f16 hi = rne(v) for the MAIN product
+// and as two e4m3 bytes for the CROSS products, hi8 = e4m3(hi) and lo8 = e4m3((v - hi) * 2^11) (the residual is exact in f32; 2^11 brings it
+// to the magnitude of hi, where e4m3 has its normal range).  4 values -> 2 dwords of f16, 1 dword of hi8, 1 dword of lo8.
+typedef half_t half2_x3 __attribute__((ext_vector_type(2)));
+typedef short s16x2_x3 __attribute__((ext_vector_type(2)));
+typedef int i32x4_x3 __attribute__((ext_vector_type(4)));
+typedef int i32x8_x3 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split4_p8(const float (&v)[4], half4& hi, uint32_t& h8, uint32_t& l8, float lo_scale) {
+    uint32_t h[2];
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        asm("v_cvt_pk_f16_f32 %0, %3, %4\n\t"
+            "v_fma_mix_f32 %1, %0, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(h[j]), "=&v"(r[2 * j]), "=&v"(r[2 * j + 1])
+            : "v"(v[2 * j]), "v"(v[2 * j + 1]));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(half4, u32x2{h[0], h[1]});
+    s16x2_x3 q = {0, 0}, p = {0, 0};
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_bit_cast(half2_x3, h[0]), 1.0f, false);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_bit_cast(half2_x3, h[1]), 1.0f, true);
+    p = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p, r[0], r[1], lo_scale, false);
+    p = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p, r[2], r[3], lo_scale, true);
+    h8 = __builtin_bit_cast(uint32_t, q);
+    l8 = __builtin_bit_cast(uint32_t, p);
+}
+// D(16x16) += A(16 x 128) * B(128 x 16), e4m3 operands: lane l holds row / column l % 16 and the 32 bytes k = (l / 16) * 32 + t of the
+// step -- the same labelling on both operands, so the sum is the plain product whatever order the hardware walks its k in
+__device__ __forceinline__ void x3_mfma8(const i32x8_x3& a, const i32x8_x3& b, f32x4& c, bool on) {
+    if (on) c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
+    else asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ i32x8_x3 x3_cat(const half8& lo16, const half8& hi16) {       // a lane's 32 operand bytes from two 16-byte pieces
+    return __builtin_shufflevector(__builtin_bit_cast(i32x4_x3, lo16), __builtin_bit_cast(i32x4_x3, hi16), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // acc += w * x[lane -/+ 1 within the 16-lane row] (lanes shifted in from outside the row contribute 0).  Through the builtin, not inline
 // assembly: a DPP operand written by a VALU instruction needs two wait states in front of the DPP read, the compiler inserts them for
 // its own instructions and does not look inside an asm statement (a hand-written v_fmac_f32_dpp here read stale registers: r03c).
@@ -989,9 +1026,16 @@ __global__ __launch_bounds__(512) void tower_x3_kernel(const X3TowerArgs a) {
 // slower (profiles/r03/h_*) -- alone, its weight stream already runs at 27 TB/s, 80 % of the L2 -> CU peak; s_setprio on the EXPAND
 // waves, a barrier that holds the PROJECT waves back until the expand MFMAs are through (profiles/r03/m_*): nothing / slower;
 // v_pk_fma_f32 for the depthwise: it does not run in the shadow of MFMAs (mix_kinds.hip: 38.5 cycles for MFMA + 2 of them).
+// P8 = Precision float16p8: the PROJECT GEMM takes its cross terms through ONE e4m3 MFMA per 64 k (v_mfma_f32_16x16x128_f8f6f4 on
+// [hi8 | lo8] x [w_lo8 ; w_hi8], split4_p8) beside the two f16 MFMAs of the main term -- 3 instructions of 19.6 + 19.6 + 34.0 issue
+// ticks where float16x3 issues 6 of 19.6 (scripts/ubench/mix_fp8.hip, profiles/r04/h_mix_fp8.log).  The depthwise output t2 is written
+// as f16 hi + e4m3 hi8 + e4m3 lo8 (the same 4 bytes per value); the project weights come scaled by a power of two per block
+// (X3TowerBlock::w3_inv undoes it in the block epilogue).  The expand GEMM and the residual stream are float16x3's.
+template <bool P8>
 __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a) {
     using G = X3Block;
     static_assert(G::NE == 1 && G::T2BUF == 2 && G::CK == 128, "the role kernel uses the NE = 1 tile geometry (two t2 buffers of 128 channels)");
+    if constexpr (P8) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // MODE.FP16_OVFL: conversions to f16 / e4m3 clamp instead of overflowing
     constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const X3Tiles T = x3_tiles(smem);
@@ -1109,6 +1153,16 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                             const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
+                                if constexpr (P8) {                  // f16 hi as before; the lo tile's bytes hold hi8 [0, 128) and lo8 [144, 272) of the row
+                                    half4 h;
+                                    uint32_t h8, l8;
+                                    split4_p8(dw.outv[t], h, h8, l8, d.lo_scale);
+                                    char* const row8 = reinterpret_cast<char*>(t2l) + (t * 16 + l15) * (TROW * 2);
+                                    *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
+                                    *reinterpret_cast<uint32_t*>(row8 + cl) = h8;
+                                    *reinterpret_cast<uint32_t*>(row8 + 144 + cl) = l8;
+                                    continue;
+                                }
                                 half4 h, l;
                                 split4(dw.outv[t], h, l);
                                 if constexpr (X3_ABL & 64) {
@@ -1150,6 +1204,100 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
             }
             __syncthreads();                                            // the PROJECT waves' block epilogue
             { const int kk = n; X3_STAMP(5); }
+        } else if constexpr (P8) {
+            // ---- PROJECT role, Precision float16p8: per 64 k of a chunk two f16 steps (main term) and one e4m3 step (both cross terms) ----
+            constexpr int NJ = 4;
+            half8 p_h[2][NJ];                                           // f16 fragments of two k-slabs (slot = slab parity)
+            i32x8_x3 p_8[NJ];                                           // e4m3 fragments of the current 64-k step: [w_lo8 (64 k) ; w_hi8 (64 k)]
+            auto load_ph = [&](int k, int s2) {                        // cout tile = w * 4 + j, K slab = k * 4 + s2
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    p_h[s2 & 1][j] = x3_frag(W.w3h, lane_off, uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + s2));
+            };
+            auto load_p8 = [&](int k, int jj) {                        // a lane's 32 bytes = its 16 of "slab" 2 jj and its 16 of "slab" 2 jj + 1 of the 8-bit image
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const uint32_t f = uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + 2 * jj);
+                    p_8[j] = x3_cat(x3_frag(W.w3l, lane_off, f), x3_frag(W.w3l, lane_off, f + 1));
+                }
+            };
+            f32x4 accP[NJ][4];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {                              // BN3 bias, already in the accumulators' scale (host: b3 * 2^p)
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(d.b3 + (w * NJ + j) * 16 + lg * 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accP[j][t] = bs;
+            }
+            load_ph(0, 0);
+            load_ph(0, 1);
+            load_p8(0, 0);
+            __syncthreads();                                            // intervals 0 and 1: chunk 0 is expanded, then run through the depthwise
+            __syncthreads();
+            for (int kk = 0; kk < n; ++kk) {                            // P(kk) runs in interval kk + 2
+                const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
+                const char* const t28 = reinterpret_cast<const char*>(T.t2l + (kk & 1) * 64 * TROW);
+                const int kn = kk + 1 < n ? kk + 1 : kk;                // (behind the last chunk: a valid address, no branch in the stretch)
+                half8 bh[2][4];
+                i32x8_x3 b8[4];
+                auto read_h = [&](int s2, half8 (&h)[4]) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) h[t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                };
+                auto read_8 = [&](int jj) {                             // lane group lg: 0, 1 = hi8 of k [0, 32), [32, 64) of the step; 2, 3 = lo8 of the same
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const char* pp = t28 + (t * 16 + l15) * (TROW * 2) + (lg >> 1) * 144 + jj * 64 + (lg & 1) * 32;
+                        b8[t] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 16));
+                    }
+                };
+                read_h(0, bh[0]);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    read_h(2 * jj + 1, bh[1]);
+                    read_8(jj);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) x3_mfma(p_h[0][j], bh[0][t], accP[j][t], true);
+                    if (jj == 0) load_ph(kk, 2); else load_ph(kn, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (jj == 0) read_h(2, bh[0]);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) x3_mfma(p_h[1][j], bh[1][t], accP[j][t], true);
+                    if (jj == 0) load_ph(kk, 3); else load_ph(kn, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) x3_mfma8(p_8[j], b8[t], accP[j][t], true);
+                    if (jj == 0) load_p8(kk, 1); else load_p8(kn, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kk + 1 < n) __syncthreads();
+            }
+            // block epilogue: new stream = x + body(x) with the project sum brought back from the weights' scale, split again, in place
+            const float inv = d.w3_inv;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int co0 = (w * NJ + j) * 16 + lg * 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int sq = t * 16 + l15;
+                    float rh[4], rl[4], v[4];
+                    load4<half_t>(T.xh + sq * XROW + co0, rh);
+                    load4<half_t>(T.xl + sq * XROW + co0, rl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(accP[j][t][r], inv, rh[r] + rl[r]);
+                    half4 h, l;
+                    split4(v, h, l);
+                    *reinterpret_cast<half4*>(T.xh + sq * XROW + co0) = h;
+                    *reinterpret_cast<half4*>(T.xl + sq * XROW + co0) = l;
+                }
+            }
+            __syncthreads();
         } else {
             // project weight window: 2 of a chunk's 4 k-slabs x 4 cout tiles x (hi, lo), running on across chunk boundaries
 #if defined(CRA_DEVELOPMENT) && defined(CRA_X3_PW)
@@ -1272,7 +1420,8 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
 void init_x3_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
 }
 int block_x3_chunk_channels() { return X3Block::CK; }
 
@@ -1284,8 +1433,11 @@ void launch_tower_x3(const X3TowerArgs& a, hipStream_t s) {
     // two-role kernel.  The two add up every output in the same order: same bits.
     const char* e = getenv("CRA_X3_TOWER");
     const bool symmetric = e != nullptr && e[0] == 's';
-    if (symmetric) hipLaunchKernelGGL(tower_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
-    else hipLaunchKernelGGL(tower_x3_roles_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+    if (a.p8) {
+        if (symmetric) throw std::invalid_argument("Precision float16p8 runs the two-role tower only");
+        hipLaunchKernelGGL(tower_x3_roles_kernel<true>, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+    } else if (symmetric) hipLaunchKernelGGL(tower_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+    else hipLaunchKernelGGL(tower_x3_roles_kernel<false>, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
 }
 
 }  // namespace cra

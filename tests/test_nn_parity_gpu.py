@@ -39,6 +39,7 @@ def logit_tol(tol, ref_logits):
 TOL["float16x3"] = TOL["float32"]
 TOL["float16x3-perblock"] = TOL["float32"]  # one launch per 3x3 block (block_x3_kernel); plain float16x3 runs them in one launch (tower_x3_kernel)
 TOL["float16x3-unfused"] = TOL["float32"]   # every block on the layer kernels (conv GEMM x3 / float depthwise), as the 5x5 blocks always are
+TOL["float16p8"] = TOL["float32"]           # float16x3 with the tower's project cross terms on e4m3 MFMAs: the same 1e-4 bound (emulated 1e-5 ... 7e-5)
 TOL["float32-unfused"] = TOL["float32"]
 TOL["float16-unfused"] = TOL["float16"]
 TOL["float16-perblock"] = TOL["float16"]
@@ -65,8 +66,8 @@ def _run(tmp_path, hip_lib, name, precision):
     return cfg, sd, x, value, probs.reshape(B, -1), aux, logits
 
 
-@pytest.mark.parametrize("precision", ["float32", "float16", "float16x3", "float16-3k", "float16-perblock", "float32-unfused", "float16-unfused",
-                                       "float16x3-perblock", "float16x3-unfused"])
+@pytest.mark.parametrize("precision", ["float32", "float16", "float16x3", "float16p8", "float16-3k", "float16-perblock", "float32-unfused",
+                                       "float16-unfused", "float16x3-perblock", "float16x3-unfused"])
 @pytest.mark.parametrize("name", list(nn_cases.CASES))
 def test_predict_matches_oracle_and_golden(tmp_path, hip_lib, name, precision):
     cfg, sd, x, value, probs, aux, logits = _run(tmp_path, hip_lib, name, precision)
@@ -439,3 +440,20 @@ def test_float16x3_two_role_tower_equals_the_symmetric_one_bit_for_bit(tmp_path,
         net.close()
         outs.append((v, p))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("name", ["risev2-3", "risev2-7", "risev2-13", "risev2-19", "risev33", "risev33-wdlp", "risev2-13-lichess"])
+def test_float16p8_equals_its_emulation(tmp_path, hip_lib, name):
+    """Precision float16p8 is DEFINED by oracle.forward_p8 (f16 main term + two e4m3 cross terms in the tower's project contraction,
+    everything else float16x3): the kernel must sit much closer to that definition than the mode sits to fp32 -- what is left is the
+    f32 accumulation order of the matrix unit -- and the mode itself within 1e-4 of fp32 on the logits (north_star: 1e-3)."""
+    cfg, sd, x, value, probs, aux, logits = _run(tmp_path, hip_lib, name, "float16p8")
+    e_value, e_logits, _ = ro.forward_p8(cfg, sd, x)
+    o_value, o_logits, _ = ro.forward(cfg, sd, x)
+    mode = float((e_logits - o_logits).abs().max())
+    kernel_vs_emulation = float(np.abs(logits - e_logits.numpy()).max())
+    kernel_vs_fp32 = float(np.abs(logits - o_logits.numpy()).max())
+    assert 2e-6 < mode < 1e-4, mode                                    # the mode is not float16x3 (1e-6) and not float16 (1e-3)
+    assert kernel_vs_emulation < max(8e-6, 0.35 * mode), (kernel_vs_emulation, mode)
+    assert kernel_vs_fp32 < 1e-4
+    assert np.abs(value - e_value.numpy().reshape(-1)).max() < 5e-6

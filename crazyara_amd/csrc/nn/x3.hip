@@ -1237,6 +1237,7 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                 const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
                 const char* const t28 = reinterpret_cast<const char*>(T.t2l + (kk & 1) * 64 * TROW);
                 const int kn = kk + 1 < n ? kk + 1 : kk;                // (behind the last chunk: a valid address, no branch in the stretch)
+                X3_STAMP(8);
                 half8 bh[2][4];
                 i32x8_x3 b8[4];
                 auto read_h = [&](int s2, half8 (&h)[4]) {
@@ -1274,9 +1275,12 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
 #pragma unroll
                         for (int t = 0; t < 4; ++t) x3_mfma8(p_8[j], b8[t], accP[j][t], true);
                     if (jj == 0) load_p8(kk, 1); else load_p8(kn, 0);
+                    if (jj == 0) X3_STAMP(9);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                X3_STAMP(10);
                 if (kk + 1 < n) __syncthreads();
+                X3_STAMP(11);
             }
             // block epilogue: new stream = x + body(x) with the project sum brought back from the weights' scale, split again, in place
             const float inv = d.w3_inv;

@@ -23,6 +23,7 @@ template <typename T> T* upload(const std::vector<T>& h) {
 int main(int argc, char** argv) {
     using namespace cra;
     const int B = argc > 1 ? atoi(argv[1]) : 256, nblocks = argc > 2 ? atoi(argv[2]) : 19, iters = argc > 3 ? atoi(argv[3]) : 20;
+    const int p8 = argc > 4 ? atoi(argv[4]) : 0;          // 1: Precision float16p8's project path (the same buffers: timing only)
     std::mt19937 rng(7);
     std::uniform_real_distribution<float> u(-0.05f, 0.05f);
     std::vector<X3TowerBlock> blocks;
@@ -42,6 +43,8 @@ int main(int argc, char** argv) {
         b.dwpk = upload(rec);
         b.b3 = upload(b3);
         b.cop_pad = cop_pad;
+        b.w3_inv = 1.f;
+        b.lo_scale = 1.f / 2048.f;
         blocks.push_back(b);
         flops += 2.0 * 64 * cop * (2.0 * 256 + 9) * B;
     }
@@ -53,6 +56,7 @@ int main(int argc, char** argv) {
     a.blocks = upload(blocks);
     a.nblocks = nblocks;
     a.batch = B;
+    a.p8 = p8;
     init_x3_kernel_attributes();
     hipStream_t s;
     CK(hipStreamCreate(&s));

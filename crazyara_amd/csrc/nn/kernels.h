@@ -91,12 +91,10 @@ struct X3TowerBlock {
     const float* se_b;                               // eca_se: [256]
     int cop_pad;                                     // multiple of block_x3_chunk_channels()
     int se_kind;                                     // 0 none, 1 ca_se, 2 eca_se
-    // Precision float16p8 (x3.hip, tower_x3_roles_kernel<true>): w3pk = f16 image of w3 * 2^p, w3pk_lo = the 8-bit image of the cross terms
-    // (per cout tile and 64 k: lanes' 32 bytes [e4m3((w3 * 2^p) - hi) for 64 k ; e4m3(w3 * 2^(p - 11)) for the same 64 k], bytes 0-15 in
-    // "slab" 2 J, bytes 16-31 in "slab" 2 J + 1 of the lo image's geometry), b3 = BN3 bias * 2^p, w3_inv = 2^-p;
-    // lo_scale = the scale operand that makes v_cvt_scalef32_pk_fp8_f32 return e4m3(residual * 2^11)
-    float w3_inv;
-    float lo_scale;
+    // Precision float16p8 (x3.hip, tower_p8_kernel): w1pk = f16 image of w1 * 2^p, w1pk_lo = the 8-bit image of the cross terms (per cout tile and
+    // 64 k: lanes' 32 bytes [e4m3((w1 * 2^p) - hi) for 64 k ; e4m3(w1 * 2^(p - 11)) for the same 64 k], bytes 0-15 in "slab" 2 J, bytes 16-31 in
+    // "slab" 2 J + 1 of the lo image's geometry); w1_inv = 2^-p brings the expand accumulators back in front of the BN1 bias
+    float w1_inv;
 };
 struct X3TowerArgs {
     const float* x;       // [B][64][256]
@@ -104,7 +102,8 @@ struct X3TowerArgs {
     const X3TowerBlock* blocks;   // device array
     int nblocks;
     int batch;
-    int p8;               // Precision float16p8
+    int p8;               // Precision float16p8 (tower_p8_kernel)
+    float lo_scale;       // float16p8: the scale operand that makes v_cvt_scalef32_pk_fp8_f32 return e4m3(residual * 2^11) (it divides: 2^-11)
 };
 void launch_tower_x3(const X3TowerArgs& a, hipStream_t s);
 template <typename T> void init_block_kernel_attributes();

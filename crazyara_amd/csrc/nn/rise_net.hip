@@ -120,7 +120,7 @@ SplitPack pack_dense_split(const Folded& f, int cout, int cin, int ks, int cout_
     return SplitPack{pack_dense<half_t>(fh, cout, cin, ks, cout_pad, cin_pad), pack_dense<half_t>(fl, cout, cin, ks, cout_pad, cin_pad)};
 }
 
-// Precision float16p8, project weights of a tower block (x3.hip: tower_x3_roles_kernel<true>; kernels.h: X3TowerBlock).  W' = w * 2^p with
+// Precision float16p8, expand weights of a tower block (x3.hip: tower_p8_kernel; kernels.h: X3TowerBlock).  W' = w * 2^p with
 // p = 11 - floor(log2(max |w|)) (the largest weight lands in [2048, 4096)): hi = rne_f16(W') is the main term's operand; the 8-bit image
 // holds, per cout tile and 64 k, a lane's 32 bytes -- lane groups 0, 1: e4m3(W' - hi) for k [0, 32), [32, 64) (they meet the
 // activations' hi8), groups 2, 3: e4m3(W' * 2^-11) for the same k (they meet lo8 = e4m3(residual * 2^11)) -- bytes 0-15 in "slab" 2 J,
@@ -268,8 +268,8 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     // the fast mode that meets "logits within 1e-3 of fp32": float activations, every dense contraction as three f16 MFMAs on split
     // operands (x3.hip)
     else if (prec == "float16x3" || prec == "fp16x3" || prec == "f16x3") { fp16_ = false; x3_ = true; }
-    // float16x3 with the cross terms of the tower's project GEMMs on ONE e4m3 MFMA per 64 k (x3.hip: tower_x3_roles_kernel<true>): logits within
-    // 1e-4 of fp32 as well (emulated 2e-5 ... 7e-5 on the parity nets), a third fewer matrix-pipe cycles in that GEMM
+    // float16x3 with the cross terms of the tower's EXPAND GEMMs on ONE e4m3 MFMA per 64 k and the residual stream in the PROJECT waves'
+    // registers (x3.hip: tower_p8_kernel): logits within 1e-4 of fp32 as well (emulated 1e-5 ... 7e-5 on the parity nets)
     else if (prec == "float16p8" || prec == "fp16p8" || prec == "f16p8") { fp16_ = false; x3_ = true; p8_ = true; }
     else throw std::invalid_argument("unsupported precision '" + precision + "' (float16 | float16x3 | float16p8 | float32 | fp8)");
     design_.batch = batch_size;
@@ -566,6 +566,10 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         op.tx.nblocks = int(x3_blocks.size());
         op.tx.batch = B;
         op.tx.p8 = p8_ ? 1 : 0;
+        {   // scale operand of v_cvt_scalef32_pk_fp8_f32 for lo8 = e4m3(residual * 2^11): the instruction DIVIDES by its scale (measured, r04i)
+            const char* ls = getenv("CRA_P8_LO_SCALE");
+            op.tx.lo_scale = ls ? float(atof(ls)) : 1.0f / 2048.0f;
+        }
         im.ops.push_back(op);
         x3_blocks.clear();
         prod_op = -1;                      // this launch does not emit channel sums: a gate behind it is an SE launch of its own
@@ -896,25 +900,16 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             Folded f1 = fold_bn(nf, p + ".body.0", p + ".body.1");
             Folded f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
             Folded f3 = fold_bn(nf, p + ".body.6", p + ".body.7");
-            SplitPack s1 = pack_dense_split(f1, cop, C, 1, cop_pad, C);
-            double w3_inv = 1.0;
-            SplitPack s3 = p8_ ? pack_dense_p8(f3, C, cop, C, cop_pad, &w3_inv) : pack_dense_split(f3, C, cop, 1, C, cop_pad);
+            double w1_inv = 1.0;
+            SplitPack s1 = p8_ ? pack_dense_p8(f1, cop, C, cop_pad, C, &w1_inv) : pack_dense_split(f1, cop, C, 1, cop_pad, C);
+            SplitPack s3 = pack_dense_split(f3, C, cop, 1, C, cop_pad);
             xb.w1pk = im.upload(s1.hi);
             xb.w1pk_lo = im.upload(s1.lo);
             xb.w3pk = im.upload(s3.hi);
             xb.w3pk_lo = im.upload(s3.lo);
             xb.dwpk = im.upload(pack_x3_depthwise_records(f1, f2, cop, cop_pad));
-            if (p8_) {                                                     // the accumulators run in the weights' scale: bias * 2^p, sum * 2^-p
-                std::vector<double> b3s(f3.b);
-                for (double& v : b3s) v /= w3_inv;
-                xb.b3 = im.upload_d2f(b3s, C);
-                xb.w3_inv = float(w3_inv);
-                // scale operand of v_cvt_scalef32_pk_fp8_f32 for lo8 = e4m3(residual * 2^11) (the instruction divides by its scale)
-                const char* ls = getenv("CRA_P8_LO_SCALE");
-                xb.lo_scale = ls ? float(atof(ls)) : 1.0f / 2048.0f;
-            } else {
-                xb.b3 = im.upload_d2f(f3.b, C);
-            }
+            xb.b3 = im.upload_d2f(f3.b, C);
+            xb.w1_inv = float(w1_inv);                                     // float16p8: the expand accumulators run in the weights' scale
             xb.cop_pad = cop_pad;
             x3_blocks.push_back(xb);
             macs += double(kSquares) * cop * (2.0 * C + k * k);

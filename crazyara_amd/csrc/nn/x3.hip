@@ -20,7 +20,8 @@
 
 // CRA_X3_ABL: development switches that TIME parts of the tower's chunk loop (scripts/ubench/x3_tower_ablate.hip); every bit computes wrong
 // results on purpose, so they only compile in a development build.  1: no depthwise arithmetic, 2: no expand MFMAs, 4: no project MFMAs,
-// 8: no LDS operand reads (expand and project), 16: no weight loads, 32: no chunk barriers, 64: no t2 stores
+// 8: no LDS operand reads (expand and project), 16: no weight loads, 32: no chunk barriers, 64: no t2 stores, 128: the expand GEMM issues
+// the mixed split's instruction mix (per 64 k two f16 MFMAs and one e4m3 16x16x128 on whatever the registers hold)
 #ifndef CRA_X3_ABL
 #define CRA_X3_ABL 0
 #endif
@@ -487,7 +488,8 @@ struct X3Depthwise {
 #pragma unroll
         for (int q = 0; q < 11; ++q) w[q] = *reinterpret_cast<const f32x2*>(rec + q * 16 + lg * 4 + 2 * P);
     }
-    template <int P> __device__ __forceinline__ void gather(const f32x4 (&acc)[4], bool upper, float mL, float mR, int c0 = 0, int c1 = 2) {
+    // acc_scale: the accumulators carry the weights' power-of-two scale (Precision float16p8): S = relu(acc * acc_scale + bias), one FMA instead of the add
+    template <int P, bool SCALED = false> __device__ __forceinline__ void gather(const f32x4 (&acc)[4], bool upper, float mL, float mR, int c0 = 0, int c1 = 2, float acc_scale = 1.f) {
         if constexpr (X3_ABL & 1) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) S[1 + t] = pair_of(acc[t], P) + w[0];
@@ -499,7 +501,7 @@ struct X3Depthwise {
             w[0][c] *= mL; w[3][c] *= mL; w[6][c] *= mL;
             w[2][c] *= mR; w[5][c] *= mR; w[8][c] *= mR;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) S[1 + t][c] = fmaxf(acc[t][2 * P + c] + w[9][c], 0.f);
+            for (int t = 0; t < 4; ++t) S[1 + t][c] = SCALED ? fmaxf(fmaf(acc[t][2 * P + c], acc_scale, w[9][c]), 0.f) : fmaxf(acc[t][2 * P + c] + w[9][c], 0.f);
             const float across_up = dpp_mov<DPP_ROW_ROR8>(S[4][c]), across_dn = dpp_mov<DPP_ROW_ROR8>(S[1][c]);
             S[0][c] = upper ? across_up : 0.f;                    // above rank 4 lies rank 3 (tile 3, other half); above rank 0 the edge
             S[5][c] = upper ? 0.f : across_dn;                    // below rank 3 lies rank 4 (tile 0, other half); below rank 7 the edge
@@ -1026,16 +1028,9 @@ __global__ __launch_bounds__(512) void tower_x3_kernel(const X3TowerArgs a) {
 // slower (profiles/r03/h_*) -- alone, its weight stream already runs at 27 TB/s, 80 % of the L2 -> CU peak; s_setprio on the EXPAND
 // waves, a barrier that holds the PROJECT waves back until the expand MFMAs are through (profiles/r03/m_*): nothing / slower;
 // v_pk_fma_f32 for the depthwise: it does not run in the shadow of MFMAs (mix_kinds.hip: 38.5 cycles for MFMA + 2 of them).
-// P8 = Precision float16p8: the PROJECT GEMM takes its cross terms through ONE e4m3 MFMA per 64 k (v_mfma_f32_16x16x128_f8f6f4 on
-// [hi8 | lo8] x [w_lo8 ; w_hi8], split4_p8) beside the two f16 MFMAs of the main term -- 3 instructions of 19.6 + 19.6 + 34.0 issue
-// ticks where float16x3 issues 6 of 19.6 (scripts/ubench/mix_fp8.hip, profiles/r04/h_mix_fp8.log).  The depthwise output t2 is written
-// as f16 hi + e4m3 hi8 + e4m3 lo8 (the same 4 bytes per value); the project weights come scaled by a power of two per block
-// (X3TowerBlock::w3_inv undoes it in the block epilogue).  The expand GEMM and the residual stream are float16x3's.
-template <bool P8>
 __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a) {
     using G = X3Block;
     static_assert(G::NE == 1 && G::T2BUF == 2 && G::CK == 128, "the role kernel uses the NE = 1 tile geometry (two t2 buffers of 128 channels)");
-    if constexpr (P8) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // MODE.FP16_OVFL: conversions to f16 / e4m3 clamp instead of overflowing
     constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const X3Tiles T = x3_tiles(smem);
@@ -1136,6 +1131,11 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                             if (st + 3 < 4 * (C / 32)) read_step(st + 3);
 #pragma unroll
                             for (int ne = 0; ne < 2; ++ne) {
+                                if constexpr ((X3_ABL & 128) != 0) {      // TIMING ONLY (wrong results): the expand GEMM's instruction mix under the mixed split
+                                    x3_mfma(e_h[sl % EW][ne], ring_h[st % 4], accE[ne][t], true);
+                                    if (sl & 1) x3_mfma8(x3_cat(e_l[0][ne], e_l[1][ne]), x3_cat(ring_l[st % 4], ring_l[(st + 1) % 4]), accE[ne][t], true);
+                                    continue;
+                                }
                                 x3_mfma(e_l[sl % EW][ne], ring_h[st % 4], accE[ne][t], !(X3_ABL & 2));
                                 x3_mfma(e_h[sl % EW][ne], ring_l[st % 4], accE[ne][t], !(X3_ABL & 2));
                                 x3_mfma(e_h[sl % EW][ne], ring_h[st % 4], accE[ne][t], !(X3_ABL & 2));
@@ -1153,16 +1153,6 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                             const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                if constexpr (P8) {                  // f16 hi as before; the lo tile's bytes hold hi8 [0, 128) and lo8 [144, 272) of the row
-                                    half4 h;
-                                    uint32_t h8, l8;
-                                    split4_p8(dw.outv[t], h, h8, l8, d.lo_scale);
-                                    char* const row8 = reinterpret_cast<char*>(t2l) + (t * 16 + l15) * (TROW * 2);
-                                    *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
-                                    *reinterpret_cast<uint32_t*>(row8 + cl) = h8;
-                                    *reinterpret_cast<uint32_t*>(row8 + 144 + cl) = l8;
-                                    continue;
-                                }
                                 half4 h, l;
                                 split4(dw.outv[t], h, l);
                                 if constexpr (X3_ABL & 64) {
@@ -1204,104 +1194,6 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
             }
             __syncthreads();                                            // the PROJECT waves' block epilogue
             { const int kk = n; X3_STAMP(5); }
-        } else if constexpr (P8) {
-            // ---- PROJECT role, Precision float16p8: per 64 k of a chunk two f16 steps (main term) and one e4m3 step (both cross terms) ----
-            constexpr int NJ = 4;
-            half8 p_h[2][NJ];                                           // f16 fragments of two k-slabs (slot = slab parity)
-            i32x8_x3 p_8[NJ];                                           // e4m3 fragments of the current 64-k step: [w_lo8 (64 k) ; w_hi8 (64 k)]
-            auto load_ph = [&](int k, int s2) {                        // cout tile = w * 4 + j, K slab = k * 4 + s2
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    p_h[s2 & 1][j] = x3_frag(W.w3h, lane_off, uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + s2));
-            };
-            auto load_p8 = [&](int k, int jj) {                        // a lane's 32 bytes = its 16 of "slab" 2 jj and its 16 of "slab" 2 jj + 1 of the 8-bit image
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const uint32_t f = uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + 2 * jj);
-                    p_8[j] = x3_cat(x3_frag(W.w3l, lane_off, f), x3_frag(W.w3l, lane_off, f + 1));
-                }
-            };
-            f32x4 accP[NJ][4];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {                              // BN3 bias, already in the accumulators' scale (host: b3 * 2^p)
-                const f32x4 bs = *reinterpret_cast<const f32x4*>(d.b3 + (w * NJ + j) * 16 + lg * 4);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) accP[j][t] = bs;
-            }
-            load_ph(0, 0);
-            load_ph(0, 1);
-            load_p8(0, 0);
-            __syncthreads();                                            // intervals 0 and 1: chunk 0 is expanded, then run through the depthwise
-            __syncthreads();
-            for (int kk = 0; kk < n; ++kk) {                            // P(kk) runs in interval kk + 2
-                const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
-                const char* const t28 = reinterpret_cast<const char*>(T.t2l + (kk & 1) * 64 * TROW);
-                const int kn = kk + 1 < n ? kk + 1 : kk;                // (behind the last chunk: a valid address, no branch in the stretch)
-                X3_STAMP(8);
-                half8 bh[2][4];
-                i32x8_x3 b8[4];
-                auto read_h = [&](int s2, half8 (&h)[4]) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) h[t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
-                };
-                auto read_8 = [&](int jj) {                             // lane group lg: 0, 1 = hi8 of k [0, 32), [32, 64) of the step; 2, 3 = lo8 of the same
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const char* pp = t28 + (t * 16 + l15) * (TROW * 2) + (lg >> 1) * 144 + jj * 64 + (lg & 1) * 32;
-                        b8[t] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 16));
-                    }
-                };
-                read_h(0, bh[0]);
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    read_h(2 * jj + 1, bh[1]);
-                    read_8(jj);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) x3_mfma(p_h[0][j], bh[0][t], accP[j][t], true);
-                    if (jj == 0) load_ph(kk, 2); else load_ph(kn, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (jj == 0) read_h(2, bh[0]);
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) x3_mfma(p_h[1][j], bh[1][t], accP[j][t], true);
-                    if (jj == 0) load_ph(kk, 3); else load_ph(kn, 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) x3_mfma8(p_8[j], b8[t], accP[j][t], true);
-                    if (jj == 0) load_p8(kk, 1); else load_p8(kn, 0);
-                    if (jj == 0) X3_STAMP(9);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                X3_STAMP(10);
-                if (kk + 1 < n) __syncthreads();
-                X3_STAMP(11);
-            }
-            // block epilogue: new stream = x + body(x) with the project sum brought back from the weights' scale, split again, in place
-            const float inv = d.w3_inv;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int co0 = (w * NJ + j) * 16 + lg * 4;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int sq = t * 16 + l15;
-                    float rh[4], rl[4], v[4];
-                    load4<half_t>(T.xh + sq * XROW + co0, rh);
-                    load4<half_t>(T.xl + sq * XROW + co0, rl);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaf(accP[j][t][r], inv, rh[r] + rl[r]);
-                    half4 h, l;
-                    split4(v, h, l);
-                    *reinterpret_cast<half4*>(T.xh + sq * XROW + co0) = h;
-                    *reinterpret_cast<half4*>(T.xl + sq * XROW + co0) = l;
-                }
-            }
-            __syncthreads();
         } else {
             // project weight window: 2 of a chunk's 4 k-slabs x 4 cout tiles x (hi, lo), running on across chunk boundaries
 #if defined(CRA_DEVELOPMENT) && defined(CRA_X3_PW)
@@ -1421,11 +1313,380 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
     }
 }
 
+// ================================================================================================================
+// Precision float16p8: the two-role tower with the EXPAND GEMM on the mixed split
+// ================================================================================================================
+// What changes against tower_x3_roles_kernel (measurements: profiles/NOTES.md round 4, sets r04h-l):
+//  * EXPAND GEMM: per 64 k two f16 MFMAs (main term hi x hi) and ONE v_mfma_f32_16x16x128_f8f6f4 on [hi8 | lo8] x [w_lo8 ; w_hi8] (both cross
+//    terms) instead of six f16 MFMAs: the EXPAND waves' instruction stream is the interval (their MFMAs queue behind the partner's in the
+//    SIMD's one matrix pipe), and this is the part of it that shrinks without making their depthwise dearer.  The PROJECT GEMM and the
+//    depthwise output t2 stay float16x3's (the 8-bit form of t2 costs the EXPAND waves more than the PROJECT waves gain, set j; converting on
+//    the PROJECT side is slower still, set k).
+//  * The stream tile in LDS holds the operand forms only: xh = rne_f16(x) and, where float16x3 keeps the lo half, a byte row [hi8 = e4m3(xh),
+//    256 B | lo8 = e4m3((x - xh) * 2^11), 256 B] (split4_p8).
+//  * The residual stream itself lives in the PROJECT waves' accumulators: wave v holds x of its 64 couts x 64 squares in f32 (exact, where
+//    float16x3 rebuilds x = hi + lo from LDS to 2^-22), the project sums of a block are accumulated ON it, and the block epilogue only writes
+//    the operand forms of the new x.  SE gates: squeeze from the registers, gate as before, x *= gate in the registers.
+// The roles are separated at the top level (the PROJECT waves' 64 registers of x must not be live in the EXPAND waves' code).
+namespace {
+// mean[c] (LDS scratch, written by the PROJECT waves) -> gate[c] in LDS: the middle of x3_se_phase, every thread of the workgroup.
+// Ends behind a barrier with se_gate valid.
+__device__ __forceinline__ void x3_se_gate_from_mean(const X3TowerBlock& d, float* scratch, int tid) {
+    constexpr int GRP = 36;
+    float* se_mean = scratch;              // [8][36]
+    float* se_h = scratch + 8 * GRP;       // [4][36]
+    float* se_gate = se_h + 4 * GRP;       // [256]
+    f32x4 wa[16], wb[16];
+    auto load_thread_weights = [&](const float* base, f32x4 (&dst)[16]) {
+        const f32x4* pk = reinterpret_cast<const f32x4*>(base) + tid;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[i] = pk[i * 512];
+    };
+    load_thread_weights(d.se_w1t, wa);
+    load_thread_weights(d.se_kind == 1 ? d.se_w2t : d.se_w1t + size_t(16) * 512 * 4, wb);
+    __syncthreads();                                                    // the means are in
+    auto dot32 = [](const f32x4 (&w)[16], const float* v, float& s0, float& s1) {
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(v + 4 * k4);
+            s0 = fmaf(w[2 * k4][0], m[0], s0); s1 = fmaf(w[2 * k4][1], m[0], s1);
+            s0 = fmaf(w[2 * k4][2], m[1], s0); s1 = fmaf(w[2 * k4][3], m[1], s1);
+            s0 = fmaf(w[2 * k4 + 1][0], m[2], s0); s1 = fmaf(w[2 * k4 + 1][1], m[2], s1);
+            s0 = fmaf(w[2 * k4 + 1][2], m[3], s0); s1 = fmaf(w[2 * k4 + 1][3], m[3], s1);
+        }
+    };
+    if (d.se_kind == 1) {
+        {
+            const int j2 = tid >> 3, kq = tid & 7;
+            float s0 = 0.f, s1 = 0.f;
+            dot32(wa, se_mean + kq * GRP, s0, s1);
+            s0 += dpp_mov<0x111>(s0); s1 += dpp_mov<0x111>(s1);
+            s0 += dpp_mov<0x112>(s0); s1 += dpp_mov<0x112>(s1);
+            s0 += dpp_mov<0x114>(s0); s1 += dpp_mov<0x114>(s1);
+            if (kq == 7) {
+                float* h = se_h + (j2 >> 4) * GRP + 2 * (j2 & 15);
+                h[0] = fmaxf(s0, 0.f);
+                h[1] = fmaxf(s1, 0.f);
+            }
+        }
+        __syncthreads();
+        {
+            const int c2 = tid >> 2, kq = tid & 3;
+            float s0 = 0.f, s1 = 0.f;
+            dot32(wb, se_h + kq * GRP, s0, s1);
+            s0 += dpp_mov<0x111>(s0); s1 += dpp_mov<0x111>(s1);
+            s0 += dpp_mov<0x112>(s0); s1 += dpp_mov<0x112>(s1);
+            if (kq == 3) {
+                se_gate[2 * c2] = hard_sigmoid(s0);
+                se_gate[2 * c2 + 1] = hard_sigmoid(s1);
+            }
+        }
+    } else {
+        const int c2 = tid >> 2, kq = tid & 3;
+        float s0 = 0.f, s1 = 0.f;
+        dot32(wa, se_mean + (2 * kq) * GRP, s0, s1);
+        dot32(wb, se_mean + (2 * kq + 1) * GRP, s0, s1);
+        s0 += dpp_mov<0x111>(s0); s1 += dpp_mov<0x111>(s1);
+        s0 += dpp_mov<0x112>(s0); s1 += dpp_mov<0x112>(s1);
+        if (kq == 3) {
+            se_gate[2 * c2] = hard_sigmoid(d.se_b[2 * c2] + s0);
+            se_gate[2 * c2 + 1] = hard_sigmoid(d.se_b[2 * c2 + 1] + s1);
+        }
+    }
+    __syncthreads();
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
+    using G = X3Block;
+    static_assert(G::NE == 1 && G::T2BUF == 2 && G::CK == 128, "the role kernels use the NE = 1 tile geometry");
+    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, X8ROW = XROW * 2, NJ = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const X3Tiles T = x3_tiles(smem);
+    char* const x8 = reinterpret_cast<char*>(T.xl);                    // [64][544 B]: hi8 bytes [0, 256), lo8 bytes [272, 528) of a row
+    float* const se_scratch = reinterpret_cast<float*>(T.t2h);         // idle between blocks
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);                        // MODE.FP16_OVFL: conversions to f16 / e4m3 clamp instead of overflowing
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wave & 3;
+    const uint32_t lane_off = uint32_t(lane) * 16u;
+    const float lo_scale = a.lo_scale;
+
+    if (wave < 4) {
+        // =================================================== EXPAND waves ===================================================
+        const bool hi = l15 >= 8;
+        const float mL = (l15 & 7) != 0 ? 1.f : 0.f;
+        const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
+        __syncthreads();                                                // the PROJECT waves have written block 0's operand tiles
+        for (int blk = 0; blk < a.nblocks; ++blk) {
+            const X3TowerBlock& d = a.blocks[blk];
+            if (blk > 0 && d.se_kind != 0) {
+                x3_se_gate_from_mean(d, se_scratch, tid);               // (the squeeze and the rescaling are the PROJECT waves')
+                __syncthreads();                                        // the gated operand tiles are written
+            }
+            const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
+            const int n = W.cop_pad / CK;
+            const float e_inv = d.w1_inv;
+            // window: f16 fragments of two k-slabs (slot = slab parity) and the e4m3 fragments of one 64-k step, for the wave's two channel tiles
+            half8 e_h[2][2];
+            i32x8_x3 e_8[2];
+            auto load_eh = [&](int i, int s) {                          // cout tile of (chunk i, wave w, ne) = i * 8 + w * 2 + ne
+#pragma unroll
+                for (int ne = 0; ne < 2; ++ne) e_h[s & 1][ne] = x3_frag(W.w1h, lane_off, uint32_t(i * (CK / 16) + w * 2 + ne) * (C / 32) + uint32_t(s));
+            };
+            auto load_e8 = [&](int i, int J) {                          // a lane's 32 bytes: its 16 of "slab" 2 J and its 16 of "slab" 2 J + 1 of the 8-bit image
+#pragma unroll
+                for (int ne = 0; ne < 2; ++ne) {
+                    const uint32_t f = uint32_t(i * (CK / 16) + w * 2 + ne) * (C / 32) + uint32_t(2 * J);
+                    e_8[ne] = x3_cat(x3_frag(W.w1l, lane_off, f), x3_frag(W.w1l, lane_off, f + 1));
+                }
+            };
+            load_eh(0, 0);
+            load_eh(0, 1);
+            load_e8(0, 0);
+            float* const my_dws = T.dws + (w * 2) * 256;
+            f32x4 accE[2][4], accD[2][4];
+            X3Depthwise dw;
+            // Interval i: E(i) (HASE) with D(i - 1) (HASD) in sixteen pieces, two per k-slab, as in tower_x3_roles_kernel.  A k-slab issues its 8
+            // f16 MFMAs; an ODD slab then the 8 e4m3 MFMAs of its 64-k step.
+            auto interval = [&](auto hase_c, auto hasd_c, int i) {
+                constexpr bool HASE = decltype(hase_c)::value, HASD = decltype(hasd_c)::value;
+                half8 ring_h[4];                                        // f16 operand of step st = slab * 4 + square tile, requested 3 steps ahead
+                i32x8_x3 ring_8[3];                                     // e4m3 operand of step q = (64-k step) * 4 + square tile, requested 2 steps ahead
+                auto read_h = [&](int st) {
+                    ring_h[st % 4] = *reinterpret_cast<const half8*>(T.xh + ((st & 3) * 16 + l15) * XROW + (st >> 2) * 32 + lg * 8);
+                };
+                auto read_8 = [&](int q) {                              // lane group lg: 0, 1 = hi8 of k [0, 32), [32, 64) of the step; 2, 3 = lo8 of the same
+                    const char* pp = x8 + ((q & 3) * 16 + l15) * X8ROW + (lg >> 1) * 272 + (q >> 2) * 64 + (lg & 1) * 32;
+                    ring_8[q % 3] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 16));
+                };
+                f32x4 dw_raw[2];
+                const int inext = i + 1 < n ? i + 1 : i;                // (behind the last chunk: a valid address, no branch in the stretch)
+                if constexpr (HASE) {
+#pragma unroll
+                    for (int ne = 0; ne < 2; ++ne)
+                        dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(i * CK + (w * 2 + ne) * 16) * 48u, 0));
+#pragma unroll
+                    for (int ne = 0; ne < 2; ++ne)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) accE[ne][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    read_h(0); read_h(1); read_h(2);
+                    read_8(0); read_8(1);
+                }
+                if constexpr (HASD) dw.template load<0>(my_dws, lg);
+                half_t* const t2h = T.t2h + ((i - 1) & 1) * 64 * TROW;
+                half_t* const t2l = T.t2l + ((i - 1) & 1) * 64 * TROW;
+#pragma unroll
+                for (int sl = 0; sl < C / 32; ++sl) {
+                    const int dt = sl / 4, ph = sl % 4;
+                    if constexpr (HASD) {
+                        if (ph == 2) dw.template load<1>(my_dws + dt * 256, lg);
+                        if (sl == 4) dw.template load<0>(my_dws + 256, lg);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (HASE) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int st = sl * 4 + t;
+                            if (st + 3 < 4 * (C / 32)) read_h(st + 3);
+#pragma unroll
+                            for (int ne = 0; ne < 2; ++ne) x3_mfma(e_h[sl & 1][ne], ring_h[st % 4], accE[ne][t], true);
+                            if (sl & 1) {
+                                const int q = (sl >> 1) * 4 + t;
+                                if (q + 2 < 4 * (C / 64)) read_8(q + 2);
+#pragma unroll
+                                for (int ne = 0; ne < 2; ++ne) x3_mfma8(e_8[ne], ring_8[q % 3], accE[ne][t], true);
+                            }
+                        }
+                        if (sl + 2 < C / 32) load_eh(i, sl + 2); else load_eh(inext, sl + 2 - C / 32);
+                        if (sl & 1) { if ((sl >> 1) + 1 < C / 64) load_e8(i, (sl >> 1) + 1); else load_e8(inext, 0); }
+                    }
+                    if constexpr (HASD) {
+                        if (ph == 0) dw.template gather<0, true>(accD[dt], hi, mL, mR, 0, 2, e_inv);
+                        if (ph == 1) { dw.template taps<0>(0, 4); dw.pin_taps(0, 4, 0); }
+                        if (ph == 2) dw.template gather<1, true>(accD[dt], hi, mL, mR, 0, 2, e_inv);
+                        if (ph == 3) {
+                            dw.template taps<1>(0, 4);
+                            const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1 (float16x3's form)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                half4 h, l;
+                                split4(dw.outv[t], h, l);
+                                *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
+                                *reinterpret_cast<half4*>(t2l + (t * 16 + l15) * TROW + cl) = l;
+                            }
+                        }
+                    }
+                    if constexpr (HASE && HASD) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {                   // behind every MFMA up to four VALU instructions
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (HASE) {                                    // the depthwise is through with chunk i - 1: its records and accumulators make room
+#pragma unroll
+                    for (int ne = 0; ne < 2; ++ne) *reinterpret_cast<f32x4*>(my_dws + ne * 256 + lane * 4) = dw_raw[ne];
+#pragma unroll
+                    for (int ne = 0; ne < 2; ++ne)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) accD[ne][t] = accE[ne][t];
+                }
+            };
+            for (int i = 0; i <= n; ++i) {
+                if (i == 0) interval(std::true_type{}, std::false_type{}, i);
+                else if (i < n) interval(std::true_type{}, std::true_type{}, i);
+                else interval(std::false_type{}, std::true_type{}, i);
+                __syncthreads();
+            }
+            __syncthreads();                                            // the PROJECT waves' block epilogue
+        }
+        return;
+    }
+
+    // =================================================== PROJECT waves ===================================================
+    // the residual stream of this wave's 64 couts: accX[j][t][r] = x[square of tile row t * 16 + l15][cout (w * 4 + j) * 16 + lg * 4 + r]
+    f32x4 accX[NJ][4];
+    {
+        const float* xb = a.x + size_t(b) * 64 * C;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                accX[j][t] = *reinterpret_cast<const f32x4*>(xb + size_t(x3_square(t * 16 + l15)) * C + (w * NJ + j) * 16 + lg * 4);
+    }
+    auto write_tiles = [&]() {                                          // the operand forms of x: xh, hi8, lo8 (this wave's 64 channel columns)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int co0 = (w * NJ + j) * 16 + lg * 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int rr = t * 16 + l15;
+                float v[4] = {accX[j][t][0], accX[j][t][1], accX[j][t][2], accX[j][t][3]};
+                half4 h;
+                uint32_t h8, l8;
+                split4_p8(v, h, h8, l8, lo_scale);
+                *reinterpret_cast<half4*>(T.xh + rr * XROW + co0) = h;
+                *reinterpret_cast<uint32_t*>(x8 + rr * X8ROW + co0) = h8;
+                *reinterpret_cast<uint32_t*>(x8 + rr * X8ROW + 272 + co0) = l8;
+            }
+        }
+    };
+    write_tiles();
+    __syncthreads();
+    for (int blk = 0; blk < a.nblocks; ++blk) {
+        const X3TowerBlock& d = a.blocks[blk];
+        if (blk > 0 && d.se_kind != 0) {
+            // squeeze (AdaptiveAvgPool2d) from the registers: sum over the four square tiles, then over the 16 lanes of the row
+            constexpr int GRP = 36;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float sum[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] = (accX[j][0][r] + accX[j][1][r]) + (accX[j][2][r] + accX[j][3][r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sum[r] += dpp_mov<0x111>(sum[r]);
+                    sum[r] += dpp_mov<0x112>(sum[r]);
+                    sum[r] += dpp_mov<0x114>(sum[r]);
+                    sum[r] += dpp_mov<0x118>(sum[r]);                    // lane 15 of the row holds the row's sum
+                }
+                if (l15 == 15) {
+                    const int c = (w * NJ + j) * 16 + lg * 4;            // channel c at (c / 32) * 36 + c % 32
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) se_scratch[((c + r) >> 5) * GRP + ((c + r) & 31)] = sum[r] * (1.f / 64.f);
+                }
+            }
+            x3_se_gate_from_mean(d, se_scratch, tid);
+            const float* se_gate = se_scratch + 12 * GRP;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {                              // x := x * gate (the residual uses the gated x, builder_util.py:473-475)
+                const f32x4 g = *reinterpret_cast<const f32x4*>(se_gate + (w * NJ + j) * 16 + lg * 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accX[j][t] *= g;
+            }
+            write_tiles();
+            __syncthreads();
+        }
+        const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
+        const int n = W.cop_pad / CK;
+        const int nslab3 = W.cop_pad >> 5;
+        constexpr int PW = 2;
+        half8 p_h[PW][NJ], p_l[PW][NJ];
+        auto load_p = [&](int k, int s2) {                             // cout tile = w * 4 + j, K slab = k * 4 + s2
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const uint32_t f = uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + s2);
+                p_h[s2 % PW][j] = x3_frag(W.w3h, lane_off, f);
+                p_l[s2 % PW][j] = x3_frag(W.w3l, lane_off, f);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {                                  // + BN3 bias; the project sums of the block are accumulated on x itself
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(d.b3 + (w * NJ + j) * 16 + lg * 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) accX[j][t] += bs;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < PW; ++s2) load_p(0, s2);
+        __syncthreads();                                                // intervals 0 and 1: chunk 0 is expanded, then run through the depthwise
+        __syncthreads();
+        for (int kk = 0; kk < n; ++kk) {                                // P(kk) runs in interval kk + 2
+            const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
+            const half_t* const t2l = T.t2l + (kk & 1) * 64 * TROW;
+            half8 bh[2][4], bl[2][4];
+            auto read_t2 = [&](int s2, half8 (&h)[4], half8 (&l)[4]) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    h[t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                    l[t] = *reinterpret_cast<const half8*>(t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                }
+            };
+            read_t2(0, bh[0], bl[0]);
+#pragma unroll
+            for (int s2 = 0; s2 < CK / 32; ++s2) {
+                if (s2 + 1 < CK / 32) read_t2(s2 + 1, bh[(s2 + 1) & 1], bl[(s2 + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) x3_mfma(p_l[s2 % PW][j], bh[s2 & 1][t], accX[j][t], true);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bl[s2 & 1][t], accX[j][t], true);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[s2 & 1][t], accX[j][t], true);
+                if (s2 + PW < CK / 32) load_p(kk, s2 + PW);
+                else load_p(kk + 1 < n ? kk + 1 : kk, s2 + PW - CK / 32);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kk + 1 < n) __syncthreads();
+        }
+        // block epilogue: accX IS the new stream; its operand forms go to LDS unless the next block gates it first (the SE phase writes them then)
+        const bool next_gated = blk + 1 < a.nblocks && a.blocks[blk + 1].se_kind != 0;
+        if (!next_gated) write_tiles();
+        __syncthreads();
+    }
+    // the stream -> HBM straight from the registers (64-byte pieces per square and lane group)
+    float* yb = a.y + size_t(b) * 64 * C;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            *reinterpret_cast<f32x4*>(yb + size_t(x3_square(t * 16 + l15)) * C + (w * NJ + j) * 16 + lg * 4) = accX[j][t];
+}
+
 void init_x3_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
 }
 int block_x3_chunk_channels() { return X3Block::CK; }
 
@@ -1439,9 +1700,9 @@ void launch_tower_x3(const X3TowerArgs& a, hipStream_t s) {
     const bool symmetric = e != nullptr && e[0] == 's';
     if (a.p8) {
         if (symmetric) throw std::invalid_argument("Precision float16p8 runs the two-role tower only");
-        hipLaunchKernelGGL(tower_x3_roles_kernel<true>, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+        hipLaunchKernelGGL(tower_p8_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
     } else if (symmetric) hipLaunchKernelGGL(tower_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
-    else hipLaunchKernelGGL(tower_x3_roles_kernel<false>, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+    else hipLaunchKernelGGL(tower_x3_roles_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
 }
 
 }  // namespace cra

@@ -272,11 +272,12 @@ def _x3_layer(sd, x, conv, bn, padding=0):
     return _x3_conv(x, sd[conv + ".weight"].double(), padding)
 
 
-# Precision float16p8 = float16x3 whose one-launch tower (3x3 bottleneck blocks at 256 channels) runs its PROJECT contraction as
-#   f16 main term  hi(t) * hi(W')                                   W' = w * 2^p, p = 11 - floor(log2(max |w|)) over the layer (BN folded, double)
-# + e4m3 cross term e4m3(hi(t)) * e4m3(W' - hi(W'))                 hi(.) = rne_f16, t = the depthwise output (f32)
-# + e4m3 cross term e4m3((t - hi(t)) * 2^11) * e4m3(W' * 2^-11)     (e4m3 = OCP e4m3fn, round to nearest even, clamped at +-448)
-# all three carrying 2^p, exact accumulation here (f32 in the kernel), the sum times 2^-p.  Everything else is forward_x3.
+# Precision float16p8 = float16x3 whose one-launch tower (3x3 bottleneck blocks at 256 channels) runs its EXPAND contraction as
+#   f16 main term  hi(x) * hi(W')                                   W' = w * 2^p, p = 11 - floor(log2(max |w|)) over the layer (BN folded, double)
+# + e4m3 cross term e4m3(hi(x)) * e4m3(W' - hi(W'))                 hi(.) = rne_f16, x = the residual stream (f32: it lives in registers there)
+# + e4m3 cross term e4m3((x - hi(x)) * 2^11) * e4m3(W' * 2^-11)     (e4m3 = OCP e4m3fn, round to nearest even, clamped at +-448)
+# all three carrying 2^p, exact accumulation here (f32 in the kernel), the sum times 2^-p in front of the BN1 bias.  The project contraction is
+# float16x3's, accumulated on the f32 residual itself (x + b3 + sum), everything outside the tower is forward_x3.
 def _p8_conv(x, w):
     m = w.abs().max()
     e = torch.floor(torch.log2(m)) if float(m) > 0 else torch.tensor(0.0, dtype=torch.float64)
@@ -329,14 +330,15 @@ def forward_x3(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, p8
             continue
         if se is not None:
             h = gate(h, True)
-        t = F.relu(_x3_layer(sd, h, p + ".body.0", p + ".body.1"))
+        in_p8_tower = p8 and k == 3 and h.shape[1] == 256      # a block of the one-launch tower
+        if in_p8_tower:
+            w1, b1 = _fold(sd, p + ".body.0", p + ".body.1")
+            t = F.relu(_p8_conv(h, w1) + b1.float().view(1, -1, 1, 1))
+        else:
+            t = F.relu(_x3_layer(sd, h, p + ".body.0", p + ".body.1"))
         cop = t.shape[1]
         t = F.relu(_bn(sd, p + ".body.4", F.conv2d(t, sd[p + ".body.3.weight"], padding=k // 2, groups=cop)))
-        if p8 and k == 3 and h.shape[1] == 256:            # a block of the one-launch tower
-            w3, b3 = _fold(sd, p + ".body.6", p + ".body.7")
-            h = h + (_p8_conv(t, w3) + b3.float().view(1, -1, 1, 1))
-        else:
-            h = h + _x3_layer(sd, t, p + ".body.6", p + ".body.7")
+        h = h + _x3_layer(sd, t, p + ".body.6", p + ".body.7")
     B = x.shape[0]
     ph = F.relu(_x3_layer(sd, h, "policy_head.body.0", "policy_head.body.1", 1))
     if cfg.select_policy_from_plane:

@@ -21,7 +21,8 @@
 // CRA_X3_ABL: development switches that TIME parts of the tower's chunk loop (scripts/ubench/x3_tower_ablate.hip); every bit computes wrong
 // results on purpose, so they only compile in a development build.  1: no depthwise arithmetic, 2: no expand MFMAs, 4: no project MFMAs,
 // 8: no LDS operand reads (expand and project), 16: no weight loads, 32: no chunk barriers, 64: no t2 stores, 128: the expand GEMM issues
-// the mixed split's instruction mix (per 64 k two f16 MFMAs and one e4m3 16x16x128 on whatever the registers hold)
+// the mixed split's instruction mix (per 64 k two f16 MFMAs and one e4m3 16x16x128 on whatever the registers hold), 256 (tower_p8_kernel):
+// a quarter of the depthwise moves from the EXPAND to the PROJECT waves (on whatever LDS holds)
 #ifndef CRA_X3_ABL
 #define CRA_X3_ABL 0
 #endif
@@ -1428,6 +1429,10 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
             const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
             const int n = W.cop_pad / CK;
             const float e_inv = d.w1_inv;
+#ifdef CRA_X3_TRACE
+            const bool tracing = (b == 0 || b == 131) && blk == CRA_X3_TRACE;
+            int trace_n = 0;
+#endif
             // window: f16 fragments of two k-slabs (slot = slab parity) and the e4m3 fragments of one 64-k step, for the wave's two channel tiles
             half8 e_h[2][2];
             i32x8_x3 e_8[2];
@@ -1491,12 +1496,12 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                             const int st = sl * 4 + t;
                             if (st + 3 < 4 * (C / 32)) read_h(st + 3);
 #pragma unroll
-                            for (int ne = 0; ne < 2; ++ne) x3_mfma(e_h[sl & 1][ne], ring_h[st % 4], accE[ne][t], true);
+                            for (int ne = 0; ne < 2; ++ne) x3_mfma(e_h[sl & 1][ne], ring_h[st % 4], accE[ne][t], !(X3_ABL & 2));
                             if (sl & 1) {
                                 const int q = (sl >> 1) * 4 + t;
                                 if (q + 2 < 4 * (C / 64)) read_8(q + 2);
 #pragma unroll
-                                for (int ne = 0; ne < 2; ++ne) x3_mfma8(e_8[ne], ring_8[q % 3], accE[ne][t], true);
+                                for (int ne = 0; ne < 2; ++ne) x3_mfma8(e_8[ne], ring_8[q % 3], accE[ne][t], !(X3_ABL & 2));
                             }
                         }
                         if (sl + 2 < C / 32) load_eh(i, sl + 2); else load_eh(inext, sl + 2 - C / 32);
@@ -1505,14 +1510,18 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                     if constexpr (HASD) {
                         if (ph == 0) dw.template gather<0, true>(accD[dt], hi, mL, mR, 0, 2, e_inv);
                         if (ph == 1) { dw.template taps<0>(0, 4); dw.pin_taps(0, 4, 0); }
-                        if (ph == 2) dw.template gather<1, true>(accD[dt], hi, mL, mR, 0, 2, e_inv);
+                        if (ph == 2 && !((X3_ABL & 256) && dt == 1)) dw.template gather<1, true>(accD[dt], hi, mL, mR, 0, 2, e_inv);
                         if (ph == 3) {
-                            dw.template taps<1>(0, 4);
+                            if (!((X3_ABL & 256) && dt == 1)) dw.template taps<1>(0, 4);
                             const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1 (float16x3's form)
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 half4 h, l;
                                 split4(dw.outv[t], h, l);
+                                if constexpr ((X3_ABL & 64) != 0) {
+                                    asm volatile("" ::"v"(h), "v"(l));
+                                    continue;
+                                }
                                 *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
                                 *reinterpret_cast<half4*>(t2l + (t * 16 + l15) * TROW + cl) = l;
                             }
@@ -1537,12 +1546,17 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                 }
             };
             for (int i = 0; i <= n; ++i) {
+                const int kk = i - 1;                                    // (stamp bookkeeping)
+                X3_STAMP(0);
                 if (i == 0) interval(std::true_type{}, std::false_type{}, i);
                 else if (i < n) interval(std::true_type{}, std::true_type{}, i);
                 else interval(std::false_type{}, std::true_type{}, i);
+                X3_STAMP(3);
                 __syncthreads();
+                X3_STAMP(4);
             }
             __syncthreads();                                            // the PROJECT waves' block epilogue
+            { const int kk = n; X3_STAMP(5); }
         }
         return;
     }
@@ -1614,6 +1628,10 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
         const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
         const int n = W.cop_pad / CK;
         const int nslab3 = W.cop_pad >> 5;
+#ifdef CRA_X3_TRACE
+        const bool tracing = (b == 0 || b == 131) && blk == CRA_X3_TRACE;
+        int trace_n = 0;
+#endif
         constexpr int PW = 2;
         half8 p_h[PW][NJ], p_l[PW][NJ];
         auto load_p = [&](int k, int s2) {                             // cout tile = w * 4 + j, K slab = k * 4 + s2
@@ -1637,6 +1655,28 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
         for (int kk = 0; kk < n; ++kk) {                                // P(kk) runs in interval kk + 2
             const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
             const half_t* const t2l = T.t2l + (kk & 1) * 64 * TROW;
+            X3_STAMP(8);
+            if constexpr ((X3_ABL & 256) != 0) {      // TIMING ONLY: a quarter of a chunk's depthwise (channel pair 1 of the partner's second tile) on this wave
+                const bool hi_ = l15 >= 8;
+                const float mL_ = (l15 & 7) != 0 ? 1.f : 0.f, mR_ = (l15 & 7) != 7 ? 1.f : 0.f;
+                f32x4 hacc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) hacc[t] = *reinterpret_cast<const f32x4*>(T.dws + ((w * 2 + 1) * 256 + ((lane * 4 + t * 16) & 255)));
+                X3Depthwise dw2;
+                dw2.template load<1>(T.dws + (w * 2 + 1) * 256, lg);
+                dw2.template gather<1, true>(hacc, hi_, mL_, mR_, 0, 2, d.w1_inv);
+                dw2.template taps<1>(0, 4);
+                half_t* const o2h = T.t2h + ((kk + 1) & 1) * 64 * TROW;
+                half_t* const o2l = T.t2l + ((kk + 1) & 1) * 64 * TROW;
+                const int cl = (w * 2 + 1) * 16 + lg * 4 + 2;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    uint32_t h_, l_;
+                    split_pair(dw2.outv[t][2], dw2.outv[t][3], h_, l_);
+                    *reinterpret_cast<uint32_t*>(o2h + (t * 16 + l15) * TROW + cl) = h_;
+                    *reinterpret_cast<uint32_t*>(o2l + (t * 16 + l15) * TROW + cl) = l_;
+                }
+            }
             half8 bh[2][4], bl[2][4];
             auto read_t2 = [&](int s2, half8 (&h)[4], half8 (&l)[4]) {
 #pragma unroll
@@ -1653,25 +1693,29 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) x3_mfma(p_l[s2 % PW][j], bh[s2 & 1][t], accX[j][t], true);
+                    for (int t = 0; t < 4; ++t) x3_mfma(p_l[s2 % PW][j], bh[s2 & 1][t], accX[j][t], !(X3_ABL & 4));
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bl[s2 & 1][t], accX[j][t], true);
+                    for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bl[s2 & 1][t], accX[j][t], !(X3_ABL & 4));
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[s2 & 1][t], accX[j][t], true);
+                    for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[s2 & 1][t], accX[j][t], !(X3_ABL & 4));
                 if (s2 + PW < CK / 32) load_p(kk, s2 + PW);
                 else load_p(kk + 1 < n ? kk + 1 : kk, s2 + PW - CK / 32);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            X3_STAMP(10);
             if (kk + 1 < n) __syncthreads();
+            X3_STAMP(11);
         }
         // block epilogue: accX IS the new stream; its operand forms go to LDS unless the next block gates it first (the SE phase writes them then)
         const bool next_gated = blk + 1 < a.nblocks && a.blocks[blk + 1].se_kind != 0;
         if (!next_gated) write_tiles();
+        { const int kk = n; X3_STAMP(12); }
         __syncthreads();
+        { const int kk = n; X3_STAMP(13); }
     }
     // the stream -> HBM straight from the registers (64-byte pieces per square and lane group)
     float* yb = a.y + size_t(b) * 64 * C;

@@ -1,0 +1,5 @@
+#!/bin/bash
+OUT=$(pwd)/gpurun_out/r04n
+mkdir -p $OUT
+CRA_X3_TOWER=roles scripts/ubench/x3_trace_blk10.bin 256 19 5 1 > $OUT/trace_p8.txt 2>&1
+head -1 $OUT/trace_p8.txt

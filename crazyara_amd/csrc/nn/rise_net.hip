@@ -1415,7 +1415,7 @@ const char* RiseNet::op_name(int i) const {
         case OpKind::ResTower: return "restower";
         case OpKind::Stem: return "stem";
         case OpKind::Forward: return "forward";
-        case OpKind::TowerX3: return "tower_x3";
+        case OpKind::TowerX3: return op.tx.p8 ? "tower_p8" : "tower_x3";
     }
     return "?";
 }

@@ -16,14 +16,14 @@ from crazyara_amd.neuralnetapi import HipAPI
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("value_head", ["one", "three"])
-def test_two_lane_float16x3_searches_reproduce_200_times(tmp_path, hip_lib, monkeypatch, value_head):
+@pytest.mark.parametrize("precision,value_head", [("float16x3", "one"), ("float16x3", "three"), ("float16p8", "one")])
+def test_two_lane_float16x3_searches_reproduce_200_times(tmp_path, hip_lib, monkeypatch, precision, value_head):
     monkeypatch.setenv("CRA_X3_VALUE_HEAD", value_head)          # read when a net is built
     monkeypatch.setenv("CRA_LANE_RECORD", "1")                   # read when a pool's lanes are made
     cfg, sd, _ = nn_cases.make_case("risev2-3")
     d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
     fens = openings.position_fens("crazyhouse")[20:28]
-    nets = [HipAPI(0, 64, d, "float16x3") for _ in range(2)]
+    nets = [HipAPI(0, 64, d, precision) for _ in range(2)]
     first, differing_runs, replay_words, reports = None, [], 0, []
     for run in range(200):
         st = search.default_settings(mode=0, version_major=1, batch_size=16, seed=3)

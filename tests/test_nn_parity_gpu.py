@@ -96,7 +96,7 @@ def test_dense_tower_kernel_shapes(tmp_path, hip_lib, name, variant):
     assert np.abs(logits - g["logits"]).max() < logit_tol(tol, g["logits"])
 
 
-@pytest.mark.parametrize("precision", ["float16", "float16x3"])
+@pytest.mark.parametrize("precision", ["float16", "float16x3", "float16p8"])
 @pytest.mark.parametrize("case", ["risev2-7", "alphazero-3-cv8"])
 @pytest.mark.parametrize("batch", [1, 3, 300])
 def test_tower_and_head_kernels_any_batch_size(tmp_path, hip_lib, batch, case, precision):
@@ -166,7 +166,7 @@ def test_submit_wait_and_device_resident_paths_agree(tmp_path, hip_lib):
     ("rise-classical-3-se", "float16", 40), ("alphazero-3-se", "float16", 40), ("risev2-3-flat", "float16", 64), ("risev33-wdlp", "float16", 64),
     ("risev2-7", "float32", 20), ("risev2-7", "float16-perblock", 20), ("risev2-7", "float16-unfused", 20), ("risev33", "float32-unfused", 8),
     ("risev2-13-lichess", "float16", 64), ("risev2-7", "float16x3", 20), ("risev33-wdlp", "float16x3", 9), ("alphazero-3-se", "float16x3", 9),
-    ("risev2-3-flat", "float16x3", 9)])
+    ("risev2-3-flat", "float16x3", 9), ("risev2-7", "float16p8", 20), ("risev33-wdlp", "float16p8", 9), ("risev2-13-lichess", "float16p8", 5)])
 def test_every_kernel_family_is_bit_identical_whatever_the_cus_held_before(tmp_path, hip_lib, lds_poison, name, precision, batch):
     """tests/test_fp8.py's call-to-call check (LDS of every CU poisoned with a different pattern before each forward) over the other
     kernel families: dense towers in one launch, per-block and layer-granular kernels, float32, flat and WDLP heads, lichess tables."""
@@ -189,7 +189,7 @@ def test_every_kernel_family_is_bit_identical_whatever_the_cus_held_before(tmp_p
 
 
 @pytest.mark.parametrize("name,precision", [("risev2-7", "float16"), ("risev33-wdlp", "float16"), ("risev2-3-flat", "float16"),
-                                            ("alphazero-5", "float16"), ("risev2-7", "float32"), ("risev2-7", "float16x3")])
+                                            ("alphazero-5", "float16"), ("risev2-7", "float32"), ("risev2-7", "float16x3"), ("risev2-7", "float16p8")])
 def test_zero_copy_predict_equals_copied_predict(tmp_path, hip_lib, name, precision):
     """predict() with the caller's buffers in pinned memory (NeuralNetAPIUser, neuralnetapiuser.cpp:50-60) issues no copy commands: the
     kernels read the planes and write value / probabilities / aux in place.  Same bits as the copy path (pageable numpy buffers),

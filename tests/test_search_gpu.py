@@ -97,7 +97,7 @@ def test_lane_count_does_not_change_the_trees(tmp_path, hip_lib):
         assert len(visits) == len(env.Position(f, False, "crazyhouse").legal_uci())      # Dirichlet: root fully expanded
 
 
-@pytest.mark.parametrize("precision", ["float16", "fp8", "float16x3"])
+@pytest.mark.parametrize("precision", ["float16", "fp8", "float16x3", "float16p8"])
 def test_priors_gathered_on_the_gpu_equal_whole_probability_vectors(tmp_path, hip_lib, monkeypatch, precision):
     """The HIP lanes bring back only the probabilities of the new nodes' legal moves (gather kernel behind the forward, ~40 KB per
     batch instead of 5.3 MB).  The same searches with the gather switched off, and with room for 4 entries per slot (fallback on

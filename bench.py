@@ -261,32 +261,43 @@ def config_search_legs(args, device, threads):
     from crazyara_amd.neuralnetapi import HipAPI
     out = {}
 
-    def nets_for(cfg, version, batch, lanes, seed):
+    other = getattr(args, "search_precision_other", None)
+    if other == args.precision:
+        other = None
+
+    def nets_for(cfg, version, batch, lanes, seed, precision=None):
         sd = rise_config.make_state_dict(cfg, seed=seed, stress=True)
         d = tempfile.mkdtemp(prefix="cra_bench_cfg_")
         netfile.export_rise(os.path.join(d, f"{cfg.name}-v{version}.cranet"), cfg, sd, input_version=version)
-        return [HipAPI(device, batch, d, args.precision) for _ in range(lanes)]
+        return [HipAPI(device, batch, d, precision or args.precision) for _ in range(lanes)]
 
-    def leg(name, workload, cfg, version, mode, batch, lanes, quota, sims, positions, trees, shared=0):
-        nets = nets_for(cfg, version, batch, lanes, seed=31)
+    def leg(name, workload, cfg, version, mode, batch, lanes, quota, sims, positions, trees, shared=0, also_other=False):
+        """The leg with nets of the line's precision mode; also_other: once more (one repeat) with nets of --search-precision-other,
+        reported inside the same entry as mcts_nodes_per_sec_<mode>."""
         st = search.default_settings(mode=mode, version_major=int(version.split(".")[0]), batch_size=quota)
         leg_threads = min(threads, shared * lanes) if shared else min(threads, max(1, trees // max(1, lanes)))
-        r = searchbench.timed_search_leg(st, nets, positions, trees, sims, max(1, leg_threads),
-                                         min_seconds=args.search_seconds, repeats=args.search_repeats, shared_collectors=shared)
-        r.pop("_median_totals")
-        r.pop("_spread")
-        r["workload"] = workload
-        r["per_tree_quota"] = quota
-        out[name] = r
-        for n in nets:
-            n.close()
+        for prec in [args.precision] + ([other] if also_other and other else []):
+            nets = nets_for(cfg, version, batch, lanes, seed=31, precision=prec)
+            r = searchbench.timed_search_leg(st, nets, positions, trees, sims, max(1, leg_threads), min_seconds=args.search_seconds,
+                                             repeats=args.search_repeats if prec == args.precision else 1, shared_collectors=shared)
+            for n in nets:
+                n.close()
+            if prec != args.precision:
+                out[name][f"mcts_nodes_per_sec_{prec}"] = r["mcts_nodes_per_sec"]
+                continue
+            r.pop("_median_totals")
+            r.pop("_spread")
+            r["workload"] = workload
+            r["per_tree_quota"] = quota
+            r["precision"] = prec
+            out[name] = r
 
     cz = [(f, False, "crazyhouse") for f in openings.crazyhouse_opening_set()]
     # config 1: the crazyhouse start position (then the rest of the opening set, one position per round), ONE tree, batch 8
     leg("config1", "crazyhouse start position + opening set one at a time, RISEv2-7, batch 8, 800 simulations, ONE tree (a single UCI go)",
-        rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 1, 8, 800, cz, 1)
+        rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 1, 8, 800, cz, 1, also_other=True)
     leg("config1_two_search_threads", "the same with the reference's default Threads = 2: two collectors (one per lane, batch 8 each) "
-        "share the one tree", rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 2, 8, 800, cz, 1, shared=1)
+        "share the one tree", rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 8, 2, 8, 800, cz, 1, shared=1, also_other=True)
     # `Threads` is a UCI option (optionsuci.cpp:182): a batch of 8 occupies 8 of the 256 CUs, so more collectors on the one tree put more
     # batches of 8 on the GPU at the same time
     leg("config1_four_search_threads", "the same with Threads = 4: four collectors (one per lane, batch 8 each) share the one tree",
@@ -296,13 +307,13 @@ def config_search_legs(args, device, threads):
     # parallel on four threads, a lane's batch = their 32 leaves (a lane is driven by one thread: eight lanes of one collector serialise
     # their collection on it)
     leg("config1_eight_collectors_two_lanes", "ONE tree, 8 collectors x 8 leaves as 2 lanes x 4 collectors (batch 32 per lane), 800 simulations",
-        rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 32, 2, 8, 800, cz, 1, shared=4)
+        rise_config.rise_v2_config(7, 34, 81), "1.0", 0, 32, 2, 8, 800, cz, 1, shared=4, also_other=True)
     # the single-position reading of config 2: one tree fills the whole batch of 256 by itself
     leg("config2_one_tree", "one crazyhouse position at a time, RISEv2-19, batch 256 collected from ONE tree by one collector, "
         "1600 simulations", rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 1, 256, 1600, cz, 1)
     leg("config2_one_tree_shared", "one crazyhouse position at a time, RISEv2-19, 2 lanes x batch 256, ONE tree shared by 8 collectors "
         "per lane (32 leaves each) under per-node locks, 1600 simulations", rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 2, 32,
-        1600, cz, 1, shared=8)
+        1600, cz, 1, shared=8, also_other=True)
     leg("config2_one_tree_three_lanes", "the same tree with a third lane (3 x 256 leaves in flight, 8 collectors per lane)",
         rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 3, 32, 1600, cz, 1, shared=8)
     leg("config2_one_tree_shared_6400", "the same with 6400 simulations per go (a longer think)",
@@ -311,16 +322,23 @@ def config_search_legs(args, device, threads):
     nets = nets_for(rise_config.rise_v2_config(19, 34, 81), "1.0", 256, 2, seed=31)
     st_b = search.default_settings(mode=0, version_major=1, batch_size=32)
     out["benchmark_positions"] = searchbench.benchmark_positions_leg(st_b, nets, 3200, min(threads, 16), shared_collectors=8)
+    out["benchmark_positions"]["precision"] = args.precision
     for n in nets:
         n.close()
+    if other:
+        nets = nets_for(rise_config.rise_v2_config(19, 34, 81), "1.0", 256, 2, seed=31, precision=other)
+        out["benchmark_positions"][f"mcts_nodes_per_sec_{other}"] = searchbench.benchmark_positions_leg(
+            st_b, nets, 3200, min(threads, 16), shared_collectors=8)["mcts_nodes_per_sec"]
+        for n in nets:
+            n.close()
     chess = [(f, False, "chess") for f in openings.position_fens("chess")]
     leg("config3", "standard chess calibration-game positions, RISEv3.3, batch 512, 3200 simulations, 2 lanes x 32 trees",
-        rise_config.rise_v33_config(52, 76, False), "3.0", 1, 512, 2, 16, 3200, chess, 64)
+        rise_config.rise_v33_config(52, 76, False), "3.0", 1, 512, 2, 16, 3200, chess, 64, also_other=True)
     from crazyara_amd import _capi
     lib = _capi.load()
     c960 = [(lib.mi_chess960_start_fen((i * 97 + 13) % 960).decode(), True, "chess") for i in range(96)]
     leg("config4_one_gpu", "chess960 start positions (Scharnagl numbers), 8 concurrent games' trees, RISEv3.3, batch 256, 1600 simulations "
-        "(the one-GPU slice of config 4)", rise_config.rise_v33_config(52, 76, False), "3.0", 1, 256, 2, 64, 1600, c960, 8)
+        "(the one-GPU slice of config 4)", rise_config.rise_v33_config(52, 76, False), "3.0", 1, 256, 2, 64, 1600, c960, 8, also_other=True)
     mixed = []
     a, b = searchbench.variant_positions("3check"), searchbench.variant_positions("kingofthehill")
     for i in range(max(len(a), len(b))):
@@ -328,7 +346,7 @@ def config_search_legs(args, device, threads):
         mixed.append(b[i % len(b)])
     leg("config5_one_gpu", "3check + king-of-the-hill positions alternating, lichess tables (80-channel planes, 5376 policy), RISEv2-13, "
         "batch 1024, 1600 simulations, 2 lanes x 64 trees (the one-GPU slice of config 5)",
-        rise_config.rise_v2_config(13, 80, 84), "3.0", 2, 1024, 2, 16, 1600, mixed, 128)
+        rise_config.rise_v2_config(13, 80, 84), "3.0", 2, 1024, 2, 16, 1600, mixed, 128, also_other=True)
     return out
 
 
@@ -346,59 +364,71 @@ def config_game_legs(args, device, threads):
         netfile.export_rise(os.path.join(d, f"{cfg.name}-v{version}.cranet"), cfg, sd, input_version=version, variant=variant)
         return d
 
-    # config 4: chess960 self-play, 8 concurrent games on this GPU, RISEv3.3, 800 simulations per move, tree reuse, temperature on
-    # the first moves (the RL settings' shape; random-init net, so the games are short and mostly drawn by the ply cap)
-    d = model_dir(rise_config.rise_v33_config(52, 76, False), "3.0", 41, "chess")
-    nets = [HipAPI(device, 256, d, args.precision) for _ in range(2)]
-    st = search.default_settings(mode=1, version_major=3, batch_size=64, seed=5)
-    pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1])
-    s = selfplay.SelfPlaySettings(variant="chess", is960=True, simulations=800, max_plies=100, mean_init_ply=2.0, init_temperature=0.8,
-                                  temperature_moves=8, temperature_decay=0.9, seed=11)
-    loop = selfplay.SelfPlay(pool, s, 8, start_fen=lambda i: lib.mi_chess960_start_fen((i * 97 + 13) % 960).decode())
-    games = loop.play(16, threads=min(threads, 8))
-    stt = loop.stats
-    out["config4_selfplay_one_gpu"] = {
-        "games_per_min": round(len(games) / stt["seconds"] * 60, 1), "games": len(games), "moves": int(stt["moves"]),
-        "seconds": round(stt["seconds"], 3), "mcts_nodes_per_sec": round(stt["nodes"] / stt["seconds"], 1),
-        "seconds_in_search": round(stt["run_seconds"], 3), "kept_subtrees": int(stt["kept_subtrees"]),
-        "workload": "chess960 self-play (native loop), 8 concurrent games, RISEv3.3, batch 256, 800 simulations per move, ply cap 100"}
-    loop.close()
-    pool.close()
-    for n in nets:
-        n.close()
-    # config 5: arena between two nets on 3check and king-of-the-hill (half of the games each), lichess tables, batch 1024
-    cfg5 = rise_config.rise_v2_config(13, 80, 84)
-    total = dict(games=0, moves=0, seconds=0.0, nodes=0, wins=0, draws=0, losses=0)
-    for variant in ("3check", "kingofthehill"):
-        da, db = model_dir(cfg5, "3.0", 42, variant), model_dir(cfg5, "3.0", 43, variant)
-        na = [HipAPI(device, 1024, da, args.precision) for _ in range(2)]
-        nb = [HipAPI(device, 1024, db, args.precision) for _ in range(2)]
-        st = search.default_settings(mode=2, version_major=3, batch_size=16, seed=6)
-        pa, pb = search.SearchPool(st, net_a=na[0], net_b=na[1]), search.SearchPool(st, net_a=nb[0], net_b=nb[1])
-        s = selfplay.SelfPlaySettings(variant=variant, simulations=400, max_plies=80, seed=12)
-        starts = [f for f, _, _ in searchbench.variant_positions(variant)]       # one start position per pair of games
-        # only the side to move searches, so half of a pool's trees sit out every round: the trees that run share the whole batch
-        # (mi_search_set_adaptive_quota) -- 128 concurrent games = 32 running trees per lane x 32 leaves = the batch of 1024
-        pa.set_adaptive_quota(32)
-        pb.set_adaptive_quota(32)
-        arena = selfplay.Arena(pa, pb, s, 128, start_fen=lambda i: starts[i % len(starts)])
-        res, recs = arena.play(128, threads=threads)
-        total["games"] += len(recs); total["moves"] += int(arena.stats["moves"]); total["seconds"] += arena.stats["seconds"]
-        total["nodes"] += int(arena.stats["nodes"]); total["wins"] += res.wins; total["draws"] += res.draws; total["losses"] += res.losses
-        total["run_seconds"] = total.get("run_seconds", 0.0) + arena.stats["run_seconds"]
-        total["move_seconds"] = total.get("move_seconds", 0.0) + arena.stats["move_seconds"]
-        arena.close()
-        pa.close(); pb.close()
-        for n in na + nb:
+    def legs(prec):
+        res_ = {}
+        # config 4: chess960 self-play, 8 concurrent games on this GPU, RISEv3.3, 800 simulations per move, tree reuse, temperature on
+        # the first moves (the RL settings' shape; random-init net, so the games are short and mostly drawn by the ply cap)
+        d = model_dir(rise_config.rise_v33_config(52, 76, False), "3.0", 41, "chess")
+        nets = [HipAPI(device, 256, d, prec) for _ in range(2)]
+        st = search.default_settings(mode=1, version_major=3, batch_size=64, seed=5)
+        pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1])
+        s = selfplay.SelfPlaySettings(variant="chess", is960=True, simulations=800, max_plies=100, mean_init_ply=2.0, init_temperature=0.8,
+                                      temperature_moves=8, temperature_decay=0.9, seed=11)
+        loop = selfplay.SelfPlay(pool, s, 8, start_fen=lambda i: lib.mi_chess960_start_fen((i * 97 + 13) % 960).decode())
+        games = loop.play(16, threads=min(threads, 8))
+        stt = loop.stats
+        res_["config4_selfplay_one_gpu"] = {
+            "games_per_min": round(len(games) / stt["seconds"] * 60, 1), "games": len(games), "moves": int(stt["moves"]),
+            "seconds": round(stt["seconds"], 3), "mcts_nodes_per_sec": round(stt["nodes"] / stt["seconds"], 1),
+            "seconds_in_search": round(stt["run_seconds"], 3), "kept_subtrees": int(stt["kept_subtrees"]),
+            "workload": "chess960 self-play (native loop), 8 concurrent games, RISEv3.3, batch 256, 800 simulations per move, ply cap 100"}
+        loop.close()
+        pool.close()
+        for n in nets:
             n.close()
-    out["config5_arena_one_gpu"] = {
-        "games_per_min": round(total["games"] / total["seconds"] * 60, 1), "games": total["games"], "moves": total["moves"],
-        "seconds": round(total["seconds"], 3), "mcts_nodes_per_sec": round(total["nodes"] / total["seconds"], 1),
-        "seconds_in_search": round(total["run_seconds"], 3), "seconds_in_move_step": round(total["move_seconds"], 3),
-        "contender_score": {"wins": total["wins"], "draws": total["draws"], "losses": total["losses"]},
-        "workload": "arena between two RISEv2-13 80-channel nets (native loop), 3check then king-of-the-hill, 128 concurrent games in colour-"
-                    "swapped pairs from the variants' opening positions, both players searching at the same time, batch 1024 shared by the "
-                    "running trees, 400 simulations per move, ply cap 80"}
+        # config 5: arena between two nets on 3check and king-of-the-hill (half of the games each), lichess tables, batch 1024
+        cfg5 = rise_config.rise_v2_config(13, 80, 84)
+        total = dict(games=0, moves=0, seconds=0.0, nodes=0, wins=0, draws=0, losses=0)
+        for variant in ("3check", "kingofthehill"):
+            da, db = model_dir(cfg5, "3.0", 42, variant), model_dir(cfg5, "3.0", 43, variant)
+            na = [HipAPI(device, 1024, da, prec) for _ in range(2)]
+            nb = [HipAPI(device, 1024, db, prec) for _ in range(2)]
+            st = search.default_settings(mode=2, version_major=3, batch_size=16, seed=6)
+            pa, pb = search.SearchPool(st, net_a=na[0], net_b=na[1]), search.SearchPool(st, net_a=nb[0], net_b=nb[1])
+            s = selfplay.SelfPlaySettings(variant=variant, simulations=400, max_plies=80, seed=12)
+            starts = [f for f, _, _ in searchbench.variant_positions(variant)]       # one start position per pair of games
+            # only the side to move searches, so half of a pool's trees sit out every round: the trees that run share the whole batch
+            # (mi_search_set_adaptive_quota) -- 128 concurrent games = 32 running trees per lane x 32 leaves = the batch of 1024
+            pa.set_adaptive_quota(32)
+            pb.set_adaptive_quota(32)
+            arena = selfplay.Arena(pa, pb, s, 128, start_fen=lambda i: starts[i % len(starts)])
+            res, recs = arena.play(128, threads=threads)
+            total["games"] += len(recs); total["moves"] += int(arena.stats["moves"]); total["seconds"] += arena.stats["seconds"]
+            total["nodes"] += int(arena.stats["nodes"]); total["wins"] += res.wins; total["draws"] += res.draws; total["losses"] += res.losses
+            total["run_seconds"] = total.get("run_seconds", 0.0) + arena.stats["run_seconds"]
+            total["move_seconds"] = total.get("move_seconds", 0.0) + arena.stats["move_seconds"]
+            arena.close()
+            pa.close(); pb.close()
+            for n in na + nb:
+                n.close()
+        res_["config5_arena_one_gpu"] = {
+            "games_per_min": round(total["games"] / total["seconds"] * 60, 1), "games": total["games"], "moves": total["moves"],
+            "seconds": round(total["seconds"], 3), "mcts_nodes_per_sec": round(total["nodes"] / total["seconds"], 1),
+            "seconds_in_search": round(total["run_seconds"], 3), "seconds_in_move_step": round(total["move_seconds"], 3),
+            "contender_score": {"wins": total["wins"], "draws": total["draws"], "losses": total["losses"]},
+            "workload": "arena between two RISEv2-13 80-channel nets (native loop), 3check then king-of-the-hill, 128 concurrent games in colour-"
+                        "swapped pairs from the variants' opening positions, both players searching at the same time, batch 1024 shared by the "
+                        "running trees, 400 simulations per move, ply cap 80"}
+        for v in res_.values():
+            v["precision"] = prec
+        return res_
+
+    out = legs(args.precision)
+    other = getattr(args, "search_precision_other", None)
+    if other and other != args.precision:                                # the same games with nets of the other mode, beside the line's
+        for k, v in legs(other).items():
+            out[k][f"games_per_min_{other}"] = v["games_per_min"]
+            out[k][f"mcts_nodes_per_sec_{other}"] = v["mcts_nodes_per_sec"]
     return out
 
 
@@ -439,6 +469,7 @@ def timed_mode_leg(local_rank, batch, model_dir, precision, x, steps, flops_peak
 
 
 def main():
+    t_bench_start = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -748,7 +779,7 @@ def main():
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "peak_definition": {"float16": "dense f16 MFMA peak", "float32": "exact-f32 MFMA peak",
                                         "float16x3": "dense f16 MFMA peak / 3: every product is three f16 MFMAs (hi*hi + hi*lo + lo*hi)",
-                                        "float16p8": "dense f16 MFMA peak / 2.5: expand GEMM three f16 MFMAs per product, project GEMM one f16 MFMA + two "
+                                        "float16p8": "dense f16 MFMA peak / 2.5: project GEMM three f16 MFMAs per product, expand GEMM one f16 MFMA + two "
                                                      "e4m3 products at the fp8 peak (5 PFLOP/s dense)"}[args.precision],
                     **traffic,
                     "whole_forward": {"event_ms_per_step": round(ev_ms, 4),
@@ -902,9 +933,15 @@ def main():
             summary[f"config2_mcts_nodes_per_sec_{mcts_headline_mode['precision']}"] = mcts_headline_mode["mcts_nodes_per_sec"]
         for k_, r_ in (mcts_configs or {}).items():
             summary[f"{k_}_nodes_per_sec"] = r_["mcts_nodes_per_sec"]
+            for kk_, v_ in r_.items():                                   # the same leg with nets of the other mode
+                if kk_.startswith("mcts_nodes_per_sec_"):
+                    summary[f"{k_}_nodes_per_sec_{kk_[len('mcts_nodes_per_sec_'):]}"] = v_
         for k_, r_ in (game_configs or {}).items():
             summary[f"{k_}_nodes_per_sec"] = r_["mcts_nodes_per_sec"]
             summary[f"{k_}_games_per_min"] = r_["games_per_min"]
+            for kk_, v_ in r_.items():
+                if kk_.startswith("games_per_min_"):
+                    summary[f"{k_}_{kk_}"] = v_
         if dropin and "skipped" not in dropin:
             for k_, r_ in dropin.items():
                 if isinstance(r_, dict):
@@ -912,6 +949,7 @@ def main():
         if "cpu_baseline" in out:
             summary["cpu_evals_per_sec"] = out["cpu_baseline"]["value"]
             summary["cpu_cores"] = out["cpu_baseline"]["cores"]
+        summary["bench_seconds"] = round(time.perf_counter() - t_bench_start, 1)
         out["summary"] = summary
     net.close()
     if dist is not None:

@@ -21,6 +21,7 @@ SIGNATURES = {
     "mi_net_destroy": (None, [C.c_void_p]),
     "mi_onnx_to_cranet": (C.c_int, [C.c_char_p, C.c_char_p]),
     "mi_e4m3_from_float": (C.c_int, [C.c_float]),
+    "mi_e5m2_from_float": (C.c_int, [C.c_float]),
     "mi_net_design": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "mi_net_model_name": (C.c_char_p, [C.c_void_p]),
     "mi_net_flops_per_position": (C.c_double, [C.c_void_p]),

@@ -55,6 +55,7 @@ mi_net* mi_net_create(const char* model_dir, int device_id, int batch_size, cons
 void mi_net_destroy(mi_net* net) { delete net; }
 
 int mi_e4m3_from_float(float v) { return int(cra::float_to_e4m3(v)); }
+int mi_e5m2_from_float(float v) { return int(cra::float_to_e5m2(v)); }
 
 int mi_onnx_to_cranet(const char* onnx_path, const char* cranet_path) {
     if (!onnx_path || !cranet_path) { g_err = "null argument to mi_onnx_to_cranet"; return 1; }

@@ -91,10 +91,12 @@ struct X3TowerBlock {
     const float* se_b;                               // eca_se: [256]
     int cop_pad;                                     // multiple of block_x3_chunk_channels()
     int se_kind;                                     // 0 none, 1 ca_se, 2 eca_se
-    // Precision float16p8 (x3.hip, tower_p8_kernel): w1pk = f16 image of w1 * 2^p, w1pk_lo = the 8-bit image of the cross terms (per cout tile and
-    // 64 k: lanes' 32 bytes [e4m3((w1 * 2^p) - hi) for 64 k ; e4m3(w1 * 2^(p - 11)) for the same 64 k], bytes 0-15 in "slab" 2 J, bytes 16-31 in
-    // "slab" 2 J + 1 of the lo image's geometry); w1_inv = 2^-p brings the expand accumulators back in front of the BN1 bias
-    float w1_inv;
+    // Precision float16p8 (x3.hip, tower_p8_kernel): w1pk / w3pk = f16 image of w * 2^p (p per layer), w1pk_lo / w3pk_lo = the 8-bit image of the cross
+    // terms (per cout tile and 64 k: lanes' 32 bytes [e5m2((w * 2^p) - hi) for 64 k ; e5m2(hi) for the same 64 k], both times the truncation
+    // compensation, bytes 0-15 in "slab" 2 J, bytes 16-31 in "slab" 2 J + 1 of the lo image's geometry; rise_net.hip: pack_dense_p8).  w1_inv = 2^-p1
+    // brings the expand accumulators back in front of the BN1 bias; the residual stream runs in the project weights' scale inside a block:
+    // x := (x + b3) * w3_scale, + the project sums, x := x * w3_inv (powers of two: exact)
+    float w1_inv, w3_scale, w3_inv;
 };
 struct X3TowerArgs {
     const float* x;       // [B][64][256]
@@ -103,7 +105,6 @@ struct X3TowerArgs {
     int nblocks;
     int batch;
     int p8;               // Precision float16p8 (tower_p8_kernel)
-    float lo_scale;       // float16p8: the scale operand that makes v_cvt_scalef32_pk_fp8_f32 return e4m3(residual * 2^11) (it divides: 2^-11)
 };
 void launch_tower_x3(const X3TowerArgs& a, hipStream_t s);
 template <typename T> void init_block_kernel_attributes();

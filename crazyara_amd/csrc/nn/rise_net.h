@@ -24,6 +24,7 @@ struct RiseDesign {
 
 // the host-side weight quantiser of Precision fp8: float -> OCP e4m3fn byte, round to nearest even, clamped at +-448
 uint8_t float_to_e4m3(float v);
+uint8_t float_to_e5m2(float v);
 
 class RiseNet {
 public:
@@ -115,7 +116,7 @@ private:
     std::string model_name_, model_file_path_;
     bool fp16_ = true;
     bool x3_ = false;            // Precision float16x3: float activations, split-operand f16 MFMAs (x3.hip); fp16_ is false
-    bool p8_ = false;            // Precision float16p8: float16x3 whose tower takes the project GEMM's cross terms through e4m3 MFMAs
+    bool p8_ = false;            // Precision float16p8: float16x3 whose one-launch tower takes the cross terms of both 1x1 GEMMs through e5m2 MFMAs
     bool fp8_tower_ = false;     // Precision fp8 (alias int8): e4m3 operands in the residual tower's GEMMs, everything else as float16
     bool fused_ = true;
     bool tower_ = true;

@@ -120,11 +120,31 @@ SplitPack pack_dense_split(const Folded& f, int cout, int cin, int ks, int cout_
     return SplitPack{pack_dense<half_t>(fh, cout, cin, ks, cout_pad, cin_pad), pack_dense<half_t>(fl, cout, cin, ks, cout_pad, cin_pad)};
 }
 
-// Precision float16p8, expand weights of a tower block (x3.hip: tower_p8_kernel; kernels.h: X3TowerBlock).  W' = w * 2^p with
-// p = 11 - floor(log2(max |w|)) (the largest weight lands in [2048, 4096)): hi = rne_f16(W') is the main term's operand; the 8-bit image
-// holds, per cout tile and 64 k, a lane's 32 bytes -- lane groups 0, 1: e4m3(W' - hi) for k [0, 32), [32, 64) (they meet the
-// activations' hi8), groups 2, 3: e4m3(W' * 2^-11) for the same k (they meet lo8 = e4m3(residual * 2^11)) -- bytes 0-15 in "slab" 2 J,
-// bytes 16-31 in "slab" 2 J + 1 of the lo image's geometry.  All three products carry the factor 2^p; *inv = 2^-p.
+// e5m2 ("bf8": f16's exponent field, two mantissa bits), round to nearest even from the float value, subnormals kept, saturating
+uint8_t to_e5m2(float f) {
+    const uint8_t sign = std::signbit(f) ? 0x80 : 0;
+    const double a = std::fabs(double(f));
+    if (!(a > 0.0)) return sign;
+    int e = 0;
+    (void)std::frexp(a, &e);
+    int E = e - 1;                                                      // a = 1.m * 2^E
+    if (E < -14) {                                                      // subnormal: units of 2^-16
+        const int q = int(std::nearbyint(std::ldexp(a, 16)));
+        return uint8_t(sign | (q >= 4 ? 0x04 : q));
+    }
+    int mant = int(std::nearbyint((std::ldexp(a, -E) - 1.0) * 4.0));
+    if (mant == 4) { mant = 0; ++E; }
+    if (E > 15) return uint8_t(sign | 0x7B);                            // the largest finite value (1.75 * 2^15)
+    return uint8_t(sign | ((E + 15) << 2) | mant);
+}
+
+// Precision float16p8, expand / project weights of a tower block (x3.hip: tower_p8_kernel; kernels.h: X3TowerBlock; oracle: _p8_conv).
+// W' = w * 2^p with p = 11 - floor(log2(max |w|)) (the largest weight lands in [2048, 4096)): hi = rne_f16(W') is the main term's operand;
+// the 8-bit image holds, per cout tile and 64 k, a lane's 32 bytes -- lane groups 0, 1: e5m2((W' - hi) * c) for k [0, 32), [32, 64) (they
+// meet the activations' hi8), groups 2, 3: e5m2(hi * c) for the same k (they meet the activations' lo8) -- bytes 0-15 in "slab" 2 J, bytes
+// 16-31 in "slab" 2 J + 1 of the lo image's geometry.  c = 1 / (1 - ln 2 / 8): the kernel's activation bytes are TRUNCATED f16 values (their
+// high bytes), which lose 2^e / 8 on average; the weight images take the mean back.  All three products carry the factor 2^p; *inv = 2^-p.
+constexpr double kP8TruncCompensation = 1.0 / (1.0 - 0.125 * 0.6931471805599453);
 SplitPack pack_dense_p8(const Folded& f, int cout, int cin, int cout_pad, int cin_pad, double* inv) {
     double mx = 0.0;
     for (double v : f.w) mx = std::max(mx, std::fabs(v));
@@ -148,7 +168,7 @@ SplitPack pack_dense_p8(const Folded& f, int cout, int cin, int cout_pad, int ci
                     if (co < cout && k < cin) {
                         const double W = fs.w[size_t(co) * cin + k];
                         const double hi = double(float(half_t(float(W))));
-                        q = lg < 2 ? to_e4m3(W - hi) : to_e4m3(std::ldexp(W, -11));
+                        q = to_e5m2(float((lg < 2 ? W - hi : hi) * kP8TruncCompensation));
                     }
                     bytes[((size_t(ct) * nslab + 2 * J + (bb >> 4)) * 64 + l) * 16 + (bb & 15)] = q;
                 }
@@ -268,8 +288,8 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     // the fast mode that meets "logits within 1e-3 of fp32": float activations, every dense contraction as three f16 MFMAs on split
     // operands (x3.hip)
     else if (prec == "float16x3" || prec == "fp16x3" || prec == "f16x3") { fp16_ = false; x3_ = true; }
-    // float16x3 with the cross terms of the tower's EXPAND GEMMs on ONE e4m3 MFMA per 64 k and the residual stream in the PROJECT waves'
-    // registers (x3.hip: tower_p8_kernel): logits within 1e-4 of fp32 as well (emulated 1e-5 ... 7e-5 on the parity nets)
+    // float16x3 with the cross terms of the one-launch tower's two 1x1 GEMMs on ONE e5m2 MFMA per 64 k and the residual stream in the PROJECT
+    // waves' registers (x3.hip: tower_p8_kernel): logits within 3e-4 of fp32 (emulated 5e-5 ... 1.3e-4 on the parity nets)
     else if (prec == "float16p8" || prec == "fp16p8" || prec == "f16p8") { fp16_ = false; x3_ = true; p8_ = true; }
     else throw std::invalid_argument("unsupported precision '" + precision + "' (float16 | float16x3 | float16p8 | float32 | fp8)");
     design_.batch = batch_size;
@@ -566,10 +586,6 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         op.tx.nblocks = int(x3_blocks.size());
         op.tx.batch = B;
         op.tx.p8 = p8_ ? 1 : 0;
-        {   // scale operand of v_cvt_scalef32_pk_fp8_f32 for lo8 = e4m3(residual * 2^11): the instruction DIVIDES by its scale (measured, r04i)
-            const char* ls = getenv("CRA_P8_LO_SCALE");
-            op.tx.lo_scale = ls ? float(atof(ls)) : 1.0f / 2048.0f;
-        }
         im.ops.push_back(op);
         x3_blocks.clear();
         prod_op = -1;                      // this launch does not emit channel sums: a gate behind it is an SE launch of its own
@@ -900,16 +916,18 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             Folded f1 = fold_bn(nf, p + ".body.0", p + ".body.1");
             Folded f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
             Folded f3 = fold_bn(nf, p + ".body.6", p + ".body.7");
-            double w1_inv = 1.0;
+            double w1_inv = 1.0, w3_inv = 1.0;
             SplitPack s1 = p8_ ? pack_dense_p8(f1, cop, C, cop_pad, C, &w1_inv) : pack_dense_split(f1, cop, C, 1, cop_pad, C);
-            SplitPack s3 = pack_dense_split(f3, C, cop, 1, C, cop_pad);
+            SplitPack s3 = p8_ ? pack_dense_p8(f3, C, cop, C, cop_pad, &w3_inv) : pack_dense_split(f3, C, cop, 1, C, cop_pad);
             xb.w1pk = im.upload(s1.hi);
             xb.w1pk_lo = im.upload(s1.lo);
             xb.w3pk = im.upload(s3.hi);
             xb.w3pk_lo = im.upload(s3.lo);
             xb.dwpk = im.upload(pack_x3_depthwise_records(f1, f2, cop, cop_pad));
             xb.b3 = im.upload_d2f(f3.b, C);
-            xb.w1_inv = float(w1_inv);                                     // float16p8: the expand accumulators run in the weights' scale
+            xb.w1_inv = float(w1_inv);                                     // float16p8: the accumulators run in the weights' scales
+            xb.w3_inv = float(w3_inv);
+            xb.w3_scale = float(1.0 / w3_inv);
             xb.cop_pad = cop_pad;
             x3_blocks.push_back(xb);
             macs += double(kSquares) * cop * (2.0 * C + k * k);
@@ -1775,5 +1793,6 @@ void* RiseNet::enable_block_dump(int* n_tiles) {
 }
 
 uint8_t float_to_e4m3(float v) { return to_e4m3(double(v)); }
+uint8_t float_to_e5m2(float v) { return to_e5m2(v); }
 
 }  // namespace cra

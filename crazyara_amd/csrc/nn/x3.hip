@@ -89,37 +89,29 @@ __device__ __forceinline__ void split4(const float (&v)[4], half4& hi, half4& lo
     lo = __builtin_bit_cast(half4, u32x2{l[0], l[1]});
 }
 
-// Precision float16p8 (the project GEMM of the two-role tower): a value v goes to the matrix unit as the f16 hi = rne(v) for the MAIN product
-// and as two e4m3 bytes for the CROSS products, hi8 = e4m3(hi) and lo8 = e4m3((v - hi) * 2^11) (the residual is exact in f32; 2^11 brings it
-// to the magnitude of hi, where e4m3 has its normal range).  4 values -> 2 dwords of f16, 1 dword of hi8, 1 dword of lo8.
-typedef half_t half2_x3 __attribute__((ext_vector_type(2)));
-typedef short s16x2_x3 __attribute__((ext_vector_type(2)));
+// Precision float16p8 (tower_p8_kernel): a value v goes to the matrix unit as the f16 pair of the float16x3 split, hi = rne(v) for the MAIN
+// product, and as two e5m2 bytes for the CROSS products: hi8 / lo8 = the HIGH BYTES of hi and of lo = rne_f16(v - hi).  e5m2 has f16's
+// exponent field, so the byte IS the value truncated to two mantissa bits: one v_perm_b32 per four values and image, no conversion instruction
+// (v_cvt_scalef32_pk_fp8_* issue at a fraction of the VALU rate: profiles/NOTES.md, round 4); the mean loss of the truncation is taken back on
+// the host-made weight images (rise_net.hip: pack_dense_p8).  4 values -> 2 dwords of f16, 1 dword of hi8, 1 dword of lo8.
 typedef int i32x4_x3 __attribute__((ext_vector_type(4)));
 typedef int i32x8_x3 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split4_p8(const float (&v)[4], half4& hi, uint32_t& h8, uint32_t& l8, float lo_scale) {
-    uint32_t h[2];
-    float r[4];
+__device__ __forceinline__ uint32_t x3_high_bytes(uint32_t p01, uint32_t p23) {      // the high bytes of four packed f16, in order
+    return __builtin_amdgcn_perm(p23, p01, 0x07050301u);
+}
+__device__ __forceinline__ void split4_b8(const float (&v)[4], half4& hi, uint32_t& h8, uint32_t& l8) {
+    uint32_t h[2], l[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-        asm("v_cvt_pk_f16_f32 %0, %3, %4\n\t"
-            "v_fma_mix_f32 %1, %0, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-            : "=&v"(h[j]), "=&v"(r[2 * j]), "=&v"(r[2 * j + 1])
-            : "v"(v[2 * j]), "v"(v[2 * j + 1]));
+    for (int j = 0; j < 2; ++j) split_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     hi = __builtin_bit_cast(half4, u32x2{h[0], h[1]});
-    s16x2_x3 q = {0, 0}, p = {0, 0};
-    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_bit_cast(half2_x3, h[0]), 1.0f, false);
-    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_bit_cast(half2_x3, h[1]), 1.0f, true);
-    p = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p, r[0], r[1], lo_scale, false);
-    p = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p, r[2], r[3], lo_scale, true);
-    h8 = __builtin_bit_cast(uint32_t, q);
-    l8 = __builtin_bit_cast(uint32_t, p);
+    h8 = x3_high_bytes(h[0], h[1]);
+    l8 = x3_high_bytes(l[0], l[1]);
 }
-// D(16x16) += A(16 x 128) * B(128 x 16), e4m3 operands: lane l holds row / column l % 16 and the 32 bytes k = (l / 16) * 32 + t of the
+// D(16x16) += A(16 x 128) * B(128 x 16), e5m2 operands (cbsz = blgp = 1): lane l holds row / column l % 16 and the 32 bytes k = (l / 16) * 32 + t of the
 // step -- the same labelling on both operands, so the sum is the plain product whatever order the hardware walks its k in
 __device__ __forceinline__ void x3_mfma8(const i32x8_x3& a, const i32x8_x3& b, f32x4& c, bool on) {
-    if (on) c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
+    if (on) c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 1, 1, 0, 0, 0, 0);
     else asm volatile("" : "+v"(c) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ i32x8_x3 x3_cat(const half8& lo16, const half8& hi16) {       // a lane's 32 operand bytes from two 16-byte pieces
@@ -1315,19 +1307,19 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
 }
 
 // ================================================================================================================
-// Precision float16p8: the two-role tower with the EXPAND GEMM on the mixed split
+// Precision float16p8: the two-role tower with both GEMMs on the mixed split
 // ================================================================================================================
-// What changes against tower_x3_roles_kernel (measurements: profiles/NOTES.md round 4, sets r04h-l):
-//  * EXPAND GEMM: per 64 k two f16 MFMAs (main term hi x hi) and ONE v_mfma_f32_16x16x128_f8f6f4 on [hi8 | lo8] x [w_lo8 ; w_hi8] (both cross
-//    terms) instead of six f16 MFMAs: the EXPAND waves' instruction stream is the interval (their MFMAs queue behind the partner's in the
-//    SIMD's one matrix pipe), and this is the part of it that shrinks without making their depthwise dearer.  The PROJECT GEMM and the
-//    depthwise output t2 stay float16x3's (the 8-bit form of t2 costs the EXPAND waves more than the PROJECT waves gain, set j; converting on
-//    the PROJECT side is slower still, set k).
-//  * The stream tile in LDS holds the operand forms only: xh = rne_f16(x) and, where float16x3 keeps the lo half, a byte row [hi8 = e4m3(xh),
-//    256 B | lo8 = e4m3((x - xh) * 2^11), 256 B] (split4_p8).
+// What changes against tower_x3_roles_kernel (measurements: profiles/NOTES.md round 4):
+//  * Both GEMMs: per 64 k two f16 MFMAs (main term hi x hi) and ONE v_mfma_f32_16x16x128_f8f6f4 (e5m2 operands) on [hi8 | lo8] x [w_lo8 ; w_hi8]
+//    (both cross terms) instead of six f16 MFMAs.  The interval is the matrix pipe time of a SIMD's two waves plus what the EXPAND wave issues
+//    beyond its MFMAs' shadow: both shrink.  The 8-bit operand bytes are the HIGH BYTES of the float16x3 split's f16 pairs (split4_b8: a byte
+//    permute; the e4m3 form of the first build paid for its conversions what the matrix pipe gained, sets j and k).
+//  * The tiles in LDS hold the operand forms only: the stream tile xh = rne_f16(x) + a byte row [hi8, 256 B | lo8, 256 B] where float16x3 keeps
+//    the lo half; the depthwise output t2h + a byte row [hi8, 128 B | lo8, 128 B] (272-byte pitch) where float16x3 keeps t2l.
 //  * The residual stream itself lives in the PROJECT waves' accumulators: wave v holds x of its 64 couts x 64 squares in f32 (exact, where
-//    float16x3 rebuilds x = hi + lo from LDS to 2^-22), the project sums of a block are accumulated ON it, and the block epilogue only writes
-//    the operand forms of the new x.  SE gates: squeeze from the registers, gate as before, x *= gate in the registers.
+//    float16x3 rebuilds x = hi + lo from LDS to 2^-22), the project sums of a block are accumulated ON it -- in the project weights' scale:
+//    x := (x + b3) * 2^p in front of the block, x := x * 2^-p behind it, both exact -- and the block epilogue only writes the operand forms of
+//    the new x.  SE gates: squeeze from the registers, gate as before, x *= gate in the registers.
 // The roles are separated at the top level (the PROJECT waves' 64 registers of x must not be live in the EXPAND waves' code).
 namespace {
 // mean[c] (LDS scratch, written by the PROJECT waves) -> gate[c] in LDS: the middle of x3_se_phase, every thread of the workgroup.
@@ -1401,18 +1393,19 @@ __device__ __forceinline__ void x3_se_gate_from_mean(const X3TowerBlock& d, floa
 __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
     using G = X3Block;
     static_assert(G::NE == 1 && G::T2BUF == 2 && G::CK == 128, "the role kernels use the NE = 1 tile geometry");
-    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, X8ROW = XROW * 2, NJ = 4;
+    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, X8ROW = XROW * 2, T8ROW = 272, T8LO = 144, NJ = 4;
+    static_assert(T8ROW <= TROW * 2 && T8LO + CK <= T8ROW, "the byte rows of t2 live where float16x3 keeps t2l");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const X3Tiles T = x3_tiles(smem);
-    char* const x8 = reinterpret_cast<char*>(T.xl);                    // [64][544 B]: hi8 bytes [0, 256), lo8 bytes [272, 528) of a row
+    char* const x8 = reinterpret_cast<char*>(T.xl);                    // [64][528 B]: hi8 bytes [0, 256), lo8 bytes [272, 528) of a row
+    char* const t28 = reinterpret_cast<char*>(T.t2l);                  // [2][64][272 B]: hi8 bytes [0, 128), lo8 bytes [144, 272) of a row (68 dwords: 16 rows, 16 bank groups)
     float* const se_scratch = reinterpret_cast<float*>(T.t2h);         // idle between blocks
-    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);                        // MODE.FP16_OVFL: conversions to f16 / e4m3 clamp instead of overflowing
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);                        // MODE.FP16_OVFL: conversions to f16 clamp instead of overflowing
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wave & 3;
     const uint32_t lane_off = uint32_t(lane) * 16u;
-    const float lo_scale = a.lo_scale;
 
     if (wave < 4) {
         // =================================================== EXPAND waves ===================================================
@@ -1433,7 +1426,7 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
             const bool tracing = (b == 0 || b == 131) && blk == CRA_X3_TRACE;
             int trace_n = 0;
 #endif
-            // window: f16 fragments of two k-slabs (slot = slab parity) and the e4m3 fragments of one 64-k step, for the wave's two channel tiles
+            // window: f16 fragments of two k-slabs (slot = slab parity) and the e5m2 fragments of one 64-k step, for the wave's two channel tiles
             half8 e_h[2][2];
             i32x8_x3 e_8[2];
             auto load_eh = [&](int i, int s) {                          // cout tile of (chunk i, wave w, ne) = i * 8 + w * 2 + ne
@@ -1454,11 +1447,11 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
             f32x4 accE[2][4], accD[2][4];
             X3Depthwise dw;
             // Interval i: E(i) (HASE) with D(i - 1) (HASD) in sixteen pieces, two per k-slab, as in tower_x3_roles_kernel.  A k-slab issues its 8
-            // f16 MFMAs; an ODD slab then the 8 e4m3 MFMAs of its 64-k step.
+            // f16 MFMAs; an ODD slab then the 8 e5m2 MFMAs of its 64-k step.
             auto interval = [&](auto hase_c, auto hasd_c, int i) {
                 constexpr bool HASE = decltype(hase_c)::value, HASD = decltype(hasd_c)::value;
                 half8 ring_h[4];                                        // f16 operand of step st = slab * 4 + square tile, requested 3 steps ahead
-                i32x8_x3 ring_8[3];                                     // e4m3 operand of step q = (64-k step) * 4 + square tile, requested 2 steps ahead
+                i32x8_x3 ring_8[3];                                     // e5m2 operand of step q = (64-k step) * 4 + square tile, requested 2 steps ahead
                 auto read_h = [&](int st) {
                     ring_h[st % 4] = *reinterpret_cast<const half8*>(T.xh + ((st & 3) * 16 + l15) * XROW + (st >> 2) * 32 + lg * 8);
                 };
@@ -1481,7 +1474,7 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                 }
                 if constexpr (HASD) dw.template load<0>(my_dws, lg);
                 half_t* const t2h = T.t2h + ((i - 1) & 1) * 64 * TROW;
-                half_t* const t2l = T.t2l + ((i - 1) & 1) * 64 * TROW;
+                char* const t2b = t28 + ((i - 1) & 1) * 64 * T8ROW;
 #pragma unroll
                 for (int sl = 0; sl < C / 32; ++sl) {
                     const int dt = sl / 4, ph = sl % 4;
@@ -1510,20 +1503,22 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                     if constexpr (HASD) {
                         if (ph == 0) dw.template gather<0, true>(accD[dt], hi, mL, mR, 0, 2, e_inv);
                         if (ph == 1) { dw.template taps<0>(0, 4); dw.pin_taps(0, 4, 0); }
-                        if (ph == 2 && !((X3_ABL & 256) && dt == 1)) dw.template gather<1, true>(accD[dt], hi, mL, mR, 0, 2, e_inv);
+                        if (ph == 2) dw.template gather<1, true>(accD[dt], hi, mL, mR, 0, 2, e_inv);
                         if (ph == 3) {
-                            if (!((X3_ABL & 256) && dt == 1)) dw.template taps<1>(0, 4);
-                            const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1 (float16x3's form)
+                            dw.template taps<1>(0, 4);
+                            const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1: the f16 hi and the two byte rows
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                half4 h, l;
-                                split4(dw.outv[t], h, l);
+                                half4 h;
+                                uint32_t h8, l8;
+                                split4_b8(dw.outv[t], h, h8, l8);
                                 if constexpr ((X3_ABL & 64) != 0) {
-                                    asm volatile("" ::"v"(h), "v"(l));
+                                    asm volatile("" ::"v"(h), "v"(h8), "v"(l8));
                                     continue;
                                 }
                                 *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
-                                *reinterpret_cast<half4*>(t2l + (t * 16 + l15) * TROW + cl) = l;
+                                *reinterpret_cast<uint32_t*>(t2b + (t * 16 + l15) * T8ROW + cl) = h8;
+                                *reinterpret_cast<uint32_t*>(t2b + (t * 16 + l15) * T8ROW + T8LO + cl) = l8;
                             }
                         }
                     }
@@ -1582,7 +1577,7 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                 float v[4] = {accX[j][t][0], accX[j][t][1], accX[j][t][2], accX[j][t][3]};
                 half4 h;
                 uint32_t h8, l8;
-                split4_p8(v, h, h8, l8, lo_scale);
+                split4_b8(v, h, h8, l8);
                 *reinterpret_cast<half4*>(T.xh + rr * XROW + co0) = h;
                 *reinterpret_cast<uint32_t*>(x8 + rr * X8ROW + co0) = h8;
                 *reinterpret_cast<uint32_t*>(x8 + rr * X8ROW + 272 + co0) = l8;
@@ -1632,83 +1627,85 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
         const bool tracing = (b == 0 || b == 131) && blk == CRA_X3_TRACE;
         int trace_n = 0;
 #endif
-        constexpr int PW = 2;
-        half8 p_h[PW][NJ], p_l[PW][NJ];
-        auto load_p = [&](int k, int s2) {                             // cout tile = w * 4 + j, K slab = k * 4 + s2
+        // window: f16 fragments of two K slabs (slot = slab parity) and the e5m2 fragments of one 64-k step, for the wave's four cout tiles
+        half8 p_h[2][NJ];
+        i32x8_x3 p_8[NJ];
+        auto load_ph = [&](int k, int s2) {                            // cout tile = w * 4 + j, K slab = k * 4 + s2
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) p_h[s2 & 1][j] = x3_frag(W.w3h, lane_off, uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + s2));
+        };
+        auto load_p8 = [&](int k, int J) {                             // a lane's 32 bytes of the 64-k step J of chunk k: "slabs" 2 J and 2 J + 1 of the 8-bit image
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const uint32_t f = uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + s2);
-                p_h[s2 % PW][j] = x3_frag(W.w3h, lane_off, f);
-                p_l[s2 % PW][j] = x3_frag(W.w3l, lane_off, f);
+                const uint32_t f = uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + 2 * J);
+                p_8[j] = x3_cat(x3_frag(W.w3l, lane_off, f), x3_frag(W.w3l, lane_off, f + 1));
             }
         };
+        {   // the residual stream enters the project weights' scale: x := (x + b3) * 2^p; the project sums of the block are accumulated on it
+            const float ps = d.w3_scale;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {                                  // + BN3 bias; the project sums of the block are accumulated on x itself
-            const f32x4 bs = *reinterpret_cast<const f32x4*>(d.b3 + (w * NJ + j) * 16 + lg * 4);
+            for (int j = 0; j < NJ; ++j) {
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(d.b3 + (w * NJ + j) * 16 + lg * 4) * ps;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) accX[j][t] += bs;
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accX[j][t][r] = fmaf(accX[j][t][r], ps, bs[r]);
+            }
         }
-#pragma unroll
-        for (int s2 = 0; s2 < PW; ++s2) load_p(0, s2);
+        load_ph(0, 0);
+        load_ph(0, 1);
+        load_p8(0, 0);
         __syncthreads();                                                // intervals 0 and 1: chunk 0 is expanded, then run through the depthwise
         __syncthreads();
         for (int kk = 0; kk < n; ++kk) {                                // P(kk) runs in interval kk + 2
             const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
-            const half_t* const t2l = T.t2l + (kk & 1) * 64 * TROW;
+            const char* const t2b = t28 + (kk & 1) * 64 * T8ROW;
             X3_STAMP(8);
-            if constexpr ((X3_ABL & 256) != 0) {      // TIMING ONLY: a quarter of a chunk's depthwise (channel pair 1 of the partner's second tile) on this wave
-                const bool hi_ = l15 >= 8;
-                const float mL_ = (l15 & 7) != 0 ? 1.f : 0.f, mR_ = (l15 & 7) != 7 ? 1.f : 0.f;
-                f32x4 hacc[4];
+            half8 bh[2][4];
+            i32x8_x3 b8[4];
+            auto read_h = [&](int s2) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) hacc[t] = *reinterpret_cast<const f32x4*>(T.dws + ((w * 2 + 1) * 256 + ((lane * 4 + t * 16) & 255)));
-                X3Depthwise dw2;
-                dw2.template load<1>(T.dws + (w * 2 + 1) * 256, lg);
-                dw2.template gather<1, true>(hacc, hi_, mL_, mR_, 0, 2, d.w1_inv);
-                dw2.template taps<1>(0, 4);
-                half_t* const o2h = T.t2h + ((kk + 1) & 1) * 64 * TROW;
-                half_t* const o2l = T.t2l + ((kk + 1) & 1) * 64 * TROW;
-                const int cl = (w * 2 + 1) * 16 + lg * 4 + 2;
+                for (int t = 0; t < 4; ++t) bh[s2 & 1][t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+            };
+            auto read_8 = [&](int J) {                                  // lane group lg: 0, 1 = hi8 of k [0, 32), [32, 64) of the step; 2, 3 = lo8 of the same
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    uint32_t h_, l_;
-                    split_pair(dw2.outv[t][2], dw2.outv[t][3], h_, l_);
-                    *reinterpret_cast<uint32_t*>(o2h + (t * 16 + l15) * TROW + cl) = h_;
-                    *reinterpret_cast<uint32_t*>(o2l + (t * 16 + l15) * TROW + cl) = l_;
-                }
-            }
-            half8 bh[2][4], bl[2][4];
-            auto read_t2 = [&](int s2, half8 (&h)[4], half8 (&l)[4]) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    h[t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
-                    l[t] = *reinterpret_cast<const half8*>(t2l + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                    const char* pp = t2b + (t * 16 + l15) * T8ROW + (lg >> 1) * T8LO + J * 64 + (lg & 1) * 32;
+                    b8[t] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 16));
                 }
             };
-            read_t2(0, bh[0], bl[0]);
+            const int knext = kk + 1 < n ? kk + 1 : kk;                 // (behind the last chunk: a valid address, no branch in the stretch)
+            read_h(0);
+            read_8(0);
 #pragma unroll
             for (int s2 = 0; s2 < CK / 32; ++s2) {
-                if (s2 + 1 < CK / 32) read_t2(s2 + 1, bh[(s2 + 1) & 1], bl[(s2 + 1) & 1]);
+                if (s2 + 1 < CK / 32) read_h(s2 + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) x3_mfma(p_l[s2 % PW][j], bh[s2 & 1][t], accX[j][t], !(X3_ABL & 4));
+                    for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 & 1][j], bh[s2 & 1][t], accX[j][t], !(X3_ABL & 4));
+                if (s2 & 1) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
+                    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bl[s2 & 1][t], accX[j][t], !(X3_ABL & 4));
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) x3_mfma(p_h[s2 % PW][j], bh[s2 & 1][t], accX[j][t], !(X3_ABL & 4));
-                if (s2 + PW < CK / 32) load_p(kk, s2 + PW);
-                else load_p(kk + 1 < n ? kk + 1 : kk, s2 + PW - CK / 32);
+                        for (int t = 0; t < 4; ++t) x3_mfma8(p_8[j], b8[t], accX[j][t], !(X3_ABL & 4));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s2 == 1) { read_8(1); load_p8(kk, 1); } else load_p8(knext, 0);
+                }
+                if (s2 + 2 < CK / 32) load_ph(kk, s2 + 2); else load_ph(knext, s2 + 2 - CK / 32);
                 __builtin_amdgcn_sched_barrier(0);
             }
             X3_STAMP(10);
             if (kk + 1 < n) __syncthreads();
             X3_STAMP(11);
+        }
+        {   // back out of the project weights' scale
+            const float pi = d.w3_inv;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) accX[j][t] *= pi;
         }
         // block epilogue: accX IS the new stream; its operand forms go to LDS unless the next block gates it first (the SE phase writes them then)
         const bool next_gated = blk + 1 < a.nblocks && a.blocks[blk + 1].se_kind != 0;

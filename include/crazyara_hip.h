@@ -55,6 +55,9 @@ void mi_net_destroy(mi_net* net);
 /* The weight quantiser of precision "fp8" (host only): float -> OCP e4m3fn byte, round to nearest even, |v| >= 448 clamps to +-448,
  * NaN -> 0x7f.  Exposed so that the CPU test suite can pin it against an independent e4m3 conversion. */
 int mi_e4m3_from_float(float v);
+/* The weight quantiser of the cross-term images of precision "float16p8" (host only): float -> e5m2 byte (f16's exponent field, two
+ * mantissa bits), round to nearest even, subnormals kept, beyond the range the largest finite value.  Exposed for the same reason. */
+int mi_e5m2_from_float(float v);
 
 /* Offline form of the same import: parse the ONNX file and write it as a .cranet container (what TensorrtAPI caches as a
  * serialized engine next to the ONNX, tensorrtapi.cpp:297-332).  Host only, no GPU needed.  0 on success. */

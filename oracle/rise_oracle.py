@@ -272,23 +272,38 @@ def _x3_layer(sd, x, conv, bn, padding=0):
     return _x3_conv(x, sd[conv + ".weight"].double(), padding)
 
 
-# Precision float16p8 = float16x3 whose one-launch tower (3x3 bottleneck blocks at 256 channels) runs its EXPAND contraction as
-#   f16 main term  hi(x) * hi(W')                                   W' = w * 2^p, p = 11 - floor(log2(max |w|)) over the layer (BN folded, double)
-# + e4m3 cross term e4m3(hi(x)) * e4m3(W' - hi(W'))                 hi(.) = rne_f16, x = the residual stream (f32: it lives in registers there)
-# + e4m3 cross term e4m3((x - hi(x)) * 2^11) * e4m3(W' * 2^-11)     (e4m3 = OCP e4m3fn, round to nearest even, clamped at +-448)
-# all three carrying 2^p, exact accumulation here (f32 in the kernel), the sum times 2^-p in front of the BN1 bias.  The project contraction is
-# float16x3's, accumulated on the f32 residual itself (x + b3 + sum), everything outside the tower is forward_x3.
+# Precision float16p8 = float16x3 whose one-launch tower (3x3 bottleneck blocks at 256 channels) runs BOTH of its 1x1 contractions as
+#   f16 main term   hi(a) * hi(W')                          W' = w * 2^p, p = 11 - floor(log2(max |w|)) over the layer (BN folded, double)
+# + e5m2 cross term t8(hi(a)) * r8((W' - hi(W')) * c)       hi(.) = rne_f16; a = the f32 operand (residual stream / depthwise output)
+# + e5m2 cross term t8(lo(a)) * r8(hi(W') * c)              lo(a) = rne_f16(a - hi(a)) (the difference is exact in f32)
+# t8 = the HIGH BYTE of the f16 value (e5m2 has f16's exponent field: truncation to two mantissa bits, one byte permute in the kernel),
+# r8 = e5m2 round to nearest even (host side), c = 1 / (1 - ln 2 / 8): the mean loss of the truncation taken back on the weight images
+# (scripts/studies/p8_format_study.py).  All three products carry 2^p; exact accumulation here (f32 in the kernel), the sum times 2^-p in
+# front of the BN bias.  Everything outside the tower is forward_x3.
+P8_TRUNC_COMPENSATION = 1.0 / (1.0 - 0.125 * 0.6931471805599453)
+
+
+def _e5m2_high_byte(x16):
+    b = x16.contiguous().view(torch.int16).to(torch.int32) & 0xFF00
+    return torch.where(b >= 0x8000, b - 0x10000, b).to(torch.int16).view(torch.float16).double()
+
+
+def _e5m2_rne(x):
+    return x.float().to(torch.float8_e5m2).double()
+
+
 def _p8_conv(x, w):
     m = w.abs().max()
     e = torch.floor(torch.log2(m)) if float(m) > 0 else torch.tensor(0.0, dtype=torch.float64)
     p = 11.0 - float(e)
     W = w * (2.0 ** p)
     wh = W.float().to(torch.float16).double()
-    xh = x.float().to(torch.float16).double()
-    res = x.double() - xh                                   # exact in f32
+    xh16 = x.float().to(torch.float16)
+    xh = xh16.double()
+    xl16 = (x.double() - xh).float().to(torch.float16)      # the difference is exact in f32
     main = F.conv2d(xh, wh)
-    c1 = F.conv2d(q_e4m3(xh).double(), q_e4m3(W - wh).double())
-    c2 = F.conv2d(q_e4m3(res * 2048.0).double(), q_e4m3(W / 2048.0).double())
+    c1 = F.conv2d(_e5m2_high_byte(xh16), _e5m2_rne((W - wh) * P8_TRUNC_COMPENSATION))
+    c2 = F.conv2d(_e5m2_high_byte(xl16), _e5m2_rne(wh * P8_TRUNC_COMPENSATION))
     return ((main + c1 + c2) * (2.0 ** -p)).float()
 
 
@@ -338,7 +353,11 @@ def forward_x3(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, p8
             t = F.relu(_x3_layer(sd, h, p + ".body.0", p + ".body.1"))
         cop = t.shape[1]
         t = F.relu(_bn(sd, p + ".body.4", F.conv2d(t, sd[p + ".body.3.weight"], padding=k // 2, groups=cop)))
-        h = h + _x3_layer(sd, t, p + ".body.6", p + ".body.7")
+        if in_p8_tower:
+            w3, b3 = _fold(sd, p + ".body.6", p + ".body.7")
+            h = h + (_p8_conv(t, w3) + b3.float().view(1, -1, 1, 1))
+        else:
+            h = h + _x3_layer(sd, t, p + ".body.6", p + ".body.7")
     B = x.shape[0]
     ph = F.relu(_x3_layer(sd, h, "policy_head.body.0", "policy_head.body.1", 1))
     if cfg.select_policy_from_plane:

@@ -44,6 +44,8 @@ int main(int argc, char** argv) {
         b.b3 = upload(b3);
         b.cop_pad = cop_pad;
         b.w1_inv = 1.f;
+        b.w3_scale = 1.f;
+        b.w3_inv = 1.f;
         blocks.push_back(b);
         flops += 2.0 * 64 * cop * (2.0 * 256 + 9) * B;
     }
@@ -56,7 +58,6 @@ int main(int argc, char** argv) {
     a.nblocks = nblocks;
     a.batch = B;
     a.p8 = p8;
-    a.lo_scale = 1.f / 2048.f;
     init_x3_kernel_attributes();
     hipStream_t s;
     CK(hipStreamCreate(&s));

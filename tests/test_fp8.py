@@ -36,6 +36,23 @@ def test_host_e4m3_quantiser_matches_torch(hip_lib):
     assert hip_lib.mi_e4m3_from_float(1e9) == 0x7e and hip_lib.mi_e4m3_from_float(-1e9) == 0xfe
 
 
+def test_host_e5m2_quantiser_matches_torch(hip_lib):
+    """the weight images of the float16p8 cross terms (rise_net.hip: pack_dense_p8) against torch's float8_e5m2"""
+    from crazyara_amd import _capi
+    hip_lib = _capi.load()
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([rng.standard_normal(4000).astype(np.float32) * s for s in (1e-5, 1e-4, 1e-3, 0.1, 1, 10, 1000, 20000)] +
+                          [np.array([0, 1, -1, 1.125, 1.375, 1.25, 57344, 2.0 ** -14, 2.0 ** -16, 2.0 ** -17, 1.5 * 2.0 ** -16, 2.5 * 2.0 ** -16,
+                                     3.5 * 2.0 ** -16, 0.99 * 2.0 ** -14, 3.9 * 2.0 ** -16], np.float32)])
+    vals = vals[np.abs(vals) <= 57344]
+    ref = torch.from_numpy(vals).to(torch.float8_e5m2).view(torch.uint8).numpy()
+    got = np.array([hip_lib.mi_e5m2_from_float(float(v)) for v in vals], np.uint8)
+    same = (ref == got) | (((ref & 0x7f) == 0) & ((got & 0x7f) == 0))
+    assert same.all(), [(float(vals[i]), hex(ref[i]), hex(got[i])) for i in np.nonzero(~same)[0][:8]]
+    assert hip_lib.mi_e5m2_from_float(1.125) == 0x3c and hip_lib.mi_e5m2_from_float(1.375) == 0x3e      # ties to even
+    assert hip_lib.mi_e5m2_from_float(1e9) == 0x7b and hip_lib.mi_e5m2_from_float(-1e9) == 0xfb          # saturates
+
+
 def test_row_scales_are_powers_of_two_that_normalise_the_row():
     w = torch.tensor([[0.3, -0.02], [1.0, 0.0], [0.0, 0.0], [1e-3, 7e-4], [3.99, 0.1]], dtype=torch.float64).view(5, 2, 1, 1)
     s = ro.row_scale_pow2(w)

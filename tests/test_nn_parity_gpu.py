@@ -39,7 +39,9 @@ def logit_tol(tol, ref_logits):
 TOL["float16x3"] = TOL["float32"]
 TOL["float16x3-perblock"] = TOL["float32"]  # one launch per 3x3 block (block_x3_kernel); plain float16x3 runs them in one launch (tower_x3_kernel)
 TOL["float16x3-unfused"] = TOL["float32"]   # every block on the layer kernels (conv GEMM x3 / float depthwise), as the 5x5 blocks always are
-TOL["float16p8"] = TOL["float32"]           # float16x3 with the tower's project cross terms on e4m3 MFMAs: the same 1e-4 bound (emulated 1e-5 ... 7e-5)
+# float16x3 whose one-launch tower takes the cross terms of both 1x1 GEMMs through e5m2 MFMAs (truncated activation bytes): emulated
+# 5e-5 ... 1.3e-4 on the logits, 3e-5 on the value (scripts/studies/p8_format_study.py); bounds at twice that, a third of north_star's 1e-3
+TOL["float16p8"] = dict(logit=3e-4, logit_rel=None, value=1e-4, prob=1e-6, aux=1e-4)
 TOL["float32-unfused"] = TOL["float32"]
 TOL["float16-unfused"] = TOL["float16"]
 TOL["float16-perblock"] = TOL["float16"]
@@ -444,16 +446,19 @@ def test_float16x3_two_role_tower_equals_the_symmetric_one_bit_for_bit(tmp_path,
 
 @pytest.mark.parametrize("name", ["risev2-3", "risev2-7", "risev2-13", "risev2-19", "risev33", "risev33-wdlp", "risev2-13-lichess"])
 def test_float16p8_equals_its_emulation(tmp_path, hip_lib, name):
-    """Precision float16p8 is DEFINED by oracle.forward_p8 (f16 main term + two e4m3 cross terms in the tower's project contraction,
-    everything else float16x3): the kernel must sit much closer to that definition than the mode sits to fp32 -- what is left is the
-    f32 accumulation order of the matrix unit -- and the mode itself within 1e-4 of fp32 on the logits (north_star: 1e-3)."""
+    """Precision float16p8 is DEFINED by oracle.forward_p8 (f16 main term + two e5m2 cross terms in the two 1x1 contractions of the
+    one-launch tower, everything else float16x3): the kernel must sit much closer to that definition than the mode sits to fp32 -- what
+    is left is the f32 accumulation order of the matrix unit -- and the mode itself within 3e-4 of fp32 on the logits (north_star: 1e-3)."""
     cfg, sd, x, value, probs, aux, logits = _run(tmp_path, hip_lib, name, "float16p8")
     e_value, e_logits, _ = ro.forward_p8(cfg, sd, x)
     o_value, o_logits, _ = ro.forward(cfg, sd, x)
     mode = float((e_logits - o_logits).abs().max())
     kernel_vs_emulation = float(np.abs(logits - e_logits.numpy()).max())
     kernel_vs_fp32 = float(np.abs(logits - o_logits.numpy()).max())
-    assert 2e-6 < mode < 1e-4, mode                                    # the mode is not float16x3 (1e-6) and not float16 (1e-3)
-    assert kernel_vs_emulation < max(1.5e-5, 0.5 * mode), (kernel_vs_emulation, mode)      # measured 3e-6 ... 1.05e-5 (19 blocks of f32 summation order)
-    assert kernel_vs_fp32 < 1e-4
-    assert np.abs(value - e_value.numpy().reshape(-1)).max() < 5e-6
+    assert 5e-6 < mode < 3e-4, mode                                    # the mode is not float16x3 (1e-6) and not float16 (1e-3)
+    # The 8-bit images are discontinuous functions of the activations (truncation to two mantissa bits): a difference of one f32 ulp between the
+    # kernel's and the emulation's accumulation order flips a byte here and there, and each flip is worth 2^-13 of a product.  The emulation
+    # moves by 4e-5 ... 6e-5 on these nets when its weights are perturbed by 1e-7 (profiles/NOTES.md, round 4); the kernel may sit that far away.
+    assert kernel_vs_emulation < max(2e-5, 0.75 * mode), (kernel_vs_emulation, mode)
+    assert kernel_vs_fp32 < 3e-4
+    assert np.abs(value - e_value.numpy().reshape(-1)).max() < 2.5e-5

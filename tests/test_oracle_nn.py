@@ -85,13 +85,13 @@ def test_float16x3_split_carries_22_bits():
 
 @pytest.mark.parametrize("name", ["risev2-3", "risev2-7", "risev2-19", "risev33", "risev2-13-lichess"])
 def test_float16p8_emulation_is_conformant(name):
-    """Precision float16p8 (crazyara_amd/csrc/nn/x3.hip: tower_p8_kernel) is DEFINED by oracle.forward_p8: float16x3 whose tower runs the expand
-    contraction as f16 main term + two e4m3 cross terms.  The definition sits within 1e-4 of the fp32 oracle on the logits (north_star:
-    1e-3) and an order of magnitude above float16x3's round-off: a mode of its own, not an alias."""
+    """Precision float16p8 (crazyara_amd/csrc/nn/x3.hip: tower_p8_kernel) is DEFINED by oracle.forward_p8: float16x3 whose tower runs its two 1x1
+    contractions as f16 main term + two e5m2 cross terms (truncated activation bytes, compensated weight images).  The definition sits within
+    3e-4 of the fp32 oracle on the logits (north_star: 1e-3) and an order of magnitude above float16x3's round-off: a mode of its own, not an alias."""
     cfg, sd, x = nn_cases.make_case(name)
     v32, l32, _ = ro.forward(cfg, sd, x)
     v8, l8, _ = ro.forward_p8(cfg, sd, x)
     v3, l3, _ = ro.forward_x3(cfg, sd, x)
     e8, e3 = float((l8 - l32).abs().max()), float((l3 - l32).abs().max())
-    assert e8 < 1e-4 and float((v8 - v32).abs().max()) < 2e-5
+    assert e8 < 3e-4 and float((v8 - v32).abs().max()) < 1e-4
     assert e8 > 2 * e3

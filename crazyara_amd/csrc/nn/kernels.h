@@ -84,7 +84,7 @@ int block_x3_chunk_channels();
 // by the caller's SE launch)
 struct X3TowerBlock {
     const void *w1pk, *w1pk_lo, *w3pk, *w3pk_lo;     // as BlockArgs
-    const float* dwpk;                               // [cop_pad / 16 tiles][12 rows: 9 folded taps, BN1 bias, BN2 bias, 0][16 channels] + 64 floats of padding (a wave loads 1 KiB where a tile's records start)
+    const float* dwpk;                               // [cop_pad / 16 tiles][16 rows: taps dx = -1 (dy = -1, 0, 1), dx = 0, dx = +1, BN1 bias, BN2 bias, 5 x 0][16 channels] (rise_net.hip: pack_x3_depthwise_records)
     const float* b3;                                 // [256]
     const float* se_w1t;                             // gate matrices in THREAD order (x3.hip: x3_se_phase; rise_net.hip: pack_se_threads_f32):
     const float* se_w2t;                             //   ca_se: W1 then W2, 16 float4 loads per thread each; eca_se: se_w1t = both halves

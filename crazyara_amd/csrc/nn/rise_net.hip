@@ -177,14 +177,15 @@ SplitPack pack_dense_p8(const Folded& f, int cout, int cin, int cout_pad, int ci
     return out;
 }
 
-// Precision float16x3, depthwise 3x3 records of a block (x3.hip: x3_depthwise): per tile of 16 expanded channels 12 rows of 16 floats --
-// the 9 folded taps, the BN1 bias, the BN2 bias, zeros -- so that a lane reads one tap of its 4 channels with one 16-byte LDS read;
-// + 64 floats of padding (a wave loads 1 KiB where a tile's 768 bytes start)
+// Precision float16x3, depthwise 3x3 records of a block (x3.hip: X3Depthwise): per tile of 16 expanded channels 16 rows of 16 floats (1 KiB,
+// one 16-byte load per lane) -- rows 0-2 the folded taps of column dx = -1 (dy = -1, 0, 1), rows 3-5 dx = 0, rows 6-8 dx = +1, row 9 the BN1
+// bias, row 10 the BN2 bias, rows 11-15 zeros: a lane on file a / h reads its dx = -1 / +1 weights from rows 11-13
 std::vector<float> pack_x3_depthwise_records(const Folded& bn1, const Folded& dw, int cop, int cop_pad) {
-    std::vector<float> rec(size_t(cop_pad) * 12 + 64, 0.f);
+    std::vector<float> rec(size_t(cop_pad) * 16, 0.f);
     for (int c = 0; c < cop; ++c) {
-        float* tile = rec.data() + size_t(c / 16) * 192 + (c % 16);
-        for (int t = 0; t < 9; ++t) tile[t * 16] = float(dw.w[size_t(c) * 9 + t]);
+        float* tile = rec.data() + size_t(c / 16) * 256 + (c % 16);
+        for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) tile[(dx * 3 + dy) * 16] = float(dw.w[size_t(c) * 9 + dy * 3 + dx]);
         tile[9 * 16] = float(bn1.b[c]);
         tile[10 * 16] = float(dw.b[c]);
     }

@@ -441,7 +441,7 @@ static_assert(X3Block::lds_bytes <= 160 * 1024, "LDS budget");
 struct X3Tiles {
     half_t *xh, *xl;        // [64][XROW] block input = residual stream, hi / lo
     half_t *t2h, *t2l;      // [T2BUF][64][TROW] depthwise output of a chunk, hi / lo (buffer = chunk parity)
-    float* dws;             // [8 waves][NE][256 floats] the waves' depthwise records of the chunk (16 channels x 12 floats + pad each)
+    float* dws;             // [8 waves][NE][256 floats] the waves' depthwise records of the chunk (16 rows x 16 channels each)
 };
 __device__ __forceinline__ X3Tiles x3_tiles(char* smem) {
     X3Tiles t;
@@ -469,20 +469,23 @@ __device__ __forceinline__ f32x2 pair_of(const f32x4& v, int p) { return p == 0 
 // block_kernel_dpp (kernels.hip).  A lane holds 4 channels (accumulator rows r) of one file on ranks t / t + 4 (x3_row); channels go two
 // at a time (P = 0, 1).
 // Horizontal neighbours: row_shr:1 / row_shl:1 copies, each feeding the three outputs it is up / mid / down neighbour of; lane 8 would
-// read lane 7 (file h of the other rank) and lane 0 a zero: the file-edge masks are folded into the dx = -1 / +1 weights.
+// read lane 7 (file h of the other rank) and lane 0 a zero: a lane on file a / h reads its dx = -1 / +1 weights from the record's ZERO rows
+// (an address offset computed once per kernel, x3_edge_offsets; as six multiplies per channel the masks were 7 % of the depthwise).
 // In pieces (load, gather<P>, taps<P>) so that a caller can spread them over a stretch of MFMAs.
-//   rec: this tile's records in LDS, [12 rows: 9 taps, BN1 bias, BN2 bias, 0][16 channels]
+//   rec: this tile's records in LDS, [16 rows: taps dx = -1 (dy = -1, 0, 1), dx = 0, dx = +1, BN1 bias, BN2 bias, 5 rows of zeros][16 channels]
+struct X3EdgeOffsets { int left, right; };                       // in floats: 11 rows / 5 rows from the dx = -1 / +1 rows to the zero rows, or 0
+__device__ __forceinline__ X3EdgeOffsets x3_edge_offsets(int l15) { return X3EdgeOffsets{(l15 & 7) == 0 ? 11 * 16 : 0, (l15 & 7) == 7 ? 5 * 16 : 0}; }
 struct X3Depthwise {
-    f32x2 w[11];                                                 // the current channel pair's records
+    f32x2 w[11];                                                 // the current channel pair's records (rows 0 ... 10)
     f32x2 S[6], L[6], R[6];                                      // rank - 1 ... rank + 4 of this lane's half: S[1 + t] = tile t
     float outv[4][4];                                            // [tile][channel r]
 
-    template <int P> __device__ __forceinline__ void load(const float* rec, int lg) {
+    template <int P> __device__ __forceinline__ void load(const float* rec, int lg, const X3EdgeOffsets& e) {
 #pragma unroll
-        for (int q = 0; q < 11; ++q) w[q] = *reinterpret_cast<const f32x2*>(rec + q * 16 + lg * 4 + 2 * P);
+        for (int q = 0; q < 11; ++q) w[q] = *reinterpret_cast<const f32x2*>(rec + (q < 3 ? e.left : q >= 6 && q < 9 ? e.right : 0) + q * 16 + lg * 4 + 2 * P);
     }
     // acc_scale: the accumulators carry the weights' power-of-two scale (Precision float16p8): S = relu(acc * acc_scale + bias), one FMA instead of the add
-    template <int P, bool SCALED = false> __device__ __forceinline__ void gather(const f32x4 (&acc)[4], bool upper, float mL, float mR, int c0 = 0, int c1 = 2, float acc_scale = 1.f) {
+    template <int P, bool SCALED = false> __device__ __forceinline__ void gather(const f32x4 (&acc)[4], bool upper, int c0 = 0, int c1 = 2, float acc_scale = 1.f) {
         if constexpr (X3_ABL & 1) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) S[1 + t] = pair_of(acc[t], P) + w[0];
@@ -491,8 +494,6 @@ struct X3Depthwise {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (c < c0 || c >= c1) continue;
-            w[0][c] *= mL; w[3][c] *= mL; w[6][c] *= mL;
-            w[2][c] *= mR; w[5][c] *= mR; w[8][c] *= mR;
 #pragma unroll
             for (int t = 0; t < 4; ++t) S[1 + t][c] = SCALED ? fmaxf(fmaf(acc[t][2 * P + c], acc_scale, w[9][c]), 0.f) : fmaxf(acc[t][2 * P + c] + w[9][c], 0.f);
             const float across_up = dpp_mov<DPP_ROW_ROR8>(S[4][c]), across_dn = dpp_mov<DPP_ROW_ROR8>(S[1][c]);
@@ -520,9 +521,9 @@ struct X3Depthwise {
                 float a = w[10][c];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
-                    a = fmaf(w[dy * 3 + 0][c], L[t + dy][c], a);
-                    a = fmaf(w[dy * 3 + 1][c], S[t + dy][c], a);
-                    a = fmaf(w[dy * 3 + 2][c], R[t + dy][c], a);
+                    a = fmaf(w[dy][c], L[t + dy][c], a);
+                    a = fmaf(w[3 + dy][c], S[t + dy][c], a);
+                    a = fmaf(w[6 + dy][c], R[t + dy][c], a);
                 }
                 outv[t][2 * P + c] = fmaxf(a, 0.f);
             }
@@ -537,13 +538,13 @@ struct X3Depthwise {
                 if (t >= t0 && t < t1) asm volatile("" : "+v"(outv[t][2 * P + c]));
     }
 };
-__device__ __forceinline__ void x3_depthwise(const f32x4 (&acc)[4], const float* rec, int lg, bool upper, float mL, float mR, float (&outv)[4][4]) {
+__device__ __forceinline__ void x3_depthwise(const f32x4 (&acc)[4], const float* rec, int lg, bool upper, const X3EdgeOffsets& e, float (&outv)[4][4]) {
     X3Depthwise dw;
-    dw.template load<0>(rec, lg);
-    dw.template gather<0>(acc, upper, mL, mR);
+    dw.template load<0>(rec, lg, e);
+    dw.template gather<0>(acc, upper);
     dw.template taps<0>(0, 4);
-    dw.template load<1>(rec, lg);
-    dw.template gather<1>(acc, upper, mL, mR);
+    dw.template load<1>(rec, lg, e);
+    dw.template gather<1>(acc, upper);
     dw.template taps<1>(0, 4);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -579,7 +580,7 @@ __device__ __forceinline__ void x3_stage_tile(const X3Tiles& T, const float* xb,
 // counter too: every wait for an LDS operand then also waits for the weight fragments requested slabs ahead.)
 struct X3Weights {
     __amdgpu_buffer_rsrc_t w1h, w1l, w3h, w3l;   // packed expand / project weights, hi / lo (kernels.h: packed-weight geometry)
-    __amdgpu_buffer_rsrc_t dw;                   // [cop_pad / 16 tiles][12 rows: 9 folded taps, BN1 bias, BN2 bias, 0][16 channels] floats
+    __amdgpu_buffer_rsrc_t dw;                   // [cop_pad / 16 tiles][16 rows: taps, BN1 bias, BN2 bias, zeros (X3Depthwise)][16 channels] floats
     int cop_pad;
 };
 // The pointer is wave-uniform, but read from a descriptor array in device memory the compiler has it in VGPRs and wraps EVERY buffer load
@@ -616,8 +617,7 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
     const int nchunk = W.cop_pad / CK;
     const int nslab3 = W.cop_pad >> 5;
     const bool hi = l15 >= 8;                                  // the tile's second rank (t + 4, x3_row)
-    const float mL = (l15 & 7) != 0 ? 1.f : 0.f;               // a left / right neighbour exists on the board
-    const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
+    const X3EdgeOffsets edge = x3_edge_offsets(l15);             // a lane on file a / h has no left / right neighbour on the board
 
     // Weight fragments come through two small rolling windows (a phase's whole set in registers leaves the compiler no room in the
     // one-launch tower): the expand window holds EW of the 8 k-slabs (hi + lo, NE channel tiles), the project window PW of CK / 32.
@@ -651,14 +651,14 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
         for (int ne = 0; ne < NE; ++ne)
 #pragma unroll
             for (int t = 0; t < 4; ++t) accE[ne][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // Depthwise records (per 16-channel tile 12 rows of 16 floats: 9 taps, BN1 bias, BN2 bias, 0) of my NE tiles: ONE 16-byte load per lane and tile
-        // (768 of its 1024 bytes are the tile's records), parked in a wave-private LDS scratch half-way through the expand MFMAs and read
-        // back per lane as 12 broadcast reads.  (Loaded per lane straight from L2 -- 12 loads of which 16 lanes each fetch the same
+        // Depthwise records (per 16-channel tile 16 rows of 16 floats: X3Depthwise) of my NE tiles: ONE 16-byte load per lane and tile
+        // (the tile's 1 KiB), parked in a wave-private LDS scratch half-way through the expand MFMAs and read back per lane as 11
+        // broadcast reads per channel pair.  (Loaded per lane straight from L2 -- 12 loads of which 16 lanes each fetch the same
         // bytes -- the records were a quarter of all bytes on the 64 B/clk L2 -> CU path, which this loop nearly saturates.)
         f32x4 dw_raw[NE];
 #pragma unroll
         for (int ne = 0; ne < NE; ++ne)
-            dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(ch * CK + (wave * NE + ne) * 16) * 48u, 0));
+            dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(ch * CK + (wave * NE + ne) * 16) * 64u, 0));
         float* my_dws = T.dws + (wave * NE) * 256;
         auto park_dw = [&]() {
 #pragma unroll
@@ -725,7 +725,7 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
 #pragma unroll
         for (int ne = 0; ne < NE; ++ne) {
             float outv[4][4];                                   // [tile][channel r]
-            x3_depthwise(accE[ne], my_dws + ne * 256, lg, hi, mL, mR, outv);
+            x3_depthwise(accE[ne], my_dws + ne * 256, lg, hi, edge, outv);
             const int cl = (wave * NE + ne) * 16 + lg * 4;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -1048,8 +1048,7 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
         // barriers of a block, the same for both roles: one behind each of the halves 0 ... 2n, then the one behind the epilogue
         if (expand_role) {
             const bool hi = l15 >= 8;                                  // the tile's second rank (t + 4, x3_row)
-            const float mL = (l15 & 7) != 0 ? 1.f : 0.f;               // a left / right neighbour exists on the board
-            const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
+            const X3EdgeOffsets edge = x3_edge_offsets(l15);             // a lane on file a / h has no left / right neighbour on the board
             // expand weight window: EW of the 8 k-slabs x 2 channel tiles x (hi, lo); the stream runs on across chunk boundaries: slab s of
             // chunk i sits in slot s % EW and is refilled with the slab EW positions ahead right behind its MFMAs
 #if defined(CRA_DEVELOPMENT) && defined(CRA_X3_EW)
@@ -1099,22 +1098,22 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                     // the interval, behind the depthwise that still reads chunk i - 1's
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
-                        dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(i * CK + (w * 2 + ne) * 16) * 48u, 0));
+                        dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(i * CK + (w * 2 + ne) * 16) * 64u, 0));
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
 #pragma unroll
                         for (int t = 0; t < 4; ++t) accE[ne][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                     read_step(0); read_step(1); read_step(2);
                 }
-                if constexpr (HASD) dw.template load<0>(my_dws, lg);
+                if constexpr (HASD) dw.template load<0>(my_dws, lg, edge);
                 half_t* const t2h = T.t2h + ((i - 1) & 1) * 64 * TROW;
                 half_t* const t2l = T.t2l + ((i - 1) & 1) * 64 * TROW;
 #pragma unroll
                 for (int sl = 0; sl < C / 32; ++sl) {
                     const int dt = sl / 4, ph = sl % 4;                 // the depthwise's tile and quarter
                     if constexpr (HASD) {
-                        if (ph == 2) dw.template load<1>(my_dws + dt * 256, lg);
-                        if (sl == 4) dw.template load<0>(my_dws + 256, lg);      // (tile 0's last pieces ran in slab 3)
+                        if (ph == 2) dw.template load<1>(my_dws + dt * 256, lg, edge);
+                        if (sl == 4) dw.template load<0>(my_dws + 256, lg, edge);      // (tile 0's last pieces ran in slab 3)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (HASE) {
@@ -1138,9 +1137,9 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                         else load_e(i + 1 < n ? i + 1 : i, sl + EW - C / 32);    // (behind the last chunk: a valid address, no branch in the stretch)
                     }
                     if constexpr (HASD) {
-                        if (ph == 0) dw.template gather<0>(accD[dt], hi, mL, mR);
+                        if (ph == 0) dw.template gather<0>(accD[dt], hi);
                         if (ph == 1) { dw.template taps<0>(0, 4); dw.pin_taps(0, 4, 0); }
-                        if (ph == 2) dw.template gather<1>(accD[dt], hi, mL, mR);
+                        if (ph == 2) dw.template gather<1>(accD[dt], hi);
                         if (ph == 3) {
                             dw.template taps<1>(0, 4);
                             const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1
@@ -1410,8 +1409,7 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
     if (wave < 4) {
         // =================================================== EXPAND waves ===================================================
         const bool hi = l15 >= 8;
-        const float mL = (l15 & 7) != 0 ? 1.f : 0.f;
-        const float mR = (l15 & 7) != 7 ? 1.f : 0.f;
+        const X3EdgeOffsets edge = x3_edge_offsets(l15);
         __syncthreads();                                                // the PROJECT waves have written block 0's operand tiles
         for (int blk = 0; blk < a.nblocks; ++blk) {
             const X3TowerBlock& d = a.blocks[blk];
@@ -1464,7 +1462,7 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                 if constexpr (HASE) {
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
-                        dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(i * CK + (w * 2 + ne) * 16) * 48u, 0));
+                        dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(i * CK + (w * 2 + ne) * 16) * 64u, 0));
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
 #pragma unroll
@@ -1472,15 +1470,15 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                     read_h(0); read_h(1); read_h(2);
                     read_8(0); read_8(1);
                 }
-                if constexpr (HASD) dw.template load<0>(my_dws, lg);
+                if constexpr (HASD) dw.template load<0>(my_dws, lg, edge);
                 half_t* const t2h = T.t2h + ((i - 1) & 1) * 64 * TROW;
                 char* const t2b = t28 + ((i - 1) & 1) * 64 * T8ROW;
 #pragma unroll
                 for (int sl = 0; sl < C / 32; ++sl) {
                     const int dt = sl / 4, ph = sl % 4;
                     if constexpr (HASD) {
-                        if (ph == 2) dw.template load<1>(my_dws + dt * 256, lg);
-                        if (sl == 4) dw.template load<0>(my_dws + 256, lg);
+                        if (ph == 2) dw.template load<1>(my_dws + dt * 256, lg, edge);
+                        if (sl == 4) dw.template load<0>(my_dws + 256, lg, edge);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (HASE) {
@@ -1501,9 +1499,9 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                         if (sl & 1) { if ((sl >> 1) + 1 < C / 64) load_e8(i, (sl >> 1) + 1); else load_e8(inext, 0); }
                     }
                     if constexpr (HASD) {
-                        if (ph == 0) dw.template gather<0, true>(accD[dt], hi, mL, mR, 0, 2, e_inv);
+                        if (ph == 0) dw.template gather<0, true>(accD[dt], hi, 0, 2, e_inv);
                         if (ph == 1) { dw.template taps<0>(0, 4); dw.pin_taps(0, 4, 0); }
-                        if (ph == 2) dw.template gather<1, true>(accD[dt], hi, mL, mR, 0, 2, e_inv);
+                        if (ph == 2) dw.template gather<1, true>(accD[dt], hi, 0, 2, e_inv);
                         if (ph == 3) {
                             dw.template taps<1>(0, 4);
                             const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1: the f16 hi and the two byte rows

@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
         std::vector<half_t> w1(size_t(cop_pad) * 256), w3(size_t(256) * cop_pad);
         for (auto& v : w1) v = half_t(u(rng));
         for (auto& v : w3) v = half_t(u(rng));
-        std::vector<float> rec(size_t(cop_pad) * 12 + 64), b3(256);
+        std::vector<float> rec(size_t(cop_pad) * 16), b3(256);
         for (auto& v : rec) v = u(rng);
         for (auto& v : b3) v = u(rng);
         X3TowerBlock b{};

@@ -45,6 +45,10 @@ struct ConvArgs {
     // read as zeros (the stem conv does the planes -> NHWC transform while it stages the board)
     const float* planes;
     int planes_c;
+    // Precision float16p8 (x3.hip: conv3x3_p8_kernel; ks = 3, cin a multiple of 128): wpk = f16 image of w * 2^p, wpk_lo = the 8-bit image of the
+    // cross terms (rise_net.hip: pack_dense_p8), acc_scale = 2^-p
+    int p8;
+    float acc_scale;
     int dev;              // development (CRA_X3_CONV_DEV): 1 = every wave leaves the kernel behind one last barrier, 2 = waves without a cout
                           // tile request no weight fragments
 };

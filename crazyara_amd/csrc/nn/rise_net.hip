@@ -145,7 +145,7 @@ uint8_t to_e5m2(float f) {
 // 16-31 in "slab" 2 J + 1 of the lo image's geometry.  c = 1 / (1 - ln 2 / 8): the kernel's activation bytes are TRUNCATED f16 values (their
 // high bytes), which lose 2^e / 8 on average; the weight images take the mean back.  All three products carry the factor 2^p; *inv = 2^-p.
 constexpr double kP8TruncCompensation = 1.0 / (1.0 - 0.125 * 0.6931471805599453);
-SplitPack pack_dense_p8(const Folded& f, int cout, int cin, int cout_pad, int cin_pad, double* inv) {
+SplitPack pack_dense_p8(const Folded& f, int cout, int cin, int ks, int cout_pad, int cin_pad, double* inv) {
     double mx = 0.0;
     for (double v : f.w) mx = std::max(mx, std::fabs(v));
     int e = 0;
@@ -155,18 +155,19 @@ SplitPack pack_dense_p8(const Folded& f, int cout, int cin, int cout_pad, int ci
     Folded fs = f;
     for (double& v : fs.w) v = std::ldexp(v, p);
     SplitPack out;
-    out.hi = pack_dense<half_t>(fs, cout, cin, 1, cout_pad, cin_pad);
-    const int nslab = cin_pad / 32, nct = cout_pad / 16;
-    if (nslab % 2 != 0) throw std::runtime_error("float16p8: K must be a multiple of 64");
-    std::vector<uint8_t> bytes(size_t(cout_pad) * cin_pad * 2, 0);
+    out.hi = pack_dense<half_t>(fs, cout, cin, ks, cout_pad, cin_pad);
+    const int nslab = ks * ks * cin_pad / 32, nct = cout_pad / 16;     // k = tap * cin_pad + ci, as pack_dense walks it
+    if (cin_pad % 64 != 0) throw std::runtime_error("float16p8: K per tap must be a multiple of 64");
+    std::vector<uint8_t> bytes(size_t(cout_pad) * ks * ks * cin_pad * 2, 0);
     for (int ct = 0; ct < nct; ++ct)
         for (int J = 0; J < nslab / 2; ++J)
             for (int l = 0; l < 64; ++l)
                 for (int bb = 0; bb < 32; ++bb) {
                     const int co = ct * 16 + (l & 15), lg = l >> 4, k = 64 * J + (lg & 1) * 32 + bb;
+                    const int tap = k / cin_pad, ci = k % cin_pad;
                     uint8_t q = 0;
-                    if (co < cout && k < cin) {
-                        const double W = fs.w[size_t(co) * cin + k];
+                    if (co < cout && ci < cin) {
+                        const double W = fs.w[(size_t(co) * cin + ci) * ks * ks + tap];
                         const double hi = double(float(half_t(float(W))));
                         q = to_e5m2(float((lg < 2 ? W - hi : hi) * kP8TruncCompensation));
                     }
@@ -412,8 +413,15 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
 
     double macs = 0;
     // packed A-fragment images of a dense layer: T, or the f16 hi / lo pair of Precision float16x3
-    auto set_conv_weights = [&](ConvArgs& c, const Folded& fd, int co, int ci, int k, int co_pad, int ci_pad) {
-        if (x3_) {
+    auto set_conv_weights = [&](ConvArgs& c, const Folded& fd, int co, int ci, int k, int co_pad, int ci_pad, bool p8 = false) {
+        if (p8 && p8_ && k == 3 && ci_pad % 128 == 0) {     // Precision float16p8: the policy head's 3x3 convs (x3.hip: conv3x3_p8_kernel)
+            double inv = 1.0;
+            SplitPack sp = pack_dense_p8(fd, co, ci, k, co_pad, ci_pad, &inv);
+            c.wpk = im.upload(sp.hi);
+            c.wpk_lo = im.upload(sp.lo);
+            c.p8 = 1;
+            c.acc_scale = float(inv);
+        } else if (x3_) {
             SplitPack sp = pack_dense_split(fd, co, ci, k, co_pad, ci_pad);
             c.wpk = im.upload(sp.hi);
             c.wpk_lo = im.upload(sp.lo);
@@ -422,13 +430,13 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
     };
     auto add_conv = [&](const std::string& conv, const std::string& bn, const T* x, T* out, const T* resid, int ci, int ci_pad,
-                        int co, int k, int relu, float* out_policy) {
+                        int co, int k, int relu, float* out_policy, bool p8 = false) {
         Folded fd = fold_bn(nf, conv, bn);
         const int co_pad = round_up(co, 16);
         Op op;
         op.kind = OpKind::Conv;
         op.conv.x = x;
-        set_conv_weights(op.conv, fd, co, ci, k, co_pad, ci_pad);
+        set_conv_weights(op.conv, fd, co, ci, k, co_pad, ci_pad, p8);
         op.conv.bias = im.upload_d2f(fd.b, co_pad);
         op.conv.resid = resid;
         op.conv.out = out_policy ? static_cast<void*>(out_policy) : static_cast<void*>(out);
@@ -918,8 +926,8 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             Folded f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
             Folded f3 = fold_bn(nf, p + ".body.6", p + ".body.7");
             double w1_inv = 1.0, w3_inv = 1.0;
-            SplitPack s1 = p8_ ? pack_dense_p8(f1, cop, C, cop_pad, C, &w1_inv) : pack_dense_split(f1, cop, C, 1, cop_pad, C);
-            SplitPack s3 = p8_ ? pack_dense_p8(f3, C, cop, C, cop_pad, &w3_inv) : pack_dense_split(f3, C, cop, 1, C, cop_pad);
+            SplitPack s1 = p8_ ? pack_dense_p8(f1, cop, C, 1, cop_pad, C, &w1_inv) : pack_dense_split(f1, cop, C, 1, cop_pad, C);
+            SplitPack s3 = p8_ ? pack_dense_p8(f3, C, cop, 1, C, cop_pad, &w3_inv) : pack_dense_split(f3, C, cop, 1, C, cop_pad);
             xb.w1pk = im.upload(s1.hi);
             xb.w1pk_lo = im.upload(s1.lo);
             xb.w3pk = im.upload(s3.hi);
@@ -1100,9 +1108,9 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
     } else {
     // _PolicyHead (select_policy_from_plane), builder_util.py:206-243
-    add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr);
+    add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr, true);
     if (policy_map) {
-        add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_);
+        add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_, true);
     } else {
         // flat labels: conv3x3(C->P) + BN + ReLU written channel-major flat (x.view(-1, nb_flatten)), then Linear(P*64 -> n_labels)
         // as a GEMM over the BATCH (64 boards play the 64 "squares" of a workgroup tile), float logits row per board

@@ -139,6 +139,100 @@ constexpr int X3_ROWP = X3_KC + 8;         // halves per LDS row (+16 B: the 16 
 // ================================================================================================================
 // Dense conv (1x1 / 3x3) as implicit GEMM -- conv_gemm_kernel<float> (kernels.hip) with split operands.
 // ================================================================================================================
+// The epilogue of the conv GEMMs: conv_gemm_kernel<float>'s, word for word (bias, ReLU before / after the shortcut, the four output layouts,
+// the fused row softmax); acc_scale: the accumulators carry the weights' power-of-two scale (Precision float16p8)
+template <int MT, int NW>
+__device__ __forceinline__ void conv_x3_finish(const ConvArgs& a, f32x4 (&acc)[MT][4], const bool (&active)[MT], char* smem, int b, int co_tile0, float acc_scale) {
+    constexpr int NTHR = 64 * NW;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    if (a.softmax_out) __syncthreads();                      // the board's logits gather in the staging tiles: every wave is done reading them
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (!active[m]) continue;
+        const int co0 = (co_tile0 + m) * 16 + lg * 4;
+        float bs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[r] = a.bias[co0 + r];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int sq = t * 16 + l15;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[m][t][r], acc_scale, bs[r]);
+            if (a.relu == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.resid) {
+                float rv[4];
+                load4<float>(reinterpret_cast<const float*>(a.resid) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, rv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rv[r];
+            }
+            if (a.relu == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.out_policy_f32) {
+                float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.cout_real * kSquares;
+                float* lds_logits = reinterpret_cast<float*>(smem);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < a.cout_real) {
+                        if (a.out) o[(co0 + r) * kSquares + sq] = v[r];
+                        if (a.softmax_out) lds_logits[(co0 + r) * kSquares + sq] = v[r];
+                    }
+            } else if (a.out_rows_f32) {
+                const int row = b * kSquares + sq;
+                if (row < a.rows_valid) {
+                    float* o = reinterpret_cast<float*>(a.out) + size_t(row) * a.cout_real;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co0 + r < a.cout_real) o[co0 + r] = v[r];
+                }
+            } else if (a.out_flat) {
+                float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.flat_pitch;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
+            } else {
+                store4<float>(reinterpret_cast<float*>(a.out) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, v);
+            }
+        }
+    }
+    if (a.softmax_out) {
+        // row softmax of the board's logits (softmax_kernel, kernels.hip; apply_softmax(), neuralnetapi.cpp:241-260): exp(x - (max + log(sum)))
+        __syncthreads();
+        const float* in = reinterpret_cast<const float*>(smem);
+        float* red = reinterpret_cast<float*>(smem) + 8192;  // behind the logits (at most 8192 of them: 32 KiB of the 35 KiB)
+        const int n = a.cout_real * kSquares;
+        float* out = a.softmax_out + size_t(b) * n;
+        float m = -INFINITY;
+        for (int i = tid; i < n; i += NTHR) m = fmaxf(m, in[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = red[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) m = fmaxf(m, red[i]);
+        float sum = 0.f;
+        for (int i = tid; i < n; i += NTHR) sum += expf(in[i] - m);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = sum;
+        __syncthreads();
+        sum = red[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) sum += red[i];
+        const float c = m + logf(sum);
+        for (int i = tid; i < n; i += NTHR) out[i] = expf(in[i] - c);
+    }
+}
+
 // Workgroup = one board x (NW waves x MT cout tiles of 16): the board's channels are staged and split ONCE per workgroup, so wide
 // layers take the whole cout range in one workgroup (NW = 8, MT = 2: 256 couts -- stem, policy conv 1; with 64 couts per workgroup the
 // split was redone four times per board), and a stream fragment read from LDS feeds MT x 3 MFMAs.
@@ -305,94 +399,161 @@ __global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a)
         }
     }
 
-    // epilogue: conv_gemm_kernel<float>'s, word for word (bias, ReLU before / after the shortcut, the four output layouts)
-    if (a.softmax_out) __syncthreads();                      // the board's logits gather in the staging tiles: every wave is done reading them
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if (!active[m]) continue;
-        const int co0 = (co_tile0 + m) * 16 + lg * 4;
-        float bs[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bs[r] = a.bias[co0 + r];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int sq = t * 16 + l15;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[m][t][r] + bs[r];
-            if (a.relu == 2) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (a.resid) {
-                float rv[4];
-                load4<float>(reinterpret_cast<const float*>(a.resid) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, rv);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += rv[r];
-            }
-            if (a.relu == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (a.out_policy_f32) {
-                float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.cout_real * kSquares;
-                float* lds_logits = reinterpret_cast<float*>(smem);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co0 + r < a.cout_real) {
-                        if (a.out) o[(co0 + r) * kSquares + sq] = v[r];
-                        if (a.softmax_out) lds_logits[(co0 + r) * kSquares + sq] = v[r];
-                    }
-            } else if (a.out_rows_f32) {
-                const int row = b * kSquares + sq;
-                if (row < a.rows_valid) {
-                    float* o = reinterpret_cast<float*>(a.out) + size_t(row) * a.cout_real;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (co0 + r < a.cout_real) o[co0 + r] = v[r];
-                }
-            } else if (a.out_flat) {
-                float* o = reinterpret_cast<float*>(a.out) + size_t(b) * a.flat_pitch;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co0 + r < a.cout_real) o[(co0 + r) * kSquares + sq] = v[r];
-            } else {
-                store4<float>(reinterpret_cast<float*>(a.out) + (size_t(b) * kSquares + sq) * a.cout_ld + co0, v);
-            }
-        }
-    }
-    if (a.softmax_out) {
-        // row softmax of the board's logits (softmax_kernel, kernels.hip; apply_softmax(), neuralnetapi.cpp:241-260): exp(x - (max + log(sum)))
-        __syncthreads();
-        const float* in = reinterpret_cast<const float*>(smem);
-        float* red = reinterpret_cast<float*>(smem) + 8192;  // behind the logits (at most 8192 of them: 32 KiB of the 35 KiB)
-        const int n = a.cout_real * kSquares;
-        float* out = a.softmax_out + size_t(b) * n;
-        float m = -INFINITY;
-        for (int i = tid; i < n; i += NTHR) m = fmaxf(m, in[i]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-        if (lane == 0) red[wave] = m;
-        __syncthreads();
-        m = red[0];
-#pragma unroll
-        for (int i = 1; i < NW; ++i) m = fmaxf(m, red[i]);
-        float sum = 0.f;
-        for (int i = tid; i < n; i += NTHR) sum += expf(in[i] - m);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-        __syncthreads();
-        if (lane == 0) red[wave] = sum;
-        __syncthreads();
-        sum = red[0];
-#pragma unroll
-        for (int i = 1; i < NW; ++i) sum += red[i];
-        const float c = m + logf(sum);
-        for (int i = tid; i < n; i += NTHR) out[i] = expf(in[i] - c);
-    }
+    conv_x3_finish<MT, NW>(a, acc, active, smem, b, co_tile0, 1.f);
     if (a.dev & 1) __syncthreads();
 }
 
+// Precision float16p8, dense 3x3 conv with cin a multiple of 128 (the two policy convs): conv_gemm_x3_kernel<3, MT, NW, 4> with the cross terms on
+// e5m2 MFMAs -- per (tap, 64 k) two f16 MFMAs hi x hi and one v_mfma_f32_16x16x128_f8f6f4 on [hi8 | lo8] x [w_lo8 ; w_hi8] per cout and
+// square tile instead of six f16 MFMAs (tower_p8_kernel's arithmetic; weights: rise_net.hip pack_dense_p8, the accumulators carry 2^p,
+// a.acc_scale = 2^-p).  The board is staged as the f16 hi tile + a byte tile [hi8, 128 B | lo8, 128 B] per square (the high bytes of the
+// split's f16 pair), double-buffered: the next pass's 32 KB are requested from HBM before this pass's MFMAs and split behind them.
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void conv3x3_p8_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWP = X3_ROWP, KC = X3_KC, NTHR = 64 * NW, R8 = 272, R8LO = 144, NS = KC / 32, NSTEP = 9 * NS, D = 3;
+    static_assert(ROWP * 2 == R8 && KC == 128, "the byte tile has the f16 tile's row pitch");
+    constexpr size_t TILE = size_t(65) * ROWP * sizeof(half_t);
+    auto xh_of = [&](int buf) { return reinterpret_cast<half_t*>(smem + size_t(buf) * 2 * TILE); };
+    auto x8_of = [&](int buf) { return smem + size_t(buf) * 2 * TILE + TILE; };
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int co_tile0 = (blockIdx.x * NW + wave) * MT;
+    bool active[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) active[m] = (co_tile0 + m) * 16 < a.cout_pad;
+    const float* xb = reinterpret_cast<const float*>(a.x) + size_t(b) * kSquares * a.cin;
+    const int nslab_ci = a.cin >> 5;
+    const int nslab = 9 * nslab_ci;
+    const half8 *wph[MT], *wp8[MT];                          // f16 image / 8-bit image: fragment (cout tile, slab) = 64 lanes x 16 B
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        wph[m] = reinterpret_cast<const half8*>(a.wpk) + size_t(active[m] ? co_tile0 + m : 0) * nslab * 64 + lane;
+        wp8[m] = reinterpret_cast<const half8*>(a.wpk_lo) + size_t(active[m] ? co_tile0 + m : 0) * nslab * 64 + lane;
+    }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 2 * ROWP; i += NTHR) {             // row 64 of both buffers: what out-of-board taps read (halves of zeros = bytes of zeros)
+        const int buf = i / ROWP, c = i - buf * ROWP;
+        xh_of(buf)[64 * ROWP + c] = half_t(0.f);
+        reinterpret_cast<half_t*>(x8_of(buf))[64 * ROWP + c] = half_t(0.f);
+    }
+    // staging: thread i of 512 (256) owns vectors i, i + NTHR, ... of the pass's 64 squares x 16 vectors of 8 channels
+    constexpr int NV = kSquares * (KC / 8) / NTHR;
+    float pre[NV][8];
+    auto request = [&](int kc0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * NTHR, r = i / (KC / 8), v = i - r * (KC / 8);
+            load8<float>(xb + size_t(r) * a.cin + kc0 + v * 8, pre[j]);
+        }
+    };
+    auto split_store = [&](int buf) {
+        half_t* xh = xh_of(buf);
+        char* x8 = x8_of(buf);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * NTHR, r = i / (KC / 8), v = i - r * (KC / 8);
+            half8 h, l;
+            split8(pre[j], h, l);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x4 hw = __builtin_bit_cast(u32x4, h), lw = __builtin_bit_cast(u32x4, l);
+            *reinterpret_cast<half8*>(xh + r * ROWP + v * 8) = h;
+            *reinterpret_cast<u32x2*>(x8 + r * R8 + v * 8) = u32x2{x3_high_bytes(hw[0], hw[1]), x3_high_bytes(hw[2], hw[3])};
+            *reinterpret_cast<u32x2*>(x8 + r * R8 + R8LO + v * 8) = u32x2{x3_high_bytes(lw[0], lw[1]), x3_high_bytes(lw[2], lw[3])};
+        }
+    };
+    request(0);
+    split_store(0);
+    const int npass = a.cin / KC;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int kc0 = pass * KC;
+        half8 wh[D][MT];
+        i32x8_x3 w8[2][MT];
+        auto wload = [&](int st) {                           // step st = tap st / NS, k-slab st % NS of this pass
+            const size_t wo = size_t((st / NS) * nslab_ci + (kc0 >> 5) + st % NS) * 64;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) wh[st % D][m] = wph[m][wo];
+        };
+        auto wload8 = [&](int q) {                           // 64-k step q = tap q / 2, slabs 2 (q % 2), 2 (q % 2) + 1 of this pass: a lane's 32 bytes
+            const size_t wo = size_t((q / (NS / 2)) * nslab_ci + (kc0 >> 5) + 2 * (q % (NS / 2))) * 64;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) w8[q & 1][m] = x3_cat(wp8[m][wo], wp8[m][wo + 64]);
+        };
+        if (active[0]) {
+#pragma unroll
+            for (int st = 0; st < D; ++st) wload(st);
+            wload8(0);
+            wload8(1);
+        }
+        __syncthreads();                                     // the pass's tiles are staged (and the other buffer is free: everybody is through the pass before)
+        if (pass + 1 < npass) request(kc0 + KC);
+        if (active[0]) {
+            const half_t* xh = xh_of(pass & 1);
+            const char* x8 = x8_of(pass & 1);
+            half8 bh[2][4];
+            i32x8_x3 b8[4];
+            auto row_of = [&](int tap, int t) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const int sq = t * 16 + l15;
+                const int ny = (sq >> 3) + dy, nx = (sq & 7) + dx;
+                return (unsigned(ny) < 8u) && (unsigned(nx) < 8u) ? ny * 8 + nx : 64;
+            };
+            auto read_frag = [&](int st) {
+                const int tap = st / NS, sl = st % NS;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bh[st & 1][t] = *reinterpret_cast<const half8*>(xh + row_of(tap, t) * ROWP + lg * 8 + sl * 32);
+            };
+            auto read_8 = [&](int q) {                       // lane group lg: 0, 1 = hi8 of k [0, 32), [32, 64) of the step; 2, 3 = lo8 of the same
+                const int tap = q / (NS / 2), J = q % (NS / 2);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const char* pp = x8 + row_of(tap, t) * R8 + (lg >> 1) * R8LO + J * 64 + (lg & 1) * 32;
+                    b8[t] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 16));
+                }
+            };
+            read_frag(0);
+            read_8(0);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                if (st + 1 < NSTEP) read_frag(st + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st % D][m], bh[st & 1][t], acc[m][t], 0, 0, 0);
+                if (st & 1) {
+                    const int q = st >> 1;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) x3_mfma8(w8[q & 1][m], b8[t], acc[m][t], true);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q + 1 < NSTEP / 2) read_8(q + 1);
+                    if (q + 2 < NSTEP / 2) wload8(q + 2);
+                }
+                if (st + D < NSTEP) wload(st + D);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (pass + 1 < npass) split_store((pass + 1) & 1);
+    }
+    conv_x3_finish<MT, NW>(a, acc, active, smem, b, co_tile0, a.acc_scale);
+}
+
+static void launch_conv3x3_p8(const ConvArgs& a, hipStream_t s) {
+    if (a.ks != 3 || a.cin % X3_KC != 0 || a.planes || a.out_rows_f32) throw std::invalid_argument("conv3x3_p8_kernel: a dense 3x3 conv with cin a multiple of 128");
+    const size_t shmem = size_t(4) * 65 * X3_ROWP * sizeof(half_t);      // 70 KB: two (f16 tile + byte tile) buffers
+    const int tiles = a.cout_pad / 16;
+    if (tiles >= 12 || (a.softmax_out && tiles > 8)) hipLaunchKernelGGL((conv3x3_p8_kernel<2, 8>), dim3((tiles + 15) / 16, a.batch), dim3(512), shmem, s, a);
+    else hipLaunchKernelGGL((conv3x3_p8_kernel<1, 8>), dim3((tiles + 7) / 8, a.batch), dim3(512), shmem, s, a);
+}
 template <int KS, int NS> static void launch_conv_gemm_x3_ks(const ConvArgs& a, hipStream_t s) {
     const size_t shmem = size_t(2) * 65 * X3_ROWP * sizeof(half_t);      // 35 KB
     const int tiles = a.cout_pad / 16;
@@ -412,7 +573,8 @@ template <int KS> static void launch_conv_gemm_x3_cin(const ConvArgs& a, hipStre
     else launch_conv_gemm_x3_ks<KS, 0>(a, s);
 }
 void launch_conv_gemm_x3(const ConvArgs& a, hipStream_t s) {
-    if (a.ks == 1) launch_conv_gemm_x3_cin<1>(a, s);
+    if (a.p8) launch_conv3x3_p8(a, s);
+    else if (a.ks == 1) launch_conv_gemm_x3_cin<1>(a, s);
     else launch_conv_gemm_x3_cin<3>(a, s);
 }
 
@@ -1726,6 +1888,9 @@ void init_x3_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    const int conv_p8_lds = int(size_t(4) * 65 * X3_ROWP * sizeof(half_t));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p8_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_p8_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p8_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_p8_lds);
 }
 int block_x3_chunk_channels() { return X3Block::CK; }
 

@@ -279,7 +279,8 @@ def _x3_layer(sd, x, conv, bn, padding=0):
 # t8 = the HIGH BYTE of the f16 value (e5m2 has f16's exponent field: truncation to two mantissa bits, one byte permute in the kernel),
 # r8 = e5m2 round to nearest even (host side), c = 1 / (1 - ln 2 / 8): the mean loss of the truncation taken back on the weight images
 # (scripts/studies/p8_format_study.py).  All three products carry 2^p; exact accumulation here (f32 in the kernel), the sum times 2^-p in
-# front of the BN bias.  Everything outside the tower is forward_x3.
+# front of the BN bias.  The same contraction runs the policy head's dense 3x3 convs whose input channels are a multiple of 128 (conv 1 of every
+# head, the policy-map conv of the select_policy_from_plane heads).  Everything else is forward_x3.
 P8_TRUNC_COMPENSATION = 1.0 / (1.0 - 0.125 * 0.6931471805599453)
 
 
@@ -292,7 +293,7 @@ def _e5m2_rne(x):
     return x.float().to(torch.float8_e5m2).double()
 
 
-def _p8_conv(x, w):
+def _p8_conv(x, w, padding=0):
     m = w.abs().max()
     e = torch.floor(torch.log2(m)) if float(m) > 0 else torch.tensor(0.0, dtype=torch.float64)
     p = 11.0 - float(e)
@@ -301,10 +302,18 @@ def _p8_conv(x, w):
     xh16 = x.float().to(torch.float16)
     xh = xh16.double()
     xl16 = (x.double() - xh).float().to(torch.float16)      # the difference is exact in f32
-    main = F.conv2d(xh, wh)
-    c1 = F.conv2d(_e5m2_high_byte(xh16), _e5m2_rne((W - wh) * P8_TRUNC_COMPENSATION))
-    c2 = F.conv2d(_e5m2_high_byte(xl16), _e5m2_rne(wh * P8_TRUNC_COMPENSATION))
+    main = F.conv2d(xh, wh, padding=padding)
+    c1 = F.conv2d(_e5m2_high_byte(xh16), _e5m2_rne((W - wh) * P8_TRUNC_COMPENSATION), padding=padding)
+    c2 = F.conv2d(_e5m2_high_byte(xl16), _e5m2_rne(wh * P8_TRUNC_COMPENSATION), padding=padding)
     return ((main + c1 + c2) * (2.0 ** -p)).float()
+
+
+def _p8_layer(sd, x, conv, bn, padding=0):
+    """_x3_layer with the contraction of Precision float16p8 (the policy head's dense 3x3 convs: x3.hip conv3x3_p8_kernel)"""
+    if bn:
+        w, b = _fold(sd, conv, bn)
+        return _p8_conv(x, w, padding) + b.float().view(1, -1, 1, 1)
+    return _p8_conv(x, sd[conv + ".weight"].double(), padding)
 
 
 @torch.no_grad()
@@ -359,9 +368,10 @@ def forward_x3(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, p8
         else:
             h = h + _x3_layer(sd, t, p + ".body.6", p + ".body.7")
     B = x.shape[0]
-    ph = F.relu(_x3_layer(sd, h, "policy_head.body.0", "policy_head.body.1", 1))
+    head_layer = _p8_layer if p8 and h.shape[1] % 128 == 0 else _x3_layer
+    ph = F.relu(head_layer(sd, h, "policy_head.body.0", "policy_head.body.1", 1))
     if cfg.select_policy_from_plane:
-        pol = _x3_layer(sd, ph, "policy_head.body.3", "", 1).reshape(B, -1)
+        pol = head_layer(sd, ph, "policy_head.body.3", "", 1).reshape(B, -1)
     else:
         pol = F.relu(_x3_layer(sd, ph, "policy_head.body.3", "policy_head.body2.0", 1)).reshape(B, -1)
         pol = _x3_conv(pol[:, :, None, None], sd["policy_head.body3.0.weight"].double()[:, :, None, None]).reshape(B, -1) \

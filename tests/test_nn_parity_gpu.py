@@ -457,8 +457,13 @@ def test_float16p8_equals_its_emulation(tmp_path, hip_lib, name):
     kernel_vs_fp32 = float(np.abs(logits - o_logits.numpy()).max())
     assert 5e-6 < mode < 3e-4, mode                                    # the mode is not float16x3 (1e-6) and not float16 (1e-3)
     # The 8-bit images are discontinuous functions of the activations (truncation to two mantissa bits): a difference of one f32 ulp between the
-    # kernel's and the emulation's accumulation order flips a byte here and there, and each flip is worth 2^-13 of a product.  The emulation
-    # moves by 4e-5 ... 6e-5 on these nets when its weights are perturbed by 1e-7 (profiles/NOTES.md, round 4); the kernel may sit that far away.
-    assert kernel_vs_emulation < max(2e-5, 0.75 * mode), (kernel_vs_emulation, mode)
+    # kernel's and the emulation's accumulation order flips a byte here and there, each flip is worth 2^-13 of a product, and the last flips
+    # sit in the policy-map conv itself.  How far such differences carry is measured on the emulation: its weights perturbed by 1e-7 (two draws).
+    sens = 0.0
+    for seed in (7, 8):
+        g = torch.Generator().manual_seed(seed)
+        sd2 = {k: (v * (1 + 1e-7 * torch.randn(v.shape, generator=g)) if v.dtype.is_floating_point and v.dim() > 0 else v) for k, v in sd.items()}
+        sens = max(sens, float((ro.forward_p8(cfg, sd2, x)[1] - e_logits).abs().max()))
+    assert kernel_vs_emulation < max(2e-5, 2.5 * sens), (kernel_vs_emulation, sens, mode)
     assert kernel_vs_fp32 < 3e-4
     assert np.abs(value - e_value.numpy().reshape(-1)).max() < 2.5e-5

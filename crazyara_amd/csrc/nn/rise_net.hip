@@ -193,6 +193,20 @@ std::vector<float> pack_x3_depthwise_records(const Folded& bn1, const Folded& dw
     return rec;
 }
 
+// the same for a 5x5 depthwise (x3.hip: X3Depthwise5): per tile 32 rows of 16 floats (2 KiB) -- rows 5 g + i the folded taps of column dx = g - 2
+// (dy = i - 2), row 25 the BN1 bias, row 26 the BN2 bias, rows 27-31 zeros
+std::vector<float> pack_x3_depthwise_records5(const Folded& bn1, const Folded& dw, int cop, int cop_pad) {
+    std::vector<float> rec(size_t(cop_pad) * 32, 0.f);
+    for (int c = 0; c < cop; ++c) {
+        float* tile = rec.data() + size_t(c / 16) * 512 + (c % 16);
+        for (int dy = 0; dy < 5; ++dy)
+            for (int dx = 0; dx < 5; ++dx) tile[(dx * 5 + dy) * 16] = float(dw.w[size_t(c) * 25 + dy * 5 + dx]);
+        tile[25 * 16] = float(bn1.b[c]);
+        tile[26 * 16] = float(dw.b[c]);
+    }
+    return rec;
+}
+
 enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower, Forward, TowerX3 };
 
 struct Op {
@@ -585,6 +599,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     };
     // Precision float16x3: runs of consecutive 3x3 blocks in one launch (x3.hip: tower_x3_kernel)
     std::vector<X3TowerBlock> x3_blocks;
+    int x3_run_ks = 3;                     // Precision float16p8: a run is all 3x3 or all 5x5 blocks (tower_p8_kernel<KS>)
     auto flush_x3_tower = [&]() {
         if (x3_blocks.empty()) return;
         Op op;
@@ -595,6 +610,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         op.tx.nblocks = int(x3_blocks.size());
         op.tx.batch = B;
         op.tx.p8 = p8_ ? 1 : 0;
+        op.tx.ks = x3_run_ks;
         im.ops.push_back(op);
         x3_blocks.clear();
         prod_op = -1;                      // this launch does not emit channel sums: a gate behind it is an SE launch of its own
@@ -741,9 +757,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         if (!in_tower) flush_tower();
         const bool se_in_kernel = in_tower && !tower_blocks.empty();
         TowerBlockDesc td{};
-        const bool in_x3_tower = x3_ && tower_ && fused_ && C == 256 && k == 3;
-        if (!in_x3_tower) flush_x3_tower();
-        const bool x3_se_in_kernel = in_x3_tower && !x3_blocks.empty();       // the first block of a run takes its gate from an SE launch
+        // Precision float16p8 also runs the 5x5 blocks (RISEv3.3) in tower launches of their own, and computes a run's first gate in the launch
+        const bool in_x3_tower = x3_ && tower_ && fused_ && C == 256 && (k == 3 || (p8_ && k == 5));
+        if (!in_x3_tower || (!x3_blocks.empty() && x3_run_ks != k)) flush_x3_tower();
+        if (in_x3_tower && x3_blocks.empty()) x3_run_ks = k;
+        const bool x3_se_in_kernel = in_x3_tower && (!x3_blocks.empty() || p8_);  // float16x3: the first block of a run takes its gate from an SE launch
         X3TowerBlock xb{};
         if (se_types[i] == "ca_se" || se_types[i] == "se") {           // _ChannelAttentionModule, builder_util.py:83-114
             const TensorView &w1 = nf.get(p + ".se.fc.0.weight"), &w2 = nf.get(p + ".se.fc.2.weight");
@@ -932,7 +950,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             xb.w1pk_lo = im.upload(s1.lo);
             xb.w3pk = im.upload(s3.hi);
             xb.w3pk_lo = im.upload(s3.lo);
-            xb.dwpk = im.upload(pack_x3_depthwise_records(f1, f2, cop, cop_pad));
+            xb.dwpk = im.upload(k == 5 ? pack_x3_depthwise_records5(f1, f2, cop, cop_pad) : pack_x3_depthwise_records(f1, f2, cop, cop_pad));
             xb.b3 = im.upload_d2f(f3.b, C);
             xb.w1_inv = float(w1_inv);                                     // float16p8: the accumulators run in the weights' scales
             xb.w3_inv = float(w3_inv);

@@ -598,7 +598,7 @@ struct X3Block {
     static constexpr int T2BUF = NE == 1 ? 2 : 1;
     static constexpr size_t lds_bytes = (size_t(2) * 64 * XROW + size_t(2) * T2BUF * 64 * TROW) * sizeof(half_t) + dws_bytes;   // NE = 1: 151,552 B; NE = 2: 155,648 B
 };
-static_assert(X3Block::lds_bytes <= 160 * 1024, "LDS budget");
+static_assert(X3Block::lds_bytes + 8192 <= 160 * 1024, "LDS budget (tower_p8_kernel<5> takes 8 KiB more for its records)");
 
 struct X3Tiles {
     half_t *xh, *xl;        // [64][XROW] block input = residual stream, hi / lo
@@ -713,6 +713,61 @@ __device__ __forceinline__ void x3_depthwise(const f32x4 (&acc)[4], const float*
 #pragma unroll
         for (int r = 0; r < 4; ++r) outv[t][r] = dw.outv[t][r];
 }
+// D of one 16-channel tile with a 5x5 depthwise (RISEv3.3's wide blocks; Precision float16p8's tower_p8_kernel<5>): X3Depthwise's scheme
+// on ranks - 2 ... + 2 and files - 2 ... + 2, one channel at a time (25 weights in registers).  The rank above / below a lane's square is the
+// same lane of the neighbouring tile; two rows on either side of the rank 3 / 4 seam come from the other half of the row (row_ror:8).
+// Horizontal neighbours are row_shr / row_shl copies by 1 and 2; a lane whose file lacks a neighbour reads that column's weights from the
+// record's zero rows (X3EdgeOffsets5).
+//   rec: this tile's records in LDS, [32 rows: taps column dx = -2 (dy = -2 ... 2), dx = -1, 0, +1, +2, BN1 bias, BN2 bias, 5 rows of zeros][16 channels]
+struct X3EdgeOffsets5 { int o[5]; };                             // in floats, per tap column: to the zero rows 27 ... 31, or 0
+__device__ __forceinline__ X3EdgeOffsets5 x3_edge_offsets5(int l15) {
+    const int f = l15 & 7;
+    X3EdgeOffsets5 e;
+    e.o[0] = f < 2 ? 27 * 16 : 0;
+    e.o[1] = f < 1 ? 22 * 16 : 0;
+    e.o[2] = 0;
+    e.o[3] = f > 6 ? 12 * 16 : 0;
+    e.o[4] = f > 5 ? 7 * 16 : 0;
+    return e;
+}
+struct X3Depthwise5 {
+    float w[27];                                                 // the current channel's records (rows 0 ... 26)
+    float S[8];                                                  // rank - 2 ... rank + 5 of this lane's half: S[2 + t] = tile t
+    float outv[4][4];                                            // [tile][channel r]
+
+    template <int CH> __device__ __forceinline__ void load(const float* rec, int lg, const X3EdgeOffsets5& e) {
+#pragma unroll
+        for (int q = 0; q < 27; ++q) w[q] = rec[(q < 25 ? e.o[q / 5] : 0) + q * 16 + lg * 4 + CH];
+    }
+    template <int CH> __device__ __forceinline__ void gather(const f32x4 (&acc)[4], bool upper, float acc_scale) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) S[2 + t] = fmaxf(fmaf(acc[t][CH], acc_scale, w[25]), 0.f);
+        const float u3 = dpp_mov<DPP_ROW_ROR8>(S[5]), u2 = dpp_mov<DPP_ROW_ROR8>(S[4]);
+        const float d0 = dpp_mov<DPP_ROW_ROR8>(S[2]), d1 = dpp_mov<DPP_ROW_ROR8>(S[3]);
+        S[1] = upper ? u3 : 0.f;                                  // above rank 4 lies rank 3 (tile 3, other half), above that rank 2; above rank 0 the edge
+        S[0] = upper ? u2 : 0.f;
+        S[6] = upper ? 0.f : d0;                                  // below rank 3 lie ranks 4, 5 (tiles 0, 1, other half); below rank 7 the edge
+        S[7] = upper ? 0.f : d1;
+    }
+    template <int CH> __device__ __forceinline__ void taps() {
+        float a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = w[26];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v[5] = {dpp_mov<DPP_ROW_SHR2>(S[j]), dpp_mov<DPP_ROW_SHR1>(S[j]), S[j], dpp_mov<DPP_ROW_SHL1>(S[j]), dpp_mov<DPP_ROW_SHL2>(S[j])};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int dy = j - t;
+                if (dy < 0 || dy > 4) continue;
+#pragma unroll
+                for (int g = 0; g < 5; ++g) a[t] = fmaf(w[g * 5 + dy], v[g], a[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) outv[t][CH] = fmaxf(a[t], 0.f);
+    }
+};
 // float board tile [64][256] (optionally x := x * gate[c], _ChannelAttentionModule.forward, builder_util.py:114) -> split tiles
 __device__ __forceinline__ void x3_stage_tile(const X3Tiles& T, const float* xb, const float* g, int tid) {
     constexpr int C = X3Block::C, XROW = X3Block::XROW;
@@ -1551,7 +1606,10 @@ __device__ __forceinline__ void x3_se_gate_from_mean(const X3TowerBlock& d, floa
 }
 }  // namespace
 
+template <int KS>
 __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
+    static_assert(KS == 3 || KS == 5, "depthwise 3x3 or 5x5");
+    constexpr int REC = KS == 3 ? 256 : 512;                            // floats of depthwise records per 16-channel tile (X3Depthwise / X3Depthwise5)
     using G = X3Block;
     static_assert(G::NE == 1 && G::T2BUF == 2 && G::CK == 128, "the role kernels use the NE = 1 tile geometry");
     constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, X8ROW = XROW * 2, T8ROW = 272, T8LO = 144, NJ = 4;
@@ -1572,10 +1630,11 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
         // =================================================== EXPAND waves ===================================================
         const bool hi = l15 >= 8;
         const X3EdgeOffsets edge = x3_edge_offsets(l15);
+        const X3EdgeOffsets5 edge5 = x3_edge_offsets5(l15);
         __syncthreads();                                                // the PROJECT waves have written block 0's operand tiles
         for (int blk = 0; blk < a.nblocks; ++blk) {
             const X3TowerBlock& d = a.blocks[blk];
-            if (blk > 0 && d.se_kind != 0) {
+            if (d.se_kind != 0) {                                       // (also the run's first block: its gate is computed in this launch)
                 x3_se_gate_from_mean(d, se_scratch, tid);               // (the squeeze and the rescaling are the PROJECT waves')
                 __syncthreads();                                        // the gated operand tiles are written
             }
@@ -1603,9 +1662,10 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
             load_eh(0, 0);
             load_eh(0, 1);
             load_e8(0, 0);
-            float* const my_dws = T.dws + (w * 2) * 256;
+            float* const my_dws = T.dws + (w * 2) * REC;
             f32x4 accE[2][4], accD[2][4];
             X3Depthwise dw;
+            X3Depthwise5 dw5;
             // Interval i: E(i) (HASE) with D(i - 1) (HASD) in sixteen pieces, two per k-slab, as in tower_x3_roles_kernel.  A k-slab issues its 8
             // f16 MFMAs; an ODD slab then the 8 e5m2 MFMAs of its 64-k step.
             auto interval = [&](auto hase_c, auto hasd_c, int i) {
@@ -1619,12 +1679,14 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                     const char* pp = x8 + ((q & 3) * 16 + l15) * X8ROW + (lg >> 1) * 272 + (q >> 2) * 64 + (lg & 1) * 32;
                     ring_8[q % 3] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 16));
                 };
-                f32x4 dw_raw[2];
+                f32x4 dw_raw[2][REC / 256];
                 const int inext = i + 1 < n ? i + 1 : i;                // (behind the last chunk: a valid address, no branch in the stretch)
                 if constexpr (HASE) {
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
-                        dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(i * CK + (w * 2 + ne) * 16) * 64u, 0));
+#pragma unroll
+                        for (int h2 = 0; h2 < REC / 256; ++h2)
+                            dw_raw[ne][h2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(i * CK + (w * 2 + ne) * 16) * uint32_t(REC / 4) + uint32_t(h2) * 1024u, 0));
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
 #pragma unroll
@@ -1632,15 +1694,21 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                     read_h(0); read_h(1); read_h(2);
                     read_8(0); read_8(1);
                 }
-                if constexpr (HASD) dw.template load<0>(my_dws, lg, edge);
+                if constexpr (HASD && KS == 3) dw.template load<0>(my_dws, lg, edge);
                 half_t* const t2h = T.t2h + ((i - 1) & 1) * 64 * TROW;
                 char* const t2b = t28 + ((i - 1) & 1) * 64 * T8ROW;
 #pragma unroll
                 for (int sl = 0; sl < C / 32; ++sl) {
                     const int dt = sl / 4, ph = sl % 4;
-                    if constexpr (HASD) {
+                    if constexpr (HASD && KS == 3) {
                         if (ph == 2) dw.template load<1>(my_dws + dt * 256, lg, edge);
                         if (sl == 4) dw.template load<0>(my_dws + 256, lg, edge);
+                    }
+                    if constexpr (HASD && KS == 5) {                    // one channel of the tile per k-slab: its 27 records, then (behind the slab's MFMAs) gather and taps
+                        if (ph == 0) dw5.template load<0>(my_dws + dt * REC, lg, edge5);
+                        if (ph == 1) dw5.template load<1>(my_dws + dt * REC, lg, edge5);
+                        if (ph == 2) dw5.template load<2>(my_dws + dt * REC, lg, edge5);
+                        if (ph == 3) dw5.template load<3>(my_dws + dt * REC, lg, edge5);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (HASE) {
@@ -1661,17 +1729,24 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                         if (sl & 1) { if ((sl >> 1) + 1 < C / 64) load_e8(i, (sl >> 1) + 1); else load_e8(inext, 0); }
                     }
                     if constexpr (HASD) {
-                        if (ph == 0) dw.template gather<0, true>(accD[dt], hi, 0, 2, e_inv);
-                        if (ph == 1) { dw.template taps<0>(0, 4); dw.pin_taps(0, 4, 0); }
-                        if (ph == 2) dw.template gather<1, true>(accD[dt], hi, 0, 2, e_inv);
+                        if constexpr (KS == 3) {
+                            if (ph == 0) dw.template gather<0, true>(accD[dt], hi, 0, 2, e_inv);
+                            if (ph == 1) { dw.template taps<0>(0, 4); dw.pin_taps(0, 4, 0); }
+                            if (ph == 2) dw.template gather<1, true>(accD[dt], hi, 0, 2, e_inv);
+                            if (ph == 3) dw.template taps<1>(0, 4);
+                        } else {
+                            if (ph == 0) { dw5.template gather<0>(accD[dt], hi, e_inv); dw5.template taps<0>(); }
+                            if (ph == 1) { dw5.template gather<1>(accD[dt], hi, e_inv); dw5.template taps<1>(); }
+                            if (ph == 2) { dw5.template gather<2>(accD[dt], hi, e_inv); dw5.template taps<2>(); }
+                            if (ph == 3) { dw5.template gather<3>(accD[dt], hi, e_inv); dw5.template taps<3>(); }
+                        }
                         if (ph == 3) {
-                            dw.template taps<1>(0, 4);
                             const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1: the f16 hi and the two byte rows
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 half4 h;
                                 uint32_t h8, l8;
-                                split4_b8(dw.outv[t], h, h8, l8);
+                                split4_b8(KS == 3 ? dw.outv[t] : dw5.outv[t], h, h8, l8);
                                 if constexpr ((X3_ABL & 64) != 0) {
                                     asm volatile("" ::"v"(h), "v"(h8), "v"(l8));
                                     continue;
@@ -1684,16 +1759,18 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                     }
                     if constexpr (HASE && HASD) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {                   // behind every MFMA up to four VALU instructions
+                        for (int r = 0; r < 16; ++r) {                   // behind every MFMA up to four (5x5: twelve) VALU instructions
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, KS == 3 ? 4 : 12, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (HASE) {                                    // the depthwise is through with chunk i - 1: its records and accumulators make room
 #pragma unroll
-                    for (int ne = 0; ne < 2; ++ne) *reinterpret_cast<f32x4*>(my_dws + ne * 256 + lane * 4) = dw_raw[ne];
+                    for (int ne = 0; ne < 2; ++ne)
+#pragma unroll
+                        for (int h2 = 0; h2 < REC / 256; ++h2) *reinterpret_cast<f32x4*>(my_dws + ne * REC + h2 * 256 + lane * 4) = dw_raw[ne][h2];
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
 #pragma unroll
@@ -1744,11 +1821,11 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
             }
         }
     };
-    write_tiles();
+    if (a.blocks[0].se_kind == 0) write_tiles();                       // (a gated first block writes them behind its gate)
     __syncthreads();
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const X3TowerBlock& d = a.blocks[blk];
-        if (blk > 0 && d.se_kind != 0) {
+        if (d.se_kind != 0) {
             // squeeze (AdaptiveAvgPool2d) from the registers: sum over the four square tiles, then over the 16 lanes of the row
             constexpr int GRP = 36;
 #pragma unroll
@@ -1887,7 +1964,8 @@ void init_x3_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes + 8192));
     const int conv_p8_lds = int(size_t(4) * 65 * X3_ROWP * sizeof(half_t));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p8_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_p8_lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p8_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_p8_lds);
@@ -1904,7 +1982,8 @@ void launch_tower_x3(const X3TowerArgs& a, hipStream_t s) {
     const bool symmetric = e != nullptr && e[0] == 's';
     if (a.p8) {
         if (symmetric) throw std::invalid_argument("Precision float16p8 runs the two-role tower only");
-        hipLaunchKernelGGL(tower_p8_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+        if (a.ks == 5) hipLaunchKernelGGL(tower_p8_kernel<5>, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes + 8192, s, a);    // (2 KiB of records per tile)
+        else hipLaunchKernelGGL(tower_p8_kernel<3>, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
     } else if (symmetric) hipLaunchKernelGGL(tower_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
     else hipLaunchKernelGGL(tower_x3_roles_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
 }

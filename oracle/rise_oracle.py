@@ -272,7 +272,7 @@ def _x3_layer(sd, x, conv, bn, padding=0):
     return _x3_conv(x, sd[conv + ".weight"].double(), padding)
 
 
-# Precision float16p8 = float16x3 whose one-launch tower (3x3 bottleneck blocks at 256 channels) runs BOTH of its 1x1 contractions as
+# Precision float16p8 = float16x3 whose tower launches (3x3 and 5x5 bottleneck blocks at 256 channels) run BOTH of their 1x1 contractions as
 #   f16 main term   hi(a) * hi(W')                          W' = w * 2^p, p = 11 - floor(log2(max |w|)) over the layer (BN folded, double)
 # + e5m2 cross term t8(hi(a)) * r8((W' - hi(W')) * c)       hi(.) = rne_f16; a = the f32 operand (residual stream / depthwise output)
 # + e5m2 cross term t8(lo(a)) * r8(hi(W') * c)              lo(a) = rne_f16(a - hi(a)) (the difference is exact in f32)
@@ -354,7 +354,7 @@ def forward_x3(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, p8
             continue
         if se is not None:
             h = gate(h, True)
-        in_p8_tower = p8 and k == 3 and h.shape[1] == 256      # a block of the one-launch tower
+        in_p8_tower = p8 and k in (3, 5) and h.shape[1] == 256      # a block of the tower launches (x3.hip: tower_p8_kernel<3 | 5>)
         if in_p8_tower:
             w1, b1 = _fold(sd, p + ".body.0", p + ".body.1")
             t = F.relu(_p8_conv(h, w1) + b1.float().view(1, -1, 1, 1))

@@ -1651,11 +1651,12 @@ void RiseNet::forward_async() {
 // The forward between other work of the same stream (descriptor expansion before, gather / copies after).  A graph launch runs its
 // nodes on the graph's own queue and is tied to the launching stream by cross-queue dependencies, which this runtime resolves from
 // the host: measured, a lane's next kernel did not start until the host called into the runtime again (0.09-0.15 ms per batch lost
-// whenever the host was busy collecting).  With the whole forward in one to three kernels there is nothing left for a graph to save,
-// so these paths put the kernels straight into the stream: one queue, in-order, no host in the loop.
+// whenever the host was busy collecting).  With the whole forward in one to five kernels there is nothing left for a graph to save,
+// so these paths put the kernels straight into the stream: one queue, in-order, no host in the loop (float16p8's five launches: config 2
+// searched at 373k nodes/s against 370k through the graph on an idle host, profiles/r04/ac_*).
 void RiseNet::launch_forward_in_stream() {
     Turn turn(*this);
-    if ((launches_ <= 4 && getenv("CRA_LANE_GRAPH") == nullptr) || getenv("CRA_LANE_NO_GRAPH") != nullptr) forward_on(stream_);
+    if ((launches_ <= 5 && getenv("CRA_LANE_GRAPH") == nullptr) || getenv("CRA_LANE_NO_GRAPH") != nullptr) forward_on(stream_);
     else HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
 }
 

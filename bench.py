@@ -521,6 +521,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is the HIP library, there is no CPU fallback")
+    # stdout carries ONE line, the JSON record: whatever the libraries of this process print on file descriptor 1 on the way (gloo's
+    # "[Gloo] Rank ... is connected", RCCL's version banner) goes to stderr instead
+    sys.stdout.flush()
+    record_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.gpus != world:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     dry = bool(args.dry_ranks) and rank > 0                 # a rehearsal rank: every collective, no compute
@@ -955,7 +960,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        record_out.write(json.dumps(out) + "\n")
+        record_out.flush()
 
 
 if __name__ == "__main__":

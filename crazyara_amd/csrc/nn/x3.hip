@@ -21,7 +21,7 @@
 // CRA_X3_ABL: development switches that TIME parts of the tower's chunk loop (scripts/ubench/x3_tower_ablate.hip); every bit computes wrong
 // results on purpose, so they only compile in a development build.  1: no depthwise arithmetic, 2: no expand MFMAs, 4: no project MFMAs,
 // 8: no LDS operand reads (expand and project), 16: no weight loads, 32: no chunk barriers, 64: no t2 stores, 128: the expand GEMM issues
-// the mixed split's instruction mix (per 64 k two f16 MFMAs and one e4m3 16x16x128 on whatever the registers hold), 256 (tower_p8_kernel):
+// the mixed split's instruction mix (per 64 k two f16 MFMAs and one 8-bit 16x16x128 on whatever the registers hold), 256 (tower_p8_kernel):
 // a quarter of the depthwise moves from the EXPAND to the PROJECT waves (on whatever LDS holds)
 #ifndef CRA_X3_ABL
 #define CRA_X3_ABL 0

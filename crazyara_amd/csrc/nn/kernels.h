@@ -49,6 +49,11 @@ struct ConvArgs {
     // cross terms (rise_net.hip: pack_dense_p8), acc_scale = 2^-p
     int p8;
     float acc_scale;
+    // float16p8, the policy head of a policy-map net in one launch (conv3x3_p8_chain_kernel): the conv 3x3 256 -> 256 + BN + ReLU in FRONT of this
+    // conv -- its weight images, bias [256] and 2^-p; x is then that conv's input
+    const void *pre_wpk, *pre_wpk_lo;
+    const float* pre_bias;
+    float pre_acc_scale;
     int dev;              // development (CRA_X3_CONV_DEV): 1 = every wave leaves the kernel behind one last barrier, 2 = waves without a cout
                           // tile request no weight fragments
 };

@@ -1126,8 +1126,22 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
     } else {
     // _PolicyHead (select_policy_from_plane), builder_util.py:206-243
-    add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr, true);
-    if (policy_map) {
+    // Precision float16p8, policy map at 256 channels: both convs of the head in ONE launch (x3.hip: conv3x3_p8_chain_kernel); CRA_P8_NO_HEAD_CHAIN: development A/B
+    const bool head_chain = p8_ && policy_map && C == 256 && round_up(cp, 16) <= 128 && getenv("CRA_P8_NO_HEAD_CHAIN") == nullptr;
+    if (head_chain) {
+        Folded f1 = fold_bn(nf, "policy_head.body.0", "policy_head.body.1");
+        double inv1 = 1.0;
+        SplitPack s1 = pack_dense_p8(f1, C, C, 3, C, C, &inv1);
+        add_conv("policy_head.body.3", "", cur, nullptr, nullptr, C, C, cp, 3, false, d_logits_, true);      // (its x: the tower's output)
+        ConvArgs& c = im.ops.back().conv;
+        c.pre_wpk = im.upload(s1.hi);
+        c.pre_wpk_lo = im.upload(s1.lo);
+        c.pre_bias = im.upload_d2f(f1.b, C);
+        c.pre_acc_scale = float(inv1);
+        macs += double(kSquares) * C * C * 9;
+    } else add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr, true);
+    if (head_chain) {
+    } else if (policy_map) {
         add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_, true);
     } else {
         // flat labels: conv3x3(C->P) + BN + ReLU written channel-major flat (x.view(-1, nb_flatten)), then Linear(P*64 -> n_labels)

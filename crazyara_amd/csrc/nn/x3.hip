@@ -408,14 +408,129 @@ __global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a)
 // square tile instead of six f16 MFMAs (tower_p8_kernel's arithmetic; weights: rise_net.hip pack_dense_p8, the accumulators carry 2^p,
 // a.acc_scale = 2^-p).  The board is staged as the f16 hi tile + a byte tile [hi8, 128 B | lo8, 128 B] per square (the high bytes of the
 // split's f16 pair), double-buffered: the next pass's 32 KB are requested from HBM before this pass's MFMAs and split behind them.
+namespace {
+struct ConvP8 {                                                  // geometry of the staged tiles and of a pass over one of them
+    static constexpr int ROWP = X3_ROWP, KC = X3_KC, R8 = 272, R8LO = 144, NS = KC / 32, NSTEP = 9 * NS, D = 3;
+    static_assert(ROWP * 2 == R8 && KC == 128, "the byte tile has the f16 tile's row pitch");
+    static constexpr size_t TILE = size_t(65) * ROWP * sizeof(half_t);
+    static constexpr size_t lds_bytes = 4 * TILE;               // two (f16 tile + byte tile) buffers: 70 KB
+    static __device__ __forceinline__ half_t* xh_of(char* smem, int buf) { return reinterpret_cast<half_t*>(smem + size_t(buf) * 2 * TILE); }
+    static __device__ __forceinline__ char* x8_of(char* smem, int buf) { return smem + size_t(buf) * 2 * TILE + TILE; }
+};
+template <int MT> struct ConvP8Window {                          // weight fragments in flight: three (tap, k-slab) steps of f16, two 64-k steps of bytes
+    half8 wh[ConvP8::D][MT];
+    i32x8_x3 w8[2][MT];
+};
+template <int MT>
+__device__ __forceinline__ void conv_p8_wload(ConvP8Window<MT>& W, const half8* const (&wph)[MT], int kc0, int nslab_ci, int st) {
+    const size_t wo = size_t((st / ConvP8::NS) * nslab_ci + (kc0 >> 5) + st % ConvP8::NS) * 64;    // step st = tap st / NS, k-slab st % NS of this pass
+#pragma unroll
+    for (int m = 0; m < MT; ++m) W.wh[st % ConvP8::D][m] = wph[m][wo];
+}
+template <int MT>
+__device__ __forceinline__ void conv_p8_wload8(ConvP8Window<MT>& W, const half8* const (&wp8)[MT], int kc0, int nslab_ci, int q) {
+    // 64-k step q = tap q / 2, slabs 2 (q % 2), 2 (q % 2) + 1 of this pass: a lane's 32 bytes
+    const size_t wo = size_t((q / (ConvP8::NS / 2)) * nslab_ci + (kc0 >> 5) + 2 * (q % (ConvP8::NS / 2))) * 64;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) W.w8[q & 1][m] = x3_cat(wp8[m][wo], wp8[m][wo + 64]);
+}
+template <int MT>
+__device__ __forceinline__ void conv_p8_prime(ConvP8Window<MT>& W, const half8* const (&wph)[MT], const half8* const (&wp8)[MT], int kc0, int nslab_ci) {
+#pragma unroll
+    for (int st = 0; st < ConvP8::D; ++st) conv_p8_wload<MT>(W, wph, kc0, nslab_ci, st);
+    conv_p8_wload8<MT>(W, wp8, kc0, nslab_ci, 0);
+    conv_p8_wload8<MT>(W, wp8, kc0, nslab_ci, 1);
+}
+// the 9 taps x 4 k-slabs of one staged pass (input channels kc0 ... kc0 + 127 in the tiles xh / x8), window primed by the caller
+template <int MT>
+__device__ __forceinline__ void conv_p8_pass(ConvP8Window<MT>& W, const half_t* xh, const char* x8, const half8* const (&wph)[MT],
+                                             const half8* const (&wp8)[MT], int kc0, int nslab_ci, int l15, int lg, f32x4 (&acc)[MT][4]) {
+    constexpr int ROWP = ConvP8::ROWP, R8 = ConvP8::R8, R8LO = ConvP8::R8LO, NS = ConvP8::NS, NSTEP = ConvP8::NSTEP, D = ConvP8::D;
+    half8 bh[2][4];
+    i32x8_x3 b8[4];
+    auto row_of = [&](int tap, int t) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int sq = t * 16 + l15;
+        const int ny = (sq >> 3) + dy, nx = (sq & 7) + dx;
+        return (unsigned(ny) < 8u) && (unsigned(nx) < 8u) ? ny * 8 + nx : 64;
+    };
+    auto read_frag = [&](int st) {
+        const int tap = st / NS, sl = st % NS;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bh[st & 1][t] = *reinterpret_cast<const half8*>(xh + row_of(tap, t) * ROWP + lg * 8 + sl * 32);
+    };
+    auto read_8 = [&](int q) {                                  // lane group lg: 0, 1 = hi8 of k [0, 32), [32, 64) of the step; 2, 3 = lo8 of the same
+        const int tap = q / (NS / 2), J = q % (NS / 2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const char* pp = x8 + row_of(tap, t) * R8 + (lg >> 1) * R8LO + J * 64 + (lg & 1) * 32;
+            b8[t] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 16));
+        }
+    };
+    read_frag(0);
+    read_8(0);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) read_frag(st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.wh[st % D][m], bh[st & 1][t], acc[m][t], 0, 0, 0);
+        if (st & 1) {
+            const int q = st >> 1;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) x3_mfma8(W.w8[q & 1][m], b8[t], acc[m][t], true);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < NSTEP / 2) read_8(q + 1);
+            if (q + 2 < NSTEP / 2) conv_p8_wload8<MT>(W, wp8, kc0, nslab_ci, q + 2);
+        }
+        if (st + D < NSTEP) conv_p8_wload<MT>(W, wph, kc0, nslab_ci, st + D);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// stages one board's input channels [kc0, kc0 + 128) as operand tiles: `request` into registers, `split_store` from them (NTHR = 512)
+struct ConvP8Stage {
+    static constexpr int NV = kSquares * (ConvP8::KC / 8) / 512;
+    float pre[NV][8];
+    __device__ __forceinline__ void request(const float* xb, int cin, int kc0, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * 512, r = i / (ConvP8::KC / 8), v = i - r * (ConvP8::KC / 8);
+            load8<float>(xb + size_t(r) * cin + kc0 + v * 8, pre[j]);
+        }
+    }
+    __device__ __forceinline__ void split_store(half_t* xh, char* x8, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * 512, r = i / (ConvP8::KC / 8), v = i - r * (ConvP8::KC / 8);
+            half8 h, l;
+            split8(pre[j], h, l);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x4 hw = __builtin_bit_cast(u32x4, h), lw = __builtin_bit_cast(u32x4, l);
+            *reinterpret_cast<half8*>(xh + r * ConvP8::ROWP + v * 8) = h;
+            *reinterpret_cast<u32x2*>(x8 + r * ConvP8::R8 + v * 8) = u32x2{x3_high_bytes(hw[0], hw[1]), x3_high_bytes(hw[2], hw[3])};
+            *reinterpret_cast<u32x2*>(x8 + r * ConvP8::R8 + ConvP8::R8LO + v * 8) = u32x2{x3_high_bytes(lw[0], lw[1]), x3_high_bytes(lw[2], lw[3])};
+        }
+    }
+};
+__device__ __forceinline__ void conv_p8_zero_rows(char* smem, int tid) {      // row 64 of both buffers: what out-of-board taps read (halves of zeros = bytes of zeros)
+    for (int i = tid; i < 2 * ConvP8::ROWP; i += 512) {
+        const int buf = i / ConvP8::ROWP, c = i - buf * ConvP8::ROWP;
+        ConvP8::xh_of(smem, buf)[64 * ConvP8::ROWP + c] = half_t(0.f);
+        reinterpret_cast<half_t*>(ConvP8::x8_of(smem, buf))[64 * ConvP8::ROWP + c] = half_t(0.f);
+    }
+}
+}  // namespace
+
 template <int MT, int NW>
 __global__ __launch_bounds__(64 * NW) void conv3x3_p8_kernel(const ConvArgs a) {
+    static_assert(NW == 8, "512 threads stage a pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ROWP = X3_ROWP, KC = X3_KC, NTHR = 64 * NW, R8 = 272, R8LO = 144, NS = KC / 32, NSTEP = 9 * NS, D = 3;
-    static_assert(ROWP * 2 == R8 && KC == 128, "the byte tile has the f16 tile's row pitch");
-    constexpr size_t TILE = size_t(65) * ROWP * sizeof(half_t);
-    auto xh_of = [&](int buf) { return reinterpret_cast<half_t*>(smem + size_t(buf) * 2 * TILE); };
-    auto x8_of = [&](int buf) { return smem + size_t(buf) * 2 * TILE + TILE; };
+    constexpr int KC = ConvP8::KC;
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -438,119 +553,114 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_p8_kernel(const ConvArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < 2 * ROWP; i += NTHR) {             // row 64 of both buffers: what out-of-board taps read (halves of zeros = bytes of zeros)
-        const int buf = i / ROWP, c = i - buf * ROWP;
-        xh_of(buf)[64 * ROWP + c] = half_t(0.f);
-        reinterpret_cast<half_t*>(x8_of(buf))[64 * ROWP + c] = half_t(0.f);
-    }
-    // staging: thread i of 512 (256) owns vectors i, i + NTHR, ... of the pass's 64 squares x 16 vectors of 8 channels
-    constexpr int NV = kSquares * (KC / 8) / NTHR;
-    float pre[NV][8];
-    auto request = [&](int kc0) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * NTHR, r = i / (KC / 8), v = i - r * (KC / 8);
-            load8<float>(xb + size_t(r) * a.cin + kc0 + v * 8, pre[j]);
-        }
-    };
-    auto split_store = [&](int buf) {
-        half_t* xh = xh_of(buf);
-        char* x8 = x8_of(buf);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * NTHR, r = i / (KC / 8), v = i - r * (KC / 8);
-            half8 h, l;
-            split8(pre[j], h, l);
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            const u32x4 hw = __builtin_bit_cast(u32x4, h), lw = __builtin_bit_cast(u32x4, l);
-            *reinterpret_cast<half8*>(xh + r * ROWP + v * 8) = h;
-            *reinterpret_cast<u32x2*>(x8 + r * R8 + v * 8) = u32x2{x3_high_bytes(hw[0], hw[1]), x3_high_bytes(hw[2], hw[3])};
-            *reinterpret_cast<u32x2*>(x8 + r * R8 + R8LO + v * 8) = u32x2{x3_high_bytes(lw[0], lw[1]), x3_high_bytes(lw[2], lw[3])};
-        }
-    };
-    request(0);
-    split_store(0);
+    conv_p8_zero_rows(smem, tid);
+    ConvP8Stage stage;
+    stage.request(xb, a.cin, 0, tid);
+    stage.split_store(ConvP8::xh_of(smem, 0), ConvP8::x8_of(smem, 0), tid);
     const int npass = a.cin / KC;
     for (int pass = 0; pass < npass; ++pass) {
         const int kc0 = pass * KC;
-        half8 wh[D][MT];
-        i32x8_x3 w8[2][MT];
-        auto wload = [&](int st) {                           // step st = tap st / NS, k-slab st % NS of this pass
-            const size_t wo = size_t((st / NS) * nslab_ci + (kc0 >> 5) + st % NS) * 64;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) wh[st % D][m] = wph[m][wo];
-        };
-        auto wload8 = [&](int q) {                           // 64-k step q = tap q / 2, slabs 2 (q % 2), 2 (q % 2) + 1 of this pass: a lane's 32 bytes
-            const size_t wo = size_t((q / (NS / 2)) * nslab_ci + (kc0 >> 5) + 2 * (q % (NS / 2))) * 64;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) w8[q & 1][m] = x3_cat(wp8[m][wo], wp8[m][wo + 64]);
-        };
-        if (active[0]) {
-#pragma unroll
-            for (int st = 0; st < D; ++st) wload(st);
-            wload8(0);
-            wload8(1);
-        }
+        ConvP8Window<MT> W;
+        if (active[0]) conv_p8_prime<MT>(W, wph, wp8, kc0, nslab_ci);
         __syncthreads();                                     // the pass's tiles are staged (and the other buffer is free: everybody is through the pass before)
-        if (pass + 1 < npass) request(kc0 + KC);
-        if (active[0]) {
-            const half_t* xh = xh_of(pass & 1);
-            const char* x8 = x8_of(pass & 1);
-            half8 bh[2][4];
-            i32x8_x3 b8[4];
-            auto row_of = [&](int tap, int t) {
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                const int sq = t * 16 + l15;
-                const int ny = (sq >> 3) + dy, nx = (sq & 7) + dx;
-                return (unsigned(ny) < 8u) && (unsigned(nx) < 8u) ? ny * 8 + nx : 64;
-            };
-            auto read_frag = [&](int st) {
-                const int tap = st / NS, sl = st % NS;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) bh[st & 1][t] = *reinterpret_cast<const half8*>(xh + row_of(tap, t) * ROWP + lg * 8 + sl * 32);
-            };
-            auto read_8 = [&](int q) {                       // lane group lg: 0, 1 = hi8 of k [0, 32), [32, 64) of the step; 2, 3 = lo8 of the same
-                const int tap = q / (NS / 2), J = q % (NS / 2);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const char* pp = x8 + row_of(tap, t) * R8 + (lg >> 1) * R8LO + J * 64 + (lg & 1) * 32;
-                    b8[t] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 16));
-                }
-            };
-            read_frag(0);
-            read_8(0);
-#pragma unroll
-            for (int st = 0; st < NSTEP; ++st) {
-                if (st + 1 < NSTEP) read_frag(st + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st % D][m], bh[st & 1][t], acc[m][t], 0, 0, 0);
-                if (st & 1) {
-                    const int q = st >> 1;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) x3_mfma8(w8[q & 1][m], b8[t], acc[m][t], true);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (q + 1 < NSTEP / 2) read_8(q + 1);
-                    if (q + 2 < NSTEP / 2) wload8(q + 2);
-                }
-                if (st + D < NSTEP) wload(st + D);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (pass + 1 < npass) split_store((pass + 1) & 1);
+        if (pass + 1 < npass) stage.request(xb, a.cin, kc0 + KC, tid);
+        if (active[0]) conv_p8_pass<MT>(W, ConvP8::xh_of(smem, pass & 1), ConvP8::x8_of(smem, pass & 1), wph, wp8, kc0, nslab_ci, l15, lg, acc);
+        if (pass + 1 < npass) stage.split_store(ConvP8::xh_of(smem, (pass + 1) & 1), ConvP8::x8_of(smem, (pass + 1) & 1), tid);
     }
     conv_x3_finish<MT, NW>(a, acc, active, smem, b, co_tile0, a.acc_scale);
 }
 
+// The policy head of a policy-map net in ONE launch (Precision float16p8): conv 3x3 256 -> 256 + BN + ReLU (a.pre_*: conv3x3_p8_kernel<2, 8>'s
+// work), its output written straight into the two staging buffers as operand tiles (channels 0-127 / 128-255: exactly the two passes of the
+// next conv), then conv 3x3 256 -> P on them (conv3x3_p8_kernel<1, 8>'s work: no staging, no barrier between its passes) and its epilogue
+// (the board's softmax).  Saves a launch, 128 KB of HBM traffic per board and the second conv's exposed staging.
+__global__ __launch_bounds__(512) void conv3x3_p8_chain_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KC = ConvP8::KC, NW = 8, C = 256;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const float* xb = reinterpret_cast<const float*>(a.x) + size_t(b) * kSquares * C;
+    constexpr int nslab_ci = C >> 5, nslab = 9 * nslab_ci;
+    {   // ---- conv 1: this wave's two cout tiles of the 16
+        const half8 *wph[2], *wp8[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            wph[m] = reinterpret_cast<const half8*>(a.pre_wpk) + size_t(wave * 2 + m) * nslab * 64 + lane;
+            wp8[m] = reinterpret_cast<const half8*>(a.pre_wpk_lo) + size_t(wave * 2 + m) * nslab * 64 + lane;
+        }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        conv_p8_zero_rows(smem, tid);
+        ConvP8Stage stage;
+        stage.request(xb, C, 0, tid);
+        stage.split_store(ConvP8::xh_of(smem, 0), ConvP8::x8_of(smem, 0), tid);
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const int kc0 = pass * KC;
+            ConvP8Window<2> W;
+            conv_p8_prime<2>(W, wph, wp8, kc0, nslab_ci);
+            __syncthreads();
+            if (pass == 0) stage.request(xb, C, KC, tid);
+            conv_p8_pass<2>(W, ConvP8::xh_of(smem, pass), ConvP8::x8_of(smem, pass), wph, wp8, kc0, nslab_ci, l15, lg, acc);
+            if (pass == 0) stage.split_store(ConvP8::xh_of(smem, 1), ConvP8::x8_of(smem, 1), tid);
+        }
+        __syncthreads();                                         // every wave is through with the input tiles: they take conv 1's output
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int c0 = (wave * 2 + m) * 16 + lg * 4;         // 4 consecutive output channels of this lane
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(a.pre_bias + c0);
+            half_t* xh = ConvP8::xh_of(smem, c0 >> 7);
+            char* x8 = ConvP8::x8_of(smem, c0 >> 7);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int sq = t * 16 + l15;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(acc[m][t][r], a.pre_acc_scale, bs[r]), 0.f);
+                half4 h;
+                uint32_t h8, l8;
+                split4_b8(v, h, h8, l8);
+                *reinterpret_cast<half4*>(xh + sq * ConvP8::ROWP + (c0 & 127)) = h;
+                *reinterpret_cast<uint32_t*>(x8 + sq * ConvP8::R8 + (c0 & 127)) = h8;
+                *reinterpret_cast<uint32_t*>(x8 + sq * ConvP8::R8 + ConvP8::R8LO + (c0 & 127)) = l8;
+            }
+        }
+    }
+    // ---- conv 2: one cout tile per wave
+    bool active[1] = {wave * 16 < a.cout_pad};
+    const half8 *wph[1], *wp8[1];
+    wph[0] = reinterpret_cast<const half8*>(a.wpk) + size_t(active[0] ? wave : 0) * nslab * 64 + lane;
+    wp8[0] = reinterpret_cast<const half8*>(a.wpk_lo) + size_t(active[0] ? wave : 0) * nslab * 64 + lane;
+    f32x4 acc2[1][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc2[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ConvP8Window<1> W;
+    if (active[0]) conv_p8_prime<1>(W, wph, wp8, 0, nslab_ci);
+    __syncthreads();                                             // conv 1's output tiles are written
+    if (active[0]) {
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) conv_p8_prime<1>(W, wph, wp8, KC, nslab_ci);
+            conv_p8_pass<1>(W, ConvP8::xh_of(smem, pass), ConvP8::x8_of(smem, pass), wph, wp8, pass * KC, nslab_ci, l15, lg, acc2);
+        }
+    }
+    conv_x3_finish<1, NW>(a, acc2, active, smem, b, wave, a.acc_scale);
+}
+
 static void launch_conv3x3_p8(const ConvArgs& a, hipStream_t s) {
     if (a.ks != 3 || a.cin % X3_KC != 0 || a.planes || a.out_rows_f32) throw std::invalid_argument("conv3x3_p8_kernel: a dense 3x3 conv with cin a multiple of 128");
-    const size_t shmem = size_t(4) * 65 * X3_ROWP * sizeof(half_t);      // 70 KB: two (f16 tile + byte tile) buffers
+    const size_t shmem = ConvP8::lds_bytes;                              // 70 KB: two (f16 tile + byte tile) buffers
     const int tiles = a.cout_pad / 16;
+    if (a.pre_wpk) {                                                     // the policy head's two convs in one launch
+        if (a.cin != 256 || tiles > 8 || a.resid) throw std::invalid_argument("conv3x3_p8_chain_kernel: 256 -> 256 -> at most 128 couts, no shortcut");
+        hipLaunchKernelGGL(conv3x3_p8_chain_kernel, dim3(1, a.batch), dim3(512), shmem, s, a);
+        return;
+    }
     if (tiles >= 12 || (a.softmax_out && tiles > 8)) hipLaunchKernelGGL((conv3x3_p8_kernel<2, 8>), dim3((tiles + 15) / 16, a.batch), dim3(512), shmem, s, a);
     else hipLaunchKernelGGL((conv3x3_p8_kernel<1, 8>), dim3((tiles + 7) / 8, a.batch), dim3(512), shmem, s, a);
 }
@@ -1966,7 +2076,8 @@ void init_x3_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes + 8192));
-    const int conv_p8_lds = int(size_t(4) * 65 * X3_ROWP * sizeof(half_t));
+    const int conv_p8_lds = int(ConvP8::lds_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p8_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, conv_p8_lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p8_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_p8_lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p8_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_p8_lds);
 }

@@ -17,12 +17,6 @@ for v in EW=4 PW=4 "EW=4 -DCRA_X3_PW=4"; do
     $REPO/scripts/ubench/x3_tower_ablate.hip -o "/tmp/x3abl/var_${v// /_}" 2> "/tmp/x3abl/build_var_${v// /_}.log" &
   pids+=($!)
 done
-# experiment: the two-role kernel with tile-major MFMA order and per-tile window refills (scripts/experiments/x3_tile_major/x3.hip)
-for v in "" "-DCRA_X3_EW=4"; do
-  hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCRA_DEVELOPMENT -DCRA_X3_ABL=0 $v -I$REPO/scripts/experiments/x3_tile_major -I$REPO/crazyara_amd/csrc/nn \
-    $REPO/scripts/ubench/x3_tower_ablate.hip -o "/tmp/x3abl/tilemajor${v// /_}" 2> "/tmp/x3abl/build_tilemajor${v// /_}.log" &
-  pids+=($!)
-done
 for p in "${pids[@]}"; do wait $p; done
 {
   echo "tower_x3 kernels, RISEv2-19 tower, 256 boards (CRA_X3_ABL bits: 1 no depthwise math, 2 no expand MFMAs, 4 no project MFMAs,"
@@ -33,6 +27,5 @@ for p in "${pids[@]}"; do wait $p; done
     done
   done
   for v in EW=4 PW=4 "EW=4 -DCRA_X3_PW=4"; do echo -n "roles, -DCRA_X3_$v: "; CRA_X3_TOWER=roles "/tmp/x3abl/var_${v// /_}" 256 19 20; done
-  for v in "" "-DCRA_X3_EW=4"; do echo -n "roles, tile-major order $v: "; CRA_X3_TOWER=roles "/tmp/x3abl/tilemajor${v// /_}" 256 19 20; done
   for bb in 512 1024; do echo -n "roles "; CRA_X3_TOWER=roles /tmp/x3abl/abl_0 $bb 19 10; echo -n "symmetric "; CRA_X3_TOWER=symmetric /tmp/x3abl/abl_0 $bb 19 10; done
 } > $OUT 2>&1

@@ -467,3 +467,17 @@ def test_float16p8_equals_its_emulation(tmp_path, hip_lib, name):
     assert kernel_vs_emulation < max(2e-5, 2.5 * sens), (kernel_vs_emulation, sens, mode)
     assert kernel_vs_fp32 < 3e-4
     assert np.abs(value - e_value.numpy().reshape(-1)).max() < 2.5e-5
+
+
+@pytest.mark.parametrize("name,towers", [("risev2-19", 1), ("risev33", 5)])
+def test_float16p8_launch_structure(tmp_path, hip_lib, name, towers):
+    """What the headline mode's forward IS, launch by launch: the stem conv, ONE tower launch per run of blocks of one depthwise size (RISEv2: one
+    for the whole tower; RISEv3.3: its 3x3 and 5x5 runs alternate -- no layer-kernel blocks and no SE launches left), the policy head of a
+    policy-map net in one launch (both convs and the softmax), the value head."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, x = nn_cases.make_case(name)
+    d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
+    net = HipAPI(0, int(x.shape[0]), d, "float16p8")
+    names = [n for n, _ in net.time_ops(1)]
+    net.close()
+    assert names == ["conv_gemm_x3_3x3"] + ["tower_p8"] * towers + ["conv_gemm_x3_3x3", "value_head"], names

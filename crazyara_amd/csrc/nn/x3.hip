@@ -26,6 +26,11 @@
 #ifndef CRA_X3_ABL
 #define CRA_X3_ABL 0
 #endif
+// tower_p8_kernel<3>, E + D intervals: how many vector instructions the scheduling recipe places behind every MFMA.  10 measured 2.4 % faster than
+// 4 over five interleaved rounds (2: 1.8 %; 3, 5, 6: 3 - 4 % SLOWER -- the recipe steers the machine scheduler, not the hardware: profiles/r04/ap-ar)
+#ifndef X3_SGB_VALU
+#define X3_SGB_VALU 10
+#endif
 #if CRA_X3_ABL != 0 && !defined(CRA_DEVELOPMENT)
 #error "CRA_X3_ABL is a development switch (wrong results): build with -DCRA_DEVELOPMENT"
 #endif
@@ -1869,9 +1874,9 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                     }
                     if constexpr (HASE && HASD) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {                   // behind every MFMA up to four (5x5: twelve) VALU instructions
+                        for (int r = 0; r < 16; ++r) {                   // behind every MFMA up to X3_SGB_VALU (5x5: twelve) VALU instructions
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, KS == 3 ? 4 : 12, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, KS == 3 ? X3_SGB_VALU : 12, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);

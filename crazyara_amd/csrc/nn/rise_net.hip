@@ -599,7 +599,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     };
     // Precision float16x3: runs of consecutive 3x3 blocks in one launch (x3.hip: tower_x3_kernel)
     std::vector<X3TowerBlock> x3_blocks;
-    int x3_run_ks = 3;                     // Precision float16p8: a run is all 3x3 or all 5x5 blocks (tower_p8_kernel<KS>)
+    int x3_run_ks = 3;                     // a run is all 3x3 or all 5x5 blocks (tower_x3_roles_kernel<KS>, tower_p8_kernel<KS>)
     auto flush_x3_tower = [&]() {
         if (x3_blocks.empty()) return;
         Op op;
@@ -757,8 +757,8 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         if (!in_tower) flush_tower();
         const bool se_in_kernel = in_tower && !tower_blocks.empty();
         TowerBlockDesc td{};
-        // Precision float16p8 also runs the 5x5 blocks (RISEv3.3) in tower launches of their own, and computes a run's first gate in the launch
-        const bool in_x3_tower = x3_ && tower_ && fused_ && C == 256 && (k == 3 || (p8_ && k == 5));
+        // the 5x5 blocks (RISEv3.3) run in tower launches of their own (tower_*_kernel<5>); Precision float16p8 also computes a run's first gate in the launch
+        const bool in_x3_tower = x3_ && tower_ && fused_ && C == 256 && (k == 3 || k == 5);
         if (!in_x3_tower || (!x3_blocks.empty() && x3_run_ks != k)) flush_x3_tower();
         if (in_x3_tower && x3_blocks.empty()) x3_run_ks = k;
         const bool x3_se_in_kernel = in_x3_tower && (!x3_blocks.empty() || p8_);  // float16x3: the first block of a run takes its gate from an SE launch

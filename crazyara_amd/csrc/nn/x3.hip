@@ -1353,7 +1353,10 @@ __global__ __launch_bounds__(512) void tower_x3_kernel(const X3TowerArgs a) {
 // slower (profiles/r03/h_*) -- alone, its weight stream already runs at 27 TB/s, 80 % of the L2 -> CU peak; s_setprio on the EXPAND
 // waves, a barrier that holds the PROJECT waves back until the expand MFMAs are through (profiles/r03/m_*): nothing / slower;
 // v_pk_fma_f32 for the depthwise: it does not run in the shadow of MFMAs (mix_kinds.hip: 38.5 cycles for MFMA + 2 of them).
+template <int KS>
 __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a) {
+    static_assert(KS == 3 || KS == 5, "depthwise 3x3 or 5x5 (X3Depthwise / X3Depthwise5)");
+    constexpr int REC = KS == 3 ? 256 : 512;                            // floats of depthwise records per 16-channel tile
     using G = X3Block;
     static_assert(G::NE == 1 && G::T2BUF == 2 && G::CK == 128, "the role kernel uses the NE = 1 tile geometry (two t2 buffers of 128 channels)");
     constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW;
@@ -1406,9 +1409,11 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
             }
 #pragma unroll
             for (int s = 0; s < EW; ++s) load_e(0, s);
-            float* const my_dws = T.dws + (w * 2) * 256;               // this wave's two record tiles (8 x 256 floats in all)
+            float* const my_dws = T.dws + (w * 2) * REC;               // this wave's two record tiles
             f32x4 accE[2][4], accD[2][4];                               // chunk i being expanded / chunk i - 1 in the depthwise
             X3Depthwise dw;
+            X3Depthwise5 dw5;
+            const X3EdgeOffsets5 edge5 = x3_edge_offsets5(l15);
             // Interval i: E(i) (HASE) with D(i - 1) (HASD) cut into sixteen pieces, two per k-slab: tile 0 in slabs 0-3, tile 1 in 4-7.
             auto interval = [&](auto hase_c, auto hasd_c, int i) {
                 constexpr bool HASE = decltype(hase_c)::value, HASD = decltype(hasd_c)::value;
@@ -1424,28 +1429,37 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                         ring_l[st % 4] = *reinterpret_cast<const half8*>(T.xl + ((st & 3) * 16 + l15) * XROW + (st >> 2) * 32 + lg * 8);
                     }
                 };
-                f32x4 dw_raw[2];
+                f32x4 dw_raw[2][REC / 256];
                 if constexpr (HASE) {
                     // depthwise records of chunk i's two tiles: one 16-byte load per lane and tile (x3_chunks); they go to LDS at the end of
                     // the interval, behind the depthwise that still reads chunk i - 1's
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
-                        dw_raw[ne] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(i * CK + (w * 2 + ne) * 16) * 64u, 0));
+#pragma unroll
+                        for (int h2 = 0; h2 < REC / 256; ++h2)
+                            dw_raw[ne][h2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.dw, lane_off, uint32_t(i * CK + (w * 2 + ne) * 16) * uint32_t(REC / 4) + uint32_t(h2) * 1024u, 0));
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
 #pragma unroll
                         for (int t = 0; t < 4; ++t) accE[ne][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                     read_step(0); read_step(1); read_step(2);
                 }
-                if constexpr (HASD) dw.template load<0>(my_dws, lg, edge);
+                if constexpr (HASD && KS == 3) dw.template load<0>(my_dws, lg, edge);
                 half_t* const t2h = T.t2h + ((i - 1) & 1) * 64 * TROW;
                 half_t* const t2l = T.t2l + ((i - 1) & 1) * 64 * TROW;
 #pragma unroll
                 for (int sl = 0; sl < C / 32; ++sl) {
                     const int dt = sl / 4, ph = sl % 4;                 // the depthwise's tile and quarter
                     if constexpr (HASD) {
-                        if (ph == 2) dw.template load<1>(my_dws + dt * 256, lg, edge);
-                        if (sl == 4) dw.template load<0>(my_dws + 256, lg, edge);      // (tile 0's last pieces ran in slab 3)
+                        if constexpr (KS == 3) {
+                            if (ph == 2) dw.template load<1>(my_dws + dt * 256, lg, edge);
+                            if (sl == 4) dw.template load<0>(my_dws + 256, lg, edge);  // (tile 0's last pieces ran in slab 3)
+                        } else {                                        // 5x5: one channel of the tile per k-slab
+                            if (ph == 0) dw5.template load<0>(my_dws + dt * REC, lg, edge5);
+                            if (ph == 1) dw5.template load<1>(my_dws + dt * REC, lg, edge5);
+                            if (ph == 2) dw5.template load<2>(my_dws + dt * REC, lg, edge5);
+                            if (ph == 3) dw5.template load<3>(my_dws + dt * REC, lg, edge5);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (HASE) {
@@ -1469,16 +1483,23 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                         else load_e(i + 1 < n ? i + 1 : i, sl + EW - C / 32);    // (behind the last chunk: a valid address, no branch in the stretch)
                     }
                     if constexpr (HASD) {
-                        if (ph == 0) dw.template gather<0>(accD[dt], hi);
-                        if (ph == 1) { dw.template taps<0>(0, 4); dw.pin_taps(0, 4, 0); }
-                        if (ph == 2) dw.template gather<1>(accD[dt], hi);
+                        if constexpr (KS == 3) {
+                            if (ph == 0) dw.template gather<0>(accD[dt], hi);
+                            if (ph == 1) { dw.template taps<0>(0, 4); dw.pin_taps(0, 4, 0); }
+                            if (ph == 2) dw.template gather<1>(accD[dt], hi);
+                        } else {
+                            if (ph == 0) { dw5.template gather<0>(accD[dt], hi, 1.f); dw5.template taps<0>(); }
+                            if (ph == 1) { dw5.template gather<1>(accD[dt], hi, 1.f); dw5.template taps<1>(); }
+                            if (ph == 2) { dw5.template gather<2>(accD[dt], hi, 1.f); dw5.template taps<2>(); }
+                            if (ph == 3) { dw5.template gather<3>(accD[dt], hi, 1.f); dw5.template taps<3>(); }
+                        }
                         if (ph == 3) {
-                            dw.template taps<1>(0, 4);
+                            if constexpr (KS == 3) dw.template taps<1>(0, 4);
                             const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 half4 h, l;
-                                split4(dw.outv[t], h, l);
+                                split4(KS == 3 ? dw.outv[t] : dw5.outv[t], h, l);
                                 if constexpr (X3_ABL & 64) {
                                     asm volatile("" ::"v"(h), "v"(l));
                                 } else {
@@ -1499,7 +1520,9 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                 }
                 if constexpr (HASE) {                                    // the depthwise is through with chunk i - 1: its records and accumulators make room
 #pragma unroll
-                    for (int ne = 0; ne < 2; ++ne) *reinterpret_cast<f32x4*>(my_dws + ne * 256 + lane * 4) = dw_raw[ne];
+                    for (int ne = 0; ne < 2; ++ne)
+#pragma unroll
+                        for (int h2 = 0; h2 < REC / 256; ++h2) *reinterpret_cast<f32x4*>(my_dws + ne * REC + h2 * 256 + lane * 4) = dw_raw[ne][h2];
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne)
 #pragma unroll
@@ -2078,7 +2101,8 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
 void init_x3_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes + 8192));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes + 8192));
     const int conv_p8_lds = int(ConvP8::lds_bytes);
@@ -2100,8 +2124,10 @@ void launch_tower_x3(const X3TowerArgs& a, hipStream_t s) {
         if (symmetric) throw std::invalid_argument("Precision float16p8 runs the two-role tower only");
         if (a.ks == 5) hipLaunchKernelGGL(tower_p8_kernel<5>, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes + 8192, s, a);    // (2 KiB of records per tile)
         else hipLaunchKernelGGL(tower_p8_kernel<3>, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+    } else if (a.ks == 5) {                                              // (5x5 runs exist in the two-role form only: the A/B switch leaves them alone)
+        hipLaunchKernelGGL(tower_x3_roles_kernel<5>, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes + 8192, s, a);
     } else if (symmetric) hipLaunchKernelGGL(tower_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
-    else hipLaunchKernelGGL(tower_x3_roles_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+    else hipLaunchKernelGGL(tower_x3_roles_kernel<3>, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
 }
 
 }  // namespace cra

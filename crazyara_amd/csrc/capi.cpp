@@ -128,6 +128,25 @@ int mi_dev_launch_op(mi_net* net, int op, int iters) {       // development hook
     if (!net) { g_err = "null net"; return 1; }
     return guard([&] { net->net.dev_launch_op(op, iters); });
 }
+// development hooks of the co-residency screen (scripts/coresidency_screen.py; RiseNet::dev_screen_*)
+int mi_dev_screen_prepare(mi_net* net) {
+    if (!net) { g_err = "null net"; return -1; }
+    int n = -1;
+    if (guard([&] { n = net->net.dev_screen_prepare(); })) return -1;
+    return n;
+}
+long mi_dev_screen_run(mi_net* net, int op, int launches, long* words) {
+    if (!net) { g_err = "null net"; return -1; }
+    long n = -1;
+    if (guard([&] { n = net->net.dev_screen_run(op, launches, words); })) return -1;
+    return n;
+}
+int mi_dev_screen_info(mi_net* net, int op, char* out, int cap) {
+    if (!net || !out || cap <= 0) { g_err = "null argument"; return 1; }
+    const std::string s = net->net.dev_screen_info(op);
+    snprintf(out, size_t(cap), "%s", s.c_str());
+    return 0;
+}
 void* mi_dev_value_head_debug(mi_net* net) { return net ? static_cast<void*>(net->net.value_head_debug()) : nullptr; }
 int mi_net_forward_device(mi_net* net) {
     if (!net) { g_err = "null net"; return 1; }

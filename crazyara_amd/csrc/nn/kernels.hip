@@ -372,7 +372,14 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
 // channels), a 16-byte LDS read of the square's row per four input channels, the weights as broadcast reads; FC1: thread = (four outputs, a quarter
 // of the inputs), a row of the transposed weight matrix as one 16-byte load per lane, 32 loads in flight.  Precision float16x3 runs this kernel (one launch instead of conv
 // GEMM + FC GEMM + final), as do the unfused layer paths.
-template <typename T>
+//
+// PROBE (development, ValueHeadArgs::variant & 16, needs dbg): the instantiation round 5's root-cause harness launches
+// (scripts/value_head_rootcause.py).  Behind the launch's [B][8 + 1024] checksum area it leaves, per board, 16 words of header (words 0-3:
+// HW_ID of waves 0-3, word 4: XCC_ID) and three more [1024]-word images in s_part's layout: (1) the FC1 sums read back from LDS right
+// behind the barrier, (2) the SAME sums stored to global memory straight from the accumulator registers, never through LDS, (3) integer
+// checksums of the 16-byte weight loads per lane and component (sum of the loaded words' bit patterns) -- so that a differing launch says
+// whether the loaded words, the accumulator register or only its way through LDS was wrong.
+template <typename T, bool PROBE = false>
 __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int CH = a.C / 2;                                    // the board is staged in two halves of its channels (LDS stays below 64 KiB)
@@ -490,8 +497,10 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
     float* s_part = (a.variant & 1) ? s_red + 8 : xs;           // [4 quarters][fc]
     float part = 0.f;
     const int kq = tid >> 6, nq = nf / 4;
+    float* probe = PROBE ? a.dbg + size_t(a.batch) * (8 + 1024) + size_t(b) * (16 + 3 * 1024) : nullptr;
     for (int j4 = tid & 63; 4 * j4 < a.fc; j4 += 64) {
         f32x4 h = {0.f, 0.f, 0.f, 0.f};
+        uint32_t cs[4] = {0u, 0u, 0u, 0u};
         const float* wt = a.w1t + size_t(kq) * nq * a.fc + 4 * j4;
         const float* fl = s_flat + kq * nq;
         int i = 0;
@@ -503,6 +512,12 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
                 else w[j] = *reinterpret_cast<const f32x4*>(wt + size_t(i + j) * a.fc);
             }
             if (a.variant & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (development) every load back before the first product
+            if constexpr (PROBE) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cs[e] += __builtin_bit_cast(uint32_t, w[j][e]);
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const f32x4 f = *reinterpret_cast<const f32x4*>(fl + i + 4 * q);
@@ -521,9 +536,22 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) h[e] = fmaf(w[e], fl[i], h[e]);
         }
+        if constexpr (PROBE) {
+            if (kq * a.fc + 4 * j4 + 3 < 1024) {
+                *reinterpret_cast<f32x4*>(probe + 16 + 1024 + kq * a.fc + 4 * j4) = h;               // (2) from the registers
+                float* oc = probe + 16 + 2048 + kq * a.fc + 4 * j4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oc[e] = __builtin_bit_cast(float, cs[e]);                 // (3) what the loads returned
+            }
+        }
         *reinterpret_cast<f32x4*>(s_part + kq * a.fc + 4 * j4) = h;
     }
     __syncthreads();
+    if constexpr (PROBE) {
+        for (int i = tid; i < 4 * a.fc && i < 1024; i += 256) probe[16 + i] = s_part[i];              // (1) first read back from LDS
+        if ((tid & 63) == 0) probe[tid >> 6] = __builtin_bit_cast(float, __builtin_amdgcn_s_getreg((31 << 11) | 4));
+        if (tid == 0) probe[4] = __builtin_bit_cast(float, __builtin_amdgcn_s_getreg((31 << 11) | 20));
+    }
     for (int t = tid; t < a.fc; t += 256) {
         const float h = a.b1[t] + ((s_part[t] + s_part[a.fc + t]) + (s_part[2 * a.fc + t] + s_part[3 * a.fc + t]));
         part = fmaf(a.w2[t], fmaxf(h, 0.f), part);
@@ -609,14 +637,17 @@ template <typename T> void prepare_value_head(const ValueHeadArgs& a) {
     // per net build, like the other kernels' allowances: the attribute belongs to the current DEVICE's copy of the function, so a
     // remembered process-wide maximum would leave the second device of a First/Last_Device_ID range at the default 64 KiB
     if (shmem > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_head_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(shmem));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_head_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(shmem));
+        if (e == hipSuccess && a.dbg && (a.variant & 16))
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_head_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(shmem));
         if (e != hipSuccess) throw std::runtime_error(std::string("value head: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
     }
 }
 template void prepare_value_head<half_t>(const ValueHeadArgs&);
 template void prepare_value_head<float>(const ValueHeadArgs&);
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((value_head_kernel<T>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
+    if (a.dbg && (a.variant & 16)) hipLaunchKernelGGL((value_head_kernel<T, true>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
+    else hipLaunchKernelGGL((value_head_kernel<T>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
 }
 template void launch_value_head<half_t>(const ValueHeadArgs&, hipStream_t);
 template void launch_value_head<float>(const ValueHeadArgs&, hipStream_t);

@@ -76,6 +76,14 @@ public:
     void* enable_block_dump(int* n_tiles);
     void dev_launch_op(int op, int iters);                        // development: op `op` of the forward `iters` times into the net's stream, no wait
     float* value_head_debug() const { return value_head_dbg_; }   // development: [B][8] stage checksums (CRA_VALUE_HEAD_DEBUG), else null
+    // development: the co-residency screen (scripts/coresidency_screen.py, profiles/NOTES.md round 5).  prepare: with a forward of
+    // OTHER planes behind it, runs the forward op by op and records, per op, which of the net's mutable device buffers it changes, their
+    // contents before and after, and whether the op gives the same bits when launched again on its own output (else its buffers are put
+    // back before every launch).  run: op `op` alone `launches` times on the net's stream, every launch compared word for word on the
+    // device with the recorded result; returns the number of launches that differed (words: how many 16-byte pieces in all).
+    int dev_screen_prepare();
+    long dev_screen_run(int op, int launches, long* words);
+    std::string dev_screen_info(int op) const;
     float* d_aux() const { return d_aux_; }           // [B][nb_aux] or nullptr
     void forward_async();
     void launch_forward_in_stream();     // the forward as part of a stream's in-order work (submit*, see rise_net.hip)                              // graph replay on stream(); no copies, no sync

@@ -230,19 +230,31 @@ struct Op {
 };
 }  // namespace
 
+// development: what the co-residency screen knows about one op (RiseNet::dev_screen_prepare)
+struct ScreenOp {
+    struct Buf { char* live; char* before; char* after; size_t bytes; };
+    std::vector<Buf> writes;          // the mutable buffers the op changes
+    bool idempotent = true;           // launched again on its own result it gives the same bits
+};
+
 struct RiseNet::Impl {
     std::vector<void*> allocs;
+    std::vector<std::pair<char*, size_t>> mutables;      // allocations that are not uploaded constants: activations, outputs, scratch
     std::vector<Op> ops;
+    std::vector<ScreenOp> screen;
+    std::vector<void*> screen_allocs;
+    unsigned* screen_bad = nullptr;
     int cin_pad = 0;
 
-    void* dalloc(size_t bytes) {
+    void* dalloc(size_t bytes, bool constant = false) {
         void* p = nullptr;
         HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
         allocs.push_back(p);
+        if (!constant) mutables.emplace_back(static_cast<char*>(p), bytes ? bytes : 16);
         return p;
     }
     template <typename U> U* upload(const std::vector<U>& h) {
-        U* d = static_cast<U*>(dalloc(h.size() * sizeof(U)));
+        U* d = static_cast<U*>(dalloc(h.size() * sizeof(U), true));
         HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(U), hipMemcpyHostToDevice));
         return d;
     }
@@ -253,6 +265,7 @@ struct RiseNet::Impl {
     }
     ~Impl() {
         for (void* p : allocs) (void)hipFree(p);
+        for (void* p : screen_allocs) (void)hipFree(p);
     }
 };
 
@@ -1332,8 +1345,10 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         }
         macs += double(kSquares) * C * cv;
         if (getenv("CRA_VALUE_HEAD_DEBUG") != nullptr) {              // development: stage checksums of every launch (ValueHeadArgs::dbg)
-            v.dbg = static_cast<float*>(im.dalloc(size_t(B) * (8 + 1024) * sizeof(float)));
-            HIP_CHECK(hipMemset(v.dbg, 0, size_t(B) * (8 + 1024) * sizeof(float)));
+            // [B][8 + 1024] checksums and FC1 sums, then (variant & 16, the PROBE instantiation) [B][16 + 3 * 1024] words
+            const size_t dbg_bytes = size_t(B) * ((8 + 1024) + (16 + 3 * 1024)) * sizeof(float);
+            v.dbg = static_cast<float*>(im.dalloc(dbg_bytes));
+            HIP_CHECK(hipMemset(v.dbg, 0, dbg_bytes));
             value_head_dbg_ = v.dbg;
         }
         if (const char* pad = getenv("CRA_VALUE_HEAD_LDS_PAD")) v.lds_pad = atoi(pad);
@@ -1515,6 +1530,105 @@ void RiseNet::time_ops(int iters, float* ms) {
                 fprintf(stderr, "\n");
             }
         }
+}
+
+// ---- development: the co-residency screen ----
+namespace {
+// 16-byte pieces of two buffers compared in place; every differing piece counts into *bad (one word per launch of the screened op)
+__global__ __launch_bounds__(256) void screen_compare_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, size_t n16, unsigned* bad) {
+    unsigned diff = 0;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n16; i += size_t(gridDim.x) * 256) {
+        const uint4 x = a[i], y = b[i];
+        diff += (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) ? 1u : 0u;
+    }
+    if (diff) atomicAdd(bad, diff);
+}
+void screen_compare(const char* a, const char* b, size_t bytes, unsigned* bad, hipStream_t s) {
+    const size_t n16 = bytes / 16;                       // (allocations are multiples of 16 bytes or compared up to the last whole piece)
+    if (!n16) return;
+    const int blocks = int(std::min<size_t>(512, (n16 + 255) / 256));
+    hipLaunchKernelGGL(screen_compare_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), n16, bad);
+}
+}  // namespace
+
+int RiseNet::dev_screen_prepare() {
+    HIP_CHECK(hipSetDevice(device_));
+    Impl& im = *impl_;
+    if (!im.screen.empty()) return int(im.screen.size());
+    auto salloc = [&](size_t bytes) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+        im.screen_allocs.push_back(p);
+        return static_cast<char*>(p);
+    };
+    im.screen_bad = reinterpret_cast<unsigned*>(salloc(sizeof(unsigned) * 65536));
+    unsigned* flag = reinterpret_cast<unsigned*>(salloc(sizeof(unsigned) * im.mutables.size()));
+    std::vector<char*> snap(im.mutables.size());
+    for (size_t i = 0; i < im.mutables.size(); ++i) snap[i] = salloc(im.mutables[i].second);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    im.screen.resize(im.ops.size());
+    std::vector<unsigned> hflag(im.mutables.size());
+    for (int k = 0; k < int(im.ops.size()); ++k) {
+        for (size_t i = 0; i < im.mutables.size(); ++i)
+            HIP_CHECK(hipMemcpyAsync(snap[i], im.mutables[i].first, im.mutables[i].second, hipMemcpyDeviceToDevice, stream_));
+        HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(unsigned) * im.mutables.size(), stream_));
+        dev_launch_op(k, 1);
+        for (size_t i = 0; i < im.mutables.size(); ++i) screen_compare(snap[i], im.mutables[i].first, im.mutables[i].second, flag + i, stream_);
+        HIP_CHECK(hipMemcpyAsync(hflag.data(), flag, sizeof(unsigned) * hflag.size(), hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        ScreenOp& so = im.screen[k];
+        for (size_t i = 0; i < im.mutables.size(); ++i) {
+            if (!hflag[i]) continue;
+            ScreenOp::Buf b{im.mutables[i].first, salloc(im.mutables[i].second), salloc(im.mutables[i].second), im.mutables[i].second};
+            HIP_CHECK(hipMemcpyAsync(b.before, snap[i], b.bytes, hipMemcpyDeviceToDevice, stream_));
+            HIP_CHECK(hipMemcpyAsync(b.after, b.live, b.bytes, hipMemcpyDeviceToDevice, stream_));
+            so.writes.push_back(b);
+        }
+        // the op once more, on its own result
+        HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(unsigned), stream_));
+        dev_launch_op(k, 1);
+        for (const ScreenOp::Buf& b : so.writes) screen_compare(b.after, b.live, b.bytes, flag, stream_);
+        HIP_CHECK(hipMemcpyAsync(hflag.data(), flag, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        so.idempotent = hflag[0] == 0;
+        if (!so.idempotent)                                   // leave the forward's state behind the op as it was
+            for (const ScreenOp::Buf& b : so.writes) HIP_CHECK(hipMemcpyAsync(b.live, b.after, b.bytes, hipMemcpyDeviceToDevice, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+    }
+    return int(im.screen.size());
+}
+
+long RiseNet::dev_screen_run(int op, int launches, long* words) {
+    HIP_CHECK(hipSetDevice(device_));
+    Impl& im = *impl_;
+    if (im.screen.empty()) throw std::runtime_error("dev_screen_run: dev_screen_prepare first");
+    if (op < 0 || op >= int(im.screen.size())) throw std::invalid_argument("op index out of range");
+    launches = std::min(launches, 65536);
+    const ScreenOp& so = im.screen[op];
+    HIP_CHECK(hipMemsetAsync(im.screen_bad, 0, sizeof(unsigned) * launches, stream_));
+    for (int l = 0; l < launches; ++l) {
+        if (!so.idempotent)
+            for (const ScreenOp::Buf& b : so.writes) HIP_CHECK(hipMemcpyAsync(b.live, b.before, b.bytes, hipMemcpyDeviceToDevice, stream_));
+        dev_launch_op(op, 1);
+        for (const ScreenOp::Buf& b : so.writes) screen_compare(b.after, b.live, b.bytes, im.screen_bad + l, stream_);
+        if ((l & 63) == 63) HIP_CHECK(hipStreamSynchronize(stream_));      // (keeps the queue short; the neighbour's stream runs on)
+    }
+    std::vector<unsigned> bad(launches);
+    HIP_CHECK(hipMemcpyAsync(bad.data(), im.screen_bad, sizeof(unsigned) * launches, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    long n = 0, w = 0;
+    for (unsigned b : bad) { n += b != 0; w += b; }
+    if (words) *words = w;
+    return n;
+}
+
+std::string RiseNet::dev_screen_info(int op) const {
+    const Impl& im = *impl_;
+    if (op < 0 || op >= int(im.screen.size())) return "";
+    size_t bytes = 0;
+    for (const ScreenOp::Buf& b : im.screen[op].writes) bytes += b.bytes;
+    return std::string(op_name(op)) + " writes " + std::to_string(im.screen[op].writes.size()) + " buffers / " + std::to_string(bytes) + " bytes" +
+           (im.screen[op].idempotent ? "" : ", not idempotent (buffers restored before every launch)");
 }
 
 void RiseNet::dev_launch_op(int op, int iters) {

@@ -1,0 +1,134 @@
+"""Co-residency screen (VERDICT r04 #1c): does ANY kernel of a conformant forward come out different when ANY kernel of a second net
+runs beside it?
+
+Round 4 found one such pair by accident (value_head_kernel beside conv_gemm_x3_kernel<3, 1, 8, 4>: one FC1 accumulator wrong in 20-30 % of
+the launches) and fenced it; this screens every (victim, aggressor) pair of ops of the conformant forwards.
+
+  victim    : net A has run a forward of OTHER planes, then the planes of the screen; RiseNet::dev_screen_prepare runs the forward op by op
+              and records every op's output buffers.  Then op k ALONE, `launches` times on A's stream, every launch compared on the device
+              with the recorded bits (an op that is not idempotent gets its buffers put back before every launch).
+  aggressor : net B (same model and mode, own weights / buffers / stream) loops ONE of its ops on another host thread.
+  control   : CRA_VALUE_HEAD_LDS_PAD=-1 (default here) drops the value head's 144 KB LDS fence, so the known pair must show up red;
+              --fenced runs the shipped form, where every cell must be 0.
+
+usage: python scripts/coresidency_screen.py [--launches 1000] [--batch 256] [--configs p8-v2,x3-v2,p8-v33,x3-v33] [--fenced] [--out file.json]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import threading
+import time
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--launches", type=int, default=1000)
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--configs", default="p8-v2,x3-v2,p8-v33,x3-v33")
+ap.add_argument("--fenced", action="store_true", help="the shipped value head (144 KB LDS fence): every cell must be 0")
+ap.add_argument("--out", default=None)
+args = ap.parse_args()
+os.environ["CRA_X3_VALUE_HEAD"] = "one"
+if not args.fenced:
+    os.environ.setdefault("CRA_VALUE_HEAD_LDS_PAD", "-1")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from crazyara_amd import _capi, netfile, rise_config  # noqa: E402
+from crazyara_amd.neuralnetapi import HipAPI, NeuralNetAPIUser  # noqa: E402
+
+lib = _capi.load()
+lib.mi_dev_launch_op.argtypes = [C.c_void_p, C.c_int, C.c_int]
+lib.mi_dev_screen_prepare.argtypes = [C.c_void_p]
+lib.mi_dev_screen_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_long)]
+lib.mi_dev_screen_run.restype = C.c_long
+lib.mi_dev_screen_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+
+CONFIGS = {
+    "p8-v2": (lambda: rise_config.rise_v2_config(19, 34, 81), "1.0", "float16p8"),
+    "x3-v2": (lambda: rise_config.rise_v2_config(19, 34, 81), "1.0", "float16x3"),
+    "p8-v33": (lambda: rise_config.rise_v33_config(52, 76, False), "3.0", "float16p8"),
+    "x3-v33": (lambda: rise_config.rise_v33_config(52, 76, False), "3.0", "float16x3"),
+    "x3-v2-3": (lambda: rise_config.rise_v2_config(3, 34, 81), "1.0", "float16x3"),          # round 4's harness net (batch 64)
+}
+
+
+def planes(batch, channels, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.random((batch, channels, 8, 8)) < 0.1).astype(np.float32)
+
+
+report = {"launches": args.launches, "batch": args.batch, "fenced": bool(args.fenced), "configs": {}}
+for name in args.configs.split(","):
+    make, version, precision = CONFIGS[name]
+    cfg = make()
+    sd = rise_config.make_state_dict(cfg, seed=77, stress=True)
+    d = tempfile.mkdtemp(prefix="cra_screen_")
+    netfile.export_rise(os.path.join(d, f"{cfg.name}-v{version}.cranet"), cfg, sd, input_version=version)
+    A, B = HipAPI(0, args.batch, d, precision), HipAPI(0, args.batch, d, precision)
+    users = [NeuralNetAPIUser([n]) for n in (A, B)]
+    for n, u, seed in ((A, users[0], 1), (B, users[1], 2)):
+        u.input_planes[:] = planes(args.batch, cfg.nb_input_channels, seed).reshape(-1)
+        n.predict(u.input_planes, u.value_outputs, u.prob_outputs, u.auxiliary_outputs if n.has_auxiliary_outputs() else None)
+    # the planes of the screen in A's device-side input (the op-by-op forward reads them there)
+    torch.as_tensor(A.device_buffers()["planes"], device="cuda").copy_(torch.from_numpy(planes(args.batch, cfg.nb_input_channels, 3)).cuda())
+    torch.as_tensor(B.device_buffers()["planes"], device="cuda").copy_(torch.from_numpy(planes(args.batch, cfg.nb_input_channels, 4)).cuda())
+    torch.cuda.synchronize()
+    B.forward_device()
+    B.sync()
+    n_ops = lib.mi_dev_screen_prepare(A._h)
+    assert n_ops > 0, lib.mi_last_error()
+    names = [nm for nm, _ in A.time_ops(1)]      # (runs the forward once more on the same planes: same bits, the record stands)
+    infos = []
+    for k in range(n_ops):
+        buf = C.create_string_buffer(256)
+        lib.mi_dev_screen_info(A._h, k, buf, 256)
+        infos.append(buf.value.decode())
+        print(f"[{name}] op {k:2d}: {infos[-1]}", flush=True)
+    matrix = {}
+    t0 = time.perf_counter()
+    for j, agg in [(-1, "nothing")] + list(enumerate(names)):
+        stop = threading.Event()
+
+        def aggressor():
+            while not stop.is_set():
+                if j >= 0:
+                    lib.mi_dev_launch_op(B._h, j, 16)
+                    B.sync()
+                else:
+                    time.sleep(0.01)
+        th = threading.Thread(target=aggressor)
+        th.start()
+        row = {}
+        for k, vic in enumerate(names):
+            words = C.c_long(0)
+            bad = lib.mi_dev_screen_run(A._h, k, args.launches, C.byref(words))
+            assert bad >= 0, lib.mi_last_error()
+            row[f"{k}:{vic}"] = [int(bad), int(words.value)]
+        stop.set()
+        th.join()
+        matrix[f"{j}:{agg}"] = row
+        red = {v: b for v, b in row.items() if b[0]}
+        print(f"[{name}] aggressor {j:2d} {agg:16s}: " + (f"RED {red}" if red else "all victims clean"), flush=True)
+    report["configs"][name] = {"precision": precision, "model": cfg.name, "ops": infos, "seconds": round(time.perf_counter() - t0, 1),
+                               "bad_launches_and_pieces_by_aggressor_then_victim": matrix}
+    for u in users:
+        u.close()
+    A.close()
+    B.close()
+line = json.dumps(report)
+if args.out:
+    with open(args.out, "w") as f:
+        f.write(line + "\n")
+# compact table: victims down, aggressors across, cells = differing launches
+for name, r in report["configs"].items():
+    m = r["bad_launches_and_pieces_by_aggressor_then_victim"]
+    aggs = list(m)
+    print(f"\n== {name} ({r['precision']}, {r['model']}, batch {args.batch}, {args.launches} launches per cell; rows = victim op, columns = aggressor op) ==")
+    print(" " * 22 + " ".join(f"{a.split(':')[0]:>5s}" for a in aggs))
+    for v in m[aggs[0]]:
+        print(f"{v:22s}" + " ".join(f"{m[a][v][0]:5d}" for a in aggs))
+red_total = sum(b[0] for r in report["configs"].values() for row in r["bad_launches_and_pieces_by_aggressor_then_victim"].values() for b in row.values())
+print(f"\nRESULT red cells' launches in all: {red_total}")

@@ -1,55 +1,77 @@
 #!/bin/bash
-# One GPU-box pass: gpu tests, headline bench, rocprofv3 kernel-trace stats of the bench, PMC passes of the forward.
-# usage (from the repo root on the GPU box): bash scripts/gpu_round.sh <tag> [tests|notests] [pmc|nopmc]
-TAG=${1:-r01}
+# GPU-box passes, one table of named sets.  usage (from the repo root on the GPU box): bash scripts/gpu_round.sh <tag> <set> [<set> ...]
+# Results land under gpurun_out/<tag>/ (copied into profiles/ by hand).  The one-off launchers of rounds 3 and 4 (scripts/gpu_r03*.sh,
+# gpu_r04*.sh) were the same commands with other arguments; profiles/NOTES.md names the set letters, git history has the files.
+#
+#   tests       pytest -m gpu (whole suite)                      smoke     __graft_entry__.smoke()
+#   newparity   the full-size parity tests of configs 2 / 3 / 5 + lane determinism
+#   bench       python bench.py (every leg) + bench_detail.json   benchquick  the NN legs only (no search / game / drop-in legs)
+#   trace       rocprofv3 --kernel-trace --stats of bench.py --timed-only, headline mode (+ float16)
+#   pmc         SQ / TCC / GRBM counter passes of the headline forward (scripts/prof_forward.py), separate --pmc runs
+#   screen      scripts/coresidency_screen.py, unfenced (positive control) and fenced
+#   rootcause   scripts/value_head_rootcause.py + scripts/ubench/neighbour_mfma.bin, every aggressor kind
+#   round       tests smoke bench trace pmc
+TAG=${1:-r05}
+shift
+SETS="$@"
+[ -z "$SETS" ] && SETS="round"
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python __graft_entry__.py > $OUT/build.log 2>&1
-if [ "${2:-tests}" = "tests" ]; then
-  timeout 1200 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1
-  echo "pytest exit $?" >> $OUT/pytest_gpu.log
-  tail -5 $OUT/pytest_gpu.log
-fi
-timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-tail -c 3000 $OUT/bench.json
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --timed-only --steps 300 --warmup 30 > $OUT/trace.log 2>&1
-# the same for Precision float16 (the one-launch forward kernel: the reference-default mode)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_f16 -- python $REPO/bench.py --timed-only --precision float16 --steps 300 --warmup 30 > $OUT/trace_f16.log 2>&1
-cd $REPO
-find $OUT/trace_f16 -type f ! -name "*stats*.csv" -delete
-find $OUT/trace -name "*kernel_stats.csv" | head -3
-if [ "${3:-pmc}" = "pmc" ]; then
-  cd /tmp
-  run() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python $REPO/scripts/prof_forward.py 19 256 float16 3 > $OUT/$name.log 2>&1; }
-  run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
-  run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES
-  run sq3 SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC
-  run tcc1 FETCH_SIZE TCC_HIT_sum
-  run tcc2 WRITE_SIZE TCC_MISS_sum
-  run grbm GRBM_GUI_ACTIVE
-  # the same forward in Precision fp8 (e4m3 GEMM operands): MFMA / LDS / L2 counters and a kernel trace of its own
-  run8() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python $REPO/scripts/prof_forward.py 19 256 fp8 3 > $OUT/$name.log 2>&1; }
-  run8 fp8_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
-  run8 fp8_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_WAVES
-  run8 fp8_tcc1 FETCH_SIZE TCC_HIT_sum
-  # the headline mode, Precision float16x3 (x3.hip): the per-block kernel's MFMA / LDS / L2 counters
-  runx() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python $REPO/scripts/prof_forward.py 19 256 float16x3 3 > $OUT/$name.log 2>&1; }
-  runx x3_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
-  runx x3_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_WAVES
-  runx x3_tcc1 FETCH_SIZE TCC_HIT_sum
-  runx x3_tcc2 WRITE_SIZE TCC_MISS_sum
-  runx x3_grbm GRBM_GUI_ACTIVE
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fp8_trace -- python $REPO/scripts/prof_forward.py 19 256 fp8 200 > $OUT/fp8_trace.log 2>&1
-  cd $REPO
-  ALL="sq1 sq2 sq3 tcc1 tcc2 grbm fp8_sq1 fp8_sq2 fp8_tcc1 x3_sq1 x3_sq2 x3_tcc1 x3_tcc2 x3_grbm"
-  for p in $ALL; do python scripts/pmc_summary.py $OUT/$p > $OUT/pmc_$p.txt 2>&1; done
-  # raw counter CSVs are large; keep the summaries only
-  for p in $ALL; do rm -rf $OUT/$p; done
-  find $OUT/fp8_trace -type f ! -name "*stats*.csv" -delete
-fi
-# keep only the stats csvs of the trace
-find $OUT/trace -type f ! -name "*stats*.csv" -delete
-ls -R $OUT | head -40
+HEADLINE=${HEADLINE:-float16p8}
+python __graft_entry__.py > $OUT/build.log 2>&1 || tail -5 $OUT/build.log
+
+pmc_run() { prec=$1; name=$2; shift; shift; (cd /tmp && timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python $REPO/scripts/prof_forward.py 19 256 $prec 3 > $OUT/$name.log 2>&1); }
+
+run_set() {
+  case $1 in
+    tests)
+      timeout 1800 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log ;;
+    smoke)
+      python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -4 $OUT/smoke.log ;;
+    newparity)
+      timeout 900 python -m pytest tests/test_nn_parity_gpu.py tests/test_lane_determinism_gpu.py -m gpu -q -k "${NEWPARITY_K:-full_size or determinism}" > $OUT/pytest_newparity.log 2>&1
+      echo "pytest exit $?" >> $OUT/pytest_newparity.log; tail -6 $OUT/pytest_newparity.log ;;
+    bench)
+      timeout 1200 python bench.py --detail-out $OUT/bench_detail.json > $OUT/bench.json 2> $OUT/bench.err
+      wc -c $OUT/bench.json; cat $OUT/bench.json; tail -3 $OUT/bench.err ;;
+    benchquick)
+      timeout 600 python bench.py --no-search --detail-out $OUT/benchquick_detail.json > $OUT/benchquick.json 2> $OUT/benchquick.err
+      wc -c $OUT/benchquick.json; cat $OUT/benchquick.json; tail -3 $OUT/benchquick.err ;;
+    trace)
+      for prec in $HEADLINE float16; do
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$prec -- python $REPO/bench.py --timed-only --precision $prec --steps 300 --warmup 30 > $OUT/trace_$prec.log 2>&1)
+        find $OUT/trace_$prec -type f ! -name "*stats*.csv" -delete
+        f=$(find $OUT/trace_$prec -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${prec}_kernel_stats.csv && head -8 $f
+      done ;;
+    pmc)
+      prec=$HEADLINE
+      pmc_run $prec ${prec}_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
+      pmc_run $prec ${prec}_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_WAVES
+      pmc_run $prec ${prec}_tcc1 FETCH_SIZE TCC_HIT_sum
+      pmc_run $prec ${prec}_tcc2 WRITE_SIZE TCC_MISS_sum
+      pmc_run $prec ${prec}_grbm GRBM_GUI_ACTIVE
+      for p in sq1 sq2 tcc1 tcc2 grbm; do python scripts/pmc_summary.py $OUT/${prec}_$p > $OUT/pmc_${prec}_$p.txt 2>&1; rm -rf $OUT/${prec}_$p; done
+      grep -h -A12 "tower_p8" $OUT/pmc_${prec}_sq2.txt | head -14 ;;
+    lds)
+      prec=$HEADLINE
+      pmc_run $prec ${prec}_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_WAVES
+      python scripts/pmc_summary.py $OUT/${prec}_sq2 > $OUT/pmc_${prec}_sq2.txt 2>&1; rm -rf $OUT/${prec}_sq2
+      grep -h -A12 "tower_p8" $OUT/pmc_${prec}_sq2.txt | head -14 ;;
+    screen)
+      timeout 500 python scripts/coresidency_screen.py --batch 64 --configs x3-v2-3 --launches 2000 --out $OUT/screen_control_batch64.json > $OUT/screen_control_batch64.txt 2>&1; tail -12 $OUT/screen_control_batch64.txt
+      timeout 900 python scripts/coresidency_screen.py --launches ${SCREEN_LAUNCHES:-1000} --out $OUT/screen_unfenced.json > $OUT/screen_unfenced.txt 2>&1; grep -E "RED|RESULT|Error|error" $OUT/screen_unfenced.txt | head -40
+      [ -n "$SCREEN_SKIP_FENCED" ] || timeout 900 python scripts/coresidency_screen.py --fenced --launches ${SCREEN_LAUNCHES:-1000} --out $OUT/screen_fenced.json > $OUT/screen_fenced.txt 2>&1; grep -E "RED|RESULT|Error|error" $OUT/screen_fenced.txt | head -40 ;;
+    rootcause)
+      timeout 400 python scripts/value_head_rootcause.py 20000 64 risev2-3 > $OUT/rootcause_probe.txt 2>&1; tail -40 $OUT/rootcause_probe.txt
+      for kind in -1 0 1 2 3 4; do timeout 120 scripts/ubench/neighbour_mfma.bin $kind 3000 8 600 64 >> $OUT/neighbour_mfma.txt 2>&1; done
+      for kind in 0 3; do timeout 120 scripts/ubench/neighbour_mfma.bin $kind 3000 8 600 256 >> $OUT/neighbour_mfma.txt 2>&1; done
+      cat $OUT/neighbour_mfma.txt | head -60 ;;
+    round)
+      for s in tests smoke bench trace pmc; do run_set $s; done ;;
+    *) echo "unknown set $1" ;;
+  esac
+}
+for s in $SETS; do echo "=== set $s ==="; run_set $s; done
+ls $OUT | head -60

@@ -5,7 +5,9 @@ counts its passes (the next instruction of the wave issues only when the matrix 
 previous one has gone through).  usage: isa_mfma_hazards.py file.s [function-substring]"""
 import re, sys
 
-NEED = {"f8f6f4": 18, "32x32": 10, "16x16": 6}     # XDL write VGPR -> VALU / LDS / VMEM read, by passes (16, 8, 4) + 2
+# XDL write VGPR -> VALU / LDS / VMEM read, by passes (16, 8, 4) + 2; the 16x16x128 8-bit form is 8 passes (+ 3 = 11: what the
+# compiler pads it with), the 32x32x64 one 16.  First match wins.
+NEED = {"16x16x128_f8f6f4": 11, "f8f6f4": 18, "32x32": 10, "16x16": 6}
 reg = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
 
 
@@ -50,8 +52,12 @@ def scan(lines, name):
                     hits += 1
                     break
             for r in touched: pending.pop(r, None) if op.startswith("v_") and r in regs(parts[0]) else None
-        if op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_barrier")) and op != "s_barrier":
-            pass      # linear scan: fall-through order is what the listing gives; branches only shorten real distances
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            # nothing falls through an unconditional jump: what the listing prints next is another path's code, reached by a branch of
+            # its own (whose taken-branch latency is not modelled: conditional branches keep the linear order, which only SHORTENS
+            # real distances)
+            pending.clear()
+            continue
         for r in list(pending):
             pending[r] = (pending[r][0] - ws, pending[r][1])
             if pending[r][0] <= 0: del pending[r]

@@ -1,0 +1,210 @@
+// Which kind of neighbour on the compute unit makes an FC1-shaped wave lose a word?  (profiles/NOTES.md rounds 4 and 5: value_head_kernel's
+// FC1 sums came out wrong in lanes 48-63 of one register whenever workgroups of conv_gemm_x3_kernel<3, 1, 8, 4> shared its compute unit;
+// round 4's passive victim beside VALU / LDS-permute / store neighbours stayed clean, but never had a neighbour that issues MFMAs, streams
+// 16-byte loads or reads 16-byte LDS rows -- the three things that conv does.)
+//
+//   victim    : value_head_kernel's FC1 loop and geometry -- 256 threads = one wave per SIMD, ~200 VGPRs, 44 KB of LDS; per round every lane
+//               requests 32 x 16 bytes (a 1 KiB row per wave and load, all 32 in flight), then
+//                 (L) checks every loaded WORD against the pattern the buffer holds (word = f(address): no arithmetic in between),
+//                 (A) runs the FMA chain on four accumulators (the words are small integers as floats, the other factor is 1.0 from a
+//                     broadcast 16-byte LDS read: the sums are exact and known),
+//                 (S) stores the accumulators with one ds_write_b128, reads them back behind a barrier and compares them with the registers.
+//               Every mismatch is reported as [kind L/A/S, block, wave, lane, load j, component, expected, found, HW_ID].
+//   aggressor : 512 threads = two waves per SIMD, 152 VGPRs (the victim compiles to 202 -> 208 allocated; 2 x 152 + 208 = 512: the pair fits a
+//               SIMD as the policy conv's 2 x 168 and the value head's 160 do),
+//               35 KB of LDS, looping ONE kind of work:
+//                 0 v_mfma_f32_16x16x32_f16 back to back     1 ds_read_b128 rows     2 global_load_dwordx4 stream     3 all three interleaved
+//                 4 v_fma_f32 only (control)                 -1 no aggressor
+//
+// usage: neighbour_mfma.bin <kind> [launches] [victim rounds] [aggressor iterations] [blocks]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int ROWS = 512;                       // rows of 256 words x 4 = 1 KiB x 4 waves ... the buffer: [4 waves][ROWS][64 lanes][4 words] (a lane's 32 loads 1 KiB apart, as FC1's)
+__host__ __device__ inline float word_at(uint32_t idx) { return float(int((idx * 2654435761u) >> 27) - 16); }     // integers -16 ... 15
+
+__device__ __forceinline__ void report_one(uint32_t* report, uint32_t* count, uint32_t kind, uint32_t j, uint32_t e, float want, float got) {
+    const uint32_t k = atomicAdd(count, 1u);
+    if (k < 512) {
+        uint32_t* o = report + k * 9;
+        o[0] = kind; o[1] = blockIdx.x; o[2] = threadIdx.x >> 6; o[3] = threadIdx.x & 63; o[4] = j; o[5] = e;
+        o[6] = __builtin_bit_cast(uint32_t, want); o[7] = __builtin_bit_cast(uint32_t, got);
+        o[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+}
+
+__global__ __launch_bounds__(256) void victim(const float* __restrict__ buf, uint32_t* report, uint32_t* count, float* dump, int rounds, int salt) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_flat = lds;                         // [128] ones (the "flattened conv output"), broadcast reads
+    float* s_part = lds + 1024;                  // [4][256]
+    const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
+    if (tid < 128) s_flat[tid] = 1.0f;
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        const int row0 = ((r + salt) * 32) % ROWS;
+        // what the round must see, from the pattern alone (a rolled loop: no registers held across the loads' shadow)
+        uint32_t want_cs[4] = {0u, 0u, 0u, 0u};
+        float want_h[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int j = 0; j < 32; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = word_at(uint32_t((kq * ROWS + row0 + j) * 64 + lane) * 4 + e);
+                want_cs[e] += __builtin_bit_cast(uint32_t, v);
+                want_h[e] += v;
+            }
+        f32x4 h = {0.f, 0.f, 0.f, 0.f};
+        f32x4 w[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            w[j] = *reinterpret_cast<const f32x4*>(buf + ((size_t(kq) * ROWS + row0 + j) * 64 + lane) * 4);
+        // (L) the words as they arrived: sum of their bit patterns per component; a mismatch reports both sums (one wrong word: their difference = found - expected bits, searched on the host)
+        uint32_t cs[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs[e] += __builtin_bit_cast(uint32_t, w[j][e]);
+        if (cs[0] != want_cs[0] || cs[1] != want_cs[1] || cs[2] != want_cs[2] || cs[3] != want_cs[3]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (cs[e] != want_cs[e]) report_one(report, count, 'L', uint32_t(row0), e, __builtin_bit_cast(float, want_cs[e]), __builtin_bit_cast(float, cs[e]));
+        }
+        // (A) the FMA chain of FC1
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 f = *reinterpret_cast<const f32x4*>(s_flat + 4 * q + (r & 3) * 32);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[0] = fmaf(w[4 * q + e][0], f[e], h[0]);
+                h[1] = fmaf(w[4 * q + e][1], f[e], h[1]);
+                h[2] = fmaf(w[4 * q + e][2], f[e], h[2]);
+                h[3] = fmaf(w[4 * q + e][3], f[e], h[3]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (h[e] != want_h[e]) report_one(report, count, 'A', 0, e, want_h[e], h[e]);
+        // (S) through LDS
+        *reinterpret_cast<f32x4*>(s_part + kq * 256 + 4 * lane) = h;
+        __syncthreads();
+        const f32x4 back = *reinterpret_cast<const f32x4*>(s_part + kq * 256 + 4 * lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (__builtin_bit_cast(uint32_t, back[e]) != __builtin_bit_cast(uint32_t, h[e])) report_one(report, count, 'S', 0, e, h[e], back[e]);
+        __syncthreads();
+    }
+}
+
+template <int KIND> __global__ __launch_bounds__(512) void aggressor(const float* __restrict__ buf, float* sink, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    asm volatile("v_mov_b32 v151, 0" ::: "v151");                 // 152 registers: 2 x 152 + the victim's 208 = 512, the two fit one SIMD exactly
+    for (int i = tid; i < 8192; i += 512) lds[i] = 0.001f * float(i & 255);
+    __syncthreads();
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    half8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = _Float16(0.01f * float((lane + i) & 15)); b[i] = _Float16(0.02f * float((lane * 3 + i) & 7)); }
+    f32x4 x = {0.1f, 0.2f, 0.3f, 0.4f};
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (KIND == 0 || KIND == 3) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[u & 3], 0, 0, 0);
+        }
+        if constexpr (KIND == 1 || KIND == 3) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(lds + ((lane * 4 + u * 256 + it * 68) & 8188));
+                x += v;
+            }
+        }
+        if constexpr (KIND == 2 || KIND == 3) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(buf + (size_t((it * 4 + u + blockIdx.x * 7) % ROWS) * 4 * 64 + (tid & 255)) * 4);
+                x += v;
+            }
+        }
+        if constexpr (KIND == 4) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) asm volatile("v_fma_f32 %0, %0, 0.5, 0.5" : "+v"(x[u & 3]));
+        }
+        if constexpr (KIND == 3) { a[it & 7] = _Float16(x[0] * 1e-9f); }
+    }
+    float s = x[0] + x[1] + x[2] + x[3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3];
+    if (s == 123.456f) sink[tid] = s;
+}
+
+int main(int argc, char** argv) {
+    const int kind = argc > 1 ? atoi(argv[1]) : 0, launches = argc > 2 ? atoi(argv[2]) : 2000, rounds = argc > 3 ? atoi(argv[3]) : 8,
+              iters = argc > 4 ? atoi(argv[4]) : 600, blocks = argc > 5 ? atoi(argv[5]) : 64;
+    hipStream_t sv, sa;
+    CHECK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
+    CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    std::vector<float> host(size_t(ROWS) * 4 * 64 * 4);
+    for (size_t i = 0; i < host.size(); ++i) host[i] = word_at(uint32_t(i));
+    float *buf, *sink;
+    uint32_t *report, *count;
+    CHECK(hipMalloc(&buf, host.size() * 4));
+    CHECK(hipMemcpy(buf, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&sink, 4096));
+    CHECK(hipMalloc(&report, 512 * 9 * 4));
+    CHECK(hipMalloc(&count, 8));
+    CHECK(hipMemset(count, 0, 8));
+    float* dump = nullptr;
+    const size_t vlds = 44064, alds = 35 * 1024;
+    for (int l = 0; l < launches; ++l) {
+        hipLaunchKernelGGL(victim, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        switch (kind) {
+            case 0: hipLaunchKernelGGL(aggressor<0>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
+            case 1: hipLaunchKernelGGL(aggressor<1>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
+            case 2: hipLaunchKernelGGL(aggressor<2>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
+            case 3: hipLaunchKernelGGL(aggressor<3>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
+            case 4: hipLaunchKernelGGL(aggressor<4>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
+            default: break;
+        }
+        if ((l & 31) == 31) { CHECK(hipStreamSynchronize(sv)); CHECK(hipStreamSynchronize(sa)); }
+    }
+    CHECK(hipDeviceSynchronize());
+    uint32_t n = 0;
+    std::vector<uint32_t> rep(512 * 9);
+    CHECK(hipMemcpy(&n, count, 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(rep.data(), report, rep.size() * 4, hipMemcpyDeviceToHost));
+    printf("aggressor kind %d: %u mismatches in %d victim launches (%d blocks x 4 waves x %d rounds x 128 loaded words)\n", kind, n, launches, blocks, rounds);
+    for (uint32_t k = 0; k < n && k < 40; ++k) {
+        const uint32_t* o = rep.data() + k * 9;
+        printf("  %c block %u wave %u lane %u load %u word %u: expected %g found %g  hw_id %08x (simd %u cu %u sh %u se %u)\n", char(o[0]), o[1], o[2], o[3], o[4],
+               o[5], double(__builtin_bit_cast(float, o[6])), double(__builtin_bit_cast(float, o[7])), o[8], (o[8] >> 4) & 3, (o[8] >> 8) & 15,
+               (o[8] >> 12) & 1, (o[8] >> 13) & 7);
+    }
+    // (L) reports carry checksums: with ONE wrong word in the lane's 32 loads of that component, found - expected = bits(found word) -
+    // bits(right word); say which load it can have been and whether the found word is what the same register held a round earlier
+    for (uint32_t k = 0; k < n && k < 40; ++k) {
+        const uint32_t* o = rep.data() + k * 9;
+        if (o[0] != 'L') continue;
+        const int kq = int(o[2]), lane = int(o[3]), row0 = int(o[4]), e = int(o[5]);
+        const uint32_t diff = o[7] - o[6];
+        for (int j = 0; j < 32; ++j) {
+            const uint32_t right = __builtin_bit_cast(uint32_t, word_at(uint32_t((kq * ROWS + row0 + j) * 64 + lane) * 4 + e));
+            const float found = __builtin_bit_cast(float, right + diff);
+            if (found == float(int(found)) && found >= -16.f && found <= 15.f) {
+                const int rb = (row0 - 32 + ROWS) % ROWS;
+                const bool stale = word_at(uint32_t((kq * ROWS + rb + j) * 64 + lane) * 4 + e) == found;
+                printf("    report %u: load %d word %d may have held %g instead of %g%s%s\n", k, j, e, double(found), double(__builtin_bit_cast(float, right)),
+                       stale ? "  (= this load's word one round earlier)" : "", found == 0.f ? "  (zero)" : "");
+            }
+        }
+    }
+    return 0;
+}

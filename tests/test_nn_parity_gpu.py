@@ -352,29 +352,28 @@ def test_onnx_model_directory_loads_and_matches_golden(tmp_path, hip_lib, name, 
             assert np.array_equal(v2, value) and np.array_equal(p2, probs)
 
 
-@pytest.mark.parametrize("precision", ["float16x3", "float16"])
-def test_headline_configuration_at_full_size(tmp_path, hip_lib, precision):
-    """BASELINE.json config 2 as bench.py runs it: RISEv2-19, batch 256, Precision float16x3 (the headline: the fast mode that meets
-    north_star's 1e-3 on the logits -- held to 1e-4 here) and Precision float16 (the reference's TensorRT default; its logits miss 1e-3,
-    bound as measured).  Beyond the per-row parity above:
-    rows 0-3 are the committed reference golden's inputs (they must come out as in the 4-board fixture), every row matches the oracle,
-    and the size-independent properties hold: probabilities sum to one, values inside the tanh range, a permuted batch gives the
-    permuted outputs bit for bit (one workgroup per board, no cross-row arithmetic)."""
+def _full_size_case(tmp_path, case, B, precision, version, golden_rows=True):
+    """One BASELINE configuration at the batch size bench.py runs it with.  Rows 0-3 are the committed reference golden's inputs (they
+    must come out as in the 4-board fixture), every row matches the oracle, and the size-independent properties hold: probabilities
+    sum to one, values inside the tanh range, a permuted batch gives the permuted outputs bit for bit (one workgroup per board, no
+    cross-row arithmetic), and a replay of the same batch gives the same bits."""
     from crazyara_amd.neuralnetapi import HipAPI
-    cfg, sd, xg = nn_cases.make_case("risev2-19")
-    B = 256
+    cfg, sd, xg = nn_cases.make_case(case)
     x = nn_cases.synthetic_planes(B, cfg.nb_input_channels, 777).numpy()
-    x[:4] = xg.numpy()
-    d = nn_cases.export_case(tmp_path, "risev2-19", cfg, sd)
+    n_g = xg.shape[0]
+    x[:n_g] = xg.numpy()
+    d = nn_cases.export_case(tmp_path, case, cfg, sd, version=version)
     net = HipAPI(0, B, d, precision, keep_logits=True)
     v, p = np.zeros(B, np.float32), np.zeros(B * cfg.nb_policy, np.float32)
-    net.predict(np.ascontiguousarray(x), v, p)
+    aux = np.zeros(B * 4, np.float32) if cfg.nb_aux else None
+    net.predict(np.ascontiguousarray(x), v, p, aux)
     logits = torch.as_tensor(net.device_buffers()["logits"], device="cuda").cpu().numpy().copy()
     p = p.reshape(B, -1)
-    g = np.load(os.path.join(nn_cases.GOLDEN_DIR, "nn_risev2-19.npz"))
     tol = TOL[precision]
-    assert np.abs(v[:4] - g["value"].reshape(-1)).max() < tol["value"]
-    assert np.abs(logits[:4] - g["logits"]).max() < logit_tol(tol, g["logits"])
+    if golden_rows:
+        g = np.load(os.path.join(nn_cases.GOLDEN_DIR, f"nn_{case}.npz"))
+        assert np.abs(v[:n_g] - g["value"].reshape(-1)).max() < tol["value"]
+        assert np.abs(logits[:n_g] - g["logits"]).max() < logit_tol(tol, g["logits"])
     o_value, o_logits, _ = ro.forward(cfg, sd, torch.from_numpy(x))
     assert np.abs(logits - o_logits.numpy()).max() < logit_tol(tol, o_logits.numpy())     # float16: measured 3.31e-3 (bound 4.2e-3)
     assert np.abs(v - o_value.numpy().reshape(-1)).max() < tol["value"]
@@ -382,12 +381,33 @@ def test_headline_configuration_at_full_size(tmp_path, hip_lib, precision):
     assert np.allclose(p.sum(axis=1), 1.0, atol=1e-4) and (p >= 0).all() and np.abs(v).max() <= 1.0
     perm = np.random.default_rng(5).permutation(B)
     v2, p2 = np.zeros(B, np.float32), np.zeros(B * cfg.nb_policy, np.float32)
-    net.predict(np.ascontiguousarray(x[perm]), v2, p2)
+    net.predict(np.ascontiguousarray(x[perm]), v2, p2, aux)
     assert np.array_equal(v2, v[perm]) and np.array_equal(p2.reshape(B, -1), p[perm])
     v3, p3 = np.zeros(B, np.float32), np.zeros(B * cfg.nb_policy, np.float32)
-    net.predict(np.ascontiguousarray(x[perm]), v3, p3)                    # and replays are deterministic
+    net.predict(np.ascontiguousarray(x[perm]), v3, p3, aux)               # and replays are deterministic
     assert np.array_equal(v3, v2) and np.array_equal(p3, p2)
     net.close()
+
+
+@pytest.mark.parametrize("precision", ["float16p8", "float16x3", "float16"])
+def test_headline_configuration_at_full_size(tmp_path, hip_lib, precision):
+    """BASELINE.json config 2 as bench.py runs it: RISEv2-19, batch 256, in Precision float16p8 (the headline: the fastest mode that
+    meets north_star's 1e-3 on the logits -- held to 3e-4 here), float16x3 (1e-4) and float16 (the reference's TensorRT default; its
+    logits miss 1e-3, bound as measured)."""
+    _full_size_case(tmp_path, "risev2-19", 256, precision, "1.0")
+
+
+@pytest.mark.parametrize("precision", ["float16p8", "float16x3"])
+def test_config3_at_full_size(tmp_path, hip_lib, precision):
+    """BASELINE.json config 3 as bench.py searches it: chess RISEv3.3 (3x3 and 5x5 bottleneck runs in tower launches, eca_se gates), batch 512."""
+    _full_size_case(tmp_path, "risev33", 512, precision, "3.0")
+
+
+@pytest.mark.parametrize("precision", ["float16p8", "float16x3"])
+def test_config5_at_full_size(tmp_path, hip_lib, precision):
+    """BASELINE.json config 5's one-GPU slice as bench.py searches it: RISEv2-13 on the lichess tables (80-channel planes, 5376 policy
+    entries), batch 1024 -- four workgroups per compute unit's worth of boards, i.e. the tower kernel's later waves of workgroups."""
+    _full_size_case(tmp_path, "risev2-13-lichess", 1024, precision, "3.0")
 
 
 @pytest.mark.parametrize("precision", ["float32", "float16", "float16x3"])

@@ -121,35 +121,68 @@ def live_pmc_traffic(kernel: str, blocks: int, batch: int, precision: str, timeo
                     "l2_to_cu_bytes_per_launch": round(out["TCC_HIT_sum"] * 128.0)}}
 
 
-def cpu_baseline(cfg, sd, x, budget_s=15.0):
-    """Reference CPU path timed beside the GPU: the oracle restatement of the reference PyTorch model (same torch ops,
-    fp32, eval, softmax included) on the host cores.  Bounded sample: whole batches of 256 until ~budget_s elapsed."""
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, sd, x, budget_s=20.0):
+    """Reference CPU path timed beside the GPU: the reference's OWN PyTorch module when /root/reference is
+    importable (this container; kind "reference"), else the oracle restatement of it (the GPU box; kind "port": the same torch ops in the
+    same order, pinned to the reference module by tests/golden/nn_*.npz) -- fp32, eval, no_grad, softmax included, on the host cores.
+    As CrazyAra::inference does (crazyara.cpp:156-181) the loop is warmed first (its 100 iterations, bounded here to ~3 s), then timed
+    over >= 5 samples of whole batches; `value` = the MEDIAN sample, the quartiles and the CPU's model string beside it, so that two
+    runs on one box can be told from two boxes."""
+    from crazyara_amd import replicas
     from oracle import rise_oracle as ro
     # measured on the MI355X host (256 logical CPUs): torch CPU inference peaks at 16 threads (8: 183, 16: 474, 32: 374,
     # 64: 198, 128: 80 evals/s on this model) -- more threads oversubscribe the 8x8 convolutions
-    from crazyara_amd import replicas
     cores = min(16, replicas.available_cpus())
     torch.set_num_threads(cores)
-    ro.predict(cfg, sd, x[:32])  # warm-up
-    # three samples of ~budget_s / 3 each: the rate swings by a factor of four between boxes and by tens of percent between samples on
-    # one box (other tenants of the host), so the line carries median / min / max, `value` = the median sample
+    kind, fn = "port", (lambda xb: ro.predict(cfg, sd, xb))
+    if os.path.isdir("/root/reference/DeepCrazyhouse"):
+        try:
+            from oracle import make_golden
+            model = make_golden.reference_model(make_golden.import_reference(), cfg)
+            model.load_state_dict(sd)
+            model.eval()
+
+            def fn(xb, model=model):
+                with torch.no_grad():
+                    out = model(xb)
+                    return out[0], torch.softmax(out[1], 1)
+            kind = "reference"
+        except Exception:  # noqa: BLE001 -- the reference would not import: the port is the baseline, and says so
+            kind = "port"
+    t0, n_warm = time.perf_counter(), 0
+    while n_warm < 100 and time.perf_counter() - t0 < 3.0:
+        fn(x[:64])
+        n_warm += 1
     rates, n_total, el_total = [], 0, 0.0
-    for _ in range(3):
+    per_sample = (budget_s - 3.0) / 5.0
+    while len(rates) < 5 or (el_total < budget_s - 3.0 and len(rates) < 9):
         n, t0 = 0, time.perf_counter()
         while True:
-            ro.predict(cfg, sd, x)
+            fn(x)
             n += x.shape[0]
             el = time.perf_counter() - t0
-            if el > budget_s / 3.0 or n >= 6 * x.shape[0]:
+            if el > per_sample or n >= 8 * x.shape[0]:
                 break
         rates.append(n / el)
         n_total += n
         el_total += el
-    n, el = n_total, el_total
-    out = {"value": round(float(np.median(rates)), 1), "unit": "evals/s", "cores": cores, "kind": "port",
-           "samples_evals_per_sec": [round(r, 1) for r in rates], "value_min": round(min(rates), 1), "value_max": round(max(rates), 1),
-           "sample": f"3 samples, {n} positions in all (batches of {x.shape[0]}) of the same synthetic workload, oracle/rise_oracle.predict "
-                     f"(torch fp32 CPU restatement of the reference RiseV3 module), {el:.1f} s; value = the median sample"}
+    q1, med, q3 = (float(v) for v in np.percentile(rates, [25, 50, 75]))
+    out = {"value": round(med, 1), "unit": "evals/s", "cores": cores, "kind": kind,
+           "value_q1": round(q1, 1), "value_q3": round(q3, 1), "iqr_over_median": round((q3 - q1) / med, 4), "n_samples": len(rates),
+           "samples_evals_per_sec": [round(r, 1) for r in rates], "cpu_model": cpu_model_string(), "warmup_iterations": n_warm,
+           "sample": f"{len(rates)} samples, {n_total} positions (batches of {x.shape[0]}) of the same synthetic workload, "
+                     + ("the reference RiseV3 module (rise_mobile_v3.py)" if kind == "reference" else "oracle/rise_oracle.predict (torch restatement of RiseV3)")
+                     + f", fp32, {cores} threads, {el_total:.1f} s; value = median"}
     out.update(cpu_baseline_mcts(cfg, sd, cores))
     out.update(cpu_baseline_reference_search(cores))
     return out
@@ -432,6 +465,90 @@ def config_game_legs(args, device, threads):
     return out
 
 
+LINE_LIMIT = 6144      # bytes of the ONE stdout line: the driver's record parser lost round 4's 21.7 KB line
+
+
+def compact_record(full, detail_path):
+    """The stdout line from the whole result: the contract's keys, `roofline` (scalars + `pmc` + `per_op_ms`), `cpu_baseline` (scalars)
+    and a flat `summary` of the companion rates; everything else -- per-mode blocks, search / game / drop-in legs, sweeps -- stays in
+    the detail file whose path the line carries.  Pure (no GPU): tests/test_bench_record.py feeds it a canned result."""
+    line = {k: full[k] for k in ("metric", "value", "value_precision", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data", "config") if k in full}
+    rf = full["roofline"]
+    keep = ("bound", "kernel", "launches_per_step", "avg_launch_ms", "achieved", "peak", "unit", "frac", "peak_definition", "traffic",
+            "traffic_unit", "traffic_source", "pmc", "per_op_ms")
+    line["roofline"] = {k: rf[k] for k in keep if k in rf}
+    if "whole_forward" in rf:
+        line["roofline"]["whole_forward_ms"] = rf["whole_forward"]["event_ms_per_step"]
+        line["roofline"]["whole_forward_frac"] = rf["whole_forward"]["frac"]
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "value_q1", "value_q3", "iqr_over_median",
+                                                   "n_samples", "cpu_model", "mcts_nodes_per_sec") if k in cb}
+        ref1 = cb.get("config1_reference_search", {})
+        if "mcts_nodes_per_sec" in ref1:
+            line["cpu_baseline"]["config1_reference_search_nodes_per_sec"] = ref1["mcts_nodes_per_sec"]
+    tr = full.get("timed_region")
+    if tr:
+        line["timed_region"] = {k: tr[k] for k in ("repeats", "ms_per_step_min", "ms_per_step_max") if k in tr}
+    summary = {"nn_evals_per_sec": full["value"], "precision": full.get("value_precision"), "roofline_frac": rf["frac"]}
+    for m_, r_ in full.get("modes", {}).items():
+        summary[f"nn_evals_per_sec_{m_}"] = r_["evals_per_sec"]
+        summary[f"frac_of_peak_{m_}"] = r_["frac"]
+    pcie = full.get("pcie_inclusive")
+    if pcie:
+        summary["pcie_inclusive_one_user"] = pcie["one_net_evals_per_sec"]
+        summary["pcie_inclusive_two_users"] = pcie["two_nets_in_flight_evals_per_sec"]
+    mcts = full.get("mcts")
+    if mcts:
+        summary[f"config2_mcts_nodes_per_sec_{mcts['precision']}"] = mcts["mcts_nodes_per_sec"]
+        summary["config2_batch_fill"] = mcts.get("avg_batch_fill")
+        summary["config2_host_throttled_ms"] = mcts.get("host_cgroup_throttled_ms_during_search")
+        for th_, v_ in mcts.get("nodes_per_sec_by_host_threads", {}).items():
+            summary[f"config2_nodes_per_sec_{th_}_host_threads"] = v_
+        if "predicted_8_gpus" in mcts:
+            summary["predicted_8_gpus_nodes_per_sec"] = mcts["predicted_8_gpus"]["mcts_nodes_per_sec"]
+        if "per_rank_nodes_per_sec" in mcts:
+            summary["per_rank_nodes_per_sec"] = mcts["per_rank_nodes_per_sec"]
+    other = full.get("mcts_other_mode")
+    if other:
+        summary[f"config2_mcts_nodes_per_sec_{other['precision']}"] = other["mcts_nodes_per_sec"]
+    for k_, r_ in (full.get("mcts_configs") or {}).items():
+        summary[f"{k_}_nodes_per_sec"] = r_["mcts_nodes_per_sec"]
+        for kk_, v_ in r_.items():                                   # the same leg with nets of the other mode
+            if kk_.startswith("mcts_nodes_per_sec_"):
+                summary[f"{k_}_nodes_per_sec_{kk_[len('mcts_nodes_per_sec_'):]}"] = v_
+    for k_, r_ in (full.get("game_configs") or {}).items():
+        summary[f"{k_}_nodes_per_sec"] = r_["mcts_nodes_per_sec"]
+        summary[f"{k_}_games_per_min"] = r_["games_per_min"]
+        for kk_, v_ in r_.items():
+            if kk_.startswith("games_per_min_"):
+                summary[f"{k_}_{kk_}"] = v_
+    dropin = full.get("dropin_reference_search")
+    if dropin and "skipped" not in dropin:
+        for k_, r_ in dropin.items():
+            if isinstance(r_, dict) and "config2_mcts_nodes_per_sec" in r_:
+                summary[f"dropin_config2_nodes_per_sec_{k_}"] = r_["config2_mcts_nodes_per_sec"]
+    if cb:
+        summary["cpu_evals_per_sec"] = cb["value"]
+        summary["cpu_cores"] = cb["cores"]
+    summary["bench_seconds"] = full.get("bench_seconds")
+    line["detail"] = detail_path
+    line["summary"] = summary
+    # the line must stay under the limit whatever legs ran: drop the least important summary keys first, then long strings
+    def size():
+        return len(json.dumps(line))
+    for victim in ("dropin_", "frac_of_peak_", "config1_", "config2_one_tree", "benchmark_positions", "config2_nodes_per_sec_"):
+        if size() < LINE_LIMIT:
+            break
+        for k_ in [k_ for k_ in summary if k_.startswith(victim)]:
+            del summary[k_]
+    if size() >= LINE_LIMIT:
+        line["roofline"].pop("per_op_ms", None)
+        line.get("cpu_baseline", {}).pop("sample", None)
+    return line
+
+
 def respawn_one_rank_per_gpu(n):
     """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): become N ranks, one per GPU, by re-executing this
     command under torch.distributed.run -- the same launch line the contract names (rl_loop.py:60: one process per GPU)."""
@@ -504,6 +621,9 @@ def main():
     ap.add_argument("--search-repeats", type=int, default=3)
     ap.add_argument("--no-config-legs", action="store_true", help="skip the search legs of BASELINE configs 1, 3, 4, 5")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the newest committed PMC pass instead of live passes")
+    ap.add_argument("--detail-out", default="bench_detail.json",
+                    help="file that receives the WHOLE result (per-mode blocks, search / game / drop-in legs, sweeps); the stdout line keeps the "
+                         "contract's keys + roofline + cpu_baseline + a flat summary and stays under 6 KB")
     ap.add_argument("--timed-only", action="store_true",
                     help="only the headline's timed region and its per-kernel events: no other modes / PCIe / search / CPU legs, no PMC child "
                          "passes (the command scripts/gpu_round.sh runs under rocprofv3 --kernel-trace --stats, so that the trace holds "
@@ -782,9 +902,8 @@ def main():
                     "avg_launch_ms": round(dom_ms / cnt[dom], 5), "achieved": round(achieved, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "peak_definition": {"float16": "dense f16 MFMA peak", "float32": "exact-f32 MFMA peak",
-                                        "float16x3": "dense f16 MFMA peak / 3: every product is three f16 MFMAs (hi*hi + hi*lo + lo*hi)",
-                                        "float16p8": "dense f16 MFMA peak / 2: a product of the tower's GEMMs costs one f16 MFMA + two e5m2 products "
-                                                     "at the 8-bit peak (5 PFLOP/s dense)"}[args.precision],
+                                        "float16x3": "dense f16 peak / 3 (three f16 MFMAs per product)",
+                                        "float16p8": "dense f16 peak / 2 (one f16 MFMA + two e5m2 products at the 5 PFLOP/s 8-bit peak per product)"}[args.precision],
                     **traffic,
                     "whole_forward": {"event_ms_per_step": round(ev_ms, 4),
                                       "achieved": round(flops_total / (ev_ms * 1e-3) / 1e12, 2),
@@ -864,20 +983,7 @@ def main():
                                         "value_out": args.batch * 4},
                     "fraction_of_value_one_net": round(pcie_rate_1 / value, 4),
                     "fraction_of_value_two_nets": round(pcie_rate_2 / value, 4)}
-        # scalars the driver's record keeps (it stores the scalar fields of `roofline`, the names of the extra keys, and the last 2000
-        # characters of the line): the other half of BASELINE's metric and the companion rates, flat
-        if mcts:
-            roofline["config2_mcts_nodes_per_sec"] = mcts["mcts_nodes_per_sec"]
-            roofline["config2_mcts_precision"] = mcts["precision"]
-        if mcts_headline_mode:
-            roofline[f"config2_mcts_nodes_per_sec_{mcts_headline_mode['precision']}"] = mcts_headline_mode["mcts_nodes_per_sec"]
-        if pcie:
-            roofline["pcie_inclusive_one_user_evals_per_sec"] = pcie["one_net_evals_per_sec"]
-            roofline["pcie_inclusive_two_users_evals_per_sec"] = pcie["two_nets_in_flight_evals_per_sec"]
-        for m_, r_ in modes.items():
-            roofline[f"{m_}_evals_per_sec"] = r_["evals_per_sec"]
-            roofline[f"{m_}_frac_of_its_peak"] = r_["frac"]
-        out = {
+        full = {
             "metric": "nn_evals_per_sec", "value": round(value, 1), "value_precision": args.precision, "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -894,67 +1000,28 @@ def main():
             "roofline": roofline,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, x)
+            full["cpu_baseline"] = cpu_baseline(cfg, sd, x)
         if pcie is not None:
             # SURVEY 8(d) Metric 1 is CrazyAra's `inference` loop INCLUDING the host copies (crazyara.cpp:156-181): one blocking user
-            out["value_pcie_inclusive"] = round(pcie_rate_1, 1)
-            out["value_pcie_inclusive_two_users"] = round(pcie_rate_2, 1)
-            out["pcie_inclusive_evals_per_sec"] = round(pcie_rate_1, 1)
-            out["pcie_inclusive"] = pcie
-        if "float16" in modes:                                           # the reference's default mode beside the headline (flat scalar)
-            out["value_float16"] = modes["float16"]["evals_per_sec"]
-        if mcts:
-            out["config2_mcts_nodes_per_sec"] = mcts["mcts_nodes_per_sec"]
-            out["config2_mcts_precision"] = mcts["precision"]
-        if mcts_headline_mode:
-            out[f"config2_mcts_nodes_per_sec_{mcts_headline_mode['precision']}"] = mcts_headline_mode["mcts_nodes_per_sec"]
+            full["pcie_inclusive"] = pcie
+        full["modes"] = modes
         if dropin is not None:
-            out["dropin_reference_search"] = dropin
-        for m_, r_ in modes.items():
-            out[m_] = r_
+            full["dropin_reference_search"] = dropin
         if mcts_configs:
-            out["mcts_configs"] = mcts_configs
+            full["mcts_configs"] = mcts_configs
         if game_configs:
-            out["game_configs"] = game_configs
+            full["game_configs"] = game_configs
         if mcts:
-            out["mcts"] = mcts
+            full["mcts"] = mcts
         if mcts_headline_mode:
-            out["mcts_other_mode"] = mcts_headline_mode
-        # LAST key: every rate of the run as flat scalars (the tail of the line is what a truncating log keeps)
-        summary = {"nn_evals_per_sec": round(value, 1), "precision": args.precision, "roofline_frac": roofline["frac"]}
-        for m_, r_ in modes.items():
-            summary[f"nn_evals_per_sec_{m_}"] = r_["evals_per_sec"]
-            summary[f"frac_of_peak_{m_}"] = r_["frac"]
-        if pcie:
-            summary["pcie_inclusive_one_user"] = pcie["one_net_evals_per_sec"]
-            summary["pcie_inclusive_two_users"] = pcie["two_nets_in_flight_evals_per_sec"]
-        if mcts:
-            summary[f"config2_mcts_nodes_per_sec_{mcts['precision']}"] = mcts["mcts_nodes_per_sec"]
-            summary["config2_host_throttled_ms"] = mcts.get("host_cgroup_throttled_ms_during_search")
-            for th_, v_ in mcts.get("nodes_per_sec_by_host_threads", {}).items():
-                summary[f"config2_mcts_nodes_per_sec_{th_}_host_threads"] = v_
-        if mcts_headline_mode:
-            summary[f"config2_mcts_nodes_per_sec_{mcts_headline_mode['precision']}"] = mcts_headline_mode["mcts_nodes_per_sec"]
-        for k_, r_ in (mcts_configs or {}).items():
-            summary[f"{k_}_nodes_per_sec"] = r_["mcts_nodes_per_sec"]
-            for kk_, v_ in r_.items():                                   # the same leg with nets of the other mode
-                if kk_.startswith("mcts_nodes_per_sec_"):
-                    summary[f"{k_}_nodes_per_sec_{kk_[len('mcts_nodes_per_sec_'):]}"] = v_
-        for k_, r_ in (game_configs or {}).items():
-            summary[f"{k_}_nodes_per_sec"] = r_["mcts_nodes_per_sec"]
-            summary[f"{k_}_games_per_min"] = r_["games_per_min"]
-            for kk_, v_ in r_.items():
-                if kk_.startswith("games_per_min_"):
-                    summary[f"{k_}_{kk_}"] = v_
-        if dropin and "skipped" not in dropin:
-            for k_, r_ in dropin.items():
-                if isinstance(r_, dict):
-                    summary[f"dropin_config2_nodes_per_sec_{k_}"] = r_["config2_mcts_nodes_per_sec"]
-        if "cpu_baseline" in out:
-            summary["cpu_evals_per_sec"] = out["cpu_baseline"]["value"]
-            summary["cpu_cores"] = out["cpu_baseline"]["cores"]
-        summary["bench_seconds"] = round(time.perf_counter() - t_bench_start, 1)
-        out["summary"] = summary
+            full["mcts_other_mode"] = mcts_headline_mode
+        full["bench_seconds"] = round(time.perf_counter() - t_bench_start, 1)
+        out = compact_record(full, args.detail_out)
+        try:
+            with open(args.detail_out, "w") as f:
+                json.dump(full, f, indent=1)
+        except OSError as e:
+            out["detail"] = f"not written: {e}"
     net.close()
     if dist is not None:
         dist.barrier()

@@ -379,7 +379,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
 // behind the barrier, (2) the SAME sums stored to global memory straight from the accumulator registers, never through LDS, (3) integer
 // checksums of the 16-byte weight loads per lane and component (sum of the loaded words' bit patterns) -- so that a differing launch says
 // whether the loaded words, the accumulator register or only its way through LDS was wrong.
-template <typename T, bool PROBE = false>
+//
+// SCALAR_FMA: FC1's products as four v_fmac_f32 per weight row instead of the two v_pk_fma_f32 the compiler makes of them (round 5's
+// root-cause experiment, profiles/NOTES.md: the words that came out wrong were always the LOW halves of v_pk_fma_f32 results).
+template <typename T, bool PROBE = false, bool SCALAR_FMA = false>
 __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int CH = a.C / 2;                                    // the board is staged in two halves of its channels (LDS stays below 64 KiB)
@@ -516,17 +519,28 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
 #pragma unroll
                 for (int j = 0; j < 32; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) cs[e] += __builtin_bit_cast(uint32_t, w[j][e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float we = w[j][e];          // (bit_cast straight on the vector element reads element 0: round 5's first probe)
+                        cs[e] += __builtin_bit_cast(uint32_t, we);
+                    }
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const f32x4 f = *reinterpret_cast<const f32x4*>(fl + i + 4 * q);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    h[0] = fmaf(w[4 * q + e][0], f[e], h[0]);
-                    h[1] = fmaf(w[4 * q + e][1], f[e], h[1]);
-                    h[2] = fmaf(w[4 * q + e][2], f[e], h[2]);
-                    h[3] = fmaf(w[4 * q + e][3], f[e], h[3]);
+                    if constexpr (SCALAR_FMA) {
+                        float h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3];
+                        const float w0 = w[4 * q + e][0], w1 = w[4 * q + e][1], w2 = w[4 * q + e][2], w3 = w[4 * q + e][3], fe = f[e];
+                        asm volatile("v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %8\n\tv_fmac_f32 %2, %6, %8\n\tv_fmac_f32 %3, %7, %8"
+                                     : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(fe));
+                        h = f32x4{h0, h1, h2, h3};
+                    } else {
+                        h[0] = fmaf(w[4 * q + e][0], f[e], h[0]);
+                        h[1] = fmaf(w[4 * q + e][1], f[e], h[1]);
+                        h[2] = fmaf(w[4 * q + e][2], f[e], h[2]);
+                        h[3] = fmaf(w[4 * q + e][3], f[e], h[3]);
+                    }
                     if (a.variant & 2) asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
                 }
             }
@@ -629,6 +643,13 @@ static size_t value_head_lds_bytes(const ValueHeadArgs& a) {
     if (a.lds_pad < 0) return used;                              // development: the kernel as it was (shares compute units)
     return std::max(used + size_t(a.lds_pad), kValueHeadExclusiveLds);
 }
+template <typename T> const void* value_head_function(const ValueHeadArgs& a) {        // the instantiation launch_value_head picks
+    const bool probe = a.dbg && (a.variant & 16), scalar = (a.variant & 32) != 0;
+    if (probe && scalar) return reinterpret_cast<const void*>(&value_head_kernel<T, true, true>);
+    if (probe) return reinterpret_cast<const void*>(&value_head_kernel<T, true, false>);
+    if (scalar) return reinterpret_cast<const void*>(&value_head_kernel<T, false, true>);
+    return reinterpret_cast<const void*>(&value_head_kernel<T, false, false>);
+}
 // once per net, outside any stream capture: the kernel's dynamic LDS allowance (the staged board is more than the default 64 KiB)
 template <typename T> void prepare_value_head(const ValueHeadArgs& a) {
     if (a.C % 16 != 0 || a.cv > 16 || (!a.wwdl && a.fc % 4 != 0)) throw std::runtime_error("value head: channels must be a multiple of 16, value channels at most 16, FC width a multiple of 4");
@@ -637,17 +658,18 @@ template <typename T> void prepare_value_head(const ValueHeadArgs& a) {
     // per net build, like the other kernels' allowances: the attribute belongs to the current DEVICE's copy of the function, so a
     // remembered process-wide maximum would leave the second device of a First/Last_Device_ID range at the default 64 KiB
     if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_head_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(shmem));
-        if (e == hipSuccess && a.dbg && (a.variant & 16))
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_head_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(shmem));
+        hipError_t e = hipFuncSetAttribute(value_head_function<T>(a), hipFuncAttributeMaxDynamicSharedMemorySize, int(shmem));
         if (e != hipSuccess) throw std::runtime_error(std::string("value head: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
     }
 }
 template void prepare_value_head<half_t>(const ValueHeadArgs&);
 template void prepare_value_head<float>(const ValueHeadArgs&);
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s) {
-    if (a.dbg && (a.variant & 16)) hipLaunchKernelGGL((value_head_kernel<T, true>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
-    else hipLaunchKernelGGL((value_head_kernel<T>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
+    const bool probe = a.dbg && (a.variant & 16), scalar = (a.variant & 32) != 0;
+    if (probe && scalar) hipLaunchKernelGGL((value_head_kernel<T, true, true>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
+    else if (probe) hipLaunchKernelGGL((value_head_kernel<T, true, false>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
+    else if (scalar) hipLaunchKernelGGL((value_head_kernel<T, false, true>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
+    else hipLaunchKernelGGL((value_head_kernel<T, false, false>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
 }
 template void launch_value_head<half_t>(const ValueHeadArgs&, hipStream_t);
 template void launch_value_head<float>(const ValueHeadArgs&, hipStream_t);

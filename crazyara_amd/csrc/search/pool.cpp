@@ -423,15 +423,16 @@ void SearchPool::evaluate_roots(uint64_t* evals, uint64_t* batches) {
     *evals += todo.size();
 }
 
+uint64_t SearchPool::open_generation() {
+    std::lock_guard<std::mutex> g(gen_mu_);
+    if (adopted_gen_ < go_gen_) return ++adopted_gen_;            // an announced go nobody has run yet (a stop sent since names it already)
+    adopted_gen_ = ++go_gen_;
+    return adopted_gen_;
+}
+
 void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats, uint32_t movetime_ms) {
     // this run's generation: the announced one (a stop sent since the announcement already names it) or a new one
-    const uint64_t my_gen = state_.load(std::memory_order_acquire) == 1 ? go_gen_.load(std::memory_order_acquire)
-                                                                        : go_gen_.fetch_add(1, std::memory_order_acq_rel) + 1;
-    state_.store(2, std::memory_order_release);
-    struct Idle {                                                  // whichever way the run ends: no search announced or running
-        std::atomic<int>& s;
-        ~Idle() { s.store(0, std::memory_order_release); }
-    } idle_at_exit{state_};
+    const uint64_t my_gen = open_generation();
     if (!simulations && !nodes && !movetime_ms) throw std::invalid_argument("run needs a simulations, a nodes or a movetime limit");
     if (!workers_ || workers_->threads() != std::max(1, threads)) workers_.reset(new WorkerPool(std::max(1, threads)));
     WorkerPool& workers = *workers_;
@@ -461,7 +462,7 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
     const auto deadline = t0 + std::chrono::milliseconds(movetime_ms);
     std::atomic<bool> time_up_flag{false};
     auto halted = [&]() {                                           // request_stop() or the movetime: every tree is "done"
-        if (stop_gen_.load(std::memory_order_acquire) == my_gen) return true;
+        if (stop_gen_.load(std::memory_order_acquire) >= my_gen) return true;
         if (time_up_flag.load(std::memory_order_relaxed)) return true;
         if (movetime_ms && std::chrono::steady_clock::now() >= deadline) {
             time_up_flag.store(true, std::memory_order_relaxed);

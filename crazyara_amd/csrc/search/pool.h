@@ -2,7 +2,6 @@
 #pragma once
 #include <atomic>
 #include <exception>
-#include <mutex>
 #include <string>
 #include <functional>
 #include <memory>
@@ -96,16 +95,20 @@ public:
     void run(uint32_t simulations, uint32_t nodes, int threads, SearchStats* stats, uint32_t movetime_ms = 0);
     // Stop protocol (SearchThread::stop, searchthread.cpp:109-112; MCTSAgent::stop, mctsagent.cpp:364-373).  Every search has a
     // generation number.  announce_go() -- called by the thread that decides to search, BEFORE it hands run() to another thread --
-    // opens the next generation; run() adopts an announced generation (or opens one itself); request_stop() from any thread names
-    // the generation that is announced or running, and the run of that generation ends as if its limits had been reached, also
-    // when it has not entered run() yet: a stop is sticky for its search and never reaches a later one.  With nothing announced or
-    // running a stop does nothing (MCTSAgent::stop: `if (!isRunning) return`).
+    // opens the next generation; run() adopts the oldest announced generation that no run has taken yet (or opens one itself);
+    // request_stop() from any thread stops EVERY generation announced or running at that moment (stop_gen_ = the newest one; a run
+    // ends as if its limits had been reached when stop_gen_ >= its generation), also a search that has not entered run() yet: a stop is
+    // sticky for its search and never reaches a later one.  There is no shared "state" word to lose: searches may overlap at the
+    // protocol level -- UCI `stop` followed directly by `go` (or ponderhit) announces the next go while the previous run() is still
+    // returning; that run's exit touches nothing the announcement or a later stop depends on (round 4's version stored "idle" over it).
+    // With nothing announced or running a stop names only generations that are over (MCTSAgent::stop: `if (!isRunning) return`).
     void announce_go() {
-        go_gen_.fetch_add(1, std::memory_order_acq_rel);
-        state_.store(1, std::memory_order_release);
+        std::lock_guard<std::mutex> g(gen_mu_);
+        ++go_gen_;
     }
     void request_stop() {
-        if (state_.load(std::memory_order_acquire) != 0) stop_gen_.store(go_gen_.load(std::memory_order_acquire), std::memory_order_release);
+        std::lock_guard<std::mutex> g(gen_mu_);
+        stop_gen_.store(go_gen_, std::memory_order_release);          // go_gen_ only grows: so does stop_gen_
     }
     // evaluates the roots that have no network result yet (new games, restarted trees) through the first lane, as run() does first;
     // a game loop reads the raw policy of fresh positions from the root priors this leaves (RawNetAgent::evaluate_board_state)
@@ -172,8 +175,10 @@ private:
     std::vector<Item> items_;
     int shared_k_ = 0;
     int adaptive_cap_ = 0;
-    std::atomic<uint64_t> go_gen_{0}, stop_gen_{0};      // stop protocol: the generation announced / running, the generation told to stop
-    std::atomic<int> state_{0};                          // 0 idle, 1 a go is announced, 2 running
+    std::mutex gen_mu_;                                  // stop protocol (above): guards go_gen_ / adopted_gen_; never taken on the search's hot path
+    uint64_t go_gen_ = 0, adopted_gen_ = 0;              // the newest generation announced or opened; the newest one a run() has taken
+    std::atomic<uint64_t> stop_gen_{0};                  // every generation <= this one has been told to stop
+    uint64_t open_generation();                          // run(): the oldest announced generation no run has taken, or a new one
     SearchSettings s_;
     int layout_;
     std::vector<std::unique_ptr<Tree>> trees_;

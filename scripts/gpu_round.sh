@@ -64,10 +64,13 @@ run_set() {
       timeout 900 python scripts/coresidency_screen.py --launches ${SCREEN_LAUNCHES:-1000} --out $OUT/screen_unfenced.json > $OUT/screen_unfenced.txt 2>&1; grep -E "RED|RESULT|Error|error" $OUT/screen_unfenced.txt | head -40
       [ -n "$SCREEN_SKIP_FENCED" ] || timeout 900 python scripts/coresidency_screen.py --fenced --launches ${SCREEN_LAUNCHES:-1000} --out $OUT/screen_fenced.json > $OUT/screen_fenced.txt 2>&1; grep -E "RED|RESULT|Error|error" $OUT/screen_fenced.txt | head -40 ;;
     rootcause)
-      timeout 400 python scripts/value_head_rootcause.py 20000 64 risev2-3 > $OUT/rootcause_probe.txt 2>&1; tail -40 $OUT/rootcause_probe.txt
-      for kind in -1 0 1 2 3 4; do timeout 120 scripts/ubench/neighbour_mfma.bin $kind 3000 8 600 64 >> $OUT/neighbour_mfma.txt 2>&1; done
-      for kind in 0 3; do timeout 120 scripts/ubench/neighbour_mfma.bin $kind 3000 8 600 256 >> $OUT/neighbour_mfma.txt 2>&1; done
-      cat $OUT/neighbour_mfma.txt | head -60 ;;
+      timeout 300 python scripts/value_head_rootcause.py 10000 64 risev2-3 > $OUT/rootcause_probe_packed.txt 2>&1; grep -E "differ|regions|RESULT" $OUT/rootcause_probe_packed.txt | head -8
+      ROOTCAUSE_EXTRA_VARIANT=32 timeout 300 python scripts/value_head_rootcause.py 10000 64 risev2-3 > $OUT/rootcause_probe_scalar.txt 2>&1; grep -E "differ|regions|RESULT" $OUT/rootcause_probe_scalar.txt | head -8
+      rm -f $OUT/neighbour_mfma.txt
+      for form in 0 1 2; do for kind in -1 0 4; do timeout 120 scripts/ubench/neighbour_mfma.bin $kind 3000 8 600 64 $form >> $OUT/neighbour_mfma.txt 2>&1; done; done
+      for kind in 1 2 3; do timeout 120 scripts/ubench/neighbour_mfma.bin $kind 3000 8 600 64 0 >> $OUT/neighbour_mfma.txt 2>&1; done
+      timeout 120 scripts/ubench/neighbour_mfma.bin 0 3000 8 600 256 0 >> $OUT/neighbour_mfma.txt 2>&1
+      grep -E "^victim form|^  [LAS] " $OUT/neighbour_mfma.txt | cut -c1-200 | awk '/^victim/{n=0} {if (n<4) print; n++}' ;;
     round)
       for s in tests smoke bench trace pmc; do run_set $s; done ;;
     *) echo "unknown set $1" ;;

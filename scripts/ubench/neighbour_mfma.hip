@@ -16,7 +16,7 @@
 //                 0 v_mfma_f32_16x16x32_f16 back to back     1 ds_read_b128 rows     2 global_load_dwordx4 stream     3 all three interleaved
 //                 4 v_fma_f32 only (control)                 -1 no aggressor
 //
-// usage: neighbour_mfma.bin <kind> [launches] [victim rounds] [aggressor iterations] [blocks]
+// usage: neighbour_mfma.bin <kind> [launches] [victim rounds] [aggressor iterations] [blocks] [victim form 0|1|2]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -41,7 +41,9 @@ __device__ __forceinline__ void report_one(uint32_t* report, uint32_t* count, ui
     }
 }
 
-__global__ __launch_bounds__(256) void victim(const float* __restrict__ buf, uint32_t* report, uint32_t* count, float* dump, int rounds, int salt) {
+// VK: 0 = the FMA chain as the compiler writes it (two v_pk_fma_f32 per weight row), 1 = four v_fmac_f32 (inline asm), 2 = the packed chain on
+// words made in registers (no loads in the round at all)
+template <int VK> __global__ __launch_bounds__(256) void victim(const float* __restrict__ buf, uint32_t* report, uint32_t* count, float* dump, int rounds, int salt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* s_flat = lds;                         // [128] ones (the "flattened conv output"), broadcast reads
     float* s_part = lds + 1024;                  // [4][256]
@@ -65,14 +67,23 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ buf, uin
         f32x4 h = {0.f, 0.f, 0.f, 0.f};
         f32x4 w[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j)
-            w[j] = *reinterpret_cast<const f32x4*>(buf + ((size_t(kq) * ROWS + row0 + j) * 64 + lane) * 4);
+        for (int j = 0; j < 32; ++j) {
+            if constexpr (VK == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[j][e] = word_at(uint32_t((kq * ROWS + row0 + j) * 64 + lane) * 4 + e);
+            } else {
+                w[j] = *reinterpret_cast<const f32x4*>(buf + ((size_t(kq) * ROWS + row0 + j) * 64 + lane) * 4);
+            }
+        }
         // (L) the words as they arrived: sum of their bit patterns per component; a mismatch reports both sums (one wrong word: their difference = found - expected bits, searched on the host)
         uint32_t cs[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < 32; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cs[e] += __builtin_bit_cast(uint32_t, w[j][e]);
+            for (int e = 0; e < 4; ++e) {
+                const float we = w[j][e];                       // (bit_cast straight on a vector element reads element 0)
+                cs[e] += __builtin_bit_cast(uint32_t, we);
+            }
         if (cs[0] != want_cs[0] || cs[1] != want_cs[1] || cs[2] != want_cs[2] || cs[3] != want_cs[3]) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -84,10 +95,18 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ buf, uin
             const f32x4 f = *reinterpret_cast<const f32x4*>(s_flat + 4 * q + (r & 3) * 32);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                h[0] = fmaf(w[4 * q + e][0], f[e], h[0]);
-                h[1] = fmaf(w[4 * q + e][1], f[e], h[1]);
-                h[2] = fmaf(w[4 * q + e][2], f[e], h[2]);
-                h[3] = fmaf(w[4 * q + e][3], f[e], h[3]);
+                if constexpr (VK == 1) {
+                    float h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3];
+                    const float w0 = w[4 * q + e][0], w1 = w[4 * q + e][1], w2 = w[4 * q + e][2], w3 = w[4 * q + e][3], fe = f[e];
+                    asm volatile("v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %8\n\tv_fmac_f32 %2, %6, %8\n\tv_fmac_f32 %3, %7, %8"
+                                 : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(fe));
+                    h = f32x4{h0, h1, h2, h3};
+                } else {
+                    h[0] = fmaf(w[4 * q + e][0], f[e], h[0]);
+                    h[1] = fmaf(w[4 * q + e][1], f[e], h[1]);
+                    h[2] = fmaf(w[4 * q + e][2], f[e], h[2]);
+                    h[3] = fmaf(w[4 * q + e][3], f[e], h[3]);
+                }
             }
         }
 #pragma unroll
@@ -148,7 +167,7 @@ template <int KIND> __global__ __launch_bounds__(512) void aggressor(const float
 
 int main(int argc, char** argv) {
     const int kind = argc > 1 ? atoi(argv[1]) : 0, launches = argc > 2 ? atoi(argv[2]) : 2000, rounds = argc > 3 ? atoi(argv[3]) : 8,
-              iters = argc > 4 ? atoi(argv[4]) : 600, blocks = argc > 5 ? atoi(argv[5]) : 64;
+              iters = argc > 4 ? atoi(argv[4]) : 600, blocks = argc > 5 ? atoi(argv[5]) : 64, vk = argc > 6 ? atoi(argv[6]) : 0;
     hipStream_t sv, sa;
     CHECK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
     CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
@@ -165,7 +184,9 @@ int main(int argc, char** argv) {
     float* dump = nullptr;
     const size_t vlds = 44064, alds = 35 * 1024;
     for (int l = 0; l < launches; ++l) {
-        hipLaunchKernelGGL(victim, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        if (vk == 1) hipLaunchKernelGGL(victim<1>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        else if (vk == 2) hipLaunchKernelGGL(victim<2>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        else hipLaunchKernelGGL(victim<0>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         switch (kind) {
             case 0: hipLaunchKernelGGL(aggressor<0>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
             case 1: hipLaunchKernelGGL(aggressor<1>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
@@ -181,7 +202,7 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> rep(512 * 9);
     CHECK(hipMemcpy(&n, count, 4, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(rep.data(), report, rep.size() * 4, hipMemcpyDeviceToHost));
-    printf("aggressor kind %d: %u mismatches in %d victim launches (%d blocks x 4 waves x %d rounds x 128 loaded words)\n", kind, n, launches, blocks, rounds);
+    printf("victim form %d (0 packed FMAs, 1 v_fmac_f32, 2 packed on register-made words), aggressor kind %d: %u mismatches in %d victim launches (%d blocks x 4 waves x %d rounds x 128 loaded words)\n", vk, kind, n, launches, blocks, rounds);
     for (uint32_t k = 0; k < n && k < 40; ++k) {
         const uint32_t* o = rep.data() + k * 9;
         printf("  %c block %u wave %u lane %u load %u word %u: expected %g found %g  hw_id %08x (simd %u cu %u sh %u se %u)\n", char(o[0]), o[1], o[2], o[3], o[4],

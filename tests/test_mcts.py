@@ -797,6 +797,42 @@ def test_stop_from_another_thread_ends_the_run(hip_lib):
     pool.close()
 
 
+def test_go_announced_before_the_previous_run_returned_keeps_its_stop(hip_lib):
+    """UCI `stop` followed directly by `go` (or ponderhit) without joining the search thread: the next go is announced while the
+    previous run() is still on its way out.  Round 4's protocol kept one shared state word that the old run's exit reset, which wiped
+    the announcement and let a stop for the NEW search get lost; generations have no such word.  Here: search 1 runs, is
+    stopped, search 2 is announced and stopped before search 1's run() has returned -- search 2 must end at once when it is entered, and
+    search 3 must run to its limit."""
+    import threading
+    import time
+    nbp = NB_POLICY[0]
+    st = search.default_settings(mode=0, version_major=1, batch_size=8)
+    pool = search.SearchPool(st, eval_fn=_slow_eval(nbp, 0.05), fn_batch=8, fn_nb_policy=nbp)       # 50 ms per batch: a slow exit
+    t = pool.add_position("", False, "crazyhouse")
+    result = {}
+
+    def first():
+        result["s1"] = pool.run(simulations=50_000_000, threads=1)
+    pool.announce_go()
+    th = threading.Thread(target=first)
+    th.start()
+    time.sleep(0.3)                                                    # search 1 is inside run(), a batch in flight
+    pool.stop()                                                        # names search 1
+    pool.announce_go()                                                 # `go`: search 2, announced while run 1 has not returned yet
+    pool.stop()                                                        # ... and stopped again before anybody entered run() for it
+    th.join(timeout=10)
+    assert not th.is_alive()
+    v1 = pool.tree_info(t)["root_visits"]
+    t0 = time.time()
+    s2 = pool.run(simulations=50_000_000, threads=1)                   # adopts search 2: already stopped
+    assert time.time() - t0 < 2.0 and s2.simulations < 64
+    assert pool.tree_info(t)["root_visits"] - v1 < 64
+    s3 = pool.run(simulations=v1 + 300, threads=1)                     # search 3 was never stopped
+    assert pool.tree_info(t)["root_visits"] >= v1 + 300 and s3.simulations > 100
+    _check_tree_invariants(pool.tree_dump(t))
+    pool.close()
+
+
 def test_stop_sent_before_the_search_thread_entered_run_is_not_lost(hip_lib):
     """The reference's stop is sticky (SearchThread::stop sets isRunning = false, searchthread.cpp:109-112; the search loop tests it
     before every mini-batch): `go` announces the search on the commanding thread (mi_search_announce_go), a `stop` that arrives before

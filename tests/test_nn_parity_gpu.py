@@ -375,7 +375,17 @@ def _full_size_case(tmp_path, case, B, precision, version, golden_rows=True):
         assert np.abs(v[:n_g] - g["value"].reshape(-1)).max() < tol["value"]
         assert np.abs(logits[:n_g] - g["logits"]).max() < logit_tol(tol, g["logits"])
     o_value, o_logits, _ = ro.forward(cfg, sd, torch.from_numpy(x))
-    assert np.abs(logits - o_logits.numpy()).max() < logit_tol(tol, o_logits.numpy())     # float16: measured 3.31e-3 (bound 4.2e-3)
+    err_rows = np.abs(logits - o_logits.numpy()).max(axis=1)
+    if precision == "float16p8":
+        # The 3e-4 of the 4-board fixtures is not the mode's bound over millions of logits: the worst of config 5's 1024 x 5376 measured
+        # 5.3e-4 (round 5, still inside north_star's 1e-3).  That this is the MODE (oracle.forward_p8, the definition) and not the kernel
+        # is checked on the worst rows: there the kernel must sit within 1e-4 of its definition.
+        assert err_rows.max() < 7e-4, err_rows.max()
+        worst = np.argsort(err_rows)[-6:]
+        _, e_logits, _ = ro.forward_p8(cfg, sd, torch.from_numpy(x[worst]))
+        assert np.abs(logits[worst] - e_logits.numpy()).max() < 1e-4
+    else:
+        assert err_rows.max() < logit_tol(tol, o_logits.numpy())                           # float16: measured 3.31e-3 (bound 4.2e-3)
     assert np.abs(v - o_value.numpy().reshape(-1)).max() < tol["value"]
     assert np.abs(p - torch.softmax(o_logits, 1).numpy()).max() < tol["prob"]
     assert np.allclose(p.sum(axis=1), 1.0, atol=1e-4) and (p >= 0).all() and np.abs(v).max() <= 1.0

@@ -971,10 +971,13 @@ def main():
             net_b = HipAPI(local_rank, args.batch, tmp, args.precision)
             pcie_rate_1, zc1 = pcie_rate([net])
             pcie_rate_2, zc2 = pcie_rate([net, net_b])
-            os.environ["CRA_PREDICT_COPY"] = "1"
-            pcie_copy_1, _ = pcie_rate([net])
-            pcie_copy_2, _ = pcie_rate([net, net_b])
+            os.environ["CRA_PREDICT_COPY"] = "1"                 # read when a net is made: the copy path runs on nets of its own
+            net_c, net_d = HipAPI(local_rank, args.batch, tmp, args.precision), HipAPI(local_rank, args.batch, tmp, args.precision)
             del os.environ["CRA_PREDICT_COPY"]
+            pcie_copy_1, _ = pcie_rate([net_c])
+            pcie_copy_2, _ = pcie_rate([net_c, net_d])
+            net_c.close()
+            net_d.close()
             net_b.close()
             pcie = {"one_net_evals_per_sec": round(pcie_rate_1, 1), "two_nets_in_flight_evals_per_sec": round(pcie_rate_2, 1),
                     "zero_copy": bool(zc1 and zc2), "copy_path_one_net_evals_per_sec": round(pcie_copy_1, 1),

@@ -115,6 +115,7 @@ struct X3TowerArgs {
     int batch;
     int p8;               // Precision float16p8 (tower_p8_kernel)
     int ks;               // float16p8: the depthwise size of every block of the run, 3 or 5 (0 = 3); a gated FIRST block has its gate computed in the launch
+    int symmetric;        // development (CRA_X3_TOWER=symmetric when the net was made): float16x3's 3x3 runs on tower_x3_kernel, every wave all three phases
 };
 void launch_tower_x3(const X3TowerArgs& a, hipStream_t s);
 template <typename T> void init_block_kernel_attributes();

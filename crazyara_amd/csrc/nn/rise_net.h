@@ -116,6 +116,19 @@ private:
     void capture();
     bool buffers_are_pinned(const float* in_planes, float* value, float* probs, float* aux);
     bool last_zero_copy_ = false;
+    // Development switches: read from the environment ONCE, when the net is constructed -- never on the per-batch path,
+    // where several lane threads would otherwise scan `environ` per kernel launch beside a host program that may call setenv.
+    struct DevSwitches {
+        int conv_dev = -1;              // CRA_X3_CONV_DEV: bisecting switches of conv_gemm_x3_kernel
+        bool device_graph = false;      // CRA_DEVICE_GRAPH: replay the graph also for a one-launch forward
+        bool lane_graph = false;        // CRA_LANE_GRAPH: the lane step replays the graph
+        bool lane_no_graph = false;     // CRA_LANE_NO_GRAPH: the lane step never replays the graph
+        bool predict_copy = false;      // CRA_PREDICT_COPY: predict() stages through device buffers also for pinned caller buffers
+        char lane_launches = 0;         // CRA_LANE_LAUNCHES: '1' / '2' / '3' force the shape of the lane step
+        bool lane_sync = false;         // CRA_LANE_SYNC: a stream sync between forward and gather
+        bool x3_symmetric = false;      // CRA_X3_TOWER=symmetric: the float16x3 tower with every wave running all three phases
+        DevSwitches();
+    } dev_;
     float* value_head_dbg_ = nullptr;
     bool keep_logits_ = false;   // the one-launch head also writes policy_out (pre-softmax) to d_logits() (parity tests); nets whose heads
                                  // run as separate launches always have it there (the softmax launch reads it)

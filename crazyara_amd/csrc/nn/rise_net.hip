@@ -269,6 +269,17 @@ struct RiseNet::Impl {
     }
 };
 
+RiseNet::DevSwitches::DevSwitches() {
+    if (const char* e = getenv("CRA_X3_CONV_DEV")) conv_dev = atoi(e);
+    device_graph = getenv("CRA_DEVICE_GRAPH") != nullptr;
+    lane_graph = getenv("CRA_LANE_GRAPH") != nullptr;
+    lane_no_graph = getenv("CRA_LANE_NO_GRAPH") != nullptr;
+    predict_copy = getenv("CRA_PREDICT_COPY") != nullptr;
+    if (const char* e = getenv("CRA_LANE_LAUNCHES")) lane_launches = e[0];
+    lane_sync = getenv("CRA_LANE_SYNC") != nullptr;
+    if (const char* e = getenv("CRA_X3_TOWER")) x3_symmetric = e[0] == 's';
+}
+
 RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, const std::string& precision)
     : device_(device_id), impl_(new Impl) {
     if (batch_size <= 0) throw std::invalid_argument("batch size must be positive");
@@ -624,6 +635,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         op.tx.batch = B;
         op.tx.p8 = p8_ ? 1 : 0;
         op.tx.ks = x3_run_ks;
+        op.tx.symmetric = dev_.x3_symmetric ? 1 : 0;
         im.ops.push_back(op);
         x3_blocks.clear();
         prod_op = -1;                      // this launch does not emit channel sums: a gate behind it is an SE launch of its own
@@ -1391,9 +1403,9 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             launch_planes_to_act<T>(op.x == d_planes_ ? planes : static_cast<const float*>(op.x), static_cast<T*>(op.y), B, op.C, im.cin_pad, s);
             break;
         case OpKind::Conv:
-            if (x3_ && getenv("CRA_X3_CONV_DEV") != nullptr) {             // development: bisecting switches of conv_gemm_x3_kernel
+            if (x3_ && dev_.conv_dev >= 0) {                                // development: bisecting switches of conv_gemm_x3_kernel
                 ConvArgs c = op.conv;
-                c.dev = atoi(getenv("CRA_X3_CONV_DEV"));
+                c.dev = dev_.conv_dev;
                 if (op.from_planes) c.planes = planes;
                 if (op.fused_softmax) { c.softmax_out = probs; if (!keep_logits_) c.out = nullptr; }
                 launch_conv_gemm_x3(c, s);
@@ -1768,7 +1780,7 @@ struct RiseNet::Turn {
 // CRA_DEVICE_GRAPH=1 forces the graph (A/B timing).
 void RiseNet::forward_async() {
     Turn turn(*this);
-    if (launches_ == 1 && getenv("CRA_DEVICE_GRAPH") == nullptr) {
+    if (launches_ == 1 && !dev_.device_graph) {
         forward_on(stream_);
         HIP_CHECK(hipGetLastError());
         return;
@@ -1784,7 +1796,7 @@ void RiseNet::forward_async() {
 // searched at 373k nodes/s against 370k through the graph on an idle host, profiles/r04/ac_*).
 void RiseNet::launch_forward_in_stream() {
     Turn turn(*this);
-    if ((launches_ <= 5 && getenv("CRA_LANE_GRAPH") == nullptr) || getenv("CRA_LANE_NO_GRAPH") != nullptr) forward_on(stream_);
+    if ((launches_ <= 5 && !dev_.lane_graph) || dev_.lane_no_graph) forward_on(stream_);
     else HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
 }
 
@@ -1792,7 +1804,7 @@ void RiseNet::launch_forward_in_stream() {
 // microsecond or two per pointer against a forward of 100+ us): a remembered answer would outlive a hipHostFree / hipHostUnregister of
 // the caller's buffers, and a later call with pageable memory at the same addresses would then be read and written by the kernels.
 bool RiseNet::buffers_are_pinned(const float* in_planes, float* value, float* probs, float* aux) {
-    if (getenv("CRA_PREDICT_COPY") != nullptr) return false;     // read per call: bench.py times both paths in one process
+    if (dev_.predict_copy) return false;     // (CRA_PREDICT_COPY when the net was made: bench.py times the copy path on nets of its own)
     const void* set[4] = {in_planes, value, probs, (d_aux_ && aux) ? aux : nullptr};
     for (const void* p : set) {
         if (!p) continue;
@@ -1861,7 +1873,8 @@ void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int la
     // and the compute queue -- five copies around three kernel groups were 0.1-0.5 ms of latency per batch (host dependent), more
     // than the forward itself on a loaded host.  One queue, three launches back to back; the host polls the stream.
     Impl& im = *impl_;
-    const char* lane_mode = getenv("CRA_LANE_LAUNCHES");              // "1" / "2" / "3": force the shape of the lane step (read per call)
+    const char lane_mode_c[2] = {dev_.lane_launches, 0};             // CRA_LANE_LAUNCHES "1" / "2" / "3": force the shape of the lane step
+    const char* lane_mode = dev_.lane_launches ? lane_mode_c : nullptr;
     if (im.ops.size() == 1 && im.ops[0].kind == OpKind::Forward && !(lane_mode && lane_mode[0] == '3')) {
         // The forward kernel's head writes the gathered priors, value and aux of a board straight into the caller's buffers: a search
         // reads nothing else (set_probabilities_for_moves, node.cpp:961-979), so neither the 20.7 KB probability vector nor the logits of
@@ -1898,7 +1911,7 @@ void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int la
     }
     if (n_valid > 0) launch_planes_from_desc(static_cast<const BoardDesc*>(descs_host), n_valid, layout, 1, d_planes_, stream_);
     launch_forward_in_stream();
-    if (getenv("CRA_LANE_SYNC") != nullptr) HIP_CHECK(hipStreamSynchronize(stream_));     // development: bisecting the lane step's ordering
+    if (dev_.lane_sync) HIP_CHECK(hipStreamSynchronize(stream_));     // development: bisecting the lane step's ordering
     launch_gather_probs(d_probs_, design_.nb_policy, idx, cnt, int(stride), n_valid, gathered, d_value_, value, int(B),
                         (d_aux_ && aux) ? d_aux_ : nullptr, aux, stream_);
 }

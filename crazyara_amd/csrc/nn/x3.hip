@@ -2116,10 +2116,9 @@ void launch_block_x3(const BlockArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(block_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
 }
 void launch_tower_x3(const X3TowerArgs& a, hipStream_t s) {
-    // CRA_X3_TOWER=symmetric: every wave runs all three phases (A/B reference, read per launch so that a test can switch); default: the
-    // two-role kernel.  The two add up every output in the same order: same bits.
-    const char* e = getenv("CRA_X3_TOWER");
-    const bool symmetric = e != nullptr && e[0] == 's';
+    // CRA_X3_TOWER=symmetric (read when the net is made, rise_net.h DevSwitches): every wave runs all three phases (A/B reference);
+    // default: the two-role kernel.  The two add up every output in the same order: same bits.
+    const bool symmetric = a.symmetric != 0;
     if (a.p8) {
         if (symmetric) throw std::invalid_argument("Precision float16p8 runs the two-role tower only");
         if (a.ks == 5) hipLaunchKernelGGL(tower_p8_kernel<5>, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes + 8192, s, a);    // (2 KiB of records per tile)

@@ -483,6 +483,7 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
 
     double t_par = 0, t_submit = 0, t_item_max = 0, t_item_sum = 0, t_wait = 0;
     const bool timing = getenv("CRA_POOL_TIMING") != nullptr;
+    const bool two_step = getenv("CRA_POOL_TWO_STEP") != nullptr;     // development A/B (once per run, not per lane step)
     std::atomic<bool> gather_overflow{false};
     // simulations / nodes the tree still lacks (>= 1 for a tree that is not done)
     auto remaining_need = [&](const Tree& t, int tree_id) -> int {
@@ -662,7 +663,7 @@ void SearchPool::run(uint32_t simulations, uint32_t nodes, int threads, SearchSt
         any = false;
         for (Lane& lane : lanes_) {
             const auto a0 = now();
-            if (lane.in_flight && lane.same_trees_next && getenv("CRA_POOL_TWO_STEP") == nullptr) {
+            if (lane.in_flight && lane.same_trees_next && !two_step) {
                 const double w_before = t_wait;
                 if (fused_step(lane)) any = true;
                 if (timing) {

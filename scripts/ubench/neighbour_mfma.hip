@@ -15,8 +15,10 @@
 //               35 KB of LDS, looping ONE kind of work:
 //                 0 v_mfma_f32_16x16x32_f16 back to back     1 ds_read_b128 rows     2 global_load_dwordx4 stream     3 all three interleaved
 //                 4 v_fma_f32 only (control)                 -1 no aggressor
+//                 5 v_mfma_f32_32x32x16_f16     6 v_mfma_scale_f32_16x16x128_f8f6f4     7 v_mfma_f32_16x16x4_f32
+//                 100 = no second kernel: the MIXED kernel, victim waves 0-3 and MFMA waves 4-7 in one workgroup
 //
-// usage: neighbour_mfma.bin <kind> [launches] [victim rounds] [aggressor iterations] [blocks] [victim form 0|1|2]
+// usage: neighbour_mfma.bin <kind> [launches] [victim rounds] [aggressor iterations] [blocks] [victim form 0-5]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -43,13 +45,14 @@ __device__ __forceinline__ void report_one(uint32_t* report, uint32_t* count, ui
 
 // VK: 0 = the FMA chain as the compiler writes it (two v_pk_fma_f32 per weight row), 1 = four v_fmac_f32 (inline asm), 2 = the packed chain on
 // words made in registers (no loads in the round at all)
-template <int VK> __global__ __launch_bounds__(256) void victim(const float* __restrict__ buf, uint32_t* report, uint32_t* count, float* dump, int rounds, int salt) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* s_flat = lds;                         // [128] ones (the "flattened conv output"), broadcast reads
+//     3 = v_pk_mul_f32 (word * 1.0 from LDS, the products' bit patterns summed), 4 = v_pk_add_f32 (word + 0.0 from LDS, likewise)
+// BARRIERS = false: no (S) stage and no workgroup barriers (the victim role inside the mixed kernel below)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int VK, bool BARRIERS> __device__ __forceinline__ void victim_rounds(const float* __restrict__ buf, uint32_t* report, uint32_t* count, float* lds,
+                                                                                int rounds, int salt) {
+    float* s_flat = lds;                         // [128] ones (the "flattened conv output"), broadcast reads; [128..255] zeros
     float* s_part = lds + 1024;                  // [4][256]
-    const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
-    if (tid < 128) s_flat[tid] = 1.0f;
-    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, kq = (tid >> 6) & 3;
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
         const int row0 = ((r + salt) * 32) % ROWS;
@@ -90,12 +93,33 @@ template <int VK> __global__ __launch_bounds__(256) void victim(const float* __r
                 if (cs[e] != want_cs[e]) report_one(report, count, 'L', uint32_t(row0), e, __builtin_bit_cast(float, want_cs[e]), __builtin_bit_cast(float, cs[e]));
         }
         // (A) the FMA chain of FC1
+        uint32_t pcs[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const f32x4 f = *reinterpret_cast<const f32x4*>(s_flat + 4 * q + (r & 3) * 32);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if constexpr (VK == 1) {
+                if constexpr (VK == 3 || VK == 4) {
+                    // one packed multiply (by 1.0) or add (of 0.0) per pair of words: the result must be the word itself
+                    const f32x2 lo = {w[4 * q + e][0], w[4 * q + e][1]}, hi = {w[4 * q + e][2], w[4 * q + e][3]};
+                    const float g = VK == 3 ? f[e] : s_flat[128 + 4 * q + e];
+                    const f32x2 gg = {g, g};
+                    f32x2 r0, r1;
+                    if constexpr (VK == 3) {
+                        asm volatile("v_pk_mul_f32 %0, %2, %4\n\tv_pk_mul_f32 %1, %3, %4" : "=&v"(r0), "=&v"(r1) : "v"(lo), "v"(hi), "v"(gg));
+                    } else {
+                        asm volatile("v_pk_add_f32 %0, %2, %4\n\tv_pk_add_f32 %1, %3, %4" : "=&v"(r0), "=&v"(r1) : "v"(lo), "v"(hi), "v"(gg));
+                    }
+                    pcs[0] += __builtin_bit_cast(uint32_t, float(r0[0]));
+                    pcs[1] += __builtin_bit_cast(uint32_t, float(r0[1]));
+                    pcs[2] += __builtin_bit_cast(uint32_t, float(r1[0]));
+                    pcs[3] += __builtin_bit_cast(uint32_t, float(r1[1]));
+                } else if constexpr (VK == 5) {            // v_pk_fma_f32 written out (no op_sel: the factor sits in both halves of a pair)
+                    f32x2 hl = {h[0], h[1]}, hh = {h[2], h[3]};
+                    const f32x2 lo = {w[4 * q + e][0], w[4 * q + e][1]}, hi = {w[4 * q + e][2], w[4 * q + e][3]}, gg = {f[e], f[e]};
+                    asm volatile("v_pk_fma_f32 %0, %2, %4, %0\n\tv_pk_fma_f32 %1, %3, %4, %1" : "+v"(hl), "+v"(hh) : "v"(lo), "v"(hi), "v"(gg));
+                    h = f32x4{hl[0], hl[1], hh[0], hh[1]};
+                } else if constexpr (VK == 1) {
                     float h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3];
                     const float w0 = w[4 * q + e][0], w1 = w[4 * q + e][1], w2 = w[4 * q + e][2], w3 = w[4 * q + e][3], fe = f[e];
                     asm volatile("v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %8\n\tv_fmac_f32 %2, %6, %8\n\tv_fmac_f32 %3, %7, %8"
@@ -110,16 +134,56 @@ template <int VK> __global__ __launch_bounds__(256) void victim(const float* __r
             }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (h[e] != want_h[e]) report_one(report, count, 'A', 0, e, want_h[e], h[e]);
-        // (S) through LDS
-        *reinterpret_cast<f32x4*>(s_part + kq * 256 + 4 * lane) = h;
-        __syncthreads();
-        const f32x4 back = *reinterpret_cast<const f32x4*>(s_part + kq * 256 + 4 * lane);
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (VK == 3 || VK == 4) {
+                if (pcs[e] != want_cs[e]) report_one(report, count, 'P', 0, e, __builtin_bit_cast(float, want_cs[e]), __builtin_bit_cast(float, pcs[e]));
+            } else {
+                if (h[e] != want_h[e]) report_one(report, count, 'A', 0, e, want_h[e], h[e]);
+            }
+        }
+        if constexpr (BARRIERS) {
+            // (S) through LDS
+            *reinterpret_cast<f32x4*>(s_part + kq * 256 + 4 * lane) = h;
+            __syncthreads();
+            const f32x4 back = *reinterpret_cast<const f32x4*>(s_part + kq * 256 + 4 * lane);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (__builtin_bit_cast(uint32_t, back[e]) != __builtin_bit_cast(uint32_t, h[e])) report_one(report, count, 'S', 0, e, h[e], back[e]);
-        __syncthreads();
+            for (int e = 0; e < 4; ++e)
+                if (__builtin_bit_cast(uint32_t, back[e]) != __builtin_bit_cast(uint32_t, h[e])) report_one(report, count, 'S', 0, e, h[e], back[e]);
+            __syncthreads();
+        }
+    }
+}
+
+template <int VK> __global__ __launch_bounds__(256) void victim(const float* __restrict__ buf, uint32_t* report, uint32_t* count, float* dump, int rounds, int salt) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (threadIdx.x < 256) lds[threadIdx.x] = threadIdx.x < 128 ? 1.0f : 0.0f;
+    __syncthreads();
+    victim_rounds<VK, true>(buf, report, count, lds, rounds, salt);
+}
+
+// ONE workgroup of eight waves: waves 0-3 run the victim's rounds, waves 4-7 (their SIMD partners) issue MFMAs back to back -- the shape of
+// the tower kernels' EXPAND / PROJECT roles.  Does the fault need a neighbour of ANOTHER workgroup, or is a partner wave enough?
+template <int VK> __global__ __launch_bounds__(512) void mixed(const float* __restrict__ buf, uint32_t* report, uint32_t* count, float* sink, int rounds, int salt,
+                                                              int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (threadIdx.x < 256) lds[threadIdx.x] = threadIdx.x < 128 ? 1.0f : 0.0f;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        victim_rounds<VK, false>(buf, report, count, lds, rounds, salt);
+    } else {
+        const int lane = threadIdx.x & 63;
+        f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        half8 a, b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a[i] = _Float16(0.01f * float((lane + i) & 15)); b[i] = _Float16(0.02f * float((lane * 3 + i) & 7)); }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[u & 3], 0, 0, 0);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3];
+        if (s == 123.456f) sink[threadIdx.x] = s;
     }
 }
 
@@ -134,6 +198,12 @@ template <int KIND> __global__ __launch_bounds__(512) void aggressor(const float
 #pragma unroll
     for (int i = 0; i < 8; ++i) { a[i] = _Float16(0.01f * float((lane + i) & 15)); b[i] = _Float16(0.02f * float((lane * 3 + i) & 7)); }
     f32x4 x = {0.1f, 0.2f, 0.3f, 0.4f};
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    f32x16 acc16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    i32x8 a8, b8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a8[i] = 0x38383838 + lane; b8[i] = 0x34343434 + i; }
     for (int it = 0; it < iters; ++it) {
         if constexpr (KIND == 0 || KIND == 3) {
 #pragma unroll
@@ -157,9 +227,21 @@ template <int KIND> __global__ __launch_bounds__(512) void aggressor(const float
 #pragma unroll
             for (int u = 0; u < 16; ++u) asm volatile("v_fma_f32 %0, %0, 0.5, 0.5" : "+v"(x[u & 3]));
         }
+        if constexpr (KIND == 5) {                          // the 32x32 form (16 accumulator registers)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc16, 0, 0, 0);
+        }
+        if constexpr (KIND == 6) {                          // the 8-bit form, K = 128
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u & 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[u & 3], 1, 1, 0, 0, 0, 0);
+        }
+        if constexpr (KIND == 7) {                          // exact f32 (not on the XDL path's f16 datapath)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[0], x[1], acc[u & 3], 0, 0, 0);
+        }
         if constexpr (KIND == 3) { a[it & 7] = _Float16(x[0] * 1e-9f); }
     }
-    float s = x[0] + x[1] + x[2] + x[3];
+    float s = x[0] + x[1] + x[2] + x[3] + acc16[0] + acc16[5] + acc16[15];
 #pragma unroll
     for (int u = 0; u < 4; ++u) s += acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3];
     if (s == 123.456f) sink[tid] = s;
@@ -184,8 +266,15 @@ int main(int argc, char** argv) {
     float* dump = nullptr;
     const size_t vlds = 44064, alds = 35 * 1024;
     for (int l = 0; l < launches; ++l) {
-        if (vk == 1) hipLaunchKernelGGL(victim<1>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        if (kind == 100) {                                   // the mixed kernel: victim and MFMA roles in ONE workgroup, no second stream
+            if (vk == 1) hipLaunchKernelGGL(mixed<1>, dim3(blocks), dim3(512), vlds, sv, buf, report, count, sink, rounds, l, iters);
+            else hipLaunchKernelGGL(mixed<5>, dim3(blocks), dim3(512), vlds, sv, buf, report, count, sink, rounds, l, iters);
+        }
+        else if (vk == 1) hipLaunchKernelGGL(victim<1>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         else if (vk == 2) hipLaunchKernelGGL(victim<2>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        else if (vk == 3) hipLaunchKernelGGL(victim<3>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        else if (vk == 4) hipLaunchKernelGGL(victim<4>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        else if (vk == 5) hipLaunchKernelGGL(victim<5>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         else hipLaunchKernelGGL(victim<0>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         switch (kind) {
             case 0: hipLaunchKernelGGL(aggressor<0>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
@@ -193,6 +282,9 @@ int main(int argc, char** argv) {
             case 2: hipLaunchKernelGGL(aggressor<2>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
             case 3: hipLaunchKernelGGL(aggressor<3>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
             case 4: hipLaunchKernelGGL(aggressor<4>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
+            case 5: hipLaunchKernelGGL(aggressor<5>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
+            case 6: hipLaunchKernelGGL(aggressor<6>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
+            case 7: hipLaunchKernelGGL(aggressor<7>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
             default: break;
         }
         if ((l & 31) == 31) { CHECK(hipStreamSynchronize(sv)); CHECK(hipStreamSynchronize(sa)); }
@@ -202,7 +294,7 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> rep(512 * 9);
     CHECK(hipMemcpy(&n, count, 4, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(rep.data(), report, rep.size() * 4, hipMemcpyDeviceToHost));
-    printf("victim form %d (0 packed FMAs, 1 v_fmac_f32, 2 packed on register-made words), aggressor kind %d: %u mismatches in %d victim launches (%d blocks x 4 waves x %d rounds x 128 loaded words)\n", vk, kind, n, launches, blocks, rounds);
+    printf("victim form %d (0 v_pk_fma_f32, 1 v_fmac_f32, 2 v_pk_fma_f32 on register-made words, 3 v_pk_mul_f32, 4 v_pk_add_f32, 5 v_pk_fma_f32 in asm), aggressor kind %d%s: %u mismatches in %d victim launches (%d blocks x 4 waves x %d rounds x 128 loaded words)\n", vk, kind, kind == 100 ? " (MIXED: both roles in one workgroup)" : "", n, launches, blocks, rounds);
     for (uint32_t k = 0; k < n && k < 40; ++k) {
         const uint32_t* o = rep.data() + k * 9;
         printf("  %c block %u wave %u lane %u load %u word %u: expected %g found %g  hw_id %08x (simd %u cu %u sh %u se %u)\n", char(o[0]), o[1], o[2], o[3], o[4],

@@ -99,6 +99,7 @@ SIGNATURES = {
     "mi_search_best_move": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "mi_traindata_create": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint]),
     "mi_traindata_destroy": (None, [C.c_void_p]),
+    "mi_traindata_set_phases": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mi_traindata_new_game": (C.c_int, [C.c_void_p]),
     "mi_traindata_save_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_float]),
     "mi_search_save_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

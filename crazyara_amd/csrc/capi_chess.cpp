@@ -190,6 +190,10 @@ mi_traindata* mi_traindata_create(const char* path, int mode, int version_major,
     return t;
 }
 void mi_traindata_destroy(mi_traindata* t) { delete t; }
+int mi_traindata_set_phases(mi_traindata* t, int num_phases, int game_phase_definition) {
+    if (!t) { cra_set_error("null exporter"); return 1; }
+    return cra_guard([&] { t->exp.set_phases(num_phases, game_phase_definition); });
+}
 int mi_traindata_new_game(mi_traindata* t) {
     if (!t) { cra_set_error("null exporter"); return 1; }
     return cra_guard([&] { t->exp.new_game(); });

@@ -109,10 +109,18 @@ void TrainDataExporter::new_game() {
     game_best_q_.clear();
 }
 
+void TrainDataExporter::set_phases(int num_phases, int game_phase_definition) {
+    if (num_phases < 1) throw std::invalid_argument("number of game phases must be at least 1");
+    if (game_phase_definition != 0 && game_phase_definition != 1) throw std::invalid_argument("game phase definition: 0 lichess, 1 movecount");
+    num_phases_ = num_phases;
+    game_phase_definition_ = game_phase_definition;
+}
+
 void TrainDataExporter::save_sample(const chess::Position& pos, const std::vector<chess::Move>& legal_moves, const double* policy,
                                     size_t n_policy, float best_move_q, int phase) {
     if (start_idx_ + cur_sample_idx_ >= number_samples_) return;      // "Extended number of maximum samples"
     if (first_move_) new_game();
+    if (phase < 0) phase = pos.game_phase(unsigned(num_phases_), game_phase_definition_);       // save_cur_phase, :91-103
     // save_planes: float planes of the un-normalised representation, truncated to int16
     std::vector<float> planes(size_t(channels_) * 64);
     chess::board_to_planes(pos, layout_, false, planes.data());

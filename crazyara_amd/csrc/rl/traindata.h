@@ -48,8 +48,11 @@ public:
                       size_t chunk_size = 128);
     // save_sample(pos, eval) (:33-47): planes, policy over `legal_moves` (policy[i] for i < n_policy, 0 beyond: EvalInfo pads moves the
     // search never expanded), bestMoveQ, side to move, running sample index, phase
+    // phase < 0 (default): save_cur_phase (:91-103) = pos->get_phase(numPhases, gamePhaseDefinition) with the exporter's own two
+    // settings, as the reference's exporter holds them (set_phases; 1 phase / lichess definition unless told otherwise)
     void save_sample(const chess::Position& pos, const std::vector<chess::Move>& legal_moves, const double* policy, size_t n_policy,
-                     float best_move_q, int phase = 0);
+                     float best_move_q, int phase = -1);
+    void set_phases(int num_phases, int game_phase_definition);       // TrainDataExporter(fileName, numPhases, gamePhaseDefinition, ...) (:136)
     // export_game_samples(result) (:110-134): applies the result to the values, turns the sample indices into plies-to-end, writes the
     // game's rows behind the previous games' and records the next start index.  Returns the number of samples written.
     size_t export_game_samples(int result);
@@ -64,6 +67,7 @@ public:
 private:
     void save_start_idx();
     int mode_, layout_, channels_, nb_labels_;
+    int num_phases_ = 1, game_phase_definition_ = 0;
     size_t number_chunks_, chunk_size_, number_samples_;
     bool first_move_ = true;
     size_t game_idx_ = 0, start_idx_ = 0, cur_sample_idx_ = 0;

@@ -46,6 +46,12 @@ class TrainDataExporter:
     def game_idx(self) -> int:
         return self.info()["game_index"]
 
+    def set_phases(self, num_phases: int, game_phase_definition: int = 0) -> None:
+        """numPhases / gamePhaseDefinition of the reference exporter's constructor (0 = lichess, 1 = movecount): save_sample writes
+        pos->get_phase(numPhases, gamePhaseDefinition) into phase_vector (traindataexporter.cpp:91-103)."""
+        if self._lib.mi_traindata_set_phases(self._h, int(num_phases), int(game_phase_definition)):
+            raise RuntimeError(_capi.last_error())
+
     def new_game(self) -> None:
         if self._lib.mi_traindata_new_game(self._h):
             raise RuntimeError(_capi.last_error())

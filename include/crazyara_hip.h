@@ -326,6 +326,10 @@ int mi_search_reset_position(mi_search* sp, int tree, const char* fen, int is_ch
 typedef struct mi_traindata mi_traindata;
 mi_traindata* mi_traindata_create(const char* path, int mode, int version_major, int version_minor, unsigned number_chunks, unsigned chunk_size);
 void mi_traindata_destroy(mi_traindata* t);
+/* numPhases / gamePhaseDefinition of TrainDataExporter's constructor (traindataexporter.cpp:136-156; 0 = lichess, 1 = movecount): what
+ * save_cur_phase (:91-103) writes into phase_vector for every sample saved through mi_traindata_save_sample / mi_search_save_sample.
+ * Default: 1 phase, lichess definition -- the native self-play loop's default. */
+int mi_traindata_set_phases(mi_traindata* t, int num_phases, int game_phase_definition);
 int mi_traindata_new_game(mi_traindata* t);                                     /* new_game(), :167-171 */
 /* save_sample(pos, evalInfo), :33-47: moves = EvalInfo::legalMoves, policy = policyProbSmall (entries beyond n_policy count as 0) */
 int mi_traindata_save_sample(mi_traindata* t, const mi_pos* pos, const uint32_t* moves, int n_moves, const double* policy, int n_policy,

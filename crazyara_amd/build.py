@@ -32,7 +32,22 @@ def _stamp():
                 h.update(fh.read())
     with open(os.path.join(os.path.dirname(HERE), "include", "crazyara_hip.h"), "rb") as fh:
         h.update(fh.read())
+    h.update(" ".join(device_flags()).encode())
     return h.hexdigest()
+
+
+# No packed f32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in any kernel of the library.  Round 5 found that the results of
+# v_pk_fma_f32 -- which the compiler forms on its own from scalar source -- come out wrong in lanes 48-63 when a wave of ANOTHER workgroup on
+# the same SIMD issues MFMAs (profiles/NOTES.md round 5, scripts/ubench/neighbour_mfma.hip: 3.0 M wrong sums in 3000 launches beside an
+# MFMA-only neighbour, 0 with v_fmac_f32; in the product: value_head_kernel beside the float16x3 policy conv, 84 % of its launches).  Which
+# kernels of a library meet on a SIMD depends on the other lanes / nets / processes of the GPU, so the instruction class is switched off
+# for every device compile (same bits: the packed forms are two IEEE FMAs); tests/test_isa_hazards.py checks the listings.
+# CRA_BUILD_PACKED_FP32=1 builds with them (A/B timing only).
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+
+
+def device_flags():
+    return [] if os.environ.get("CRA_BUILD_PACKED_FP32") else list(NO_PACKED_FP32)
 
 
 def hipcc():
@@ -54,7 +69,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.relpath(src, CSRC).replace(os.sep, "_") + ".o")
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", *device_flags(),
                "-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

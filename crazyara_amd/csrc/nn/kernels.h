@@ -300,7 +300,7 @@ struct ValueHeadArgs {
     int variant;            // development (CRA_VALUE_HEAD_VARIANT): 1 = FC1 partial sums in LDS of their own (not over the dead board tile),
                             // 2 = FC1 accumulators pinned per step (no packed f32 FMAs), 4 = s_waitcnt vmcnt(0) behind every group of 32 weight
                             // loads, 8 = weight loads non-temporal, 16 = the PROBE instantiation (kernels.hip: sums from the registers, read
-                            // back from LDS, checksums of the loaded words, HW_ID per wave), 32 = FC1 on v_fmac_f32 instead of v_pk_fma_f32
+                            // back from LDS, checksums of the loaded words, HW_ID per wave), 32 = FC1 as plain fmaf (v_pk_fma_f32 in a build with packed f32 ops) instead of the v_fmac_f32 asm
 };
 template <typename T> void prepare_value_head(const ValueHeadArgs& a);   // once per net: LDS allowance of the kernel
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s);

@@ -380,8 +380,12 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
 // checksums of the 16-byte weight loads per lane and component (sum of the loaded words' bit patterns) -- so that a differing launch says
 // whether the loaded words, the accumulator register or only its way through LDS was wrong.
 //
-// SCALAR_FMA: FC1's products as four v_fmac_f32 per weight row instead of the two v_pk_fma_f32 the compiler makes of them (round 5's
-// root-cause experiment, profiles/NOTES.md: the words that came out wrong were always the LOW halves of v_pk_fma_f32 results).
+// SCALAR_FMA (the product form): FC1's products as four v_fmac_f32 per weight row, written out, instead of the two v_pk_fma_f32 the
+// compiler makes of them.  Round 5's root cause of the "value head's compute unit" (profiles/NOTES.md): the words that came out wrong
+// were always the LOW halves of v_pk_fma_f32 results in lanes 48-63, beside a neighbour workgroup that issues MFMAs on the same SIMD --
+// 8,401 of 10,000 launches with the packed form, 0 of 10,000 with this one, same co-residency.  The whole library is built without
+// packed f32 arithmetic since (crazyara_amd/build.py); the asm pins this kernel's form whatever the build says.  variant & 32 brings the
+// packed form back (the harness's positive control, meaningful only in a CRA_BUILD_PACKED_FP32 build).
 template <typename T, bool PROBE = false, bool SCALAR_FMA = false>
 __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -644,7 +648,7 @@ static size_t value_head_lds_bytes(const ValueHeadArgs& a) {
     return std::max(used + size_t(a.lds_pad), kValueHeadExclusiveLds);
 }
 template <typename T> const void* value_head_function(const ValueHeadArgs& a) {        // the instantiation launch_value_head picks
-    const bool probe = a.dbg && (a.variant & 16), scalar = (a.variant & 32) != 0;
+    const bool probe = a.dbg && (a.variant & 16), scalar = (a.variant & 32) == 0;
     if (probe && scalar) return reinterpret_cast<const void*>(&value_head_kernel<T, true, true>);
     if (probe) return reinterpret_cast<const void*>(&value_head_kernel<T, true, false>);
     if (scalar) return reinterpret_cast<const void*>(&value_head_kernel<T, false, true>);
@@ -665,7 +669,7 @@ template <typename T> void prepare_value_head(const ValueHeadArgs& a) {
 template void prepare_value_head<half_t>(const ValueHeadArgs&);
 template void prepare_value_head<float>(const ValueHeadArgs&);
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s) {
-    const bool probe = a.dbg && (a.variant & 16), scalar = (a.variant & 32) != 0;
+    const bool probe = a.dbg && (a.variant & 16), scalar = (a.variant & 32) == 0;
     if (probe && scalar) hipLaunchKernelGGL((value_head_kernel<T, true, true>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
     else if (probe) hipLaunchKernelGGL((value_head_kernel<T, true, false>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
     else if (scalar) hipLaunchKernelGGL((value_head_kernel<T, false, true>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);

@@ -8,6 +8,8 @@ blocking).  `NeuralNetAPIUser` mirrors the buffer-owning base class (engine/src/
 from __future__ import annotations
 
 import ctypes as C
+import os
+import sys
 from typing import Optional
 
 import numpy as np
@@ -32,6 +34,13 @@ class _DevArray:
 class HipAPI:
     def __init__(self, device_id: int, batch_size: int, model_directory: str, precision: str = "float16", keep_logits: bool = False):
         self._lib = _capi.load()
+        self.precision_requested = precision
+        if precision == "int8" and os.environ.get("CRA_INT8_STRICT") is None:
+            # the option layer (integration/hipapi.h does the same): the reference's Precision int8 (TensorRT's calibrated INT8) does not
+            # exist here and the LIBRARY refuses the name; a configuration written for TensorRT still starts, on the reference's default
+            print("info string HipAPI: Precision int8 is not available on this back end (no calibrated INT8 mode); running float16 instead. "
+                  "Precision fp8 selects the 8-bit e4m3 mode explicitly.", file=sys.stderr)
+            precision = "float16"
         self._h = self._lib.mi_net_create(model_directory.encode(), int(device_id), int(batch_size), precision.encode())
         if not self._h:
             msg = _capi.last_error()

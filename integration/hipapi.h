@@ -36,6 +36,15 @@ private:
     // ONNX / .cranet parse, BN folding, weight packing, upload, stream + graph); the hooks keep initialize()'s template-method
     // shape (neuralnetapi.cpp:93-99).
     void load_model() override {
+        // `Precision int8` is a valid value of the reference's option (optionsuci.cpp:143-147: TensorRT's entropy-calibrated INT8,
+        // tensorrtapi.cpp:334-360).  The library has no calibrated INT8 mode and refuses the name (its own 8-bit mode, `fp8`, has another
+        // accuracy contract and must be asked for by name); so that an engine or RL configuration written for TensorRT still starts, the
+        // OPTION layer maps it to the reference's default precision and says so.
+        if (precision == "int8") {
+            info_string_important("HipAPI: Precision int8 is not available on this back end (no calibrated INT8 mode);",
+                                  "running float16 instead. Precision fp8 selects the 8-bit e4m3 mode explicitly.");
+            precision = "float16";
+        }
         net = mi_net_create(modelDir.c_str(), deviceID, int(batchSize), precision.c_str());
         if (net == nullptr) {
             throw std::runtime_error(std::string("HipAPI: ") + mi_last_error());          // ctor errors throw, neuralnetapi.cpp:65-70

@@ -1,6 +1,7 @@
 """Register, load or LDS?  The known co-residency fault of value_head_kernel's FC1 (profiles/NOTES.md rounds 4 and 5), taken apart.
 
-Net A (float16x3, one-launch value head WITHOUT its LDS fence, the PROBE instantiation: CRA_VALUE_HEAD_VARIANT=16) relaunches only its
+Net A (float16x3, one-launch value head WITHOUT an LDS fence, the PROBE instantiation: CRA_VALUE_HEAD_VARIANT=16; ROOTCAUSE_EXTRA_VARIANT=32
+selects the packed-FMA form of FC1, which only a CRA_BUILD_PACKED_FP32=1 library still contains) relaunches only its
 value head; net B loops its policy-map conv (conv_gemm_x3_kernel<3, 1, 8, 4>) on another stream.  Every launch of A leaves, per board:
   region 0  the FC1 partial sums as the END of the kernel reads them from LDS           (round 4's dump)
   region 1  the same sums read from LDS right behind the barrier

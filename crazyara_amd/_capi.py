@@ -112,6 +112,7 @@ SIGNATURES = {
     "mi_selfplay_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p]),
     "mi_selfplay_destroy": (None, [C.c_void_p]),
     "mi_selfplay_set_start_fens": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mi_selfplay_set_epd_file": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mi_selfplay_play": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mi_selfplay_game": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_long]),
     "mi_selfplay_get_stats": (C.c_int, [C.c_void_p, C.c_void_p]),

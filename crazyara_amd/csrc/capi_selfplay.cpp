@@ -104,6 +104,14 @@ int mi_selfplay_set_start_fens(mi_selfplay* sp, const char* fens) {
     });
 }
 
+int mi_selfplay_set_epd_file(mi_selfplay* sp, const char* path) {
+    if (!sp || !path) { cra_set_error("null argument"); return 1; }
+    return cra_guard([&] {
+        if (sp->self) sp->self->set_epd_file(path);
+        else sp->arena->set_epd_file(path);
+    });
+}
+
 int mi_selfplay_set_phase_exporter(mi_selfplay* sp, int phase, mi_traindata* exporter) {
     if (!sp || !exporter) { cra_set_error("null argument"); return 1; }
     return cra_guard([&] {

@@ -1,6 +1,8 @@
 // Native self-play / arena loops -- see selfplay.h for the reference lines each step follows.
 #include "selfplay.h"
 
+#include <fstream>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -153,6 +155,20 @@ bool SelfPlayDriver::check_over(Game& g, const std::string* san, const std::stri
     return true;
 }
 
+std::vector<std::string> read_epd_file(const std::string& path) {
+    std::vector<std::string> lines;
+    if (path.empty() || path == "<empty>") return lines;                  // load_random_fen, rl/selfplay.cpp:60-62
+    std::ifstream f(path);
+    if (!f) throw std::invalid_argument("EPD file cannot be read: " + path);
+    std::string line;
+    while (std::getline(f, line)) {
+        while (!line.empty() && (line.back() == '\r' || line.back() == ' ' || line.back() == '\t')) line.pop_back();
+        if (!line.empty()) lines.push_back(line);
+    }
+    if (lines.empty()) throw std::invalid_argument("EPD file holds no position: " + path);
+    return lines;
+}
+
 // refill free slots; init_starting_state_from_raw_policy for all games that start in this round, ply by ply, one batch per ply
 void SelfPlayDriver::start_games(size_t n_games) {
     std::vector<Game*> fresh;
@@ -163,7 +179,9 @@ void SelfPlayDriver::start_games(size_t n_games) {
         g->slot = slot;
         std::seed_seq seq{uint32_t(s_.seed), uint32_t(s_.seed >> 32), uint32_t(idx), uint32_t(uint64_t(idx) >> 32)};
         g->rng.seed(seq);
-        g->pos = make_position(start_fens_.empty() ? std::string() : start_fens_[idx % start_fens_.size()], is960_, variant_);
+        // load position from file if epd filepath was set (rl/selfplay.cpp:200-202)
+        g->pos = make_position(!epd_lines_.empty() ? pick_epd_line(epd_lines_, g->rng)
+                               : start_fens_.empty() ? std::string() : start_fens_[idx % start_fens_.size()], is960_, variant_);
         g->rec.start_fen = g->pos.fen();
         pool_->reset_position(slot, g->pos);
         pool_->set_active(slot, true);
@@ -381,7 +399,13 @@ size_t ArenaDriver::play(size_t n_games, int threads) {
             const size_t idx = started_++;
             const size_t pair = idx / 2;
             if (idx % 2 == 0) {
-                g.pos = make_position(start_fens_.empty() ? std::string() : start_fens_[pair % start_fens_.size()], is960_, variant_);
+                std::string fen = start_fens_.empty() ? std::string() : start_fens_[pair % start_fens_.size()];
+                if (!epd_lines_.empty()) {                                  // load_random_fen(rlSettings->epdFilePath), rl/selfplay.cpp:396
+                    std::seed_seq seq{uint32_t(s_.seed), uint32_t(s_.seed >> 32), uint32_t(pair), 0xE9Du};
+                    std::mt19937_64 rng(seq);
+                    fen = pick_epd_line(epd_lines_, rng);
+                }
+                g.pos = make_position(fen, is960_, variant_);
                 if (pair_fen_.size() <= pair) pair_fen_.resize(pair + 1);
                 pair_fen_[pair] = g.pos.fen();
             } else {

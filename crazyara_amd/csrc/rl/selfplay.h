@@ -79,6 +79,18 @@ double get_quantile(const std::vector<double>& p, double quantile);
 void apply_quantile_clipping(double quantile, std::vector<double>& p);
 void sharpen_distribution(std::vector<double>& p, double thresh);          // blazeutil.h:94-105
 
+// RLSettings::epdFilePath / UCI option EPD_File_Path (optionsuci.cpp:206; load_random_fen, rl/selfplay.cpp:58-80): the lines of an EPD
+// file, one start position each.  "" and "<empty>" mean "no file" (an empty list); a file that cannot be read throws.  Empty lines are
+// skipped; pick_epd_line() draws one line uniformly with the caller's generator (the reference's reservoir draw over the lines seeds a
+// fresh random_device per call; here the game's own seeded generator, so a run replays) and drops ONE trailing ';' as the reference does.
+std::vector<std::string> read_epd_file(const std::string& path);
+template <typename Rng> std::string pick_epd_line(const std::vector<std::string>& lines, Rng& rng) {
+    if (lines.empty()) return std::string();
+    std::string r = lines[size_t(std::uniform_int_distribution<size_t>(0, lines.size() - 1)(rng))];
+    if (!r.empty() && r.back() == ';') r.pop_back();
+    return r;
+}
+
 class SelfPlayDriver {
 public:
     // takes over an EMPTY pool: adds one tree slot per concurrent game.  exporter may be null.
@@ -86,6 +98,8 @@ public:
                    TrainDataExporter* exporter);
     // game i starts from start_fens[i % size] ("" = the variant's start position); default: always the start position
     void set_start_fens(std::vector<std::string> fens) { start_fens_ = std::move(fens); }
+    // epdFilePath: every game starts from a random line of the file (drawn with the game's generator); overrides set_start_fens
+    void set_epd_file(const std::string& path) { epd_lines_ = read_epd_file(path); }
     // one more exporter per further game phase (phase 0 = the constructor's): SelfPlay's `exporters` (selfplay.cpp:115-125)
     void set_phase_exporter(int phase, TrainDataExporter* exporter);
     // n_games > 0: plays until n_games are finished in total (over all calls) -- SelfPlay::go(N): every game is played out, positions
@@ -121,7 +135,7 @@ private:
     std::vector<TrainDataExporter*> exporters_;      // by phase; [0] == exporter_
     size_t samples_taken_ = 0;              // generatedSamples: positions accepted for export so far (buffered in their games or written)
     size_t sample_capacity() const;         // max_samples_per_iteration() = the export file's capacity
-    std::vector<std::string> start_fens_;
+    std::vector<std::string> start_fens_, epd_lines_;
     std::vector<std::unique_ptr<Game>> games_;
     std::vector<GameRecord> finished_;
     size_t started_ = 0;
@@ -136,6 +150,8 @@ public:
     ArenaDriver(search::SearchPool* pool_a, search::SearchPool* pool_b, const SelfPlaySettings& s, int concurrent, chess::Variant variant,
                 bool is960);
     void set_start_fens(std::vector<std::string> fens) { start_fens_ = std::move(fens); }   // pair i uses start_fens[i % size]
+    // epdFilePath (go_arena, rl/selfplay.cpp:396): every PAIR of games starts from a random line of the file; overrides set_start_fens
+    void set_epd_file(const std::string& path) { epd_lines_ = read_epd_file(path); }
     size_t play(size_t n_games, int threads);
     const std::vector<GameRecord>& finished() const { return finished_; }
     const LoopStats& stats() const { return stats_; }
@@ -155,7 +171,7 @@ private:
     int concurrent_;
     chess::Variant variant_;
     bool is960_;
-    std::vector<std::string> start_fens_;
+    std::vector<std::string> start_fens_, epd_lines_;
     std::vector<Game> games_;
     std::vector<std::string> pair_fen_;
     std::vector<GameRecord> finished_;

@@ -160,6 +160,12 @@ class _NativeLoop:
         self._start_fen, self._n_fens_sent = start_fen, 0
         self._read = 0
 
+    def set_epd_file(self, path: str) -> None:
+        """RLSettings.epdFilePath / UCI EPD_File_Path: every game (arena: every pair) starts from a random line of the file
+        (load_random_fen, rl/selfplay.cpp:58-80); "" or "<empty>" switches it off."""
+        if self._lib.mi_selfplay_set_epd_file(self._h, (path or "").encode()):
+            raise (ValueError if "EPD" in _capi.last_error() else RuntimeError)(_capi.last_error())
+
     def _send_fens(self, n: int):
         if self._start_fen is None or n <= self._n_fens_sent:
             return

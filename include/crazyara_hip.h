@@ -390,6 +390,11 @@ mi_selfplay* mi_selfplay_create(mi_search* pool_a, mi_search* pool_b, const mi_s
 void mi_selfplay_destroy(mi_selfplay* sp);
 /* start positions, '\n'-separated FENs ("" line = the variant's start position): game i (arena: pair i) uses entry i mod count */
 int mi_selfplay_set_start_fens(mi_selfplay* sp, const char* fens);
+/* RLSettings::epdFilePath (UCI option EPD_File_Path, optionsuci.cpp:206; load_random_fen, rl/selfplay.cpp:58-80,201,396): every game
+ * (arena: every colour-swapped pair of games) starts from a random line of the EPD file -- one FEN per line, a trailing ';' dropped --
+ * drawn with the game's own seeded generator.  "" or "<empty>" = no file (back to mi_selfplay_set_start_fens / the start position);
+ * an unreadable or empty file is an error.  Overrides mi_selfplay_set_start_fens. */
+int mi_selfplay_set_epd_file(mi_selfplay* sp, const char* path);
 /* self-play with num_phases > 1: the exporter of game phase `phase` >= 1 (phase 0 is mi_selfplay_create's); every sample goes to the
  * exporter of its position's phase (rl/selfplay.cpp:232-238, Board::get_phase, board.cpp:540-587) */
 int mi_selfplay_set_phase_exporter(mi_selfplay* sp, int phase, mi_traindata* exporter);

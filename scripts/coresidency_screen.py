@@ -2,16 +2,19 @@
 runs beside it?
 
 Round 4 found one such pair by accident (value_head_kernel beside conv_gemm_x3_kernel<3, 1, 8, 4>: one FC1 accumulator wrong in 20-30 % of
-the launches) and fenced it; this screens every (victim, aggressor) pair of ops of the conformant forwards.
+the launches) and fenced it with 144 KB of LDS; this screens every (victim, aggressor) pair of ops of the conformant forwards.  Round 5's
+first run of it (library with packed f32 arithmetic, fence off; profiles/r05/a_screen_*) showed exactly that pair red in every net and
+nothing else; with the cause removed (v_pk_fma_f32, profiles/NOTES.md round 5) the shipped library has no fence and every cell is 0
+(profiles/r05/e_screen_*).
 
   victim    : net A has run a forward of OTHER planes, then the planes of the screen; RiseNet::dev_screen_prepare runs the forward op by op
               and records every op's output buffers.  Then op k ALONE, `launches` times on A's stream, every launch compared on the device
               with the recorded bits (an op that is not idempotent gets its buffers put back before every launch).
   aggressor : net B (same model and mode, own weights / buffers / stream) loops ONE of its ops on another host thread.
-  control   : CRA_VALUE_HEAD_LDS_PAD=-1 (default here) drops the value head's 144 KB LDS fence, so the known pair must show up red;
-              --fenced runs the shipped form, where every cell must be 0.
+  control   : a library built with CRA_BUILD_PACKED_FP32=1 and CRA_VALUE_HEAD_VARIANT=32 (FC1 as the compiler writes it) shows the known
+              pair red; the shipped library must show 0 everywhere.  --fence adds round 4's 144 KB LDS fence (A/B).
 
-usage: python scripts/coresidency_screen.py [--launches 1000] [--batch 256] [--configs p8-v2,x3-v2,p8-v33,x3-v33] [--fenced] [--out file.json]
+usage: python scripts/coresidency_screen.py [--launches 1000] [--batch 256] [--configs p8-v2,x3-v2,p8-v33,x3-v33] [--fence] [--out file.json]
 """
 import argparse
 import ctypes as C
@@ -26,12 +29,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--launches", type=int, default=1000)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--configs", default="p8-v2,x3-v2,p8-v33,x3-v33")
-ap.add_argument("--fenced", action="store_true", help="the shipped value head (144 KB LDS fence): every cell must be 0")
+ap.add_argument("--fence", action="store_true", help="round 4's 144 KB LDS fence around the value head (A/B; the shipped kernel has none)")
 ap.add_argument("--out", default=None)
 args = ap.parse_args()
 os.environ["CRA_X3_VALUE_HEAD"] = "one"
-if not args.fenced:
-    os.environ.setdefault("CRA_VALUE_HEAD_LDS_PAD", "-1")
+if args.fence:
+    os.environ["CRA_VALUE_HEAD_LDS_PAD"] = "0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
@@ -60,7 +63,7 @@ def planes(batch, channels, seed):
     return (rng.random((batch, channels, 8, 8)) < 0.1).astype(np.float32)
 
 
-report = {"launches": args.launches, "batch": args.batch, "fenced": bool(args.fenced), "configs": {}}
+report = {"launches": args.launches, "batch": args.batch, "fence": bool(args.fence), "configs": {}}
 for name in args.configs.split(","):
     make, version, precision = CONFIGS[name]
     cfg = make()

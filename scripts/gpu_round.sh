@@ -8,7 +8,7 @@
 #   bench       python bench.py (every leg) + bench_detail.json   benchquick  the NN legs only (no search / game / drop-in legs)
 #   trace       rocprofv3 --kernel-trace --stats of bench.py --timed-only, headline mode (+ float16)
 #   pmc         SQ / TCC / GRBM counter passes of the headline forward (scripts/prof_forward.py), separate --pmc runs
-#   screen      scripts/coresidency_screen.py, unfenced (positive control) and fenced
+#   screen      scripts/coresidency_screen.py: round 4's harness net at batch 64, then the four conformant forwards at batch 256
 #   rootcause   scripts/value_head_rootcause.py (packed / scalar FC1) + scripts/ubench/neighbour_mfma.bin, every aggressor kind
 #   erratum     neighbour_mfma.bin: packed mul / add / fma victims, MFMA kinds, victim and MFMA roles in one workgroup
 #   round       tests smoke bench trace pmc
@@ -61,9 +61,8 @@ run_set() {
       python scripts/pmc_summary.py $OUT/${prec}_sq2 > $OUT/pmc_${prec}_sq2.txt 2>&1; rm -rf $OUT/${prec}_sq2
       grep -h -A12 "tower_p8" $OUT/pmc_${prec}_sq2.txt | head -14 ;;
     screen)
-      timeout 500 python scripts/coresidency_screen.py --batch 64 --configs x3-v2-3 --launches 2000 --out $OUT/screen_control_batch64.json > $OUT/screen_control_batch64.txt 2>&1; tail -12 $OUT/screen_control_batch64.txt
-      timeout 900 python scripts/coresidency_screen.py --launches ${SCREEN_LAUNCHES:-1000} --out $OUT/screen_unfenced.json > $OUT/screen_unfenced.txt 2>&1; grep -E "RED|RESULT|Error|error" $OUT/screen_unfenced.txt | head -40
-      [ -n "$SCREEN_SKIP_FENCED" ] || timeout 900 python scripts/coresidency_screen.py --fenced --launches ${SCREEN_LAUNCHES:-1000} --out $OUT/screen_fenced.json > $OUT/screen_fenced.txt 2>&1; grep -E "RED|RESULT|Error|error" $OUT/screen_fenced.txt | head -40 ;;
+      timeout 500 python scripts/coresidency_screen.py --batch 64 --configs x3-v2-3 --launches 2000 --out $OUT/screen_batch64.json > $OUT/screen_batch64.txt 2>&1; tail -12 $OUT/screen_batch64.txt
+      timeout 900 python scripts/coresidency_screen.py --launches ${SCREEN_LAUNCHES:-1000} --out $OUT/screen.json > $OUT/screen.txt 2>&1; grep -E "RED|RESULT|Error|error" $OUT/screen.txt | head -40 ;;
     rootcause)
       timeout 300 python scripts/value_head_rootcause.py 10000 64 risev2-3 > $OUT/rootcause_probe_packed.txt 2>&1; grep -E "differ|regions|RESULT" $OUT/rootcause_probe_packed.txt | head -8
       ROOTCAUSE_EXTRA_VARIANT=32 timeout 300 python scripts/value_head_rootcause.py 10000 64 risev2-3 > $OUT/rootcause_probe_scalar.txt 2>&1; grep -E "differ|regions|RESULT" $OUT/rootcause_probe_scalar.txt | head -8

@@ -5,6 +5,9 @@ that end in different trees got different numbers from the GPU.  The scenario th
 lanes (two float16x3 nets on two streams, batch 64, so the two forwards overlap freely on the chip), 4 host threads, 240 simulations
 -- repeated 200 times for both forms of the float16x3 value head.  Every batch of every run is also recorded and replayed alone on the
 device (mi_search_debug_replay): a differing word names the batch, the slot and the output that was not reproducible.
+
+Round 5: the fault was v_pk_fma_f32 in the value head's FC1 beside the MFMA waves of the other lane's policy conv (profiles/NOTES.md);
+the kernel runs on v_fmac_f32 since and WITHOUT round 4's LDS fence -- this test is what holds that the unfenced kernel reproduces.
 """
 import numpy as np
 import pytest

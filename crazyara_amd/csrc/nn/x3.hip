@@ -1744,6 +1744,9 @@ __device__ __forceinline__ void x3_se_gate_from_mean(const X3TowerBlock& d, floa
 }
 }  // namespace
 
+// byte position of channel c inside a byte row of the residual stream: the 16-byte pieces of a 64-channel step in the order A0 B0 A1 B1
+__device__ __forceinline__ int x8_pos(int c) { return (c & ~0x30) | ((c & 0x10) << 1) | ((c & 0x20) >> 1); }
+
 template <int KS>
 __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
     static_assert(KS == 3 || KS == 5, "depthwise 3x3 or 5x5");
@@ -1814,8 +1817,12 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                     ring_h[st % 4] = *reinterpret_cast<const half8*>(T.xh + ((st & 3) * 16 + l15) * XROW + (st >> 2) * 32 + lg * 8);
                 };
                 auto read_8 = [&](int q) {                              // lane group lg: 0, 1 = hi8 of k [0, 32), [32, 64) of the step; 2, 3 = lo8 of the same
-                    const char* pp = x8 + ((q & 3) * 16 + l15) * X8ROW + (lg >> 1) * 272 + (q >> 2) * 64 + (lg & 1) * 32;
-                    ring_8[q % 3] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 16));
+                    // the byte rows of x hold a 64-k step as the 16-byte pieces A0 B0 A1 B1 (A = k [0, 32), B = k [32, 64): x8_pos): the
+                    // two lane groups of a pair then read NEIGHBOURING slots, which with the 544-byte pitch puts the 16 lanes of every
+                    // ds_read_b128 group on 16 different slots (linear A0 A1 B0 B1: two lanes per slot, 8 LDS cycles instead of 4 -- a
+                    // third of the kernel's bank-conflict cycles, scripts/studies/lds_bank_model.py)
+                    const char* pp = x8 + ((q & 3) * 16 + l15) * X8ROW + (lg >> 1) * 272 + (q >> 2) * 64 + (lg & 1) * 16;
+                    ring_8[q % 3] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 32));
                 };
                 f32x4 dw_raw[2][REC / 256];
                 const int inext = i + 1 < n ? i + 1 : i;                // (behind the last chunk: a valid address, no branch in the stretch)
@@ -1954,8 +1961,9 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                 uint32_t h8, l8;
                 split4_b8(v, h, h8, l8);
                 *reinterpret_cast<half4*>(T.xh + rr * XROW + co0) = h;
-                *reinterpret_cast<uint32_t*>(x8 + rr * X8ROW + co0) = h8;
-                *reinterpret_cast<uint32_t*>(x8 + rr * X8ROW + 272 + co0) = l8;
+                const int cb = x8_pos(co0);                             // (bits 4 and 5 of the channel swapped: read_8)
+                *reinterpret_cast<uint32_t*>(x8 + rr * X8ROW + cb) = h8;
+                *reinterpret_cast<uint32_t*>(x8 + rr * X8ROW + 272 + cb) = l8;
             }
         }
     };

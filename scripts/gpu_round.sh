@@ -11,6 +11,7 @@
 #   screen      scripts/coresidency_screen.py: round 4's harness net at batch 64, then the four conformant forwards at batch 256
 #   rootcause   scripts/value_head_rootcause.py (packed / scalar FC1) + scripts/ubench/neighbour_mfma.bin, every aggressor kind
 #   erratum     neighbour_mfma.bin: packed mul / add / fma victims, MFMA kinds, victim and MFMA roles in one workgroup
+#   dropin      scripts/dropin_threads.py (the reference's MCTSAgent on HipAPI nets: Threads x simulations)     onetree  scripts/one_tree_sweep.py
 #   round       tests smoke bench trace pmc
 TAG=${1:-r05}
 shift
@@ -79,6 +80,10 @@ run_set() {
       for kind in 4 5 6 7; do timeout 120 scripts/ubench/neighbour_mfma.bin $kind 3000 8 600 64 6 >> $OUT/erratum.txt 2>&1; done
       for form in 6 7 5 1; do for blocks in 64 256 1024; do timeout 120 scripts/ubench/neighbour_mfma.bin 100 3000 8 600 $blocks $form >> $OUT/erratum.txt 2>&1; done; done
       grep -E "^victim form|^  [LASP] " $OUT/erratum.txt | cut -c130-360 | awk '/aggressor kind/{n=0} {if (n<2) print; n++}' ;;
+    dropin)
+      timeout 600 python scripts/dropin_threads.py ${HEADLINE} > $OUT/dropin_threads.txt 2>&1; grep -E "^simulations|Error" $OUT/dropin_threads.txt | cut -c1-330 ;;
+    onetree)
+      timeout 600 python scripts/one_tree_sweep.py ${HEADLINE} > $OUT/one_tree_sweep.txt 2>&1; grep -E "^\{|Error" $OUT/one_tree_sweep.txt | cut -c1-330 ;;
     round)
       for s in tests smoke bench trace pmc; do run_set $s; done ;;
     *) echo "unknown set $1" ;;

@@ -1753,12 +1753,19 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
     constexpr int REC = KS == 3 ? 256 : 512;                            // floats of depthwise records per 16-channel tile (X3Depthwise / X3Depthwise5)
     using G = X3Block;
     static_assert(G::NE == 1 && G::T2BUF == 2 && G::CK == 128, "the role kernels use the NE = 1 tile geometry");
-    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, X8ROW = XROW * 2, T8ROW = 272, T8LO = 144, NJ = 4;
+    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, X8ROW = XROW * 2, T8ROW = 288, T8LO = 144, NJ = 4;
     static_assert(T8ROW <= TROW * 2 && T8LO + CK <= T8ROW, "the byte rows of t2 live where float16x3 keeps t2l");
+    // t2's rows (f16 tile and byte tile, both at a 288-byte pitch) are SWIZZLED: bit 0 of a row's 16-byte slot index is XORed with bit 2, and
+    // bit 2 with bit 3, of the row's index inside its square tile (g0 / g2 below; both slot bits are lane constants or wave constants on
+    // the storing side, so a lane keeps ONE column per tile and the second channel tile of a wave is an immediate away), and the byte tile
+    // holds a 64-channel step as the pieces A0 B0 A1 B1 like the stream's byte rows (x8_pos).  With that the PROJECT waves' ds_read_b128
+    // put every lane group on 16 different slots (4 LDS cycles; was 8 for the bytes at the 272-byte pitch, and 8 for the f16 tile at any
+    // pitch that serves the stores), and the EXPAND waves' 8- and 4-byte stores stay at the two lanes per bank that their row-per-lane
+    // mapping allows (scripts/studies/lds_bank_model.py: 384 -> 256 LDS cycles per interval and role pair for t2).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const X3Tiles T = x3_tiles(smem);
     char* const x8 = reinterpret_cast<char*>(T.xl);                    // [64][528 B]: hi8 bytes [0, 256), lo8 bytes [272, 528) of a row
-    char* const t28 = reinterpret_cast<char*>(T.t2l);                  // [2][64][272 B]: hi8 bytes [0, 128), lo8 bytes [144, 272) of a row (68 dwords: 16 rows, 16 bank groups)
+    char* const t28 = reinterpret_cast<char*>(T.t2l);                  // [2][64][288 B]: hi8 bytes [0, 128), lo8 bytes [144, 272) of a row, slots swizzled (above)
     float* const se_scratch = reinterpret_cast<float*>(T.t2h);         // idle between blocks
     __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);                        // MODE.FP16_OVFL: conversions to f16 clamp instead of overflowing
     const int b = blockIdx.x;
@@ -1766,10 +1773,16 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wave & 3;
     const uint32_t lane_off = uint32_t(lane) * 16u;
+    const int g0 = (l15 >> 2) & 1, g2 = (l15 >> 3) & 1;                 // t2's slot swizzle of this lane's rows
 
     if (wave < 4) {
         // =================================================== EXPAND waves ===================================================
         const bool hi = l15 >= 8;
+        // where this lane's four channels of channel tile w * 2 (dt = 0) go inside a t2 row: f16 tile in halves (slot = channel / 8 =
+        // w * 4 + dt * 2 + lg / 2), byte tile in bytes (the tile's 16 bytes are slot (w / 2) * 4 + dt * 2 + w % 2 of the A0 B0 A1 B1
+        // order); slots swizzled; tile w * 2 + 1 (dt = 1) is two slots further in both
+        const int t2h_col = ((w ^ g2) * 4 + ((lg >> 1) ^ g0)) * 8 + (lg & 1) * 4;
+        const int t2b_col = (((w >> 1) ^ g2) * 4 + ((w & 1) ^ g0)) * 16 + lg * 4;
         const X3EdgeOffsets edge = x3_edge_offsets(l15);
         const X3EdgeOffsets5 edge5 = x3_edge_offsets5(l15);
         __syncthreads();                                                // the PROJECT waves have written block 0's operand tiles
@@ -1885,8 +1898,7 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                             if (ph == 2) { dw5.template gather<2>(accD[dt], hi, e_inv); dw5.template taps<2>(); }
                             if (ph == 3) { dw5.template gather<3>(accD[dt], hi, e_inv); dw5.template taps<3>(); }
                         }
-                        if (ph == 3) {
-                            const int cl = (w * 2 + dt) * 16 + lg * 4;  // split -> t2 of chunk i - 1: the f16 hi and the two byte rows
+                        if (ph == 3) {                                  // split -> t2 of chunk i - 1: the f16 hi and the two byte rows (t2h_col / t2b_col)
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 half4 h;
@@ -1896,9 +1908,9 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                                     asm volatile("" ::"v"(h), "v"(h8), "v"(l8));
                                     continue;
                                 }
-                                *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + cl) = h;
-                                *reinterpret_cast<uint32_t*>(t2b + (t * 16 + l15) * T8ROW + cl) = h8;
-                                *reinterpret_cast<uint32_t*>(t2b + (t * 16 + l15) * T8ROW + T8LO + cl) = l8;
+                                *reinterpret_cast<half4*>(t2h + (t * 16 + l15) * TROW + t2h_col + dt * 16) = h;
+                                *reinterpret_cast<uint32_t*>(t2b + (t * 16 + l15) * T8ROW + t2b_col + dt * 32) = h8;
+                                *reinterpret_cast<uint32_t*>(t2b + (t * 16 + l15) * T8ROW + T8LO + t2b_col + dt * 32) = l8;
                             }
                         }
                     }
@@ -1967,6 +1979,11 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
             }
         }
     };
+    // this lane's operand rows in t2 (buffer 0, square tile 0): the f16 tile's even / odd k-slabs and the byte tile's two 64-k steps (swizzle)
+    const half_t* const t2h_even = T.t2h + l15 * TROW + g2 * 32 + (lg ^ g0) * 8;
+    const half_t* const t2h_odd = T.t2h + l15 * TROW + (g2 ^ 1) * 32 + (lg ^ g0) * 8;
+    const char* const t2b_j0 = t28 + l15 * T8ROW + (lg >> 1) * T8LO + g2 * 64 + (((lg & 1) ^ g0) << 4);
+    const char* const t2b_j1 = t28 + l15 * T8ROW + (lg >> 1) * T8LO + (g2 ^ 1) * 64 + (((lg & 1) ^ g0) << 4);
     if (a.blocks[0].se_kind == 0) write_tiles();                       // (a gated first block writes them behind its gate)
     __syncthreads();
     for (int blk = 0; blk < a.nblocks; ++blk) {
@@ -2041,20 +2058,20 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
         __syncthreads();                                                // intervals 0 and 1: chunk 0 is expanded, then run through the depthwise
         __syncthreads();
         for (int kk = 0; kk < n; ++kk) {                                // P(kk) runs in interval kk + 2
-            const half_t* const t2h = T.t2h + (kk & 1) * 64 * TROW;
-            const char* const t2b = t28 + (kk & 1) * 64 * T8ROW;
             X3_STAMP(8);
             half8 bh[2][4];
             i32x8_x3 b8[4];
-            auto read_h = [&](int s2) {
+            auto read_h = [&](int s2) {                                 // slot s2 * 4 + lg of the row, swizzled: (s2 ^ g2) * 4 + (lg ^ g0)
+                const half_t* const pe = s2 & 1 ? t2h_odd : t2h_even;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bh[s2 & 1][t] = *reinterpret_cast<const half8*>(t2h + (t * 16 + l15) * TROW + s2 * 32 + lg * 8);
+                for (int t = 0; t < 4; ++t) bh[s2 & 1][t] = *reinterpret_cast<const half8*>(pe + (kk & 1) * 64 * TROW + t * 16 * TROW + (s2 >> 1) * 64);
             };
             auto read_8 = [&](int J) {                                  // lane group lg: 0, 1 = hi8 of k [0, 32), [32, 64) of the step; 2, 3 = lo8 of the same
+                const char* const pj = J ? t2b_j1 : t2b_j0;              // the lane's 32 bytes: pieces (lg & 1) and 2 + (lg & 1) of the step's A0 B0 A1 B1, swizzled
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const char* pp = t2b + (t * 16 + l15) * T8ROW + (lg >> 1) * T8LO + J * 64 + (lg & 1) * 32;
-                    b8[t] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 16));
+                    const char* pp = pj + (kk & 1) * 64 * T8ROW + t * 16 * T8ROW;
+                    b8[t] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 32));
                 }
             };
             const int knext = kk + 1 < n ? kk + 1 : kk;                 // (behind the last chunk: a valid address, no branch in the stretch)

@@ -351,6 +351,10 @@ def config_search_legs(args, device, threads):
         rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 3, 32, 1600, cz, 1, shared=8)
     leg("config2_one_tree_shared_6400", "the same with 6400 simulations per go (a longer think)",
         rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 2, 32, 6400, cz, 1, shared=8)
+    # the lane shape that serves ONE tree best (profiles/r05/f_one_tree_sweep_*: 2 / 3 lanes x 256, 4-6 x 128, 8-12 x 64, 16 x 32 at 1600
+    # and 6400 simulations): a third batch in flight pays once the tree is wide enough to fill it
+    leg("config2_one_tree_three_lanes_6400", "ONE tree, 3 lanes x 256, 8 collectors per lane, 6400 simulations per go",
+        rise_config.rise_v2_config(19, 34, 81), "1.0", 0, 256, 3, 32, 6400, cz, 1, shared=8)
     # CrazyAra::benchmark on its own position table (one tree, one go per position)
     nets = nets_for(rise_config.rise_v2_config(19, 34, 81), "1.0", 256, 2, seed=31)
     st_b = search.default_settings(mode=0, version_major=1, batch_size=32)
@@ -515,6 +519,8 @@ def compact_record(full, detail_path):
         summary[f"config2_mcts_nodes_per_sec_{other['precision']}"] = other["mcts_nodes_per_sec"]
     for k_, r_ in (full.get("mcts_configs") or {}).items():
         summary[f"{k_}_nodes_per_sec"] = r_["mcts_nodes_per_sec"]
+        if k_.startswith("config2_one_tree") and "avg_batch_fill" in r_:
+            summary[f"{k_}_fill"] = r_["avg_batch_fill"]
         for kk_, v_ in r_.items():                                   # the same leg with nets of the other mode
             if kk_.startswith("mcts_nodes_per_sec_"):
                 summary[f"{k_}_nodes_per_sec_{kk_[len('mcts_nodes_per_sec_'):]}"] = v_

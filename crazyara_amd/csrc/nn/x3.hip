@@ -752,20 +752,9 @@ __device__ __forceinline__ f32x2 pair_of(const f32x4& v, int p) { return p == 0 
 //   rec: this tile's records in LDS, [16 rows: taps dx = -1 (dy = -1, 0, 1), dx = 0, dx = +1, BN1 bias, BN2 bias, 5 rows of zeros][16 channels]
 struct X3EdgeOffsets { int left, right; };                       // in floats: 11 rows / 5 rows from the dx = -1 / +1 rows to the zero rows, or 0
 __device__ __forceinline__ X3EdgeOffsets x3_edge_offsets(int l15) { return X3EdgeOffsets{(l15 & 7) == 0 ? 11 * 16 : 0, (l15 & 7) == 7 ? 5 * 16 : 0}; }
-// acc += w * (x of the lane one file to the left / right in its 16-lane row, 0 outside the row): ONE v_fmac_f32 with the lane move in its
-// DPP operand instead of a v_mov_b32_dpp copy + v_fmac_f32 (the compiler's DPP combiner does not fold copies into FMACs: 12 copies per
-// channel pair and chunk were 11 % of the EXPAND waves' instruction stream, which IS the towers' interval -- profiles/NOTES.md round 5).
-// Plain (not volatile) asm: the scheduler places every instruction on its own, as it does the FMAC it replaces.  The same arithmetic: an
-// FMA on the same three values.
-__device__ __forceinline__ void fmac_from_left(float& acc, float x, float w) {
-    asm("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(w));
-}
-__device__ __forceinline__ void fmac_from_right(float& acc, float x, float w) {
-    asm("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(w));
-}
 struct X3Depthwise {
     f32x2 w[11];                                                 // the current channel pair's records (rows 0 ... 10)
-    f32x2 S[6];                                                  // rank - 1 ... rank + 4 of this lane's half: S[1 + t] = tile t
+    f32x2 S[6], L[6], R[6];                                      // rank - 1 ... rank + 4 of this lane's half: S[1 + t] = tile t
     float outv[4][4];                                            // [tile][channel r]
 
     template <int P> __device__ __forceinline__ void load(const float* rec, int lg, const X3EdgeOffsets& e) {
@@ -787,16 +776,16 @@ struct X3Depthwise {
             const float across_up = dpp_mov<DPP_ROW_ROR8>(S[4][c]), across_dn = dpp_mov<DPP_ROW_ROR8>(S[1][c]);
             S[0][c] = upper ? across_up : 0.f;                    // above rank 4 lies rank 3 (tile 3, other half); above rank 0 the edge
             S[5][c] = upper ? 0.f : across_dn;                    // below rank 3 lies rank 4 (tile 0, other half); below rank 7 the edge
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                L[j][c] = dpp_mov<DPP_ROW_SHR1>(S[j][c]);
+                R[j][c] = dpp_mov<DPP_ROW_SHL1>(S[j][c]);
+            }
         }
     }
     // plain v_fmac_f32, NOT v_pk_fma_f32: a packed f32 FMA does not run in the shadow of MFMAs (scripts/ubench/mix_kinds.hip: an MFMA
     // followed by two of them 38.5 cycles, by two v_fmac_f32 18.5; beside another wave's MFMAs 14.7 cycles each against 8.75)
     template <int P> __device__ __forceinline__ void taps(int t0, int t1) {
-        if constexpr (!(X3_ABL & 1)) {
-            // a DPP operand must not be read within two wait states of the VALU instruction that wrote the register; the compiler does not
-            // look inside the asm, so the S values pass through this fence first (one per call: 16 per chunk and wave)
-            asm volatile("s_nop 1" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]));
-        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t < t0 || t >= t1) continue;
@@ -809,9 +798,9 @@ struct X3Depthwise {
                 float a = w[10][c];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
-                    fmac_from_left(a, S[t + dy][c], w[dy][c]);
+                    a = fmaf(w[dy][c], L[t + dy][c], a);
                     a = fmaf(w[3 + dy][c], S[t + dy][c], a);
-                    fmac_from_right(a, S[t + dy][c], w[6 + dy][c]);
+                    a = fmaf(w[6 + dy][c], R[t + dy][c], a);
                 }
                 outv[t][2 * P + c] = fmaxf(a, 0.f);
             }

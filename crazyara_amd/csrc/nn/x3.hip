@@ -1785,6 +1785,12 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
         const int t2b_col = (((w >> 1) ^ g2) * 4 + ((w & 1) ^ g0)) * 16 + lg * 4;
         const X3EdgeOffsets edge = x3_edge_offsets(l15);
         const X3EdgeOffsets5 edge5 = x3_edge_offsets5(l15);
+        // this lane's operand rows in the stream tile (square tile 0): even / odd k-slabs of xh, even / odd 64-k steps of the byte rows -- the
+        // stream tile is swizzled like t2 (same 32-byte-mod-256 pitch), which takes the block epilogue's stores from four lanes per bank to two
+        const half_t* const xh_even = T.xh + l15 * XROW + g2 * 32 + (lg ^ g0) * 8;
+        const half_t* const xh_odd = T.xh + l15 * XROW + (g2 ^ 1) * 32 + (lg ^ g0) * 8;
+        const char* const x8_even = x8 + l15 * X8ROW + (lg >> 1) * 272 + g2 * 64 + (((lg & 1) ^ g0) << 4);
+        const char* const x8_odd = x8 + l15 * X8ROW + (lg >> 1) * 272 + (g2 ^ 1) * 64 + (((lg & 1) ^ g0) << 4);
         __syncthreads();                                                // the PROJECT waves have written block 0's operand tiles
         for (int blk = 0; blk < a.nblocks; ++blk) {
             const X3TowerBlock& d = a.blocks[blk];
@@ -1826,15 +1832,16 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                 constexpr bool HASE = decltype(hase_c)::value, HASD = decltype(hasd_c)::value;
                 half8 ring_h[4];                                        // f16 operand of step st = slab * 4 + square tile, requested 3 steps ahead
                 i32x8_x3 ring_8[3];                                     // e5m2 operand of step q = (64-k step) * 4 + square tile, requested 2 steps ahead
-                auto read_h = [&](int st) {
-                    ring_h[st % 4] = *reinterpret_cast<const half8*>(T.xh + ((st & 3) * 16 + l15) * XROW + (st >> 2) * 32 + lg * 8);
+                auto read_h = [&](int st) {                             // slot slab * 4 + lg of the row, swizzled like t2: (slab ^ g2) * 4 + (lg ^ g0)
+                    const half_t* const pe = (st >> 2) & 1 ? xh_odd : xh_even;
+                    ring_h[st % 4] = *reinterpret_cast<const half8*>(pe + (st & 3) * 16 * XROW + (st >> 3) * 64);
                 };
                 auto read_8 = [&](int q) {                              // lane group lg: 0, 1 = hi8 of k [0, 32), [32, 64) of the step; 2, 3 = lo8 of the same
                     // the byte rows of x hold a 64-k step as the 16-byte pieces A0 B0 A1 B1 (A = k [0, 32), B = k [32, 64): x8_pos): the
                     // two lane groups of a pair then read NEIGHBOURING slots, which with the 544-byte pitch puts the 16 lanes of every
                     // ds_read_b128 group on 16 different slots (linear A0 A1 B0 B1: two lanes per slot, 8 LDS cycles instead of 4 -- a
                     // third of the kernel's bank-conflict cycles, scripts/studies/lds_bank_model.py)
-                    const char* pp = x8 + ((q & 3) * 16 + l15) * X8ROW + (lg >> 1) * 272 + (q >> 2) * 64 + (lg & 1) * 16;
+                    const char* pp = ((q >> 2) & 1 ? x8_odd : x8_even) + (q & 3) * 16 * X8ROW + (q >> 3) * 128;      // (and swizzled like t2: x8_even / x8_odd)
                     ring_8[q % 3] = x3_cat(*reinterpret_cast<const half8*>(pp), *reinterpret_cast<const half8*>(pp + 32));
                 };
                 f32x4 dw_raw[2][REC / 256];
@@ -1972,8 +1979,11 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
                 half4 h;
                 uint32_t h8, l8;
                 split4_b8(v, h, h8, l8);
-                *reinterpret_cast<half4*>(T.xh + rr * XROW + co0) = h;
-                const int cb = x8_pos(co0);                             // (bits 4 and 5 of the channel swapped: read_8)
+                // xh: slot (w * 4 + j) * 2 + lg / 2 of the row, bit 0 ^ g0, bit 2 ^ g2; byte rows: slot w * 4 + (j & 1) * 2 + j / 2 of the
+                // A0 B0 A1 B1 order (x8_pos(co0) / 16), the same two bits swizzled
+                const int ch = ((w * 4 + j) * 2 + (lg >> 1)) ^ g0 ^ (g2 << 2);
+                const int cb = ((w * 4 + (j & 1) * 2 + (j >> 1)) ^ g0 ^ (g2 << 2)) * 16 + lg * 4;
+                *reinterpret_cast<half4*>(T.xh + rr * XROW + ch * 8 + (lg & 1) * 4) = h;
                 *reinterpret_cast<uint32_t*>(x8 + rr * X8ROW + cb) = h8;
                 *reinterpret_cast<uint32_t*>(x8 + rr * X8ROW + 272 + cb) = l8;
             }

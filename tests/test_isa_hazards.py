@@ -11,17 +11,17 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ["forward", "tower", "restower", "head", "stem", "x3", "kernels", "block", "policy_value"]
+FILES = ["forward", "tower", "restower", "head", "stem", "x3", "kernels", "rise_net", "block", "policy_value"]
 
 
 def test_no_reader_in_the_shadow_of_an_mfma(tmp_path):
     from crazyara_amd import build
     nn = os.path.join(ROOT, "crazyara_amd", "csrc", "nn")
-    files = [f for f in FILES if os.path.exists(os.path.join(nn, f + ".hip"))]
+    files = [f for f in FILES if os.path.exists(os.path.join(nn, f + ".hip"))] + ["../chess/planes_kernel"]    # (every .hip of the library)
     assert {"forward", "tower", "restower", "head", "stem", "x3", "kernels"} <= set(files)      # x3 + kernels: the headline forward
     procs = []
     for f in files:
-        out = tmp_path / (f + ".s")
+        out = tmp_path / (os.path.basename(f) + ".s")
         cmd = [build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", *build.device_flags(), "-x", "hip", "--cuda-device-only", "-S",
                os.path.join(nn, f + ".hip"), "-o", str(out)]
         procs.append((f, out, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=str(tmp_path))))

@@ -61,6 +61,11 @@ run_set() {
       pmc_run $prec ${prec}_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_WAVES
       python scripts/pmc_summary.py $OUT/${prec}_sq2 > $OUT/pmc_${prec}_sq2.txt 2>&1; rm -rf $OUT/${prec}_sq2
       grep -h -A12 "tower_p8" $OUT/pmc_${prec}_sq2.txt | head -14 ;;
+    icache)
+      prec=$HEADLINE
+      pmc_run $prec ${prec}_ic1 SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE
+      pmc_run $prec ${prec}_ic2 SQ_IFETCH SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES
+      for p in ic1 ic2; do python scripts/pmc_summary.py $OUT/${prec}_$p > $OUT/pmc_${prec}_$p.txt 2>&1; rm -rf $OUT/${prec}_$p; grep -h -A8 "tower_p8" $OUT/pmc_${prec}_$p.txt | head -9; tail -3 $OUT/${prec}_$p.log; done ;;
     screen)
       timeout 500 python scripts/coresidency_screen.py --batch 64 --configs x3-v2-3 --launches 2000 --out $OUT/screen_batch64.json > $OUT/screen_batch64.txt 2>&1; tail -12 $OUT/screen_batch64.txt
       timeout 900 python scripts/coresidency_screen.py --launches ${SCREEN_LAUNCHES:-1000} --out $OUT/screen.json > $OUT/screen.txt 2>&1; grep -E "RED|RESULT|Error|error" $OUT/screen.txt | head -40 ;;

@@ -1,9 +1,9 @@
 """Why does the reference's own search on HipAPI nets lose going from 4 to 8 SearchThreads?  
 
 The reference's MCTSAgent + SearchThreads (oracle/_ref/libcrazyara_ref_hip_release.so, compiled from /root/reference with its Release
-flags) on HipAPI nets, Batch_Size 256, crazyhouse openings: `Threads` x `go simulations N`.  Per cell: nodes/s, predict() calls per go and
-their fill (the reference always evaluates whole batches: a call costs one forward whatever it holds), host CPU seconds per wall second
-(user + system of the process), the cgroup's throttled time, and -- CRA_WAIT_POLL / blocking sync -- whether the way predict() waits matters.
+flags) on HipAPI nets, Batch_Size 256, crazyhouse openings: `Threads` x `go simulations N`.  Per cell: nodes/s, host CPU seconds per wall
+second (user + system of the process) and the cgroup's throttled time (the reference always evaluates whole batches: a predict() costs one
+forward whatever it holds, and Threads x Batch_Size leaves are in flight on the ONE tree of the go).
 A MEASUREMENT script like bench.py's dropin leg: the product path never runs this code.   python scripts/dropin_threads.py [precision]
 """
 import json
@@ -32,7 +32,6 @@ for sims in (1600, 6400, 25600):
         agent = ref_mcts.RefAgent(st, hip_model_dir=d, device_id=0, precision=precision, threads=th, release=True)
         agent.set_position(fens[0], False, "crazyhouse")
         agent.go(simulations=400)
-        c0 = agent.net_counters()
         ru0, thr0, t0 = resource.getrusage(resource.RUSAGE_SELF), replicas.cgroup_throttled_usec(), time.perf_counter()
         nodes = 0
         use = fens if sims <= 6400 else fens[:4]
@@ -41,13 +40,9 @@ for sims in (1600, 6400, 25600):
             agent.go(simulations=sims)
             nodes += agent.root_info()["node_count"]
         el = time.perf_counter() - t0
-        ru1, thr1, c1 = resource.getrusage(resource.RUSAGE_SELF), replicas.cgroup_throttled_usec(), agent.net_counters()
+        ru1, thr1 = resource.getrusage(resource.RUSAGE_SELF), replicas.cgroup_throttled_usec()
         agent.close()
-        calls = c1["batch_calls"] - c0["batch_calls"]
-        evals = c1["batch_evals"] - c0["batch_evals"]
-        cell = {"nodes_per_sec": round(nodes / el, 1), "predict_calls_per_go": round(calls / len(use), 1),
-                "leaves_per_predict": round(evals / max(1, calls), 1), "fill": round(evals / max(1, calls) / 256.0, 3),
-                "ms_per_predict_call_wall_times_threads": round(el * 1e3 * th / max(1, calls), 3),
+        cell = {"nodes_per_sec": round(nodes / el, 1), "leaves_in_flight": th * 256, "simulations_per_go": sims,
                 "host_cpu_seconds_per_wall_second": round(((ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)) / el, 2),
                 "cgroup_throttled_ms": None if thr0 is None or thr1 is None else round((thr1 - thr0) / 1e3, 1)}
         out["cells"][f"sims{sims}_threads{th}"] = cell

@@ -55,8 +55,10 @@ __device__ unsigned long long x3_trace[2][8][128][2];      // [workgroup 0 | 131
             ++trace_n;                                                                                  \
         }                                                                                               \
     } while (0)
+#define X3_STAMP_SLAB(i_, sl_) do { const int kk = (i_) - 1; X3_STAMP(6); (void)(sl_); } while (0)      // (a k-slab of an EXPAND interval begins)
 #else
 #define X3_STAMP(id) do { } while (0)
+#define X3_STAMP_SLAB(i_, sl_) do { } while (0)
 #endif
 
 namespace {
@@ -1865,6 +1867,7 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
 #pragma unroll
                 for (int sl = 0; sl < C / 32; ++sl) {
                     const int dt = sl / 4, ph = sl % 4;
+                    X3_STAMP_SLAB(i, sl);
                     if constexpr (HASD && KS == 3) {
                         if (ph == 2) dw.template load<1>(my_dws + dt * 256, lg, edge);
                         if (sl == 4) dw.template load<0>(my_dws + 256, lg, edge);

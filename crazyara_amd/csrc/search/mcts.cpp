@@ -86,7 +86,9 @@ int NodeArena::emplace_back() {
     if (table_[c].load(std::memory_order_acquire) == nullptr) {
         std::lock_guard<std::mutex> lk(grow_);
         if (table_[c].load(std::memory_order_acquire) == nullptr) {
-            new (&table_[c]) std::atomic<Node*>(nullptr);               // the object's lifetime starts here (its bytes are already zero)
+            // (no placement-new of the entry here: its write of a null pointer would be a NON-atomic write racing with the unlocked
+            // first check of other collectors -- ThreadSanitizer's report of round 5.  std::atomic<Node*> is an implicit-lifetime type
+            // whose all-zero bytes from mmap are the null pointer; every access to an entry is an atomic operation)
             table_[c].store(new Node[kChunk], std::memory_order_release);
         }
     }

@@ -104,6 +104,27 @@ int main() {
         std::printf("pv length %zu, cp %d, mate %d\n", pv.size(), cp, mate);
         if (pv.empty() || st.seconds > 5.0) return 1;
     }
+    // the stop protocol with overlapping searches (round 5): a commanding thread announces, stops, announces the next go and stops it too
+    // while the search thread is still inside / between run() calls; generations are guarded by a mutex, stop_gen_ is an atomic
+    {
+        SearchPool gen(s, make_callback_evaluator(eval, nullptr, 64, 5184), make_callback_evaluator(eval, nullptr, 64, 5184));
+        for (int i = 0; i < 4; ++i) gen.add_position(p);
+        SearchStats st1, st2, st3;
+        gen.announce_go();
+        std::thread searcher([&] {
+            gen.run(50000000, 0, 4, &st1);                               // search 1: stopped from outside
+            gen.run(50000000, 0, 4, &st2);                               // search 2: announced and stopped while search 1 was running
+            gen.run(uint32_t(gen.tree(0).root_visits()) + 300, 0, 4, &st3);   // search 3: never stopped
+        });
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        gen.request_stop();
+        gen.announce_go();
+        gen.request_stop();
+        searcher.join();
+        std::printf("generations: search 1 %llu, search 2 %llu, search 3 %llu simulations\n", (unsigned long long)st1.simulations,
+                    (unsigned long long)st2.simulations, (unsigned long long)st3.simulations);
+        if (st2.simulations > 4 * 64 || st3.simulations < 100) { std::printf("stop protocol: a stop was lost or leaked\n"); return 1; }
+    }
     std::printf("done\n");
     return 0;
 }

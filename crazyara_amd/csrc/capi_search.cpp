@@ -153,7 +153,7 @@ int mi_search_announce_go(mi_search* sp) {
 
 int mi_search_stop(mi_search* sp) {
     if (!sp) { cra_set_error("null search"); return 1; }
-    sp->pool->request_stop();          // atomics only: safe beside a running mi_search_run of another thread
+    sp->pool->request_stop();          // a short mutex + one atomic store: safe beside a running mi_search_run of another thread
     return 0;
 }
 

@@ -249,7 +249,10 @@ int mi_search_run_timed(mi_search* sp, unsigned simulations, unsigned nodes, uns
  * BEFORE it hands mi_search_run / mi_search_run_timed to its search thread: a stop that arrives between the announcement and the
  * moment the search thread enters the run call is kept and ends that search at once (after the roots are evaluated, so that a best
  * move exists) -- it is sticky for ITS search and never reaches a later one.  A run that was not announced opens its own generation
- * on entry; with nothing announced or running a stop does nothing (MCTSAgent::stop: `if (!isRunning) return`). */
+ * on entry; with nothing announced or running a stop does nothing (MCTSAgent::stop: `if (!isRunning) return`).  Searches may overlap
+ * at this level -- `stop` followed directly by `go` (or ponderhit) announces the next search while the previous run call is still
+ * returning: a stop names every search announced or running at that moment, a run adopts the oldest announcement nobody has run yet,
+ * and the previous run's exit touches neither (tests/test_mcts.py::test_go_announced_before_the_previous_run_returned_keeps_its_stop). */
 int mi_search_announce_go(mi_search* sp);
 int mi_search_stop(mi_search* sp);
 /* root statistics of one tree, children in the node's (prior-sorted) order: returns number of expanded children */

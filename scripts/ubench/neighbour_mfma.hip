@@ -16,9 +16,10 @@
 //                 0 v_mfma_f32_16x16x32_f16 back to back     1 ds_read_b128 rows     2 global_load_dwordx4 stream     3 all three interleaved
 //                 4 v_fma_f32 only (control)                 -1 no aggressor
 //                 5 v_mfma_f32_32x32x16_f16     6 v_mfma_scale_f32_16x16x128_f8f6f4     7 v_mfma_f32_16x16x4_f32
+//                 8 = kind 0 with 120 registers (the SIMD's register file is then not full beside the victim)
 //                 100 = no second kernel: the MIXED kernel, victim waves 0-3 and MFMA waves 4-7 in one workgroup
 //
-// usage: neighbour_mfma.bin <kind> [launches] [victim rounds] [aggressor iterations] [blocks] [victim form 0-7]
+// usage: neighbour_mfma.bin <kind> [launches] [victim rounds] [aggressor iterations] [blocks] [victim form 0-10]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -53,6 +54,7 @@ template <int VK, bool BARRIERS> __device__ __forceinline__ void victim_rounds(c
     float* s_flat = lds;                         // [128] ones (the "flattened conv output"), broadcast reads; [128..255] zeros
     float* s_part = lds + 1024;                  // [4][256]
     const int tid = threadIdx.x, lane = tid & 63, kq = (tid >> 6) & 3;
+    if constexpr (VK == 9 || VK == 10) asm volatile("v_mov_b32 v199, 0" ::: "v199");          // the allocation of the failing compiler form: 200 registers
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
         const int row0 = ((r + salt) * 32) % ROWS;
@@ -119,11 +121,24 @@ template <int VK, bool BARRIERS> __device__ __forceinline__ void victim_rounds(c
                     const f32x2 lo = {w[4 * q + e][0], w[4 * q + e][1]}, hi = {w[4 * q + e][2], w[4 * q + e][3]}, gg = {f[e], f[e]};
                     asm volatile("v_pk_fma_f32 %0, %2, %4, %0\n\tv_pk_fma_f32 %1, %3, %4, %1" : "+v"(hl), "+v"(hh) : "v"(lo), "v"(hi), "v"(gg));
                     h = f32x4{hl[0], hl[1], hh[0], hh[1]};
-                } else if constexpr (VK == 6 || VK == 7) {   // the compiler's forms: the factor is ONE dword of a pair, picked by op_sel
+                } else if constexpr (VK == 8 || VK == 10) {  // BOTH forms alternating on one pair of factors, as the compiler writes FC1's chain
+                    if constexpr ((0) == 0) {
+                        if ((e & 1) == 0) {
+                            f32x2 hl = {h[0], h[1]}, hh = {h[2], h[3]};
+                            const f32x2 lo0 = {w[4 * q + e][0], w[4 * q + e][1]}, hi0 = {w[4 * q + e][2], w[4 * q + e][3]};
+                            const f32x2 lo1 = {w[4 * q + e + 1][0], w[4 * q + e + 1][1]}, hi1 = {w[4 * q + e + 1][2], w[4 * q + e + 1][3]};
+                            const f32x2 gg = {f[e], f[e + 1]};
+                            asm volatile("v_pk_fma_f32 %0, %2, %6, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %6, %1 op_sel_hi:[1,0,1]\n\t"
+                                         "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[0,1,0]\n\tv_pk_fma_f32 %1, %5, %6, %1 op_sel:[0,1,0]"
+                                         : "+v"(hl), "+v"(hh) : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(gg));
+                            h = f32x4{hl[0], hl[1], hh[0], hh[1]};
+                        }
+                    }
+                } else if constexpr (VK == 6 || VK == 7 || VK == 9) {   // the compiler's forms: the factor is ONE dword of a pair, picked by op_sel
                     f32x2 hl = {h[0], h[1]}, hh = {h[2], h[3]};
                     const f32x2 lo = {w[4 * q + e][0], w[4 * q + e][1]}, hi = {w[4 * q + e][2], w[4 * q + e][3]};
-                    const f32x2 gg = VK == 6 ? f32x2{f[e], 777.f} : f32x2{777.f, f[e]};
-                    if constexpr (VK == 6)       // both halves take src1's LOW dword
+                    const f32x2 gg = VK != 7 ? f32x2{f[e], 777.f} : f32x2{777.f, f[e]};
+                    if constexpr (VK != 7)       // both halves take src1's LOW dword
                         asm volatile("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel_hi:[1,0,1]" : "+v"(hl), "+v"(hh) : "v"(lo), "v"(hi), "v"(gg));
                     else                         // both halves take src1's HIGH dword
                         asm volatile("v_pk_fma_f32 %0, %2, %4, %0 op_sel:[0,1,0]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel:[0,1,0]" : "+v"(hl), "+v"(hh) : "v"(lo), "v"(hi), "v"(gg));
@@ -199,7 +214,8 @@ template <int VK> __global__ __launch_bounds__(512) void mixed(const float* __re
 template <int KIND> __global__ __launch_bounds__(512) void aggressor(const float* __restrict__ buf, float* sink, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    asm volatile("v_mov_b32 v151, 0" ::: "v151");                 // 152 registers: 2 x 152 + the victim's 208 = 512, the two fit one SIMD exactly
+    if constexpr (KIND == 8) asm volatile("v_mov_b32 v119, 0" ::: "v119");          // 120 registers: 2 x 120 + 200 = 440, the register file is NOT full
+    else asm volatile("v_mov_b32 v151, 0" ::: "v151");            // 152 registers: 2 x 152 + the victim's 200 = 504, the pair fills the SIMD's register file
     for (int i = tid; i < 8192; i += 512) lds[i] = 0.001f * float(i & 255);
     __syncthreads();
     f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -214,7 +230,7 @@ template <int KIND> __global__ __launch_bounds__(512) void aggressor(const float
 #pragma unroll
     for (int i = 0; i < 8; ++i) { a8[i] = 0x38383838 + lane; b8[i] = 0x34343434 + i; }
     for (int it = 0; it < iters; ++it) {
-        if constexpr (KIND == 0 || KIND == 3) {
+        if constexpr (KIND == 0 || KIND == 3 || KIND == 8) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[u & 3], 0, 0, 0);
         }
@@ -279,6 +295,7 @@ int main(int argc, char** argv) {
             if (vk == 1) hipLaunchKernelGGL(mixed<1>, dim3(blocks), dim3(512), vlds, sv, buf, report, count, sink, rounds, l, iters);
             else if (vk == 6) hipLaunchKernelGGL(mixed<6>, dim3(blocks), dim3(512), vlds, sv, buf, report, count, sink, rounds, l, iters);
             else if (vk == 7) hipLaunchKernelGGL(mixed<7>, dim3(blocks), dim3(512), vlds, sv, buf, report, count, sink, rounds, l, iters);
+            else if (vk == 8) hipLaunchKernelGGL(mixed<8>, dim3(blocks), dim3(512), vlds, sv, buf, report, count, sink, rounds, l, iters);
             else hipLaunchKernelGGL(mixed<5>, dim3(blocks), dim3(512), vlds, sv, buf, report, count, sink, rounds, l, iters);
         }
         else if (vk == 1) hipLaunchKernelGGL(victim<1>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
@@ -288,6 +305,9 @@ int main(int argc, char** argv) {
         else if (vk == 5) hipLaunchKernelGGL(victim<5>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         else if (vk == 6) hipLaunchKernelGGL(victim<6>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         else if (vk == 7) hipLaunchKernelGGL(victim<7>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        else if (vk == 8) hipLaunchKernelGGL(victim<8>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        else if (vk == 9) hipLaunchKernelGGL(victim<9>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        else if (vk == 10) hipLaunchKernelGGL(victim<10>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         else hipLaunchKernelGGL(victim<0>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         switch (kind) {
             case 0: hipLaunchKernelGGL(aggressor<0>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
@@ -298,6 +318,7 @@ int main(int argc, char** argv) {
             case 5: hipLaunchKernelGGL(aggressor<5>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
             case 6: hipLaunchKernelGGL(aggressor<6>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
             case 7: hipLaunchKernelGGL(aggressor<7>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
+            case 8: hipLaunchKernelGGL(aggressor<8>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
             default: break;
         }
         if ((l & 31) == 31) { CHECK(hipStreamSynchronize(sv)); CHECK(hipStreamSynchronize(sa)); }
@@ -307,7 +328,7 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> rep(512 * 9);
     CHECK(hipMemcpy(&n, count, 4, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(rep.data(), report, rep.size() * 4, hipMemcpyDeviceToHost));
-    printf("victim form %d (0 v_pk_fma_f32, 1 v_fmac_f32, 2 v_pk_fma_f32 on register-made words, 3 v_pk_mul_f32, 4 v_pk_add_f32, 5 v_pk_fma_f32 plain, 6 op_sel_hi:[1,0,1], 7 op_sel:[0,1,0]), aggressor kind %d%s: %u mismatches in %d victim launches (%d blocks x 4 waves x %d rounds x 128 loaded words)\n", vk, kind, kind == 100 ? " (MIXED: both roles in one workgroup)" : "", n, launches, blocks, rounds);
+    printf("victim form %d (0 v_pk_fma_f32, 1 v_fmac_f32, 2 v_pk_fma_f32 on register-made words, 3 v_pk_mul_f32, 4 v_pk_add_f32, 5 v_pk_fma_f32 plain, 6 op_sel_hi:[1,0,1], 7 op_sel:[0,1,0], 8 both forms alternating, 9 = 6 and 10 = 8 padded to 200 registers), aggressor kind %d%s: %u mismatches in %d victim launches (%d blocks x 4 waves x %d rounds x 128 loaded words)\n", vk, kind, kind == 100 ? " (MIXED: both roles in one workgroup)" : "", n, launches, blocks, rounds);
     for (uint32_t k = 0; k < n && k < 40; ++k) {
         const uint32_t* o = rep.data() + k * 9;
         printf("  %c block %u wave %u lane %u load %u word %u: expected %g found %g  hw_id %08x (simd %u cu %u sh %u se %u)\n", char(o[0]), o[1], o[2], o[3], o[4],

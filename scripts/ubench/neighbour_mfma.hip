@@ -1,7 +1,18 @@
-// Which kind of neighbour on the compute unit makes an FC1-shaped wave lose a word?  (profiles/NOTES.md rounds 4 and 5: value_head_kernel's
-// FC1 sums came out wrong in lanes 48-63 of one register whenever workgroups of conv_gemm_x3_kernel<3, 1, 8, 4> shared its compute unit;
-// round 4's passive victim beside VALU / LDS-permute / store neighbours stayed clean, but never had a neighbour that issues MFMAs, streams
-// 16-byte loads or reads 16-byte LDS rows -- the three things that conv does.)
+// REPRODUCER (gfx950 / MI355X, ROCm 7.2): v_pk_fma_f32 gives wrong results when a wave of ANOTHER workgroup on the same SIMD issues
+// v_mfma_f32_16x16x32_f16.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 neighbour_mfma.hip -o neighbour_mfma.bin
+//   ./neighbour_mfma.bin 0 3000 8 600 64 8     ->  ~9 million wrong sums in 3000 launches (always lanes 48-63, always the LOW half of the packed result)
+//   ./neighbour_mfma.bin 0 3000 8 600 64 6     ->  0   (the same chain with only op_sel_hi:[1,0,1]; form 7: only op_sel:[0,1,0]; form 5: plain; form 1: v_fmac_f32)
+//   ./neighbour_mfma.bin 5 3000 8 600 64 8     ->  0   (neighbour on v_mfma_f32_32x32x16_f16; 6: 16x16x128 f8f6f4; 7: 16x16x4 f32; 4: v_fma_f32; -1: none)
+//   ./neighbour_mfma.bin 100 3000 8 600 64 8   ->  0   (the same two roles as waves of ONE workgroup)
+// Victim condition: a dependent chain of v_pk_fma_f32 that reads ONE VGPR pair as src1 first with op_sel_hi:[1,0,1] (low dword for both halves)
+// and then with op_sel:[0,1,0] (high dword for both halves) -- what hipcc makes of `h += w[i] * f[i]; h += w[i + 1] * f[i + 1]` on float4
+// accumulators with (f[i], f[i + 1]) in one register pair (form 0).  How full the SIMD's register file is does not matter (kind 8).
+//
+// History: which kind of neighbour on the compute unit makes an FC1-shaped wave lose a word?  (profiles/NOTES.md rounds 4 and 5:
+// value_head_kernel's FC1 sums came out wrong in lanes 48-63 of one register whenever workgroups of conv_gemm_x3_kernel<3, 1, 8, 4> shared
+// its compute unit; round 4's passive victim beside VALU / LDS-permute / store neighbours stayed clean, but never had a neighbour that
+// issues MFMAs, streams 16-byte loads or reads 16-byte LDS rows -- the three things that conv does.)
 //
 //   victim    : value_head_kernel's FC1 loop and geometry -- 256 threads = one wave per SIMD, ~200 VGPRs, 44 KB of LDS; per round every lane
 //               requests 32 x 16 bytes (a 1 KiB row per wave and load, all 32 in flight), then

@@ -30,7 +30,7 @@
 //                 8 = kind 0 with 120 registers (the SIMD's register file is then not full beside the victim)
 //                 100 = no second kernel: the MIXED kernel, victim waves 0-3 and MFMA waves 4-7 in one workgroup
 //
-// usage: neighbour_mfma.bin <kind> [launches] [victim rounds] [aggressor iterations] [blocks] [victim form 0-10]
+// usage: neighbour_mfma.bin <kind> [launches] [victim rounds] [aggressor iterations] [blocks] [victim form 0-11]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -132,6 +132,18 @@ template <int VK, bool BARRIERS> __device__ __forceinline__ void victim_rounds(c
                     const f32x2 lo = {w[4 * q + e][0], w[4 * q + e][1]}, hi = {w[4 * q + e][2], w[4 * q + e][3]}, gg = {f[e], f[e]};
                     asm volatile("v_pk_fma_f32 %0, %2, %4, %0\n\tv_pk_fma_f32 %1, %3, %4, %1" : "+v"(hl), "+v"(hh) : "v"(lo), "v"(hi), "v"(gg));
                     h = f32x4{hl[0], hl[1], hh[0], hh[1]};
+                } else if constexpr (VK == 11) {             // the same alternation on PACKED F16 (v_pk_fma_f16: the float16 kernels' depthwise instruction)
+                    if ((e & 1) == 0) {
+                        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                        half2v hl = {_Float16(h[0]), _Float16(h[1])}, hh = {_Float16(h[2]), _Float16(h[3])};
+                        const half2v lo0 = {_Float16(w[4 * q + e][0]), _Float16(w[4 * q + e][1])}, hi0 = {_Float16(w[4 * q + e][2]), _Float16(w[4 * q + e][3])};
+                        const half2v lo1 = {_Float16(w[4 * q + e + 1][0]), _Float16(w[4 * q + e + 1][1])}, hi1 = {_Float16(w[4 * q + e + 1][2]), _Float16(w[4 * q + e + 1][3])};
+                        const half2v gg = {_Float16(f[e]), _Float16(f[e + 1])};
+                        asm volatile("v_pk_fma_f16 %0, %2, %6, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f16 %1, %3, %6, %1 op_sel_hi:[1,0,1]\n\t"
+                                     "v_pk_fma_f16 %0, %4, %6, %0 op_sel:[0,1,0]\n\tv_pk_fma_f16 %1, %5, %6, %1 op_sel:[0,1,0]"
+                                     : "+v"(hl), "+v"(hh) : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(gg));
+                        h = f32x4{float(hl[0]), float(hl[1]), float(hh[0]), float(hh[1])};
+                    }
                 } else if constexpr (VK == 8 || VK == 10) {  // BOTH forms alternating on one pair of factors, as the compiler writes FC1's chain
                     if constexpr ((0) == 0) {
                         if ((e & 1) == 0) {
@@ -319,6 +331,7 @@ int main(int argc, char** argv) {
         else if (vk == 8) hipLaunchKernelGGL(victim<8>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         else if (vk == 9) hipLaunchKernelGGL(victim<9>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         else if (vk == 10) hipLaunchKernelGGL(victim<10>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
+        else if (vk == 11) hipLaunchKernelGGL(victim<11>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         else hipLaunchKernelGGL(victim<0>, dim3(blocks), dim3(256), vlds, sv, buf, report, count, dump, rounds, l);
         switch (kind) {
             case 0: hipLaunchKernelGGL(aggressor<0>, dim3(blocks), dim3(512), alds, sa, buf, sink, iters); break;
@@ -339,7 +352,7 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> rep(512 * 9);
     CHECK(hipMemcpy(&n, count, 4, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(rep.data(), report, rep.size() * 4, hipMemcpyDeviceToHost));
-    printf("victim form %d (0 v_pk_fma_f32, 1 v_fmac_f32, 2 v_pk_fma_f32 on register-made words, 3 v_pk_mul_f32, 4 v_pk_add_f32, 5 v_pk_fma_f32 plain, 6 op_sel_hi:[1,0,1], 7 op_sel:[0,1,0], 8 both forms alternating, 9 = 6 and 10 = 8 padded to 200 registers), aggressor kind %d%s: %u mismatches in %d victim launches (%d blocks x 4 waves x %d rounds x 128 loaded words)\n", vk, kind, kind == 100 ? " (MIXED: both roles in one workgroup)" : "", n, launches, blocks, rounds);
+    printf("victim form %d (0 v_pk_fma_f32, 1 v_fmac_f32, 2 v_pk_fma_f32 on register-made words, 3 v_pk_mul_f32, 4 v_pk_add_f32, 5 v_pk_fma_f32 plain, 6 op_sel_hi:[1,0,1], 7 op_sel:[0,1,0], 8 both forms alternating, 9 = 6 and 10 = 8 padded to 200 registers, 11 = 8 on v_pk_fma_f16), aggressor kind %d%s: %u mismatches in %d victim launches (%d blocks x 4 waves x %d rounds x 128 loaded words)\n", vk, kind, kind == 100 ? " (MIXED: both roles in one workgroup)" : "", n, launches, blocks, rounds);
     for (uint32_t k = 0; k < n && k < 40; ++k) {
         const uint32_t* o = rep.data() + k * 9;
         printf("  %c block %u wave %u lane %u load %u word %u: expected %g found %g  hw_id %08x (simd %u cu %u sh %u se %u)\n", char(o[0]), o[1], o[2], o[3], o[4],

@@ -1008,7 +1008,7 @@ def main():
                              "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4)},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:                      # (rank 0 at N = 1 only: the other ranks of a node would wait for it)
             full["cpu_baseline"] = cpu_baseline(cfg, sd, x)
         if pcie is not None:
             # SURVEY 8(d) Metric 1 is CrazyAra's `inference` loop INCLUDING the host copies (crazyara.cpp:156-181): one blocking user

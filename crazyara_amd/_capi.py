@@ -84,6 +84,7 @@ SIGNATURES = {
     "mi_search_run_timed": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_void_p]),
     "mi_search_stop": (C.c_int, [C.c_void_p]),
     "mi_search_announce_go": (C.c_int, [C.c_void_p]),
+    "mi_search_cancel_go": (C.c_int, [C.c_void_p]),
     "mi_search_pv_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), c_float_p]),
     "mi_time_for_move": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mi_search_pv": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

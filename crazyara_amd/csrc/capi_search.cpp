@@ -151,6 +151,11 @@ int mi_search_announce_go(mi_search* sp) {
     return 0;
 }
 
+int mi_search_cancel_go(mi_search* sp) {
+    if (!sp) { cra_set_error("null search"); return -1; }
+    return sp->pool->cancel_go() ? 1 : 0;
+}
+
 int mi_search_stop(mi_search* sp) {
     if (!sp) { cra_set_error("null search"); return 1; }
     sp->pool->request_stop();          // a short mutex + one atomic store: safe beside a running mi_search_run of another thread

@@ -118,6 +118,25 @@ struct X3TowerArgs {
     int symmetric;        // development (CRA_X3_TOWER=symmetric when the net was made): float16x3's 3x3 runs on tower_x3_kernel, every wave all three phases
 };
 void launch_tower_x3(const X3TowerArgs& a, hipStream_t s);
+// Small batches (round 6): ONE 3x3 bottleneck block per launch with G workgroups per board (x3.hip: block_x3_split_kernel).  Workgroup g of a
+// board stages the whole board (every workgroup needs all 256 input channels of the expand GEMM), runs the chunks [g n / G, (g + 1) n / G) of
+// the block's n = C_op / 128 chunks through expand -> depthwise -> project (float16x3 arithmetic, x3_chunks) and ADDS its partial project sums
+// -- workgroup 0 also the residual x + b3 -- to the block's output as 64-bit FIXED-POINT integers (2^-32 units, atomic adds): integer sums
+// do not depend on the order the workgroups arrive in, so the forward is run-to-run identical, which float atomics would not give.  The next
+// launch reads the sum back as floats while it stages.  Three accumulators rotate: launch k reads q[k % 3], adds into q[(k + 1) % 3] and
+// clears q[(k + 2) % 3] for the launch behind it; launch_x3_split_finish turns the last sum into the float stream the heads read and clears
+// the first launch's accumulator for the next forward.  One board per workgroup costs a batch of ONE the whole tower's latency on one CU
+// (0.46 ms for RISEv2-19); this form spreads a board's block over up to n CUs.
+struct X3SplitArgs {
+    X3TowerBlock blk;         // this launch's block (SE gate, if any, computed by every workgroup from the staged board)
+    const float* x_f;         // the run's FIRST block: the stream as float [B][64][256]; else nullptr
+    const long long* x_q;     // else: the stream as the previous launch's fixed-point sum [B][64][256]
+    long long* y_q;           // this block's sum
+    long long* zero_q;        // cleared here (the next launch's y_q)
+    int batch, G;             // grid = (G, batch); 1 <= G <= cop_pad / 128
+};
+void launch_block_x3_split(const X3SplitArgs& a, hipStream_t s);
+void launch_x3_split_finish(const long long* x_q, float* y, long long* zero_q, int batch, hipStream_t s);    // y = float(x_q); zero_q := 0 (may be x_q itself)
 template <typename T> void init_block_kernel_attributes();
 template <typename T> int block_chunk_channels();   // C_op must be padded to a multiple of this
 

@@ -207,7 +207,7 @@ std::vector<float> pack_x3_depthwise_records5(const Folded& bn1, const Folded& d
     return rec;
 }
 
-enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower, Forward, TowerX3 };
+enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower, Forward, TowerX3, BlockX3Split, X3SplitFinish };
 
 struct Op {
     OpKind kind;
@@ -227,6 +227,8 @@ struct Op {
     ResTowerArgs rt{};
     StemArgs st{};
     X3TowerArgs tx{};
+    X3SplitArgs xs{};             // BlockX3Split; X3SplitFinish: x_q, zero_q, batch and (as y) the float stream
+    float* xs_y = nullptr;
 };
 }  // namespace
 
@@ -293,6 +295,10 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     if (prec.size() > 3 && prec.compare(prec.size() - 3, 3, "-8w") == 0) {   // dense tower: 8 thin waves instead of 4 fat ones
         rt_thin_waves_ = true;
         prec.resize(prec.size() - 3);
+    }
+    if (prec.size() > 4 && prec.compare(prec.size() - 4, 4, "-1wg") == 0) {  // float16x3 / float16p8: one workgroup per board also for small batches
+        board_split_ = false;
+        prec.resize(prec.size() - 4);
     }
     if (prec.size() > 3 && (prec.compare(prec.size() - 3, 3, "-1b") == 0 || prec.compare(prec.size() - 3, 3, "-2b") == 0)) {
         boards_per_wg_ = prec[prec.size() - 2] - '0';
@@ -624,8 +630,44 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     // Precision float16x3: runs of consecutive 3x3 blocks in one launch (x3.hip: tower_x3_kernel)
     std::vector<X3TowerBlock> x3_blocks;
     int x3_run_ks = 3;                     // a run is all 3x3 or all 5x5 blocks (tower_x3_roles_kernel<KS>, tower_p8_kernel<KS>)
+    // small batches: 3x3 runs one block per launch, several workgroups per board (kernels.h: X3SplitArgs)
+    const bool x3_split = x3_ && tower_ && fused_ && C == 256 && board_split_ && B <= kBoardSplitMaxBatch;
+    long long* split_q[3] = {nullptr, nullptr, nullptr};
     auto flush_x3_tower = [&]() {
         if (x3_blocks.empty()) return;
+        if (x3_split && x3_run_ks == 3) {
+            if (!split_q[0]) {
+                for (auto& q : split_q) {
+                    q = static_cast<long long*>(im.dalloc(size_t(B) * kSquares * C * sizeof(long long)));
+                    HIP_CHECK(hipMemset(q, 0, size_t(B) * kSquares * C * sizeof(long long)));
+                }
+            }
+            const int max_g = std::max(1, std::min(16, cu_count_ / B));
+            const int nb = int(x3_blocks.size());
+            for (int k = 0; k < nb; ++k) {
+                Op op;
+                op.kind = OpKind::BlockX3Split;
+                op.xs.blk = x3_blocks[k];
+                op.xs.x_f = k == 0 ? reinterpret_cast<const float*>(cur) : nullptr;
+                op.xs.x_q = k == 0 ? nullptr : split_q[k % 3];
+                op.xs.y_q = split_q[(k + 1) % 3];
+                op.xs.zero_q = split_q[(k + 2) % 3];
+                op.xs.batch = B;
+                op.xs.G = std::min(max_g, x3_blocks[k].cop_pad / block_x3_chunk_channels());
+                im.ops.push_back(op);
+            }
+            Op fin;
+            fin.kind = OpKind::X3SplitFinish;
+            fin.xs.x_q = split_q[nb % 3];
+            fin.xs.zero_q = split_q[1];                  // the first launch of the next forward (or of this forward's next run) adds into q[1]
+            fin.xs.batch = B;
+            fin.xs_y = reinterpret_cast<float*>(nxt);
+            im.ops.push_back(fin);
+            x3_blocks.clear();
+            prod_op = -1;
+            std::swap(cur, nxt);
+            return;
+        }
         Op op;
         op.kind = OpKind::TowerX3;
         op.tx.x = reinterpret_cast<const float*>(cur);
@@ -786,7 +828,8 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         const bool in_x3_tower = x3_ && tower_ && fused_ && C == 256 && (k == 3 || k == 5);
         if (!in_x3_tower || (!x3_blocks.empty() && x3_run_ks != k)) flush_x3_tower();
         if (in_x3_tower && x3_blocks.empty()) x3_run_ks = k;
-        const bool x3_se_in_kernel = in_x3_tower && (!x3_blocks.empty() || p8_);  // float16x3: the first block of a run takes its gate from an SE launch
+        const bool split_block = in_x3_tower && x3_split && k == 3;        // small batches: this block runs on block_x3_split_kernel (float16x3 images, own gate)
+        const bool x3_se_in_kernel = in_x3_tower && (!x3_blocks.empty() || p8_ || split_block);  // float16x3: the first block of a run takes its gate from an SE launch
         X3TowerBlock xb{};
         if (se_types[i] == "ca_se" || se_types[i] == "se") {           // _ChannelAttentionModule, builder_util.py:83-114
             const TensorView &w1 = nf.get(p + ".se.fc.0.weight"), &w2 = nf.get(p + ".se.fc.2.weight");
@@ -969,8 +1012,9 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
             Folded f2 = fold_bn(nf, p + ".body.3", p + ".body.4");
             Folded f3 = fold_bn(nf, p + ".body.6", p + ".body.7");
             double w1_inv = 1.0, w3_inv = 1.0;
-            SplitPack s1 = p8_ ? pack_dense_p8(f1, cop, C, 1, cop_pad, C, &w1_inv) : pack_dense_split(f1, cop, C, 1, cop_pad, C);
-            SplitPack s3 = p8_ ? pack_dense_p8(f3, C, cop, 1, C, cop_pad, &w3_inv) : pack_dense_split(f3, C, cop, 1, C, cop_pad);
+            const bool p8_images = p8_ && !split_block;
+            SplitPack s1 = p8_images ? pack_dense_p8(f1, cop, C, 1, cop_pad, C, &w1_inv) : pack_dense_split(f1, cop, C, 1, cop_pad, C);
+            SplitPack s3 = p8_images ? pack_dense_p8(f3, C, cop, 1, C, cop_pad, &w3_inv) : pack_dense_split(f3, C, cop, 1, C, cop_pad);
             xb.w1pk = im.upload(s1.hi);
             xb.w1pk_lo = im.upload(s1.lo);
             xb.w3pk = im.upload(s3.hi);
@@ -1457,6 +1501,8 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
         }
         case OpKind::ResTower: launch_restower(op.rt, s); break;
         case OpKind::TowerX3: launch_tower_x3(op.tx, s); break;
+        case OpKind::BlockX3Split: launch_block_x3_split(op.xs, s); break;
+        case OpKind::X3SplitFinish: launch_x3_split_finish(op.xs.x_q, op.xs_y, op.xs.zero_q, op.xs.batch, s); break;
         case OpKind::Stem: {
             StemArgs st = op.st;
             st.planes = planes;
@@ -1503,6 +1549,8 @@ const char* RiseNet::op_name(int i) const {
         case OpKind::Stem: return "stem";
         case OpKind::Forward: return "forward";
         case OpKind::TowerX3: return op.tx.p8 ? "tower_p8" : "tower_x3";
+        case OpKind::BlockX3Split: return "block_x3_split";
+        case OpKind::X3SplitFinish: return "x3_split_finish";
     }
     return "?";
 }

@@ -15,14 +15,18 @@
 #include "kernels.h"
 #include "device_utils.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <stdexcept>
 #include <type_traits>
 
 // CRA_X3_ABL: development switches that TIME parts of the tower's chunk loop (scripts/ubench/x3_tower_ablate.hip); every bit computes wrong
 // results on purpose, so they only compile in a development build.  1: no depthwise arithmetic, 2: no expand MFMAs, 4: no project MFMAs,
 // 8: no LDS operand reads (expand and project), 16: no weight loads, 32: no chunk barriers, 64: no t2 stores, 128: the expand GEMM issues
-// the mixed split's instruction mix (per 64 k two f16 MFMAs and one 8-bit 16x16x128 on whatever the registers hold), 256 (tower_p8_kernel):
-// a quarter of the depthwise moves from the EXPAND to the PROJECT waves (on whatever LDS holds)
+// the mixed split's instruction mix (per 64 k two f16 MFMAs and one 8-bit 16x16x128 on whatever the registers hold); tower_p8_kernel
+// honours 1, 2, 4, 16, 64 and (round 6, the weight-port question) 512: the 8-bit weight images are fetched at HALF size -- one 16-byte
+// piece per lane and 64-k step, the other half a register copy -- i.e. the L2 -> CU stream of a 3-bytes-per-weight layout with its byte
+// permutes stood in for by the copies; 1024: no 8-bit weight fetches at all (2 bytes per weight)
 #ifndef CRA_X3_ABL
 #define CRA_X3_ABL 0
 #endif
@@ -942,13 +946,14 @@ __device__ __forceinline__ half8 x3_frag(__amdgpu_buffer_rsrc_t r, uint32_t lane
 // Measured and NOT kept (profiles/r03/o_*): P(ch - 1) and D(ch) as one instruction stream per wave (the depthwise cut in four pieces
 // between the project MFMAs, sched_group_barrier recipes): 0.754 ms against 0.710 for this form -- 256 registers with spills, and the
 // scheduler interleaved only half of the stretches.
-__device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, f32x4 (&accP)[X3Block::NJ][4]) {
+// ch0 / ch1: the chunk range [ch0, ch1) of the block (block_x3_split_kernel); default: all of them.
+__device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, f32x4 (&accP)[X3Block::NJ][4], int ch0 = 0, int ch1 = -1) {
     using G = X3Block;
     constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NJ = G::NJ, NE = G::NE;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lane_off = uint32_t(lane) * 16u;
-    const int nchunk = W.cop_pad / CK;
+    const int nchunk = ch1 < 0 ? W.cop_pad / CK : ch1;
     const int nslab3 = W.cop_pad >> 5;
     const bool hi = l15 >= 8;                                  // the tile's second rank (t + 4, x3_row)
     const X3EdgeOffsets edge = x3_edge_offsets(l15);             // a lane on file a / h has no left / right neighbour on the board
@@ -975,8 +980,8 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
         }
     };
 #pragma unroll
-    for (int s = 0; s < EW; ++s) load_expand(0, s);
-    for (int ch = 0; ch < nchunk; ++ch) {
+    for (int s = 0; s < EW; ++s) load_expand(ch0, s);
+    for (int ch = ch0; ch < nchunk; ++ch) {
         half_t* const t2h = T.t2h + (G::T2BUF == 2 ? (ch & 1) * 64 * TROW : 0);
         half_t* const t2l = T.t2l + (G::T2BUF == 2 ? (ch & 1) * 64 * TROW : 0);
         // ---------------- E: expand, NE x 16 channels x 64 squares per wave, K = C; a tile fragment of the stream feeds NE channel tiles ----
@@ -1332,6 +1337,108 @@ __global__ __launch_bounds__(512) void tower_x3_kernel(const X3TowerArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) fh[j] += fl[j];
         store8<float>(yb + size_t(sq) * C + v * 8, fh);
+    }
+}
+
+// ---- small batches: one block per launch, G workgroups per board (kernels.h: X3SplitArgs) ----
+namespace {
+// float <-> 64-bit fixed point in units of 2^-32 (|v| < 2^31).  v - floor(v) is exact except where it rounds up to 1 (a negative v of tiny
+// magnitude): the clamp keeps that inside the low word, an error below the unit.  The way back rounds twice (low word to 24 bits, then the
+// sum): a fixed function of the integer, the same on every launch.
+__device__ __forceinline__ long long x3_to_fixed(float v) {
+    const float fl = floorf(v);
+    const float fr = fminf((v - fl) * 4294967296.f, 4294967040.f);
+    return (static_cast<long long>(static_cast<int>(fl)) << 32) | static_cast<long long>(static_cast<unsigned>(fr));
+}
+__device__ __forceinline__ float x3_from_fixed(long long q) {
+    return fmaf(static_cast<float>(static_cast<unsigned>(q)), 2.3283064365386963e-10f, static_cast<float>(static_cast<int>(q >> 32)));
+}
+// fixed-point board tile [64][256] -> split tiles
+__device__ __forceinline__ void x3_stage_tile_fixed(const X3Tiles& T, const long long* xq, int tid) {
+    constexpr int C = X3Block::C, XROW = X3Block::XROW;
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll 1
+    for (int i = tid; i < 64 * (C / 8); i += X3Block::NTHR) {
+        const int sq = i / (C / 8), v = i - sq * (C / 8), r = x3_row(sq);
+        const i64x2* p = reinterpret_cast<const i64x2*>(xq + size_t(sq) * C + v * 8);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64x2 q = p[j];
+            f[2 * j] = x3_from_fixed(q.x);
+            f[2 * j + 1] = x3_from_fixed(q.y);
+        }
+        half8 h, l;
+        split8(f, h, l);
+        *reinterpret_cast<half8*>(T.xh + r * XROW + v * 8) = h;
+        *reinterpret_cast<half8*>(T.xl + r * XROW + v * 8) = l;
+    }
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) void block_x3_split_kernel(const X3SplitArgs a) {
+    using G = X3Block;
+    constexpr int C = G::C, CK = G::CK, XROW = G::XROW, NJ = G::NJ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const X3Tiles T = x3_tiles(smem);
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const X3TowerBlock& d = a.blk;
+    if (a.x_f) x3_stage_tile(T, a.x_f + size_t(b) * 64 * C, nullptr, tid);
+    else x3_stage_tile_fixed(T, a.x_q + size_t(b) * 64 * C, tid);
+    {   // this workgroup's share of the accumulator behind the next one
+        typedef long long i64x2 __attribute__((ext_vector_type(2)));
+        const int per = 64 * C / 2 / int(gridDim.x);                   // 16-byte pieces per workgroup (G divides 8192: G <= 10 is checked by the launcher)
+        i64x2* z = reinterpret_cast<i64x2*>(a.zero_q + size_t(b) * 64 * C) + size_t(g) * per;
+        const int n2 = g + 1 == int(gridDim.x) ? 64 * C / 2 - g * per : per;
+        for (int i = tid; i < n2; i += G::NTHR) z[i] = i64x2{0, 0};
+    }
+    __syncthreads();
+    if (d.se_kind != 0) x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid);      // every workgroup of the board: the same gate, the same gated tiles
+    const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
+    const int n = W.cop_pad / CK;
+    const int ch0 = __builtin_amdgcn_readfirstlane(g * n / int(gridDim.x)), ch1 = __builtin_amdgcn_readfirstlane((g + 1) * n / int(gridDim.x));
+    f32x4 accP[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const f32x4 bs = g == 0 ? *reinterpret_cast<const f32x4*>(d.b3 + (wave * NJ + j) * 16 + lg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accP[j][t] = bs;
+    }
+    x3_chunks(T, W, accP, ch0, ch1);
+    // epilogue: this workgroup's part of x + b3 + body(x) -> the block's sum (workgroup 0 carries x and b3)
+    unsigned long long* yq = reinterpret_cast<unsigned long long*>(a.y_q + size_t(b) * 64 * C);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int co0 = (wave * NJ + j) * 16 + lg * 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int sq = t * 16 + l15;
+            float v[4] = {accP[j][t][0], accP[j][t][1], accP[j][t][2], accP[j][t][3]};
+            if (g == 0) {
+                float rh[4], rl[4];
+                load4<half_t>(T.xh + sq * XROW + co0, rh);
+                load4<half_t>(T.xl + sq * XROW + co0, rl);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rh[r] + rl[r];
+            }
+            unsigned long long* dst = yq + size_t(x3_square(sq)) * C + co0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                (void)__hip_atomic_fetch_add(dst + r, static_cast<unsigned long long>(x3_to_fixed(v[r])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// the last block's sum -> the float stream [B][64][256]; clears zero_q (the first launch's accumulator of the NEXT forward; it may be x_q itself:
+// a thread clears what it has just read)
+__global__ __launch_bounds__(256) void x3_split_finish_kernel(const long long* x_q, float* y, long long* zero_q, int n4) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const i64x2 q0 = reinterpret_cast<const i64x2*>(x_q)[2 * i], q1 = reinterpret_cast<const i64x2*>(x_q)[2 * i + 1];
+        reinterpret_cast<f32x4*>(y)[i] = f32x4{x3_from_fixed(q0.x), x3_from_fixed(q0.y), x3_from_fixed(q1.x), x3_from_fixed(q1.y)};
+        reinterpret_cast<i64x2*>(zero_q)[2 * i] = i64x2{0, 0};
+        reinterpret_cast<i64x2*>(zero_q)[2 * i + 1] = i64x2{0, 0};
     }
 }
 
@@ -1811,6 +1918,7 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
             half8 e_h[2][2];
             i32x8_x3 e_8[2];
             auto load_eh = [&](int i, int s) {                          // cout tile of (chunk i, wave w, ne) = i * 8 + w * 2 + ne
+                if constexpr (X3_ABL & 16) return;
 #pragma unroll
                 for (int ne = 0; ne < 2; ++ne) e_h[s & 1][ne] = x3_frag(W.w1h, lane_off, uint32_t(i * (CK / 16) + w * 2 + ne) * (C / 32) + uint32_t(s));
             };
@@ -1818,9 +1926,23 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
 #pragma unroll
                 for (int ne = 0; ne < 2; ++ne) {
                     const uint32_t f = uint32_t(i * (CK / 16) + w * 2 + ne) * (C / 32) + uint32_t(2 * J);
+                    if constexpr (X3_ABL & (16 | 1024)) continue;
+                    if constexpr (X3_ABL & 512) {
+                        const half8 piece = x3_frag(W.w1l, lane_off, f);
+                        e_8[ne] = x3_cat(piece, piece);
+                        continue;
+                    }
                     e_8[ne] = x3_cat(x3_frag(W.w1l, lane_off, f), x3_frag(W.w1l, lane_off, f + 1));
                 }
             };
+            if constexpr (X3_ABL & (16 | 1024)) {                       // (timing switches: the windows hold whatever LDS holds)
+#pragma unroll
+                for (int ne = 0; ne < 2; ++ne) {
+                    const half8 any = *reinterpret_cast<const half8*>(T.xh + lane * 8 + ne * 512);
+                    e_8[ne] = x3_cat(any, any);
+                    if constexpr (X3_ABL & 16) e_h[0][ne] = e_h[1][ne] = any;
+                }
+            }
             load_eh(0, 0);
             load_eh(0, 1);
             load_e8(0, 0);
@@ -2044,6 +2166,7 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
         half8 p_h[2][NJ];
         i32x8_x3 p_8[NJ];
         auto load_ph = [&](int k, int s2) {                            // cout tile = w * 4 + j, K slab = k * 4 + s2
+            if constexpr (X3_ABL & 16) return;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) p_h[s2 & 1][j] = x3_frag(W.w3h, lane_off, uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + s2));
         };
@@ -2051,9 +2174,23 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const uint32_t f = uint32_t(w * NJ + j) * uint32_t(nslab3) + uint32_t(k * (CK / 32) + 2 * J);
+                if constexpr (X3_ABL & (16 | 1024)) continue;
+                if constexpr (X3_ABL & 512) {
+                    const half8 piece = x3_frag(W.w3l, lane_off, f);
+                    p_8[j] = x3_cat(piece, piece);
+                    continue;
+                }
                 p_8[j] = x3_cat(x3_frag(W.w3l, lane_off, f), x3_frag(W.w3l, lane_off, f + 1));
             }
         };
+        if constexpr (X3_ABL & (16 | 1024)) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const half8 any = *reinterpret_cast<const half8*>(T.xh + lane * 8 + j * 512);
+                p_8[j] = x3_cat(any, any);
+                if constexpr (X3_ABL & 16) p_h[0][j] = p_h[1][j] = any;
+            }
+        }
         {   // the residual stream enters the project weights' scale: x := (x + b3) * 2^p; the project sums of the block are accumulated on it
             const float ps = d.w3_scale;
 #pragma unroll
@@ -2139,6 +2276,7 @@ __global__ __launch_bounds__(512) void tower_p8_kernel(const X3TowerArgs a) {
 void init_x3_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_x3_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes + 8192));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
@@ -2152,6 +2290,15 @@ int block_x3_chunk_channels() { return X3Block::CK; }
 
 void launch_block_x3(const BlockArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(block_x3_kernel, dim3(a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+}
+void launch_block_x3_split(const X3SplitArgs& a, hipStream_t s) {
+    const int n = a.blk.cop_pad / X3Block::CK;
+    if (a.G < 1 || a.G > n || a.G > 16) throw std::invalid_argument("block_x3_split: 1 <= G <= min(chunks, 16)");
+    hipLaunchKernelGGL(block_x3_split_kernel, dim3(a.G, a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+}
+void launch_x3_split_finish(const long long* x_q, float* y, long long* zero_q, int batch, hipStream_t s) {
+    const int n4 = batch * 64 * X3Block::C / 4;
+    hipLaunchKernelGGL(x3_split_finish_kernel, dim3(std::min(1024, (n4 + 255) / 256)), dim3(256), 0, s, x_q, y, zero_q, n4);
 }
 void launch_tower_x3(const X3TowerArgs& a, hipStream_t s) {
     // CRA_X3_TOWER=symmetric (read when the net is made, rise_net.h DevSwitches): every wave runs all three phases (A/B reference);

@@ -106,6 +106,16 @@ public:
         std::lock_guard<std::mutex> g(gen_mu_);
         ++go_gen_;
     }
+    // An announced search that will NOT be run (the commanding thread dropped it: its search thread failed to start, or the go was
+    // stopped and discarded before it began): without this the announcement would stay the oldest un-run generation for the life of
+    // the pool, and the next run() would adopt it -- together with any stop it has collected.  Returns false when no
+    // announced generation is waiting for its run.
+    bool cancel_go() {
+        std::lock_guard<std::mutex> g(gen_mu_);
+        if (adopted_gen_ >= go_gen_) return false;
+        ++adopted_gen_;                                                // the oldest waiting generation is over
+        return true;
+    }
     void request_stop() {
         std::lock_guard<std::mutex> g(gen_mu_);
         stop_gen_.store(go_gen_, std::memory_order_release);          // go_gen_ only grows: so does stop_gen_

@@ -94,6 +94,11 @@ class SearchPool:
         search thread has entered it (mi_search_announce_go)."""
         self._lib.mi_search_announce_go(self._h)
 
+    def cancel_go(self) -> bool:
+        """Withdraws the oldest announced search that no `run` has taken (the commanding thread dropped it); True if one was waiting
+        (mi_search_cancel_go)."""
+        return self._lib.mi_search_cancel_go(self._h) == 1
+
     def stop(self) -> None:
         """Ends the `run` that is executing in another thread or has been announced (SearchThread::stop); no effect otherwise."""
         self._lib.mi_search_stop(self._h)

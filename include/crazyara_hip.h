@@ -254,6 +254,11 @@ int mi_search_run_timed(mi_search* sp, unsigned simulations, unsigned nodes, uns
  * returning: a stop names every search announced or running at that moment, a run adopts the oldest announcement nobody has run yet,
  * and the previous run's exit touches neither (tests/test_mcts.py::test_go_announced_before_the_previous_run_returned_keeps_its_stop). */
 int mi_search_announce_go(mi_search* sp);
+/* Every mi_search_announce_go must be followed by exactly one run call -- or by mi_search_cancel_go when the commanding thread drops
+ * the search before its run was entered (the search thread could not be started, a `stop` made the go pointless): the oldest
+ * announcement no run has taken is withdrawn, together with any stop it has collected, so that the next run does not inherit either.
+ * Returns 1 if an announcement was withdrawn, 0 if none was waiting, -1 on a null handle. */
+int mi_search_cancel_go(mi_search* sp);
 int mi_search_stop(mi_search* sp);
 /* root statistics of one tree, children in the node's (prior-sorted) order: returns number of expanded children */
 int mi_search_root_children(mi_search* sp, int tree, int cap, uint32_t* moves, uint32_t* visits, float* q, float* priors);

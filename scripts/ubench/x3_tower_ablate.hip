@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "x3.hip"        // -I crazyara_amd/csrc/nn
@@ -58,6 +59,10 @@ int main(int argc, char** argv) {
     a.nblocks = nblocks;
     a.batch = B;
     a.p8 = p8;
+    {   // launch_tower_x3 reads X3TowerArgs::symmetric (RiseNet::build sets it from CRA_X3_TOWER when a net is made); here it comes from the same variable
+        const char* tw = getenv("CRA_X3_TOWER");
+        a.symmetric = tw && std::string(tw) == "symmetric" ? 1 : 0;
+    }
     init_x3_kernel_attributes();
     hipStream_t s;
     CK(hipStreamCreate(&s));

@@ -833,6 +833,33 @@ def test_go_announced_before_the_previous_run_returned_keeps_its_stop(hip_lib):
     pool.close()
 
 
+def test_an_announced_go_that_is_never_run_does_not_hand_its_stop_to_the_next_search(hip_lib):
+    """`go` is announced, stopped, and the commanding thread never enters run() for it.  The withdrawn announcement
+    (mi_search_cancel_go) must not stay the oldest un-run generation: the next announced search runs to its limit, also when another
+    idle `stop` arrived in between."""
+    nbp = NB_POLICY[0]
+    st = search.default_settings(mode=0, version_major=1, batch_size=8)
+    pool = search.SearchPool(st, eval_fn=_slow_eval(nbp, 0.0), fn_batch=8, fn_nb_policy=nbp)
+    t = pool.add_position("", False, "crazyhouse")
+    assert not pool.cancel_go()                                        # nothing announced
+    pool.announce_go()
+    pool.stop()
+    assert pool.cancel_go()                                            # the dropped search: no run() for it
+    assert not pool.cancel_go()
+    pool.stop()                                                        # an idle stop: names only generations that are over
+    pool.announce_go()
+    s1 = pool.run(simulations=300, threads=1)
+    assert pool.tree_info(t)["root_visits"] >= 300 and s1.simulations > 100
+    # two announcements waiting, the first one dropped: the run belongs to the second and ignores the first one's stop
+    pool.announce_go()
+    pool.stop()
+    pool.announce_go()
+    assert pool.cancel_go()
+    s2 = pool.run(simulations=600, threads=1)
+    assert pool.tree_info(t)["root_visits"] >= 600 and s2.simulations > 100
+    pool.close()
+
+
 def test_stop_sent_before_the_search_thread_entered_run_is_not_lost(hip_lib):
     """The reference's stop is sticky (SearchThread::stop sets isRunning = false, searchthread.cpp:109-112; the search loop tests it
     before every mini-batch): `go` announces the search on the commanding thread (mi_search_announce_go), a `stop` that arrives before

@@ -42,6 +42,10 @@ TOL["float16x3-unfused"] = TOL["float32"]   # every block on the layer kernels (
 # float16x3 whose one-launch tower takes the cross terms of both 1x1 GEMMs through e5m2 MFMAs (truncated activation bytes): emulated
 # 5e-5 ... 1.3e-4 on the logits, 3e-5 on the value (scripts/studies/p8_format_study.py); bounds at twice that, a third of north_star's 1e-3
 TOL["float16p8"] = dict(logit=3e-4, logit_rel=None, value=1e-4, prob=1e-6, aux=1e-4)
+# "-1wg": nets made for at most 32 boards run their 3x3 blocks one per launch with several workgroups per board (block_x3_split_kernel,
+# round 6); the suffix keeps the one-workgroup-per-board tower kernels, which the four-board fixtures would otherwise never reach
+TOL["float16x3-1wg"] = TOL["float32"]
+TOL["float16p8-1wg"] = TOL["float16p8"]
 TOL["float32-unfused"] = TOL["float32"]
 TOL["float16-unfused"] = TOL["float16"]
 TOL["float16-perblock"] = TOL["float16"]
@@ -68,8 +72,8 @@ def _run(tmp_path, hip_lib, name, precision):
     return cfg, sd, x, value, probs.reshape(B, -1), aux, logits
 
 
-@pytest.mark.parametrize("precision", ["float32", "float16", "float16x3", "float16p8", "float16-3k", "float16-perblock", "float32-unfused",
-                                       "float16-unfused", "float16x3-perblock", "float16x3-unfused"])
+@pytest.mark.parametrize("precision", ["float32", "float16", "float16x3", "float16p8", "float16x3-1wg", "float16p8-1wg", "float16-3k", "float16-perblock",
+                                       "float32-unfused", "float16-unfused", "float16x3-perblock", "float16x3-unfused"])
 @pytest.mark.parametrize("name", list(nn_cases.CASES))
 def test_predict_matches_oracle_and_golden(tmp_path, hip_lib, name, precision):
     cfg, sd, x, value, probs, aux, logits = _run(tmp_path, hip_lib, name, precision)
@@ -98,7 +102,7 @@ def test_dense_tower_kernel_shapes(tmp_path, hip_lib, name, variant):
     assert np.abs(logits - g["logits"]).max() < logit_tol(tol, g["logits"])
 
 
-@pytest.mark.parametrize("precision", ["float16", "float16x3", "float16p8"])
+@pytest.mark.parametrize("precision", ["float16", "float16x3", "float16p8", "float16x3-1wg", "float16p8-1wg"])
 @pytest.mark.parametrize("case", ["risev2-7", "alphazero-3-cv8"])
 @pytest.mark.parametrize("batch", [1, 3, 300])
 def test_tower_and_head_kernels_any_batch_size(tmp_path, hip_lib, batch, case, precision):
@@ -481,7 +485,7 @@ def test_float16x3_two_role_tower_equals_the_symmetric_one_bit_for_bit(tmp_path,
     outs = []
     for mode in ("roles", "symmetric"):
         monkeypatch.setenv("CRA_X3_TOWER", mode)
-        net = HipAPI(0, batch, d, "float16x3")
+        net = HipAPI(0, batch, d, "float16x3-1wg")
         v, p = np.zeros(batch, np.float32), np.zeros(batch * cfg.nb_policy, np.float32)
         net.predict(x, v, p)
         net.close()
@@ -494,7 +498,7 @@ def test_float16p8_equals_its_emulation(tmp_path, hip_lib, name):
     """Precision float16p8 is DEFINED by oracle.forward_p8 (f16 main term + two e5m2 cross terms in the two 1x1 contractions of the
     one-launch tower, everything else float16x3): the kernel must sit much closer to that definition than the mode sits to fp32 -- what
     is left is the f32 accumulation order of the matrix unit -- and the mode itself within 3e-4 of fp32 on the logits (north_star: 1e-3)."""
-    cfg, sd, x, value, probs, aux, logits = _run(tmp_path, hip_lib, name, "float16p8")
+    cfg, sd, x, value, probs, aux, logits = _run(tmp_path, hip_lib, name, "float16p8-1wg")     # (the tower kernels: four boards would run split, below)
     e_value, e_logits, _ = ro.forward_p8(cfg, sd, x)
     o_value, o_logits, _ = ro.forward(cfg, sd, x)
     mode = float((e_logits - o_logits).abs().max())
@@ -522,7 +526,51 @@ def test_float16p8_launch_structure(tmp_path, hip_lib, name, towers):
     from crazyara_amd.neuralnetapi import HipAPI
     cfg, sd, x = nn_cases.make_case(name)
     d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
-    net = HipAPI(0, int(x.shape[0]), d, "float16p8")
+    net = HipAPI(0, int(x.shape[0]), d, "float16p8-1wg")
     names = [n for n, _ in net.time_ops(1)]
     net.close()
     assert names == ["conv_gemm_x3_3x3"] + ["tower_p8"] * towers + ["conv_gemm_x3_3x3", "value_head"], names
+    # at batch 256 the plain name is that structure; at 32 boards and below the 3x3 runs go one block per launch, several workgroups per board
+    net = HipAPI(0, 256, d, "float16p8")
+    assert [n for n, _ in net.time_ops(1)] == names
+    net.close()
+    net = HipAPI(0, 8, d, "float16p8")
+    small = [n for n, _ in net.time_ops(1)]
+    net.close()
+    assert "block_x3_split" in small and "x3_split_finish" in small and ("tower_p8" in small) == (name == "risev33"), small
+
+
+@pytest.mark.parametrize("precision", ["float16p8", "float16x3"])
+@pytest.mark.parametrize("name,batch", [("risev2-19", 1), ("risev2-19", 3), ("risev2-19", 8), ("risev2-19", 32), ("risev2-7", 8), ("risev33-wdlp", 5),
+                                        ("risev2-13-lichess", 16)])
+def test_board_split_forward_small_batches(tmp_path, hip_lib, name, batch, precision):
+    """Round 6 (VERDICT r05 next #1b): nets made for <= 32 boards run every 3x3 bottleneck block as ONE launch with up to C_op / 128 workgroups
+    per board, each owning a share of the block's chunks, partial project sums added as 64-bit fixed point (block_x3_split_kernel).  The
+    arithmetic is float16x3's in both modes, so the bound is float16x3's 1e-4 on the logits; integer sums are order-free: two nets, three
+    forwards each, identical bits; and the split forward sits within float16x3 round-off of the one-workgroup-per-board tower."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, _ = nn_cases.make_case(name)
+    d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
+    x = nn_cases.synthetic_planes(batch, cfg.nb_input_channels, 77)
+    xin = np.ascontiguousarray(x.numpy())
+    o_value, o_logits, o_aux = ro.forward(cfg, sd, x)
+    outs = []
+    for prec in (precision, precision, "float16x3-1wg"):
+        net = HipAPI(0, batch, d, prec, keep_logits=True)
+        if prec == precision:
+            assert "block_x3_split" in [n for n, _ in net.time_ops(1)]
+        for _ in range(3):
+            v, p = np.full(batch, 7.0, np.float32), np.full(batch * cfg.nb_policy, 7.0, np.float32)
+            aux = np.full(batch * 4, 7.0, np.float32) if cfg.nb_aux else None
+            net.predict(xin, v, p, aux)
+            logits = torch.as_tensor(net.device_buffers()["logits"], device="cuda").cpu().numpy()
+            outs.append((prec, v, p, logits.copy()))
+        net.close()
+    tol = TOL["float16x3"] if name != "risev33-wdlp" or precision == "float16x3" else TOL["float16p8"]      # (RISEv3.3's 5x5 runs stay on tower_p8_kernel<5> in float16p8)
+    for prec, v, p, logits in outs[:6]:
+        assert np.abs(v - o_value.numpy().reshape(-1)).max() < tol["value"]
+        assert np.abs(logits - o_logits.numpy()).max() < tol["logit"]
+        assert np.abs(p.reshape(batch, -1) - torch.softmax(o_logits, 1).numpy()).max() < tol["prob"]
+        assert np.array_equal(v, outs[0][1]) and np.array_equal(p, outs[0][2]) and np.array_equal(logits, outs[0][3])    # run to run, net to net
+    if precision == "float16x3":
+        assert np.abs(outs[0][3] - outs[6][3]).max() < 2e-5            # against the tower kernel's bits: f32 round-off of another summation order

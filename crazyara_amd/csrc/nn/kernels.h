@@ -120,23 +120,24 @@ struct X3TowerArgs {
 void launch_tower_x3(const X3TowerArgs& a, hipStream_t s);
 // Small batches (round 6): ONE 3x3 bottleneck block per launch with G workgroups per board (x3.hip: block_x3_split_kernel).  Workgroup g of a
 // board stages the whole board (every workgroup needs all 256 input channels of the expand GEMM), runs the chunks [g n / G, (g + 1) n / G) of
-// the block's n = C_op / 128 chunks through expand -> depthwise -> project (float16x3 arithmetic, x3_chunks) and ADDS its partial project sums
-// -- workgroup 0 also the residual x + b3 -- to the block's output as 64-bit FIXED-POINT integers (2^-32 units, atomic adds): integer sums
-// do not depend on the order the workgroups arrive in, so the forward is run-to-run identical, which float atomics would not give.  The next
-// launch reads the sum back as floats while it stages.  Three accumulators rotate: launch k reads q[k % 3], adds into q[(k + 1) % 3] and
-// clears q[(k + 2) % 3] for the launch behind it; launch_x3_split_finish turns the last sum into the float stream the heads read and clears
-// the first launch's accumulator for the next forward.  One board per workgroup costs a batch of ONE the whole tower's latency on one CU
-// (0.46 ms for RISEv2-19); this form spreads a board's block over up to n CUs.
+// the block's n = C_op / 128 chunks through expand -> depthwise -> project (float16x3 arithmetic, x3_chunks) and writes its PARTIAL project
+// sums -- workgroup 0 also the residual x + b3 -- as a float image of its own, [B][G][64][256]; the next launch adds the G images of a board
+// in the order of their index while it stages (the same bits in every workgroup and on every launch: no atomics, nothing depends on the
+// order in which workgroups arrive).  Two image sets alternate.  launch_x3_split_finish adds the last block's images into the float stream
+// the heads read.  One board per workgroup costs a batch of ONE the whole tower's latency on one CU (0.46 ms for RISEv2-19); this form
+// spreads a board's block over up to n CUs.  (Built first with 64-bit fixed-point atomic adds into one sum per board: order-free as well,
+// but device-scope atomics execute at the memory side on this chip -- 4.5 us per block at batch 1, 1 ms per forward at batch 32;
+// profiles/r06/b_*.)
 struct X3SplitArgs {
     X3TowerBlock blk;         // this launch's block (SE gate, if any, computed by every workgroup from the staged board)
-    const float* x_f;         // the run's FIRST block: the stream as float [B][64][256]; else nullptr
-    const long long* x_q;     // else: the stream as the previous launch's fixed-point sum [B][64][256]
-    long long* y_q;           // this block's sum
-    long long* zero_q;        // cleared here (the next launch's y_q)
-    int batch, G;             // grid = (G, batch); 1 <= G <= cop_pad / 128
+    const float* x_parts;     // [B][gin][64][256]: the stream = the sum of these images (the run's first block: gin = 1, the float stream itself)
+    float* y_parts;           // [B][G][64][256]
+    int gin;                  // 1 ... 16
+    int batch, G;             // 1 <= G <= min(cop_pad / 128, 16)
+    int dev;                  // development (CRA_X3_SPLIT_DEV when the net was made; timing switches, x3.hip)
 };
 void launch_block_x3_split(const X3SplitArgs& a, hipStream_t s);
-void launch_x3_split_finish(const long long* x_q, float* y, long long* zero_q, int batch, hipStream_t s);    // y = float(x_q); zero_q := 0 (may be x_q itself)
+void launch_x3_split_finish(const float* parts, int gin, float* y, int batch, hipStream_t s);
 template <typename T> void init_block_kernel_attributes();
 template <typename T> int block_chunk_channels();   // C_op must be padded to a multiple of this
 

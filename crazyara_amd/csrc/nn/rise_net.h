@@ -127,6 +127,9 @@ private:
         char lane_launches = 0;         // CRA_LANE_LAUNCHES: '1' / '2' / '3' force the shape of the lane step
         bool lane_sync = false;         // CRA_LANE_SYNC: a stream sync between forward and gather
         bool x3_symmetric = false;      // CRA_X3_TOWER=symmetric: the float16x3 tower with every wave running all three phases
+        int x3_split_dev = 0;           // CRA_X3_SPLIT_DEV: timing switches of block_x3_split_kernel (x3.hip; bits 2 and 4 give wrong results)
+        int x3_split_max_g = 0;         // CRA_X3_SPLIT_MAX_G: upper bound on the workgroups per board of the split-board blocks
+        int x3_split_max_batch = 0;     // CRA_X3_SPLIT_MAX_BATCH: the largest batch that runs split-board (default kBoardSplitMaxBatch)
         DevSwitches();
     } dev_;
     float* value_head_dbg_ = nullptr;

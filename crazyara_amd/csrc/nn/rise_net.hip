@@ -227,7 +227,7 @@ struct Op {
     ResTowerArgs rt{};
     StemArgs st{};
     X3TowerArgs tx{};
-    X3SplitArgs xs{};             // BlockX3Split; X3SplitFinish: x_q, zero_q, batch and (as y) the float stream
+    X3SplitArgs xs{};             // BlockX3Split; X3SplitFinish: x_parts, gin, batch and (xs_y) the float stream
     float* xs_y = nullptr;
 };
 }  // namespace
@@ -280,6 +280,9 @@ RiseNet::DevSwitches::DevSwitches() {
     if (const char* e = getenv("CRA_LANE_LAUNCHES")) lane_launches = e[0];
     lane_sync = getenv("CRA_LANE_SYNC") != nullptr;
     if (const char* e = getenv("CRA_X3_TOWER")) x3_symmetric = e[0] == 's';
+    if (const char* e = getenv("CRA_X3_SPLIT_DEV")) x3_split_dev = atoi(e);
+    if (const char* e = getenv("CRA_X3_SPLIT_MAX_G")) x3_split_max_g = atoi(e);
+    if (const char* e = getenv("CRA_X3_SPLIT_MAX_BATCH")) x3_split_max_batch = atoi(e);
 }
 
 RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, const std::string& precision)
@@ -631,35 +634,35 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     std::vector<X3TowerBlock> x3_blocks;
     int x3_run_ks = 3;                     // a run is all 3x3 or all 5x5 blocks (tower_x3_roles_kernel<KS>, tower_p8_kernel<KS>)
     // small batches: 3x3 runs one block per launch, several workgroups per board (kernels.h: X3SplitArgs)
-    const bool x3_split = x3_ && tower_ && fused_ && C == 256 && board_split_ && B <= kBoardSplitMaxBatch;
-    long long* split_q[3] = {nullptr, nullptr, nullptr};
+    const bool x3_split = x3_ && tower_ && fused_ && C == 256 && board_split_ && B <= (dev_.x3_split_max_batch > 0 ? dev_.x3_split_max_batch : kBoardSplitMaxBatch);
+    float* split_parts[2] = {nullptr, nullptr};
+    constexpr int kSplitMaxG = 10;
     auto flush_x3_tower = [&]() {
         if (x3_blocks.empty()) return;
         if (x3_split && x3_run_ks == 3) {
-            if (!split_q[0]) {
-                for (auto& q : split_q) {
-                    q = static_cast<long long*>(im.dalloc(size_t(B) * kSquares * C * sizeof(long long)));
-                    HIP_CHECK(hipMemset(q, 0, size_t(B) * kSquares * C * sizeof(long long)));
-                }
-            }
-            const int max_g = std::max(1, std::min(16, cu_count_ / B));
+            if (!split_parts[0])
+                for (auto& q : split_parts) q = static_cast<float*>(im.dalloc(size_t(B) * kSplitMaxG * kSquares * C * sizeof(float)));
+            int max_g = std::max(1, std::min(kSplitMaxG, cu_count_ / B));
+            if (dev_.x3_split_max_g > 0) max_g = std::min(max_g, dev_.x3_split_max_g);
             const int nb = int(x3_blocks.size());
+            int gin = 1;
             for (int k = 0; k < nb; ++k) {
                 Op op;
                 op.kind = OpKind::BlockX3Split;
                 op.xs.blk = x3_blocks[k];
-                op.xs.x_f = k == 0 ? reinterpret_cast<const float*>(cur) : nullptr;
-                op.xs.x_q = k == 0 ? nullptr : split_q[k % 3];
-                op.xs.y_q = split_q[(k + 1) % 3];
-                op.xs.zero_q = split_q[(k + 2) % 3];
+                op.xs.x_parts = k == 0 ? reinterpret_cast<const float*>(cur) : split_parts[k % 2];
+                op.xs.y_parts = split_parts[(k + 1) % 2];
+                op.xs.gin = gin;
                 op.xs.batch = B;
                 op.xs.G = std::min(max_g, x3_blocks[k].cop_pad / block_x3_chunk_channels());
+                op.xs.dev = dev_.x3_split_dev;
+                gin = op.xs.G;
                 im.ops.push_back(op);
             }
             Op fin;
             fin.kind = OpKind::X3SplitFinish;
-            fin.xs.x_q = split_q[nb % 3];
-            fin.xs.zero_q = split_q[1];                  // the first launch of the next forward (or of this forward's next run) adds into q[1]
+            fin.xs.x_parts = split_parts[nb % 2];
+            fin.xs.gin = gin;
             fin.xs.batch = B;
             fin.xs_y = reinterpret_cast<float*>(nxt);
             im.ops.push_back(fin);
@@ -1502,7 +1505,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
         case OpKind::ResTower: launch_restower(op.rt, s); break;
         case OpKind::TowerX3: launch_tower_x3(op.tx, s); break;
         case OpKind::BlockX3Split: launch_block_x3_split(op.xs, s); break;
-        case OpKind::X3SplitFinish: launch_x3_split_finish(op.xs.x_q, op.xs_y, op.xs.zero_q, op.xs.batch, s); break;
+        case OpKind::X3SplitFinish: launch_x3_split_finish(op.xs.x_parts, op.xs.gin, op.xs_y, op.xs.batch, s); break;
         case OpKind::Stem: {
             StemArgs st = op.st;
             st.planes = planes;

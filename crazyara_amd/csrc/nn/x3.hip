@@ -1342,32 +1342,36 @@ __global__ __launch_bounds__(512) void tower_x3_kernel(const X3TowerArgs a) {
 
 // ---- small batches: one block per launch, G workgroups per board (kernels.h: X3SplitArgs) ----
 namespace {
-// float <-> 64-bit fixed point in units of 2^-32 (|v| < 2^31).  v - floor(v) is exact except where it rounds up to 1 (a negative v of tiny
-// magnitude): the clamp keeps that inside the low word, an error below the unit.  The way back rounds twice (low word to 24 bits, then the
-// sum): a fixed function of the integer, the same on every launch.
-__device__ __forceinline__ long long x3_to_fixed(float v) {
-    const float fl = floorf(v);
-    const float fr = fminf((v - fl) * 4294967296.f, 4294967040.f);
-    return (static_cast<long long>(static_cast<int>(fl)) << 32) | static_cast<long long>(static_cast<unsigned>(fr));
-}
-__device__ __forceinline__ float x3_from_fixed(long long q) {
-    return fmaf(static_cast<float>(static_cast<unsigned>(q)), 2.3283064365386963e-10f, static_cast<float>(static_cast<int>(q >> 32)));
-}
-// fixed-point board tile [64][256] -> split tiles
-__device__ __forceinline__ void x3_stage_tile_fixed(const X3Tiles& T, const long long* xq, int tid) {
-    constexpr int C = X3Block::C, XROW = X3Block::XROW;
-    typedef long long i64x2 __attribute__((ext_vector_type(2)));
-#pragma unroll 1
-    for (int i = tid; i < 64 * (C / 8); i += X3Block::NTHR) {
-        const int sq = i / (C / 8), v = i - sq * (C / 8), r = x3_row(sq);
-        const i64x2* p = reinterpret_cast<const i64x2*>(xq + size_t(sq) * C + v * 8);
-        float f[8];
+// The board tile as the sum of `gin` float images [64][256] (the previous launch's partial sums, added in the order of their index: the same
+// bits on every launch and in every workgroup of the board; gin = 1: a plain float tile) -> split tiles.  A thread's loads of one pass are all
+// requested before the first add: the images come from HBM / the memory-side cache, and dependent round trips are what a launch of this
+// kernel mostly consists of.
+template <int GIN>
+__device__ __forceinline__ void x3_stage_tile_sum(const X3Tiles& T, const float* parts, int gin, int tid) {
+    constexpr int C = X3Block::C, XROW = X3Block::XROW, IT = 64 * (C / 8) / X3Block::NTHR;
+    constexpr int NG = GIN > 0 ? GIN : 16;
+    f32x4 q[NG][2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const i64x2 q = p[j];
-            f[2 * j] = x3_from_fixed(q.x);
-            f[2 * j + 1] = x3_from_fixed(q.y);
+    for (int it = 0; it < IT; ++it) {
+        const int i = tid + it * X3Block::NTHR, sq = i / (C / 8), v = i - sq * (C / 8), r = x3_row(sq);
+        const float* p0 = parts + size_t(sq) * C + v * 8;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (GIN > 0 || g < gin) {
+                const f32x4* p = reinterpret_cast<const f32x4*>(p0 + size_t(g) * 64 * C);
+                q[g][0] = p[0];
+                q[g][1] = p[1];
+            }
         }
+        f32x4 s0 = q[0][0], s1 = q[0][1];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+            if (GIN > 0 || g < gin) {
+                s0 += q[g][0];
+                s1 += q[g][1];
+            }
+        }
+        const float f[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
         half8 h, l;
         split8(f, h, l);
         *reinterpret_cast<half8*>(T.xh + r * XROW + v * 8) = h;
@@ -1381,23 +1385,36 @@ __global__ __launch_bounds__(512) void block_x3_split_kernel(const X3SplitArgs a
     constexpr int C = G::C, CK = G::CK, XROW = G::XROW, NJ = G::NJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const X3Tiles T = x3_tiles(smem);
-    const int g = blockIdx.x, b = blockIdx.y;
+    // Workgroup -> (board, share): workgroups go to the eight XCDs round-robin by their linear id; the G workgroups of a board read the same
+    // partial sums, which one XCD's L2 then fetches once.  Board b lives on XCD b % 8: id = xcd + 8 j, b = xcd + 8 (j / G), g = j % G; ids
+    // beyond the batch leave at once.  (Placement is a matter of speed only.)
+    const int G_ = a.G;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int g = jj % G_, b = xcd + 8 * (jj / G_);
+    if (b >= a.batch) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const X3TowerBlock& d = a.blk;
-    if (a.x_f) x3_stage_tile(T, a.x_f + size_t(b) * 64 * C, nullptr, tid);
-    else x3_stage_tile_fixed(T, a.x_q + size_t(b) * 64 * C, tid);
-    {   // this workgroup's share of the accumulator behind the next one
-        typedef long long i64x2 __attribute__((ext_vector_type(2)));
-        const int per = 64 * C / 2 / int(gridDim.x);                   // 16-byte pieces per workgroup (G divides 8192: G <= 10 is checked by the launcher)
-        i64x2* z = reinterpret_cast<i64x2*>(a.zero_q + size_t(b) * 64 * C) + size_t(g) * per;
-        const int n2 = g + 1 == int(gridDim.x) ? 64 * C / 2 - g * per : per;
-        for (int i = tid; i < n2; i += G::NTHR) z[i] = i64x2{0, 0};
+    {
+        const float* parts = a.x_parts + size_t(b) * a.gin * 64 * C;
+        switch (a.gin) {                                                // (the usual counts with every load of a pass in flight at once)
+            case 1: x3_stage_tile_sum<1>(T, parts, 1, tid); break;
+            case 2: x3_stage_tile_sum<2>(T, parts, 2, tid); break;
+            case 3: x3_stage_tile_sum<3>(T, parts, 3, tid); break;
+            case 4: x3_stage_tile_sum<4>(T, parts, 4, tid); break;
+            case 5: x3_stage_tile_sum<5>(T, parts, 5, tid); break;
+            case 6: x3_stage_tile_sum<6>(T, parts, 6, tid); break;
+            case 7: x3_stage_tile_sum<7>(T, parts, 7, tid); break;
+            case 8: x3_stage_tile_sum<8>(T, parts, 8, tid); break;
+            case 9: x3_stage_tile_sum<9>(T, parts, 9, tid); break;
+            case 10: x3_stage_tile_sum<10>(T, parts, 10, tid); break;
+            default: x3_stage_tile_sum<0>(T, parts, a.gin, tid); break;
+        }
     }
     __syncthreads();
     if (d.se_kind != 0) x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid);      // every workgroup of the board: the same gate, the same gated tiles
     const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
     const int n = W.cop_pad / CK;
-    const int ch0 = __builtin_amdgcn_readfirstlane(g * n / int(gridDim.x)), ch1 = __builtin_amdgcn_readfirstlane((g + 1) * n / int(gridDim.x));
+    const int ch0 = __builtin_amdgcn_readfirstlane(g * n / G_), ch1 = __builtin_amdgcn_readfirstlane((g + 1) * n / G_);
     f32x4 accP[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -1405,16 +1422,16 @@ __global__ __launch_bounds__(512) void block_x3_split_kernel(const X3SplitArgs a
 #pragma unroll
         for (int t = 0; t < 4; ++t) accP[j][t] = bs;
     }
-    x3_chunks(T, W, accP, ch0, ch1);
-    // epilogue: this workgroup's part of x + b3 + body(x) -> the block's sum (workgroup 0 carries x and b3)
-    unsigned long long* yq = reinterpret_cast<unsigned long long*>(a.y_q + size_t(b) * 64 * C);
+    if (!(a.dev & 4)) x3_chunks(T, W, accP, ch0, ch1);                   // (development bit 4, timing only: no chunk loop)
+    // epilogue: this workgroup's part of x + b3 + body(x) (workgroup 0 carries x and b3) -> its own image
+    float* yb = a.y_parts + (size_t(b) * G_ + g) * 64 * C;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int co0 = (wave * NJ + j) * 16 + lg * 4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int sq = t * 16 + l15;
-            float v[4] = {accP[j][t][0], accP[j][t][1], accP[j][t][2], accP[j][t][3]};
+            f32x4 v = accP[j][t];
             if (g == 0) {
                 float rh[4], rl[4];
                 load4<half_t>(T.xh + sq * XROW + co0, rh);
@@ -1422,23 +1439,20 @@ __global__ __launch_bounds__(512) void block_x3_split_kernel(const X3SplitArgs a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += rh[r] + rl[r];
             }
-            unsigned long long* dst = yq + size_t(x3_square(sq)) * C + co0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                (void)__hip_atomic_fetch_add(dst + r, static_cast<unsigned long long>(x3_to_fixed(v[r])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<f32x4*>(yb + size_t(x3_square(sq)) * C + co0) = v;
         }
     }
 }
 
-// the last block's sum -> the float stream [B][64][256]; clears zero_q (the first launch's accumulator of the NEXT forward; it may be x_q itself:
-// a thread clears what it has just read)
-__global__ __launch_bounds__(256) void x3_split_finish_kernel(const long long* x_q, float* y, long long* zero_q, int n4) {
-    typedef long long i64x2 __attribute__((ext_vector_type(2)));
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
-        const i64x2 q0 = reinterpret_cast<const i64x2*>(x_q)[2 * i], q1 = reinterpret_cast<const i64x2*>(x_q)[2 * i + 1];
-        reinterpret_cast<f32x4*>(y)[i] = f32x4{x3_from_fixed(q0.x), x3_from_fixed(q0.y), x3_from_fixed(q1.x), x3_from_fixed(q1.y)};
-        reinterpret_cast<i64x2*>(zero_q)[2 * i] = i64x2{0, 0};
-        reinterpret_cast<i64x2*>(zero_q)[2 * i + 1] = i64x2{0, 0};
+// the last block's partial sums -> the float stream [B][64][256] the heads read (the same order of addition as the staging above)
+__global__ __launch_bounds__(256) void x3_split_finish_kernel(const float* parts, int gin, float* y, int batch) {
+    constexpr int per_board = 64 * X3Block::C / 4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < batch * per_board; i += gridDim.x * 256) {
+        const int b = i / per_board, e = i - b * per_board;
+        const f32x4* p = reinterpret_cast<const f32x4*>(parts + size_t(b) * gin * 64 * X3Block::C) + e;
+        f32x4 s = p[0];
+        for (int g = 1; g < gin; ++g) s += p[size_t(g) * per_board];
+        reinterpret_cast<f32x4*>(y)[i] = s;
     }
 }
 
@@ -2293,12 +2307,12 @@ void launch_block_x3(const BlockArgs& a, hipStream_t s) {
 }
 void launch_block_x3_split(const X3SplitArgs& a, hipStream_t s) {
     const int n = a.blk.cop_pad / X3Block::CK;
-    if (a.G < 1 || a.G > n || a.G > 16) throw std::invalid_argument("block_x3_split: 1 <= G <= min(chunks, 16)");
-    hipLaunchKernelGGL(block_x3_split_kernel, dim3(a.G, a.batch), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
+    if (a.G < 1 || a.G > n || a.G > 16 || a.gin < 1 || a.gin > 16) throw std::invalid_argument("block_x3_split: 1 <= G <= min(chunks, 16), 1 <= gin <= 16");
+    hipLaunchKernelGGL(block_x3_split_kernel, dim3(8 * a.G * ((a.batch + 7) / 8)), dim3(X3Block::NTHR), X3Block::lds_bytes, s, a);
 }
-void launch_x3_split_finish(const long long* x_q, float* y, long long* zero_q, int batch, hipStream_t s) {
+void launch_x3_split_finish(const float* parts, int gin, float* y, int batch, hipStream_t s) {
     const int n4 = batch * 64 * X3Block::C / 4;
-    hipLaunchKernelGGL(x3_split_finish_kernel, dim3(std::min(1024, (n4 + 255) / 256)), dim3(256), 0, s, x_q, y, zero_q, n4);
+    hipLaunchKernelGGL(x3_split_finish_kernel, dim3(std::min(1024, (n4 + 255) / 256)), dim3(256), 0, s, parts, gin, y, batch);
 }
 void launch_tower_x3(const X3TowerArgs& a, hipStream_t s) {
     // CRA_X3_TOWER=symmetric (read when the net is made, rise_net.h DevSwitches): every wave runs all three phases (A/B reference);

@@ -53,7 +53,9 @@ struct SearchSettings {
     // MCTS_Solver (optionsuci.cpp:129, default true): terminal backups mark parents WIN / LOSS / DRAW once their children
     // prove it (Node::solve_for_terminal, node.cpp:365-453); a solved root ends the search (searchthread.cpp:333-340).
     // Search_Type "mcgs" needs no switch here: in the reference the transposition link of add_new_node_to_tree is
-    // unreachable (node.cpp:730-731 reads the candidate from the still-empty child slot), so mcgs and mcts search the same tree.
+    // unreachable (node.cpp:730-731 reads the candidate from the still-empty child slot), so mcgs and mcts search the same tree --
+    // pinned on the compiled reference run under both values of useMCGS (tests/test_mcts_reference_build.py::
+    // test_mcgs_flag_searches_the_same_tree: identical dumps on transposition-rich positions, equal to this tree).
     bool mcts_solver = true;
     // Dirichlet noise on the root priors (mctsagent.cpp:311-316, node.cpp:950-954, blazeutil.h:113-124): applied at the start of
     // every search when epsilon > 0.009, followed by fully_expand_node.  UCI defaults: Centi_Dirichlet_Epsilon 0 (25 in RL builds),

@@ -168,6 +168,13 @@ const char* ref_last_error(void) { return g_error.c_str(); }
 
 }  // extern "C"
 
+// UCI option Search_Type (crazyara.cpp:736: useMCGS = Search_Type == "mcgs"; the option's default IS mcgs, optionsuci.cpp).  The product has no
+// such switch: Node::add_new_node_to_tree's transposition link reads its candidate from the child slot it is about to fill (node.cpp:730-731),
+// which SearchThread only calls for an EMPTY slot (searchthread.cpp:194-211), so the flag changes no tree.  ref_set_use_mcgs lets the tests
+// run the compiled reference under both values and compare the dumps (tests/test_mcts_reference_build.py).  Applies to agents created afterwards.
+static bool g_use_mcgs = false;
+extern "C" void ref_set_use_mcgs(int on) { g_use_mcgs = on != 0; }
+
 // SearchSettings / PlaySettings exactly as CrazyAra::init_search_settings fills them, from the product's settings struct
 // search_threads = the UCI option `Threads`: that many SearchThreads on the one tree, each with its own batch net (crazyara.cpp:548-563)
 template <typename MakeNet>
@@ -186,7 +193,7 @@ static ref_agent* create_agent(const mi_search_settings* s, MakeNet&& make_net, 
             ss.multiPV = 1;
             ss.threads = search_threads;
             ss.batchSize = unsigned(s->batch_size);
-            ss.useMCGS = false;                                 // see DESIGN: the transposition link is unreachable in this snapshot
+            ss.useMCGS = g_use_mcgs;                            // default false; ref_set_use_mcgs(1) = the UCI default Search_Type mcgs (above)
             ss.searchPlayerMode = MODE_TWO_PLAYER;
             ss.qValueWeight = s->q_value_weight;
             ss.qVetoDelta = s->q_veto_delta;

@@ -50,6 +50,8 @@ def _declare(lib):
     lib.ref_agent_create.restype = C.c_void_p
     lib.ref_agent_create.argtypes = [C.POINTER(SearchSettingsC), EVAL_FN, C.c_void_p, C.c_int]
     lib.ref_agent_destroy.argtypes = [C.c_void_p]
+    lib.ref_set_use_mcgs.argtypes = [C.c_int]
+    lib.ref_set_use_mcgs.restype = None
     lib.ref_agent_set_position.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p]
     lib.ref_agent_go.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
     lib.ref_agent_apply_move.argtypes = [C.c_void_p, C.c_char_p]
@@ -185,6 +187,11 @@ class RefHipAPI:
         if getattr(self, "_h", None):
             self._lib.ref_hipapi_destroy(self._h)
             self._h = None
+
+
+def set_use_mcgs(on: bool) -> None:
+    """SearchSettings::useMCGS of the agents created from now on (UCI Search_Type mcgs | mcts, crazyara.cpp:736); default False."""
+    load().ref_set_use_mcgs(1 if on else 0)
 
 
 class RefAgent:

@@ -127,6 +127,56 @@ def test_product_tree_equals_reference_build(hip_lib, variant, is960, fen, mode,
     ra.close()
 
 
+MCGS_CASES = [
+    # positions whose trees hold many transpositions (move-order permutations reach the same position inside a few hundred simulations)
+    ("chess", False, "", 1, 1200, 8, 1.7),
+    ("chess", False, "8/2k5/8/8/8/8/3K4/R6r w - - 0 1", 1, 800, 8, 1.7),                 # two kings, two rooks: nearly every node is reached twice
+    ("crazyhouse", False, "", 0, 800, 16, 1.7),
+    ("crazyhouse", False, "8/2k5/8/8/8/8/3K4/R6r[Pp] w - - 0 1", 0, 600, 8, 1.7),         # drops and rook moves permute freely
+    ("kingofthehill", False, "", 2, 1000, 8, 1.7),
+]
+
+
+@pytest.mark.parametrize("variant,is960,fen,mode,sims,quota,temp", MCGS_CASES)
+def test_mcgs_flag_searches_the_same_tree(hip_lib, variant, is960, fen, mode, sims, quota, temp):
+    """`mcts.h` says "mcgs and mcts search the same tree" -- the reference's transposition link
+    (Node::add_new_node_to_tree, node.cpp:722-762) takes its candidate from the child slot that is still empty when SearchThread calls it
+    (searchthread.cpp:194-211), so useMCGS only fills a hash table nobody reads a node from.  Pinned here on the compiled reference itself:
+    the same searches with SearchSettings::useMCGS = true (the UCI default, Search_Type mcgs) and = false dump identical trees, a second `go`
+    on the kept tree included, and both equal the product's tree; the positions are transposition-rich (the dump is checked to hold
+    positions that occur more than once, i.e. the table had hits to offer)."""
+    nbp = NB_POLICY[mode]
+    st = search.default_settings(mode=mode, version_major=1 if mode == 0 else 3, is_policy_map=1, node_policy_temperature=temp, batch_size=quota)
+    seen = []
+
+    def evaluator(descs):
+        seen.extend(d[0:96] + d[112:123] for d in descs)
+        return _evaluator(nbp)(descs)
+    dumps = []
+    for mcgs in (True, False):
+        ref_mcts.set_use_mcgs(mcgs)
+        try:
+            ra = ref_mcts.RefAgent(st, evaluator if mcgs else _evaluator(nbp), nbp)
+        finally:
+            ref_mcts.set_use_mcgs(False)
+        ra.set_position(fen, is960, variant)
+        ra.go(simulations=sims)
+        first = ra.tree_dump().copy()
+        ra.go(simulations=2 * sims)                               # "reuse the full tree": the table of the first go is still there
+        dumps.append((first, ra.tree_dump().copy(), ra.root_children(), ra.eval_info()["best_move"]))
+        if not mcgs:
+            pool = search.SearchPool(st, eval_fn=_evaluator(nbp), fn_batch=quota, fn_nb_policy=nbp)
+            t = pool.add_position(fen, is960, variant)
+            pool.run(simulations=sims, threads=1)
+            pool.run(simulations=2 * sims, threads=1)
+            _compare(pool, t, ra, centi_base=1.4 if mode == 1 else None)
+            pool.close()
+        ra.close()
+    assert len(set(seen)) < len(seen)                             # some position was expanded at two places of the tree: transpositions exist
+    assert np.array_equal(dumps[0][0], dumps[1][0]) and np.array_equal(dumps[0][1], dumps[1][1])
+    assert dumps[0][2][0] == dumps[1][2][0] and dumps[0][2][1] == dumps[1][2][1] and dumps[0][3] == dumps[1][3]
+
+
 @pytest.mark.parametrize("variant,fen,mode,verdict,best", [
     ("chess", "6k1/5ppp/8/8/8/8/8/R3K3 w - - 0 1", 1, (0, 1), "a1a8"),                  # back-rank mate in 1: WIN in 1
     ("antichess", "8/8/8/8/8/4p3/5P1q/8 b - - 0 1", 2, (2, 1), None),                    # both forced captures take White's last piece: LOSS in 1

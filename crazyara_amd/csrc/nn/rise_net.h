@@ -144,12 +144,12 @@ private:
     bool fp8_tower_ = false;     // Precision fp8 (alias int8): e4m3 operands in the residual tower's GEMMs, everything else as float16
     bool fused_ = true;
     bool tower_ = true;
-    // Small batches (round 6): float16x3 / float16p8 nets made for at most kBoardSplitMaxBatch boards run their 3x3 bottleneck blocks one per
+    // Small batches (round 6): float16x3 / float16p8 nets made for at most kBoardSplitMaxBatch boards (64: measured faster up to 96, profiles/r06/d_*) run their 3x3 bottleneck blocks one per
     // launch with up to C_op / 128 workgroups per board (x3.hip: block_x3_split_kernel, float16x3 arithmetic in both modes) instead of the
     // one-workgroup-per-board tower, whose latency a small batch pays in full on a handful of CUs.  "-1wg" after the precision keeps the
     // one-workgroup-per-board tower (A/B, and the parity tests of the tower kernels on the small fixtures).
     bool board_split_ = true;
-    static constexpr int kBoardSplitMaxBatch = 32;
+    static constexpr int kBoardSplitMaxBatch = 64;
     bool one_launch_ = true;     // stem + tower + head in one launch when the net is exactly that chain ("-3k": three launches)
     bool rt_thin_waves_ = false; // dense residual tower: 8 waves x 32 couts ("-8w") instead of 4 x 64
     int boards_per_wg_ = 0;      // dense residual tower: 0 = by batch size (2 from 512 boards), 1 / 2 = forced ("-1b" / "-2b")

@@ -1199,7 +1199,9 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     } else {
     // _PolicyHead (select_policy_from_plane), builder_util.py:206-243
     // Precision float16p8, policy map at 256 channels: both convs of the head in ONE launch (x3.hip: conv3x3_p8_chain_kernel); CRA_P8_NO_HEAD_CHAIN: development A/B
-    const bool head_chain = p8_ && policy_map && C == 256 && round_up(cp, 16) <= 128 && getenv("CRA_P8_NO_HEAD_CHAIN") == nullptr;
+    // (a small batch: two launches, the first conv's couts over two workgroups per board -- 0.0xx against 0.049 ms at batch 1, profiles/r06/f_*)
+    const bool head_chain = p8_ && policy_map && C == 256 && round_up(cp, 16) <= 128 && getenv("CRA_P8_NO_HEAD_CHAIN") == nullptr &&
+                            !(x3_split && getenv("CRA_SMALL_BATCH_HEAD_CHAIN") == nullptr);
     if (head_chain) {
         Folded f1 = fold_bn(nf, "policy_head.body.0", "policy_head.body.1");
         double inv1 = 1.0;
@@ -1211,7 +1213,10 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         c.pre_bias = im.upload_d2f(f1.b, C);
         c.pre_acc_scale = float(inv1);
         macs += double(kSquares) * C * C * 9;
-    } else add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr, true);
+    } else {
+        add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr, true);
+        im.ops.back().conv.few_boards = x3_split ? 1 : 0;
+    }
     if (head_chain) {
     } else if (policy_map) {
         add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_, true);
@@ -1530,6 +1535,8 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
 }
 
 template <typename T> void RiseNet::enqueue(hipStream_t s, const IoOverride* io) {
+    // (Round 6 tried the value head of a small batch on a side stream beside the policy head -- two branches of the captured graph: the
+    // forward got SLOWER, 0.354 against 0.335 ms at batch 1, the cross-queue joins cost more than the 24 us they hide: profiles/r06/e_*.)
     for (int i = 0; i < int(impl_->ops.size()); ++i) launch_op<T>(i, s, io);
     HIP_CHECK(hipGetLastError());
 }

@@ -672,7 +672,8 @@ static void launch_conv3x3_p8(const ConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(conv3x3_p8_chain_kernel, dim3(1, a.batch), dim3(512), shmem, s, a);
         return;
     }
-    if (tiles >= 12 || (a.softmax_out && tiles > 8)) hipLaunchKernelGGL((conv3x3_p8_kernel<2, 8>), dim3((tiles + 15) / 16, a.batch), dim3(512), shmem, s, a);
+    // (a.few_boards: a small batch leaves CUs idle, so a 256-cout layer goes as two workgroups of 128 couts per board)
+    if ((tiles >= 12 && !a.few_boards) || (a.softmax_out && tiles > 8)) hipLaunchKernelGGL((conv3x3_p8_kernel<2, 8>), dim3((tiles + 15) / 16, a.batch), dim3(512), shmem, s, a);
     else hipLaunchKernelGGL((conv3x3_p8_kernel<1, 8>), dim3((tiles + 7) / 8, a.batch), dim3(512), shmem, s, a);
 }
 template <int KS, int NS> static void launch_conv_gemm_x3_ks(const ConvArgs& a, hipStream_t s) {
@@ -680,7 +681,7 @@ template <int KS, int NS> static void launch_conv_gemm_x3_ks(const ConvArgs& a, 
     const int tiles = a.cout_pad / 16;
     if (a.out_rows_f32) {                   // an FC over the batch: few "boards" (64 rows each), so as many workgroups as the couts give
         hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 1, 4, NS>), dim3((tiles + 3) / 4, a.batch), dim3(256), shmem, s, a);
-    } else if (tiles >= 12 || (a.softmax_out && tiles > 8)) {   // 192 couts and more (or a fused softmax: the board in one workgroup): 8 waves x 2 tiles, the whole cout range of a 256-wide layer in one workgroup
+    } else if ((tiles >= 12 && !a.few_boards) || (a.softmax_out && tiles > 8)) {   // 192 couts and more (or a fused softmax: the board in one workgroup): 8 waves x 2 tiles, the whole cout range of a 256-wide layer in one workgroup
         hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 2, 8, NS>), dim3((tiles + 15) / 16, a.batch), dim3(512), shmem, s, a);
     } else if (tiles >= 5) {                // 80 ... 176 couts: 8 waves x 1 tile (measured against 4 waves x 2 tiles: 0.036 / 0.042 ms for 96 couts)
         hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 1, 8, NS>), dim3((tiles + 7) / 8, a.batch), dim3(512), shmem, s, a);
@@ -946,8 +947,24 @@ __device__ __forceinline__ half8 x3_frag(__amdgpu_buffer_rsrc_t r, uint32_t lane
 // Measured and NOT kept (profiles/r03/o_*): P(ch - 1) and D(ch) as one instruction stream per wave (the depthwise cut in four pieces
 // between the project MFMAs, sched_group_barrier recipes): 0.754 ms against 0.710 for this form -- 256 registers with spills, and the
 // scheduler interleaved only half of the stretches.
-// ch0 / ch1: the chunk range [ch0, ch1) of the block (block_x3_split_kernel); default: all of them.
-__device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, f32x4 (&accP)[X3Block::NJ][4], int ch0 = 0, int ch1 = -1) {
+// ch0 / ch1: the chunk range [ch0, ch1) of the block (block_x3_split_kernel); default: all of them.  PRE: the caller has requested the
+// first chunk's expand window already (x3_expand_window_request, before it staged the board) and hands the registers in.
+struct X3ExpandWindow { half8 h[X3Block::NE == 1 ? 4 : 2][X3Block::NE], l[X3Block::NE == 1 ? 4 : 2][X3Block::NE]; };
+__device__ __forceinline__ void x3_expand_window_request(X3ExpandWindow& E, const X3Weights& W, int ch) {
+    constexpr int EW = X3Block::NE == 1 ? 4 : 2, NE = X3Block::NE;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+#pragma unroll
+    for (int s = 0; s < EW; ++s)
+#pragma unroll
+        for (int ne = 0; ne < NE; ++ne) {
+            const uint32_t f = uint32_t(ch * (X3Block::CK / 16) + wave * NE + ne) * (X3Block::C / 32) + uint32_t(s);
+            E.h[s][ne] = x3_frag(W.w1h, uint32_t(lane) * 16u, f);
+            E.l[s][ne] = x3_frag(W.w1l, uint32_t(lane) * 16u, f);
+        }
+}
+template <bool PRE = false>
+__device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, f32x4 (&accP)[X3Block::NJ][4], int ch0 = 0, int ch1 = -1,
+                                          const X3ExpandWindow* pre = nullptr) {
     using G = X3Block;
     constexpr int C = G::C, CK = G::CK, XROW = G::XROW, TROW = G::TROW, NJ = G::NJ, NE = G::NE;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
@@ -979,8 +996,15 @@ __device__ __forceinline__ void x3_chunks(const X3Tiles& T, const X3Weights& W, 
             e_l[s % EW][ne] = x3_frag(W.w1l, lane_off, f);
         }
     };
+    if constexpr (PRE) {
 #pragma unroll
-    for (int s = 0; s < EW; ++s) load_expand(ch0, s);
+        for (int s = 0; s < EW; ++s)
+#pragma unroll
+            for (int ne = 0; ne < NE; ++ne) { e_h[s][ne] = pre->h[s][ne]; e_l[s][ne] = pre->l[s][ne]; }
+    } else {
+#pragma unroll
+        for (int s = 0; s < EW; ++s) load_expand(ch0, s);
+    }
     for (int ch = ch0; ch < nchunk; ++ch) {
         half_t* const t2h = T.t2h + (G::T2BUF == 2 ? (ch & 1) * 64 * TROW : 0);
         half_t* const t2l = T.t2l + (G::T2BUF == 2 ? (ch & 1) * 64 * TROW : 0);
@@ -1180,7 +1204,14 @@ namespace {
 //   ca_se : FC1 thread t -> hidden 2*(t/8), +1 over c in [32*(t%8), +32);  FC2 thread t -> gate 2*(t/4), +1 over j in [32*(t%4), +32)
 //   eca_se: thread t -> gate 2*(t/4), +1 over inputs i in [64*(t%4), +64)
 // scratch (the t2 tiles, idle between blocks): mean 8 x 36, hidden 4 x 36, gate 256 floats.  Ends with a barrier.
-__device__ __forceinline__ void x3_se_phase(const X3Tiles& T, const X3TowerBlock& d, float* scratch, int tid) {
+// pre_wa: the thread's first 16 weight loads, requested by the caller before it staged the board (block_x3_split_kernel), else nullptr
+struct X3SeFirstWeights { f32x4 w[16]; };
+__device__ __forceinline__ void x3_se_first_weights_request(X3SeFirstWeights& S, const X3TowerBlock& d, int tid) {
+    const f32x4* pk = reinterpret_cast<const f32x4*>(d.se_w1t) + tid;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S.w[i] = pk[i * 512];
+}
+__device__ __forceinline__ void x3_se_phase(const X3Tiles& T, const X3TowerBlock& d, float* scratch, int tid, const X3SeFirstWeights* pre_wa = nullptr) {
     constexpr int C = X3Block::C, XROW = X3Block::XROW, GRP = 36;     // floats per group of 32 means / hidden values (bank spread)
     float* se_mean = scratch;              // [8][36]
     float* se_h = scratch + 8 * GRP;       // [4][36]
@@ -1191,7 +1222,11 @@ __device__ __forceinline__ void x3_se_phase(const X3Tiles& T, const X3TowerBlock
 #pragma unroll
         for (int i = 0; i < 16; ++i) dst[i] = pk[i * 512];
     };
-    load_thread_weights(d.se_w1t, wa);
+    if (pre_wa) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wa[i] = pre_wa->w[i];
+        load_thread_weights(d.se_kind == 1 ? d.se_w2t : d.se_w1t + size_t(16) * 512 * 4, wb);      // (the second set flies during the squeeze)
+    } else load_thread_weights(d.se_w1t, wa);
     {   // squeeze: a wave owns 32 channels: lane = (4 groups of 8 channels) x (16 groups of 4 squares); 16-lane DPP row reduction
         const int lane = tid & 63, wv = tid >> 6, cg = lane >> 4, sg = lane & 15;
         float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1215,7 +1250,7 @@ __device__ __forceinline__ void x3_se_phase(const X3Tiles& T, const X3TowerBlock
             for (int j = 0; j < 8; ++j) se_mean[wv * GRP + cg * 8 + j] = sum[j] * (1.f / 64.f);      // channel c at (c / 32) * 36 + c % 32
         }
     }
-    load_thread_weights(d.se_kind == 1 ? d.se_w2t : d.se_w1t + size_t(16) * 512 * 4, wb);      // flies during FC1 (eca: the second half)
+    if (!pre_wa) load_thread_weights(d.se_kind == 1 ? d.se_w2t : d.se_w1t + size_t(16) * 512 * 4, wb);      // flies during FC1 (eca: the second half)
     __syncthreads();
     auto dot32 = [](const f32x4 (&w)[16], const float* v, float& s0, float& s1) {   // v: 32 floats, 16-byte aligned; w[i] = (a, b, a', b') of k = 2i, 2i+1
 #pragma unroll
@@ -1350,32 +1385,41 @@ template <int GIN>
 __device__ __forceinline__ void x3_stage_tile_sum(const X3Tiles& T, const float* parts, int gin, int tid) {
     constexpr int C = X3Block::C, XROW = X3Block::XROW, IT = 64 * (C / 8) / X3Block::NTHR;
     constexpr int NG = GIN > 0 ? GIN : 16;
-    f32x4 q[NG][2];
+    constexpr int FLY = GIN > 0 && GIN <= 2 ? 4 : GIN > 0 && GIN <= 5 ? 2 : 1;       // passes requested together (8 NG registers each)
+    static_assert(IT % FLY == 0, "passes");
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int i = tid + it * X3Block::NTHR, sq = i / (C / 8), v = i - sq * (C / 8), r = x3_row(sq);
-        const float* p0 = parts + size_t(sq) * C + v * 8;
+    for (int it0 = 0; it0 < IT; it0 += FLY) {
+        f32x4 q[FLY][NG][2];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (GIN > 0 || g < gin) {
-                const f32x4* p = reinterpret_cast<const f32x4*>(p0 + size_t(g) * 64 * C);
-                q[g][0] = p[0];
-                q[g][1] = p[1];
+        for (int u = 0; u < FLY; ++u) {
+            const int i = tid + (it0 + u) * X3Block::NTHR, sq = i / (C / 8), v = i - sq * (C / 8);
+            const float* p0 = parts + size_t(sq) * C + v * 8;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (GIN > 0 || g < gin) {
+                    const f32x4* p = reinterpret_cast<const f32x4*>(p0 + size_t(g) * 64 * C);
+                    q[u][g][0] = p[0];
+                    q[u][g][1] = p[1];
+                }
             }
         }
-        f32x4 s0 = q[0][0], s1 = q[0][1];
 #pragma unroll
-        for (int g = 1; g < NG; ++g) {
-            if (GIN > 0 || g < gin) {
-                s0 += q[g][0];
-                s1 += q[g][1];
+        for (int u = 0; u < FLY; ++u) {
+            const int i = tid + (it0 + u) * X3Block::NTHR, sq = i / (C / 8), v = i - sq * (C / 8), r = x3_row(sq);
+            f32x4 s0 = q[u][0][0], s1 = q[u][0][1];
+#pragma unroll
+            for (int g = 1; g < NG; ++g) {
+                if (GIN > 0 || g < gin) {
+                    s0 += q[u][g][0];
+                    s1 += q[u][g][1];
+                }
             }
+            const float f[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            half8 h, l;
+            split8(f, h, l);
+            *reinterpret_cast<half8*>(T.xh + r * XROW + v * 8) = h;
+            *reinterpret_cast<half8*>(T.xl + r * XROW + v * 8) = l;
         }
-        const float f[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-        half8 h, l;
-        split8(f, h, l);
-        *reinterpret_cast<half8*>(T.xh + r * XROW + v * 8) = h;
-        *reinterpret_cast<half8*>(T.xl + r * XROW + v * 8) = l;
     }
 }
 }  // namespace
@@ -1394,6 +1438,15 @@ __global__ __launch_bounds__(512) void block_x3_split_kernel(const X3SplitArgs a
     if (b >= a.batch) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const X3TowerBlock& d = a.blk;
+    // the first chunk's expand weights are requested before the board is staged: they come from the memory-side cache (every chunk of the
+    // net is read by exactly one workgroup per forward) and land while the partial sums are added up
+    const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
+    const int n = W.cop_pad / CK;
+    const int ch0 = __builtin_amdgcn_readfirstlane(g * n / G_), ch1 = __builtin_amdgcn_readfirstlane((g + 1) * n / G_);
+    X3ExpandWindow win;
+    x3_expand_window_request(win, W, ch0);
+    X3SeFirstWeights se_first;                                          // a gated block: the gate matrices' first half as well (128 KB per workgroup)
+    if (d.se_kind != 0) x3_se_first_weights_request(se_first, d, tid);
     {
         const float* parts = a.x_parts + size_t(b) * a.gin * 64 * C;
         switch (a.gin) {                                                // (the usual counts with every load of a pass in flight at once)
@@ -1411,10 +1464,7 @@ __global__ __launch_bounds__(512) void block_x3_split_kernel(const X3SplitArgs a
         }
     }
     __syncthreads();
-    if (d.se_kind != 0) x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid);      // every workgroup of the board: the same gate, the same gated tiles
-    const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
-    const int n = W.cop_pad / CK;
-    const int ch0 = __builtin_amdgcn_readfirstlane(g * n / G_), ch1 = __builtin_amdgcn_readfirstlane((g + 1) * n / G_);
+    if (d.se_kind != 0) x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid, &se_first);      // every workgroup of the board: the same gate, the same gated tiles
     f32x4 accP[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -1422,7 +1472,7 @@ __global__ __launch_bounds__(512) void block_x3_split_kernel(const X3SplitArgs a
 #pragma unroll
         for (int t = 0; t < 4; ++t) accP[j][t] = bs;
     }
-    if (!(a.dev & 4)) x3_chunks(T, W, accP, ch0, ch1);                   // (development bit 4, timing only: no chunk loop)
+    if (!(a.dev & 4)) x3_chunks<true>(T, W, accP, ch0, ch1, &win);       // (development bit 4, timing only: no chunk loop)
     // epilogue: this workgroup's part of x + b3 + body(x) (workgroup 0 carries x and b3) -> its own image
     float* yb = a.y_parts + (size_t(b) * G_ + g) * 64 * C;
 #pragma unroll

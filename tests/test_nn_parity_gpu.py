@@ -42,7 +42,7 @@ TOL["float16x3-unfused"] = TOL["float32"]   # every block on the layer kernels (
 # float16x3 whose one-launch tower takes the cross terms of both 1x1 GEMMs through e5m2 MFMAs (truncated activation bytes): emulated
 # 5e-5 ... 1.3e-4 on the logits, 3e-5 on the value (scripts/studies/p8_format_study.py); bounds at twice that, a third of north_star's 1e-3
 TOL["float16p8"] = dict(logit=3e-4, logit_rel=None, value=1e-4, prob=1e-6, aux=1e-4)
-# "-1wg": nets made for at most 32 boards run their 3x3 blocks one per launch with several workgroups per board (block_x3_split_kernel,
+# "-1wg": nets made for at most 64 boards run their 3x3 blocks one per launch with several workgroups per board (block_x3_split_kernel,
 # round 6); the suffix keeps the one-workgroup-per-board tower kernels, which the four-board fixtures would otherwise never reach
 TOL["float16x3-1wg"] = TOL["float32"]
 TOL["float16p8-1wg"] = TOL["float16p8"]
@@ -530,7 +530,7 @@ def test_float16p8_launch_structure(tmp_path, hip_lib, name, towers):
     names = [n for n, _ in net.time_ops(1)]
     net.close()
     assert names == ["conv_gemm_x3_3x3"] + ["tower_p8"] * towers + ["conv_gemm_x3_3x3", "value_head"], names
-    # at batch 256 the plain name is that structure; at 32 boards and below the 3x3 runs go one block per launch, several workgroups per board
+    # at batch 256 the plain name is that structure; at 64 boards and below the 3x3 runs go one block per launch, several workgroups per board
     net = HipAPI(0, 256, d, "float16p8")
     assert [n for n, _ in net.time_ops(1)] == names
     net.close()
@@ -544,7 +544,7 @@ def test_float16p8_launch_structure(tmp_path, hip_lib, name, towers):
 @pytest.mark.parametrize("name,batch", [("risev2-19", 1), ("risev2-19", 3), ("risev2-19", 8), ("risev2-19", 32), ("risev2-7", 8), ("risev33-wdlp", 5),
                                         ("risev2-13-lichess", 16)])
 def test_board_split_forward_small_batches(tmp_path, hip_lib, name, batch, precision):
-    """Round 6 (VERDICT r05 next #1b): nets made for <= 32 boards run every 3x3 bottleneck block as ONE launch with up to C_op / 128 workgroups
+    """Round 6 (VERDICT r05 next #1b): nets made for <= 64 boards run every 3x3 bottleneck block as ONE launch with up to C_op / 128 workgroups
     per board, each owning a share of the block's chunks, partial project sums added as 64-bit fixed point (block_x3_split_kernel).  The
     arithmetic is float16x3's in both modes, so the bound is float16x3's 1e-4 on the logits; integer sums are order-free: two nets, three
     forwards each, identical bits; and the split forward sits within float16x3 round-off of the one-workgroup-per-board tower."""

@@ -116,6 +116,7 @@ private:
     void capture();
     bool buffers_are_pinned(const float* in_planes, float* value, float* probs, float* aux);
     bool last_zero_copy_ = false;
+    bool counted_in_flight_ = false;   // this net's predict is counted in the device's predicts-in-flight (submit ... wait)
     // Development switches: read from the environment ONCE, when the net is constructed -- never on the per-batch path,
     // where several lane threads would otherwise scan `environ` per kernel launch beside a host program that may call setenv.
     struct DevSwitches {
@@ -124,6 +125,7 @@ private:
         bool lane_graph = false;        // CRA_LANE_GRAPH: the lane step replays the graph
         bool lane_no_graph = false;     // CRA_LANE_NO_GRAPH: the lane step never replays the graph
         bool predict_copy = false;      // CRA_PREDICT_COPY: predict() stages through device buffers also for pinned caller buffers
+        bool predict_zero_copy = false; // CRA_PREDICT_ZERO_COPY: predict() on pinned buffers never stages, whatever else is in flight
         char lane_launches = 0;         // CRA_LANE_LAUNCHES: '1' / '2' / '3' force the shape of the lane step
         bool lane_sync = false;         // CRA_LANE_SYNC: a stream sync between forward and gather
         bool x3_symmetric = false;      // CRA_X3_TOWER=symmetric: the float16x3 tower with every wave running all three phases

@@ -1,5 +1,6 @@
 #include "rise_net.h"
 
+#include <atomic>
 #include <mutex>
 
 #include <cmath>
@@ -277,6 +278,7 @@ RiseNet::DevSwitches::DevSwitches() {
     lane_graph = getenv("CRA_LANE_GRAPH") != nullptr;
     lane_no_graph = getenv("CRA_LANE_NO_GRAPH") != nullptr;
     predict_copy = getenv("CRA_PREDICT_COPY") != nullptr;
+    predict_zero_copy = getenv("CRA_PREDICT_ZERO_COPY") != nullptr;
     if (const char* e = getenv("CRA_LANE_LAUNCHES")) lane_launches = e[0];
     lane_sync = getenv("CRA_LANE_SYNC") != nullptr;
     if (const char* e = getenv("CRA_X3_TOWER")) x3_symmetric = e[0] == 's';
@@ -379,8 +381,13 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
 }
 
 static void turns_forget_stream(int device, hipStream_t s);     // below, next to RiseNet::Turn
+// predict()s in flight per device (submit ... wait of any net): what decides between the two forms of a predict on pinned buffers (submit)
+namespace {
+std::atomic<int> g_predicts_in_flight[64];
+}
 
 RiseNet::~RiseNet() {
+    if (counted_in_flight_) g_predicts_in_flight[device_].fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(device_);
     if (stream_) {
         (void)hipStreamSynchronize(stream_);
@@ -1881,7 +1888,18 @@ bool RiseNet::buffers_are_pinned(const float* in_planes, float* value, float* pr
 void RiseNet::submit(const float* in_planes, float* value, float* probs, float* aux) {
     HIP_CHECK(hipSetDevice(device_));   // every predict selects its device, tensorrtapi.cpp:198
     const size_t B = design_.batch;
-    last_zero_copy_ = buffers_are_pinned(in_planes, value, probs, aux);
+    // Zero-copy or staged?  With pinned buffers the kernels can read the planes and write value / probabilities across PCIe themselves: no
+    // copy commands, the best form for ONE user (338k against 331k evals/s at batch 256, profiles/r05/p_*).  With a second user's forward
+    // on the device the staged form wins by 6 - 12 % in every measurement (422k against 377k: the copies of one user run on the DMA
+    // engines beside the other user's forward, while a zero-copy forward holds its CUs for the whole PCIe write): so the form is chosen
+    // from what is in flight when the call arrives -- the reference's default is Threads = 2 (optionsuci.cpp), i.e. two users.
+    // CRA_PREDICT_COPY / CRA_PREDICT_ZERO_COPY (when the net was made) force one form.
+    const bool others_in_flight = device_ >= 0 && device_ < 64 && g_predicts_in_flight[device_].load(std::memory_order_relaxed) > (counted_in_flight_ ? 1 : 0);
+    if (!counted_in_flight_ && device_ >= 0 && device_ < 64) {
+        g_predicts_in_flight[device_].fetch_add(1, std::memory_order_relaxed);
+        counted_in_flight_ = true;
+    }
+    last_zero_copy_ = buffers_are_pinned(in_planes, value, probs, aux) && (dev_.predict_zero_copy || !others_in_flight);
     if (last_zero_copy_) {
         IoOverride io;
         io.planes = in_planes;
@@ -1976,6 +1994,15 @@ void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int la
 }
 
 void RiseNet::wait() {
+    struct Done {                                                       // the predict is over however this call ends
+        RiseNet& n;
+        ~Done() {
+            if (n.counted_in_flight_) {
+                g_predicts_in_flight[n.device_].fetch_sub(1, std::memory_order_relaxed);
+                n.counted_in_flight_ = false;
+            }
+        }
+    } done{*this};
     // CRA_WAIT_POLL=1 polls hipStreamQuery instead (development: on the hosts measured so far the runtime's own wait was not the
     // source of the per-batch latency; both give the same pipeline rate)
     static const bool poll = getenv("CRA_WAIT_POLL") != nullptr;

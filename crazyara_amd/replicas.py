@@ -34,6 +34,24 @@ def reduce_stats(local: ReplicaStats, dist=None, device: Optional[torch.device] 
     return float(vec[0]), float(sec.cpu()[0]), [float(v) for v in vec[1:]]
 
 
+def reduce_game_leg(local: Optional[dict], dist=None, device: Optional[torch.device] = None, world: int = 1) -> dict:
+    """One game leg (self-play / arena) of a sharded run: this rank's {games, moves, seconds, mcts_nodes_per_sec} -> the whole job's
+    games/min and nodes/sec (SUM of games, moves and nodes, MAX of seconds: one all_reduce pair, rl_loop.py:60 / selfplay.cpp:339-351
+    sum their per-device files the same way) with every rank's own games/min beside it (one all_gather of two scalars).  `local` None:
+    a rank that played nothing (a rehearsal rank) still takes part in both collectives."""
+    r = local or {"games": 0, "moves": 0, "seconds": 1e-9, "mcts_nodes_per_sec": 0.0}
+    nodes = float(r["mcts_nodes_per_sec"]) * float(r["seconds"])
+    games_t, sec_t, ex = reduce_stats(ReplicaStats(units=float(r["games"]), seconds=float(r["seconds"]), extra=(float(r["moves"]), nodes)), dist, device)
+    mine = torch.tensor([r["games"] / r["seconds"] * 60 if r["games"] else 0.0, float(r["games"])], dtype=torch.float64, device=device)
+    allr = [mine]
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+    return {"games_per_min": round(games_t / sec_t * 60, 1), "games": int(games_t), "moves": int(ex[0]), "seconds": round(sec_t, 3),
+            "mcts_nodes_per_sec": round(ex[1] / sec_t, 1),
+            "per_rank_games_per_min": [round(float(v[0]), 1) for v in allr], "per_rank_games": [int(v[1]) for v in allr]}
+
+
 def throughput(local: ReplicaStats, dist=None, device: Optional[torch.device] = None) -> float:
     units, seconds, _ = reduce_stats(local, dist, device)
     return units / seconds if seconds > 0 else 0.0

@@ -87,6 +87,39 @@ public:
     void submit(float* in, float* value, float* probs, float* aux) { mi_net_submit(net, in, value, probs, aux); }
     void wait() { mi_net_wait(net); }
     mi_net* handle() const { return net; }
+
+    // Descriptor-fed batches (integration/searchthread_hip.patch: SearchThread under HIP_BACKEND).  A leaf is handed
+    // over as its 192-byte board descriptor (BoardState::fill_board_desc) and the input planes are built on the GPU; the layout id follows
+    // the engine's build mode and the version in the model's file name, like board_to_planes' dispatch (inputrepresentation.cpp:628-680).
+    int planes_layout() const {
+#if defined(HIP_ENGINE_MODE)
+        const int mode = HIP_ENGINE_MODE;               // (a build whose mode is a run-time value)
+#elif defined(MODE_CRAZYHOUSE)
+        const int mode = MI_MODE_CRAZYHOUSE;
+#elif defined(MODE_LICHESS)
+        const int mode = MI_MODE_LICHESS;
+#else
+        const int mode = MI_MODE_CHESS;
+#endif
+        return mi_planes_layout_minor(mode, int(version::get_major(version)), int(version::get_minor(version)));
+    }
+    // whole probability vectors (value / probs / aux as predict() fills them; any host memory)
+    void predict_boards(const void* descs, int nValid, float* valueOutput, float* probOutputs, float* auxiliaryOutputs) {
+        if (mi_net_submit_boards(net, descs, nValid, planes_layout(), valueOutput, probOutputs, auxiliaryOutputs) != 0 || mi_net_wait(net) != 0) {
+            info_string_important("HipAPI::predict_boards:", mi_last_error());
+            std::abort();
+        }
+    }
+    // only the priors the search reads: gathered[s * stride + j] = probs[s][idx[s * stride + j]], j < cnt[s] (what
+    // Node::set_probabilities_for_moves picks out, node.cpp:961-979).  Every buffer must come from mi_host_alloc.
+    void predict_boards_gathered(const void* descs, int nValid, const unsigned short* idx, const unsigned* cnt, unsigned stride,
+                                 float* valueOutput, float* gathered) {
+        if (mi_net_submit_boards_gathered(net, descs, nValid, planes_layout(), idx, cnt, stride, valueOutput, gathered, nullptr) != 0 ||
+            mi_net_wait(net) != 0) {
+            info_string_important("HipAPI::predict_boards_gathered:", mi_last_error());
+            std::abort();
+        }
+    }
 };
 
 #endif // HIPAPI_H

@@ -33,6 +33,11 @@ OUT = os.path.join(os.path.dirname(HERE), "_ref")
 LIB = os.path.join(OUT, "libcrazyara_ref.so")
 LIB_HIP = os.path.join(OUT, "libcrazyara_ref_hip.so")     # + integration/hipapi.h, linked against the product library
 LIB_HIP_RELEASE = os.path.join(OUT, "libcrazyara_ref_hip_release.so")
+# the reference's SearchThread with integration/searchthread_hip.patch applied (descriptor-fed batches, gathered priors): the patch is
+# applied to a COPY of searchthread.cpp made here at build time (oracle/_ref/patched/, git-ignored) -- nothing of the reference is committed
+LIB_HIP_PATCHED = os.path.join(OUT, "libcrazyara_ref_hip_patched.so")                  # asserting build: the parity test
+LIB_HIP_PATCHED_RELEASE = os.path.join(OUT, "libcrazyara_ref_hip_patched_release.so")  # -O3 -DNDEBUG: the drop-in throughput leg
+PATCH = os.path.join(ROOT, "integration", "searchthread_hip.patch")
 
 REFERENCE_SOURCES = [
     "nodedata.cpp", "searchthread.cpp", "evalinfo.cpp", "state.cpp", "stateobj.cpp",
@@ -61,6 +66,7 @@ def _inputs():
     files += [os.path.join(ROOT, "crazyara_amd", "csrc", "chess", h) for h in ("position.h", "policy.h", "planes.h", "planes_host.h")]
     files.append(os.path.join(ROOT, "include", "crazyara_hip.h"))
     files.append(os.path.join(ROOT, "integration", "hipapi.h"))
+    files.append(PATCH)
     return files
 
 
@@ -143,6 +149,30 @@ def build(force: bool = False, verbose: bool = False):
                             "-Wl,-rpath,$ORIGIN/../../crazyara_amd/lib", "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed (HipAPI release build):\n" + r.stdout)
+        # ---- the patched SearchThread (HIP_BACKEND): same objects, searchthread.cpp replaced by the patched copy ----
+        pdir = os.path.join(OUT, "patched")
+        os.makedirs(pdir, exist_ok=True)
+        patched_src = os.path.join(pdir, "searchthread.cpp")
+        shutil.copyfile(os.path.join(SRC, "searchthread.cpp"), patched_src)
+        r = subprocess.run(["patch", "-p3", "--no-backup-if-mismatch", patched_src, PATCH], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("integration/searchthread_hip.patch does not apply to the reference's searchthread.cpp:\n" + r.stdout)
+        hip_defs = ["-DHIP_BACKEND", "-DHIP_ENGINE_MODE=refshim::config().mode", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "integration"),
+                    "-I", os.path.join(pdir, "inc")]
+        # the patch includes "nn/hipapi.h" (where a maintainer puts the file): give the include path that shape
+        os.makedirs(os.path.join(pdir, "inc", "nn"), exist_ok=True)
+        shutil.copyfile(os.path.join(ROOT, "integration", "hipapi.h"), os.path.join(pdir, "inc", "nn", "hipapi.h"))
+        for flags, base_objs, drv_obj, lib in ((FLAGS, others, drv, LIB_HIP_PATCHED),
+                                               (rel_flags, [o for o in rel_objs if not o.endswith("searchthread.cpp.o")], None, LIB_HIP_PATCHED_RELEASE)):
+            obj = os.path.join(pdir, ("rel_" if lib == LIB_HIP_PATCHED_RELEASE else "") + "searchthread_patched.o")
+            r = subprocess.run([gxx] + flags + inc + hip_defs + ["-c", patched_src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("g++ failed on the patched searchthread.cpp:\n" + r.stdout)
+            link_objs = [o for o in base_objs if not o.endswith("searchthread.cpp.o")] + [obj] + ([drv_obj] if drv_obj else [])
+            r = subprocess.run([gxx, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", lib] + link_objs + ["-L", product_lib_dir, "-lcrazyara_hip",
+                                "-Wl,-rpath,$ORIGIN/../../crazyara_amd/lib", "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("link failed (patched SearchThread build):\n" + r.stdout)
     with open(stamp_file, "w") as f:
         f.write(stamp)
     return LIB

@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include <cstring>
+
 #include "state.h"
 
 #include "chess/planes.h"
@@ -106,6 +108,13 @@ public:
         cra::BoardDesc d;
         cra::chess::pack_desc(pos, d, cra::layout_needs_move_features(refshim::config().layout));
         refshim::pending_descs().push_back(d);
+    }
+    // what a maintainer adds to BoardState for the descriptor-fed SearchThread (integration/searchthread_hip.patch): the position as the
+    // 192-byte descriptor the GPU plane builder reads (include/crazyara_hip.h: mi_pos_desc)
+    void fill_board_desc(void* out) const {
+        cra::BoardDesc d;
+        cra::chess::pack_desc(pos, d, cra::layout_needs_move_features(refshim::config().layout));
+        std::memcpy(out, &d, sizeof(d));
     }
     unsigned int steps_from_null() const override { return unsigned(pos.game_ply()); }     // boardstate.cpp:82-85
     bool is_chess960() const override { return pos.is_chess960(); }

@@ -86,7 +86,6 @@ def _declare(lib):
 
 
 LIB_HIP_PATH = os.path.join(HERE, "_ref", "libcrazyara_ref_hip.so")
-_lib_hip = None
 
 
 def hip_available() -> bool:
@@ -95,37 +94,13 @@ def hip_available() -> bool:
 
 
 LIB_HIP_RELEASE_PATH = os.path.join(HERE, "_ref", "libcrazyara_ref_hip_release.so")
-_lib_hip_release = None
+# the reference's SearchThread with integration/searchthread_hip.patch applied (descriptor-fed batches, priors gathered on the GPU)
+LIB_HIP_PATCHED_PATH = os.path.join(HERE, "_ref", "libcrazyara_ref_hip_patched.so")
+LIB_HIP_PATCHED_RELEASE_PATH = os.path.join(HERE, "_ref", "libcrazyara_ref_hip_patched_release.so")
+_libs_hip = {}
 
 
-def load_hip(release: bool = False):
-    """The same library with integration/hipapi.h compiled in (the reference-side binding of the product library).
-    release = True: the -O3 -DNDEBUG build of the same sources (the reference's Release configuration), for throughput measurements."""
-    global _lib_hip, _lib_hip_release
-    if release:
-        if _lib_hip_release is None:
-            from oracle.ref import build_ref
-            build_ref.build()
-            if not os.path.exists(LIB_HIP_RELEASE_PATH):
-                raise RuntimeError("oracle/_ref/libcrazyara_ref_hip_release.so is not built")
-            from crazyara_amd import _capi
-            _capi.load()
-            lib = C.CDLL(LIB_HIP_RELEASE_PATH)
-            _declare(lib)
-            lib.ref_agent_create_hip_threads.restype = C.c_void_p
-            lib.ref_agent_create_hip_threads.argtypes = [C.POINTER(SearchSettingsC), C.c_char_p, C.c_int, C.c_char_p, C.c_int]
-            _lib_hip_release = lib
-        return _lib_hip_release
-    if _lib_hip is not None:
-        return _lib_hip
-    from oracle.ref import build_ref
-    build_ref.build()
-    if not os.path.exists(LIB_HIP_PATH):
-        raise RuntimeError("oracle/_ref/libcrazyara_ref_hip.so is not built")
-    from crazyara_amd import _capi
-    _capi.load()                                  # the product library first (RTLD_GLOBAL), then the binding that links against it
-    lib = C.CDLL(LIB_HIP_PATH)
-    _declare(lib)
+def _declare_hip(lib):
     lib.ref_agent_create_hip.restype = C.c_void_p
     lib.ref_agent_create_hip.argtypes = [C.POINTER(SearchSettingsC), C.c_char_p, C.c_int, C.c_char_p]
     lib.ref_agent_create_hip_threads.restype = C.c_void_p
@@ -138,7 +113,33 @@ def load_hip(release: bool = False):
     lib.ref_hipapi_validate.argtypes = [C.c_void_p]
     lib.ref_hipapi_run_inference.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                              C.POINTER(C.c_float), C.POINTER(C.c_double)]
-    _lib_hip = lib
+
+
+def hip_patched_available() -> bool:
+    from oracle.ref import build_ref
+    return os.path.exists(LIB_HIP_PATCHED_PATH) or build_ref.reference_present()
+
+
+def load_hip(release: bool = False, patched: bool = False):
+    """The same library with integration/hipapi.h compiled in (the reference-side binding of the product library).
+    release = True: the -O3 -DNDEBUG build of the same sources (the reference's Release configuration), for throughput measurements.
+    patched = True: the build whose SearchThread carries integration/searchthread_hip.patch (every library has its own copy of the
+    reference's globals, so agents of the plain and of the patched build live side by side in one process)."""
+    key = (bool(release), bool(patched))
+    if key in _libs_hip:
+        return _libs_hip[key]
+    path = {(False, False): LIB_HIP_PATH, (True, False): LIB_HIP_RELEASE_PATH,
+            (False, True): LIB_HIP_PATCHED_PATH, (True, True): LIB_HIP_PATCHED_RELEASE_PATH}[key]
+    from oracle.ref import build_ref
+    build_ref.build()
+    if not os.path.exists(path):
+        raise RuntimeError(f"oracle/_ref/{os.path.basename(path)} is not built")
+    from crazyara_amd import _capi
+    _capi.load()                                  # the product library first (RTLD_GLOBAL), then the binding that links against it
+    lib = C.CDLL(path)
+    _declare(lib)
+    _declare_hip(lib)
+    _libs_hip[key] = lib
     return lib
 
 
@@ -200,10 +201,10 @@ class RefAgent:
     eval_fn(list of 192-byte board descriptors) -> (values, probs[n][nb_policy]) -- the signature the product's callback lane uses."""
 
     def __init__(self, settings: SearchSettingsC, eval_fn: Callable = None, nb_policy: int = 0, hip_model_dir: str = None,
-                 device_id: int = 0, precision: str = "float16", threads: int = 1, release: bool = False):
+                 device_id: int = 0, precision: str = "float16", threads: int = 1, release: bool = False, patched: bool = False):
         self.nb_policy = nb_policy
         if hip_model_dir is not None:                       # the agent's nets are HipAPI objects: `go` evaluates on the GPU
-            self._lib = load_hip(release)
+            self._lib = load_hip(release, patched)
             self._cb = None
             # threads = the UCI option `Threads`: that many SearchThreads (own batch net each) on the one tree, crazyara.cpp:548-563
             self._h = self._lib.ref_agent_create_hip_threads(C.byref(settings), hip_model_dir.encode(), device_id, precision.encode(), int(threads))

@@ -61,6 +61,29 @@ def make_case(name):
     return cfg, sd, x
 
 
+def scale_activations(cfg, sd, act=8.0):
+    """A copy of `sd` whose activations -- stem output, every tensor of the bottleneck blocks, the heads' hidden layers -- and policy
+    logits are `act` times larger (trained nets have logits of +-10 and more; the seeded random nets sit at +-2): the stem's BatchNorm scales
+    its output, every later BatchNorm takes running_mean * act and bias * act (BN(act u) with those = act BN(u)), the value head's last
+    Linear is divided by `act` so that the value does not saturate.  SE gates see larger means (not homogeneous): a different net, not a
+    rescaling of the same function -- a stress case for the precision modes' ABSOLUTE error bounds."""
+    out = {k: v.clone() for k, v in sd.items()}
+    pre = cfg.key_prefix
+    for k in (pre + ".0.body.1.weight", pre + ".0.body.1.bias"):
+        out[k] = out[k] * act
+    for k in list(out):
+        if k.startswith(pre + ".0.body.1."):
+            continue
+        if k.endswith(".running_mean") or (k.endswith(".bias") and k[:-5] + ".running_mean" in out):
+            out[k] = out[k] * act
+    out["value_head.body_final.0.bias"] = out["value_head.body_final.0.bias"] * act
+    out["value_head.body_final.2.weight"] = out["value_head.body_final.2.weight"] / act
+    for k in ("value_head.body_wdl.0.weight", "value_head.body_plys.0.weight"):
+        if k in out:
+            out[k] = out[k] / act
+    return out
+
+
 def synthetic_planes(batch, channels, seed):
     """Board-like planes: ~88 % zeros, sparse ones, a few constant planes with fractional values."""
     rng = np.random.default_rng(seed)

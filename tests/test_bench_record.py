@@ -36,7 +36,11 @@ def test_line_is_small_and_complete():
     assert list(back)[-1] == "summary"                                       # a truncating log keeps the tail
     # no companion rates inside roofline, nothing repeated at the top level
     assert not [k for k in back["roofline"] if "nodes_per_sec" in k or "evals_per_sec" in k]
-    assert not [k for k in back if k.startswith(("config2_", "value_float16", "value_pcie"))]
+    assert not [k for k in back if k.startswith(("config2_", "value_float16"))]
+    # SURVEY 8(d) Metric 1 (the reference's `inference` loop, host copies included) sits at the top level beside the device-resident `value`
+    assert back["value_device_resident"] == back["value"]
+    assert back["value_pcie_inclusive_one_user"] == full["pcie_inclusive"]["one_net_evals_per_sec"]
+    assert back["value_pcie_inclusive_two_users"] == full["pcie_inclusive"]["two_nets_in_flight_evals_per_sec"]
     # the other half of the metric and the reference-default mode are in the summary
     s = back["summary"]
     assert s["config2_mcts_nodes_per_sec_float16p8"] == full["mcts"]["mcts_nodes_per_sec"]
@@ -52,3 +56,49 @@ def test_line_shrinks_when_the_result_grows():
     line = bench.compact_record(full, "d.json")
     assert len(json.dumps(line)) < bench.LINE_LIMIT
     assert line["roofline"]["frac"] and line["cpu_baseline"]["value"]
+
+
+def test_round6_reporting_keys():
+    """NN evals/s at batch 8 / 512 / 1024 and config 3 with both value heads, the copy-path rates, the dominant kernel
+    against the RAW dense f16 peak, the whole forward on the timed region's clock -- and, from a multi-rank run, configs 4 and 5 as sharded
+    game legs with per-rank arrays."""
+    import bench
+    full = _round4_full()
+    full["nn_by_batch"] = {k: {"evals_per_sec": 1000.0 + i, "ms_per_step": 0.5, "frac": 0.1} for i, k in
+                           enumerate(("batch8", "batch512", "batch1024", "config3_tanh", "config3_wdlp"))}
+    full["pcie_inclusive"].update({"copy_path_one_net_evals_per_sec": 1.0, "copy_path_two_nets_evals_per_sec": 2.0,
+                                   "zero_copy_forced_two_nets_evals_per_sec": 3.0})
+    full["roofline"]["frac_of_dense_f16_peak"] = 0.17
+    full["roofline"]["whole_forward"] = {"ms_per_step": 0.6, "event_ms_per_step": 0.66, "achieved": 400.0, "frac": 0.33}
+    full["game_configs"] = {"config4_selfplay": {"games_per_min": 900.0, "games": 24, "moves": 1000, "seconds": 1.6, "mcts_nodes_per_sec": 1.5e6,
+                                                 "per_rank_games_per_min": [300.0, 310.0, 290.0], "per_rank_games": [8, 8, 8]},
+                            "config5_arena": {"games_per_min": 2000.0, "games": 96, "moves": 5000, "seconds": 2.9, "mcts_nodes_per_sec": 1.8e6,
+                                              "per_rank_games_per_min": [700.0, 650.0, 660.0], "per_rank_games": [32, 32, 32]}}
+    line = bench.compact_record(full, "d.json")
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    s = line["summary"]
+    for k in ("batch8", "batch512", "batch1024", "config3_tanh", "config3_wdlp"):
+        assert s[f"nn_evals_per_sec_{k}"] == full["nn_by_batch"][k]["evals_per_sec"]
+    assert s["copy_path_one_user"] == 1.0 and s["copy_path_two_users"] == 2.0 and s["zero_copy_forced_two_users"] == 3.0
+    assert line["roofline"]["frac_of_dense_f16_peak"] == 0.17
+    assert line["roofline"]["whole_forward_ms"] == 0.6 and line["roofline"]["whole_forward_frac"] == 0.33
+    assert s["config4_selfplay_games_per_min"] == 900.0 and s["config4_selfplay_per_rank_games_per_min"] == [300.0, 310.0, 290.0]
+    assert s["config5_arena_games_per_min"] == 2000.0 and len(s["config5_arena_per_rank_games_per_min"]) == 3
+
+
+def test_line_limit_holds_for_an_oversized_result_and_for_legs_without_rates():
+    """a large roofline.pmc block, many modes and game legs must not push the line past the limit, and a leg that recorded a skip
+    or an error (no rate field) must not raise after the whole bench has run."""
+    import bench
+    full = _round4_full()
+    full["roofline"]["pmc"] = {f"COUNTER_{i}": 123456789.0 + i for i in range(150)}
+    for i in range(60):
+        full["modes"][f"mode_{i}"] = dict(full["modes"]["float16"])
+        full["game_configs"][f"config_extra_{i}"] = {"games_per_min": 1.0, "mcts_nodes_per_sec": 2.0, "games_per_min_float16": 3.0}
+    full["modes"]["broken"] = {"error": "hipErrorOutOfMemory"}
+    full["mcts_configs"]["config_skipped"] = {"skipped": "no reference build"}
+    full["game_configs"]["config_failed"] = {"error": "x"}
+    line = bench.compact_record(full, "d.json")
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    assert line["summary"]["nn_evals_per_sec"] == full["value"]

@@ -33,7 +33,10 @@ def test_every_op_reproduces_beside_every_op_of_a_second_net(tmp_path, hip_lib, 
     cfg, sd, _ = nn_cases.make_case("risev2-3")
     d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
     batch = 64
-    A, B = HipAPI(0, batch, d, precision), HipAPI(0, batch, d, precision)
+    # "-1wg": the one-workgroup-per-board tower kernels this harness was built around (every op writes buffers of its own, so an op can be
+    # relaunched alone on the state the forward left); a batch of 64 would otherwise run split-board (round 6), whose launches hand
+    # their partial sums on through two alternating buffers -- that forward is screened whole, below
+    A, B = HipAPI(0, batch, d, precision + "-1wg"), HipAPI(0, batch, d, precision + "-1wg")
     users = [NeuralNetAPIUser([n]) for n in (A, B)]
     rng = np.random.default_rng(1)
     for n, u in zip((A, B), users):
@@ -70,3 +73,49 @@ def test_every_op_reproduces_beside_every_op_of_a_second_net(tmp_path, hip_lib, 
     A.close()
     B.close()
     assert not red, red
+
+
+@pytest.mark.parametrize("precision", ["float16x3", "float16p8"])
+@pytest.mark.parametrize("batch", [8, 64])
+def test_split_board_forward_reproduces_beside_a_second_forward(tmp_path, hip_lib, precision, batch):
+    """The split-board forward of small batches (block_x3_split_kernel: one launch per bottleneck block, partial sums handed on through
+    two alternating buffers) screened as a WHOLE: net A's forward is repeated 300 times on the device and every result compared bit
+    for bit with the first, while net B (same model, other planes; then a one-workgroup-per-board net of batch 256) replays its own
+    forward on a second stream without pause."""
+    cfg, sd, _ = nn_cases.make_case("risev2-7")
+    d = nn_cases.export_case(tmp_path, "risev2-7", cfg, sd)
+    rng = np.random.default_rng(3)
+    A = HipAPI(0, batch, d, precision, keep_logits=True)
+    assert "block_x3_split" in [nm for nm, _ in A.time_ops(1)]
+    for b_batch, b_prec in ((batch, precision), (256, precision)):
+        B = HipAPI(0, b_batch, d, b_prec)
+        for n, bb in ((A, batch), (B, b_batch)):
+            x = torch.from_numpy((rng.random((bb, cfg.nb_input_channels, 8, 8)) < 0.1).astype(np.float32)).cuda()
+            torch.as_tensor(n.device_buffers()["planes"], device="cuda").copy_(x)
+        torch.cuda.synchronize()
+        stop = threading.Event()
+
+        def aggressor():
+            while not stop.is_set():
+                for _ in range(8):
+                    B.forward_device()
+                B.sync()
+        th = threading.Thread(target=aggressor)
+        th.start()
+        time.sleep(0.01)
+        bufs = A.device_buffers()
+        first = None
+        bad = 0
+        for it in range(300):
+            A.forward_device()
+            A.sync()
+            out = (torch.as_tensor(bufs["logits"], device="cuda").clone(), torch.as_tensor(bufs["value"], device="cuda").clone())
+            if first is None:
+                first = out
+            elif not (torch.equal(out[0], first[0]) and torch.equal(out[1], first[1])):
+                bad += 1
+        stop.set()
+        th.join()
+        B.close()
+        assert bad == 0, (bad, b_batch)
+    A.close()

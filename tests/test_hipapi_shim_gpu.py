@@ -115,3 +115,34 @@ def test_reference_mctsagent_on_hipapi_equals_the_product_search_pool(tmp_path, 
     pool.close()
     net.close()
     ra.close()
+
+
+@pytest.mark.parametrize("variant,fen,sims,quota", [
+    ("crazyhouse", "", 400, 8), ("crazyhouse", "", 700, 64),
+    ("crazyhouse", "r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] w KQkq - 0 8", 500, 16),
+    ("crazyhouse", "5r2/ppp2pkp/3p4/2bP4/2Pnp1N1/3P2pP/PP2n1P1/R2Q1R1K[PBRQnbb] w - - 0 28", 400, 8),
+])
+def test_patched_reference_searchthread_grows_the_same_tree(tmp_path, hip_lib, variant, fen, sims, quota):
+    """integration/searchthread_hip.patch: the reference's SearchThread under HIP_BACKEND hands every new leaf over as
+    its 192-byte descriptor (planes built on the GPU) and takes back only the priors of its legal moves (mi_net_submit_boards_gathered,
+    scattered into the slots Node::set_probabilities_for_moves reads) instead of building float planes on the host and copying whole
+    probability vectors.  oracle/ref/build_ref.py applies the patch to a build-time copy of searchthread.cpp; the patched and the unpatched
+    reference, both on HipAPI nets of the same model, must grow the same tree bit for bit (and that tree is the product pool's)."""
+    if not ref_mcts.hip_patched_available():
+        pytest.skip("oracle/_ref/libcrazyara_ref_hip_patched.so not built")
+    from crazyara_amd import search
+    from test_mcts_reference_build import _normalise_ref_dump
+    cfg, sd, _, d = _export(tmp_path, "risev2-7", "1.0")
+    st = search.default_settings(mode=0, version_major=1, is_policy_map=1, batch_size=quota)
+    dumps = []
+    for patched in (False, True):
+        ra = ref_mcts.RefAgent(st, hip_model_dir=d, precision="float16", patched=patched)
+        ra.set_position(fen, False, variant)
+        ra.go(simulations=sims)
+        first = ra.tree_dump().copy()
+        ra.go(simulations=2 * sims)                                   # a second go on the kept tree
+        dumps.append((first, ra.tree_dump().copy(), ra.root_children(), ra.eval_info()["best_move"]))
+        ra.close()
+    assert np.array_equal(dumps[0][0], dumps[1][0]) and np.array_equal(dumps[0][1], dumps[1][1])
+    assert dumps[0][2][0] == dumps[1][2][0] and dumps[0][2][1] == dumps[1][2][1] and dumps[0][3] == dumps[1][3]
+    assert np.array_equal(dumps[0][2][2], dumps[1][2][2]) and np.array_equal(dumps[0][2][3], dumps[1][2][3])

@@ -574,3 +574,40 @@ def test_board_split_forward_small_batches(tmp_path, hip_lib, name, batch, preci
         assert np.array_equal(v, outs[0][1]) and np.array_equal(p, outs[0][2]) and np.array_equal(logits, outs[0][3])    # run to run, net to net
     if precision == "float16x3":
         assert np.abs(outs[0][3] - outs[6][3]).max() < 2e-5            # against the tower kernel's bits: f32 round-off of another summation order
+
+
+@pytest.mark.parametrize("case,B,version", [("risev2-19", 256, "1.0"), ("risev2-13-lichess", 1024, "3.0")])
+def test_float16p8_error_grows_with_the_logit_scale_float16x3_does_not(tmp_path, hip_lib, case, B, version):
+    """float16p8's bound on the seeded random nets (3e-4 fixtures / 7e-4 over a million logits, max|logit| ~ 2) is a
+    property of those weights.  The mode's cross terms keep two mantissa bits: its error is RELATIVE to the activations, so on a net whose
+    activations and logits are 8 times larger (nn_cases.scale_activations: logits +-15, what trained nets have) the absolute error is about 8 times
+    larger and passes north_star's 1e-3.  Stated bound: |logit error| <= 3.5e-4 x max|logit| (+ 1e-4); float16x3 (f32-grade
+    products, relative 2^-22) stays inside 1e-3 -- in fact 1e-4 x max(1, max|logit| / 4) -- at every scale.  Hence bench.py's headline mode is float16x3;
+    float16p8 is reported beside it with this bound."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, _ = nn_cases.make_case(case)
+    x = nn_cases.synthetic_planes(B, cfg.nb_input_channels, 4711)
+    xin = np.ascontiguousarray(x.numpy())
+    report = {}
+    for act in (1.0, 8.0):
+        sds = nn_cases.scale_activations(cfg, sd, act) if act != 1.0 else sd
+        d = nn_cases.export_case(tmp_path / f"a{int(act)}", case, cfg, sds, version=version)
+        o_value, o_logits, _ = ro.forward(cfg, sds, x)
+        mx = float(o_logits.abs().max())
+        for precision in ("float16p8", "float16x3"):
+            net = HipAPI(0, B, d, precision, keep_logits=True)
+            v, p = np.zeros(B, np.float32), np.zeros(B * cfg.nb_policy, np.float32)
+            net.predict(xin, v, p, np.zeros(B * 4, np.float32) if cfg.nb_aux else None)
+            logits = torch.as_tensor(net.device_buffers()["logits"], device="cuda").cpu().numpy()
+            net.close()
+            err = float(np.abs(logits - o_logits.numpy()).max())
+            verr = float(np.abs(v - o_value.numpy().reshape(-1)).max())
+            report[(act, precision)] = dict(max_logit=round(mx, 2), logit_err=err, per_unit_logit=err / mx, value_err=verr)
+    print("precision against the logit scale:", case, B, report)
+    for act in (1.0, 8.0):
+        r8, r3 = report[(act, "float16p8")], report[(act, "float16x3")]
+        assert r8["logit_err"] < 1e-4 + 3.5e-4 * r8["max_logit"], report
+        assert r3["logit_err"] < 1e-4 * max(1.0, r3["max_logit"] / 4.0), report
+        assert r3["logit_err"] < 1e-3 and r3["value_err"] < 1e-4 and r8["value_err"] < 5e-4, report
+    assert report[(8.0, "float16p8")]["max_logit"] > 8.0                 # the stress case IS at the scale of trained nets
+    assert report[(1.0, "float16p8")]["logit_err"] < 1e-3                # the seeded nets of the fixtures and of bench.py: inside north_star

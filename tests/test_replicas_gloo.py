@@ -45,6 +45,42 @@ def test_two_rank_reduction_and_sharding():
     assert sorted(out[0][4] + out[1][4]) == list(range(11)) and not set(out[0][4]) & set(out[1][4])
 
 
+def _game_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # configs 4 and 5 of a sharded bench run (bench.py --gpus N): rank 0 played 8 self-play games in 2 s, rank 1 8 games in 4 s; in the arena
+    # leg rank 1 is a rehearsal rank that played nothing (it must still take part in the collectives)
+    c4 = {"games": 8, "moves": 400 + 40 * rank, "seconds": 2.0 * (rank + 1), "mcts_nodes_per_sec": 1000.0 * (rank + 1)}
+    c5 = {"games": 32, "moves": 1600, "seconds": 3.0, "mcts_nodes_per_sec": 5000.0} if rank == 0 else None
+    r4 = replicas.reduce_game_leg(c4, dist, None, world)
+    r5 = replicas.reduce_game_leg(c5, dist, None, world)
+    dist.barrier()
+    dist.destroy_process_group()
+    out[rank] = (r4, r5)
+
+
+def test_two_ranks_reduce_the_sharded_game_legs():
+    """bench.py --gpus N runs BASELINE configs 4 (chess960 self-play) and 5 (3check / KOTH arena) sharded over the ranks; the whole-job
+    record is SUM of games / moves / nodes over MAX of seconds, with every rank's own games/min beside it."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_game_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        r4, r5 = out[r]
+        assert r4["games"] == 16 and r4["moves"] == 840 and r4["seconds"] == 4.0
+        assert r4["games_per_min"] == 240.0                              # 16 games in the slowest rank's 4 s
+        assert r4["mcts_nodes_per_sec"] == (1000.0 * 2.0 + 2000.0 * 4.0) / 4.0
+        assert r4["per_rank_games_per_min"] == [240.0, 120.0] and r4["per_rank_games"] == [8, 8]
+        assert r5["games"] == 32 and r5["per_rank_games"] == [32, 0] and r5["per_rank_games_per_min"] == [640.0, 0.0]
+        assert r5["games_per_min"] == 640.0 and r5["mcts_nodes_per_sec"] == 5000.0
+    # one rank: the identity
+    solo = replicas.reduce_game_leg({"games": 4, "moves": 10, "seconds": 2.0, "mcts_nodes_per_sec": 50.0})
+    assert solo["games_per_min"] == 120.0 and solo["per_rank_games"] == [4] and solo["mcts_nodes_per_sec"] == 50.0
+
+
 def test_single_rank_is_identity():
     local = replicas.ReplicaStats(units=42.0, seconds=2.0, extra=(1.0,))
     assert replicas.reduce_stats(local) == (42.0, 2.0, [1.0])

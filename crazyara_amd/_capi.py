@@ -109,6 +109,7 @@ SIGNATURES = {
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mi_search_set_shared_collectors": (C.c_int, [C.c_void_p, C.c_int]),
     "mi_search_set_adaptive_quota": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi_search_set_state_budget": (C.c_int, [C.c_void_p, C.c_uint]),
     "mi_selfplay_default_settings": (None, [C.c_void_p]),
     "mi_selfplay_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p]),
     "mi_selfplay_destroy": (None, [C.c_void_p]),

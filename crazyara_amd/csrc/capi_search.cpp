@@ -345,6 +345,11 @@ int mi_search_set_shared_collectors(mi_search* sp, int k) {
     return cra_guard([&] { sp->pool->set_shared_collectors(k); });
 }
 
+int mi_search_set_state_budget(mi_search* sp, unsigned budget) {
+    if (!sp) { cra_set_error("null search"); return 1; }
+    return cra_guard([&] { sp->pool->set_state_budget(budget); });
+}
+
 int mi_search_set_adaptive_quota(mi_search* sp, int cap) {
     if (!sp) { cra_set_error("null search"); return 1; }
     return cra_guard([&] { sp->pool->set_adaptive_quota(cap); });

@@ -260,17 +260,27 @@ bool Tree::apply_move(Move m) {
     // get_root_node_from_tree: the candidate must be a playout node (has NodeData) with at least one visit below it
     const bool keep = child >= 0 && nodes_[child].has_data && nodes_[child].has_nn && !nodes_[child].terminal && nodes_[child].visit_sum > 0;
     if (keep) {
+        // Stored states of the kept subtree: their key history is the game's (absolute), but in a build whose root clone starts the
+        // move history afresh (crazyhouse: Board::operator= drops lastMoves, board.cpp:106-108) their last-move lists reach back beyond
+        // the NEW root, where a replay from it would not -- for a layout with last-move planes they are dropped (the nodes then replay
+        // from the root like nodes beyond the budget); every other layout never reads the list.
+        const bool drop_states = !keep_last_moves_ && layout_needs_move_features(layout_);
+        uint32_t kept_states = 0;
         NodeArena fresh;
         std::vector<int> order{child};               // breadth-first copy; remap[i] = new index of old node order[i]
         for (size_t head = 0; head < order.size(); ++head) {
             Node& n = fresh[fresh.emplace_back()];
             n = std::move(nodes_[order[head]]);
+            if (drop_states || head == 0) n.state.reset();       // (the root's position is root_pos_)
+            kept_states += n.state != nullptr;
             for (int32_t& c : n.child)
                 if (c >= 0) { order.push_back(c); c = int32_t(order.size()) - 1; }
         }
         nodes_.swap(fresh);
+        stored_states_.store(kept_states, std::memory_order_relaxed);
     } else {
         nodes_.clear();
+        stored_states_.store(0, std::memory_order_relaxed);
         new_node(root_pos_);
     }
     for (auto& c : collectors_) { c->depth_sum = 0; c->depth_max = 0; }
@@ -506,9 +516,56 @@ int Tree::best_action_index_fast(const Node& n) const {
     return best;
 }
 
+// CRA_REPLAY_PROFILE (scripts/hostbench/replay_share_bench.cpp only; never in the library): ticks spent on what MCTS_STORE_STATES would
+// remove -- the clone of the root position and the do_move replay down the selected path -- by depth, against the whole of collect().
+#ifdef CRA_REPLAY_PROFILE
+#include <x86intrin.h>
+unsigned long long g_replay_ticks[128], g_replay_steps[128], g_clone_ticks, g_expand_ticks, g_collect_ticks, g_leaf_depth_hist[128];
+#define CRA_TICK(var) const unsigned long long var = __rdtsc()
+#define CRA_TOCK(acc, var) (acc) += __rdtsc() - (var)
+#else
+#define CRA_TICK(var) do { } while (0)
+#define CRA_TOCK(acc, var) do { } while (0)
+#endif
+
+// The position of a simulation on its way down, lazily: `base` = the stored state of the deepest node passed that has one (else the
+// root position) and the moves since; get() materialises it in the collector's scratch position -- one copy and only the moves behind the
+// last stored state, instead of a clone of the root and a do_move per ply (SearchThread::get_new_child_to_evaluate with / without
+// MCTS_STORE_STATES, searchthread.cpp:198-213).  After get() the scratch position is kept current move by move.
+struct Tree::LazyPos {
+    Tree& t;
+    Collector& col;
+    const Position* base;
+    bool from_root = true, live = false;
+    LazyPos(Tree& tree, Collector& c) : t(tree), col(c), base(&tree.root_pos_) { col.replay.clear(); }
+    void step(int next, Move mv) {                            // the descent moves on to node `next` by `mv`
+        const Node& n = t.nodes_[next];
+        if (live) { col.scratch_pos.do_move(mv, &n.key); return; }
+        if (n.state) { base = n.state.get(); from_root = false; col.replay.clear(); return; }
+        col.replay.emplace_back(mv, &n.key);
+    }
+    Position& get() {
+        if (!live) {
+            CRA_TICK(t_clone);
+            col.scratch_pos = *base;                          // rootState->clone() / currentNode->get_state()->clone()
+            if (from_root && !t.keep_last_moves_) col.scratch_pos.clear_last_moves();
+            CRA_TOCK(g_clone_ticks, t_clone);
+            CRA_TICK(t_replay);
+            for (const auto& mk : col.replay) col.scratch_pos.do_move(mk.first, mk.second);     // actionsBuffer replay
+            CRA_TOCK(g_replay_ticks[col.replay.size() < 127 ? col.replay.size() : 127], t_replay);
+#ifdef CRA_REPLAY_PROFILE
+            g_replay_steps[col.replay.size() < 127 ? col.replay.size() : 127] += col.replay.size();
+#endif
+            col.replay.clear();
+            live = true;
+        }
+        return col.scratch_pos;
+    }
+};
+
 // get_starting_node (searchthread.cpp:144-162): walk the most-visited line for a random number of plies.  No virtual loss and
 // no trajectory entries on the way down: the value found below is only backed up from the starting node.
-int Tree::get_starting_node(Collector& col, int cur, uint32_t& depth, int& child_idx, Position& pos) {
+int Tree::get_starting_node(Collector& col, int cur, uint32_t& depth, int& child_idx, LazyPos& lp) {
     const size_t d = get_random_depth(col);
     for (size_t cd = 0; cd < d; ++cd) {
         Node& n = nodes_[cur];
@@ -524,7 +581,7 @@ int Tree::get_starting_node(Collector& col, int cur, uint32_t& depth, int& child
         if (next < 0 || !ld_has_data(nodes_[next]) || ld_visits(nodes_[next]) < uint32_t(s_.epsilon_greedy_counter) ||
             ld_type(nodes_[next]) != NT_UNSOLVED)
             break;
-        pos.do_move(mv, &nodes_[next].key);
+        lp.step(next, mv);
         cur = next;
         ++depth;
     }
@@ -570,18 +627,17 @@ int Tree::select_enhanced_move(int cur, const Position& pos) {
 int Tree::get_new_child_to_evaluate(Collector& col, NodeBackup& type, uint32_t& depth, BoardDesc* desc_out) {
     depth = 0;
     int cur = 0;
-    Position& pos = col.scratch_pos;
-    pos = root_pos_;                             // rootState->clone()
-    if (!keep_last_moves_) pos.clear_last_moves();
+    LazyPos lp(*this, col);
     int forced = -1;                             // childIdx chosen by the exploration step (uint16_t(-1) = none)
     if (s_.epsilon_greedy_counter && nodes_[0].has_data && next_rand(col) % uint32_t(s_.epsilon_greedy_counter) == 0) {
-        cur = get_starting_node(col, cur, depth, forced, pos);
+        cur = get_starting_node(col, cur, depth, forced, lp);
         NodeLock lk(nodes_[cur], concurrent_);
         random_playout(col, cur, forced);
     } else if (s_.epsilon_checks_counter && nodes_[0].has_data && next_rand(col) % uint32_t(s_.epsilon_checks_counter) == 0) {
-        cur = get_starting_node(col, cur, depth, forced, pos);
+        cur = get_starting_node(col, cur, depth, forced, lp);
+        const Position& at_start = lp.get();
         NodeLock lk(nodes_[cur], concurrent_);
-        forced = select_enhanced_move(cur, pos);
+        forced = select_enhanced_move(cur, at_start);
         if (forced < 0) random_playout(col, cur, forced);
     }
     while (true) {
@@ -603,8 +659,15 @@ int Tree::get_new_child_to_evaluate(Collector& col, NodeBackup& type, uint32_t& 
             }
         }
         if (next == CHILD_NONE) {
+            Position& pos = lp.get();
+            CRA_TICK(t_expand);
             pos.do_move(mv);
             const int nn = new_node(pos);
+            // MCTS_STORE_STATES: the new node keeps its position (before it is linked: nobody else sees the node yet)
+            if (!nodes_[nn].terminal && stored_states_.load(std::memory_order_relaxed) < state_budget_) {
+                nodes_[nn].state.reset(new Position(pos));
+                stored_states_.fetch_add(1, std::memory_order_relaxed);
+            }
             {
                 Node& n = nodes_[cur];
                 NodeLock lk(n, concurrent_);
@@ -612,22 +675,30 @@ int Tree::get_new_child_to_evaluate(Collector& col, NodeBackup& type, uint32_t& 
             }
             if (nodes_[nn].terminal) {           // SearchThread::add_new_node_to_tree, searchthread.cpp:93-96
                 type = NODE_TERMINAL;
+                CRA_TOCK(g_expand_ticks, t_expand);
                 return nn;
             }
             // newState->get_state_planes(true, ...), searchthread.cpp:229; the new node holds the legal moves already
             chess::pack_desc(pos, *desc_out, layout_needs_move_features(layout_), &nodes_[nn].actions);
             type = NODE_NEW_NODE;
+            CRA_TOCK(g_expand_ticks, t_expand);
+#ifdef CRA_REPLAY_PROFILE
+            ++g_leaf_depth_hist[depth < 127 ? depth : 127];
+#endif
             return nn;
         }
         if (next == CHILD_PENDING) { type = NODE_COLLISION; return -1; }
         if (nodes_[next].terminal) { type = NODE_TERMINAL; return next; }
         if (!ld_has_nn(nodes_[next])) { type = NODE_COLLISION; return next; }
-        pos.do_move(mv, &nodes_[next].key);      // actionsBuffer replay, done incrementally
+        lp.step(next, mv);                        // (no position needed yet: the move is noted, or a stored state becomes the new base)
         cur = next;
     }
 }
 
 int Tree::collect(int quota, BoardDesc* descs, int ctx) {
+#ifdef CRA_REPLAY_PROFILE
+    struct Whole { unsigned long long t0 = __rdtsc(); ~Whole() { g_collect_ticks += __rdtsc() - t0; } } whole;
+#endif
     Collector& col = *collectors_.at(size_t(ctx));
     size_t num_terminal = 0;
     const size_t terminal_cache = size_t(TERMINAL_NODE_CACHE_FACTOR) * size_t(std::max(quota, 1));

@@ -89,6 +89,11 @@ struct Node {
     bool terminal = false, has_nn = false, sorted = false, has_data = false, inspected = false;
     uint8_t stm = 0;
     uint8_t lock = 0;                     // per-node spin lock (Node::mtx, node.h:100): taken only by trees with several collectors
+    // MCTS_STORE_STATES (node.h:111,530; searchthread.cpp:198-213): the position this node stands for, kept from its creation so that a
+    // later expansion below it starts HERE instead of cloning the root and replaying the whole path.  Optional per node (a tree over its
+    // state budget, or a kept subtree whose move history no longer starts at the root, simply replays from the nearest ancestor that
+    // has one); written before the node is linked into its parent, read-only afterwards.
+    std::unique_ptr<chess::Position> state;
 
     float value() const { return float(value_sum / real_visits); }                         // node.cpp:595-598
     void set_value(float v) { ++real_visits; value_sum = double(v * float(real_visits)); } // node.cpp:716-720
@@ -114,6 +119,7 @@ struct Collector {
     std::vector<int32_t> new_nodes;
     std::vector<Trajectory> new_trajectories, collision_trajectories;
     chess::Position scratch_pos;          // the simulation's running position (assigned from the root: keeps its buffers)
+    std::vector<std::pair<chess::Move, const chess::Key*>> replay;   // moves since the last stored state on the way down (Tree::LazyPos)
     std::vector<int> sort_perm;
     std::vector<chess::Move> sort_moves;
     std::vector<float> sort_priors;
@@ -169,6 +175,16 @@ public:
     void end_search();
     // replace the search settings for the following searches (quick-search switches of self-play, selfplay.cpp:217-222)
     void set_search_settings(const SearchSettings& s) { s_ = s; }
+    // Stored leaf states (the reference's MCTS_STORE_STATES build option): every new non-terminal node keeps its position, up to `budget`
+    // nodes per tree; 0 = off, the default here as in the reference's default build: every simulation clones the root and replays its
+    // path.  Same trees bit for bit either way (tests/test_mcts.py::test_stored_leaf_states_grow_the_same_trees).  MEASURED before it was
+    // made a default (round 6, scripts/hostbench/replay_share_bench.cpp, profiles/r06/g_*): on ONE tree of 25,600 simulations (leaf depth
+    // 6.8 on average, 26 at most) the clone of the root and the replay of the path are 5.5 % of Tree::collect = 4.5 % of the host's
+    // search time (the replay is an incremental do_move with the child's key known, ~80 ticks a ply; a first reading of 22 - 25 % was
+    // the tick counter around every single ply), and a stored state is a Position with three heap vectors: with states the same search
+    // took 6.3 us per simulation against 5.6 without (-8 ... -13 %; level at 102,400 simulations).  Kept as an option, not the default.
+    void set_state_budget(uint32_t budget) { state_budget_ = budget; }
+    uint32_t stored_states() const { return stored_states_.load(std::memory_order_relaxed); }
 
     // --- SearchThread::create_mini_batch (searchthread.cpp:347-380) with `quota` in the role of batchSize ---
     // Writes one BoardDesc per NEW leaf to descs[0..returned).  Terminals are backed up immediately, collisions are
@@ -250,7 +266,10 @@ private:
     int get_new_child_to_evaluate(Collector& col, NodeBackup& type, uint32_t& depth, BoardDesc* desc_out);
     uint32_t next_rand(Collector& col);
     size_t get_random_depth(Collector& col);
-    int get_starting_node(Collector& col, int cur, uint32_t& depth, int& child_idx, chess::Position& pos);
+    // the simulation's position, materialised only when something needs it (an expansion, the exploration steps): the nearest stored
+    // state on the way down + the moves since (mcts.cpp)
+    struct LazyPos;
+    int get_starting_node(Collector& col, int cur, uint32_t& depth, int& child_idx, LazyPos& lp);
     void random_playout(Collector& col, int cur, int& child_idx);
     int select_enhanced_move(int cur, const chess::Position& pos);
     int best_action_index_fast(const Node& n) const;
@@ -264,6 +283,8 @@ private:
     NodeArena nodes_;
     std::vector<std::unique_ptr<Collector>> collectors_;   // [0] always exists
     bool concurrent_ = false;                               // several collectors: per-node locks are taken
+    uint32_t state_budget_ = 0;                             // stored leaf states per tree (set_state_budget); 0 = off
+    std::atomic<uint32_t> stored_states_{0};
     float last_value_eval_ = -1.0f;            // MCTSAgent::lastValueEval (mctsagent.cpp:47), reset with the game (clear_game_history)
     uint8_t last_stm_ = 0;                     // MCTSAgent::lastSideToMove
     std::minstd_rand0 noise_rng_;              // std::default_random_engine of libstdc++ (randomgen.h:35)

@@ -347,6 +347,7 @@ int SearchPool::add_position(const chess::Position& pos) {
     SearchSettings st = s_;
     st.seed = s_.seed + uint32_t(trees_.size());     // every tree owns its exploration stream
     trees_.emplace_back(new Tree(pos, st));
+    if (state_budget_ >= 0) trees_.back()->set_state_budget(uint32_t(state_budget_));
     rebuild_items();
     return int(trees_.size()) - 1;
 }
@@ -360,6 +361,7 @@ void SearchPool::reset_position(int i, const chess::Position& pos) {
     SearchSettings st = s_;
     st.seed = s_.seed + uint32_t(i);
     trees_.at(i).reset(new Tree(pos, st));
+    if (state_budget_ >= 0) trees_[i]->set_state_budget(uint32_t(state_budget_));
     if (shared_k_ > 0) trees_[i]->set_collectors(shared_k_ * int(lanes_.size()));
 }
 

@@ -142,6 +142,12 @@ public:
     // other trees.  With the absolute limits of tree reuse the trees of a round need very different numbers of simulations; the fixed
     // quota then ends a round with mostly empty batches for the one tree that needs the most.
     void set_adaptive_quota(int cap) { adaptive_cap_ = cap < 0 ? 0 : cap; }
+    // stored leaf states per tree (Tree::set_state_budget; the reference's MCTS_STORE_STATES): 0 = every simulation replays its path from
+    // the root.  Applies to the trees of the pool and to the ones added later; between runs.
+    void set_state_budget(uint32_t budget) {
+        state_budget_ = int64_t(budget);
+        for (auto& t : trees_) t->set_state_budget(budget);
+    }
     // Per-tree limits for the following runs, replacing run()'s simulations / nodes for that tree (both 0 = back to run()'s): the
     // concurrent games of a self-play loop search with their own node budgets -- quick searches and the per-move node jitter of
     // SelfPlay::generate_game (selfplay.cpp:146-152,213-221), which the reference sets on its one SearchLimits before every move.
@@ -185,6 +191,7 @@ private:
     std::vector<Item> items_;
     int shared_k_ = 0;
     int adaptive_cap_ = 0;
+    int64_t state_budget_ = -1;                          // set_state_budget; -1 = the Tree's default
     std::mutex gen_mu_;                                  // stop protocol (above): guards go_gen_ / adopted_gen_; never taken on the search's hot path
     uint64_t go_gen_ = 0, adopted_gen_ = 0;              // the newest generation announced or opened; the newest one a run() has taken
     std::atomic<uint64_t> stop_gen_{0};                  // every generation <= this one has been told to stop

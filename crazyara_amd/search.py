@@ -187,6 +187,11 @@ class SearchPool:
         if self._lib.mi_search_set_shared_collectors(self._h, int(k)):
             raise ValueError(_capi.last_error())
 
+    def set_state_budget(self, budget: int) -> None:
+        """Stored leaf states per tree (the reference's MCTS_STORE_STATES): 0 = every simulation replays its path from the root."""
+        if self._lib.mi_search_set_state_budget(self._h, int(budget)):
+            raise RuntimeError(_capi.last_error())
+
     def set_adaptive_quota(self, cap: int) -> None:
         """cap > 0: the trees of a lane that are still searching share the whole batch (throughput setting for self-play); 0 = fixed quota"""
         if self._lib.mi_search_set_adaptive_quota(self._h, int(cap)):

@@ -305,6 +305,12 @@ int mi_search_set_shared_collectors(mi_search* sp, int k);
 /* Throughput setting of the many-trees mode (self-play): cap > 0 = the trees of a lane that are still searching share the whole batch
  * (each batch / running-trees slots, at most cap, never more than the tree still needs); 0 = the reference's fixed per-tree quota. */
 int mi_search_set_adaptive_quota(mi_search* sp, int cap);
+/* Stored leaf states -- the reference's MCTS_STORE_STATES build option (engine/src/node.h:111,530, searchthread.cpp:198-213): every new
+ * node keeps its position, so that an expansion below it copies that state and plays ONE move instead of cloning the root and replaying
+ * the whole path.  budget = how many nodes of a tree may hold a state (~0.5 KB each); 0 = off (the default, as in the reference's
+ * default build: the replay is 4.5 % of the host's search time on one tree of 25,600 simulations, and with states that search measured
+ * 8 - 13 % SLOWER -- a stored state is a position with its history vectors).  The trees are the same bit for bit either way.  Between runs. */
+int mi_search_set_state_budget(mi_search* sp, unsigned budget);
 /* the whole tree as a flat word list, for inspection and the parity tests (the reference's counterpart: MCTSAgent::export_search_tree,
  * mctsagent.cpp:420-448): depth-first preorder over the expanded children, one record per node that was selected at least once:
  * [n_expanded, visit_sum, real_visits, free_visits, node_type, end_in_ply, terminal, float bits of value], then per expanded child

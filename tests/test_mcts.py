@@ -833,6 +833,39 @@ def test_go_announced_before_the_previous_run_returned_keeps_its_stop(hip_lib):
     pool.close()
 
 
+@pytest.mark.parametrize("variant,is960,fen,mode,version,eps", [
+    ("crazyhouse", False, "", 0, 1, 0), ("crazyhouse", False, "", 0, 3, 0),          # v3 planes carry last moves: kept subtrees drop their states
+    ("crazyhouse", False, "r1b1k2r/ppp2ppp/2n5/3qp3/1b1P4/2N1PN2/PP3PPP/R1BQKB1R[Pn] w KQkq - 0 8", 0, 2, 20),
+    ("chess", False, "r3k2r/pppq1ppp/2npbn2/2b1p3/2B1P3/2NPBN2/PPPQ1PPP/R3K2R b KQkq - 4 8", 1, 3, 0),
+    ("chess", True, "bnnrkbrq/pppppppp/8/8/8/8/PPPPPPPP/BNNRKBRQ w GDgd - 0 1", 1, 3, 20),
+    ("3check", False, "", 2, 3, 0), ("kingofthehill", False, "", 2, 1, 10),
+])
+def test_stored_leaf_states_grow_the_same_trees(hip_lib, variant, is960, fen, mode, version, eps):
+    """mi_search_set_state_budget (the reference's MCTS_STORE_STATES, searchthread.cpp:198-213): with every new node keeping its position
+    an expansion starts from its parent's state instead of a root clone + path replay.  The trees must be the same bit for bit -- over
+    two searches, a played move with tree reuse between them (kept subtrees of a crazyhouse tree with last-move planes drop their
+    states: their move lists reach back beyond the new root), epsilon exploration (whose steps need the position on the way down), and
+    with a budget that runs out in the middle of the search (nodes beyond it replay from the nearest ancestor that has a state)."""
+    nbp = NB_POLICY[mode]
+    dumps = []
+    for budget in (0, 1 << 20, 150):
+        st = search.default_settings(mode=mode, version_major=version, is_policy_map=1, batch_size=8, epsilon_greedy_counter=eps,
+                                     epsilon_checks_counter=eps * 2, seed=9)
+        pool = search.SearchPool(st, eval_fn=_slow_eval(nbp, 0.0), fn_batch=8, fn_nb_policy=nbp)
+        pool.set_state_budget(budget)
+        t = pool.add_position(fen, is960, variant)
+        pool.run(simulations=400, threads=1)
+        first = pool.tree_dump(t).copy()
+        best = pool.best_move(t)
+        kept = pool.apply_move(t, best)
+        pool.run(simulations=600, threads=1)
+        dumps.append((first, pool.tree_dump(t).copy(), best, kept, pool.best_move(t)))
+        _check_tree_invariants(pool.tree_dump(t))
+        pool.close()
+    for d in dumps[1:]:
+        assert np.array_equal(d[0], dumps[0][0]) and np.array_equal(d[1], dumps[0][1]) and d[2:] == dumps[0][2:]
+
+
 def test_an_announced_go_that_is_never_run_does_not_hand_its_stop_to_the_next_search(hip_lib):
     """`go` is announced, stopped, and the commanding thread never enters run() for it.  The withdrawn announcement
     (mi_search_cancel_go) must not stay the oldest un-run generation: the next announced search runs to its limit, also when another

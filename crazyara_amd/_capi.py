@@ -19,6 +19,8 @@ SIGNATURES = {
     "mi_host_free": (None, [C.c_void_p]),
     "mi_net_create": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_char_p]),
     "mi_net_destroy": (None, [C.c_void_p]),
+    "mi_net_calibrate_int8": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int]),
+    "mi_net_has_int8_calibration": (C.c_int, [C.c_char_p]),
     "mi_onnx_to_cranet": (C.c_int, [C.c_char_p, C.c_char_p]),
     "mi_e4m3_from_float": (C.c_int, [C.c_float]),
     "mi_e5m2_from_float": (C.c_int, [C.c_float]),

@@ -54,6 +54,27 @@ mi_net* mi_net_create(const char* model_dir, int device_id, int batch_size, cons
 }
 void mi_net_destroy(mi_net* net) { delete net; }
 
+int mi_net_calibrate_int8(const char* model_dir, int device_id, const float* planes, int n_boards) {
+    if (!model_dir) { g_err = "null argument to mi_net_calibrate_int8"; return 1; }
+    return guard([&] { (void)cra::calibrate_int8(model_dir, device_id, planes, n_boards); });
+}
+int mi_net_has_int8_calibration(const char* model_dir) {
+    if (!model_dir) { g_err = "null argument to mi_net_has_int8_calibration"; return -1; }
+    int found = 0;
+    if (guard([&] {
+            std::string path = model_dir;
+            const bool is_file = path.size() > 5 && (path.compare(path.size() - 5, 5, ".onnx") == 0 || (path.size() > 7 && path.compare(path.size() - 7, 7, ".cranet") == 0));
+            if (!is_file) {
+                if (path.empty()) throw std::invalid_argument("The given directory must not be empty.");
+                if (path.back() != '/') path += "/";
+                path += cra::find_model_file(path, 0);
+            }
+            found = cra::read_int8_calibration(path).empty() ? 0 : 1;
+        }))
+        return -1;
+    return found;
+}
+
 int mi_e4m3_from_float(float v) { return int(cra::float_to_e4m3(v)); }
 int mi_e5m2_from_float(float v) { return int(cra::float_to_e5m2(v)); }
 

@@ -20,7 +20,7 @@ constexpr int FW_DYN_LDS_F8 = fw_max(TW_DYN_LDS_BYTES_F8, fw_max(HD_LDS_BYTES, F
 static_assert(ST_OROW == TW_XROW && TW_XROW == HD_ROW, "the three kernels must agree on the pitch of the board tile");
 }  // namespace
 
-template <int NKS, bool F8 = false>
+template <int NKS, int F8 = 0>      // F8: 0 Precision float16, 1 fp8 (e4m3), 2 int8 (tower.hip: Q)
 __global__ __launch_bounds__(512) void forward_kernel(const StemArgs sa, const TowerArgs ta, const HeadArgs ha) {
 #ifdef CRA_DEV_SEAMS                     // development: bit 0 / bit 1 = hand the tile over through global memory at the first / second seam
     stem_body<NKS>(sa, (CRA_DEV_SEAMS & 1) != 0);
@@ -41,19 +41,32 @@ void init_forward_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&forward_kernel<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, FW_DYN_LDS_F8);
 }
 
 void launch_forward(const StemArgs& sa, const TowerArgs& ta, const HeadArgs& ha, hipStream_t s) {
+    if (ta.fp8 == 2) {
+        switch (sa.cin_pad / 16) {
+            case 3: hipLaunchKernelGGL((forward_kernel<3, 2>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+            case 4: hipLaunchKernelGGL((forward_kernel<4, 2>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+            case 5: hipLaunchKernelGGL((forward_kernel<5, 2>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+            default: hipLaunchKernelGGL((forward_kernel<6, 2>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+        }
+        return;
+    }
     if (ta.fp8) {
         switch (sa.cin_pad / 16) {
-            case 3: hipLaunchKernelGGL((forward_kernel<3, true>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
-            case 4: hipLaunchKernelGGL((forward_kernel<4, true>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
-            case 5: hipLaunchKernelGGL((forward_kernel<5, true>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
-            default: hipLaunchKernelGGL((forward_kernel<6, true>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+            case 3: hipLaunchKernelGGL((forward_kernel<3, 1>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+            case 4: hipLaunchKernelGGL((forward_kernel<4, 1>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+            case 5: hipLaunchKernelGGL((forward_kernel<5, 1>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
+            default: hipLaunchKernelGGL((forward_kernel<6, 1>), dim3(sa.batch), dim3(512), FW_DYN_LDS_F8, s, sa, ta, ha); break;
         }
         return;
     }

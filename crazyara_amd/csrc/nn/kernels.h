@@ -166,6 +166,12 @@ struct TowerBlockDesc {
     int cop_pad;          // multiple of 128
     int ks;               // depthwise kernel size: 3 or 5
     int se_kind;          // 0 none, 1 ca_se, 2 eca_se: gate applied to this block's input (from the previous block's output sums)
+    // Precision int8 (TowerArgs::fp8 == 2; tower.hip Q = 2): the calibrated activation steps of this block as their reciprocals (f16
+    // numbers): qx_inv for the (gated) stream in front of it (+-127), qt_inv for its depthwise output (0 ... 255); escale = what the
+    // expand accumulators are multiplied with on their way to f16 (2^-7).  b3 then holds INT32 bit patterns -- the BN3 bias in units of
+    // the project accumulator plus 128 x the row's weight sum (the depthwise output is stored as u - 128) -- and s3 the value of such a
+    // unit per cout; the bias stream holds the BN1 biases as int32 bit patterns likewise.
+    float qx_inv, qt_inv, escale;
 };
 struct TowerArgs {
     const void* x;        // [B][64][256] f16
@@ -180,7 +186,7 @@ struct TowerArgs {
     const float* gate_in; // optional [B][256]: SE gate of blocks[0] computed by a previous launch (blocks[0].se_kind is ignored)
     float* pool_out;      // optional [B][256]: sum over the 64 squares of y (feeds an SE gate computed by a later launch)
     unsigned long long* trace;   // development: s_memtime stamps of workgroup 0 (CRA_TOWER_TRACE), [wave 0 | wave 4][256]
-    int fp8;              // Precision fp8: e4m3 GEMM operands (v_mfma_f32_32x32x64_f8f6f4).  wstream = bytes; a matrix wave's region holds TWO
+    int fp8;              // 2: Precision int8 (same streams, int8 bytes, v_mfma_i32_32x32x32_i8; TowerBlockDesc).  1: Precision fp8: e4m3 GEMM operands (v_mfma_f32_32x32x64_f8f6f4).  wstream = bytes; a matrix wave's region holds TWO
                           // streams of 1 KiB loads: [0, wstream_e_frags) expand, per chunk 8 loads [k-step of 64][half][lane][16 B] (lane l = row
                           // l%32, bytes k = ks*64 + (l/32)*32 + half*16 + t), then project, per chunk 8 loads [k-step][row tile][half][lane][16 B];
                           // each closed by 8 loads of zeros.  Weights divided by a power of two per row (max |w_q| in [1, 2)): the expand

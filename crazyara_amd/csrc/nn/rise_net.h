@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "netfile.h"
@@ -63,6 +64,11 @@ public:
     // from mi_host_alloc / hipHostMalloc: the kernels read and write them in place, there is no copy.
     void submit_boards_gathered(const void* descs_host, int n_valid, int layout, const uint16_t* idx, const uint32_t* cnt, uint32_t stride,
                                 float* value, float* gathered, float* aux);
+
+    // INT8 calibration (the reference: Int8EntropyCalibrator2 over ChessBatchStream, tensorrtapi.cpp:334-360): on a net made with Precision
+    // "float16-unfused" -- every tensor of a block passes through HBM there -- runs the n boards (float planes, NCHW, as predict() takes
+    // them) and returns per bottleneck block the largest |value| of the (gated) stream in front of it and of its depthwise output.
+    std::vector<std::pair<float, float>> calibration_maxima(const float* planes_host, int n_boards);
 
     // Device-resident path: the captured forward reads d_planes() and writes d_value()/d_probs()/d_aux()/d_logits().
     float* d_planes() const { return d_planes_; }     // [B][C][64] float (NCHW, as predict() takes it)
@@ -143,7 +149,9 @@ private:
     bool fp16_ = true;
     bool x3_ = false;            // Precision float16x3: float activations, split-operand f16 MFMAs (x3.hip); fp16_ is false
     bool p8_ = false;            // Precision float16p8: float16x3 whose one-launch tower takes the cross terms of both 1x1 GEMMs through e5m2 MFMAs
-    bool fp8_tower_ = false;     // Precision fp8 (alias int8): e4m3 operands in the residual tower's GEMMs, everything else as float16
+    bool fp8_tower_ = false;     // Precision fp8 / int8: 8-bit operands in the residual tower's GEMMs, everything else as float16
+    bool int8_ = false;          // Precision int8: the calibrated INT8 mode (tower.hip Q = 2); fp8_tower_ is set too (same streams and tiles)
+    std::vector<std::pair<float, float>> int8_calib_;   // per block: max |stream in front of it|, max depthwise output (read_int8_calibration)
     bool fused_ = true;
     bool tower_ = true;
     // Small batches (round 6): float16x3 / float16p8 nets made for at most kBoardSplitMaxBatch boards (64: measured faster up to 96, profiles/r06/d_*) run their 3x3 bottleneck blocks one per
@@ -166,5 +174,14 @@ private:
     float *d_planes_ = nullptr, *d_value_ = nullptr, *d_probs_ = nullptr, *d_logits_ = nullptr, *d_aux_ = nullptr;
     std::unique_ptr<Impl> impl_;
 };
+
+// Precision int8's calibration file beside the model (TensorRT keeps its calibration cache the same way): <model file>.int8calib, text --
+// "crazyara-int8-calibration 1", "boards <n>", "blocks <m>", then m lines "<max |stream|> <max depthwise output>".
+std::string int8_calibration_path(const std::string& model_file_path);
+std::vector<std::pair<float, float>> read_int8_calibration(const std::string& model_file_path);      // empty if the file is missing
+// runs the calibration pass (a float16 layer-kernel net of its own on `device_id`) and writes the file; returns its path.
+// planes_host == nullptr: the default calibration positions -- the plies of the reference's calibration games (calibration.cpp)
+std::string calibrate_int8(const std::string& model_path, int device_id, const float* planes_host, int n_boards);
+std::vector<float> default_calibration_planes(int channels, int version, int* n_boards);
 
 }  // namespace cra

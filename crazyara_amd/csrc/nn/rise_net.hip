@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <type_traits>
 #include <stdexcept>
 
@@ -320,17 +321,17 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
         prec.resize(prec.size() - perblock_tag.size());
     }
     if (prec == "float16" || prec == "fp16" || prec == "half") fp16_ = true;
-    // The reference's reduced-precision mode is TensorRT INT8, entropy-calibrated on the plies of two recorded games
-    // (tensorrtapi.cpp:334-360, chessbatchstream.cpp:44-94; UCI option Precision = int8).  This back end has no calibrated 8-bit mode:
-    // its 8-bit mode is e4m3 (the format with a one-instruction conversion from f16 and a matrix instruction at twice the f16 rate on
-    // gfx950) in the GEMMs of the residual tower -- per-row power-of-two weight scales, f32 accumulation, f16 residual stream, f16 stem
-    // and heads -- and calibrated activation scales do not improve it (e4m3 keeps three mantissa bits wherever a scale puts the values:
-    // profiles/r03/fp8_calibration_study.txt; value error ~3e-2 with or without).  So `int8` is REFUSED rather than mapped to a mode
-    // with another accuracy contract; the e4m3 mode is an explicit opt-in under its own name.
-    else if (prec == "int8")
-        throw std::invalid_argument("unsupported precision 'int8': this back end has no calibrated INT8 mode (tensorrtapi.cpp:334-360); its 8-bit "
-                                    "mode is e4m3 in the residual tower, value within ~3e-2 of fp32 -- select it explicitly with Precision fp8, "
-                                    "or use float16 / float16x3 / float32");
+    // Precision int8: the reference's calibrated reduced-precision mode (TensorRT INT8, entropy-calibrated on the plies of two recorded
+    // games: tensorrtapi.cpp:334-360, chessbatchstream.cpp:44-94; UCI option Precision = int8).  Here: int8 operands in the two GEMMs of
+    // every bottleneck block (v_mfma_i32_32x32x32_i8, tower.hip Q = 2), one activation step per tensor and block from a calibration pass
+    // (mi_net_calibrate_int8 -> <model file>.int8calib beside the model, like TensorRT's calibration cache), one weight step per output
+    // row; everything else as float16.  Round 6's study on int8 itself (scripts/studies/int8_calibration_study.py: value within 6 - 8e-3
+    // of fp32, e4m3's 1 - 3e-2) replaced round 3's refusal, which rested on an e4m3 study.
+    else if (prec == "int8") {
+        fp16_ = true;
+        fp8_tower_ = true;
+        int8_ = true;
+    }
     else if (prec == "fp8" || prec == "float8") {
         fp16_ = true;
         fp8_tower_ = true;
@@ -342,7 +343,7 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     // float16x3 with the cross terms of the one-launch tower's two 1x1 GEMMs on ONE e5m2 MFMA per 64 k and the residual stream in the PROJECT
     // waves' registers (x3.hip: tower_p8_kernel): logits within 3e-4 of fp32 (emulated 5e-5 ... 1.3e-4 on the parity nets)
     else if (prec == "float16p8" || prec == "fp16p8" || prec == "f16p8") { fp16_ = false; x3_ = true; p8_ = true; }
-    else throw std::invalid_argument("unsupported precision '" + precision + "' (float16 | float16x3 | float16p8 | float32 | fp8)");
+    else throw std::invalid_argument("unsupported precision '" + precision + "' (float16 | float16x3 | float16p8 | float32 | fp8 | int8)");
     design_.batch = batch_size;
 
     // model discovery (TensorrtAPI ctor, tensorrtapi.cpp:53-58)
@@ -376,6 +377,12 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     else nf.load(model_file_path_);
     if (nf.str("arch") != "rise") throw std::runtime_error("unsupported arch '" + nf.str("arch") + "' in " + model_file_path_);
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    if (int8_) {
+        int8_calib_ = read_int8_calibration(model_file_path_);
+        if (int8_calib_.empty())
+            throw std::runtime_error("Precision int8 needs a calibration of this model: " + int8_calibration_path(model_file_path_) +
+                                     " is missing -- mi_net_calibrate_int8 makes it (integration/hipapi.h does that with the engine's calibration positions)");
+    }
     if (fp16_) build<half_t>(nf); else build<float>(nf);   // init_nn_design + load_parameters + buffers
     capture();                                   // bind_executor
 }
@@ -588,7 +595,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                     w8.insert(w8.end(), tower_w8e[w].begin(), tower_w8e[w].end());
                     w8.insert(w8.end(), tower_w8p[w].begin(), tower_w8p[w].end());
                 }
-                op.tw.fp8 = 1;
+                op.tw.fp8 = int8_ ? 2 : 1;
                 op.tw.wstream_e_frags = (long long)(tower_w8e[0].size() / 1024);
             }
             for (int w = 0; w < 4; ++w) {
@@ -912,17 +919,39 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 const int n = cop_pad / 128;
                 // Precision fp8: power-of-two scale per expand channel / per cout; s1 goes into the depthwise weights (ReLU commutes with
                 // a positive factor), b1 / s1 is where the expand accumulator starts, y = x + s3 * (acc + b3 / s3)
+                // Precision int8 (oracle/rise_oracle.py: int8_block is the definition): s1 / s3 = max |row| / 127, weights rounded half to
+                // even; with the block's calibrated activation steps 1 / qx_inv (stream) and 1 / qt_inv (depthwise output) a unit of the
+                // expand accumulator is worth k1 = s1 / qx_inv, of the project accumulator k3 = s3 / qt_inv: the biases enter the
+                // accumulators as round(b / k), t1 = relu(acc) * 2^-7, k1 * 2^7 goes into the depthwise weights, y = x + k3 * acc
                 std::vector<double> s1(size_t(cop_pad), 1.0), s3(size_t(C), 1.0);
+                std::vector<double> k1(size_t(cop_pad), 1.0), k3(size_t(C), 1.0);
+                constexpr double kInt8Escale = 1.0 / 128.0;
+                double qx_inv = 0.0, qt_inv = 0.0;
+                if (int8_) {
+                    if (i >= int8_calib_.size()) throw std::runtime_error("INT8 calibration file holds fewer blocks than the model");
+                    qx_inv = double(float(half_t(float(127.0 / std::max(double(int8_calib_[i].first), 1e-6)))));     // f16 numbers: the kernel's quantiser multiplies in f16
+                    qt_inv = double(float(half_t(float(255.0 / std::max(double(int8_calib_[i].second), 1e-6)))));
+                    td.qx_inv = float(qx_inv);
+                    td.qt_inv = float(qt_inv);
+                    td.escale = float(kInt8Escale);
+                }
+                auto weight_byte = [&](double v) -> uint8_t {               // v = w / row step
+                    if (!int8_) return to_e4m3(v);
+                    const double r = std::max(-127.0, std::min(127.0, std::nearbyint(v)));
+                    return uint8_t(int8_t(int(r)));
+                };
                 if (fp8_tower_) {
                     for (int ch = 0; ch < cop; ++ch) {
                         double m = 0;
                         for (int k2 = 0; k2 < C; ++k2) m = std::max(m, std::fabs(f1.w[size_t(ch) * C + k2]));
-                        s1[ch] = row_scale_pow2(m);
+                        s1[ch] = int8_ ? std::max(m, 1e-30) / 127.0 : row_scale_pow2(m);
+                        k1[ch] = s1[ch] / qx_inv;
                     }
                     for (int co = 0; co < C; ++co) {
                         double m = 0;
                         for (int ch = 0; ch < cop; ++ch) m = std::max(m, std::fabs(f3.w[size_t(co) * cop + ch]));
-                        s3[co] = row_scale_pow2(m);
+                        s3[co] = int8_ ? std::max(m, 1e-30) / 127.0 : row_scale_pow2(m);
+                        k3[co] = s3[co] / qt_inv;
                     }
                     for (int w = 0; w < 4; ++w)
                         for (int c = 0; c < n; ++c) {
@@ -931,7 +960,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                                     for (int l = 0; l < 64; ++l)
                                         for (int t = 0; t < 16; ++t) {
                                             const int ch = c * 128 + w * 32 + (l & 31), k2 = ks * 64 + (l >> 5) * 32 + hf * 16 + t;
-                                            tower_w8e[w].push_back(ch < cop ? to_e4m3(f1.w[size_t(ch) * C + k2] / s1[ch]) : uint8_t(0));
+                                            tower_w8e[w].push_back(ch < cop ? weight_byte(f1.w[size_t(ch) * C + k2] / s1[ch]) : uint8_t(0));
                                         }
                             for (int ks = 0; ks < 2; ++ks)           // project: [k-step of 64][row tile][half][lane][16 B]
                                 for (int rt = 0; rt < 2; ++rt)
@@ -940,12 +969,29 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                                             for (int t = 0; t < 16; ++t) {
                                                 const int co = w * 64 + rt * 32 + (l & 31);
                                                 const int ch = tower_k_channel(c * 128 + ks * 64 + (l >> 5) * 32 + hf * 16 + t);
-                                                tower_w8p[w].push_back(ch < cop ? to_e4m3(f3.w[size_t(co) * cop + ch] / s3[co]) : uint8_t(0));
+                                                tower_w8p[w].push_back(ch < cop ? weight_byte(f3.w[size_t(co) * cop + ch] / s3[co]) : uint8_t(0));
                                             }
                         }
-                    for (int co = 0; co < C; ++co) f3.b[co] /= s3[co];
-                    std::vector<float> s3f(s3.begin(), s3.end());
-                    td.s3 = im.upload(s3f);
+                    if (int8_) {
+                        // project accumulators: int32, started at round(b3 / k3) + 128 x the row's weight sum (the depthwise output u is held as
+                        // u - 128); y = x + k3 * acc.  The bit patterns travel in the float arrays the fp8 path uses.
+                        std::vector<float> b3bits, k3f;
+                        b3bits.resize(size_t(C));
+                        k3f.resize(size_t(C));
+                        for (int co = 0; co < C; ++co) {
+                            long long rowsum = 0;
+                            for (int ch = 0; ch < cop; ++ch) rowsum += (long long)(int8_t(weight_byte(f3.w[size_t(co) * cop + ch] / s3[co])));
+                            const int32_t start = int32_t(std::nearbyint(f3.b[co] / k3[co])) + int32_t(128 * rowsum);
+                            std::memcpy(&b3bits[co], &start, 4);
+                            k3f[co] = float(k3[co]);
+                        }
+                        td.s3 = im.upload(k3f);
+                        td.b3 = im.upload(b3bits);
+                    } else {
+                        for (int co = 0; co < C; ++co) f3.b[co] /= s3[co];
+                        std::vector<float> s3f(s3.begin(), s3.end());
+                        td.s3 = im.upload(s3f);
+                    }
                 }
                 for (int w = 0; w < 4; ++w) {
                     std::vector<half_t>& ws = tower_ws[w];
@@ -975,6 +1021,12 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                         for (int lh = 0; lh < 2; ++lh)                  // BN1 biases [lane/32][accumulator element v]
                             for (int v = 0; v < 16; ++v) {
                                 const int ch = c * 128 + w * 32 + (v % 4) + 8 * (v / 4) + 4 * lh;
+                                if (int8_) {                        // int32 bit pattern of the BN1 bias in the accumulator's unit
+                                    const int32_t start = ch < cop ? int32_t(std::nearbyint(f1.b[ch] / k1[ch])) : 0;
+                                    float bits;
+                                    std::memcpy(&bits, &start, 4);
+                                    tower_bs[w].push_back(bits);
+                                } else
                                 tower_bs[w].push_back(ch < cop ? float(f1.b[ch] / s1[ch]) : 0.f);
                             }
                         // depthwise weights for K positions w*32 + lg*8 + pi*2 + {0,1}, entries = k*k taps then the BN2 bias:
@@ -984,7 +1036,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                         auto dwv = [&](int lgk, int ent, int pi, int hh) {
                             const int ch = tower_k_channel(c * 128 + w * 32 + lgk * 8 + pi * 2 + hh);
                             double v = 0.0;
-                            if (ch < cop && ent <= k * k) v = ent < k * k ? f2.w[size_t(ch) * k * k + ent] * s1[ch] : f2.b[ch];
+                            if (ch < cop && ent <= k * k) v = ent < k * k ? f2.w[size_t(ch) * k * k + ent] * (int8_ ? k1[ch] / kInt8Escale : s1[ch]) : f2.b[ch];
                             return v;
                         };
                         const size_t chunk_begin = tower_ps[w].size();
@@ -1006,7 +1058,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                         tower_ps[w].resize(chunk_begin + 1024, half_t(0.f));
                     }
                 }
-                td.b3 = im.upload_d2f(f3.b, C);
+                if (!int8_) td.b3 = im.upload_d2f(f3.b, C);
                 td.cop_pad = cop_pad;
                 td.ks = k;
                 if (tower_blocks.empty()) {
@@ -2045,6 +2097,86 @@ void* RiseNet::enable_block_dump(int* n_tiles) {
     }
     if (n_tiles) *n_tiles = tiles;
     return tower->tw.block_dump;
+}
+
+std::string int8_calibration_path(const std::string& model_file_path) { return model_file_path + ".int8calib"; }
+
+std::vector<std::pair<float, float>> read_int8_calibration(const std::string& model_file_path) {
+    std::vector<std::pair<float, float>> out;
+    std::ifstream f(int8_calibration_path(model_file_path));
+    if (!f) return out;
+    std::string magic, word;
+    int version = 0, boards = 0, blocks = 0;
+    f >> magic >> version >> word >> boards >> word >> blocks;
+    if (magic != "crazyara-int8-calibration" || version != 1 || blocks <= 0 || blocks > 4096)
+        throw std::runtime_error("malformed INT8 calibration file " + int8_calibration_path(model_file_path));
+    for (int i = 0; i < blocks; ++i) {
+        float a = 0.f, b = 0.f;
+        if (!(f >> a >> b) || !(a >= 0.f) || !(b >= 0.f)) throw std::runtime_error("malformed INT8 calibration file " + int8_calibration_path(model_file_path));
+        out.emplace_back(a, b);
+    }
+    return out;
+}
+
+std::vector<std::pair<float, float>> RiseNet::calibration_maxima(const float* planes_host, int n_boards) {
+    if (fused_ || !fp16_ || fp8_tower_) throw std::logic_error("calibration_maxima: a net made with Precision float16-unfused");
+    if (!planes_host || n_boards <= 0) throw std::invalid_argument("calibration needs at least one board");
+    HIP_CHECK(hipSetDevice(device_));
+    Impl& im = *impl_;
+    const int B = design_.batch;
+    const size_t per_board = size_t(design_.nb_input_channels) * kSquares;
+    std::vector<std::pair<float, float>> out;
+    std::vector<half_t> host;
+    auto absmax = [&](const void* dev, size_t count) {
+        host.resize(count);
+        HIP_CHECK(hipMemcpy(host.data(), dev, count * sizeof(half_t), hipMemcpyDeviceToHost));
+        float m = 0.f;
+        for (size_t i = 0; i < count; ++i) m = std::max(m, std::fabs(float(host[i])));
+        return m;
+    };
+    std::vector<float> chunk(size_t(B) * per_board);
+    for (int b0 = 0; b0 < n_boards; b0 += B) {
+        for (int j = 0; j < B; ++j)                          // the last chunk repeats boards: a maximum does not mind
+            std::memcpy(chunk.data() + size_t(j) * per_board, planes_host + size_t((b0 + j) % n_boards) * per_board, per_board * sizeof(float));
+        HIP_CHECK(hipMemcpy(d_planes_, chunk.data(), chunk.size() * sizeof(float), hipMemcpyHostToDevice));
+        size_t blk = 0;
+        for (int k = 0; k < int(im.ops.size()); ++k) {
+            launch_op<half_t>(k, stream_);
+            HIP_CHECK(hipStreamSynchronize(stream_));
+            const Op& op = im.ops[k];
+            if (op.kind != OpKind::Depthwise) continue;
+            if (k == 0 || im.ops[k - 1].kind != OpKind::Conv || im.ops[k - 1].conv.out != op.x)
+                throw std::logic_error("calibration_maxima: a depthwise op without its expand conv in front");
+            const Op& ex = im.ops[k - 1];                     // the expand conv has run: its input (the gated stream) is untouched
+            const float mx = absmax(ex.conv.x, size_t(B) * kSquares * size_t(ex.conv.cin));
+            const float mt = absmax(op.y, size_t(B) * kSquares * size_t(op.C));
+            if (blk == out.size()) out.emplace_back(0.f, 0.f);
+            out[blk].first = std::max(out[blk].first, mx);
+            out[blk].second = std::max(out[blk].second, mt);
+            ++blk;
+        }
+    }
+    return out;
+}
+
+std::string calibrate_int8(const std::string& model_path, int device_id, const float* planes_host, int n_boards) {
+    if (planes_host && n_boards <= 0) throw std::invalid_argument("calibration needs at least one board");
+    RiseNet net(model_path, device_id, planes_host ? std::min(n_boards, 64) : 64, "float16-unfused");
+    std::vector<float> own;
+    if (!planes_host) {
+        own = default_calibration_planes(net.design().nb_input_channels, net.design().version, &n_boards);
+        planes_host = own.data();
+    }
+    const std::vector<std::pair<float, float>> mx = net.calibration_maxima(planes_host, n_boards);
+    if (mx.empty()) throw std::runtime_error("Precision int8 runs on the one-launch bottleneck tower only: this model has no bottleneck blocks");
+    const std::string path = int8_calibration_path(net.model_file_path());
+    std::ofstream f(path);
+    if (!f) throw std::runtime_error("cannot write " + path);
+    f << "crazyara-int8-calibration 1\nboards " << n_boards << "\nblocks " << mx.size() << "\n";
+    f.precision(9);
+    for (const auto& p : mx) f << p.first << " " << p.second << "\n";
+    if (!f) throw std::runtime_error("cannot write " + path);
+    return path;
 }
 
 uint8_t float_to_e4m3(float v) { return to_e4m3(double(v)); }

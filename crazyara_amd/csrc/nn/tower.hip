@@ -165,7 +165,55 @@ __device__ __forceinline__ uint32_t f16x4_to_e4m3(uint32_t lo, uint32_t hi) {
     q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, __builtin_bit_cast(half2_t, hi), 1.0f, true);
     return __builtin_bit_cast(uint32_t, q);
 }
-__device__ __forceinline__ uint2 f16x8_to_e4m3(const uint4& h) { return uint2{f16x4_to_e4m3(h.x, h.y), f16x4_to_e4m3(h.z, h.w)}; }
+
+// ---- Precision int8 (Q = 2): the calibrated INT8 mode (the reference's TensorRT INT8, tensorrtapi.cpp:334-360), Precision fp8's structure with
+// int8 operands on v_mfma_i32_32x32x32_i8.  An fp8 MFMA's 32 bytes per lane are two int8 MFMAs' 16 + 16 (the same bytes meet on both
+// operands, so the sum is the same dot product); the accumulators are int32 in the registers the fp8 path holds floats in.
+//   quantiser: z = x * inv + magic in ONE f16 FMA -- magic = 1536 (1152) puts z into [1024, 2048), where an f16's unit is 1: the FMA's
+//   single rounding IS the rounding to the integer grid (half to even), and the LOW BYTE of z's bits is the integer (two's complement:
+//   1536 = 6 * 256; 1152 = 4 * 256 + 128 stores an unsigned u as u - 128); clamped to +-127 (0 ... 255) by a packed min / max.
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mma64_i8(const i32x8& a, const i32x8& b, const f32x16& c) {
+    i32x16 ci = __builtin_bit_cast(i32x16, c);
+    ci = __builtin_amdgcn_mfma_i32_32x32x32_i8(i32x4{a[0], a[1], a[2], a[3]}, i32x4{b[0], b[1], b[2], b[3]}, ci, 0, 0, 0);
+    ci = __builtin_amdgcn_mfma_i32_32x32x32_i8(i32x4{a[4], a[5], a[6], a[7]}, i32x4{b[4], b[5], b[6], b[7]}, ci, 0, 0, 0);
+    return __builtin_bit_cast(f32x16, ci);
+}
+template <int Q> __device__ __forceinline__ void mma8(const i32x8& a, const i32x8& b, f32x16& c) {
+    if constexpr (Q == 2) c = mma64_i8(a, b, c); else mma64(a, b, c);
+}
+template <int Q> __device__ __forceinline__ f32x16 mma8_init(const i32x8& a, const i32x8& b, const f32x16& c) {
+    if constexpr (Q == 2) return mma64_i8(a, b, c); else return mma64_init(a, b, c);
+}
+struct Q8 { uint32_t inv2, magic2, lo2, hi2; };      // packed f16 pairs: 1 / step, the rounding constant, the clamps
+__device__ __forceinline__ Q8 q8_signed(float inv) {       // the residual stream: +-127
+    const uint32_t h = __builtin_bit_cast(unsigned short, half_t(inv));
+    return Q8{h | (h << 16), 0x66006600u, 0x65816581u, 0x667f667fu};
+}
+__device__ __forceinline__ Q8 q8_unsigned(float inv) {     // the depthwise output (post-ReLU): 0 ... 255, stored as u - 128
+    const uint32_t h = __builtin_bit_cast(unsigned short, half_t(inv));
+    return Q8{h | (h << 16), 0x64806480u, 0x64806480u, 0x657f657fu};
+}
+__device__ __forceinline__ uint32_t f16x4_to_i8(uint32_t lo, uint32_t hi, const Q8& q) {
+    uint32_t a, b;
+    asm("v_pk_fma_f16 %0, %2, %4, %5\n\tv_pk_fma_f16 %1, %3, %4, %5\n\t"
+        "v_pk_min_f16 %0, %0, %7\n\tv_pk_min_f16 %1, %1, %7\n\tv_pk_max_f16 %0, %0, %6\n\tv_pk_max_f16 %1, %1, %6"
+        : "=&v"(a), "=&v"(b)
+        : "v"(lo), "v"(hi), "v"(q.inv2), "v"(q.magic2), "v"(q.lo2), "v"(q.hi2));
+    return __builtin_amdgcn_perm(b, a, 0x06040200u);                 // the low bytes of the four halves, in order
+}
+// the two byte forms behind one name: Q = 1 e4m3, Q = 2 int8 at the tensor's calibrated step
+template <int Q> __device__ __forceinline__ uint32_t f16x4_to_q8(uint32_t lo, uint32_t hi, const Q8& q) {
+    if constexpr (Q == 2) return f16x4_to_i8(lo, hi, q); else return f16x4_to_e4m3(lo, hi);
+}
+template <int Q> __device__ __forceinline__ uint2 f16x8_to_q8(const uint4& h, const Q8& q) {
+    return uint2{f16x4_to_q8<Q>(h.x, h.y, q), f16x4_to_q8<Q>(h.z, h.w, q)};
+}
+// expand epilogue, int8: the int32 accumulator (it started at the BN1 bias in its own unit) -> relu -> x 2^-7 -> f16 (the per-row value of
+// a unit and the 2^7 are folded into the depthwise weights on the host)
+__device__ __forceinline__ uint32_t pack_relu_cvt_i32(float a_bits, float b_bits, float scale) {
+    return pack_relu_cvt(float(__builtin_bit_cast(int, a_bits)) * scale, float(__builtin_bit_cast(int, b_bits)) * scale);
+}
 
 // matrix role, Precision fp8, one phase.  A fragment (32 rows x 64 k) is two loads of 1 KiB ([half][lane][16 B]: a lane's bytes 0..15
 // and 16..31), so a phase needs 8 loads where the f16 phase needs 16.  The expand and the project fragments therefore come as TWO streams
@@ -173,6 +221,7 @@ __device__ __forceinline__ uint2 f16x8_to_e4m3(const uint4& h) { return uint2{f1
 // the next phase of its kind, whatever the other kind does in between (the first and last intervals of a block run only one of them).
 //   expand : 4 k-steps x {1 fragment, 2 square tiles}: 8 MFMAs          project: 2 k-steps x {2 row tiles, 2 square tiles}: 8 MFMAs
 constexpr int TW_WIN8 = 8;
+template <int Q>
 __device__ __forceinline__ void expand_phase8(f32x16 (&accE)[2], half8 (&win)[TW_WIN8], WStream& sp, f32x16& bias,
                                               const float* __restrict__& bp, const char* xqr) {
     constexpr int BASE = 0;
@@ -192,11 +241,11 @@ __device__ __forceinline__ void expand_phase8(f32x16 (&accE)[2], half8 (&win)[TW
         const i32x8 a = cat32(win[BASE + 2 * s], win[BASE + 2 * s + 1]);
         // youngest operands first, the bias as the first MFMA's C operand (see matrix_interval)
         if (s == 0) {
-            accE[1] = mma64_init(a, cat32(cur[2], cur[3]), bias);
-            accE[0] = mma64_init(a, cat32(cur[0], cur[1]), bias);
+            accE[1] = mma8_init<Q>(a, cat32(cur[2], cur[3]), bias);
+            accE[0] = mma8_init<Q>(a, cat32(cur[0], cur[1]), bias);
         } else {
-            mma64(a, cat32(cur[2], cur[3]), accE[1]);
-            mma64(a, cat32(cur[0], cur[1]), accE[0]);
+            mma8<Q>(a, cat32(cur[2], cur[3]), accE[1]);
+            mma8<Q>(a, cat32(cur[0], cur[1]), accE[0]);
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) win[BASE + 2 * s + e] = sp.frag_at(2 * s + e + TW_WIN8);
@@ -209,7 +258,7 @@ __device__ __forceinline__ void expand_phase8(f32x16 (&accE)[2], half8 (&win)[TW
     }
     sp.advance(8 * 1024);
 }
-template <typename EPI>
+template <int Q, typename EPI>
 __device__ __forceinline__ void project_phase8(f32x16 (&accP)[2][2], half8 (&win)[TW_WIN8], WStream& sp, const char* t2r, const EPI& epilogue) {
     using frag = half8;
     constexpr int BASE = 0;
@@ -228,8 +277,8 @@ __device__ __forceinline__ void project_phase8(f32x16 (&accP)[2][2], half8 (&win
 #pragma unroll
         for (int rt = 1; rt >= 0; --rt) {            // youngest operands first (see matrix_interval)
             const i32x8 a = cat32(win[BASE + s * 4 + rt * 2], win[BASE + s * 4 + rt * 2 + 1]);
-            mma64(a, cat32(cur[2], cur[3]), accP[rt][1]);
-            mma64(a, cat32(cur[0], cur[1]), accP[rt][0]);
+            mma8<Q>(a, cat32(cur[2], cur[3]), accP[rt][1]);
+            mma8<Q>(a, cat32(cur[0], cur[1]), accP[rt][0]);
         }
         epilogue(s);
 #pragma unroll
@@ -345,23 +394,24 @@ __device__ __forceinline__ void matrix_interval(bool do_e, bool do_p, f32x16 (&a
 }
 
 // the same interval in Precision fp8 (window halves: [0, 8) expand stream, [8, 16) project stream)
+template <int Q>
 __device__ __forceinline__ void matrix_interval8(bool do_e, bool do_p, f32x16 (&accP)[2][2], half8 (&winE)[TW_WIN8], half8 (&winP)[TW_WIN8],
                                                  WStream& spE, WStream& spP, f32x16& bias, const float* __restrict__& bp, const char* xqr,
-                                                 half_t* t1w, const char* t2r) {
+                                                 half_t* t1w, const char* t2r, float escale) {
     constexpr int T1ROW = TW_T1ROW;
     f32x16 accE[2];
-    if (do_e) expand_phase8(accE, winE, spE, bias, bp, xqr);
+    if (do_e) expand_phase8<Q>(accE, winE, spE, bias, bp, xqr);
     auto expand_epilogue = [&](int ct) {             // as in matrix_interval: the accumulators started at the (scaled) BN1 bias
         uint32_t o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = pack_relu_cvt(accE[ct][2 * i], accE[ct][2 * i + 1]);
+        for (int i = 0; i < 8; ++i) o[i] = Q == 2 ? pack_relu_cvt_i32(accE[ct][2 * i], accE[ct][2 * i + 1], escale) : pack_relu_cvt(accE[ct][2 * i], accE[ct][2 * i + 1]);
         uint4* dst = reinterpret_cast<uint4*>(t1w + ct * 32 * T1ROW);
         dst[0] = uint4{o[0], o[1], o[2], o[3]};
         dst[1] = uint4{o[4], o[5], o[6], o[7]};
     };
     if (do_p) {
         auto epi = [&](int s) { if (do_e) expand_epilogue(s); };
-        project_phase8(accP, winP, spP, t2r, epi);
+        project_phase8<Q>(accP, winP, spP, t2r, epi);
     } else if (do_e) {
         mfma_retire(accE[0], accE[1]);               // the last expand MFMAs (16 passes) retire first
         expand_epilogue(0);
@@ -425,17 +475,18 @@ __device__ __forceinline__ uint4 vec_row_read(const char* p) {
 }
 
 // t2w: byte address of my output slot in tile 0 of t2 buffer 0 (f16: row pitch T2ROW halves, 16 bytes; fp8: TW_T2ROW8 bytes, 8 bytes)
-template <bool F8>
-__device__ __forceinline__ void vector_store(char* t2w, int parity, int t, const uint32_t (&o)[4]) {
-    if constexpr (F8) *reinterpret_cast<uint2*>(t2w + parity * TW_T2_BYTES + t * 16 * TW_T2ROW8) = uint2{f16x4_to_e4m3(o[0], o[1]), f16x4_to_e4m3(o[2], o[3])};
+template <int Q>
+__device__ __forceinline__ void vector_store(char* t2w, int parity, int t, const uint32_t (&o)[4], const Q8& qt) {
+    constexpr bool F8 = Q != 0;
+    if constexpr (F8) *reinterpret_cast<uint2*>(t2w + parity * TW_T2_BYTES + t * 16 * TW_T2ROW8) = uint2{f16x4_to_q8<Q>(o[0], o[1], qt), f16x4_to_q8<Q>(o[2], o[3], qt)};
     else *reinterpret_cast<uint4*>(t2w + parity * TW_T2_BYTES + t * 16 * TW_T2ROW * 2) = uint4{o[0], o[1], o[2], o[3]};
 }
 
 // prm_off: byte offset of my weights inside an entry = lane group * 48 + file variant * 16.  The board has no file left of a and none
 // right of h: instead of multiplying the taps that leave the board by zero in every interval (24 packed multiplies), the stream
 // carries the weights three times -- as they are, with the dx = -1 taps zeroed (file a), with the dx = +1 taps zeroed (file h).
-template <int PARITY, bool F8>
-__device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf, int prm_off, const VecAddr& va, char* t2w) {
+template <int PARITY, int Q>
+__device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf, int prm_off, const VecAddr& va, char* t2w, const Q8& qt) {
     constexpr int T1ROW = TW_T1ROW;
     constexpr int TILE = 16 * T1ROW * 2;             // bytes between square tiles of a t1 buffer
     const char* prm = prm_buf + prm_off;
@@ -493,7 +544,7 @@ __device__ __forceinline__ void vector_interval(VParams& vp, const char* prm_buf
         uint32_t o[4];
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) o[pi] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(acc[pi], half2_t{0, 0}));
-        vector_store<F8>(t2w, PARITY, t, o);
+        vector_store<Q>(t2w, PARITY, t, o, qt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) { top[i] = bot[i]; mid[i] = nmid[i]; bot[i] = nbot[i]; }
@@ -511,8 +562,8 @@ struct VecAddr5 {
     const char* zero3;   // the zero row below the board at my columns, pre-biased by -3 tiles
 };
 
-template <int PARITY, bool F8>
-__device__ __forceinline__ void vector_interval5(VParams& vp, const char* prm_buf, int lg, const VecAddr5& va, char* t2w, const half2_t (&mk)[5]) {
+template <int PARITY, int Q>
+__device__ __forceinline__ void vector_interval5(VParams& vp, const char* prm_buf, int lg, const VecAddr5& va, char* t2w, const half2_t (&mk)[5], const Q8& qt) {
     constexpr int T1ROW = TW_T1ROW;
     const char* prm = prm_buf + lg * 16;
     half2_t W[26][4];
@@ -552,15 +603,17 @@ __device__ __forceinline__ void vector_interval5(VParams& vp, const char* prm_bu
         uint32_t o[4];
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) o[pi] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(acc[pi], half2_t{0, 0}));
-        vector_store<F8>(t2w, PARITY, t, o);
+        vector_store<Q>(t2w, PARITY, t, o, qt);
     }
     vp.fetch_next();
 }
 
 // SE gate of a block (squeeze over the residual stream in LDS, excitation MLP, scale in place); executed by all 512 threads
-template <bool F8>
+template <int Q>
 __device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_t* xs, char* xq, const float* pool_sum, float* se_mean,
                                      float* se_part, float* se_h, float* se_gate, unsigned long long* trc, int& trn) {
+    constexpr bool F8 = Q != 0;
+    const Q8 qx = q8_signed(d.qx_inv);               // (int8: the gated stream is quantised at this block's calibrated step)
     constexpr int XROW = TW_XROW, SE_GRP = 36;       // floats per group of 32 means / hidden values (bank spread, see below)
     {
         // The gate weights do not depend on the data: a thread's first 32 dwords go out before the squeeze and fly while it runs,
@@ -677,7 +730,7 @@ __device__ __forceinline__ void se_phase(const TowerBlockDesc& d, int tid, half_
             for (int j = 0; j < 8; ++j) xv[j] *= gv[j];
             store8<half_t>(xs + r * XROW + v * 8, xv);
             if constexpr (F8)                        // the e4m3 copy follows the ROUNDED f16 values (what the oracle's emulation quantises)
-                *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_e4m3(*reinterpret_cast<const uint4*>(xs + r * XROW + v * 8));
+                *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_q8<Q>(*reinterpret_cast<const uint4*>(xs + r * XROW + v * 8), qx);
         }
         __syncthreads();
 #ifdef TW_TRACE_SE
@@ -694,8 +747,9 @@ size_t tower_lds_bytes() { return TW_LDS_BYTES; }
 
 // x_in_lds: the board's residual-stream tile is already at offset 0 of the dynamic LDS segment (left there by the stem of the same
 // launch, forward.hip); y_to_global = false: it stays there for the head of the same launch.  Both need gate_in == pool_out == nullptr.
-template <bool F8>
+template <int Q>
 __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_lds, const bool y_to_global) {
+    constexpr bool F8 = Q != 0;                      // the byte tiles, the two weight streams, the windows of 8: Precision fp8 and int8 alike
     using frag = half8;
     if constexpr (F8) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);       // MODE.FP16_OVFL: conversions to f16 / e4m3 clamp instead of overflowing
     constexpr int C = TW_C, XROW = TW_XROW, T1ROW = TW_T1ROW, T2ROW = TW_T2ROW;
@@ -727,6 +781,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
     TW_STAMP();
 
     // ---- residual stream tile -> LDS (optionally gated: the first block's SE gate was computed by a previous launch) ----
+    const Q8 qx0 = q8_signed(a.blocks[0].qx_inv);    // int8: the first block's stream step
     auto load_board = [&]() {
         if (tid < 6 * T1ROW / 2) {       // zero rows 0, 65 and 66 of both t1 buffers (6 rows of T1ROW halves, as 32-bit words)
             const int rowi = tid / (T1ROW / 2), col = tid % (T1ROW / 2), r3 = rowi % 3;
@@ -736,7 +791,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
             if constexpr (F8) {                      // the stem of this launch left the f16 tile: make its e4m3 copy
                 for (int i = tid; i < 64 * 32; i += 512) {
                     const int r = i >> 5, v = i & 31;
-                    *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_e4m3(*reinterpret_cast<const uint4*>(xs + r * XROW + v * 8));
+                    *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_q8<Q>(*reinterpret_cast<const uint4*>(xs + r * XROW + v * 8), qx0);
                 }
             }
             return;
@@ -747,7 +802,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                 const int r = i >> 5, v = i & 31;
                 const uint4 u = *reinterpret_cast<const uint4*>(xb + size_t(r) * C + v * 8);
                 *reinterpret_cast<uint4*>(xs + r * XROW + v * 8) = u;
-                if constexpr (F8) *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_e4m3(u);
+                if constexpr (F8) *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_q8<Q>(u, qx0);
             }
         } else {
             const float* gt = a.gate_in + size_t(b) * C;
@@ -760,7 +815,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                 for (int j = 0; j < 8; ++j) xv[j] *= gv[j];
                 store8<half_t>(xs + r * XROW + v * 8, xv);
                 if constexpr (F8)
-                    *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_e4m3(*reinterpret_cast<const uint4*>(xs + r * XROW + v * 8));
+                    *reinterpret_cast<uint2*>(xq + r * TW_XQROW + v * 8) = f16x8_to_q8<Q>(*reinterpret_cast<const uint4*>(xs + r * XROW + v * 8), qx0);
             }
         }
     };
@@ -812,7 +867,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
         const int t2off8 = l31 * TW_T2ROW8 + lh * 32;
         for (int blk = 0; blk < a.nblocks; ++blk) {
             const TowerBlockDesc& d = a.blocks[blk];
-            if (blk > 0 && d.se_kind != 0) se_phase<F8>(d, tid, xs, xq, pool_sum, se_mean, se_part, se_h, se_gate, trc, trn);
+            if (blk > 0 && d.se_kind != 0) se_phase<Q>(d, tid, xs, xq, pool_sum, se_mean, se_part, se_h, se_gate, trc, trn);
             TW_STAMP();
             const int n = d.cop_pad / TW_CK;
             // project accumulators start at the BN3 bias of their cout: row (v%4) + 8*(v/4) + 4*lh of tile rt
@@ -832,8 +887,8 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                 const half_t* t2r = t2 + ((k - 1) & 1) * (TW_T2_BYTES / 2) + t2off;
 #ifndef TW_DEV_NO_MATRIX
                 if constexpr (F8)
-                    matrix_interval8(k + 1 < n, k >= 1, accP, reinterpret_cast<frag(&)[TW_WIN8]>(win[0]), reinterpret_cast<frag(&)[TW_WIN8]>(win[TW_WIN8]),
-                                     sp, spP, bias, bp, xqr, t1w, smem + TW_T2_OFF + ((k - 1) & 1) * TW_T2_BYTES + t2off8);
+                    matrix_interval8<Q>(k + 1 < n, k >= 1, accP, reinterpret_cast<frag(&)[TW_WIN8]>(win[0]), reinterpret_cast<frag(&)[TW_WIN8]>(win[TW_WIN8]),
+                                        sp, spP, bias, bp, xqr, t1w, smem + TW_T2_OFF + ((k - 1) & 1) * TW_T2_BYTES + t2off8, d.escale);
                 else
                     matrix_interval(k + 1 < n, k >= 1, accP, win, sp, bias, bp, xsr, t1w, t2r);
 #endif
@@ -859,6 +914,8 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
             // Precision fp8: the accumulators are in units of the cout's weight scale (they started at b3 / s3): y = x + s3 * acc, and the
             // new stream's e4m3 copy is made from the rounded f16 values.
             mfma_retire(accP[0][0], accP[0][1], accP[1][0], accP[1][1]);      // asm readers below (device_utils.h)
+            // int8: the new stream is quantised at the NEXT block's step (a gated next block quantises it again behind its gate)
+            const Q8 qxn = q8_signed(a.blocks[blk + 1 < a.nblocks ? blk + 1 : blk].qx_inv);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 uint2 rv[4][2];
@@ -877,8 +934,12 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
                         half_t* px = xs + (ct * 32 + l31) * XROW + co0;
-                        const float t0 = accP[rt][ct][g4 * 4 + 0], t1 = accP[rt][ct][g4 * 4 + 1];
-                        const float t2 = accP[rt][ct][g4 * 4 + 2], t3 = accP[rt][ct][g4 * 4 + 3];
+                        float t0 = accP[rt][ct][g4 * 4 + 0], t1 = accP[rt][ct][g4 * 4 + 1];
+                        float t2 = accP[rt][ct][g4 * 4 + 2], t3 = accP[rt][ct][g4 * 4 + 3];
+                        if constexpr (Q == 2) {      // int32 sums (they started at the BN3 bias in their unit): y = x + (step of t2 * row step) * acc
+                            t0 = float(__builtin_bit_cast(int, t0)); t1 = float(__builtin_bit_cast(int, t1));
+                            t2 = float(__builtin_bit_cast(int, t2)); t3 = float(__builtin_bit_cast(int, t3));
+                        }
                         uint2 o;
                         if constexpr (F8) {
                             asm("v_fma_mixlo_f16 %0, %2, %8, %6 op_sel_hi:[0,0,1]\n\t"
@@ -888,7 +949,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                                 : "=&v"(o.x), "=&v"(o.y)
                                 : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(rv[g4][ct].x), "v"(rv[g4][ct].y), "v"(sc[g4][0]), "v"(sc[g4][1]),
                                   "v"(sc[g4][2]), "v"(sc[g4][3]));
-                            *reinterpret_cast<uint32_t*>(xq + (ct * 32 + l31) * TW_XQROW + co0) = f16x4_to_e4m3(o.x, o.y);
+                            *reinterpret_cast<uint32_t*>(xq + (ct * 32 + l31) * TW_XQROW + co0) = f16x4_to_q8<Q>(o.x, o.y, qxn);
                         } else {
                             asm("v_fma_mixlo_f16 %0, %2, 1.0, %6 op_sel_hi:[0,0,1]\n\t"
                                 "v_fma_mixhi_f16 %0, %3, 1.0, %6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
@@ -987,7 +1048,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
         TW_STAMP();
         for (int blk = 0; blk < a.nblocks; ++blk) {
             const TowerBlockDesc& d = a.blocks[blk];
-            if (blk > 0 && d.se_kind != 0) se_phase<F8>(d, tid, xs, xq, pool_sum, se_mean, se_part, se_h, se_gate, trc, trn);
+            if (blk > 0 && d.se_kind != 0) se_phase<Q>(d, tid, xs, xq, pool_sum, se_mean, se_part, se_h, se_gate, trc, trn);
             TW_STAMP();
             const int n = d.cop_pad / TW_CK;
             // the NEXT block's SE-gate weights (128 KiB, read by every workgroup at the same moment) get the same treatment:
@@ -999,6 +1060,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                                                                   : reinterpret_cast<const char*>(dn.se_w1);
                 pf_sink ^= *reinterpret_cast<const int*>(base + line * 128);
             }
+            const Q8 qt = q8_unsigned(d.qt_inv);     // int8: this block's depthwise-output step
             const bool five = __builtin_amdgcn_readfirstlane(d.ks) == 5;    // read ONCE per block: inside the loop the compiler re-loads it
                                                                             // from global memory every interval and waits for vmcnt(0),
                                                                             // i.e. also for the L2 warm-up load it has just issued
@@ -1031,11 +1093,11 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
                 }
                 if (work) {
                     if (five) {
-                        if (k & 1) vector_interval5<1, F8>(vp, prm_buf, lg, va5, t2w, mk5);
-                        else vector_interval5<0, F8>(vp, prm_buf, lg, va5, t2w, mk5);
+                        if (k & 1) vector_interval5<1, Q>(vp, prm_buf, lg, va5, t2w, mk5, qt);
+                        else vector_interval5<0, Q>(vp, prm_buf, lg, va5, t2w, mk5, qt);
                     } else {
-                        if (k & 1) vector_interval<1, F8>(vp, prm_buf, prm_off3, va, t2w);
-                        else vector_interval<0, F8>(vp, prm_buf, prm_off3, va, t2w);
+                        if (k & 1) vector_interval<1, Q>(vp, prm_buf, prm_off3, va, t2w, qt);
+                        else vector_interval<0, Q>(vp, prm_buf, prm_off3, va, t2w, qt);
                     }
                 }
 #ifdef TW_TRACE_BARRIERS
@@ -1077,16 +1139,19 @@ __device__ __forceinline__ void tower_body(const TowerArgs& a, const bool x_in_l
 }
 
 #ifndef CRA_FORWARD_TU
-__global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) { tower_body<false>(a, false, true); }
-__global__ __launch_bounds__(512) void tower_kernel_fp8(const TowerArgs a) { tower_body<true>(a, false, true); }
+__global__ __launch_bounds__(512) void tower_kernel(const TowerArgs a) { tower_body<0>(a, false, true); }
+__global__ __launch_bounds__(512) void tower_kernel_fp8(const TowerArgs a) { tower_body<1>(a, false, true); }
+__global__ __launch_bounds__(512) void tower_kernel_int8(const TowerArgs a) { tower_body<2>(a, false, true); }
 
 void init_tower_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TW_DYN_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel_fp8), hipFuncAttributeMaxDynamicSharedMemorySize, TW_DYN_LDS_BYTES_F8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel_int8), hipFuncAttributeMaxDynamicSharedMemorySize, TW_DYN_LDS_BYTES_F8);
 }
 
 void launch_tower(const TowerArgs& a, hipStream_t s) {
-    if (a.fp8) hipLaunchKernelGGL(tower_kernel_fp8, dim3(a.batch), dim3(512), TW_DYN_LDS_BYTES_F8, s, a);
+    if (a.fp8 == 2) hipLaunchKernelGGL(tower_kernel_int8, dim3(a.batch), dim3(512), TW_DYN_LDS_BYTES_F8, s, a);
+    else if (a.fp8) hipLaunchKernelGGL(tower_kernel_fp8, dim3(a.batch), dim3(512), TW_DYN_LDS_BYTES_F8, s, a);
     else hipLaunchKernelGGL(tower_kernel, dim3(a.batch), dim3(512), TW_DYN_LDS_BYTES, s, a);
 }
 

@@ -31,16 +31,31 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+def calibrate_int8(model_directory: str, device_id: int = 0, planes=None) -> None:
+    """mi_net_calibrate_int8: writes <model file>.int8calib beside the model.  planes: float32 [n][C][8][8] calibration boards, or None
+    for the plies of the reference's calibration games (chessbatchstream.cpp:44-94)."""
+    lib = _capi.load()
+    if planes is None:
+        rc = lib.mi_net_calibrate_int8(model_directory.encode(), int(device_id), None, 0)
+    else:
+        import numpy as np
+        arr = np.ascontiguousarray(planes, dtype=np.float32)
+        rc = lib.mi_net_calibrate_int8(model_directory.encode(), int(device_id), arr.ctypes.data_as(C.c_void_p), int(arr.shape[0]))
+    if rc:
+        raise RuntimeError(_capi.last_error())
+
+
 class HipAPI:
     def __init__(self, device_id: int, batch_size: int, model_directory: str, precision: str = "float16", keep_logits: bool = False):
         self._lib = _capi.load()
         self.precision_requested = precision
-        if precision == "int8" and os.environ.get("CRA_INT8_STRICT") is None:
-            # the option layer (integration/hipapi.h does the same): the reference's Precision int8 (TensorRT's calibrated INT8) does not
-            # exist here and the LIBRARY refuses the name; a configuration written for TensorRT still starts, on the reference's default
-            print("info string HipAPI: Precision int8 is not available on this back end (no calibrated INT8 mode); running float16 instead. "
-                  "Precision fp8 selects the 8-bit e4m3 mode explicitly.", file=sys.stderr)
-            precision = "float16"
+        if precision == "int8" and self._lib.mi_net_has_int8_calibration(model_directory.encode()) == 0:
+            # the option layer (integration/hipapi.h does the same; TensorRT runs its calibrator when the engine cache is missing,
+            # tensorrtapi.cpp:297-360): Precision int8 on a model without a calibration file calibrates it first, on the plies of the
+            # reference's calibration games
+            print("info string HipAPI: run INT8 quantization calibration", file=sys.stderr)
+            if self._lib.mi_net_calibrate_int8(model_directory.encode(), int(device_id), None, 0):
+                raise RuntimeError(_capi.last_error())
         self._h = self._lib.mi_net_create(model_directory.encode(), int(device_id), int(batch_size), precision.encode())
         if not self._h:
             msg = _capi.last_error()

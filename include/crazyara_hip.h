@@ -50,6 +50,19 @@ typedef struct mi_net mi_net;
  * residual stream, stem and heads stay f16).  256-channel bottleneck (RISE) nets only; error against fp32 about 2^7 times float16's
  * (DESIGN 4.3).  Other models: RuntimeError, as an unsupported precision is in the reference. */
 mi_net* mi_net_create(const char* model_dir, int device_id, int batch_size, const char* precision);
+/* Precision "int8" -- the reference's calibrated INT8 mode (TensorRT INT8 with an Int8EntropyCalibrator2 over the engine's
+ * ChessBatchStream positions, engine/src/nn/tensorrtapi.cpp:334-360, environments/chess_related/chessbatchstream.cpp:44-94) -- needs one
+ * calibration pass per model, kept beside it as <model file>.int8calib (TensorRT keeps its calibration cache the same way):
+ * mi_net_calibrate_int8 runs n_boards positions (float planes [n][C][8][8], what ChessBatchStream::getBatch hands the calibrator) through
+ * the float16 layer kernels on `device_id` and records, per bottleneck block, the largest |value| of the stream in front of it and of its
+ * depthwise output; mi_net_create(..., "int8") then quantises activations with those steps (one per tensor), weights per output row, and
+ * runs both GEMMs of every block on v_mfma_i32_32x32x32_i8.  planes == NULL: the library's default calibration positions -- the plies of
+ * the reference's own calibration games (chessbatchstream.cpp:44-94: 232 crazyhouse / 104 chess plies, kept as data in
+ * crazyara_amd/data/opening_games.json beside the library, CRA_DATA_DIR names another directory), encoded with the plane layout the
+ * model's input shape and file-name version select.  mi_net_create fails with a message that names this call when the file is
+ * missing.  mi_net_has_int8_calibration: 1 / 0, -1 on error. */
+int mi_net_calibrate_int8(const char* model_dir, int device_id, const float* planes, int n_boards);
+int mi_net_has_int8_calibration(const char* model_dir);
 void mi_net_destroy(mi_net* net);
 
 /* The weight quantiser of precision "fp8" (host only): float -> OCP e4m3fn byte, round to nearest even, |v| >= 448 clamps to +-448,

@@ -36,14 +36,14 @@ private:
     // ONNX / .cranet parse, BN folding, weight packing, upload, stream + graph); the hooks keep initialize()'s template-method
     // shape (neuralnetapi.cpp:93-99).
     void load_model() override {
-        // `Precision int8` is a valid value of the reference's option (optionsuci.cpp:143-147: TensorRT's entropy-calibrated INT8,
-        // tensorrtapi.cpp:334-360).  The library has no calibrated INT8 mode and refuses the name (its own 8-bit mode, `fp8`, has another
-        // accuracy contract and must be asked for by name); so that an engine or RL configuration written for TensorRT still starts, the
-        // OPTION layer maps it to the reference's default precision and says so.
-        if (precision == "int8") {
-            info_string_important("HipAPI: Precision int8 is not available on this back end (no calibrated INT8 mode);",
-                                  "running float16 instead. Precision fp8 selects the 8-bit e4m3 mode explicitly.");
-            precision = "float16";
+        // `Precision int8` (optionsuci.cpp:143-147): TensorRT's entropy-calibrated INT8 runs its calibrator over the engine's ChessBatchStream
+        // when no engine cache exists (tensorrtapi.cpp:297-360).  Here: a calibration file beside the model (<model>.int8calib), made on
+        // first use from the same positions -- the plies of the reference's calibration games, which the library holds as data.
+        if (precision == "int8" && mi_net_has_int8_calibration(modelDir.c_str()) == 0) {
+            info_string("run INT8 quantization calibration");
+            if (mi_net_calibrate_int8(modelDir.c_str(), deviceID, nullptr, 0) != 0) {
+                throw std::runtime_error(std::string("HipAPI: INT8 calibration failed: ") + mi_last_error());
+            }
         }
         net = mi_net_create(modelDir.c_str(), deviceID, int(batchSize), precision.c_str());
         if (net == nullptr) {

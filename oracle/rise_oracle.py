@@ -246,6 +246,98 @@ def predict_fp8_tower(cfg, sd, x):
 
 
 # --------------------------------------------------------------------------------------------------------------
+# Precision int8 (crazyara_amd/csrc/nn/tower.hip, Q = 2): the calibrated INT8 mode -- the reference's third `Precision` value, TensorRT's
+# entropy-calibrated INT8 (tensorrtapi.cpp:334-360, chessbatchstream.cpp:44-94).  Emulation of the mode's rounding points, NOT a restatement
+# of reference code (TensorRT's kernels are not in the reference).  Precision fp8's shape with int8 in e4m3's place:
+#   * the two 1x1 GEMMs of every bottleneck block on int8 operands (v_mfma_i32_32x32x32_i8), exact int32 accumulation;
+#   * activations: ONE step per tensor and block, fixed by calibration (max |.| over the calibration positions -> 127 for the stream in
+#     front of the block, -> 255 for the post-ReLU depthwise output, which is stored as u - 128); the quantiser is one f16 FMA
+#     x * inv + 1536 (1152) -- a single rounding to the integer grid, half to even -- clamped; inv is an f16 number and the step is 1 / inv;
+#   * weights: one step per output row (max |row| / 127), round half to even;
+#   * the BN1 / BN3 biases enter the integer accumulators rounded to the accumulator's unit;
+#   * t1 = f16(relu(acc) * 2^-7), depthwise in f16 with the dequantisation factors folded into its weights, stream and heads as float16.
+# calib = [(max|x_i|, max t2_i)] per block (calibrate_int8 below, or the library's mi_net_calibrate_int8 through the float16 layer kernels).
+# --------------------------------------------------------------------------------------------------------------
+INT8_ESCALE = 2.0 ** -7
+
+
+def _f16(t):
+    return t.to(torch.float16).to(torch.float32)
+
+
+def int8_steps(calib):
+    """calibration maxima -> [(inv_x, inv_t)] as the kernel holds them: f16 numbers; the steps are their reciprocals"""
+    out = []
+    for mx, mt in calib:
+        out.append((float(_f16(torch.tensor(127.0 / max(float(mx), 1e-6)))), float(_f16(torch.tensor(255.0 / max(float(mt), 1e-6))))))
+    return out
+
+
+@torch.no_grad()
+def int8_block(cfg: RiseConfig, sd, i: int, h: torch.Tensor, inv_x: float, inv_t: float, se_f16_weights=False, collect=None):
+    """Block i of Precision int8 from the f16 stream h in front of it (its SE gate included) -> the f16 stream behind it."""
+    k, se = cfg.kernels[i], cfg.se_types[i]
+    p = f"{cfg.key_prefix}.{i + 1}"
+    if se is not None:
+        h = _f16(h * _se_gate(sd, p, se, h, se_f16_weights)[:, :, None, None])
+    w1, b1 = _fold(sd, p + ".body.0", p + ".body.1")
+    w2, b2 = _fold(sd, p + ".body.3", p + ".body.4")
+    w3, b3 = _fold(sd, p + ".body.6", p + ".body.7")
+    s1 = w1.abs().amax(dim=(1, 2, 3)).clamp_min(1e-30) / 127.0
+    s3 = w3.abs().amax(dim=(1, 2, 3)).clamp_min(1e-30) / 127.0
+    q1 = torch.round(w1 / s1.view(-1, 1, 1, 1)).clamp(-127, 127)
+    q3 = torch.round(w3 / s3.view(-1, 1, 1, 1)).clamp(-127, 127)
+    if collect is not None:
+        collect.append([float(h.abs().max()), 0.0])
+    k1 = s1 / inv_x                                                              # value of one unit of the expand accumulator, per row
+    k3 = s3 / inv_t
+    qx = torch.round(h.double() * inv_x).clamp(-127, 127)                        # f16 x f16 is exact in double; one rounding, half to even
+    acc = F.conv2d(qx, q1) + torch.round(b1 / k1).view(1, -1, 1, 1)
+    t = _f16((F.relu(acc) * INT8_ESCALE).float())                                # t1
+    t = F.relu(_depthwise_f16_chain(t, (w2 * (k1 / INT8_ESCALE).view(-1, 1, 1, 1)).float(), b2.float(), k))
+    if collect is not None:
+        collect[-1][1] = float(t.max())
+    u = torch.round(t.double() * inv_t).clamp(0, 255)
+    acc3 = F.conv2d(u, q3) + torch.round(b3 / k3).view(1, -1, 1, 1)              # (the kernel holds u - 128 and starts at + 128 * rowsum: the same integers)
+    return _f16((h.double() + acc3 * k3.view(1, -1, 1, 1)).float())
+
+
+@torch.no_grad()
+def forward_int8_tower(cfg: RiseConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, calib, collect=None):
+    """(value, policy logits, aux) of Precision int8 as emulated on the CPU (bottleneck-block nets only)."""
+    assert not cfg.dense_blocks
+    x = x.to(torch.float32)
+    pre = cfg.key_prefix
+    w0, b0 = _fold(sd, pre + ".0.body.0", pre + ".0.body.1")
+    h = _f16(F.relu(F.conv2d(_f16(x), _f16(w0.float()), padding=1) + b0.float().view(1, -1, 1, 1)))
+    steps = int8_steps(calib)
+    for i in range(len(cfg.kernels)):
+        h = int8_block(cfg, sd, i, h, steps[i][0], steps[i][1], collect=collect)
+    return _heads(cfg, sd, h, torch.float16)
+
+
+@torch.no_grad()
+def calibrate_int8(cfg: RiseConfig, sd, x_calib: torch.Tensor):
+    """[(max |stream in front of block i| (gated), max depthwise output of block i)] of the float16 forward over the calibration positions"""
+    pre = cfg.key_prefix
+    w0, b0 = _fold(sd, pre + ".0.body.0", pre + ".0.body.1")
+    h = _f16(F.relu(F.conv2d(_f16(x_calib.float()), _f16(w0.float()), padding=1) + b0.float().view(1, -1, 1, 1)))
+    out = []
+    for i, (k, se) in enumerate(zip(cfg.kernels, cfg.se_types)):
+        p = f"{pre}.{i + 1}"
+        if se is not None:
+            h = _f16(h * _se_gate(sd, p, se, h)[:, :, None, None])
+        w1, b1 = _fold(sd, p + ".body.0", p + ".body.1")
+        w2, b2 = _fold(sd, p + ".body.3", p + ".body.4")
+        w3, b3 = _fold(sd, p + ".body.6", p + ".body.7")
+        t = _f16(F.relu(F.conv2d(h, _f16(w1.float())) + b1.float().view(1, -1, 1, 1)))
+        t = _f16(F.relu(F.conv2d(t, _f16(w2.float()), padding=k // 2, groups=t.shape[1]) + b2.float().view(1, -1, 1, 1)))
+        out.append((float(h.abs().max()), float(t.max())))
+        h = _f16(h + F.conv2d(t, _f16(w3.float())) + b3.float().view(1, -1, 1, 1))
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------
 # Precision float16x3 (crazyara_amd/csrc/nn/x3.hip): emulation of the mode's rounding points, NOT a restatement of reference code.
 # What is pinned is the fp32 forward above; this function says what the split-operand mode adds to it:
 #   every dense contraction (stem, expand / project 1x1, dense 3x3, policy convs, value conv, value FC1, flat-policy Linear):

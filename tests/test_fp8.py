@@ -270,42 +270,3 @@ def test_float16_tower_block_by_block_against_the_oracle(tmp_path, hip_lib):
         h_32 = ro.fp32_block(cfg, sd, i, h_in)
         err = (h_gpu - h_32).abs() - _f16_ulp(h_32)
         assert float(err.max()) < 3e-3 * max(1.0, float(h_32.abs().max())), (i, float(err.max()))
-
-
-def test_int8_is_refused_by_name(tmp_path, hip_lib, monkeypatch, capfd):
-    """The reference's Precision int8 is TensorRT's entropy-calibrated INT8 (tensorrtapi.cpp:334-360, chessbatchstream.cpp:44-94).  This
-    back end has no calibrated 8-bit mode (calibration of its e4m3 mode was measured without gain, profiles/r03/fp8_calibration_study.txt),
-    so the LIBRARY refuses the name -- loudly, naming the explicit opt-in -- instead of selecting a mode with another accuracy contract.
-    (The precision is checked before the device is touched: the refusal is the same with and without a GPU.)  The OPTION layer
-    (integration/hipapi.h and its Python mirror) maps the name to the reference's default float16 with an info string, so that a
-    configuration written for TensorRT still starts; never to the e4m3 mode."""
-    from crazyara_amd import _capi
-    from crazyara_amd.neuralnetapi import HipAPI
-    cfg = ro.rise_v2_config(1, 34, 81)
-    sd = ro.make_state_dict(cfg, seed=31, stress=True)
-    d = nn_cases.export_case(tmp_path, "int8-refused", cfg, sd)
-    assert not _capi.load().mi_net_create(d.encode(), 0, 4, b"int8")                  # the C ABI itself
-    msg = _capi.last_error()
-    assert "int8" in msg and "fp8" in msg and "calibrated" in msg
-    monkeypatch.setenv("CRA_INT8_STRICT", "1")                                         # the mirror without its option layer
-    with pytest.raises(ValueError) as e:
-        HipAPI(0, 4, d, "int8")
-    assert "int8" in str(e.value) and "fp8" in str(e.value) and "calibrated" in str(e.value)
-    shim = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "integration", "hipapi.h")).read()
-    assert 'precision == "int8"' in shim and 'precision = "float16"' in shim and "info_string_important" in shim
-
-
-@pytest.mark.gpu
-def test_int8_in_a_reference_configuration_runs_float16_with_an_info_string(tmp_path, hip_lib, capfd):
-    from crazyara_amd.neuralnetapi import HipAPI
-    cfg, sd, x = nn_cases.make_case("risev2-3")
-    d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
-    outs = []
-    for prec in ("int8", "float16"):
-        net = HipAPI(0, 4, d, prec)
-        v, p = np.zeros(4, np.float32), np.zeros(4 * cfg.nb_policy, np.float32)
-        net.predict(np.ascontiguousarray(x.numpy()), v, p)
-        net.close()
-        outs.append((v, p))
-    assert "info string HipAPI: Precision int8 is not available" in capfd.readouterr().err
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

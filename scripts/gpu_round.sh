@@ -21,7 +21,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-HEADLINE=${HEADLINE:-float16p8}
+HEADLINE=${HEADLINE:-float16x3}
 python __graft_entry__.py > $OUT/build.log 2>&1 || tail -5 $OUT/build.log
 
 pmc_run() { prec=$1; name=$2; shift; shift; (cd /tmp && timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python $REPO/scripts/prof_forward.py 19 256 $prec 3 > $OUT/$name.log 2>&1); }
@@ -55,12 +55,12 @@ run_set() {
       pmc_run $prec ${prec}_tcc2 WRITE_SIZE TCC_MISS_sum
       pmc_run $prec ${prec}_grbm GRBM_GUI_ACTIVE
       for p in sq1 sq2 tcc1 tcc2 grbm; do python scripts/pmc_summary.py $OUT/${prec}_$p > $OUT/pmc_${prec}_$p.txt 2>&1; rm -rf $OUT/${prec}_$p; done
-      grep -h -A12 "tower_p8" $OUT/pmc_${prec}_sq2.txt | head -14 ;;
+      grep -h -A12 "tower_" $OUT/pmc_${prec}_sq2.txt | head -14 ;;
     lds)
       prec=$HEADLINE
       pmc_run $prec ${prec}_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_WAVES
       python scripts/pmc_summary.py $OUT/${prec}_sq2 > $OUT/pmc_${prec}_sq2.txt 2>&1; rm -rf $OUT/${prec}_sq2
-      grep -h -A12 "tower_p8" $OUT/pmc_${prec}_sq2.txt | head -14 ;;
+      grep -h -A12 "tower_" $OUT/pmc_${prec}_sq2.txt | head -14 ;;
     icache)
       prec=$HEADLINE
       pmc_run $prec ${prec}_ic1 SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE

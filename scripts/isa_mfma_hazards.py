@@ -21,13 +21,21 @@ def regs(tok):
 
 def scan(lines, name):
     pending = {}          # register -> (wait states still required, mfma line no)
+    branch_state = {}     # label -> the pending state the branches to it carry (worst case)
     in_asm = False
     hits = 0
     for no, raw in lines:
         ln = raw.split(";")[0].strip() if not raw.strip().startswith(";") else raw.strip()
         if ln.startswith((";APP", ";;#ASMSTART")): in_asm = True; continue
         if ln.startswith((";NO_APP", ";;#ASMEND")): in_asm = False; continue
-        if not ln or ln.startswith((".", ";")) or ln.endswith(":"): continue
+        if ln.endswith(":") and not ln.startswith(";"):
+            # a label: besides what falls through from the line above, the block is entered by the branches that name it.  Their state
+            # is the one recorded at the conditional branch (taken-branch latency not modelled: a few cycles in the code's favour, never
+            # against it) -- kept per target label; an unknown entry (a backward branch further down) adds nothing, as before
+            for r, v in branch_state.get(ln[:-1], {}).items():
+                if r not in pending or pending[r][0] < v[0]: pending[r] = v
+            continue
+        if not ln or ln.startswith((".", ";")): continue
         op = ln.split()[0]
         args = ln[len(op):]
         parts = [a.strip() for a in args.split(",")]
@@ -52,6 +60,12 @@ def scan(lines, name):
                     hits += 1
                     break
             for r in touched: pending.pop(r, None) if op.startswith("v_") and r in regs(parts[0]) else None
+        if op.startswith("s_cbranch") or op == "s_branch":
+            tgt = parts[0].strip() if parts else ""
+            if tgt:                                   # what a taken branch carries to its target (worst case over the branches seen so far);
+                st = branch_state.setdefault(tgt, {})  # the branch occupies an issue slot itself
+                for r, v in pending.items():
+                    if v[0] - 1 > 0 and (r not in st or st[r][0] < v[0] - 1): st[r] = (v[0] - 1, v[1])
         if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
             # nothing falls through an unconditional jump: what the listing prints next is another path's code, reached by a branch of
             # its own (whose taken-branch latency is not modelled: conditional branches keep the linear order, which only SHORTENS

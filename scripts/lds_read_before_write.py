@@ -24,7 +24,7 @@ def poison_lib():
     out = os.path.join(ROOT, "tests", "support", "_build", "liblds_poison.so")
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", src, "-o", out], check=True, cwd="/tmp")
+        subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O2", *build.device_flags(), "-shared", "-fPIC", src, "-o", out], check=True, cwd="/tmp")
     lib = ctypes.CDLL(out)
     lib.poison_lds.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
     return lib

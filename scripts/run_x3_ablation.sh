@@ -2,18 +2,20 @@
 # Development: builds scripts/ubench/x3_tower_ablate.hip once per CRA_X3_ABL switch and runs the set on this box's GPU, for the
 # symmetric kernel (CRA_X3_TOWER=symmetric) and the two-role kernel (default).
 # usage (repo root): bash scripts/run_x3_ablation.sh [out file]
+# every device compile takes the library's flags (no packed f32 arithmetic: crazyara_amd/build.py)
+FLAGS=$(cd "$(dirname "$0")/.." && python3 -c 'from crazyara_amd import build; print(*build.device_flags())')
 OUT=${1:-/dev/stdout}
 REPO=$(pwd)
 mkdir -p /tmp/x3abl
 ABLS="0 1 2 4 6 8 16 32 7 15 31 127"
 pids=()
 for abl in $ABLS; do
-  hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCRA_DEVELOPMENT -DCRA_X3_ABL=$abl -I$REPO/crazyara_amd/csrc/nn \
+  hipcc -O3 -std=c++17 --offload-arch=gfx950 $FLAGS -DCRA_DEVELOPMENT -DCRA_X3_ABL=$abl -I$REPO/crazyara_amd/csrc/nn \
     $REPO/scripts/ubench/x3_tower_ablate.hip -o /tmp/x3abl/abl_$abl 2> /tmp/x3abl/build_$abl.log &
   pids+=($!)
 done
 for v in EW=4 PW=4 "EW=4 -DCRA_X3_PW=4"; do
-  hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCRA_DEVELOPMENT -DCRA_X3_ABL=0 -DCRA_X3_$v -I$REPO/crazyara_amd/csrc/nn \
+  hipcc -O3 -std=c++17 --offload-arch=gfx950 $FLAGS -DCRA_DEVELOPMENT -DCRA_X3_ABL=0 -DCRA_X3_$v -I$REPO/crazyara_amd/csrc/nn \
     $REPO/scripts/ubench/x3_tower_ablate.hip -o "/tmp/x3abl/var_${v// /_}" 2> "/tmp/x3abl/build_var_${v// /_}.log" &
   pids+=($!)
 done

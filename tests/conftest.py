@@ -35,7 +35,7 @@ def lds_poison():
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         from crazyara_amd import build
-        subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", src, "-o", out], check=True, cwd="/tmp")
+        subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O2", *build.device_flags(), "-shared", "-fPIC", src, "-o", out], check=True, cwd="/tmp")
     lib = ctypes.CDLL(out)
     lib.poison_lds.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int]
     lib.poison_lds.restype = ctypes.c_int

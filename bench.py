@@ -1038,7 +1038,7 @@ def main():
         # users on two nets (two SearchThreads, crazyara.cpp:548-563) show what the engine gets with its default Threads = 2. ----
         import threading
         from crazyara_amd.neuralnetapi import NeuralNetAPIUser
-        it = max(60, args.steps // 2)
+        it = max(400, args.steps)          # >= 0.25 s per leg: 150 iterations (0.1 s) made the legs swing by 10 % between runs (round 6)
 
         def pcie_rate(nets_):
             users = [NeuralNetAPIUser([n_]) for n_ in nets_]

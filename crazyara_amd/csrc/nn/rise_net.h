@@ -138,6 +138,7 @@ private:
         int x3_split_dev = 0;           // CRA_X3_SPLIT_DEV: timing switches of block_x3_split_kernel (x3.hip; bits 2 and 4 give wrong results)
         int x3_split_max_g = 0;         // CRA_X3_SPLIT_MAX_G: upper bound on the workgroups per board of the split-board blocks
         int x3_split_max_batch = 0;     // CRA_X3_SPLIT_MAX_BATCH: the largest batch that runs split-board (default kBoardSplitMaxBatch)
+        bool no_small_path = false;     // CRA_NO_SMALL_PATH: partial batches run the whole batch's forward as before round 6 (A/B)
         DevSwitches();
     } dev_;
     float* value_head_dbg_ = nullptr;
@@ -160,6 +161,16 @@ private:
     // one-workgroup-per-board tower (A/B, and the parity tests of the tower kernels on the small fixtures).
     bool board_split_ = true;
     static constexpr int kBoardSplitMaxBatch = 64;
+    // A net made for MORE boards still meets small batches: the root of a `go` (one board), the first batches of a single tree, the tail of
+    // a game loop.  submit_boards / submit_boards_gathered with at most kBoardSplitMaxBatch valid boards go to a companion net of that batch
+    // size (same model and precision, made on first use) whose launches take the number of boards of THIS call -- a forward of n boards
+    // instead of one of the whole batch (0.33 ms instead of 0.70 for one board of RISEv2-19).  float16x3 / float16p8 only.
+    std::unique_ptr<RiseNet> small_;
+    bool last_on_small_ = false;      // the submit in flight went to small_: wait() waits for ITS stream
+    std::string precision_arg_;       // what the constructor was given (the companion is made with the same)
+    int dyn_n_ = 0, dyn_prev_g_ = 1;  // > 0 while a forward of dyn_n_ boards is being enqueued (launch_op)
+    bool small_path_ok() const;
+    RiseNet& small_net();
     bool one_launch_ = true;     // stem + tower + head in one launch when the net is exactly that chain ("-3k": three launches)
     bool rt_thin_waves_ = false; // dense residual tower: 8 waves x 32 couts ("-8w") instead of 4 x 64
     int boards_per_wg_ = 0;      // dense residual tower: 0 = by batch size (2 from 512 boards), 1 / 2 = forced ("-1b" / "-2b")

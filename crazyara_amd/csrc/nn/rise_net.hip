@@ -286,11 +286,13 @@ RiseNet::DevSwitches::DevSwitches() {
     if (const char* e = getenv("CRA_X3_SPLIT_DEV")) x3_split_dev = atoi(e);
     if (const char* e = getenv("CRA_X3_SPLIT_MAX_G")) x3_split_max_g = atoi(e);
     if (const char* e = getenv("CRA_X3_SPLIT_MAX_BATCH")) x3_split_max_batch = atoi(e);
+    no_small_path = getenv("CRA_NO_SMALL_PATH") != nullptr;
 }
 
 RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, const std::string& precision)
     : device_(device_id), impl_(new Impl) {
     if (batch_size <= 0) throw std::invalid_argument("batch size must be positive");
+    precision_arg_ = precision;
     std::string prec = precision;
     // "-3k": stem, tower and head as three launches instead of one (forward.hip); per-kernel timing and A/B reference
     if (prec.size() > 3 && prec.compare(prec.size() - 3, 3, "-3k") == 0) {
@@ -1503,8 +1505,12 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
 
 template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOverride* io) {
     Impl& im = *impl_;
-    const int B = design_.batch;
+    const int B = dyn_n_ > 0 ? dyn_n_ : design_.batch;       // (a forward of fewer boards than the net was made for: small_net())
     const Op& op = im.ops[i];
+    auto boards = [&](ConvArgs c) {                            // a board-batched conv of such a forward
+        if (dyn_n_ > 0 && c.batch == design_.batch && !c.out_rows_f32) c.batch = dyn_n_;
+        return c;
+    };
     // io: the caller's pinned host buffers stand in for the device-side input / output tensors of this forward (zero-copy predict)
     const float* planes = io ? io->planes : d_planes_;
     float* value = io ? io->value : d_value_;
@@ -1516,21 +1522,21 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             break;
         case OpKind::Conv:
             if (x3_ && dev_.conv_dev >= 0) {                                // development: bisecting switches of conv_gemm_x3_kernel
-                ConvArgs c = op.conv;
+                ConvArgs c = boards(op.conv);
                 c.dev = dev_.conv_dev;
                 if (op.from_planes) c.planes = planes;
                 if (op.fused_softmax) { c.softmax_out = probs; if (!keep_logits_) c.out = nullptr; }
                 launch_conv_gemm_x3(c, s);
             } else if (x3_ && op.from_planes) {
-                ConvArgs c = op.conv;
+                ConvArgs c = boards(op.conv);
                 c.planes = planes;
                 launch_conv_gemm_x3(c, s);
             } else if (x3_ && op.fused_softmax) {
-                ConvArgs c = op.conv;
+                ConvArgs c = boards(op.conv);
                 c.softmax_out = probs;
                 if (!keep_logits_) c.out = nullptr;          // (the logits stay in LDS unless a test / analysis asked for them)
                 launch_conv_gemm_x3(c, s);
-            } else if (x3_) launch_conv_gemm_x3(op.conv, s);
+            } else if (x3_) launch_conv_gemm_x3(boards(op.conv), s);
             else launch_conv_gemm<T>(op.conv, s);
             break;
         case OpKind::Depthwise:
@@ -1541,6 +1547,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             ValueHeadArgs v = op.vh;
             v.value = value;
             v.aux = aux;
+            if (dyn_n_ > 0) v.batch = dyn_n_;
             launch_value_head<T>(v, s);
             break;
         }
@@ -1567,9 +1574,25 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             break;
         }
         case OpKind::ResTower: launch_restower(op.rt, s); break;
-        case OpKind::TowerX3: launch_tower_x3(op.tx, s); break;
-        case OpKind::BlockX3Split: launch_block_x3_split(op.xs, s); break;
-        case OpKind::X3SplitFinish: launch_x3_split_finish(op.xs.x_parts, op.xs.gin, op.xs_y, op.xs.batch, s); break;
+        case OpKind::TowerX3:
+            if (dyn_n_ > 0) {
+                X3TowerArgs t = op.tx;
+                t.batch = dyn_n_;
+                launch_tower_x3(t, s);
+            } else launch_tower_x3(op.tx, s);
+            break;
+        case OpKind::BlockX3Split:
+            if (dyn_n_ > 0) {                                    // the workgroups per board follow the boards of THIS forward; a launch reads
+                X3SplitArgs a = op.xs;                           // as many images per board as the launch before it wrote
+                a.batch = dyn_n_;
+                a.G = std::max(1, std::min(std::min(10, cu_count_ / dyn_n_), a.blk.cop_pad / block_x3_chunk_channels()));
+                if (dev_.x3_split_max_g > 0) a.G = std::min(a.G, dev_.x3_split_max_g);
+                a.gin = (i == 0 || im.ops[i - 1].kind != OpKind::BlockX3Split) ? 1 : dyn_prev_g_;      // (a run's first block reads the float stream)
+                dyn_prev_g_ = a.G;
+                launch_block_x3_split(a, s);
+            } else launch_block_x3_split(op.xs, s);
+            break;
+        case OpKind::X3SplitFinish: launch_x3_split_finish(op.xs.x_parts, dyn_n_ > 0 ? dyn_prev_g_ : op.xs.gin, op.xs_y, B, s); break;
         case OpKind::Stem: {
             StemArgs st = op.st;
             st.planes = planes;
@@ -1596,6 +1619,7 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
 template <typename T> void RiseNet::enqueue(hipStream_t s, const IoOverride* io) {
     // (Round 6 tried the value head of a small batch on a side stream beside the policy head -- two branches of the captured graph: the
     // forward got SLOWER, 0.354 against 0.335 ms at batch 1, the cross-queue joins cost more than the 24 us they hide: profiles/r06/e_*.)
+    dyn_prev_g_ = 1;
     for (int i = 0; i < int(impl_->ops.size()); ++i) launch_op<T>(i, s, io);
     HIP_CHECK(hipGetLastError());
 }
@@ -1914,7 +1938,7 @@ void RiseNet::forward_async() {
 // searched at 373k nodes/s against 370k through the graph on an idle host, profiles/r04/ac_*).
 void RiseNet::launch_forward_in_stream() {
     Turn turn(*this);
-    if ((launches_ <= 5 && !dev_.lane_graph) || dev_.lane_no_graph) forward_on(stream_);
+    if (dyn_n_ > 0 || (launches_ <= 5 && !dev_.lane_graph) || dev_.lane_no_graph) forward_on(stream_);      // (a forward of fewer boards: its own arguments)
     else HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
 }
 
@@ -1970,6 +1994,15 @@ void RiseNet::submit(const float* in_planes, float* value, float* probs, float* 
     if (d_aux_ && aux) HIP_CHECK(hipMemcpyAsync(aux, d_aux_, B * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
 }
 
+// a float16x3 / float16p8 net made for more than kBoardSplitMaxBatch boards, asked for at most that many: the companion net's business
+bool RiseNet::small_path_ok() const {
+    return !dev_.no_small_path && x3_ && tower_ && fused_ && board_split_ && design_.batch > kBoardSplitMaxBatch;
+}
+RiseNet& RiseNet::small_net() {
+    if (!small_) small_.reset(new RiseNet(model_file_path_, device_, kBoardSplitMaxBatch, precision_arg_));
+    return *small_;
+}
+
 void RiseNet::submit_boards(const void* descs_host, int n_valid, int layout, float* value, float* probs, float* aux) {
     HIP_CHECK(hipSetDevice(device_));
     const size_t B = design_.batch;
@@ -1977,14 +2010,24 @@ void RiseNet::submit_boards(const void* descs_host, int n_valid, int layout, flo
     if (layout_channels(layout) != design_.nb_input_channels)
         throw std::invalid_argument("plane layout has " + std::to_string(layout_channels(layout)) + " channels, net expects " +
                                     std::to_string(design_.nb_input_channels));
+    if (n_valid > 0 && n_valid <= kBoardSplitMaxBatch && small_path_ok()) {
+        small_net().submit_boards(descs_host, n_valid, layout, value, probs, aux);
+        last_on_small_ = true;
+        return;
+    }
+    // (this net as the companion of a larger one: a forward of n_valid boards, and only their results go back)
+    const bool partial = n_valid > 0 && x3_ && board_split_ && design_.batch <= kBoardSplitMaxBatch && size_t(n_valid) < B && !dev_.no_small_path;
+    const size_t rows = partial ? size_t(n_valid) : B;
     if (n_valid > 0) {
         HIP_CHECK(hipMemcpyAsync(d_desc_, descs_host, size_t(n_valid) * sizeof(BoardDesc), hipMemcpyHostToDevice, stream_));
         launch_planes_from_desc(static_cast<const BoardDesc*>(d_desc_), n_valid, layout, 1, d_planes_, stream_);
     }
+    dyn_n_ = partial ? n_valid : 0;
     launch_forward_in_stream();
-    HIP_CHECK(hipMemcpyAsync(value, d_value_, B * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipMemcpyAsync(probs, d_probs_, B * design_.nb_policy * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (d_aux_ && aux) HIP_CHECK(hipMemcpyAsync(aux, d_aux_, B * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    dyn_n_ = 0;
+    HIP_CHECK(hipMemcpyAsync(value, d_value_, rows * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(probs, d_probs_, rows * design_.nb_policy * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (d_aux_ && aux) HIP_CHECK(hipMemcpyAsync(aux, d_aux_, rows * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
 }
 
 void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int layout, const uint16_t* idx, const uint32_t* cnt, uint32_t stride,
@@ -1996,6 +2039,11 @@ void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int la
     if (layout_channels(layout) != design_.nb_input_channels)
         throw std::invalid_argument("plane layout has " + std::to_string(layout_channels(layout)) + " channels, net expects " +
                                     std::to_string(design_.nb_input_channels));
+    if (n_valid > 0 && n_valid <= kBoardSplitMaxBatch && small_path_ok()) {          // few boards on a net made for many: the companion net
+        small_net().submit_boards_gathered(descs_host, n_valid, layout, idx, cnt, stride, value, gathered, aux);
+        last_on_small_ = true;
+        return;
+    }
     // No copy commands at all: the descriptors and the gather lists are read by the kernels straight from the caller's pinned
     // (device-visible, coherent) buffers, and the gather kernel writes values, gathered priors and aux straight into them.  A batch
     // moves ~50 KB in and ~170 KB out, so PCIe bandwidth is irrelevant; what a copy costs is the hand-over between the DMA engine
@@ -2039,7 +2087,10 @@ void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int la
         return;
     }
     if (n_valid > 0) launch_planes_from_desc(static_cast<const BoardDesc*>(descs_host), n_valid, layout, 1, d_planes_, stream_);
+    // (this net as the companion of a larger one, or any small-batch net with fewer valid boards than its batch: a forward of n_valid boards)
+    dyn_n_ = (n_valid > 0 && x3_ && board_split_ && design_.batch <= kBoardSplitMaxBatch && size_t(n_valid) < B && !dev_.no_small_path) ? n_valid : 0;
     launch_forward_in_stream();
+    dyn_n_ = 0;
     if (dev_.lane_sync) HIP_CHECK(hipStreamSynchronize(stream_));     // development: bisecting the lane step's ordering
     launch_gather_probs(d_probs_, design_.nb_policy, idx, cnt, int(stride), n_valid, gathered, d_value_, value, int(B),
                         (d_aux_ && aux) ? d_aux_ : nullptr, aux, stream_);
@@ -2055,6 +2106,11 @@ void RiseNet::wait() {
             }
         }
     } done{*this};
+    if (last_on_small_) {                                               // the submit in flight went to the companion net
+        last_on_small_ = false;
+        small_->wait();
+        return;
+    }
     // CRA_WAIT_POLL=1 polls hipStreamQuery instead (development: on the hosts measured so far the runtime's own wait was not the
     // source of the per-batch latency; both give the same pipeline rate)
     static const bool poll = getenv("CRA_WAIT_POLL") != nullptr;

@@ -184,3 +184,58 @@ def test_one_tree_many_collectors_on_the_gpu(tmp_path, hip_lib):
         pool.close()
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("precision", ["float16x3", "float16p8"])
+def test_few_boards_on_a_net_made_for_many_take_the_small_forward(tmp_path, hip_lib, precision, monkeypatch):
+    """Round 6: a float16x3 / float16p8 net made for 256 boards that is handed n <= 64 (the root of a `go`, the first batches of one tree)
+    runs a forward of n boards on its companion net (the split-board launches with the boards of THIS call) instead of the whole batch's
+    tower: the same numbers within float16x3's bounds whatever n, bit-identical from call to call, and faster; CRA_NO_SMALL_PATH=1 is the old
+    behaviour (the A/B and the reference for the numbers)."""
+    import ctypes as C
+    import time
+    from crazyara_amd import _capi, env, openings
+    from crazyara_amd.neuralnetapi import HipAPI
+    from oracle import rise_oracle as ro
+    cfg, sd, _ = nn_cases.make_case("risev2-7")
+    d = nn_cases.export_case(tmp_path, "risev2-7", cfg, sd)
+    lib = _capi.load()
+    B = 256
+    fens = openings.position_fens("crazyhouse")[:B]
+    pos = [env.Position(f, False, "crazyhouse") for f in fens]
+    descs = b"".join(p.desc() for p in pos)
+    planes = torch.from_numpy(np.stack([p.planes(0, 1, True) for p in pos]).astype(np.float32))
+    o_value, o_logits, _ = ro.forward(cfg, sd, planes)
+    o_probs = torch.softmax(o_logits, 1).numpy()
+    layout = lib.mi_planes_layout(0, 1)
+    dbuf = lib.mi_host_alloc(len(descs)); C.memmove(dbuf, descs, len(descs))
+    v = lib.mi_host_alloc(4 * B); p = lib.mi_host_alloc(4 * B * cfg.nb_policy)
+    va = np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_float)), shape=(B,))
+    pa = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(B, cfg.nb_policy))
+    tol = 1e-4 if precision == "float16x3" else 3e-4
+    times = {}
+    for small in (True, False):
+        if small:
+            monkeypatch.delenv("CRA_NO_SMALL_PATH", raising=False)
+        else:
+            monkeypatch.setenv("CRA_NO_SMALL_PATH", "1")
+        net = HipAPI(0, B, d, precision)
+        for n in (1, 5, 33, 64, 65, 256):
+            outs = []
+            for rep in range(3):
+                va[:] = 7.0; pa[:] = 7.0
+                t0 = time.perf_counter()
+                assert lib.mi_net_submit_boards(net._h, dbuf, n, layout, v, p, None) == 0
+                net.wait()
+                dt = time.perf_counter() - t0
+                outs.append((va[:n].copy(), pa[:n].copy()))
+                if rep == 2:
+                    times[(small, n)] = dt
+            assert np.abs(outs[0][0] - o_value.numpy().reshape(-1)[:n]).max() < tol
+            assert np.abs(outs[0][1] - o_probs[:n]).max() < 1e-5
+            for a, b_ in outs[1:]:
+                assert np.array_equal(a, outs[0][0]) and np.array_equal(b_, outs[0][1])
+        net.close()
+    print("seconds per call (small path, old path):", {n: (round(times[(True, n)] * 1e3, 3), round(times[(False, n)] * 1e3, 3)) for n in (1, 5, 33, 64, 65, 256)})
+    assert times[(True, 1)] < 0.9 * times[(False, 1)]
+    lib.mi_host_free(dbuf); lib.mi_host_free(v); lib.mi_host_free(p)

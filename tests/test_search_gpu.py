@@ -201,7 +201,8 @@ def test_few_boards_on_a_net_made_for_many_take_the_small_forward(tmp_path, hip_
     d = nn_cases.export_case(tmp_path, "risev2-7", cfg, sd)
     lib = _capi.load()
     B = 256
-    fens = openings.position_fens("crazyhouse")[:B]
+    fens = openings.position_fens("crazyhouse")
+    fens = [fens[i % len(fens)] for i in range(B)]
     pos = [env.Position(f, False, "crazyhouse") for f in fens]
     descs = b"".join(p.desc() for p in pos)
     planes = torch.from_numpy(np.stack([p.planes(0, 1, True) for p in pos]).astype(np.float32))
@@ -225,7 +226,7 @@ def test_few_boards_on_a_net_made_for_many_take_the_small_forward(tmp_path, hip_
             for rep in range(3):
                 va[:] = 7.0; pa[:] = 7.0
                 t0 = time.perf_counter()
-                assert lib.mi_net_submit_boards(net._h, dbuf, n, layout, v, p, None) == 0
+                assert lib.mi_net_submit_boards(net._h, dbuf, n, layout, v, p, None) == 0, _capi.last_error()
                 net.wait()
                 dt = time.perf_counter() - t0
                 outs.append((va[:n].copy(), pa[:n].copy()))

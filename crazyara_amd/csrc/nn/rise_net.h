@@ -123,6 +123,7 @@ private:
     bool buffers_are_pinned(const float* in_planes, float* value, float* probs, float* aux);
     bool last_zero_copy_ = false;
     bool counted_in_flight_ = false;   // this net's predict is counted in the device's predicts-in-flight (submit ... wait)
+    int staged_calls_left_ = 0;        // predict on pinned buffers: calls that still take the staged form after another user was met in flight
     // Development switches: read from the environment ONCE, when the net is constructed -- never on the per-batch path,
     // where several lane threads would otherwise scan `environ` per kernel launch beside a host program that may call setenv.
     struct DevSwitches {

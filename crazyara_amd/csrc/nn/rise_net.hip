@@ -387,6 +387,11 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     }
     if (fp16_) build<half_t>(nf); else build<float>(nf);   // init_nn_design + load_parameters + buffers
     capture();                                   // bind_executor
+    // the companion net for calls with few boards (rise_net.h: small_) is made HERE, on the thread that makes this net: made on first use it
+    // was made by whichever SearchThread came first, and two of them making nets at once -- one capturing its graph, one uploading weights
+    // through the legacy stream -- is an error of the runtime ("would make the legacy stream depend on a capturing blocking stream")
+    if (!dev_.no_small_path && x3_ && tower_ && fused_ && board_split_ && design_.batch > kBoardSplitMaxBatch)
+        small_.reset(new RiseNet(model_file_path_, device_id, kBoardSplitMaxBatch, precision_arg_));
 }
 
 static void turns_forget_stream(int device, hipStream_t s);     // below, next to RiseNet::Turn
@@ -1975,7 +1980,11 @@ void RiseNet::submit(const float* in_planes, float* value, float* probs, float* 
         g_predicts_in_flight[device_].fetch_add(1, std::memory_order_relaxed);
         counted_in_flight_ = true;
     }
-    last_zero_copy_ = buffers_are_pinned(in_planes, value, probs, aux) && (dev_.predict_zero_copy || !others_in_flight);
+    // with hysteresis: a user that has met another one in flight stays on the staged form for its next 64 calls (two blocking users drift in
+    // and out of phase: one of them would otherwise find the device "empty" at every other call and alternate between the forms)
+    if (others_in_flight) staged_calls_left_ = 64;
+    else if (staged_calls_left_ > 0) --staged_calls_left_;
+    last_zero_copy_ = buffers_are_pinned(in_planes, value, probs, aux) && (dev_.predict_zero_copy || staged_calls_left_ == 0);
     if (last_zero_copy_) {
         IoOverride io;
         io.planes = in_planes;
@@ -1996,12 +2005,9 @@ void RiseNet::submit(const float* in_planes, float* value, float* probs, float* 
 
 // a float16x3 / float16p8 net made for more than kBoardSplitMaxBatch boards, asked for at most that many: the companion net's business
 bool RiseNet::small_path_ok() const {
-    return !dev_.no_small_path && x3_ && tower_ && fused_ && board_split_ && design_.batch > kBoardSplitMaxBatch;
+    return small_ != nullptr;
 }
-RiseNet& RiseNet::small_net() {
-    if (!small_) small_.reset(new RiseNet(model_file_path_, device_, kBoardSplitMaxBatch, precision_arg_));
-    return *small_;
-}
+RiseNet& RiseNet::small_net() { return *small_; }
 
 void RiseNet::submit_boards(const void* descs_host, int n_valid, int layout, float* value, float* probs, float* aux) {
     HIP_CHECK(hipSetDevice(device_));

@@ -166,8 +166,8 @@ private:
     // a game loop.  submit_boards / submit_boards_gathered with at most kBoardSplitMaxBatch valid boards go to a companion net of that batch
     // size (same model and precision, made on first use) whose launches take the number of boards of THIS call -- a forward of n boards
     // instead of one of the whole batch (0.33 ms instead of 0.70 for one board of RISEv2-19).  float16x3 / float16p8 only.
-    std::unique_ptr<RiseNet> small_;
-    bool last_on_small_ = false;      // the submit in flight went to small_: wait() waits for ITS stream
+    std::unique_ptr<RiseNet> small_;  // works in this net's stream (owns_stream_ = false there)
+    bool owns_stream_ = true;
     std::string precision_arg_;       // what the constructor was given (the companion is made with the same)
     int dyn_n_ = 0, dyn_prev_g_ = 1;  // > 0 while a forward of dyn_n_ boards is being enqueued (launch_op)
     bool small_path_ok() const;

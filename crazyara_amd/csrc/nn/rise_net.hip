@@ -289,6 +289,8 @@ RiseNet::DevSwitches::DevSwitches() {
     no_small_path = getenv("CRA_NO_SMALL_PATH") != nullptr;
 }
 
+static thread_local hipStream_t g_companion_stream = nullptr;   // set by a constructor for the constructor of its companion net (same thread, next statement)
+
 RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, const std::string& precision)
     : device_(device_id), impl_(new Impl) {
     if (batch_size <= 0) throw std::invalid_argument("batch size must be positive");
@@ -378,7 +380,11 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     if (model_file_path_.size() > 5 && model_file_path_.compare(model_file_path_.size() - 5, 5, ".onnx") == 0) import_onnx(model_file_path_, nf);
     else nf.load(model_file_path_);
     if (nf.str("arch") != "rise") throw std::runtime_error("unsupported arch '" + nf.str("arch") + "' in " + model_file_path_);
-    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    if (g_companion_stream) {                    // the companion net of a larger one works in ITS stream (never at the same time: a call goes to one of them)
+        stream_ = g_companion_stream;
+        owns_stream_ = false;
+        g_companion_stream = nullptr;
+    } else HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     if (int8_) {
         int8_calib_ = read_int8_calibration(model_file_path_);
         if (int8_calib_.empty())
@@ -390,8 +396,12 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     // the companion net for calls with few boards (rise_net.h: small_) is made HERE, on the thread that makes this net: made on first use it
     // was made by whichever SearchThread came first, and two of them making nets at once -- one capturing its graph, one uploading weights
     // through the legacy stream -- is an error of the runtime ("would make the legacy stream depend on a capturing blocking stream")
-    if (!dev_.no_small_path && x3_ && tower_ && fused_ && board_split_ && design_.batch > kBoardSplitMaxBatch)
+    // It shares this net's stream: a stream of its own shifted which hardware queue every later stream of the process got, and two lanes
+    // of a later search landed on ONE queue (config 1 with two lanes: 35k nodes/s instead of 63k, profiles/r06/t_*).
+    if (!dev_.no_small_path && x3_ && tower_ && fused_ && board_split_ && design_.batch > kBoardSplitMaxBatch) {
+        g_companion_stream = stream_;
         small_.reset(new RiseNet(model_file_path_, device_id, kBoardSplitMaxBatch, precision_arg_));
+    }
 }
 
 static void turns_forget_stream(int device, hipStream_t s);     // below, next to RiseNet::Turn
@@ -403,14 +413,15 @@ std::atomic<int> g_predicts_in_flight[64];
 RiseNet::~RiseNet() {
     if (counted_in_flight_) g_predicts_in_flight[device_].fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(device_);
+    small_.reset();                              // (it works in this net's stream)
     if (stream_) {
         (void)hipStreamSynchronize(stream_);
-        turns_forget_stream(device_, stream_);
+        if (owns_stream_) turns_forget_stream(device_, stream_);
     }
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
     if (graph_) (void)hipGraphDestroy(graph_);
     impl_.reset();
-    if (stream_) (void)hipStreamDestroy(stream_);
+    if (stream_ && owns_stream_) (void)hipStreamDestroy(stream_);
 }
 
 template <typename T> void RiseNet::build(const NetFile& nf) {
@@ -2017,8 +2028,7 @@ void RiseNet::submit_boards(const void* descs_host, int n_valid, int layout, flo
         throw std::invalid_argument("plane layout has " + std::to_string(layout_channels(layout)) + " channels, net expects " +
                                     std::to_string(design_.nb_input_channels));
     if (n_valid > 0 && n_valid <= kBoardSplitMaxBatch && small_path_ok()) {
-        small_net().submit_boards(descs_host, n_valid, layout, value, probs, aux);
-        last_on_small_ = true;
+        small_net().submit_boards(descs_host, n_valid, layout, value, probs, aux);      // (into this net's stream: wait() as ever)
         return;
     }
     // (this net as the companion of a larger one: a forward of n_valid boards, and only their results go back)
@@ -2047,7 +2057,6 @@ void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int la
                                     std::to_string(design_.nb_input_channels));
     if (n_valid > 0 && n_valid <= kBoardSplitMaxBatch && small_path_ok()) {          // few boards on a net made for many: the companion net
         small_net().submit_boards_gathered(descs_host, n_valid, layout, idx, cnt, stride, value, gathered, aux);
-        last_on_small_ = true;
         return;
     }
     // No copy commands at all: the descriptors and the gather lists are read by the kernels straight from the caller's pinned
@@ -2112,11 +2121,6 @@ void RiseNet::wait() {
             }
         }
     } done{*this};
-    if (last_on_small_) {                                               // the submit in flight went to the companion net
-        last_on_small_ = false;
-        small_->wait();
-        return;
-    }
     // CRA_WAIT_POLL=1 polls hipStreamQuery instead (development: on the hosts measured so far the runtime's own wait was not the
     // source of the per-batch latency; both give the same pipeline rate)
     static const bool poll = getenv("CRA_WAIT_POLL") != nullptr;

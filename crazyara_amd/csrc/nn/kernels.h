@@ -331,7 +331,17 @@ struct ValueHeadArgs {
                             // back from LDS, checksums of the loaded words, HW_ID per wave), 32 = FC1 as plain fmaf (v_pk_fma_f32 in a build with packed f32 ops) instead of the v_fmac_f32 asm
 };
 template <typename T> void prepare_value_head(const ValueHeadArgs& a);   // once per net: LDS allowance of the kernel
+size_t value_head_lds_bytes(const ValueHeadArgs& a);
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s);
+
+// Small batches (nets made for at most 64 boards, Precision float16x3 / float16p8): the second policy conv with its softmax and the value
+// head as the two roles of ONE launch, side by side (x3.hip: heads_small_kernel)
+struct HeadsSmallArgs {
+    ConvArgs conv;
+    ValueHeadArgs vh;
+};
+bool heads_small_fits(const ConvArgs& c, const ValueHeadArgs& v);
+void launch_heads_small(const HeadsSmallArgs& a, hipStream_t s);
 
 // last stage of the value head, one wave per board.
 //  tanh head : value = tanh(b2 + dot(w2, h[b]))            h: [B][fc] T (FC1 + ReLU output of the conv_gemm "FC" launch)

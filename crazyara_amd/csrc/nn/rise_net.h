@@ -140,6 +140,8 @@ private:
         int x3_split_max_g = 0;         // CRA_X3_SPLIT_MAX_G: upper bound on the workgroups per board of the split-board blocks
         int x3_split_max_batch = 0;     // CRA_X3_SPLIT_MAX_BATCH: the largest batch that runs split-board (default kBoardSplitMaxBatch)
         bool no_small_path = false;     // CRA_NO_SMALL_PATH: partial batches run the whole batch's forward as before round 6 (A/B)
+        int small_conv_split = 2;       // CRA_SMALL_BATCH_CONV_SPLIT: the wide convs of a small-batch net as 1 = two workgroups of 128 couts per board, 2 = four of 64
+        bool own_stream = false;        // CRA_OWN_STREAM_PER_NET: a stream created (and destroyed) per net, as before the streams of the library (A/B)
         DevSwitches();
     } dev_;
     float* value_head_dbg_ = nullptr;
@@ -167,7 +169,9 @@ private:
     // size (same model and precision, made on first use) whose launches take the number of boards of THIS call -- a forward of n boards
     // instead of one of the whole batch (0.33 ms instead of 0.70 for one board of RISEv2-19).  float16x3 / float16p8 only.
     std::unique_ptr<RiseNet> small_;  // works in this net's stream (owns_stream_ = false there)
-    bool owns_stream_ = true;
+    bool owns_stream_ = true;         // this net took stream_ itself (from the library's set, or created it: stream_slot_ < 0)
+    int stream_slot_ = -1;            // which stream of the library's per-device set this net works in (rise_net.hip: NetStreams)
+    void touch_stream() const;        // this net is submitting work: its stream was used NOW (what the choice for the next new net looks at)
     std::string precision_arg_;       // what the constructor was given (the companion is made with the same)
     int dyn_n_ = 0, dyn_prev_g_ = 1;  // > 0 while a forward of dyn_n_ boards is being enqueued (launch_op)
     bool small_path_ok() const;

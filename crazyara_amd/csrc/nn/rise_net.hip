@@ -209,7 +209,7 @@ std::vector<float> pack_x3_depthwise_records5(const Folded& bn1, const Folded& d
     return rec;
 }
 
-enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower, Forward, TowerX3, BlockX3Split, X3SplitFinish };
+enum class OpKind { PlanesToAct, Conv, Depthwise, SE, ValueHead, Softmax, Block, ValueFinal, SEGate, Tower, Head, Stem, ResTower, Forward, TowerX3, BlockX3Split, X3SplitFinish, HeadsSmall };
 
 struct Op {
     OpKind kind;
@@ -287,9 +287,55 @@ RiseNet::DevSwitches::DevSwitches() {
     if (const char* e = getenv("CRA_X3_SPLIT_MAX_G")) x3_split_max_g = atoi(e);
     if (const char* e = getenv("CRA_X3_SPLIT_MAX_BATCH")) x3_split_max_batch = atoi(e);
     no_small_path = getenv("CRA_NO_SMALL_PATH") != nullptr;
+    own_stream = getenv("CRA_OWN_STREAM_PER_NET") != nullptr;
+    if (const char* e = getenv("CRA_SMALL_BATCH_CONV_SPLIT")) small_conv_split = atoi(e);
+}
+
+// The streams nets work in.  The runtime binds every stream to one of GPU_MAX_HW_QUEUES (4) hardware queues -- the one with the fewest
+// streams on it, whether those streams do anything or not -- and two streams of one queue run strictly one after the other
+// (scripts/ubench/stream_queues.hip, profiles/r06/v_stream_queues.txt: two 2 ms kernels take 4.0 ms on streams 0 and 7 of eight, 2.0 ms on
+// any two of different queues).  With a stream created per net, which queue two evaluator lanes (or two NeuralNetAPIUsers) shared was
+// decided by how many nets the process had opened before and not yet closed: the same two-lane search measured 35k or 63k nodes/s, the
+// same two predict() users 302k or 359k evals/s, depending on nets that were idle at the time (profiles/r06/t_*, u_*).  So the library
+// keeps one stream per hardware queue and device, made together on first need and never destroyed (their queues stay four different
+// ones), and a new net takes the one that has gone unused the longest: idle nets do not keep a queue busy, and up to four nets that work
+// at the same time work on four queues.  More nets than queues share streams as they shared queues before -- in order, which is correct
+// for everything a net does (each net's work is in-order in its stream; graphs are captured on a stream of their own, see capture()).
+namespace {
+struct NetStreams {
+    std::mutex mu;
+    int n = 0;
+    hipStream_t s[16] = {};
+    std::atomic<uint64_t> last[16] = {};
+};
+NetStreams g_net_streams[64];                  // per device
+std::atomic<uint64_t> g_stream_tick{1};
+
+int take_net_stream(int device, hipStream_t* out) {
+    NetStreams& ns = g_net_streams[device];
+    std::lock_guard<std::mutex> lk(ns.mu);
+    if (ns.n == 0) {
+        int n = 4;                              // the runtime's default number of hardware queues per process and device
+        if (const char* e = getenv("GPU_MAX_HW_QUEUES")) n = atoi(e);
+        n = n < 1 ? 1 : n > 16 ? 16 : n;
+        for (int i = 0; i < n; ++i) HIP_CHECK(hipStreamCreateWithFlags(&ns.s[i], hipStreamNonBlocking));
+        ns.n = n;
+    }
+    int best = 0;
+    for (int i = 1; i < ns.n; ++i)
+        if (ns.last[i].load(std::memory_order_relaxed) < ns.last[best].load(std::memory_order_relaxed)) best = i;
+    ns.last[best].store(g_stream_tick.fetch_add(1, std::memory_order_relaxed), std::memory_order_relaxed);
+    *out = ns.s[best];
+    return best;
+}
+}  // namespace
+
+void RiseNet::touch_stream() const {
+    if (stream_slot_ >= 0) g_net_streams[device_].last[stream_slot_].store(g_stream_tick.fetch_add(1, std::memory_order_relaxed), std::memory_order_relaxed);
 }
 
 static thread_local hipStream_t g_companion_stream = nullptr;   // set by a constructor for the constructor of its companion net (same thread, next statement)
+static thread_local int g_companion_slot = -1;
 
 RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, const std::string& precision)
     : device_(device_id), impl_(new Impl) {
@@ -382,9 +428,14 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     if (nf.str("arch") != "rise") throw std::runtime_error("unsupported arch '" + nf.str("arch") + "' in " + model_file_path_);
     if (g_companion_stream) {                    // the companion net of a larger one works in ITS stream (never at the same time: a call goes to one of them)
         stream_ = g_companion_stream;
+        stream_slot_ = g_companion_slot;
         owns_stream_ = false;
         g_companion_stream = nullptr;
-    } else HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    } else if (dev_.own_stream || device_id >= 64) {
+        HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    } else {
+        stream_slot_ = take_net_stream(device_id, &stream_);
+    }
     if (int8_) {
         int8_calib_ = read_int8_calibration(model_file_path_);
         if (int8_calib_.empty())
@@ -400,6 +451,7 @@ RiseNet::RiseNet(const std::string& model_path, int device_id, int batch_size, c
     // of a later search landed on ONE queue (config 1 with two lanes: 35k nodes/s instead of 63k, profiles/r06/t_*).
     if (!dev_.no_small_path && x3_ && tower_ && fused_ && board_split_ && design_.batch > kBoardSplitMaxBatch) {
         g_companion_stream = stream_;
+        g_companion_slot = stream_slot_;
         small_.reset(new RiseNet(model_file_path_, device_id, kBoardSplitMaxBatch, precision_arg_));
     }
 }
@@ -416,12 +468,12 @@ RiseNet::~RiseNet() {
     small_.reset();                              // (it works in this net's stream)
     if (stream_) {
         (void)hipStreamSynchronize(stream_);
-        if (owns_stream_) turns_forget_stream(device_, stream_);
+        if (owns_stream_ && stream_slot_ < 0) turns_forget_stream(device_, stream_);
     }
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
     if (graph_) (void)hipGraphDestroy(graph_);
     impl_.reset();
-    if (stream_ && owns_stream_) (void)hipStreamDestroy(stream_);
+    if (stream_ && owns_stream_ && stream_slot_ < 0) (void)hipStreamDestroy(stream_);
 }
 
 template <typename T> void RiseNet::build(const NetFile& nf) {
@@ -667,6 +719,9 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     int x3_run_ks = 3;                     // a run is all 3x3 or all 5x5 blocks (tower_x3_roles_kernel<KS>, tower_p8_kernel<KS>)
     // small batches: 3x3 runs one block per launch, several workgroups per board (kernels.h: X3SplitArgs)
     const bool x3_split = x3_ && tower_ && fused_ && C == 256 && board_split_ && B <= (dev_.x3_split_max_batch > 0 ? dev_.x3_split_max_batch : kBoardSplitMaxBatch);
+    if (x3_split)
+        for (Op& o : im.ops)
+            if (o.kind == OpKind::Conv && o.from_planes) o.conv.few_boards = dev_.small_conv_split;      // the stem's couts over several workgroups per board
     float* split_parts[2] = {nullptr, nullptr};
     constexpr int kSplitMaxG = 10;
     auto flush_x3_tower = [&]() {
@@ -1291,12 +1346,13 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         c.pre_acc_scale = float(inv1);
         macs += double(kSquares) * C * C * 9;
     } else {
-        add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr, true);
-        im.ops.back().conv.few_boards = x3_split ? 1 : 0;
+        // (a small batch: float16x3's convs in both modes, like its blocks -- the cross terms on e5m2 buy nothing where a launch is its latency)
+        add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr, !x3_split);
+        im.ops.back().conv.few_boards = x3_split ? dev_.small_conv_split : 0;
     }
     if (head_chain) {
     } else if (policy_map) {
-        add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_, true);
+        add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_, !x3_split);
     } else {
         // flat labels: conv3x3(C->P) + BN + ReLU written channel-major flat (x.view(-1, nb_flatten)), then Linear(P*64 -> n_labels)
         // as a GEMM over the BATCH (64 boards play the 64 "squares" of a workgroup tile), float logits row per board
@@ -1498,6 +1554,17 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         prepare_value_head<T>(op.vh);
         im.ops.push_back(op);
     }
+    // a small batch: the policy conv that ends in the softmax and the value head side by side in one launch (x3.hip: heads_small_kernel);
+    // CRA_SMALL_BATCH_HEADS_APART: development A/B
+    if (x3_split && im.ops.size() >= 2 && im.ops.back().kind == OpKind::ValueHead && im.ops[im.ops.size() - 2].kind == OpKind::Conv &&
+        im.ops[im.ops.size() - 2].fused_softmax && heads_small_fits(im.ops[im.ops.size() - 2].conv, im.ops.back().vh) &&
+        getenv("CRA_SMALL_BATCH_HEADS_APART") == nullptr) {
+        Op vh = im.ops.back();
+        im.ops.pop_back();
+        Op& op = im.ops.back();
+        op.kind = OpKind::HeadsSmall;
+        op.vh = vh.vh;
+    }
     }   // !head_ok
     init_block_kernel_attributes<T>();
     init_x3_kernel_attributes();
@@ -1565,6 +1632,18 @@ template <typename T> void RiseNet::launch_op(int i, hipStream_t s, const IoOver
             v.aux = aux;
             if (dyn_n_ > 0) v.batch = dyn_n_;
             launch_value_head<T>(v, s);
+            break;
+        }
+        case OpKind::HeadsSmall: {
+            HeadsSmallArgs h;
+            h.conv = boards(op.conv);
+            h.conv.softmax_out = probs;
+            if (!keep_logits_) h.conv.out = nullptr;
+            h.vh = op.vh;
+            h.vh.value = value;
+            h.vh.aux = aux;
+            h.vh.batch = h.conv.batch;
+            launch_heads_small(h, s);
             break;
         }
         case OpKind::Softmax: launch_softmax(d_logits_, probs, B, design_.nb_policy, s); break;
@@ -1660,6 +1739,7 @@ const char* RiseNet::op_name(int i) const {
         case OpKind::TowerX3: return op.tx.p8 ? "tower_p8" : "tower_x3";
         case OpKind::BlockX3Split: return "block_x3_split";
         case OpKind::X3SplitFinish: return "x3_split_finish";
+        case OpKind::HeadsSmall: return "heads_small";
     }
     return "?";
 }
@@ -1840,16 +1920,27 @@ void RiseNet::keep_logits(bool on) {
 }
 
 void RiseNet::capture() {
-    HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    // on a stream of its own: stream_ may be shared with a net that another thread is working with right now (NetStreams), and whatever
+    // that thread launched between Begin and End would land in THIS graph
+    hipStream_t cs = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipError_t err = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (err != hipSuccess) {
+        (void)hipStreamDestroy(cs);
+        HIP_CHECK(err);
+    }
     try {
-        forward_on(stream_);
+        forward_on(cs);
     } catch (...) {
         hipGraph_t g = nullptr;
-        (void)hipStreamEndCapture(stream_, &g);
+        (void)hipStreamEndCapture(cs, &g);
         if (g) (void)hipGraphDestroy(g);
+        (void)hipStreamDestroy(cs);
         throw;
     }
-    HIP_CHECK(hipStreamEndCapture(stream_, &graph_));
+    err = hipStreamEndCapture(cs, &graph_);
+    (void)hipStreamDestroy(cs);
+    HIP_CHECK(err);
     HIP_CHECK(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0));
 }
 
@@ -1937,6 +2028,7 @@ struct RiseNet::Turn {
 // graph launch's own cost between consecutive replays: it goes into the stream as a plain launch.  Everything else replays the graph.
 // CRA_DEVICE_GRAPH=1 forces the graph (A/B timing).
 void RiseNet::forward_async() {
+    touch_stream();
     Turn turn(*this);
     if (launches_ == 1 && !dev_.device_graph) {
         forward_on(stream_);
@@ -1953,6 +2045,7 @@ void RiseNet::forward_async() {
 // so these paths put the kernels straight into the stream: one queue, in-order, no host in the loop (float16p8's five launches: config 2
 // searched at 373k nodes/s against 370k through the graph on an idle host, profiles/r04/ac_*).
 void RiseNet::launch_forward_in_stream() {
+    touch_stream();
     Turn turn(*this);
     if (dyn_n_ > 0 || (launches_ <= 5 && !dev_.lane_graph) || dev_.lane_no_graph) forward_on(stream_);      // (a forward of fewer boards: its own arguments)
     else HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
@@ -2096,6 +2189,7 @@ void RiseNet::submit_boards_gathered(const void* descs_host, int n_valid, int la
         h.g_out = gathered;
         h.g_stride = int(stride);
         h.g_n_valid = n_valid;
+        touch_stream();
         Turn turn(*this);                         // forwards that fill the chip take turns (small batches: a no-op)
         launch_forward(st, op.tw, h, stream_);
         HIP_CHECK(hipGetLastError());

@@ -14,6 +14,7 @@
 // Reference semantics: the same modules as kernels.hip (builder_util.py:154-178, 437-475, 206-326).
 #include "kernels.h"
 #include "device_utils.h"
+#include "value_head_body.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -251,17 +252,15 @@ __device__ __forceinline__ void conv_x3_finish(const ConvArgs& a, f32x4 (&acc)[M
 // weight fragments through a window of three (tap, k-slab) steps -- requested before the pass is staged, refilled right behind
 // their MFMAs -- and the stream fragments of the next step read from LDS before this step's MFMAs (as in the tower).  NS = 0: any cin.
 template <int KS, int MT, int NW, int NS>
-__global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void conv_gemm_x3_body(const ConvArgs& a, char* smem, const int bx, const int b) {
     half_t* xh = reinterpret_cast<half_t*>(smem);            // [65][ROWP] hi
     half_t* xl = xh + 65 * X3_ROWP;                          // [65][ROWP] lo
     constexpr int ROWP = X3_ROWP, KC = X3_KC, NTHR = 64 * NW;
 
-    const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int co_tile0 = (blockIdx.x * NW + wave) * MT;
+    const int co_tile0 = (bx * NW + wave) * MT;
     bool active[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) active[m] = (co_tile0 + m) * 16 < a.cout_pad;
@@ -412,6 +411,25 @@ __global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a)
 
     conv_x3_finish<MT, NW>(a, acc, active, smem, b, co_tile0, 1.f);
     if (a.dev & 1) __syncthreads();
+}
+template <int KS, int MT, int NW, int NS>
+__global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_gemm_x3_body<KS, MT, NW, NS>(a, smem, blockIdx.x, blockIdx.y);
+}
+
+// The heads of a small batch in ONE launch (nets made for at most 64 boards, rise_net.hip): workgroup (0, b) runs the second policy conv
+// with the board's softmax -- conv_gemm_x3_kernel<3, 1, 8, 4>'s work -- and workgroup (1, b) the value head (value_head_kernel's, four of
+// its eight waves leave at once).  Behind one another the two cost a batch of one 20 + 25 us on two CUs of 256; side by side the longer of
+// the two.  (On two streams instead: slower than in sequence, the joins across queues cost more than they hide -- profiles/r06/e_*.)
+__global__ __launch_bounds__(512) void heads_small_kernel(const HeadsSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.x == 0) {
+        conv_gemm_x3_body<3, 1, 8, 4>(a.conv, smem, 0, blockIdx.y);
+    } else {
+        if (threadIdx.x >= 256) return;
+        value_head_body<float, false, true>(a.vh, smem, blockIdx.y);
+    }
 }
 
 // Precision float16p8, dense 3x3 conv with cin a multiple of 128 (the two policy convs): conv_gemm_x3_kernel<3, MT, NW, 4> with the cross terms on
@@ -681,6 +699,8 @@ template <int KS, int NS> static void launch_conv_gemm_x3_ks(const ConvArgs& a, 
     const int tiles = a.cout_pad / 16;
     if (a.out_rows_f32) {                   // an FC over the batch: few "boards" (64 rows each), so as many workgroups as the couts give
         hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 1, 4, NS>), dim3((tiles + 3) / 4, a.batch), dim3(256), shmem, s, a);
+    } else if (a.few_boards >= 2 && tiles >= 8 && !a.softmax_out) {   // a small batch: the couts of a wide layer over tiles / 4 workgroups per board (CUs are idle, the launch is its latency)
+        hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 1, 4, NS>), dim3((tiles + 3) / 4, a.batch), dim3(256), shmem, s, a);
     } else if ((tiles >= 12 && !a.few_boards) || (a.softmax_out && tiles > 8)) {   // 192 couts and more (or a fused softmax: the board in one workgroup): 8 waves x 2 tiles, the whole cout range of a 256-wide layer in one workgroup
         hipLaunchKernelGGL((conv_gemm_x3_kernel<KS, 2, 8, NS>), dim3((tiles + 15) / 16, a.batch), dim3(512), shmem, s, a);
     } else if (tiles >= 5) {                // 80 ... 176 couts: 8 waves x 1 tile (measured against 4 waves x 2 tiles: 0.036 / 0.042 ms for 96 couts)
@@ -698,6 +718,15 @@ void launch_conv_gemm_x3(const ConvArgs& a, hipStream_t s) {
     if (a.p8) launch_conv3x3_p8(a, s);
     else if (a.ks == 1) launch_conv_gemm_x3_cin<1>(a, s);
     else launch_conv_gemm_x3_cin<3>(a, s);
+}
+bool heads_small_fits(const ConvArgs& c, const ValueHeadArgs& v) {
+    return !c.p8 && c.ks == 3 && c.cin % X3_KC == 0 && !c.planes && !c.out_rows_f32 && c.out_policy_f32 && !c.resid && c.cout_pad <= 128 && !v.dbg && v.lds_pad < 0 &&
+           v.variant == 0 && value_head_lds_bytes(v) <= 64 * 1024;
+}
+void launch_heads_small(const HeadsSmallArgs& a, hipStream_t s) {
+    if (!heads_small_fits(a.conv, a.vh) || !a.conv.softmax_out || a.conv.batch != a.vh.batch) throw std::invalid_argument("heads_small_kernel: a 3x3 policy conv of at most 128 couts with its softmax, and the one-launch value head");
+    const size_t shmem = std::max(size_t(2) * 65 * X3_ROWP * sizeof(half_t), value_head_lds_bytes(a.vh));
+    hipLaunchKernelGGL(heads_small_kernel, dim3(2, a.conv.batch), dim3(512), shmem, s, a);
 }
 
 // ================================================================================================================

@@ -538,6 +538,41 @@ def test_float16p8_launch_structure(tmp_path, hip_lib, name, towers):
     small = [n for n, _ in net.time_ops(1)]
     net.close()
     assert "block_x3_split" in small and "x3_split_finish" in small and ("tower_p8" in small) == (name == "risev33"), small
+    assert small[-2:] == ["conv_gemm_x3_3x3", "heads_small"], small       # policy conv 1; policy conv 2 + softmax beside the value head
+
+
+@pytest.mark.parametrize("precision", ["float16p8", "float16x3"])
+@pytest.mark.parametrize("name,batch", [("risev2-7", 8), ("risev2-19", 1), ("risev33-wdlp", 5), ("risev2-13-lichess", 64)])
+def test_small_batch_heads_side_by_side_equal_heads_in_sequence(tmp_path, hip_lib, name, batch, precision, monkeypatch):
+    """Round 6: a net made for <= 64 boards runs the second policy conv (with the softmax) and the value head as the two roles of ONE launch
+    (x3.hip: heads_small_kernel) and spreads the couts of its wide convs (stem, policy conv 1) over four workgroups per board.  Neither changes
+    one output's arithmetic: identical bits to the same net with the heads as two launches and two workgroups per wide conv
+    (CRA_SMALL_BATCH_HEADS_APART, CRA_SMALL_BATCH_CONV_SPLIT=1), value, probabilities, logits and the WDLP outputs."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, _ = nn_cases.make_case(name)
+    d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
+    xin = np.ascontiguousarray(nn_cases.synthetic_planes(batch, cfg.nb_input_channels, 78).numpy())
+    outs = {}
+    for apart in (False, True):
+        if apart:
+            monkeypatch.setenv("CRA_SMALL_BATCH_HEADS_APART", "1")
+            monkeypatch.setenv("CRA_SMALL_BATCH_CONV_SPLIT", "1")
+        else:
+            monkeypatch.delenv("CRA_SMALL_BATCH_HEADS_APART", raising=False)
+            monkeypatch.delenv("CRA_SMALL_BATCH_CONV_SPLIT", raising=False)
+        net = HipAPI(0, batch, d, precision, keep_logits=True)
+        names = [n for n, _ in net.time_ops(1)]
+        assert ("heads_small" in names) == (not apart) and ("value_head" in names) == apart, names
+        v, p = np.full(batch, 7.0, np.float32), np.full(batch * cfg.nb_policy, 7.0, np.float32)
+        aux = np.full(batch * 4, 7.0, np.float32) if cfg.nb_aux else None
+        for _ in range(2):
+            net.predict(xin, v, p, aux)
+        logits = torch.as_tensor(net.device_buffers()["logits"], device="cuda").cpu().numpy().copy()
+        outs[apart] = (v, p, logits, aux)
+        net.close()
+    for a, b in zip(outs[False], outs[True]):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    assert np.abs(outs[False][0]).max() <= 1.0 and not np.any(outs[False][1] == 7.0)
 
 
 @pytest.mark.parametrize("precision", ["float16p8", "float16x3"])

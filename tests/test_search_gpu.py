@@ -240,3 +240,48 @@ def test_few_boards_on_a_net_made_for_many_take_the_small_forward(tmp_path, hip_
     print("seconds per call (small path, old path):", {n: (round(times[(True, n)] * 1e3, 3), round(times[(False, n)] * 1e3, 3)) for n in (1, 5, 33, 64, 65, 256)})
     assert times[(True, 1)] < 0.9 * times[(False, 1)]
     lib.mi_host_free(dbuf); lib.mi_host_free(v); lib.mi_host_free(p)
+
+
+def test_nets_of_one_process_work_on_different_hardware_queues(tmp_path, hip_lib, monkeypatch):
+    """Round 6: nets take their stream from a per-device set the library keeps (one per hardware queue, never destroyed), the one unused
+    the longest -- not a stream created per net, whose hardware queue depended on how many idle nets the process still held
+    (scripts/ubench/stream_queues.hip).  Four nets open at once work in four different streams; a fifth shares the one that has been
+    idle the longest; a net that is closed frees nothing that matters; every net still computes the same numbers in whichever stream."""
+    from crazyara_amd import _capi
+    cfg, sd, _ = nn_cases.make_case("risev2-7")
+    d = nn_cases.export_case(tmp_path, "risev2-7", cfg, sd)
+    lib = _capi.load()
+    monkeypatch.delenv("CRA_OWN_STREAM_PER_NET", raising=False)
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    x = np.ascontiguousarray(torch.rand(8, cfg.nb_input_channels, 8, 8).numpy())
+
+    def run(n):
+        v = np.full(8, 7.0, np.float32)
+        p = np.full(8 * cfg.nb_policy, 7.0, np.float32)
+        n.predict(x, v, p, np.full(8 * 4, 7.0, np.float32) if cfg.nb_aux else None)
+        return v, p
+
+    nets = [HipAPI(0, 8, d, "float16") for _ in range(4)]
+    streams = [lib.mi_net_stream(n._h) for n in nets]
+    assert len(set(streams)) == 4
+    ref = run(nets[0])
+    for n in nets[1:]:
+        out = run(n)
+        assert all(np.array_equal(a, b) for a, b in zip(ref, out))
+    # nets[0] predicted first of the four: its stream is the one unused the longest now
+    fifth = HipAPI(0, 8, d, "float16")
+    assert lib.mi_net_stream(fifth._h) == streams[0]
+    assert all(np.array_equal(a, b) for a, b in zip(ref, run(fifth)))
+    nets[1].close()
+    sixth = HipAPI(0, 8, d, "float16x3")          # a float16x3 net made for 8 boards (several launches, a captured graph)
+    assert lib.mi_net_stream(sixth._h) in streams
+    o_value, o_logits, _ = ro.forward(cfg, sd, torch.from_numpy(x))
+    v6 = run(sixth)[0]
+    assert np.abs(v6 - o_value.numpy().reshape(-1)).max() < 1e-4
+    for n in (nets[0], nets[2], nets[3], fifth, sixth):
+        n.close()
+    monkeypatch.setenv("CRA_OWN_STREAM_PER_NET", "1")
+    own = HipAPI(0, 8, d, "float16")
+    assert lib.mi_net_stream(own._h) not in streams
+    assert all(np.array_equal(a, b) for a, b in zip(ref, run(own)))
+    own.close()

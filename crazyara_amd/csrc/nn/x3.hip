@@ -312,6 +312,9 @@ __device__ __forceinline__ void conv_gemm_x3_body(const ConvArgs& a, char* smem,
                     const int c = kc0 + v * 8 + j;
                     f[j] = c < a.planes_c ? pb[c * kSquares] : 0.f;
                 }
+            } else if (a.dev & 16) {                         // (development, timing only: no loads of the board)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = 0.f;
             } else {
                 load8<float>(xb + size_t(r) * a.cin + kc0 + v * 8, f);
             }
@@ -322,7 +325,7 @@ __device__ __forceinline__ void conv_gemm_x3_body(const ConvArgs& a, char* smem,
         }
         __syncthreads();
         if constexpr (NS > 0) {
-            if (active[0]) {
+            if (active[0] && !(a.dev & 8)) {                 // (development bit 8, timing only: no K loop)
                 half8 bh[2][4], bl[2][4];
                 auto read_frag = [&](int st) {
                     const int tap = st / NS, sl = st % NS, dy = tap / KS - KS / 2, dx = tap % KS - KS / 2;

@@ -135,6 +135,12 @@ struct X3SplitArgs {
     float* y_parts;           // [B][G][64][256]
     int gin;                  // 1 ... 16
     int batch, G;             // 1 <= G <= min(cop_pad / 128, 16)
+    // A gated block needs the board's channel means before it can use the board.  Means are linear: the launch before it leaves, per
+    // workgroup, the channel sums of the image it wrote ([B][G][256], pool_out), and the gated block adds them up (pool_in, gin of them per
+    // board) and has its gate BEFORE it stages the board -- the gate is then applied while staging.  nullptr: the gate phase on the staged
+    // tiles (a run's first block; CRA_X3_SPLIT_DEV bit 8).
+    const float* pool_in;
+    float* pool_out;
     int dev;                  // development (CRA_X3_SPLIT_DEV when the net was made; timing switches, x3.hip)
 };
 void launch_block_x3_split(const X3SplitArgs& a, hipStream_t s);

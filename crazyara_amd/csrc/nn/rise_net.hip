@@ -743,6 +743,11 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
                 op.xs.batch = B;
                 op.xs.G = std::min(max_g, x3_blocks[k].cop_pad / block_x3_chunk_channels());
                 op.xs.dev = dev_.x3_split_dev;
+                if (k > 0 && x3_blocks[k].se_kind != 0 && !(dev_.x3_split_dev & 8)) {      // the launch before a gated block leaves its images' channel sums
+                    float* pools = static_cast<float*>(im.dalloc(size_t(B) * kSplitMaxG * C * sizeof(float)));
+                    im.ops.back().xs.pool_out = pools;
+                    op.xs.pool_in = pools;
+                }
                 gin = op.xs.G;
                 im.ops.push_back(op);
             }
@@ -1556,7 +1561,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     }
     // a small batch: the policy conv that ends in the softmax and the value head side by side in one launch (x3.hip: heads_small_kernel);
     // CRA_SMALL_BATCH_HEADS_APART: development A/B
-    if (x3_split && im.ops.size() >= 2 && im.ops.back().kind == OpKind::ValueHead && im.ops[im.ops.size() - 2].kind == OpKind::Conv &&
+    if ((x3_split || getenv("CRA_HEADS_TOGETHER") != nullptr) && x3_ && im.ops.size() >= 2 && im.ops.back().kind == OpKind::ValueHead && im.ops[im.ops.size() - 2].kind == OpKind::Conv &&
         im.ops[im.ops.size() - 2].fused_softmax && heads_small_fits(im.ops[im.ops.size() - 2].conv, im.ops.back().vh) &&
         getenv("CRA_SMALL_BATCH_HEADS_APART") == nullptr) {
         Op vh = im.ops.back();

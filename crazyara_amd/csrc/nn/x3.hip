@@ -1237,53 +1237,10 @@ namespace {
 //   eca_se: thread t -> gate 2*(t/4), +1 over inputs i in [64*(t%4), +64)
 // scratch (the t2 tiles, idle between blocks): mean 8 x 36, hidden 4 x 36, gate 256 floats.  Ends with a barrier.
 // pre_wa: the thread's first 16 weight loads, requested by the caller before it staged the board (block_x3_split_kernel), else nullptr
-struct X3SeFirstWeights { f32x4 w[16]; };
-__device__ __forceinline__ void x3_se_first_weights_request(X3SeFirstWeights& S, const X3TowerBlock& d, int tid) {
-    const f32x4* pk = reinterpret_cast<const f32x4*>(d.se_w1t) + tid;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) S.w[i] = pk[i * 512];
-}
-__device__ __forceinline__ void x3_se_phase(const X3Tiles& T, const X3TowerBlock& d, float* scratch, int tid, const X3SeFirstWeights* pre_wa = nullptr) {
-    constexpr int C = X3Block::C, XROW = X3Block::XROW, GRP = 36;     // floats per group of 32 means / hidden values (bank spread)
-    float* se_mean = scratch;              // [8][36]
-    float* se_h = scratch + 8 * GRP;       // [4][36]
-    float* se_gate = se_h + 4 * GRP;       // [256]
-    f32x4 wa[16], wb[16];
-    auto load_thread_weights = [&](const float* base, f32x4 (&dst)[16]) {
-        const f32x4* pk = reinterpret_cast<const f32x4*>(base) + tid;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dst[i] = pk[i * 512];
-    };
-    if (pre_wa) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) wa[i] = pre_wa->w[i];
-        load_thread_weights(d.se_kind == 1 ? d.se_w2t : d.se_w1t + size_t(16) * 512 * 4, wb);      // (the second set flies during the squeeze)
-    } else load_thread_weights(d.se_w1t, wa);
-    {   // squeeze: a wave owns 32 channels: lane = (4 groups of 8 channels) x (16 groups of 4 squares); 16-lane DPP row reduction
-        const int lane = tid & 63, wv = tid >> 6, cg = lane >> 4, sg = lane & 15;
-        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float fh[8], fl[8];
-            load8<half_t>(T.xh + x3_row(sg * 4 + q) * XROW + wv * 32 + cg * 8, fh);     // squares in board order: the sum's rounding does not depend on the tile-row order
-            load8<half_t>(T.xl + x3_row(sg * 4 + q) * XROW + wv * 32 + cg * 8, fl);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sum[j] += fh[j] + fl[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            sum[j] += dpp_mov<0x111>(sum[j]);    // row_shr:1
-            sum[j] += dpp_mov<0x112>(sum[j]);    // row_shr:2
-            sum[j] += dpp_mov<0x114>(sum[j]);    // row_shr:4
-            sum[j] += dpp_mov<0x118>(sum[j]);    // row_shr:8 -> lane 15 of the row holds the row's sum
-        }
-        if (sg == 15) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) se_mean[wv * GRP + cg * 8 + j] = sum[j] * (1.f / 64.f);      // channel c at (c / 32) * 36 + c % 32
-        }
-    }
-    if (!pre_wa) load_thread_weights(d.se_kind == 1 ? d.se_w2t : d.se_w1t + size_t(16) * 512 * 4, wb);      // flies during FC1 (eca: the second half)
-    __syncthreads();
+//
+// x3_se_fcs: the gate from the channel means (se_mean, LDS, written and barrier'd by the caller): both FC stages of ca_se / the one of eca_se; ends with a barrier
+__device__ __forceinline__ void x3_se_fcs(const X3TowerBlock& d, const float* se_mean, float* se_h, float* se_gate, const f32x4 (&wa)[16], const f32x4 (&wb)[16], int tid) {
+    constexpr int GRP = 36;
     auto dot32 = [](const f32x4 (&w)[16], const float* v, float& s0, float& s1) {   // v: 32 floats, 16-byte aligned; w[i] = (a, b, a', b') of k = 2i, 2i+1
 #pragma unroll
         for (int k4 = 0; k4 < 8; ++k4) {
@@ -1333,6 +1290,55 @@ __device__ __forceinline__ void x3_se_phase(const X3Tiles& T, const X3TowerBlock
         }
     }
     __syncthreads();
+}
+struct X3SeFirstWeights { f32x4 w[16]; };
+__device__ __forceinline__ void x3_se_first_weights_request(X3SeFirstWeights& S, const X3TowerBlock& d, int tid) {
+    const f32x4* pk = reinterpret_cast<const f32x4*>(d.se_w1t) + tid;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S.w[i] = pk[i * 512];
+}
+__device__ __forceinline__ void x3_se_phase(const X3Tiles& T, const X3TowerBlock& d, float* scratch, int tid, const X3SeFirstWeights* pre_wa = nullptr) {
+    constexpr int C = X3Block::C, XROW = X3Block::XROW, GRP = 36;     // floats per group of 32 means / hidden values (bank spread)
+    float* se_mean = scratch;              // [8][36]
+    float* se_h = scratch + 8 * GRP;       // [4][36]
+    float* se_gate = se_h + 4 * GRP;       // [256]
+    f32x4 wa[16], wb[16];
+    auto load_thread_weights = [&](const float* base, f32x4 (&dst)[16]) {
+        const f32x4* pk = reinterpret_cast<const f32x4*>(base) + tid;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[i] = pk[i * 512];
+    };
+    if (pre_wa) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wa[i] = pre_wa->w[i];
+        load_thread_weights(d.se_kind == 1 ? d.se_w2t : d.se_w1t + size_t(16) * 512 * 4, wb);      // (the second set flies during the squeeze)
+    } else load_thread_weights(d.se_w1t, wa);
+    {   // squeeze: a wave owns 32 channels: lane = (4 groups of 8 channels) x (16 groups of 4 squares); 16-lane DPP row reduction
+        const int lane = tid & 63, wv = tid >> 6, cg = lane >> 4, sg = lane & 15;
+        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float fh[8], fl[8];
+            load8<half_t>(T.xh + x3_row(sg * 4 + q) * XROW + wv * 32 + cg * 8, fh);     // squares in board order: the sum's rounding does not depend on the tile-row order
+            load8<half_t>(T.xl + x3_row(sg * 4 + q) * XROW + wv * 32 + cg * 8, fl);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum[j] += fh[j] + fl[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sum[j] += dpp_mov<0x111>(sum[j]);    // row_shr:1
+            sum[j] += dpp_mov<0x112>(sum[j]);    // row_shr:2
+            sum[j] += dpp_mov<0x114>(sum[j]);    // row_shr:4
+            sum[j] += dpp_mov<0x118>(sum[j]);    // row_shr:8 -> lane 15 of the row holds the row's sum
+        }
+        if (sg == 15) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) se_mean[wv * GRP + cg * 8 + j] = sum[j] * (1.f / 64.f);      // channel c at (c / 32) * 36 + c % 32
+        }
+    }
+    if (!pre_wa) load_thread_weights(d.se_kind == 1 ? d.se_w2t : d.se_w1t + size_t(16) * 512 * 4, wb);      // flies during FC1 (eca: the second half)
+    __syncthreads();
+    x3_se_fcs(d, se_mean, se_h, se_gate, wa, wb, tid);
 #pragma unroll 1
     for (int i = tid; i < 64 * (C / 8); i += X3Block::NTHR) {      // x := x * gate (the residual uses the gated x, builder_util.py:473-475)
         const int r = i / (C / 8), v = i - r * (C / 8);
@@ -1413,8 +1419,9 @@ namespace {
 // bits on every launch and in every workgroup of the board; gin = 1: a plain float tile) -> split tiles.  A thread's loads of one pass are all
 // requested before the first add: the images come from HBM / the memory-side cache, and dependent round trips are what a launch of this
 // kernel mostly consists of.
+// gate: nullptr, or the board's 256 channel gates (LDS): the tile staged is x * gate (a gated block whose gate is known before the board is)
 template <int GIN>
-__device__ __forceinline__ void x3_stage_tile_sum(const X3Tiles& T, const float* parts, int gin, int tid) {
+__device__ __forceinline__ void x3_stage_tile_sum(const X3Tiles& T, const float* parts, int gin, int tid, const float* gate = nullptr) {
     constexpr int C = X3Block::C, XROW = X3Block::XROW, IT = 64 * (C / 8) / X3Block::NTHR;
     constexpr int NG = GIN > 0 ? GIN : 16;
     constexpr int FLY = GIN > 0 && GIN <= 2 ? 4 : GIN > 0 && GIN <= 5 ? 2 : 1;       // passes requested together (8 NG registers each)
@@ -1446,7 +1453,13 @@ __device__ __forceinline__ void x3_stage_tile_sum(const X3Tiles& T, const float*
                     s1 += q[u][g][1];
                 }
             }
-            const float f[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            float f[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            if (gate) {
+                float gv[8];
+                load8<float>(gate + v * 8, gv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] *= gv[j];
+            }
             half8 h, l;
             split8(f, h, l);
             *reinterpret_cast<half8*>(T.xh + r * XROW + v * 8) = h;
@@ -1477,26 +1490,55 @@ __global__ __launch_bounds__(512) void block_x3_split_kernel(const X3SplitArgs a
     const int ch0 = __builtin_amdgcn_readfirstlane(g * n / G_), ch1 = __builtin_amdgcn_readfirstlane((g + 1) * n / G_);
     X3ExpandWindow win;
     x3_expand_window_request(win, W, ch0);
+    const bool gate_first = d.se_kind != 0 && a.pool_in != nullptr;     // the launch before left the channel sums of its images: the gate comes BEFORE the board
     X3SeFirstWeights se_first;                                          // a gated block: the gate matrices' first half as well (128 KB per workgroup)
-    if (d.se_kind != 0) x3_se_first_weights_request(se_first, d, tid);
+    if (d.se_kind != 0 && !gate_first) x3_se_first_weights_request(se_first, d, tid);
+    const float* gate = nullptr;
+    if (gate_first) {
+        constexpr int GRP = 36;
+        float* scratch = reinterpret_cast<float*>(T.t2h);               // x3_se_phase's scratch: mean 8 x 36, hidden 4 x 36, gate 256
+        float *se_mean = scratch, *se_h = scratch + 8 * GRP, *se_gate = se_h + 4 * GRP;
+        f32x4 wa[16], wb[16];                                           // both gate matrices (256 KB per workgroup), in flight from here
+        {
+            const f32x4* pa = reinterpret_cast<const f32x4*>(d.se_w1t) + tid;
+            const f32x4* pb = reinterpret_cast<const f32x4*>(d.se_kind == 1 ? d.se_w2t : d.se_w1t + size_t(16) * 512 * 4) + tid;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wa[i] = pa[i * 512];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wb[i] = pb[i * 512];
+        }
+        if (tid < C) {                                                  // mean of channel tid = the images' channel sums in index order / 64
+            const float* pin = a.pool_in + size_t(b) * a.gin * C + tid;
+            float ps[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ps[q] = q < a.gin ? pin[q * C] : 0.f;
+            float sum = ps[0];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) sum += ps[q];
+            se_mean[(tid >> 5) * GRP + (tid & 31)] = sum * (1.f / 64.f);
+        }
+        __syncthreads();
+        x3_se_fcs(d, se_mean, se_h, se_gate, wa, wb, tid);
+        gate = se_gate;
+    }
     {
         const float* parts = a.x_parts + size_t(b) * a.gin * 64 * C;
         switch (a.gin) {                                                // (the usual counts with every load of a pass in flight at once)
-            case 1: x3_stage_tile_sum<1>(T, parts, 1, tid); break;
-            case 2: x3_stage_tile_sum<2>(T, parts, 2, tid); break;
-            case 3: x3_stage_tile_sum<3>(T, parts, 3, tid); break;
-            case 4: x3_stage_tile_sum<4>(T, parts, 4, tid); break;
-            case 5: x3_stage_tile_sum<5>(T, parts, 5, tid); break;
-            case 6: x3_stage_tile_sum<6>(T, parts, 6, tid); break;
-            case 7: x3_stage_tile_sum<7>(T, parts, 7, tid); break;
-            case 8: x3_stage_tile_sum<8>(T, parts, 8, tid); break;
-            case 9: x3_stage_tile_sum<9>(T, parts, 9, tid); break;
-            case 10: x3_stage_tile_sum<10>(T, parts, 10, tid); break;
-            default: x3_stage_tile_sum<0>(T, parts, a.gin, tid); break;
+            case 1: x3_stage_tile_sum<1>(T, parts, 1, tid, gate); break;
+            case 2: x3_stage_tile_sum<2>(T, parts, 2, tid, gate); break;
+            case 3: x3_stage_tile_sum<3>(T, parts, 3, tid, gate); break;
+            case 4: x3_stage_tile_sum<4>(T, parts, 4, tid, gate); break;
+            case 5: x3_stage_tile_sum<5>(T, parts, 5, tid, gate); break;
+            case 6: x3_stage_tile_sum<6>(T, parts, 6, tid, gate); break;
+            case 7: x3_stage_tile_sum<7>(T, parts, 7, tid, gate); break;
+            case 8: x3_stage_tile_sum<8>(T, parts, 8, tid, gate); break;
+            case 9: x3_stage_tile_sum<9>(T, parts, 9, tid, gate); break;
+            case 10: x3_stage_tile_sum<10>(T, parts, 10, tid, gate); break;
+            default: x3_stage_tile_sum<0>(T, parts, a.gin, tid, gate); break;
         }
     }
     __syncthreads();
-    if (d.se_kind != 0) x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid, &se_first);      // every workgroup of the board: the same gate, the same gated tiles
+    if (d.se_kind != 0 && !gate_first) x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid, &se_first);      // every workgroup of the board: the same gate, the same gated tiles
     f32x4 accP[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -1507,6 +1549,9 @@ __global__ __launch_bounds__(512) void block_x3_split_kernel(const X3SplitArgs a
     if (!(a.dev & 4)) x3_chunks<true>(T, W, accP, ch0, ch1, &win);       // (development bit 4, timing only: no chunk loop)
     // epilogue: this workgroup's part of x + b3 + body(x) (workgroup 0 carries x and b3) -> its own image
     float* yb = a.y_parts + (size_t(b) * G_ + g) * 64 * C;
+    f32x4 psum[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) psum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int co0 = (wave * NJ + j) * 16 + lg * 4;
@@ -1522,6 +1567,25 @@ __global__ __launch_bounds__(512) void block_x3_split_kernel(const X3SplitArgs a
                 for (int r = 0; r < 4; ++r) v[r] += rh[r] + rl[r];
             }
             *reinterpret_cast<f32x4*>(yb + size_t(x3_square(sq)) * C + co0) = v;
+            if (a.pool_out) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) psum[j][r] += v[r];
+            }
+        }
+    }
+    if (a.pool_out) {                                                   // the channel sums of this image (squares: tiles 0..3 in a lane, then the 16 lanes of the row)
+        float* po = a.pool_out + (size_t(b) * G_ + g) * C;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float p[4] = {psum[j][0], psum[j][1], psum[j][2], psum[j][3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] += dpp_mov<0x111>(p[r]);
+                p[r] += dpp_mov<0x112>(p[r]);
+                p[r] += dpp_mov<0x114>(p[r]);
+                p[r] += dpp_mov<0x118>(p[r]);
+            }
+            if (l15 == 15) *reinterpret_cast<f32x4*>(po + (wave * NJ + j) * 16 + lg * 4) = f32x4{p[0], p[1], p[2], p[3]};
         }
     }
 }

@@ -611,6 +611,39 @@ def test_board_split_forward_small_batches(tmp_path, hip_lib, name, batch, preci
         assert np.abs(outs[0][3] - outs[6][3]).max() < 2e-5            # against the tower kernel's bits: f32 round-off of another summation order
 
 
+@pytest.mark.parametrize("name,batch", [("risev2-19", 1), ("risev2-19", 8), ("risev2-19", 40), ("risev33", 4)])
+def test_gate_from_the_images_channel_sums_equals_the_gate_phase(tmp_path, hip_lib, name, batch, monkeypatch):
+    """Round 6: a gated block of the split-board forward takes the board's channel means from the channel sums the launch before left per
+    image (means are linear) and has its gate before it stages the board, instead of squeezing the staged tiles (x3_se_phase;
+    CRA_X3_SPLIT_DEV=8 keeps that form).  Same gate up to f32 round-off of another summation order: logits within 2e-5 of the old form, both
+    inside float16x3's bound against the oracle, and run to run identical."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, _ = nn_cases.make_case(name)
+    d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
+    x = nn_cases.synthetic_planes(batch, cfg.nb_input_channels, 79)
+    xin = np.ascontiguousarray(x.numpy())
+    o_value, o_logits, _ = ro.forward(cfg, sd, x)
+    outs = {}
+    for old in (False, True):
+        if old:
+            monkeypatch.setenv("CRA_X3_SPLIT_DEV", "8")
+        else:
+            monkeypatch.delenv("CRA_X3_SPLIT_DEV", raising=False)
+        net = HipAPI(0, batch, d, "float16x3", keep_logits=True)
+        runs = []
+        for _ in range(3):
+            v, p = np.full(batch, 7.0, np.float32), np.full(batch * cfg.nb_policy, 7.0, np.float32)
+            net.predict(xin, v, p, np.full(batch * 4, 7.0, np.float32) if cfg.nb_aux else None)
+            runs.append((v, torch.as_tensor(net.device_buffers()["logits"], device="cuda").cpu().numpy().copy()))
+        net.close()
+        assert all(np.array_equal(r[0], runs[0][0]) and np.array_equal(r[1], runs[0][1]) for r in runs)
+        assert np.abs(runs[0][1] - o_logits.numpy()).max() < TOL["float16x3"]["logit"]
+        assert np.abs(runs[0][0] - o_value.numpy().reshape(-1)).max() < TOL["float16x3"]["value"]
+        outs[old] = runs[0]
+    assert np.abs(outs[False][1] - outs[True][1]).max() < 2e-5
+    assert not np.array_equal(outs[False][1], outs[True][1]) or name == "risev33"      # (the switch does switch: other bits in the last place)
+
+
 @pytest.mark.parametrize("case,B,version,stress", [("risev2-19", 256, "1.0", 3.0), ("risev2-13-lichess", 1024, "3.0", 2.0)])
 def test_float16p8_error_grows_with_the_logit_scale_float16x3_holds(tmp_path, hip_lib, case, B, version, stress):
     """float16p8's bound on the seeded random nets (3e-4 on the fixtures, 7e-4 over a million logits; max|logit| 2 ... 7)

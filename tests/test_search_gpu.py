@@ -97,6 +97,32 @@ def test_lane_count_does_not_change_the_trees(tmp_path, hip_lib):
         assert len(visits) == len(env.Position(f, False, "crazyhouse").legal_uci())      # Dirichlet: root fully expanded
 
 
+def test_lanes_on_two_devices_search_the_same_trees(tmp_path, hip_lib):
+    """The reference's other multi-GPU mode: evaluator lanes of ONE pool whose nets sit on different devices (Threads x (Last_Device_ID -
+    First_Device_ID + 1) SearchThreads, uci/crazyara.cpp:555-561,734).  Every mi_net call selects its own device, so a pool with a lane on
+    device 0 and a lane on device 1 searches exactly the trees of two lanes on device 0.  Needs two visible devices: skipped on the one-GPU
+    boxes this repository is developed on (never run so far -- DESIGN 8)."""
+    from crazyara_amd import _capi
+    if _capi.load().mi_device_count() < 2:
+        pytest.skip("one visible device")
+    cfg, sd, _ = nn_cases.make_case("risev2-3")
+    d = nn_cases.export_case(tmp_path, "risev2-3", cfg, sd)
+    fens = openings.position_fens("crazyhouse")[5:13]
+    results = []
+    for devices in ((0, 0), (0, 1)):
+        nets = [HipAPI(dev, 64, d, "float32") for dev in devices]
+        st = search.default_settings(mode=0, version_major=1, batch_size=16, seed=9)
+        pool = search.SearchPool(st, net_a=nets[0], net_b=nets[1])
+        for f in fens:
+            pool.add_position(f, False, "crazyhouse")
+        pool.run(simulations=160, threads=3)
+        results.append([(pool.root_children(i)[1], pool.best_move(i)) for i in range(len(fens))])
+        pool.close()
+        for n in nets:
+            n.close()
+    assert results[0] == results[1]
+
+
 @pytest.mark.parametrize("precision", ["float16", "fp8", "float16x3", "float16p8"])
 def test_priors_gathered_on_the_gpu_equal_whole_probability_vectors(tmp_path, hip_lib, monkeypatch, precision):
     """The HIP lanes bring back only the probabilities of the new nodes' legal moves (gather kernel behind the forward, ~40 KB per

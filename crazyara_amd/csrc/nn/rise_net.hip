@@ -1561,7 +1561,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     }
     // a small batch: the policy conv that ends in the softmax and the value head side by side in one launch (x3.hip: heads_small_kernel);
     // CRA_SMALL_BATCH_HEADS_APART: development A/B
-    if ((x3_split || getenv("CRA_HEADS_TOGETHER") != nullptr) && x3_ && im.ops.size() >= 2 && im.ops.back().kind == OpKind::ValueHead && im.ops[im.ops.size() - 2].kind == OpKind::Conv &&
+    if (x3_split && x3_ && im.ops.size() >= 2 && im.ops.back().kind == OpKind::ValueHead && im.ops[im.ops.size() - 2].kind == OpKind::Conv &&
         im.ops[im.ops.size() - 2].fused_softmax && heads_small_fits(im.ops[im.ops.size() - 2].conv, im.ops.back().vh) &&
         getenv("CRA_SMALL_BATCH_HEADS_APART") == nullptr) {
         Op vh = im.ops.back();

@@ -421,17 +421,24 @@ __global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a)
     conv_gemm_x3_body<KS, MT, NW, NS>(a, smem, blockIdx.x, blockIdx.y);
 }
 
-// The heads of a small batch in ONE launch (nets made for at most 64 boards, rise_net.hip): workgroup (0, b) runs the second policy conv
-// with the board's softmax -- conv_gemm_x3_kernel<3, 1, 8, 4>'s work -- and workgroup (1, b) the value head (value_head_kernel's, four of
+// The heads of a small batch in ONE launch (nets made for at most 64 boards, rise_net.hip): one workgroup of board b runs the second policy conv
+// with the board's softmax -- conv_gemm_x3_kernel<3, 1, 8, 4>'s work -- and another one the value head (value_head_kernel's, four of
 // its eight waves leave at once).  Behind one another the two cost a batch of one 20 + 25 us on two CUs of 256; side by side the longer of
-// the two.  (On two streams instead: slower than in sequence, the joins across queues cost more than they hide -- profiles/r06/e_*.)
+// the two.  (For a FULL batch the same launch -- or the value head beside policy conv 1 -- gains nothing: 0.074 ms against 0.049 + 0.025,
+// the chip is full either way and the dispatcher, not the kernel, decides which workgroups share a CU; profiles/NOTES.md round 6.)  (On two streams instead: slower than in sequence, the joins across queues cost more than they hide -- profiles/r06/e_*.)
 __global__ __launch_bounds__(512) void heads_small_kernel(const HeadsSmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (blockIdx.x == 0) {
-        conv_gemm_x3_body<3, 1, 8, 4>(a.conv, smem, 0, blockIdx.y);
+    // Workgroups go to the eight XCDs round-robin by their linear id: with (role, board) = (id % 2, id / 2) every conv role would sit on the
+    // even XCDs, two to a CU, and every value head on the odd ones.  id = xcd + 8 slot: role = slot % 2, board = xcd + 8 (slot / 2) --
+    // both roles of a board on one XCD (they read the same tile), each XCD half and half.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = xcd + 8 * (slot >> 1);
+    if (b >= a.conv.batch) return;
+    if ((slot & 1) == 0) {
+        conv_gemm_x3_body<3, 1, 8, 4>(a.conv, smem, 0, b);
     } else {
         if (threadIdx.x >= 256) return;
-        value_head_body<float, false, true>(a.vh, smem, blockIdx.y);
+        value_head_body<float, false, true>(a.vh, smem, b);
     }
 }
 
@@ -729,7 +736,8 @@ bool heads_small_fits(const ConvArgs& c, const ValueHeadArgs& v) {
 void launch_heads_small(const HeadsSmallArgs& a, hipStream_t s) {
     if (!heads_small_fits(a.conv, a.vh) || !a.conv.softmax_out || a.conv.batch != a.vh.batch) throw std::invalid_argument("heads_small_kernel: a 3x3 policy conv of at most 128 couts with its softmax, and the one-launch value head");
     const size_t shmem = std::max(size_t(2) * 65 * X3_ROWP * sizeof(half_t), value_head_lds_bytes(a.vh));
-    hipLaunchKernelGGL(heads_small_kernel, dim3(2, a.conv.batch), dim3(512), shmem, s, a);
+    const dim3 grid(16 * ((a.conv.batch + 7) / 8));
+    hipLaunchKernelGGL(heads_small_kernel, grid, dim3(512), shmem, s, a);
 }
 
 // ================================================================================================================

@@ -92,6 +92,13 @@ for vic_name, agg_name in pairs:
     name = vic_name if vic_name == agg_name else f"{vic_name}:{agg_name}"
     cfg, d, precision, version = make_net_dir(vic_name)
     cfg_b, d_b, precision_b, version_b = (cfg, d, precision, version) if agg_name == vic_name else make_net_dir(agg_name)
+    if args.batch <= 64:
+        # nets made for <= 64 boards run the split-board forward, whose launches pass partial images through two alternating buffers and end
+        # in the policy conv that overwrites the first block's input: an op replayed on its own does not see the input it had inside the
+        # forward (every cell of such an op reads as different, beside any neighbour and beside none).  The op-by-op screen therefore takes the
+        # one-workgroup-per-board form; the split forward is screened whole (tests/test_coresidency_screen_gpu.py).
+        precision = precision + "-1wg" if precision in ("float16x3", "float16p8") else precision
+        precision_b = precision_b + "-1wg" if precision_b in ("float16x3", "float16p8") else precision_b
     A, B = HipAPI(0, args.batch, d, precision), HipAPI(0, args.batch, d_b, precision_b)
     users = [NeuralNetAPIUser([n]) for n in (A, B)]
     for n, u, seed, c_ in ((A, users[0], 1, cfg), (B, users[1], 2, cfg_b)):

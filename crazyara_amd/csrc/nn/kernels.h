@@ -334,7 +334,8 @@ struct ValueHeadArgs {
     int variant;            // development (CRA_VALUE_HEAD_VARIANT): 1 = FC1 partial sums in LDS of their own (not over the dead board tile),
                             // 2 = FC1 accumulators pinned per step (no packed f32 FMAs), 4 = s_waitcnt vmcnt(0) behind every group of 32 weight
                             // loads, 8 = weight loads non-temporal, 16 = the PROBE instantiation (kernels.hip: sums from the registers, read
-                            // back from LDS, checksums of the loaded words, HW_ID per wave), 32 = FC1 as plain fmaf (v_pk_fma_f32 in a build with packed f32 ops) instead of the v_fmac_f32 asm
+                            // back from LDS, checksums of the loaded words, HW_ID per wave), 32 = FC1 as plain fmaf (v_pk_fma_f32 in a build with packed f32 ops) instead of the v_fmac_f32 asm,
+                            // 64 = four waves per board (the form up to round 6's set D; the product form runs eight: 22.5 -> 17 us at batch 256)
 };
 template <typename T> void prepare_value_head(const ValueHeadArgs& a);   // once per net: LDS allowance of the kernel
 size_t value_head_lds_bytes(const ValueHeadArgs& a);

@@ -379,6 +379,11 @@ __global__ __launch_bounds__(256) void value_head_kernel(const ValueHeadArgs a) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     value_head_body<T, PROBE, SCALAR_FMA>(a, smem, blockIdx.x);     // value_head_body.h
 }
+template <typename T>
+__global__ __launch_bounds__(512) void value_head_kernel_8w(const ValueHeadArgs a) {      // the product form on eight waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    value_head_body<T, false, true, 512>(a, smem, blockIdx.x);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void value_final_kernel(const ValueFinalArgs a) {
@@ -435,7 +440,10 @@ size_t value_head_lds_bytes(const ValueHeadArgs& a) {
     if (a.lds_pad < 0) return used;                              // development: the kernel as it was (shares compute units)
     return std::max(used + size_t(a.lds_pad), kValueHeadExclusiveLds);
 }
+// the product form (no debug record, FC1 on v_fmac_f32, partial sums over the dead board tile) runs on eight waves; variant & 64: on four (A/B)
+static bool value_head_eight_waves(const ValueHeadArgs& a) { return !a.dbg && (a.variant & (1 | 16 | 32 | 64)) == 0; }
 template <typename T> const void* value_head_function(const ValueHeadArgs& a) {        // the instantiation launch_value_head picks
+    if (value_head_eight_waves(a)) return reinterpret_cast<const void*>(&value_head_kernel_8w<T>);
     const bool probe = a.dbg && (a.variant & 16), scalar = (a.variant & 32) == 0;
     if (probe && scalar) return reinterpret_cast<const void*>(&value_head_kernel<T, true, true>);
     if (probe) return reinterpret_cast<const void*>(&value_head_kernel<T, true, false>);
@@ -458,6 +466,10 @@ template void prepare_value_head<half_t>(const ValueHeadArgs&);
 template void prepare_value_head<float>(const ValueHeadArgs&);
 template <typename T> void launch_value_head(const ValueHeadArgs& a, hipStream_t s) {
     const bool probe = a.dbg && (a.variant & 16), scalar = (a.variant & 32) == 0;
+    if (value_head_eight_waves(a)) {
+        hipLaunchKernelGGL((value_head_kernel_8w<T>), dim3(a.batch), dim3(512), value_head_lds_bytes(a), s, a);
+        return;
+    }
     if (probe && scalar) hipLaunchKernelGGL((value_head_kernel<T, true, true>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
     else if (probe) hipLaunchKernelGGL((value_head_kernel<T, true, false>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);
     else if (scalar) hipLaunchKernelGGL((value_head_kernel<T, false, true>), dim3(a.batch), dim3(256), value_head_lds_bytes(a), s, a);

@@ -1339,6 +1339,21 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     // (a small batch: two launches, the first conv's couts over two workgroups per board -- 0.0xx against 0.049 ms at batch 1, profiles/r06/f_*)
     const bool head_chain = p8_ && policy_map && C == 256 && round_up(cp, 16) <= 128 && getenv("CRA_P8_NO_HEAD_CHAIN") == nullptr &&
                             !(x3_split && getenv("CRA_SMALL_BATCH_HEAD_CHAIN") == nullptr);
+    // Precision float16x3 has the same head as one launch since round 6 (x3.hip: conv3x3_x3_chain_kernel, the same bits as the two launches);
+    // CRA_X3_NO_HEAD_CHAIN: development A/B.  Small-batch nets keep the two launches (the first conv's couts over four workgroups per board).
+    const bool head_chain_x3 = x3_ && !p8_ && fused_ && policy_map && C == 256 && round_up(cp, 16) <= 128 && !x3_split &&
+                               getenv("CRA_X3_NO_HEAD_CHAIN") == nullptr;
+    if (head_chain_x3) {
+        Folded f1 = fold_bn(nf, "policy_head.body.0", "policy_head.body.1");
+        SplitPack s1 = pack_dense_split(f1, C, C, 3, C, C);
+        add_conv("policy_head.body.3", "", cur, nullptr, nullptr, C, C, cp, 3, false, d_logits_, false);       // (its x: the tower's output)
+        ConvArgs& c = im.ops.back().conv;
+        c.pre_wpk = im.upload(s1.hi);
+        c.pre_wpk_lo = im.upload(s1.lo);
+        c.pre_bias = im.upload_d2f(f1.b, C);
+        c.pre_acc_scale = 1.f;
+        macs += double(kSquares) * C * C * 9;
+    } else
     if (head_chain) {
         Folded f1 = fold_bn(nf, "policy_head.body.0", "policy_head.body.1");
         double inv1 = 1.0;
@@ -1355,7 +1370,7 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
         add_conv("policy_head.body.0", "policy_head.body.1", cur, nxt, nullptr, C, C, C, 3, true, nullptr, !x3_split);
         im.ops.back().conv.few_boards = x3_split ? dev_.small_conv_split : 0;
     }
-    if (head_chain) {
+    if (head_chain || head_chain_x3) {
     } else if (policy_map) {
         add_conv("policy_head.body.3", "", nxt, nullptr, nullptr, C, C, cp, 3, false, d_logits_, !x3_split);
     } else {

@@ -12,17 +12,27 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* s_red) {      // (NT = 256: ((w0 + w1) + w2) + w3, the order this kernel has always had)
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    float t = s_red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) t += s_red[i];
+    return t;
 }
 
 // (the comments on PROBE and SCALAR_FMA are in front of value_head_kernel, kernels.hip)
-template <typename T, bool PROBE, bool SCALAR_FMA>
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) { return block_sum<256>(v, s_red); }
+
+// NT threads: 256 (the PROBE instantiation, whose record layout is four FC1 groups) or 512 -- NT / 64 groups of conv outputs and of FC1
+// inputs; the product form runs 512 (a board's head is a chain of latencies, and eight waves keep twice the loads in flight)
+template <typename T, bool PROBE, bool SCALAR_FMA, int NT = 256>
 __device__ __forceinline__ void value_head_body(const ValueHeadArgs& a, char* smem, const int b) {
+    constexpr int NG = NT / 64;
+    static_assert(NT == 256 || (NT == 512 && !PROBE), "256 or 512 threads");
     const int CH = a.C / 2;                                    // the board is staged in two halves of its channels (LDS stays below 64 KiB)
     const int XP = CH + 4;                                    // floats per staged row: rows step 4 banks
     float* xs = reinterpret_cast<float*>(smem);               // [64][C / 2 + 4]
@@ -33,14 +43,14 @@ __device__ __forceinline__ void value_head_body(const ValueHeadArgs& a, char* sm
     const T* xb = reinterpret_cast<const T*>(a.x) + size_t(b) * kSquares * a.C;
     const int nf = kSquares * a.cv;
 
-    for (int i0 = tid * 4; i0 < a.cv * a.C; i0 += 4 * 1024) {    // the folded conv weights, 16 bytes per thread and piece, four pieces in flight
+    for (int i0 = tid * 4; i0 < a.cv * a.C; i0 += 4 * 4 * NT) {    // the folded conv weights, 16 bytes per thread and piece, four pieces in flight
         f32x4 wv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i0 + u * 1024 < a.cv * a.C) wv[u] = *reinterpret_cast<const f32x4*>(a.wconv + i0 + u * 1024);
+            if (i0 + u * 4 * NT < a.cv * a.C) wv[u] = *reinterpret_cast<const f32x4*>(a.wconv + i0 + u * 4 * NT);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i0 + u * 1024 < a.cv * a.C) *reinterpret_cast<f32x4*>(ws + i0 + u * 1024) = wv[u];
+            if (i0 + u * 4 * NT < a.cv * a.C) *reinterpret_cast<f32x4*>(ws + i0 + u * 4 * NT) = wv[u];
     }
     float dbg_in = 0.f;                                        // (development) what this thread staged of the board
     {   // conv 1x1 + BN + ReLU: thread = square tid % 64, channels tid / 64, + 4, ... (at most four per thread)
@@ -51,16 +61,16 @@ __device__ __forceinline__ void value_head_body(const ValueHeadArgs& a, char* sm
             if (half) __syncthreads();                         // everyone is through with the first half of the tile
             // (four pieces per thread at C = 256, all loads in flight before the first LDS write: taken one by one the loop is four
             // HBM round trips long)
-            for (int i0 = tid; i0 < kSquares * (CH / 8); i0 += 4 * 256) {
+            for (int i0 = tid; i0 < kSquares * (CH / 8); i0 += 4 * NT) {
                 float f[4][8];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * 256;
+                    const int i = i0 + u * NT;
                     if (i < kSquares * (CH / 8)) load8<T>(xb + size_t(i / (CH / 8)) * a.C + half * CH + (i % (CH / 8)) * 8, f[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * 256;
+                    const int i = i0 + u * NT;
                     if (i < kSquares * (CH / 8)) {
                         const int r = i / (CH / 8), v = i % (CH / 8);
                         *reinterpret_cast<f32x4*>(xs + r * XP + v * 8) = f32x4{f[u][0], f[u][1], f[u][2], f[u][3]};
@@ -75,7 +85,7 @@ __device__ __forceinline__ void value_head_body(const ValueHeadArgs& a, char* sm
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int co = g + 4 * k;
+                    const int co = g + NG * k;
                     if (co < a.cv) {
                         const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + co * a.C + half * CH + c);
                         acc[k] = fmaf(wv[0], xv[0], acc[k]);
@@ -88,7 +98,7 @@ __device__ __forceinline__ void value_head_body(const ValueHeadArgs& a, char* sm
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int co = g + 4 * k;
+            const int co = g + NG * k;
             if (co < a.cv) s_flat[co * kSquares + sq] = fmaxf(acc[k] + a.bconv[co], 0.f);
         }
     }
@@ -96,7 +106,7 @@ __device__ __forceinline__ void value_head_body(const ValueHeadArgs& a, char* sm
 
     if (a.wwdl) {
         float p[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < nf; i += 256) {
+        for (int i = tid; i < nf; i += NT) {
             const float f = s_flat[i];
             p[0] = fmaf(a.wwdl[i], f, p[0]);
             p[1] = fmaf(a.wwdl[nf + i], f, p[1]);
@@ -104,7 +114,7 @@ __device__ __forceinline__ void value_head_body(const ValueHeadArgs& a, char* sm
             p[3] = fmaf(a.wplys[i], f, p[3]);
         }
         float r[4];
-        for (int k = 0; k < 4; ++k) r[k] = block_sum_256(p[k], s_red);
+        for (int k = 0; k < 4; ++k) r[k] = block_sum<NT>(p[k], s_red);
         if (tid == 0) {
             const float l0 = r[0] + a.bwdl[0], l1 = r[1] + a.bwdl[1], l2 = r[2] + a.bwdl[2];
             const float m = fmaxf(l0, fmaxf(l1, l2));
@@ -123,11 +133,11 @@ __device__ __forceinline__ void value_head_body(const ValueHeadArgs& a, char* sm
 
     if (a.dbg) {                                               // (development) stage checksums, see ValueHeadArgs::dbg
         float* o = a.dbg + size_t(b) * 8;
-        const float s_in = block_sum_256(dbg_in, s_red);
+        const float s_in = block_sum<NT>(dbg_in, s_red);
         float w_sum = 0.f, f_sum = 0.f;
-        for (int i = tid; i < a.cv * a.C; i += 256) w_sum += ws[i];
-        for (int i = tid; i < nf; i += 256) f_sum += s_flat[i];
-        const float s_w = block_sum_256(w_sum, s_red), s_f = block_sum_256(f_sum, s_red);
+        for (int i = tid; i < a.cv * a.C; i += NT) w_sum += ws[i];
+        for (int i = tid; i < nf; i += NT) f_sum += s_flat[i];
+        const float s_w = block_sum<NT>(w_sum, s_red), s_f = block_sum<NT>(f_sum, s_red);
         if (tid == 0) { o[0] = s_in; o[1] = s_w; o[2] = s_f; }
         __syncthreads();
     }
@@ -136,7 +146,7 @@ __device__ __forceinline__ void value_head_body(const ValueHeadArgs& a, char* sm
     // lane (a wave reads 1 KiB), 32 of them in flight; the quarters' partial sums meet in LDS (the staged board is dead by now)
     float* s_part = (a.variant & 1) ? s_red + 8 : xs;           // [4 quarters][fc]
     float part = 0.f;
-    const int kq = tid >> 6, nq = nf / 4;
+    const int kq = tid >> 6, nq = nf / NG;
     float* probe = PROBE ? a.dbg + size_t(a.batch) * (8 + 1024) + size_t(b) * (16 + 3 * 1024) : nullptr;
     for (int j4 = tid & 63; 4 * j4 < a.fc; j4 += 64) {
         f32x4 h = {0.f, 0.f, 0.f, 0.f};
@@ -199,21 +209,23 @@ __device__ __forceinline__ void value_head_body(const ValueHeadArgs& a, char* sm
     }
     __syncthreads();
     if constexpr (PROBE) {
-        for (int i = tid; i < 4 * a.fc && i < 1024; i += 256) probe[16 + i] = s_part[i];              // (1) first read back from LDS
+        for (int i = tid; i < 4 * a.fc && i < 1024; i += NT) probe[16 + i] = s_part[i];              // (1) first read back from LDS
         if ((tid & 63) == 0) probe[tid >> 6] = __builtin_bit_cast(float, __builtin_amdgcn_s_getreg((31 << 11) | 4));
         if (tid == 0) probe[4] = __builtin_bit_cast(float, __builtin_amdgcn_s_getreg((31 << 11) | 20));
     }
-    for (int t = tid; t < a.fc; t += 256) {
-        const float h = a.b1[t] + ((s_part[t] + s_part[a.fc + t]) + (s_part[2 * a.fc + t] + s_part[3 * a.fc + t]));
+    for (int t = tid; t < a.fc; t += NT) {
+        float ps = (s_part[t] + s_part[a.fc + t]) + (s_part[2 * a.fc + t] + s_part[3 * a.fc + t]);
+        if constexpr (NG == 8) ps += (s_part[4 * a.fc + t] + s_part[5 * a.fc + t]) + (s_part[6 * a.fc + t] + s_part[7 * a.fc + t]);
+        const float h = a.b1[t] + ps;
         part = fmaf(a.w2[t], fmaxf(h, 0.f), part);
     }
-    const float tot = block_sum_256(part, s_red);
+    const float tot = block_sum<NT>(part, s_red);
     if (tid == 0) a.value[b] = tanhf(tot + a.b2);
     if (a.dbg) {
         float p_sum = 0.f;
-        for (int i = tid; i < 4 * a.fc; i += 256) p_sum += s_part[i];
-        const float s_p = block_sum_256(p_sum, s_red);
-        for (int i = tid; i < 4 * a.fc && i < 1024; i += 256) a.dbg[size_t(a.batch) * 8 + size_t(b) * 1024 + i] = s_part[i];   // the partial sums themselves
+        for (int i = tid; i < NG * a.fc; i += NT) p_sum += s_part[i];
+        const float s_p = block_sum<NT>(p_sum, s_red);
+        for (int i = tid; i < 4 * a.fc && i < 1024; i += NT) a.dbg[size_t(a.batch) * 8 + size_t(b) * 1024 + i] = s_part[i];   // the partial sums themselves
         if (tid == 0) {
             float* o = a.dbg + size_t(b) * 8;
             o[3] = s_p;

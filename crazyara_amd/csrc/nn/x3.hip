@@ -422,8 +422,7 @@ __global__ __launch_bounds__(64 * NW) void conv_gemm_x3_kernel(const ConvArgs a)
 }
 
 // The heads of a small batch in ONE launch (nets made for at most 64 boards, rise_net.hip): one workgroup of board b runs the second policy conv
-// with the board's softmax -- conv_gemm_x3_kernel<3, 1, 8, 4>'s work -- and another one the value head (value_head_kernel's, four of
-// its eight waves leave at once).  Behind one another the two cost a batch of one 20 + 25 us on two CUs of 256; side by side the longer of
+// with the board's softmax -- conv_gemm_x3_kernel<3, 1, 8, 4>'s work -- and another one the value head (value_head_kernel_8w's).  Behind one another the two cost a batch of one 20 + 25 us on two CUs of 256; side by side the longer of
 // the two.  (For a FULL batch the same launch -- or the value head beside policy conv 1 -- gains nothing: 0.074 ms against 0.049 + 0.025,
 // the chip is full either way and the dispatcher, not the kernel, decides which workgroups share a CU; profiles/NOTES.md round 6.)  (On two streams instead: slower than in sequence, the joins across queues cost more than they hide -- profiles/r06/e_*.)
 __global__ __launch_bounds__(512) void heads_small_kernel(const HeadsSmallArgs a) {
@@ -437,8 +436,7 @@ __global__ __launch_bounds__(512) void heads_small_kernel(const HeadsSmallArgs a
     if ((slot & 1) == 0) {
         conv_gemm_x3_body<3, 1, 8, 4>(a.conv, smem, 0, b);
     } else {
-        if (threadIdx.x >= 256) return;
-        value_head_body<float, false, true>(a.vh, smem, b);
+        value_head_body<float, false, true, 512>(a.vh, smem, b);
     }
 }
 
@@ -691,6 +689,175 @@ __global__ __launch_bounds__(512) void conv3x3_p8_chain_kernel(const ConvArgs a)
     conv_x3_finish<1, NW>(a, acc2, active, smem, b, wave, a.acc_scale);
 }
 
+// ---- Precision float16x3: the policy head of a policy-map net in ONE launch (the float16x3 twin of conv3x3_p8_chain_kernel) ----
+// conv 3x3 256 -> 256 + BN + ReLU (a.pre_*: conv_gemm_x3_kernel<3, 2, 8, 4>'s arithmetic, step for step) with both passes of the board staged
+// in two buffers (the second pass's loads fly during the first pass's K loop: the two-launch form stages them one after the other, exposed);
+// its output split straight into the same two buffers as operand tiles (channels 0-127 / 128-255: the two passes of the next conv -- the
+// same halves the two-launch form makes of the floats it reads back); then conv 3x3 256 -> P on them (conv_gemm_x3_kernel<3, 1, 8, 4>'s
+// arithmetic) and its epilogue, the board's softmax.  Same bits as the two launches; saves a launch, 128 KB of HBM traffic per board and
+// every exposed staging pass but the first.
+namespace {
+struct ConvX3 {
+    static constexpr int KC = X3_KC, ROWP = X3_ROWP, NS = KC / 32, NSTEP = 9 * NS, D = 3;
+    static constexpr size_t buf_bytes = size_t(2) * 65 * ROWP * sizeof(half_t);          // hi tile + lo tile, 65 rows (row 64: zeros)
+    static constexpr size_t lds_bytes = 2 * buf_bytes;                                     // 70.7 KB
+    static __device__ __forceinline__ half_t* xh_of(char* smem, int buf) { return reinterpret_cast<half_t*>(smem + buf * buf_bytes); }
+    static __device__ __forceinline__ half_t* xl_of(char* smem, int buf) { return xh_of(smem, buf) + 65 * ROWP; }
+};
+template <int MT> struct ConvX3Window { half8 wh[ConvX3::D][MT], wl[ConvX3::D][MT]; };
+template <int MT>
+__device__ __forceinline__ void conv_x3_wload(ConvX3Window<MT>& W, const half8* const (&wph)[MT], const half8* const (&wpl)[MT], int kc0, int nslab_ci, int st) {
+    const size_t wo = size_t((st / ConvX3::NS) * nslab_ci + (kc0 >> 5) + st % ConvX3::NS) * 64;      // step st = tap st / NS, k-slab st % NS of this pass
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { W.wh[st % ConvX3::D][m] = wph[m][wo]; W.wl[st % ConvX3::D][m] = wpl[m][wo]; }
+}
+template <int MT>
+__device__ __forceinline__ void conv_x3_prime(ConvX3Window<MT>& W, const half8* const (&wph)[MT], const half8* const (&wpl)[MT], int kc0, int nslab_ci) {
+#pragma unroll
+    for (int st = 0; st < ConvX3::D; ++st) conv_x3_wload<MT>(W, wph, wpl, kc0, nslab_ci, st);
+}
+// the 9 taps x 4 k-slabs of one staged pass: conv_gemm_x3_body's static schedule (NS = 4), window primed by the caller
+template <int MT>
+__device__ __forceinline__ void conv_x3_pass(ConvX3Window<MT>& W, const half_t* xh, const half_t* xl, const half8* const (&wph)[MT],
+                                             const half8* const (&wpl)[MT], int kc0, int nslab_ci, int l15, int lg, f32x4 (&acc)[MT][4]) {
+    constexpr int ROWP = ConvX3::ROWP, NS = ConvX3::NS, NSTEP = ConvX3::NSTEP, D = ConvX3::D;
+    half8 bh[2][4], bl[2][4];
+    auto read_frag = [&](int st) {
+        const int tap = st / NS, sl = st % NS, dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int sq = t * 16 + l15;
+            const int ny = (sq >> 3) + dy, nx = (sq & 7) + dx;
+            const bool ok = (unsigned(ny) < 8u) && (unsigned(nx) < 8u);
+            const int off = (ok ? ny * 8 + nx : 64) * ROWP + lg * 8 + sl * 32;
+            bh[st & 1][t] = *reinterpret_cast<const half8*>(xh + off);
+            bl[st & 1][t] = *reinterpret_cast<const half8*>(xl + off);
+        }
+    };
+    read_frag(0);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) read_frag(st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.wl[st % D][m], bh[st & 1][t], acc[m][t], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.wh[st % D][m], bl[st & 1][t], acc[m][t], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.wh[st % D][m], bh[st & 1][t], acc[m][t], 0, 0, 0);
+        if (st + D < NSTEP) conv_x3_wload<MT>(W, wph, wpl, kc0, nslab_ci, st + D);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// stages one board's input channels [kc0, kc0 + 128) as split tiles: `request` into registers, `split_store` from them (512 threads)
+struct ConvX3Stage {
+    static constexpr int NV = kSquares * (ConvX3::KC / 8) / 512;
+    float pre[NV][8];
+    __device__ __forceinline__ void request(const float* xb, int cin, int kc0, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * 512, r = i / (ConvX3::KC / 8), v = i - r * (ConvX3::KC / 8);
+            load8<float>(xb + size_t(r) * cin + kc0 + v * 8, pre[j]);
+        }
+    }
+    __device__ __forceinline__ void split_store(half_t* xh, half_t* xl, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * 512, r = i / (ConvX3::KC / 8), v = i - r * (ConvX3::KC / 8);
+            half8 h, l;
+            split8(pre[j], h, l);
+            *reinterpret_cast<half8*>(xh + r * ConvX3::ROWP + v * 8) = h;
+            *reinterpret_cast<half8*>(xl + r * ConvX3::ROWP + v * 8) = l;
+        }
+    }
+};
+}  // namespace
+
+__global__ __launch_bounds__(512) void conv3x3_x3_chain_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KC = ConvX3::KC, ROWP = ConvX3::ROWP, NW = 8, C = 256;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const float* xb = reinterpret_cast<const float*>(a.x) + size_t(b) * kSquares * C;
+    constexpr int nslab_ci = C >> 5, nslab = 9 * nslab_ci;
+    {   // ---- conv 1: this wave's two cout tiles of the 16
+        const half8 *wph[2], *wpl[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            wph[m] = reinterpret_cast<const half8*>(a.pre_wpk) + size_t(wave * 2 + m) * nslab * 64 + lane;
+            wpl[m] = reinterpret_cast<const half8*>(a.pre_wpk_lo) + size_t(wave * 2 + m) * nslab * 64 + lane;
+        }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < 4 * ROWP; i += 512) {              // row 64 of all four tiles: what out-of-board taps read
+            const int tile = i / ROWP, c = i - tile * ROWP;
+            (tile & 1 ? ConvX3::xl_of(smem, tile >> 1) : ConvX3::xh_of(smem, tile >> 1))[64 * ROWP + c] = half_t(0.f);
+        }
+        ConvX3Stage stage;
+        stage.request(xb, C, 0, tid);
+        stage.split_store(ConvX3::xh_of(smem, 0), ConvX3::xl_of(smem, 0), tid);
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const int kc0 = pass * KC;
+            ConvX3Window<2> W;
+            conv_x3_prime<2>(W, wph, wpl, kc0, nslab_ci);
+            __syncthreads();
+            if (pass == 0) stage.request(xb, C, KC, tid);
+            conv_x3_pass<2>(W, ConvX3::xh_of(smem, pass), ConvX3::xl_of(smem, pass), wph, wpl, kc0, nslab_ci, l15, lg, acc);
+            if (pass == 0) stage.split_store(ConvX3::xh_of(smem, 1), ConvX3::xl_of(smem, 1), tid);
+        }
+        __syncthreads();                                         // every wave is through with the input tiles: they take conv 1's output
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int c0 = (wave * 2 + m) * 16 + lg * 4;         // 4 consecutive output channels of this lane
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(a.pre_bias + c0);
+            half_t* xh = ConvX3::xh_of(smem, c0 >> 7);
+            half_t* xl = ConvX3::xl_of(smem, c0 >> 7);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int sq = t * 16 + l15;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(acc[m][t][r], 1.f, bs[r]), 0.f);      // (conv_x3_finish's form: fma by acc_scale = 1, ReLU)
+                half4 h, l;
+                split4(v, h, l);
+                *reinterpret_cast<half4*>(xh + sq * ROWP + (c0 & 127)) = h;
+                *reinterpret_cast<half4*>(xl + sq * ROWP + (c0 & 127)) = l;
+            }
+        }
+    }
+    // ---- conv 2: one cout tile per wave
+    bool active[1] = {wave * 16 < a.cout_pad};
+    const half8 *wph[1], *wpl[1];
+    wph[0] = reinterpret_cast<const half8*>(a.wpk) + size_t(active[0] ? wave : 0) * nslab * 64 + lane;
+    wpl[0] = reinterpret_cast<const half8*>(a.wpk_lo) + size_t(active[0] ? wave : 0) * nslab * 64 + lane;
+    f32x4 acc2[1][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc2[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ConvX3Window<1> W;
+    if (active[0]) conv_x3_prime<1>(W, wph, wpl, 0, nslab_ci);
+    __syncthreads();                                             // conv 1's output tiles are written
+    if (active[0]) {
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) conv_x3_prime<1>(W, wph, wpl, KC, nslab_ci);
+            conv_x3_pass<1>(W, ConvX3::xh_of(smem, pass), ConvX3::xl_of(smem, pass), wph, wpl, pass * KC, nslab_ci, l15, lg, acc2);
+        }
+    }
+    conv_x3_finish<1, NW>(a, acc2, active, smem, b, wave, 1.f);
+}
+
 static void launch_conv3x3_p8(const ConvArgs& a, hipStream_t s) {
     if (a.ks != 3 || a.cin % X3_KC != 0 || a.planes || a.out_rows_f32) throw std::invalid_argument("conv3x3_p8_kernel: a dense 3x3 conv with cin a multiple of 128");
     const size_t shmem = ConvP8::lds_bytes;                              // 70 KB: two (f16 tile + byte tile) buffers
@@ -725,6 +892,12 @@ template <int KS> static void launch_conv_gemm_x3_cin(const ConvArgs& a, hipStre
     else launch_conv_gemm_x3_ks<KS, 0>(a, s);
 }
 void launch_conv_gemm_x3(const ConvArgs& a, hipStream_t s) {
+    if (a.pre_wpk && !a.p8) {                                            // float16x3: the policy head's two convs in one launch
+        if (a.ks != 3 || a.cin != 256 || a.cout_pad > 128 || a.resid || a.planes || a.out_rows_f32 || !a.out_policy_f32)
+            throw std::invalid_argument("conv3x3_x3_chain_kernel: 256 -> 256 -> at most 128 couts of a policy map, no shortcut");
+        hipLaunchKernelGGL(conv3x3_x3_chain_kernel, dim3(1, a.batch), dim3(512), ConvX3::lds_bytes, s, a);
+        return;
+    }
     if (a.p8) launch_conv3x3_p8(a, s);
     else if (a.ks == 1) launch_conv_gemm_x3_cin<1>(a, s);
     else launch_conv_gemm_x3_cin<3>(a, s);
@@ -2449,6 +2622,7 @@ void init_x3_kernel_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_x3_roles_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes + 8192));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_p8_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, int(X3Block::lds_bytes + 8192));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(ConvX3::lds_bytes));
     const int conv_p8_lds = int(ConvP8::lds_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p8_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, conv_p8_lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p8_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_p8_lds);

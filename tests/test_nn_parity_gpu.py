@@ -611,6 +611,39 @@ def test_board_split_forward_small_batches(tmp_path, hip_lib, name, batch, preci
         assert np.abs(outs[0][3] - outs[6][3]).max() < 2e-5            # against the tower kernel's bits: f32 round-off of another summation order
 
 
+@pytest.mark.parametrize("name,batch,precision", [("risev2-7", 72, "float16x3"), ("risev2-19", 256, "float16x3"), ("risev2-13-lichess", 16, "float16x3-1wg"),
+                                                  ("risev33-wdlp", 8, "float16x3-1wg")])
+def test_float16x3_policy_head_in_one_launch_equals_two_launches(tmp_path, hip_lib, name, batch, precision, monkeypatch):
+    """Round 6: Precision float16x3 runs the policy head of a policy-map net -- conv 3x3 256 -> 256 + BN + ReLU, conv 3x3 256 -> P, softmax --
+    as ONE launch (x3.hip: conv3x3_x3_chain_kernel; the first conv's output goes into the second's operand tiles in LDS instead of through
+    HBM).  The arithmetic is the two launches' step for step: identical logits, probabilities and values (CRA_X3_NO_HEAD_CHAIN = the two
+    launches)."""
+    from crazyara_amd.neuralnetapi import HipAPI
+    cfg, sd, _ = nn_cases.make_case(name)
+    d = nn_cases.export_case(tmp_path, name, cfg, sd, version="3.0" if cfg.nb_input_channels in (52, 64, 80) else "1.0")
+    x = nn_cases.synthetic_planes(batch, cfg.nb_input_channels, 80)
+    xin = np.ascontiguousarray(x.numpy())
+    o_value, o_logits, _ = ro.forward(cfg, sd, x)
+    outs = {}
+    for chain in (True, False):
+        if chain:
+            monkeypatch.delenv("CRA_X3_NO_HEAD_CHAIN", raising=False)
+        else:
+            monkeypatch.setenv("CRA_X3_NO_HEAD_CHAIN", "1")
+        net = HipAPI(0, batch, d, precision, keep_logits=True)
+        names = [n for n, _ in net.time_ops(1)]
+        assert names.count("conv_gemm_x3_3x3") == (2 if chain else 3), names
+        v, p = np.full(batch, 7.0, np.float32), np.full(batch * cfg.nb_policy, 7.0, np.float32)
+        for _ in range(2):
+            net.predict(xin, v, p, np.full(batch * 4, 7.0, np.float32) if cfg.nb_aux else None)
+        outs[chain] = (v, p, torch.as_tensor(net.device_buffers()["logits"], device="cuda").cpu().numpy().copy())
+        net.close()
+    for a, b in zip(outs[True], outs[False]):
+        assert np.array_equal(a, b)
+    assert np.abs(outs[True][2] - o_logits.numpy()).max() < TOL["float16x3"]["logit"]
+    assert np.abs(outs[True][1].reshape(batch, -1) - torch.softmax(o_logits, 1).numpy()).max() < TOL["float16x3"]["prob"]
+
+
 @pytest.mark.parametrize("name,batch", [("risev2-19", 1), ("risev2-19", 8), ("risev2-19", 40), ("risev33", 4)])
 def test_gate_from_the_images_channel_sums_equals_the_gate_phase(tmp_path, hip_lib, name, batch, monkeypatch):
     """Round 6: a gated block of the split-board forward takes the board's channel means from the channel sums the launch before left per

@@ -56,7 +56,8 @@ struct ConvArgs {
     float pre_acc_scale;
     int dev;              // development (CRA_X3_CONV_DEV): 1 = every wave leaves the kernel behind one last barrier, 2 = waves without a cout
                           // tile request no weight fragments
-    int few_boards;       // the net was made for a small batch (board-split forward): wide layers go as two workgroups of 128 couts per board
+    int few_boards;       // the net was made for a small batch (board-split forward): the couts of a wide layer go over several workgroups per
+                          // board -- 1: two of 128 couts, 2: four of 64 (RiseNet::DevSwitches::small_conv_split)
 };
 
 template <typename T> void launch_conv_gemm(const ConvArgs& a, hipStream_t s);

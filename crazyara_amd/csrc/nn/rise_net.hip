@@ -1336,7 +1336,8 @@ template <typename T> void RiseNet::build(const NetFile& nf) {
     } else {
     // _PolicyHead (select_policy_from_plane), builder_util.py:206-243
     // Precision float16p8, policy map at 256 channels: both convs of the head in ONE launch (x3.hip: conv3x3_p8_chain_kernel); CRA_P8_NO_HEAD_CHAIN: development A/B
-    // (a small batch: two launches, the first conv's couts over two workgroups per board -- 0.0xx against 0.049 ms at batch 1, profiles/r06/f_*)
+    // (a small batch: float16x3's convs, the first one's couts over four workgroups per board, the second beside the value head -- the
+    // chain's 0.049 ms at batch 1 became 0.017 + 0.024, the latter shared with the value head: profiles/r06/f_*, y_*)
     const bool head_chain = p8_ && policy_map && C == 256 && round_up(cp, 16) <= 128 && getenv("CRA_P8_NO_HEAD_CHAIN") == nullptr &&
                             !(x3_split && getenv("CRA_SMALL_BATCH_HEAD_CHAIN") == nullptr);
     // Precision float16x3 has the same head as one launch since round 6 (x3.hip: conv3x3_x3_chain_kernel, the same bits as the two launches);

@@ -1820,9 +1820,37 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
     const uint32_t lane_off = uint32_t(lane) * 16u;
     x3_stage_tile(T, a.x + size_t(b) * 64 * C, nullptr, tid);
     __syncthreads();
+    // EXPAND role: the expand weight window (below).  Its first two k-slabs of a block are requested at the END of the block before (unless a
+    // gate phase comes in between: that needs the registers), where the EXPAND waves wait 9 k ticks for the PROJECT waves' last chunk and
+    // epilogue.  A block's first interval runs E(0) alone -- one wave per SIMD, 384 cycles of MFMAs per k-slab behind a window of two slabs:
+    // a fragment is asked for 770 cycles before it is needed and takes ~1500, so the interval runs at the L2's latency (5.9 k ticks for 3.1 k
+    // of matrix pipe, 2.3 k with the weight loads switched off; profiles/r06/J_*) -- and asked for at the block's start its first fragments
+    // were a whole latency late on top: 5.9 k -> 4.5 k.  (The rest of the first chunk held in registers as well -- the depthwise's are idle
+    // in that interval -- spills: 16 to 96 more registers measured, 144 to 572 bytes of scratch, no faster or slower.)
+#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_EW)
+    constexpr int EW = CRA_X3_EW;
+#else
+    constexpr int EW = 2;
+#endif
+    half8 e_h[EW][2], e_l[EW][2];
+    bool first_chunk_requested = false;
+    // The two roles run the block loop separately (the same barriers in the same order): with one loop around an if / else, a value an EXPAND
+    // wave carries from one block into the next -- the first chunk's fragments -- counts as live through the PROJECT branch of the
+    // iteration between (the allocator does not know that a wave never changes its role), and that branch has no register to spare.
+    if (expand_role) {
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const X3TowerBlock& d = a.blocks[blk];
-        if (blk > 0 && d.se_kind != 0) x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid);
+        if (blk > 0 && d.se_kind != 0) {
+            x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid);
+            // (never requested in front of a gate phase.  The flag alone does not tell the register allocator: an empty definition of every
+            // fragment here ends their live ranges in front of the phase, which needs the registers)
+            first_chunk_requested = false;
+#pragma unroll
+            for (int ne = 0; ne < 2; ++ne) {
+#pragma unroll
+                for (int q = 0; q < EW; ++q) { asm volatile("" : "=v"(e_h[q][ne])); asm volatile("" : "=v"(e_l[q][ne])); }
+            }
+        }
         const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
         const int n = W.cop_pad / CK;
         const int nslab3 = W.cop_pad >> 5;
@@ -1831,17 +1859,11 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
         int trace_n = 0;
 #endif
         // barriers of a block, the same for both roles: one behind each of the halves 0 ... 2n, then the one behind the epilogue
-        if (expand_role) {
+        {
             const bool hi = l15 >= 8;                                  // the tile's second rank (t + 4, x3_row)
             const X3EdgeOffsets edge = x3_edge_offsets(l15);             // a lane on file a / h has no left / right neighbour on the board
             // expand weight window: EW of the 8 k-slabs x 2 channel tiles x (hi, lo); the stream runs on across chunk boundaries: slab s of
             // chunk i sits in slot s % EW and is refilled with the slab EW positions ahead right behind its MFMAs
-#if defined(CRA_DEVELOPMENT) && defined(CRA_X3_EW)
-            constexpr int EW = CRA_X3_EW;
-#else
-            constexpr int EW = 2;
-#endif
-            half8 e_h[EW][2], e_l[EW][2];
             auto load_e = [&](int i, int s) {                          // cout tile (16 channels) of (chunk i, wave w, ne) = i * 8 + w * 2 + ne
                 if constexpr (X3_ABL & 16) return;
 #pragma unroll
@@ -1851,14 +1873,24 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                     e_l[s % EW][ne] = x3_frag(W.w1l, lane_off, f);
                 }
             };
+            auto load_first_chunk = [&](const X3Weights& Wx) {          // the window's slots with the first k-slabs of chunk 0's two tiles
+                if constexpr (X3_ABL & 16) return;
+#pragma unroll
+                for (int s = 0; s < EW; ++s)
+#pragma unroll
+                    for (int ne = 0; ne < 2; ++ne) {
+                        const uint32_t f = uint32_t(w * 2 + ne) * (C / 32) + uint32_t(s);
+                        e_h[s][ne] = x3_frag(Wx.w1h, lane_off, f);
+                        e_l[s][ne] = x3_frag(Wx.w1l, lane_off, f);
+                    }
+            };
             if constexpr (X3_ABL & 16) {
 #pragma unroll
                 for (int s = 0; s < EW; ++s)
 #pragma unroll
                     for (int ne = 0; ne < 2; ++ne) e_h[s][ne] = e_l[s][ne] = *reinterpret_cast<const half8*>(T.xh + lane * 8);
             }
-#pragma unroll
-            for (int s = 0; s < EW; ++s) load_e(0, s);
+            if (!first_chunk_requested) load_first_chunk(W);
             float* const my_dws = T.dws + (w * 2) * REC;               // this wave's two record tiles
             f32x4 accE[2][4], accD[2][4];                               // chunk i being expanded / chunk i - 1 in the depthwise
             X3Depthwise dw;
@@ -1989,9 +2021,29 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
                 if constexpr (!(X3_ABL & 32)) __syncthreads();
                 X3_STAMP(4);
             }
+            // the next block's first fragments (unless a gate phase comes first): they land while the PROJECT waves finish this block
+            first_chunk_requested = false;
+            if (blk + 1 < a.nblocks && a.blocks[blk + 1].se_kind == 0) {
+                const X3TowerBlock& dn = a.blocks[blk + 1];
+                load_first_chunk(x3_weights(dn.w1pk, dn.w1pk_lo, dn.w3pk, dn.w3pk_lo, dn.dwpk, dn.cop_pad));
+                first_chunk_requested = true;
+            }
             __syncthreads();                                            // the PROJECT waves' block epilogue
             { const int kk = n; X3_STAMP(5); }
-        } else {
+        }
+    }
+    } else {
+    for (int blk = 0; blk < a.nblocks; ++blk) {
+        const X3TowerBlock& d = a.blocks[blk];
+        if (blk > 0 && d.se_kind != 0) x3_se_phase(T, d, reinterpret_cast<float*>(T.t2h), tid);
+        const X3Weights W = x3_weights(d.w1pk, d.w1pk_lo, d.w3pk, d.w3pk_lo, d.dwpk, d.cop_pad);
+        const int n = W.cop_pad / CK;
+        const int nslab3 = W.cop_pad >> 5;
+#ifdef CRA_X3_TRACE
+        const bool tracing = (b == 0 || b == 131) && blk == CRA_X3_TRACE;
+        int trace_n = 0;
+#endif
+        {
             // project weight window: 2 of a chunk's 4 k-slabs x 4 cout tiles x (hi, lo), running on across chunk boundaries
 #if defined(CRA_DEVELOPMENT) && defined(CRA_X3_PW)
             constexpr int PW = CRA_X3_PW, NJ = 4;
@@ -2095,6 +2147,7 @@ __global__ __launch_bounds__(512) void tower_x3_roles_kernel(const X3TowerArgs a
             __syncthreads();
             { const int kk = n; X3_STAMP(13); }
         }
+    }
     }
     // stream -> HBM as float, 32-byte pieces per thread
     float* yb = a.y + size_t(b) * 64 * C;

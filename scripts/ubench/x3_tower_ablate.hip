@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "x3.hip"        // -I crazyara_amd/csrc/nn
+namespace cra { size_t value_head_lds_bytes(const ValueHeadArgs&) { return 0; } }      // (kernels.hip's, which this harness does not link: the head launches are not used here)
 
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "HIP error %s at %s\n", hipGetErrorString(_e), #e); exit(1); } } while (0)
 

@@ -1,5 +1,5 @@
 """Development: latency of one evaluator lane (descriptors in -> results out) and rate of two lanes alternating, without any host-side
-search work in between; compare with the device-resident forward.  usage: python scripts/lane_latency.py [blocks=19] [batch=256]"""
+search work in between; compare with the device-resident forward.  usage: python scripts/lane_latency.py [blocks=19] [batch=256] [precision=float16]"""
 import ctypes as C
 import os
 import sys
@@ -16,12 +16,13 @@ from crazyara_amd.neuralnetapi import HipAPI
 
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 19
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+PREC = sys.argv[3] if len(sys.argv) > 3 else "float16"
 cfg = rise_config.rise_v2_config(blocks, 34, 81)
 sd = rise_config.make_state_dict(cfg, seed=1)
 tmp = tempfile.mkdtemp()
 netfile.export_rise(os.path.join(tmp, "m-v1.0.cranet"), cfg, sd)
 lib = _capi.load()
-nets = [HipAPI(0, B, tmp, "float16") for _ in range(2)]
+nets = [HipAPI(0, B, tmp, PREC) for _ in range(2)]
 fens = openings.position_fens("crazyhouse")
 descs = b"".join(env.Position(fens[i % len(fens)], False, "crazyhouse").desc() for i in range(B))
 layout = lib.mi_planes_layout(0, 1)
